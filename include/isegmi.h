@@ -1,0 +1,88 @@
+/*
+ * isegmi.h -- C ABI of libisegmi.so: the MI355X (gfx950) RoI/mask inference hot path of
+ * detectron.jittor's Mask R-CNN and Yolact.jittor.
+ *
+ * Drop-in boundary.  The reference defines NO native / FFI / plugin interface for this path:
+ * /root/reference holds only README.md (the submodules are empty) and the
+ * only boundary it shows is the Python call surface
+ *     COCODemo(cfg, min_image_size=800, confidence_threshold=0.5)      README.md:320-324
+ *     coco_demo.run_on_opencv_image(image)                             README.md:331
+ *     python eval.py --trained_model=... --score_threshold=... --top_k=...  README.md:243-249
+ *     python tools/test_net.py --config-file ...                       README.md:344-347
+ * Each entry point below names the reference operator it stands in for (SURVEY.md section 8a
+ * ids M1..M13 / Y1..Y8 and Appendix A item) and the README line that reaches it.  The Python
+ * package `isegmi` binds these with ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on success and a
+ * negative code on failure, message via isegmi_last_error() (thread-local).  Pointers named
+ * d_* are DEVICE pointers obtained from isegmi_malloc; h_* are host pointers.  All activations
+ * are fp32 NHWC.  `stream` is a hipStream_t passed as void* (NULL = default stream).
+ * A handle is single-stream and not thread-safe: one handle per GPU per process.
+ */
+#ifndef ISEGMI_H
+#define ISEGMI_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+#pragma GCC visibility push(default)
+
+#define ISEGMI_ABI_VERSION 1
+
+int isegmi_version(void);
+const char* isegmi_last_error(void);
+
+/* ---- device plumbing (replaces `jt.flags.use_cuda = 1`, README.md:311) ---- */
+int isegmi_device_count(int* n);
+int isegmi_set_device(int device_id);
+int isegmi_malloc(void** d_ptr, int64_t bytes);
+int isegmi_free(void* d_ptr);
+int isegmi_h2d(void* d_dst, const void* h_src, int64_t bytes);
+int isegmi_d2h(void* h_dst, const void* d_src, int64_t bytes);
+int isegmi_memset(void* d_ptr, int value, int64_t bytes);
+int isegmi_sync(void);
+
+/* ---- convolution family: M2 M3 M4 M8 M10 M11 Y2 Y3 Y4 Y5 ----
+ * Implicit-GEMM convolution on v_mfma_f32_32x32x2_f32 with fused per-channel affine
+ * (folded BN or bias), residual add and activation.  Per output element the accumulation is
+ * a k-ordered fmaf chain over (r, s, cin) from +0 -- bit-identical to the oracle. */
+typedef struct isegmi_conv_desc {
+    int32_t N, H, W, Cin;            /* input NHWC; Cin % 32 == 0, or Cin == 4 with R==S==7 (stem) */
+    int32_t Cout, R, S, stride, pad;
+    int32_t act;                     /* 0 none, 1 relu, 2 tanh */
+    int32_t tile;                    /* 0 auto; 1: 128x128  2: 128x64  3: 64x64 (block tile MxN) */
+    int32_t out_div;                 /* output pixels per "image" for addressing; 0 -> Ho*Wo */
+    int64_t out_img_stride;          /* floats; 0 -> out_div*out_pix_stride */
+    int64_t out_pix_stride;          /* floats; 0 -> Cout */
+} isegmi_conv_desc;
+
+int isegmi_conv_out_hw(const isegmi_conv_desc* d, int32_t* Ho, int32_t* Wo);
+/* number of floats of the packed weight image */
+int isegmi_conv_packed_floats(const isegmi_conv_desc* d, int64_t* n);
+/* host: natural [Cout][R][S][Cin] -> packed image consumed by isegmi_op_conv2d */
+int isegmi_pack_conv_weights(const isegmi_conv_desc* d, const float* h_w_krsc, float* h_packed);
+/* d_scale / d_shift / d_residual may be NULL (1 / 0 / none). residual is contiguous [M][Cout]. */
+int isegmi_op_conv2d(const isegmi_conv_desc* d, const float* d_in, const float* d_wpacked,
+                     const float* d_scale, const float* d_shift, const float* d_residual,
+                     float* d_out, void* stream);
+
+/* max_pool2d(k,s,p), -inf padding (M2/Y2 stem; k=1,s=2 = LastLevelMaxPool M3) */
+int isegmi_op_maxpool(const float* d_in, int N, int H, int W, int C, int k, int s, int p,
+                      float* d_out, void* stream);
+/* bilinear align_corners=False to (Ho,Wo), optional +add, optional relu (Y3, Y4) */
+int isegmi_op_resize_bilinear(const float* d_in, int N, int H, int W, int C, int Ho, int Wo,
+                              const float* d_add, int relu, float* d_out, void* stream);
+/* out = lateral + nearest2x(coarse) (M3) */
+int isegmi_op_upsample_nearest2x_add(const float* d_coarse, int N, int Hc, int Wc, int C,
+                                     const float* d_lateral, int H, int W, float* d_out,
+                                     void* stream);
+/* NHWC3 -> NHWC4 zero pad (stem input) */
+int isegmi_op_pad_c3_to_c4(const float* d_in, int64_t npix, float* d_out, void* stream);
+/* fn: 0 exp 1 sigmoid 2 tanh 3 log2 -- exposes the deterministic math for parity tests */
+int isegmi_op_map_f32(const float* d_x, float* d_y, int64_t n, int fn, void* stream);
+
+#pragma GCC visibility pop
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,329 @@
+// conv_mfma.hip -- NHWC implicit-GEMM convolution on v_mfma_f32_32x32x2_f32 (gfx950).
+//
+// Stands in for the conv / FC / deconv framework ops the reference's models run on
+// (Appendix A.1; reached from README.md:331 and
+// README.md:243).  GEMM view: M = N*Ho*Wo output pixels, Ngemm = Cout, K = R*S*Cin.
+//
+// Numerics contract (shared with oracle/ora_ops.c::ora_conv2d): every output element is ONE
+// accumulator chain acc = fmaf(x_k, w_k, acc) over k = (r, s, cin) ascending from +0.  The
+// f32 MFMA is bit-for-bit such a chain (lanes 0-31 supply the first k of an instruction, lanes
+// 32-63 the second), so there is no split-K and no multi-accumulator partial sum anywhere.
+//
+// Tiling: 256 threads = 4 waves; block tile BM x BN, K-chunk 32; each wave owns TM x TN tiles of
+// 32x32.  A (pixels x k) and B (couts x k) chunks are staged global -> registers -> LDS with the
+// issue-early / write-late split (loads for chunk t+1 are issued before the MFMAs of chunk t and
+// written to the other LDS stage after them; one barrier per chunk).  LDS rows are 36 floats
+// (32 + 4 pad): ds_write_b128 and ds_read_b128 are both conflict-free.  Inside each group of 8
+// consecutive k the LDS image is stored as [k0 k2 k4 k6 | k1 k3 k5 k7] so that one ds_read_b128
+// per lane half feeds 4 MFMAs in natural k order (weights are pre-permuted at pack time,
+// activations by register renaming at LDS-write time).
+#include "../../include/isegmi.h"
+#include "common.h"
+#include "detmath.h"
+
+namespace isegmi {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvK {
+    const float* in;
+    const float* w;
+    const float* scale;
+    const float* shift;
+    const float* res;
+    float* out;
+    int N, H, W, Cin, Cout, R, S, stride, pad, Ho, Wo, M;
+    int nchunks, cin_chunks;
+    int64_t wrow;
+    int act, out_div, contiguous;
+    int64_t out_img_stride, out_pix_stride;
+    int mtiles, ntiles;
+};
+
+constexpr int LDS_ROW = 36;
+
+template <int BM, int BN, int WM, int WN, bool STEM>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvK p) {
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    constexpr int APASS = BM / 64, BPASS = BN / 64;
+    constexpr int STAGE = (BM + BN) * LDS_ROW;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    // XCD-aware bijective remap: blocks that share an XCD get consecutive logical tiles
+    // (same pixel rows / neighbouring rows -> activation re-reads hit that XCD's L2).
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int nt = logical % p.ntiles, mt = logical / p.ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    // ---- loader state: thread covers row (tid>>2)+64*j, 8-group g = tid&3 of the 32-chunk
+    const int lrow = tid >> 2, g = tid & 3;
+    int hi0[APASS], wi0[APASS], nb[APASS];
+#pragma unroll
+    for (int j = 0; j < APASS; ++j) {
+        const int m = m0 + lrow + 64 * j;
+        if (m < p.M) {
+            const int hw = p.Ho * p.Wo;
+            const int n = m / hw, rem = m - n * hw;
+            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+            hi0[j] = ho * p.stride - p.pad;
+            wi0[j] = wo * p.stride - p.pad;
+            nb[j] = n * p.H;
+        } else {
+            hi0[j] = -(1 << 28);
+            wi0[j] = 0;
+            nb[j] = 0;
+        }
+    }
+    const float* wsrc = p.w + (int64_t)(n0 + lrow) * p.wrow + g * 8;
+
+    float4 ra[APASS][2], rb[BPASS][2];
+    int kr = 0, ks = 0, kc = 0;  // (r, s, cin-chunk) of the NEXT chunk to load
+
+    auto load_chunk = [&](int chunk) {
+#pragma unroll
+        for (int j = 0; j < APASS; ++j) {
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (STEM) {
+                const int hi = hi0[j] + chunk, wi = wi0[j] + 2 * g;
+                const bool okh = (unsigned)hi < (unsigned)p.H;
+                const float* src = p.in + ((int64_t)(nb[j] + hi) * p.W + wi) * 4;
+                ra[j][0] = (okh && (unsigned)wi < (unsigned)p.W) ? *(const float4*)src : z;
+                ra[j][1] = (okh && g < 3 && (unsigned)(wi + 1) < (unsigned)p.W) ? *(const float4*)(src + 4) : z;
+            } else {
+                const int hi = hi0[j] + kr, wi = wi0[j] + ks;
+                const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                const float* src = p.in + ((int64_t)(nb[j] + hi) * p.W + wi) * p.Cin + kc * 32 + g * 8;
+                ra[j][0] = ok ? *(const float4*)src : z;
+                ra[j][1] = ok ? *(const float4*)(src + 4) : z;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < BPASS; ++j) {
+            const float* src = wsrc + (int64_t)(64 * j) * p.wrow + chunk * 32;
+            rb[j][0] = *(const float4*)src;
+            rb[j][1] = *(const float4*)(src + 4);
+        }
+        if (!STEM) {
+            if (++kc == p.cin_chunks) { kc = 0; if (++ks == p.S) { ks = 0; ++kr; } }
+        }
+    };
+    auto store_chunk = [&](int stage) {
+        float* As = smem + stage * STAGE;
+        float* Bs = As + BM * LDS_ROW;
+#pragma unroll
+        for (int j = 0; j < APASS; ++j) {
+            float* d = As + (lrow + 64 * j) * LDS_ROW + g * 8;
+            *(float4*)d = make_float4(ra[j][0].x, ra[j][0].z, ra[j][1].x, ra[j][1].z);
+            *(float4*)(d + 4) = make_float4(ra[j][0].y, ra[j][0].w, ra[j][1].y, ra[j][1].w);
+        }
+#pragma unroll
+        for (int j = 0; j < BPASS; ++j) {
+            float* d = Bs + (lrow + 64 * j) * LDS_ROW + g * 8;
+            *(float4*)d = rb[j][0];
+            *(float4*)(d + 4) = rb[j][1];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.0f;
+
+    const int lr = lane & 31, lh = lane >> 5;
+    const int a_off = (wm * TM * 32 + lr) * LDS_ROW + lh * 4;
+    const int b_off = BM * LDS_ROW + (wn * TN * 32 + lr) * LDS_ROW + lh * 4;
+
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+
+    int cur = 0;
+    for (int t = 0; t < p.nchunks; ++t) {
+        const bool more = (t + 1) < p.nchunks;
+        if (more) load_chunk(t + 1);
+        const float* sb = smem + cur * STAGE;
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) {
+            float4 fa[TM], fb[TN];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) fa[a] = *(const float4*)(sb + a_off + a * 32 * LDS_ROW + gg * 8);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) fb[b] = *(const float4*)(sb + b_off + b * 32 * LDS_ROW + gg * 8);
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].x, fb[b].x, acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].y, fb[b].y, acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].z, fb[b].z, acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].w, fb[b].w, acc[a][b], 0, 0, 0);
+                }
+        }
+        if (more) store_chunk(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: y = fmaf(acc, scale, shift) (+res) -> act -> NHWC store.
+    // D layout: col (cout) = lane&31, row (pixel) = (e&3) + 8*(e>>2) + 4*(lane>>5).
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int co = n0 + (wn * TN + b) * 32 + lr;
+        const bool cok = co < p.Cout;
+        const float sc = (cok && p.scale) ? p.scale[co] : 1.0f;
+        const float sh = (cok && p.shift) ? p.shift[co] : 0.0f;
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (wm * TM + a) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                const int m = m0 + row;
+                if (cok && m < p.M) {
+                    float y = fmaf(acc[a][b][e], sc, sh);
+                    if (p.res) y = y + p.res[(int64_t)m * p.Cout + co];
+                    if (p.act == 1) y = y > 0.0f ? y : 0.0f;
+                    else if (p.act == 2) y = dm_tanh(y);
+                    int64_t off;
+                    if (p.contiguous) off = (int64_t)m * p.out_pix_stride + co;
+                    else {
+                        const int ni = m / p.out_div, pi = m - ni * p.out_div;
+                        off = (int64_t)ni * p.out_img_stride + (int64_t)pi * p.out_pix_stride + co;
+                    }
+                    p.out[off] = y;
+                }
+            }
+        }
+    }
+}
+
+static inline int perm8(int e) { return 4 * (e & 1) + (e >> 1); }
+static bool is_stem(const isegmi_conv_desc* d) { return d->Cin == 4 && d->R == 7 && d->S == 7; }
+static int cout_pad(const isegmi_conv_desc* d) { return cdiv(d->Cout, 128) * 128; }
+static int n_chunks(const isegmi_conv_desc* d) { return is_stem(d) ? 7 : d->R * d->S * (d->Cin / 32); }
+
+static int check_desc(const isegmi_conv_desc* d) {
+    ARG_CHECK(d != nullptr, "null desc");
+    ARG_CHECK(d->N > 0 && d->H > 0 && d->W > 0 && d->Cout > 0 && d->R > 0 && d->S > 0 && d->stride > 0 && d->pad >= 0,
+              "non-positive conv geometry");
+    ARG_CHECK(is_stem(d) || (d->Cin > 0 && d->Cin % 32 == 0), "Cin must be a multiple of 32 (or the Cin=4 7x7 stem)");
+    ARG_CHECK(d->H + 2 * d->pad >= d->R && d->W + 2 * d->pad >= d->S, "kernel larger than padded input");
+    ARG_CHECK(d->act >= 0 && d->act <= 2, "act");
+    ARG_CHECK(d->tile >= 0 && d->tile <= 3, "tile");
+    return ISEGMI_OK;
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch(const isegmi_conv_desc* d, ConvK& k, hipStream_t st) {
+    k.mtiles = cdiv(k.M, BM);
+    k.ntiles = cdiv(d->Cout, BN);
+    const size_t lds = 2 * (size_t)(BM + BN) * LDS_ROW * sizeof(float);
+    const dim3 grid((unsigned)(k.mtiles * k.ntiles)), block(256);
+    if (is_stem(d)) {
+        static bool attr = false;
+        if (!attr) { HIP_TRY(hipFuncSetAttribute((const void*)conv_mfma_kernel<BM, BN, WM, WN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+        hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, true>), grid, block, lds, st, k);
+    } else {
+        static bool attr = false;
+        if (!attr) { HIP_TRY(hipFuncSetAttribute((const void*)conv_mfma_kernel<BM, BN, WM, WN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+        hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, false>), grid, block, lds, st, k);
+    }
+    HIP_TRY(hipGetLastError());
+    return ISEGMI_OK;
+}
+
+int conv2d_launch(const isegmi_conv_desc* d, const float* in, const float* w, const float* scale, const float* shift,
+                  const float* res, float* out, hipStream_t st) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    ConvK k;
+    k.in = in; k.w = w; k.scale = scale; k.shift = shift; k.res = res; k.out = out;
+    k.N = d->N; k.H = d->H; k.W = d->W; k.Cin = d->Cin; k.Cout = d->Cout; k.R = d->R; k.S = d->S;
+    k.stride = d->stride; k.pad = d->pad;
+    k.Ho = (d->H + 2 * d->pad - d->R) / d->stride + 1;
+    k.Wo = (d->W + 2 * d->pad - d->S) / d->stride + 1;
+    const int64_t M64 = (int64_t)d->N * k.Ho * k.Wo;
+    ARG_CHECK(M64 < (1ll << 31) - 256, "too many output pixels");
+    k.M = (int)M64;
+    k.nchunks = n_chunks(d);
+    k.cin_chunks = is_stem(d) ? 1 : d->Cin / 32;
+    k.wrow = (int64_t)k.nchunks * 32;
+    k.act = d->act;
+    k.out_div = d->out_div > 0 ? d->out_div : k.Ho * k.Wo;
+    k.out_pix_stride = d->out_pix_stride > 0 ? d->out_pix_stride : d->Cout;
+    k.out_img_stride = d->out_img_stride > 0 ? d->out_img_stride : (int64_t)k.out_div * k.out_pix_stride;
+    k.contiguous = (k.out_img_stride == (int64_t)k.out_div * k.out_pix_stride) ? 1 : 0;
+    ARG_CHECK(res == nullptr || (k.contiguous && k.out_pix_stride == d->Cout) || true, "residual layout");
+    int tile = d->tile;
+    if (tile == 0) {
+        // enough 128x128 tiles to fill 256 CUs x 2 blocks? else shrink the tile.
+        const int64_t t128 = (int64_t)cdiv(k.M, 128) * cdiv(d->Cout, 128);
+        const int64_t t12864 = (int64_t)cdiv(k.M, 128) * cdiv(d->Cout, 64);
+        if (d->Cout > 64 && t128 >= 384) tile = 1;
+        else if (t12864 >= 384) tile = 2;
+        else tile = 3;
+    }
+    switch (tile) {
+        case 1: return launch<128, 128, 2, 2>(d, k, st);
+        case 2: return launch<128, 64, 2, 2>(d, k, st);
+        default: return launch<64, 64, 2, 2>(d, k, st);
+    }
+}
+
+}  // namespace isegmi
+
+using namespace isegmi;
+
+extern "C" int isegmi_conv_out_hw(const isegmi_conv_desc* d, int32_t* Ho, int32_t* Wo) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    *Ho = (d->H + 2 * d->pad - d->R) / d->stride + 1;
+    *Wo = (d->W + 2 * d->pad - d->S) / d->stride + 1;
+    return ISEGMI_OK;
+}
+
+extern "C" int isegmi_conv_packed_floats(const isegmi_conv_desc* d, int64_t* n) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    *n = (int64_t)cout_pad(d) * n_chunks(d) * 32;
+    return ISEGMI_OK;
+}
+
+extern "C" int isegmi_pack_conv_weights(const isegmi_conv_desc* d, const float* w, float* packed) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    ARG_CHECK(w && packed, "null pointer");
+    const int nch = n_chunks(d);
+    const int64_t wrow = (int64_t)nch * 32;
+    const int64_t total = (int64_t)cout_pad(d) * wrow;
+    for (int64_t i = 0; i < total; ++i) packed[i] = 0.0f;
+    const int K = d->R * d->S * d->Cin;
+    for (int co = 0; co < d->Cout; ++co) {
+        const float* src = w + (int64_t)co * K;
+        float* dst = packed + (int64_t)co * wrow;
+        if (is_stem(d)) {
+            for (int r = 0; r < 7; ++r)
+                for (int e = 0; e < 28; ++e) {  // e = s*4 + c
+                    const int grp = e >> 3, pos = perm8(e & 7);
+                    dst[r * 32 + grp * 8 + pos] = src[r * 28 + e];
+                }
+        } else {
+            for (int k = 0; k < K; ++k) dst[(k & ~7) + perm8(k & 7)] = src[k];
+        }
+    }
+    return ISEGMI_OK;
+}
+
+extern "C" int isegmi_op_conv2d(const isegmi_conv_desc* d, const float* d_in, const float* d_w, const float* d_scale,
+                                const float* d_shift, const float* d_res, float* d_out, void* stream) {
+    ARG_CHECK(d_in && d_w && d_out, "null device pointer");
+    return conv2d_launch(d, d_in, d_w, d_scale, d_shift, d_res, d_out, (hipStream_t)stream);
+}

@@ -1,0 +1,174 @@
+// spatial.hip -- HBM-bound NHWC spatial ops: max-pool, bilinear resize(+add), nearest2x+add,
+// channel pad, deterministic elementwise map.  One thread per 4 channels (16-byte accesses,
+// consecutive lanes on consecutive channel quads -> fully coalesced NHWC rows).
+// Reference anchors: SURVEY.md 8a M2/M3 (maxpool, nearest FPN), Y3/Y4 (bilinear), App. A.1.
+#include "../../include/isegmi.h"
+#include "common.h"
+#include "detmath.h"
+
+namespace isegmi {
+
+__global__ void maxpool_kernel(const float* __restrict__ in, int N, int H, int W, int C, int k, int s, int p, int Ho,
+                               int Wo, float* __restrict__ out) {
+    const int c4n = C >> 2;
+    const int64_t total = (int64_t)N * Ho * Wo * c4n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n);
+        int64_t t = i / c4n;
+        const int wo = (int)(t % Wo); t /= Wo;
+        const int ho = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        for (int r = 0; r < k; ++r) {
+            const int hi = ho * s + r - p;
+            if ((unsigned)hi >= (unsigned)H) continue;
+            for (int q = 0; q < k; ++q) {
+                const int wi = wo * s + q - p;
+                if ((unsigned)wi >= (unsigned)W) continue;
+                const float4 v = *(const float4*)(in + (((int64_t)n * H + hi) * W + wi) * C + c4 * 4);
+                m.x = v.x > m.x ? v.x : m.x; m.y = v.y > m.y ? v.y : m.y;
+                m.z = v.z > m.z ? v.z : m.z; m.w = v.w > m.w ? v.w : m.w;
+            }
+        }
+        *(float4*)(out + (((int64_t)n * Ho + ho) * Wo + wo) * C + c4 * 4) = m;
+    }
+}
+
+__device__ __forceinline__ float bil1(float lx0, float lx1, float ly0, float ly1, float v00, float v01, float v10,
+                                      float v11) {
+    float top = lx0 * v00; top = fmaf(lx1, v01, top);
+    float bot = lx0 * v10; bot = fmaf(lx1, v11, bot);
+    float v = ly0 * top; v = fmaf(ly1, bot, v);
+    return v;
+}
+
+__global__ void resize_bilinear_kernel(const float* __restrict__ in, int N, int H, int W, int C, int Ho, int Wo,
+                                       const float* __restrict__ add, int relu, float* __restrict__ out) {
+    const int c4n = C >> 2;
+    const int64_t total = (int64_t)N * Ho * Wo * c4n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n);
+        int64_t t = i / c4n;
+        const int x = (int)(t % Wo); t /= Wo;
+        const int y = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
+        dm_bil_coef(y, H, Ho, y0, y1, ly0, ly1);
+        dm_bil_coef(x, W, Wo, x0, x1, lx0, lx1);
+        const float* b = in + (int64_t)n * H * W * C + c4 * 4;
+        const float4 v00 = *(const float4*)(b + ((int64_t)y0 * W + x0) * C);
+        const float4 v01 = *(const float4*)(b + ((int64_t)y0 * W + x1) * C);
+        const float4 v10 = *(const float4*)(b + ((int64_t)y1 * W + x0) * C);
+        const float4 v11 = *(const float4*)(b + ((int64_t)y1 * W + x1) * C);
+        float4 o;
+        o.x = bil1(lx0, lx1, ly0, ly1, v00.x, v01.x, v10.x, v11.x);
+        o.y = bil1(lx0, lx1, ly0, ly1, v00.y, v01.y, v10.y, v11.y);
+        o.z = bil1(lx0, lx1, ly0, ly1, v00.z, v01.z, v10.z, v11.z);
+        o.w = bil1(lx0, lx1, ly0, ly1, v00.w, v01.w, v10.w, v11.w);
+        const int64_t oo = (((int64_t)n * Ho + y) * Wo + x) * C + c4 * 4;
+        if (add) {
+            const float4 a = *(const float4*)(add + oo);
+            o.x = o.x + a.x; o.y = o.y + a.y; o.z = o.z + a.z; o.w = o.w + a.w;
+        }
+        if (relu) {
+            o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f;
+            o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
+        }
+        *(float4*)(out + oo) = o;
+    }
+}
+
+__global__ void nearest2x_add_kernel(const float* __restrict__ coarse, int N, int Hc, int Wc, int C,
+                                     const float* __restrict__ lat, int H, int W, float* __restrict__ out) {
+    const int c4n = C >> 2;
+    const int64_t total = (int64_t)N * H * W * c4n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n);
+        int64_t t = i / c4n;
+        const int x = (int)(t % W); t /= W;
+        const int y = (int)(t % H);
+        const int n = (int)(t / H);
+        int yc = y >> 1, xc = x >> 1;
+        yc = yc > Hc - 1 ? Hc - 1 : yc;
+        xc = xc > Wc - 1 ? Wc - 1 : xc;
+        const float4 a = *(const float4*)(lat + i * 4);
+        const float4 b = *(const float4*)(coarse + (((int64_t)n * Hc + yc) * Wc + xc) * C + c4 * 4);
+        *(float4*)(out + i * 4) = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
+}
+
+__global__ void pad_c3_c4_kernel(const float* __restrict__ in, int64_t npix, float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+        const float* s = in + i * 3;
+        *(float4*)(out + i * 4) = make_float4(s[0], s[1], s[2], 0.0f);
+    }
+}
+
+__global__ void map_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, int fn) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        y[i] = fn == 0 ? dm_exp(v) : fn == 1 ? dm_sigmoid(v) : fn == 2 ? dm_tanh(v) : dm_log2(v);
+    }
+}
+
+static inline unsigned grid_for(int64_t total) {
+    int64_t b = cdiv64(total, 256);
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+int maxpool_launch(const float* in, int N, int H, int W, int C, int k, int s, int p, float* out, hipStream_t st) {
+    ARG_CHECK(C % 4 == 0, "C % 4");
+    const int Ho = (H + 2 * p - k) / s + 1, Wo = (W + 2 * p - k) / s + 1;
+    hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for((int64_t)N * Ho * Wo * (C / 4))), dim3(256), 0, st, in, N, H, W, C, k,
+                       s, p, Ho, Wo, out);
+    HIP_TRY(hipGetLastError());
+    return ISEGMI_OK;
+}
+int resize_bilinear_launch(const float* in, int N, int H, int W, int C, int Ho, int Wo, const float* add, int relu,
+                           float* out, hipStream_t st) {
+    ARG_CHECK(C % 4 == 0, "C % 4");
+    hipLaunchKernelGGL(resize_bilinear_kernel, dim3(grid_for((int64_t)N * Ho * Wo * (C / 4))), dim3(256), 0, st, in, N, H,
+                       W, C, Ho, Wo, add, relu, out);
+    HIP_TRY(hipGetLastError());
+    return ISEGMI_OK;
+}
+int nearest2x_add_launch(const float* coarse, int N, int Hc, int Wc, int C, const float* lat, int H, int W, float* out,
+                         hipStream_t st) {
+    ARG_CHECK(C % 4 == 0, "C % 4");
+    hipLaunchKernelGGL(nearest2x_add_kernel, dim3(grid_for((int64_t)N * H * W * (C / 4))), dim3(256), 0, st, coarse, N, Hc,
+                       Wc, C, lat, H, W, out);
+    HIP_TRY(hipGetLastError());
+    return ISEGMI_OK;
+}
+int pad_c3_c4_launch(const float* in, int64_t npix, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(pad_c3_c4_kernel, dim3(grid_for(npix)), dim3(256), 0, st, in, npix, out);
+    HIP_TRY(hipGetLastError());
+    return ISEGMI_OK;
+}
+
+}  // namespace isegmi
+
+using namespace isegmi;
+
+extern "C" int isegmi_op_maxpool(const float* d_in, int N, int H, int W, int C, int k, int s, int p, float* d_out,
+                                 void* stream) {
+    return maxpool_launch(d_in, N, H, W, C, k, s, p, d_out, (hipStream_t)stream);
+}
+extern "C" int isegmi_op_resize_bilinear(const float* d_in, int N, int H, int W, int C, int Ho, int Wo,
+                                         const float* d_add, int relu, float* d_out, void* stream) {
+    return resize_bilinear_launch(d_in, N, H, W, C, Ho, Wo, d_add, relu, d_out, (hipStream_t)stream);
+}
+extern "C" int isegmi_op_upsample_nearest2x_add(const float* d_coarse, int N, int Hc, int Wc, int C,
+                                                const float* d_lateral, int H, int W, float* d_out, void* stream) {
+    return nearest2x_add_launch(d_coarse, N, Hc, Wc, C, d_lateral, H, W, d_out, (hipStream_t)stream);
+}
+extern "C" int isegmi_op_pad_c3_to_c4(const float* d_in, int64_t npix, float* d_out, void* stream) {
+    return pad_c3_c4_launch(d_in, npix, d_out, (hipStream_t)stream);
+}
+extern "C" int isegmi_op_map_f32(const float* d_x, float* d_y, int64_t n, int fn, void* stream) {
+    hipLaunchKernelGGL(map_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, d_x, d_y, n, fn);
+    HIP_TRY(hipGetLastError());
+    return ISEGMI_OK;
+}

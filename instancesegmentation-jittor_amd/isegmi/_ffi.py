@@ -1,0 +1,183 @@
+"""ctypes binding of libisegmi.so (C ABI in include/isegmi.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or a call fails, an
+exception is raised.  Nothing here imports torch, triton or the test oracle.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG, "lib", "libisegmi.so")
+
+
+class IsegmiError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise IsegmiError(
+                "libisegmi.so not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C instancesegmentation-jittor_amd`; there is no CPU fallback" % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        _lib.isegmi_last_error.restype = C.c_char_p
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise IsegmiError("libisegmi error %d: %s" % (rc, lib().isegmi_last_error().decode(errors="replace")))
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("N", "H", "W", "Cin", "Cout", "R", "S", "stride", "pad", "act", "tile", "out_div")] + \
+               [("out_img_stride", C.c_int64), ("out_pix_stride", C.c_int64)]
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = lib().isegmi_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def set_device(i):
+    check(lib().isegmi_set_device(C.c_int(i)))
+
+
+def sync():
+    check(lib().isegmi_sync())
+
+
+class DeviceBuffer:
+    """Owning device allocation with numpy shape/dtype metadata."""
+
+    def __init__(self, shape, dtype=np.float32):
+        self.shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        p = C.c_void_p()
+        check(lib().isegmi_malloc(C.byref(p), C.c_int64(self.nbytes)))
+        self.ptr = p
+
+    @classmethod
+    def from_numpy(cls, a):
+        a = np.ascontiguousarray(a)
+        b = cls(a.shape, a.dtype)
+        if b.nbytes:
+            check(lib().isegmi_h2d(b.ptr, a.ctypes.data_as(C.c_void_p), C.c_int64(b.nbytes)))
+        return b
+
+    def upload(self, a):
+        a = np.ascontiguousarray(a, dtype=self.dtype)
+        assert a.nbytes == self.nbytes, (a.shape, self.shape)
+        check(lib().isegmi_h2d(self.ptr, a.ctypes.data_as(C.c_void_p), C.c_int64(self.nbytes)))
+
+    def numpy(self):
+        out = np.empty(self.shape, self.dtype)
+        if self.nbytes:
+            check(lib().isegmi_d2h(out.ctypes.data_as(C.c_void_p), self.ptr, C.c_int64(self.nbytes)))
+        return out
+
+    def zero(self):
+        check(lib().isegmi_memset(self.ptr, C.c_int(0), C.c_int64(self.nbytes)))
+
+    def free(self):
+        if self.ptr is not None and self.ptr.value:
+            lib().isegmi_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _ptr(b):
+    return None if b is None else b.ptr
+
+
+def make_conv_desc(N, H, W, Cin, Cout, R, S, stride=1, pad=0, act=0, tile=0, out_div=0, out_img_stride=0,
+                   out_pix_stride=0):
+    return ConvDesc(N, H, W, Cin, Cout, R, S, stride, pad, act, tile, out_div, out_img_stride, out_pix_stride)
+
+
+def conv_out_hw(desc):
+    ho, wo = C.c_int32(), C.c_int32()
+    check(lib().isegmi_conv_out_hw(C.byref(desc), C.byref(ho), C.byref(wo)))
+    return ho.value, wo.value
+
+
+def pack_conv_weights(desc, w_krsc):
+    """host: [Cout,R,S,Cin] fp32 -> packed 1-D fp32 array."""
+    w = np.ascontiguousarray(w_krsc, np.float32)
+    assert w.shape == (desc.Cout, desc.R, desc.S, desc.Cin), (w.shape, desc.Cout, desc.R, desc.S, desc.Cin)
+    n = C.c_int64()
+    check(lib().isegmi_conv_packed_floats(C.byref(desc), C.byref(n)))
+    out = np.empty(n.value, np.float32)
+    check(lib().isegmi_pack_conv_weights(C.byref(desc), w.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)))
+    return out
+
+
+def op_conv2d(desc, d_in, d_wpacked, d_scale=None, d_shift=None, d_residual=None, d_out=None):
+    check(lib().isegmi_op_conv2d(C.byref(desc), _ptr(d_in), _ptr(d_wpacked), _ptr(d_scale), _ptr(d_shift),
+                                 _ptr(d_residual), _ptr(d_out), None))
+
+
+def conv2d(x, w_krsc, stride=1, pad=0, scale=None, shift=None, residual=None, act=0, tile=0):
+    """Convenience host->device->host convolution (tests / small inputs)."""
+    x = np.ascontiguousarray(x, np.float32)
+    N, H, W, Cin = x.shape
+    Cout, R, S, _ = w_krsc.shape
+    d = make_conv_desc(N, H, W, Cin, Cout, R, S, stride, pad, act, tile)
+    ho, wo = conv_out_hw(d)
+    dx = DeviceBuffer.from_numpy(x)
+    dw = DeviceBuffer.from_numpy(pack_conv_weights(d, w_krsc))
+    ds = None if scale is None else DeviceBuffer.from_numpy(np.asarray(scale, np.float32))
+    dh = None if shift is None else DeviceBuffer.from_numpy(np.asarray(shift, np.float32))
+    dr = None if residual is None else DeviceBuffer.from_numpy(np.asarray(residual, np.float32))
+    do = DeviceBuffer((N, ho, wo, Cout))
+    op_conv2d(d, dx, dw, ds, dh, dr, do)
+    return do.numpy()
+
+
+def maxpool(x, k, s, p):
+    x = np.ascontiguousarray(x, np.float32)
+    N, H, W, Cc = x.shape
+    ho, wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    dx = DeviceBuffer.from_numpy(x); do = DeviceBuffer((N, ho, wo, Cc))
+    check(lib().isegmi_op_maxpool(dx.ptr, N, H, W, Cc, k, s, p, do.ptr, None))
+    return do.numpy()
+
+
+def resize_bilinear(x, Ho, Wo, add=None, relu=0):
+    x = np.ascontiguousarray(x, np.float32)
+    N, H, W, Cc = x.shape
+    dx = DeviceBuffer.from_numpy(x); do = DeviceBuffer((N, Ho, Wo, Cc))
+    da = None if add is None else DeviceBuffer.from_numpy(np.asarray(add, np.float32))
+    check(lib().isegmi_op_resize_bilinear(dx.ptr, N, H, W, Cc, Ho, Wo, _ptr(da), relu, do.ptr, None))
+    return do.numpy()
+
+
+def upsample_nearest2x_add(coarse, lateral):
+    coarse = np.ascontiguousarray(coarse, np.float32); lateral = np.ascontiguousarray(lateral, np.float32)
+    N, Hc, Wc, Cc = coarse.shape
+    _, H, W, _ = lateral.shape
+    dc = DeviceBuffer.from_numpy(coarse); dl = DeviceBuffer.from_numpy(lateral); do = DeviceBuffer(lateral.shape)
+    check(lib().isegmi_op_upsample_nearest2x_add(dc.ptr, N, Hc, Wc, Cc, dl.ptr, H, W, do.ptr, None))
+    return do.numpy()
+
+
+def map_f32(x, fn):
+    x = np.ascontiguousarray(x, np.float32)
+    dx = DeviceBuffer.from_numpy(x); dy = DeviceBuffer(x.shape)
+    check(lib().isegmi_op_map_f32(dx.ptr, dy.ptr, C.c_int64(x.size), fn, None))
+    return dy.numpy()

@@ -1,0 +1,78 @@
+"""HIP implicit-GEMM conv vs the CPU oracle: BIT-EXACT (k-ordered fmaf chain on both sides)."""
+import numpy as np
+import pytest
+
+from oracle import ora
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(rng, shape, scale=1.0):
+    return (rng.standard_normal(shape) * scale).astype(np.float32)
+
+
+CASES = [
+    # N, H, W, Cin, Cout, R, stride, pad
+    (2, 19, 23, 32, 48, 3, 1, 1),
+    (1, 35, 35, 64, 64, 1, 1, 0),
+    (2, 35, 33, 64, 128, 3, 2, 1),
+    (1, 18, 18, 256, 243, 3, 1, 1),
+    (3, 9, 9, 128, 12, 3, 1, 1),
+    (1, 40, 56, 256, 256, 1, 2, 0),
+    (1, 7, 7, 256, 1024, 7, 1, 0),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+def test_conv_bit_exact(ffi, case, tile):
+    N, H, W, Cin, Cout, R, stride, pad = case
+    rng = np.random.default_rng(hash(case) % (2**32))
+    x = _rand(rng, (N, H, W, Cin))
+    w = _rand(rng, (Cout, R, R, Cin), (2.0 / (R * R * Cin)) ** 0.5)
+    sc = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+    sh = _rand(rng, (Cout,), 0.1)
+    Ho = (H + 2 * pad - R) // stride + 1
+    Wo = (W + 2 * pad - R) // stride + 1
+    res = _rand(rng, (N, Ho, Wo, Cout))
+    for act, use_res in [(1, True), (0, False), (2, False)]:
+        ref = ora.conv2d(x, w, stride, pad, sc, sh, res if use_res else None, act)
+        got = ffi.conv2d(x, w, stride, pad, sc, sh, res if use_res else None, act, tile)
+        assert got.shape == ref.shape
+        assert np.array_equal(got, ref), "max abs diff %g" % np.max(np.abs(got - ref))
+
+
+def test_stem_bit_exact(ffi):
+    rng = np.random.default_rng(7)
+    x3 = _rand(rng, (2, 70, 62, 3), 50.0)
+    x = np.concatenate([x3, np.zeros((2, 70, 62, 1), np.float32)], -1)
+    w3 = _rand(rng, (64, 7, 7, 3), 0.05)
+    w = np.concatenate([w3, np.zeros((64, 7, 7, 1), np.float32)], -1)
+    sc = rng.uniform(0.5, 1.5, 64).astype(np.float32)
+    sh = _rand(rng, (64,), 0.1)
+    for tile in (0, 1, 2, 3):
+        ref = ora.conv2d(x, w, 2, 3, sc, sh, None, 1)
+        got = ffi.conv2d(x, w, 2, 3, sc, sh, None, 1, tile)
+        assert np.array_equal(got, ref), "max abs diff %g" % np.max(np.abs(got - ref))
+
+
+def test_detmath_bit_exact(ffi):
+    rng = np.random.default_rng(3)
+    x = np.concatenate([_rand(rng, (200000,), 10.0), np.linspace(-100, 100, 4001, dtype=np.float32),
+                        np.array([0.0, -0.0, 0.625, -0.625, 88.5, -87.4, 44.5], np.float32)])
+    for fn in (0, 1, 2):
+        assert np.array_equal(ffi.map_f32(x, fn), ora.map_f32(x, fn)), fn
+    xp = np.abs(x) + 1e-6
+    assert np.array_equal(ffi.map_f32(xp, 3), ora.map_f32(xp, 3))
+
+
+def test_spatial_bit_exact(ffi):
+    rng = np.random.default_rng(5)
+    a = _rand(rng, (2, 19, 23, 32))
+    assert np.array_equal(ffi.maxpool(a, 3, 2, 1), ora.maxpool(a, 3, 2, 1))
+    assert np.array_equal(ffi.maxpool(a, 1, 2, 0), ora.maxpool(a, 1, 2, 0))
+    add = _rand(rng, (2, 35, 41, 32))
+    assert np.array_equal(ffi.resize_bilinear(a, 35, 41, add, 0), ora.resize_bilinear(a, 35, 41, add, 0))
+    assert np.array_equal(ffi.resize_bilinear(a, 38, 46, None, 1), ora.resize_bilinear(a, 38, 46, None, 1))
+    lat = _rand(rng, (2, 38, 46, 32))
+    assert np.array_equal(ffi.upsample_nearest2x_add(a, lat), ora.upsample_nearest2x_add(a, lat))
