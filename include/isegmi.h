@@ -81,6 +81,55 @@ int isegmi_op_pad_c3_to_c4(const float* d_in, int64_t npix, float* d_out, void* 
 /* fn: 0 exp 1 sigmoid 2 tanh 3 log2 -- exposes the deterministic math for parity tests */
 int isegmi_op_map_f32(const float* d_x, float* d_y, int64_t n, int fn, void* stream);
 
+/* ---- selection: torch.topk / sort stand-in (M6, M9, Y6) ----
+ * rows independent problems; row r = d_keys + r*row_stride, n elements; output sorted by
+ * (score desc, index asc); k <= 1024.  k_eff = min(k, n, d_limit[r / rows_per_limit]) when
+ * d_limit != NULL.  d_vals/d_idx are [rows][k]; d_cnt [rows] (optional) receives k_eff. */
+int isegmi_op_topk(const float* d_keys, int64_t row_stride, int rows, int n, int k,
+                   const int32_t* d_limit, int rows_per_limit, float* d_vals, int32_t* d_idx,
+                   int32_t* d_cnt, void* stream);
+
+/* ---- Yolact Detect (Y6; App. A.6/A.9; README.md:243 --top_k / --score_threshold path) ----
+ * softmax -> decode -> conf prefilter -> per-class top_k -> fast-NMS -> per-image top max_det.
+ * d_conf holds LOGITS [N][P][ncls]; d_loc [N][P][4]; d_mask [N][P][mask_dim] (tanh applied);
+ * d_priors [P][4] (cx,cy,w,h).  Outputs are fixed-capacity [N][max_det]. */
+typedef struct isegmi_yolact_detect_args {
+    int32_t N, P, ncls, mask_dim, top_k, max_det;
+    float conf_thresh, nms_thresh;
+    const float* d_conf;
+    const float* d_loc;
+    const float* d_mask;
+    const float* d_priors;
+    /* workspace (caller-allocated device memory) */
+    float* d_ws_scoresT;     /* [N][ncls-1][P] */
+    float* d_ws_boxes;       /* [N][P][4] decoded xyxy (relative) */
+    int32_t* d_ws_counts;    /* [2N] */
+    float* d_ws_tk_vals;     /* [N][ncls-1][top_k] */
+    int32_t* d_ws_tk_idx;    /* [N][ncls-1][top_k] */
+    int32_t* d_ws_tk_cnt;    /* [N][ncls-1] */
+    float* d_ws_cand;        /* [N][ncls-1][top_k] */
+    float* d_ws_fin_vals;    /* [N][max_det] */
+    int32_t* d_ws_fin_idx;   /* [N][max_det] */
+    int32_t* d_ws_fin_cnt;   /* [N] */
+    /* outputs */
+    int32_t* d_out_count;    /* [N] */
+    float* d_out_boxes;      /* [N][max_det][4] relative xyxy */
+    float* d_out_scores;     /* [N][max_det] */
+    int32_t* d_out_classes;  /* [N][max_det] 0..ncls-2 */
+    float* d_out_coeffs;     /* [N][max_det][mask_dim] */
+    int32_t* d_out_prior;    /* [N][max_det] */
+} isegmi_yolact_detect_args;
+int isegmi_op_yolact_detect(const isegmi_yolact_detect_args* a, void* stream);
+
+/* ---- Yolact postprocess masks (Y7; App. A.9) ----
+ * d_proto [N][PH][PW][32]; d_coeffs [N][K][32]; d_boxes [N][K][4] relative; d_count [N].
+ * d_ws_lo [N][K][PH][PW] fp32 workspace; d_out_masks [N][K][h][w] uint8 {0,1} (only the first
+ * count[n] masks of image n are written); d_out_boxes [N][K][4] int64 (may be NULL). */
+int isegmi_op_yolact_masks(const float* d_proto, const float* d_coeffs, const float* d_boxes,
+                           const int32_t* d_count, int N, int PH, int PW, int mask_dim, int K, int h,
+                           int w, float* d_ws_lo, uint8_t* d_out_masks, int64_t* d_out_boxes,
+                           void* stream);
+
 #pragma GCC visibility pop
 #ifdef __cplusplus
 }

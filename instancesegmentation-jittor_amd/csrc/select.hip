@@ -1,0 +1,193 @@
+// select.hip -- batched top-k selection + sort on wavefront-64 primitives.
+//
+// Stands in for torch.topk / sort as used by RPNPostProcessor (M6: per-level top-1000 of up to
+// 201 600 objectness scores), Yolact Detect (Y6: per-class top-200 of 19 248, final top-100) and
+// the box post-processor (M9).  Total order = (score descending, index ascending): exactly the
+// oracle's ora_topk, so indices are bit-identical.
+//
+// One block per problem row:
+//   A. 3-pass radix select (12+12+8 bits, LDS histogram) of the threshold score T with
+//      count(score > T) < k <= count(score >= T);
+//   B. ordered compaction: each wave owns a contiguous segment and walks it 64 elements at a time;
+//      __ballot + popcount give every survivor its rank in INDEX order, so ties at T are resolved
+//      lowest-index-first without atomics (deterministic);
+//   C. bitonic sort of <= KCAP 64-bit keys (ordered score << 32 | ~index) in LDS.
+#include "../../include/isegmi.h"
+#include "common.h"
+
+namespace isegmi {
+
+__device__ __forceinline__ unsigned f2ord(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned o) {
+    const unsigned u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    return __uint_as_float(u);
+}
+
+struct TopkArgs {
+    const float* keys;      // row r at keys + r*row_stride
+    int64_t row_stride;
+    int n;                  // elements per row
+    int k;                  // requested k (<= KCAP)
+    const int* limit;       // optional: k_eff = min(k, n, limit[r / rows_per_limit])
+    int rows_per_limit;
+    float* out_vals;        // [rows][k]
+    int* out_idx;           // [rows][k]
+    int* out_cnt;           // [rows] (optional)
+};
+
+template <int NT, int KCAP>
+__global__ __launch_bounds__(NT) void topk_kernel(const TopkArgs a) {
+    constexpr int NW = NT / 64;
+    constexpr int BINS = 4096;
+    __shared__ unsigned hist[BINS];
+    __shared__ unsigned long long sbuf[KCAP];
+    __shared__ unsigned wsum[NW];
+    __shared__ unsigned w_gt[NW], w_eq[NW];
+    __shared__ unsigned sel_digit, sel_kk;
+
+    const int row = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* keys = a.keys + (int64_t)row * a.row_stride;
+    const int n = a.n;
+    int k_eff = a.k < n ? a.k : n;
+    if (a.limit) {
+        const int l = a.limit[row / a.rows_per_limit];
+        k_eff = k_eff < l ? k_eff : l;
+    }
+    if (k_eff <= 0) {
+        if (tid == 0 && a.out_cnt) a.out_cnt[row] = 0;
+        return;
+    }
+
+    // ---- A. radix select of threshold T
+    unsigned prefix = 0, kk = (unsigned)k_eff;
+    for (int pass = 0; pass < 3; ++pass) {
+        const int shift = pass == 0 ? 20 : (pass == 1 ? 8 : 0);
+        const unsigned dmask = pass == 2 ? 0xffu : 0xfffu;
+        const int pshift = pass == 0 ? 32 : (pass == 1 ? 20 : 8);  // bits above this pass's digit
+        for (int i = tid; i < BINS; i += NT) hist[i] = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += NT) {
+            const unsigned u = f2ord(keys[i]);
+            const bool match = pshift >= 32 ? true : ((u >> pshift) == (prefix >> pshift));
+            if (match) atomicAdd(&hist[(u >> shift) & dmask], 1u);
+        }
+        __syncthreads();
+        // suffix scan over bins: thread owns BINS/NT consecutive bins
+        constexpr int PER = BINS / NT;
+        unsigned loc[PER], tsum = 0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { loc[j] = hist[tid * PER + j]; tsum += loc[j]; }
+        // inclusive suffix scan across threads (higher tid = higher bins)
+        unsigned v = tsum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned o = __shfl_down(v, off, 64);
+            if (lane + off < 64) v += o;
+        }
+        if (lane == 0) wsum[wave] = v;
+        __syncthreads();
+        unsigned above_waves = 0;
+        for (int w = wave + 1; w < NW; ++w) above_waves += wsum[w];
+        // v = sum over lanes >= lane in this wave (inclusive); exclusive-above for this thread:
+        unsigned above = above_waves + (v - tsum);
+#pragma unroll
+        for (int j = PER - 1; j >= 0; --j) {
+            if (above < kk && above + loc[j] >= kk) { sel_digit = (unsigned)(tid * PER + j); sel_kk = kk - above; }
+            above += loc[j];
+        }
+        __syncthreads();
+        prefix |= sel_digit << shift;
+        kk = sel_kk;
+        __syncthreads();
+    }
+    const unsigned T = prefix;
+    const unsigned need_eq = kk;
+
+    // ---- B. ordered compaction
+    const int seg = ((n + NW - 1) / NW + 63) & ~63;
+    const int s0 = wave * seg, s1 = (s0 + seg) < n ? (s0 + seg) : n;
+    unsigned cgt = 0, ceq = 0;
+    for (int i = s0 + lane; (i - lane) < s1; i += 64) {
+        const bool in = i < s1;
+        const unsigned u = in ? f2ord(keys[i]) : 0u;
+        cgt += __popcll(__ballot(in && u > T));
+        ceq += __popcll(__ballot(in && u == T));
+    }
+    if (lane == 0) { w_gt[wave] = cgt; w_eq[wave] = ceq; }
+    __syncthreads();
+    unsigned gt_before = 0, eq_before = 0;
+    for (int w = 0; w < wave; ++w) { gt_before += w_gt[w]; eq_before += w_eq[w]; }
+    unsigned run_sel = gt_before + (eq_before < need_eq ? eq_before : need_eq);
+    unsigned run_eq = eq_before;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    for (int i = s0 + lane; (i - lane) < s1; i += 64) {
+        const bool in = i < s1;
+        const unsigned u = in ? f2ord(keys[i]) : 0u;
+        const bool gt = in && u > T, eq = in && u == T;
+        const unsigned long long beq = __ballot(eq);
+        const unsigned eq_rank = run_eq + (unsigned)__popcll(beq & lt_mask);
+        const bool sel = gt || (eq && eq_rank < need_eq);
+        const unsigned long long bsel = __ballot(sel);
+        if (sel) {
+            const unsigned pos = run_sel + (unsigned)__popcll(bsel & lt_mask);
+            if (pos < (unsigned)KCAP) sbuf[pos] = ((unsigned long long)u << 32) | (unsigned long long)(0xffffffffu - (unsigned)i);
+        }
+        run_sel += (unsigned)__popcll(bsel);
+        run_eq += (unsigned)__popcll(beq);
+    }
+    for (int i = k_eff + tid; i < KCAP; i += NT) sbuf[i] = 0ull;
+    __syncthreads();
+
+    // ---- C. bitonic sort, descending
+    for (int size = 2; size <= KCAP; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < KCAP / 2; t += NT) {
+                const int lo = ((t / stride) * stride * 2) + (t % stride);
+                const int hi = lo + stride;
+                const bool desc = ((lo & size) == 0);
+                const unsigned long long x = sbuf[lo], y = sbuf[hi];
+                if (desc ? (x < y) : (x > y)) { sbuf[lo] = y; sbuf[hi] = x; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < k_eff; i += NT) {
+        const unsigned long long kx = sbuf[i];
+        a.out_vals[(int64_t)row * a.k + i] = ord2f((unsigned)(kx >> 32));
+        a.out_idx[(int64_t)row * a.k + i] = (int)(0xffffffffu - (unsigned)(kx & 0xffffffffull));
+    }
+    if (tid == 0 && a.out_cnt) a.out_cnt[row] = k_eff;
+}
+
+int topk_launch(const float* keys, int64_t row_stride, int rows, int n, int k, const int* limit, int rows_per_limit,
+                float* out_vals, int* out_idx, int* out_cnt, hipStream_t st) {
+    ARG_CHECK(rows >= 0 && n >= 0 && k > 0 && k <= 1024, "topk sizes (k <= 1024)");
+    if (rows == 0) return ISEGMI_OK;
+    TopkArgs a{keys, row_stride, n, k, limit, rows_per_limit > 0 ? rows_per_limit : 1, out_vals, out_idx, out_cnt};
+    if (k <= 128) {
+        if (n > 65536) hipLaunchKernelGGL((topk_kernel<1024, 128>), dim3(rows), dim3(1024), 0, st, a);
+        else hipLaunchKernelGGL((topk_kernel<256, 128>), dim3(rows), dim3(256), 0, st, a);
+    } else if (k <= 256) {
+        if (n > 65536) hipLaunchKernelGGL((topk_kernel<1024, 256>), dim3(rows), dim3(1024), 0, st, a);
+        else hipLaunchKernelGGL((topk_kernel<256, 256>), dim3(rows), dim3(256), 0, st, a);
+    } else {
+        if (n > 16384) hipLaunchKernelGGL((topk_kernel<1024, 1024>), dim3(rows), dim3(1024), 0, st, a);
+        else hipLaunchKernelGGL((topk_kernel<256, 1024>), dim3(rows), dim3(256), 0, st, a);
+    }
+    HIP_TRY(hipGetLastError());
+    return ISEGMI_OK;
+}
+
+}  // namespace isegmi
+
+using namespace isegmi;
+
+extern "C" int isegmi_op_topk(const float* d_keys, int64_t row_stride, int rows, int n, int k, const int* d_limit,
+                              int rows_per_limit, float* d_vals, int* d_idx, int* d_cnt, void* stream) {
+    ARG_CHECK(d_keys && d_vals && d_idx, "null device pointer");
+    return topk_launch(d_keys, row_stride, rows, n, k, d_limit, rows_per_limit, d_vals, d_idx, d_cnt, (hipStream_t)stream);
+}

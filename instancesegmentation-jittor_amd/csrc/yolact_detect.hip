@@ -1,0 +1,291 @@
+// yolact_detect.hip -- Yolact Detect + postprocess on the GPU (App. A.6, A.9).
+//
+//   softmax_decode : conf [N][P][C] logits -> probabilities, written TRANSPOSED [N][C-1][P]
+//                    (per-class rows are then contiguous for the top-k kernel); priors whose
+//                    max foreground prob <= conf_thresh get -1 in every class row (excluded);
+//                    loc+priors -> xyxy boxes; per-image kept-prior count.
+//   fast_nms       : per (image, class): box j survives iff max_{i<j} IoU(i,j) <= thr over the
+//                    class's score-sorted top-k (IoU without +1, NaN drops the box).
+//   gather         : final per-image top-100 -> boxes / scores / classes / 32 mask coefficients.
+//   proto masks    : m = sigmoid(fmaf-chain_k proto*coeff) cropped to the box (+1 px) in proto space,
+//                    then bilinear (align_corners=False) to (h,w), > 0.5 -> uint8.
+// Reference anchors: README.md:243-249 (eval.py --score_threshold/--top_k reach Detect+postprocess).
+#include "../../include/isegmi.h"
+#include "common.h"
+#include "detmath.h"
+
+namespace isegmi {
+
+constexpr int SM_ROWS = 128;
+
+__global__ __launch_bounds__(SM_ROWS) void yolact_softmax_decode_kernel(
+    const float* __restrict__ conf, const float* __restrict__ loc, const float* __restrict__ priors, int P, int C,
+    float conf_thresh, float* __restrict__ scoresT, float* __restrict__ boxes, int* __restrict__ keep_count) {
+    extern __shared__ float sm[];  // [SM_ROWS][C]
+    const int n = blockIdx.y;
+    const int p0 = blockIdx.x * SM_ROWS;
+    const int rows = (P - p0) < SM_ROWS ? (P - p0) : SM_ROWS;
+    const float* src = conf + ((int64_t)n * P + p0) * C;
+    for (int i = threadIdx.x; i < rows * C; i += SM_ROWS) sm[i] = src[i];
+    __syncthreads();
+    const int t = threadIdx.x;
+    const int p = p0 + t;
+    bool kept = false;
+    if (t < rows) {
+        float* r = sm + t * C;
+        float m = r[0];
+        for (int c = 1; c < C; ++c) m = r[c] > m ? r[c] : m;
+        float s = 0.0f;
+        for (int c = 0; c < C; ++c) { const float e = dm_exp(r[c] - m); r[c] = e; s = s + e; }
+        float fg = -1.0f;
+        for (int c = 0; c < C; ++c) { const float pr = dm_div(r[c], s); r[c] = pr; if (c >= 1) fg = pr > fg ? pr : fg; }
+        kept = fg > conf_thresh;
+        // decode
+        const float4 l = *(const float4*)(loc + ((int64_t)n * P + p) * 4);
+        const float4 q = *(const float4*)(priors + (int64_t)p * 4);
+        float tx = l.x * 0.1f; tx = tx * q.z;
+        float ty = l.y * 0.1f; ty = ty * q.w;
+        const float cx = q.x + tx, cy = q.y + ty;
+        const float w = q.z * dm_exp(l.z * 0.2f), h = q.w * dm_exp(l.w * 0.2f);
+        const float x1 = cx - dm_div(w, 2.0f), y1 = cy - dm_div(h, 2.0f);
+        *(float4*)(boxes + ((int64_t)n * P + p) * 4) = make_float4(x1, y1, w + x1, h + y1);
+    }
+    const int cnt = __syncthreads_count(kept ? 1 : 0);
+    if (t == 0 && cnt) atomicAdd(&keep_count[n], cnt);
+    if (t < rows) {
+        const float* r = sm + t * C;
+        float* dst = scoresT + (int64_t)n * (C - 1) * P + p;
+        for (int c = 1; c < C; ++c) dst[(int64_t)(c - 1) * P] = kept ? r[c] : -1.0f;
+    }
+}
+
+__device__ __forceinline__ float jaccard(const float4 a, const float4 b) {
+    const float mx2 = a.z < b.z ? a.z : b.z, mx1 = a.x > b.x ? a.x : b.x;
+    const float my2 = a.w < b.w ? a.w : b.w, my1 = a.y > b.y ? a.y : b.y;
+    float iw = mx2 - mx1, ih = my2 - my1;
+    iw = iw > 0.0f ? iw : 0.0f;
+    ih = ih > 0.0f ? ih : 0.0f;
+    const float inter = iw * ih;
+    const float aa = (a.z - a.x) * (a.w - a.y), ab = (b.z - b.x) * (b.w - b.y);
+    const float uni = aa + ab - inter;
+    return dm_div(inter, uni);
+}
+
+// grid (ncls_fg, N); block 256. topk_idx/vals: [N][nc][top_k]; cnt: [N][nc].
+__global__ __launch_bounds__(256) void yolact_fast_nms_kernel(const float* __restrict__ boxes, const float* __restrict__ tk_vals,
+                                                               const int* __restrict__ tk_idx, const int* __restrict__ tk_cnt,
+                                                               int P, int nc, int top_k, float thr,
+                                                               float* __restrict__ cand, int* __restrict__ kept_count) {
+    __shared__ float4 sb[256];
+    const int c = blockIdx.x, n = blockIdx.y;
+    const int base = (n * nc + c) * top_k;
+    const int cnt = tk_cnt[n * nc + c];
+    const int j = threadIdx.x;
+    if (j < cnt) sb[j] = *(const float4*)(boxes + ((int64_t)n * P + tk_idx[base + j]) * 4);
+    __syncthreads();
+    bool keep = false;
+    if (j < cnt) {
+        keep = true;
+        const float4 bj = sb[j];
+        for (int i = 0; i < j; ++i) {
+            const float o = jaccard(sb[i], bj);
+            if (!(o <= thr)) { keep = false; break; }
+        }
+    }
+    if (j < top_k) cand[base + j] = keep ? tk_vals[base + j] : -1.0f;
+    const int k = __syncthreads_count(keep ? 1 : 0);
+    if (j == 0 && k) atomicAdd(&kept_count[n], k);
+}
+
+// grid (N); block 128: one thread per output slot.
+__global__ void yolact_gather_kernel(const float* __restrict__ boxes, const float* __restrict__ mask, const int* __restrict__ tk_idx,
+                                     const float* __restrict__ fin_vals, const int* __restrict__ fin_idx,
+                                     const int* __restrict__ fin_cnt, int P, int nc, int top_k, int mask_dim, int max_det,
+                                     int* __restrict__ out_count, float* __restrict__ out_boxes, float* __restrict__ out_scores,
+                                     int* __restrict__ out_classes, float* __restrict__ out_coeffs, int* __restrict__ out_prior) {
+    const int n = blockIdx.x;
+    const int cnt = fin_cnt[n];
+    if (threadIdx.x == 0) out_count[n] = cnt;
+    for (int q = threadIdx.x; q < max_det; q += blockDim.x) {
+        const int64_t o = (int64_t)n * max_det + q;
+        if (q < cnt) {
+            const int flat = fin_idx[o];
+            const int c = flat / top_k;
+            const int prior = tk_idx[(int64_t)n * nc * top_k + flat];
+            *(float4*)(out_boxes + o * 4) = *(const float4*)(boxes + ((int64_t)n * P + prior) * 4);
+            out_scores[o] = fin_vals[o];
+            out_classes[o] = c;
+            out_prior[o] = prior;
+            for (int k = 0; k < mask_dim; ++k) out_coeffs[o * mask_dim + k] = mask[((int64_t)n * P + prior) * mask_dim + k];
+        } else {
+            *(float4*)(out_boxes + o * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            out_scores[o] = 0.0f;
+            out_classes[o] = -1;
+            out_prior[o] = -1;
+            for (int k = 0; k < mask_dim; ++k) out_coeffs[o * mask_dim + k] = 0.0f;
+        }
+    }
+}
+
+__device__ __forceinline__ void sanitize(float a, float b, int img, float padding, float& o1, float& o2) {
+    a = a * (float)img; b = b * (float)img;
+    float lo = a < b ? a : b, hi = a > b ? a : b;
+    lo = lo - padding; hi = hi + padding;
+    lo = lo > 0.0f ? lo : 0.0f;
+    hi = hi < (float)img ? hi : (float)img;
+    o1 = lo; o2 = hi;
+}
+
+// proto [N][PH][PW][32]; coeffs [N][K][32]; boxes [N][K][4]; lo [N][K][PH][PW].
+// grid (ceil(PH*PW/256), N); one thread per proto pixel keeps its 32 prototype values in registers
+// and loops over the image's detections (coefficients + crop windows staged in LDS).
+constexpr int MD = 32;
+__global__ __launch_bounds__(256) void yolact_proto_masks_kernel(const float* __restrict__ proto, const float* __restrict__ coeffs,
+                                                                  const float* __restrict__ boxes, const int* __restrict__ count,
+                                                                  int PH, int PW, int K, float* __restrict__ lo) {
+    extern __shared__ float sm[];  // [K][MD] coeffs + [K][4] windows
+    const int n = blockIdx.y;
+    const int cnt = count[n];
+    float* sc = sm;
+    float* sw = sm + K * MD;
+    for (int i = threadIdx.x; i < cnt * MD; i += 256) sc[i] = coeffs[(int64_t)n * K * MD + i];
+    for (int d = threadIdx.x; d < cnt; d += 256) {
+        const float4 b = *(const float4*)(boxes + ((int64_t)n * K + d) * 4);
+        float x1, x2, y1, y2;
+        sanitize(b.x, b.z, PW, 1.0f, x1, x2);
+        sanitize(b.y, b.w, PH, 1.0f, y1, y2);
+        sw[d * 4 + 0] = x1; sw[d * 4 + 1] = x2; sw[d * 4 + 2] = y1; sw[d * 4 + 3] = y2;
+    }
+    __syncthreads();
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= PH * PW) return;
+    const int y = pix / PW, x = pix - y * PW;
+    float pv[MD];
+    const float4* ps = (const float4*)(proto + ((int64_t)n * PH * PW + pix) * MD);
+#pragma unroll
+    for (int k = 0; k < MD / 4; ++k) { const float4 v = ps[k]; pv[4 * k] = v.x; pv[4 * k + 1] = v.y; pv[4 * k + 2] = v.z; pv[4 * k + 3] = v.w; }
+    const float fx = (float)x, fy = (float)y;
+    for (int d = 0; d < cnt; ++d) {
+        const float* cf = sc + d * MD;
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < MD; ++k) acc = fmaf(pv[k], cf[k], acc);
+        const float v = dm_sigmoid(acc);
+        const bool inside = fx >= sw[d * 4] && fx < sw[d * 4 + 1] && fy >= sw[d * 4 + 2] && fy < sw[d * 4 + 3];
+        lo[(((int64_t)n * K + d) * PH * PW) + pix] = inside ? v : 0.0f;
+    }
+}
+
+// out [N][K][h][w] uint8, written 4 bytes per thread over the flat valid range of each image.
+__global__ __launch_bounds__(256) void yolact_upsample_masks_kernel(const float* __restrict__ lo, const int* __restrict__ count, int PH,
+                                                                     int PW, int K, int h, int w, uint8_t* __restrict__ out) {
+    const int n = blockIdx.y;
+    const int cnt = count[n];
+    const int64_t total = (int64_t)cnt * h * w;  // flat bytes of this image's valid masks
+    const float* lo_n = lo + (int64_t)n * K * PH * PW;
+    uint8_t* out_n = out + (int64_t)n * K * h * w;
+    for (int64_t q = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; q < total; q += (int64_t)gridDim.x * 256 * 4) {
+        uint32_t word = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int64_t f = q + e;
+            if (f < total) {
+                const int d = (int)(f / ((int64_t)h * w));
+                const int rem = (int)(f - (int64_t)d * h * w);
+                const int y = rem / w, x = rem - y * w;
+                int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
+                dm_bil_coef(y, PH, h, y0, y1, ly0, ly1);
+                dm_bil_coef(x, PW, w, x0, x1, lx0, lx1);
+                const float* m = lo_n + (int64_t)d * PH * PW;
+                float top = lx0 * m[y0 * PW + x0]; top = fmaf(lx1, m[y0 * PW + x1], top);
+                float bot = lx0 * m[y1 * PW + x0]; bot = fmaf(lx1, m[y1 * PW + x1], bot);
+                float v = ly0 * top; v = fmaf(ly1, bot, v);
+                if (v > 0.5f) word |= (1u << (8 * e));
+            }
+        }
+        if (q + 3 < total) *(uint32_t*)(out_n + q) = word;
+        else for (int e = 0; e < 4 && q + e < total; ++e) out_n[q + e] = (uint8_t)((word >> (8 * e)) & 0xff);
+    }
+}
+
+// integer boxes (A.9 last line): sanitize(pad 0) against (w,h) then truncate to int64.
+__global__ void yolact_int_boxes_kernel(const float* __restrict__ boxes, const int* __restrict__ count, int K, int h, int w,
+                                        int64_t* __restrict__ out) {
+    const int n = blockIdx.x;
+    for (int d = threadIdx.x; d < K; d += blockDim.x) {
+        int64_t* o = out + ((int64_t)n * K + d) * 4;
+        if (d < count[n]) {
+            const float4 b = *(const float4*)(boxes + ((int64_t)n * K + d) * 4);
+            float x1, x2, y1, y2;
+            sanitize(b.x, b.z, w, 0.0f, x1, x2);
+            sanitize(b.y, b.w, h, 0.0f, y1, y2);
+            o[0] = (int64_t)x1; o[1] = (int64_t)y1; o[2] = (int64_t)x2; o[3] = (int64_t)y2;
+        } else { o[0] = o[1] = o[2] = o[3] = 0; }
+    }
+}
+
+int topk_launch(const float* keys, int64_t row_stride, int rows, int n, int k, const int* limit, int rows_per_limit,
+                float* out_vals, int* out_idx, int* out_cnt, hipStream_t st);
+
+int yolact_detect_launch(const isegmi_yolact_detect_args* a, hipStream_t st) {
+    ARG_CHECK(a->N > 0 && a->P > 0 && a->ncls >= 2 && a->ncls <= 256, "detect sizes");
+    ARG_CHECK(a->top_k > 0 && a->top_k <= 256 && a->max_det > 0 && a->max_det <= 128, "top_k<=256, max_det<=128");
+    ARG_CHECK(a->mask_dim > 0, "mask_dim");
+    const int nc = a->ncls - 1;
+    HIP_TRY(hipMemsetAsync(a->d_ws_counts, 0, sizeof(int) * 2 * (size_t)a->N, st));
+    int* keep_count = a->d_ws_counts;
+    int* kept2 = a->d_ws_counts + a->N;
+    const size_t lds = (size_t)SM_ROWS * a->ncls * sizeof(float);
+    hipLaunchKernelGGL(yolact_softmax_decode_kernel, dim3(cdiv(a->P, SM_ROWS), a->N), dim3(SM_ROWS), lds, st, a->d_conf, a->d_loc,
+                       a->d_priors, a->P, a->ncls, a->conf_thresh, a->d_ws_scoresT, a->d_ws_boxes, keep_count);
+    HIP_TRY(hipGetLastError());
+    int rc = topk_launch(a->d_ws_scoresT, a->P, a->N * nc, a->P, a->top_k, keep_count, nc, a->d_ws_tk_vals, a->d_ws_tk_idx,
+                         a->d_ws_tk_cnt, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(yolact_fast_nms_kernel, dim3(nc, a->N), dim3(256), 0, st, a->d_ws_boxes, a->d_ws_tk_vals, a->d_ws_tk_idx,
+                       a->d_ws_tk_cnt, a->P, nc, a->top_k, a->nms_thresh, a->d_ws_cand, kept2);
+    HIP_TRY(hipGetLastError());
+    rc = topk_launch(a->d_ws_cand, (int64_t)nc * a->top_k, a->N, nc * a->top_k, a->max_det, kept2, 1, a->d_ws_fin_vals,
+                     a->d_ws_fin_idx, a->d_ws_fin_cnt, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(yolact_gather_kernel, dim3(a->N), dim3(128), 0, st, a->d_ws_boxes, a->d_mask, a->d_ws_tk_idx, a->d_ws_fin_vals,
+                       a->d_ws_fin_idx, a->d_ws_fin_cnt, a->P, nc, a->top_k, a->mask_dim, a->max_det, a->d_out_count,
+                       a->d_out_boxes, a->d_out_scores, a->d_out_classes, a->d_out_coeffs, a->d_out_prior);
+    HIP_TRY(hipGetLastError());
+    return ISEGMI_OK;
+}
+
+int yolact_masks_launch(const float* proto, const float* coeffs, const float* boxes, const int* count, int N, int PH, int PW,
+                        int mask_dim, int K, int h, int w, float* ws_lo, uint8_t* out_masks, int64_t* out_boxes, hipStream_t st) {
+    ARG_CHECK(mask_dim == MD, "mask_dim must be 32");
+    ARG_CHECK(N > 0 && K > 0 && K <= 128 && h > 0 && w > 0, "mask sizes");
+    const size_t lds = (size_t)K * (MD + 4) * sizeof(float);
+    hipLaunchKernelGGL(yolact_proto_masks_kernel, dim3(cdiv(PH * PW, 256), N), dim3(256), lds, st, proto, coeffs, boxes, count, PH,
+                       PW, K, ws_lo);
+    HIP_TRY(hipGetLastError());
+    int64_t blocks = cdiv64((int64_t)K * h * w, 1024);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(yolact_upsample_masks_kernel, dim3((unsigned)blocks, N), dim3(256), 0, st, ws_lo, count, PH, PW, K, h, w,
+                       out_masks);
+    HIP_TRY(hipGetLastError());
+    if (out_boxes) {
+        hipLaunchKernelGGL(yolact_int_boxes_kernel, dim3(N), dim3(128), 0, st, boxes, count, K, h, w, out_boxes);
+        HIP_TRY(hipGetLastError());
+    }
+    return ISEGMI_OK;
+}
+
+}  // namespace isegmi
+
+using namespace isegmi;
+
+extern "C" int isegmi_op_yolact_detect(const isegmi_yolact_detect_args* a, void* stream) {
+    ARG_CHECK(a, "null args");
+    return yolact_detect_launch(a, (hipStream_t)stream);
+}
+extern "C" int isegmi_op_yolact_masks(const float* d_proto, const float* d_coeffs, const float* d_boxes, const int* d_count,
+                                      int N, int PH, int PW, int mask_dim, int K, int h, int w, float* d_ws_lo,
+                                      uint8_t* d_out_masks, int64_t* d_out_boxes, void* stream) {
+    return yolact_masks_launch(d_proto, d_coeffs, d_boxes, d_count, N, PH, PW, mask_dim, K, h, w, d_ws_lo, d_out_masks, d_out_boxes,
+                               (hipStream_t)stream);
+}

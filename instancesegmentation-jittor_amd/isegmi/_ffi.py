@@ -181,3 +181,65 @@ def map_f32(x, fn):
     dx = DeviceBuffer.from_numpy(x); dy = DeviceBuffer(x.shape)
     check(lib().isegmi_op_map_f32(dx.ptr, dy.ptr, C.c_int64(x.size), fn, None))
     return dy.numpy()
+
+
+def topk(keys2d, k, limit=None, rows_per_limit=1):
+    """keys2d [rows][n] -> (vals [rows][k], idx [rows][k], cnt [rows])"""
+    keys2d = np.ascontiguousarray(keys2d, np.float32)
+    rows, n = keys2d.shape
+    dk = DeviceBuffer.from_numpy(keys2d)
+    dv = DeviceBuffer((rows, k), np.float32); di = DeviceBuffer((rows, k), np.int32); dc = DeviceBuffer((rows,), np.int32)
+    dv.zero(); di.zero()
+    dl = None if limit is None else DeviceBuffer.from_numpy(np.asarray(limit, np.int32))
+    check(lib().isegmi_op_topk(dk.ptr, C.c_int64(n), rows, n, k, _ptr(dl), rows_per_limit, dv.ptr, di.ptr, dc.ptr, None))
+    return dv.numpy(), di.numpy(), dc.numpy()
+
+
+class YolactDetectArgs(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("N", "P", "ncls", "mask_dim", "top_k", "max_det")] + \
+               [("conf_thresh", C.c_float), ("nms_thresh", C.c_float)] + \
+               [(n, C.c_void_p) for n in (
+                   "d_conf", "d_loc", "d_mask", "d_priors", "d_ws_scoresT", "d_ws_boxes", "d_ws_counts", "d_ws_tk_vals",
+                   "d_ws_tk_idx", "d_ws_tk_cnt", "d_ws_cand", "d_ws_fin_vals", "d_ws_fin_idx", "d_ws_fin_cnt",
+                   "d_out_count", "d_out_boxes", "d_out_scores", "d_out_classes", "d_out_coeffs", "d_out_prior")]
+
+
+def yolact_detect(conf_logits, loc, mask, priors, conf_thresh=0.05, nms_thresh=0.5, top_k=200, max_det=100):
+    """Host convenience wrapper: conf_logits [N,P,ncls], loc [N,P,4], mask [N,P,md], priors [P,4]."""
+    conf_logits = np.ascontiguousarray(conf_logits, np.float32)
+    N, P, ncls = conf_logits.shape
+    md = mask.shape[-1]
+    nc = ncls - 1
+    bufs = dict(
+        d_conf=DeviceBuffer.from_numpy(conf_logits), d_loc=DeviceBuffer.from_numpy(np.asarray(loc, np.float32)),
+        d_mask=DeviceBuffer.from_numpy(np.asarray(mask, np.float32)), d_priors=DeviceBuffer.from_numpy(np.asarray(priors, np.float32)),
+        d_ws_scoresT=DeviceBuffer((N, nc, P)), d_ws_boxes=DeviceBuffer((N, P, 4)), d_ws_counts=DeviceBuffer((2 * N,), np.int32),
+        d_ws_tk_vals=DeviceBuffer((N, nc, top_k)), d_ws_tk_idx=DeviceBuffer((N, nc, top_k), np.int32),
+        d_ws_tk_cnt=DeviceBuffer((N, nc), np.int32), d_ws_cand=DeviceBuffer((N, nc, top_k)),
+        d_ws_fin_vals=DeviceBuffer((N, max_det)), d_ws_fin_idx=DeviceBuffer((N, max_det), np.int32),
+        d_ws_fin_cnt=DeviceBuffer((N,), np.int32), d_out_count=DeviceBuffer((N,), np.int32),
+        d_out_boxes=DeviceBuffer((N, max_det, 4)), d_out_scores=DeviceBuffer((N, max_det)),
+        d_out_classes=DeviceBuffer((N, max_det), np.int32), d_out_coeffs=DeviceBuffer((N, max_det, md)),
+        d_out_prior=DeviceBuffer((N, max_det), np.int32))
+    a = YolactDetectArgs(N, P, ncls, md, top_k, max_det, conf_thresh, nms_thresh, *[bufs[n].ptr for n, _ in YolactDetectArgs._fields_[8:]])
+    check(lib().isegmi_op_yolact_detect(C.byref(a), None))
+    cnt = bufs["d_out_count"].numpy()
+    out = []
+    B, S, Cl, M, Pr = (bufs[k].numpy() for k in ("d_out_boxes", "d_out_scores", "d_out_classes", "d_out_coeffs", "d_out_prior"))
+    for n in range(N):
+        c = int(cnt[n])
+        out.append(dict(box=B[n, :c], score=S[n, :c], cls=Cl[n, :c], mask=M[n, :c], prior=Pr[n, :c]))
+    return out, bufs["d_ws_boxes"].numpy()
+
+
+def yolact_masks(proto, coeffs, boxes, counts, h, w):
+    """proto [N,PH,PW,32]; coeffs [N,K,32]; boxes [N,K,4]; counts [N] -> (masks u8 [N,K,h,w], boxes i64 [N,K,4])"""
+    proto = np.ascontiguousarray(proto, np.float32)
+    N, PH, PW, md = proto.shape
+    K = coeffs.shape[1]
+    dp = DeviceBuffer.from_numpy(proto); dc = DeviceBuffer.from_numpy(np.asarray(coeffs, np.float32))
+    db = DeviceBuffer.from_numpy(np.asarray(boxes, np.float32)); dn = DeviceBuffer.from_numpy(np.asarray(counts, np.int32))
+    dlo = DeviceBuffer((N, K, PH, PW)); dm = DeviceBuffer((N, K, h, w), np.uint8); dm.zero()
+    dob = DeviceBuffer((N, K, 4), np.int64)
+    check(lib().isegmi_op_yolact_masks(dp.ptr, dc.ptr, db.ptr, dn.ptr, N, PH, PW, md, K, h, w, dlo.ptr, dm.ptr, dob.ptr, None))
+    return dm.numpy(), dob.numpy()
