@@ -130,6 +130,35 @@ int isegmi_op_yolact_masks(const float* d_proto, const float* d_coeffs, const fl
                            int w, float* d_ws_lo, uint8_t* d_out_masks, int64_t* d_out_boxes,
                            void* stream);
 
+/* ---- model engine ----
+ * Replaces the model object the reference builds inside COCODemo(cfg, ...) (README.md:320-324)
+ * and Yolact eval.py (README.md:243): weights are pushed per layer under their upstream
+ * state-dict names with BN already folded to (scale, shift) by the Python host; activations,
+ * workspaces and outputs live in named device buffers owned by the engine. */
+typedef struct isegmi_engine isegmi_engine;
+/* model_kind: 1 = Yolact R50-FPN, 2 = Mask R-CNN R50/R101-FPN.  H, W = network input size. */
+int isegmi_engine_create(int model_kind, int max_batch, int H, int W, isegmi_engine** out);
+int isegmi_engine_destroy(isegmi_engine* e);
+int isegmi_engine_set_param(isegmi_engine* e, const char* name, float value);
+/* h_w_krsc: natural [Cout][R][S][Cin]; h_scale / h_shift [Cout] or NULL */
+int isegmi_engine_set_conv(isegmi_engine* e, const char* name, int Cout, int R, int S, int Cin,
+                           const float* h_w_krsc, const float* h_scale, const float* h_shift);
+/* constant tensors (priors, anchors, deconv weights ...) */
+int isegmi_engine_set_tensor(isegmi_engine* e, const char* name, const void* h_data, int64_t bytes);
+/* Yolact.forward (Y2-Y6): d_images NHWC3 fp32 [N][H][W][3] already normalised (Y1). Asynchronous
+ * on the engine stream; results in buffers det.count/box/score/class/coeff/prior and proto. */
+int isegmi_yolact_forward(isegmi_engine* e, const float* d_images_nhwc3, int N);
+/* postprocess (Y7): masks of the last forward at (out_h,out_w) -> det.masks u8, det.box_int i64 */
+int isegmi_yolact_postprocess(isegmi_engine* e, int out_h, int out_w);
+int isegmi_engine_sync(isegmi_engine* e);
+int isegmi_engine_stream(isegmi_engine* e, void** stream);
+/* dtype: 0 f32, 1 i32, 2 u8, 3 i64; shape4 receives up to 4 dims */
+int isegmi_engine_buffer_info(isegmi_engine* e, const char* name, void** d_ptr, int64_t* bytes,
+                              int32_t* dtype, int64_t* shape4, int32_t* ndim);
+/* per-stage hipEvent timings of the last synchronised forward (set_param "timing" 1 first) */
+int isegmi_engine_get_timings(isegmi_engine* e, char* names, int names_cap, float* ms, int ms_cap,
+                              int* count);
+
 #pragma GCC visibility pop
 #ifdef __cplusplus
 }

@@ -1,0 +1,356 @@
+// engine.cpp -- engine object behind the C ABI: weights, buffers, timings, and the Yolact graph.
+//
+// Yolact graph = SURVEY.md 8a Y2..Y7 (App. A.9): ResNet-50 (stride on the 3x3) -> FPN (bilinear
+// top-down, relu'd 3x3 preds, two stride-2 downsamples) -> protonet on P3 -> shared prediction head
+// on P3..P7 -> Detect -> postprocess.  BN is folded into the conv epilogue (scale, shift) by the
+// Python host (isegmi/yolact.py) exactly once, in fp32.
+#include "engine.h"
+
+#include <string.h>
+
+namespace isegmi {
+
+int eng_buf(Engine& e, const std::string& name, int64_t bytes, void** out, int dtype, std::vector<int64_t> shape) {
+    RawBuf& b = e.bufs[name];
+    if (b.bytes < bytes) {
+        if (b.d) HIP_TRY(hipFree(b.d));
+        b.d = nullptr;
+        HIP_TRY(hipMalloc(&b.d, (size_t)(bytes > 0 ? bytes : 16)));
+        b.bytes = bytes;
+    }
+    b.dtype = dtype;
+    b.shape = shape;
+    *out = b.d;
+    return ISEGMI_OK;
+}
+
+int eng_act(Engine& e, const std::string& name, int N, int H, int W, int C, Tensor* t) {
+    void* p = nullptr;
+    int rc = eng_buf(e, name, (int64_t)N * H * W * C * (int64_t)sizeof(float), &p, 0, {N, H, W, C});
+    if (rc) return rc;
+    t->d = (float*)p; t->N = N; t->H = H; t->W = W; t->C = C;
+    return ISEGMI_OK;
+}
+
+static int find_conv(Engine& e, const std::string& layer, const ConvLayer** out) {
+    auto it = e.convs.find(layer);
+    if (it == e.convs.end()) { set_error("conv layer not set: " + layer); return ISEGMI_ERR_STATE; }
+    *out = &it->second;
+    return ISEGMI_OK;
+}
+
+int eng_conv_into(Engine& e, const std::string& layer, const Tensor& in, int stride, int pad, int act, float* dst, int out_div,
+                  int64_t out_img_stride, int64_t out_pix_stride) {
+    const ConvLayer* L;
+    int rc = find_conv(e, layer, &L);
+    if (rc) return rc;
+    if (L->Cin != in.C) { set_error("conv " + layer + ": Cin mismatch"); return ISEGMI_ERR_ARG; }
+    isegmi_conv_desc d;
+    memset(&d, 0, sizeof(d));
+    d.N = in.N; d.H = in.H; d.W = in.W; d.Cin = in.C; d.Cout = L->Cout; d.R = L->R; d.S = L->S; d.stride = stride; d.pad = pad;
+    d.act = act; d.tile = (int)e.param("conv_tile", 0); d.out_div = out_div; d.out_img_stride = out_img_stride;
+    d.out_pix_stride = out_pix_stride;
+    return conv2d_launch(&d, in.d, L->d_w, L->d_scale, L->d_shift, nullptr, dst, e.stream);
+}
+
+int eng_conv(Engine& e, const std::string& layer, const Tensor& in, int stride, int pad, int act, const Tensor* residual,
+             const std::string& out_name, Tensor* out) {
+    const ConvLayer* L;
+    int rc = find_conv(e, layer, &L);
+    if (rc) return rc;
+    if (L->Cin != in.C) { set_error("conv " + layer + ": Cin mismatch"); return ISEGMI_ERR_ARG; }
+    const int Ho = (in.H + 2 * pad - L->R) / stride + 1, Wo = (in.W + 2 * pad - L->S) / stride + 1;
+    rc = eng_act(e, out_name, in.N, Ho, Wo, L->Cout, out);
+    if (rc) return rc;
+    isegmi_conv_desc d;
+    memset(&d, 0, sizeof(d));
+    d.N = in.N; d.H = in.H; d.W = in.W; d.Cin = in.C; d.Cout = L->Cout; d.R = L->R; d.S = L->S; d.stride = stride; d.pad = pad;
+    d.act = act; d.tile = (int)e.param("conv_tile", 0);
+    return conv2d_launch(&d, in.d, L->d_w, L->d_scale, L->d_shift, residual ? residual->d : nullptr, out->d, e.stream);
+}
+
+void eng_mark(Engine& e, const char* name) {
+    if (!e.timing) return;
+    StageTime s;
+    s.name = name;
+    if (hipEventCreate(&s.ev) != hipSuccess) return;
+    hipEventRecord(s.ev, e.stream);
+    e.marks.push_back(s);
+}
+
+static void collect_times(Engine& e) {
+    e.last_times.clear();
+    if (!e.timing || e.marks.empty()) return;
+    hipEventSynchronize(e.marks.back().ev);
+    for (size_t i = 1; i < e.marks.size(); ++i) {
+        float ms = 0;
+        hipEventElapsedTime(&ms, e.marks[i - 1].ev, e.marks[i].ev);
+        e.last_times.push_back({e.marks[i].name, ms});
+    }
+    for (auto& m : e.marks) hipEventDestroy(m.ev);
+    e.marks.clear();
+}
+
+#define TRY(x)            \
+    do {                  \
+        int _rc = (x);    \
+        if (_rc) return _rc; \
+    } while (0)
+
+int yolact_forward(Engine& e, const float* d_images, int N) {
+    const int H = e.H, W = e.W;
+    eng_mark(e, "start");
+    Tensor x4;
+    TRY(eng_act(e, "input4", N, H, W, 4, &x4));
+    TRY(pad_c3_c4_launch(d_images, (int64_t)N * H * W, x4.d, e.stream));
+    Tensor s, x;
+    TRY(eng_conv(e, "backbone.conv1", x4, 2, 3, 1, nullptr, "stem", &s));
+    {
+        const int Ho = (s.H + 2 - 3) / 2 + 1, Wo = (s.W + 2 - 3) / 2 + 1;
+        TRY(eng_act(e, "pool", N, Ho, Wo, s.C, &x));
+        TRY(maxpool_launch(s.d, N, s.H, s.W, s.C, 3, 2, 1, x.d, e.stream));
+    }
+    eng_mark(e, "stem");
+    const int blocks[4] = {3, 4, 6, 3};
+    Tensor outs[4];
+    for (int li = 0; li < 4; ++li) {
+        for (int b = 0; b < blocks[li]; ++b) {
+            const std::string nm = "backbone.layers." + std::to_string(li) + "." + std::to_string(b);
+            const int st = (b == 0 && li > 0) ? 2 : 1;
+            Tensor idt = x, t1, t2, y;
+            if (b == 0) TRY(eng_conv(e, nm + ".downsample.0", x, st, 0, 0, nullptr, nm + ".ds", &idt));
+            TRY(eng_conv(e, nm + ".conv1", x, 1, 0, 1, nullptr, nm + ".t1", &t1));
+            TRY(eng_conv(e, nm + ".conv2", t1, st, 1, 1, nullptr, nm + ".t2", &t2));
+            TRY(eng_conv(e, nm + ".conv3", t2, 1, 0, 1, &idt, nm + ".out", &y));
+            x = y;
+        }
+        outs[li] = x;
+        eng_mark(e, li == 0 ? "layer1" : li == 1 ? "layer2" : li == 2 ? "layer3" : "layer4");
+    }
+    const Tensor C3 = outs[1], C4 = outs[2], C5 = outs[3];
+    // FPN
+    Tensor l5, l4, l3, x4f, x3f, P[5];
+    TRY(eng_conv(e, "fpn.lat_layers.0", C5, 1, 0, 0, nullptr, "fpn.lat5", &l5));
+    TRY(eng_conv(e, "fpn.lat_layers.1", C4, 1, 0, 0, nullptr, "fpn.lat4", &l4));
+    TRY(eng_conv(e, "fpn.lat_layers.2", C3, 1, 0, 0, nullptr, "fpn.lat3", &l3));
+    TRY(eng_act(e, "fpn.x4", N, l4.H, l4.W, l4.C, &x4f));
+    TRY(resize_bilinear_launch(l5.d, N, l5.H, l5.W, l5.C, l4.H, l4.W, l4.d, 0, x4f.d, e.stream));
+    TRY(eng_act(e, "fpn.x3", N, l3.H, l3.W, l3.C, &x3f));
+    TRY(resize_bilinear_launch(x4f.d, N, x4f.H, x4f.W, x4f.C, l3.H, l3.W, l3.d, 0, x3f.d, e.stream));
+    TRY(eng_conv(e, "fpn.pred_layers.0", l5, 1, 1, 1, nullptr, "P5", &P[2]));
+    TRY(eng_conv(e, "fpn.pred_layers.1", x4f, 1, 1, 1, nullptr, "P4", &P[1]));
+    TRY(eng_conv(e, "fpn.pred_layers.2", x3f, 1, 1, 1, nullptr, "P3", &P[0]));
+    TRY(eng_conv(e, "fpn.downsample_layers.0", P[2], 2, 1, 0, nullptr, "P6", &P[3]));
+    TRY(eng_conv(e, "fpn.downsample_layers.1", P[3], 2, 1, 0, nullptr, "P7", &P[4]));
+    eng_mark(e, "fpn");
+    // protonet
+    Tensor t, u, proto;
+    TRY(eng_conv(e, "proto_net.0", P[0], 1, 1, 1, nullptr, "proto.t0", &t));
+    TRY(eng_conv(e, "proto_net.2", t, 1, 1, 1, nullptr, "proto.t1", &u));
+    TRY(eng_conv(e, "proto_net.4", u, 1, 1, 1, nullptr, "proto.t2", &t));
+    TRY(eng_act(e, "proto.up", N, t.H * 2, t.W * 2, t.C, &u));
+    TRY(resize_bilinear_launch(t.d, N, t.H, t.W, t.C, t.H * 2, t.W * 2, nullptr, 1, u.d, e.stream));
+    TRY(eng_conv(e, "proto_net.8", u, 1, 1, 1, nullptr, "proto.t3", &t));
+    TRY(eng_conv(e, "proto_net.10", t, 1, 0, 1, nullptr, "proto", &proto));
+    eng_mark(e, "protonet");
+    // shared prediction head
+    const int A = 3, ncls = 81, md = 32;
+    int Ptot = 0, off[5];
+    for (int l = 0; l < 5; ++l) { off[l] = Ptot; Ptot += P[l].H * P[l].W * A; }
+    {
+        auto it = e.tensors.find("priors");
+        if (it == e.tensors.end() || it->second.bytes != (int64_t)Ptot * 16) { set_error("priors tensor missing or wrong size"); return ISEGMI_ERR_STATE; }
+    }
+    void *loc, *conf, *mask;
+    TRY(eng_buf(e, "loc", (int64_t)N * Ptot * 4 * 4, &loc, 0, {N, Ptot, 4}));
+    TRY(eng_buf(e, "conf", (int64_t)N * Ptot * ncls * 4, &conf, 0, {N, Ptot, ncls}));
+    TRY(eng_buf(e, "mask", (int64_t)N * Ptot * md * 4, &mask, 0, {N, Ptot, md}));
+    for (int l = 0; l < 5; ++l) {
+        Tensor uf;
+        const std::string ln = "head.up" + std::to_string(l);
+        TRY(eng_conv(e, "prediction_layers.0.upfeature.0", P[l], 1, 1, 1, nullptr, ln, &uf));
+        const int hw = uf.H * uf.W;
+        TRY(eng_conv_into(e, "prediction_layers.0.bbox_layer", uf, 1, 1, 0, (float*)loc + (int64_t)off[l] * 4, hw, (int64_t)Ptot * 4, A * 4));
+        TRY(eng_conv_into(e, "prediction_layers.0.conf_layer", uf, 1, 1, 0, (float*)conf + (int64_t)off[l] * ncls, hw, (int64_t)Ptot * ncls, A * ncls));
+        TRY(eng_conv_into(e, "prediction_layers.0.mask_layer", uf, 1, 1, 2, (float*)mask + (int64_t)off[l] * md, hw, (int64_t)Ptot * md, A * md));
+    }
+    eng_mark(e, "heads");
+    // Detect
+    const int top_k = (int)e.param("nms_top_k", 200), max_det = (int)e.param("max_num_detections", 100);
+    const int nc = ncls - 1;
+    isegmi_yolact_detect_args a;
+    memset(&a, 0, sizeof(a));
+    a.N = N; a.P = Ptot; a.ncls = ncls; a.mask_dim = md; a.top_k = top_k; a.max_det = max_det;
+    a.conf_thresh = e.param("nms_conf_thresh", 0.05f);
+    a.nms_thresh = e.param("nms_thresh", 0.5f);
+    a.d_conf = (const float*)conf; a.d_loc = (const float*)loc; a.d_mask = (const float*)mask;
+    a.d_priors = (const float*)e.tensors["priors"].d;
+    void* p;
+    TRY(eng_buf(e, "ws.scoresT", (int64_t)N * nc * Ptot * 4, &p)); a.d_ws_scoresT = (float*)p;
+    TRY(eng_buf(e, "boxes_all", (int64_t)N * Ptot * 16, &p, 0, {N, Ptot, 4})); a.d_ws_boxes = (float*)p;
+    TRY(eng_buf(e, "ws.counts", (int64_t)2 * N * 4, &p, 1)); a.d_ws_counts = (int32_t*)p;
+    TRY(eng_buf(e, "ws.tk_vals", (int64_t)N * nc * top_k * 4, &p)); a.d_ws_tk_vals = (float*)p;
+    TRY(eng_buf(e, "ws.tk_idx", (int64_t)N * nc * top_k * 4, &p, 1)); a.d_ws_tk_idx = (int32_t*)p;
+    TRY(eng_buf(e, "ws.tk_cnt", (int64_t)N * nc * 4, &p, 1)); a.d_ws_tk_cnt = (int32_t*)p;
+    TRY(eng_buf(e, "ws.cand", (int64_t)N * nc * top_k * 4, &p)); a.d_ws_cand = (float*)p;
+    TRY(eng_buf(e, "ws.fin_vals", (int64_t)N * max_det * 4, &p)); a.d_ws_fin_vals = (float*)p;
+    TRY(eng_buf(e, "ws.fin_idx", (int64_t)N * max_det * 4, &p, 1)); a.d_ws_fin_idx = (int32_t*)p;
+    TRY(eng_buf(e, "ws.fin_cnt", (int64_t)N * 4, &p, 1)); a.d_ws_fin_cnt = (int32_t*)p;
+    TRY(eng_buf(e, "det.count", (int64_t)N * 4, &p, 1, {N})); a.d_out_count = (int32_t*)p;
+    TRY(eng_buf(e, "det.box", (int64_t)N * max_det * 16, &p, 0, {N, max_det, 4})); a.d_out_boxes = (float*)p;
+    TRY(eng_buf(e, "det.score", (int64_t)N * max_det * 4, &p, 0, {N, max_det})); a.d_out_scores = (float*)p;
+    TRY(eng_buf(e, "det.class", (int64_t)N * max_det * 4, &p, 1, {N, max_det})); a.d_out_classes = (int32_t*)p;
+    TRY(eng_buf(e, "det.coeff", (int64_t)N * max_det * md * 4, &p, 0, {N, max_det, md})); a.d_out_coeffs = (float*)p;
+    TRY(eng_buf(e, "det.prior", (int64_t)N * max_det * 4, &p, 1, {N, max_det})); a.d_out_prior = (int32_t*)p;
+    TRY(yolact_detect_launch(&a, e.stream));
+    eng_mark(e, "detect");
+    e.last_N = N;
+    return ISEGMI_OK;
+}
+
+int yolact_postprocess(Engine& e, int h, int w) {
+    const int N = e.last_N;
+    if (N <= 0) { set_error("postprocess before forward"); return ISEGMI_ERR_STATE; }
+    const int K = (int)e.param("max_num_detections", 100);
+    RawBuf& proto = e.bufs["proto"];
+    const int PH = (int)proto.shape[1], PW = (int)proto.shape[2], md = (int)proto.shape[3];
+    void *lo, *masks, *ib;
+    TRY(eng_buf(e, "ws.lo", (int64_t)N * K * PH * PW * 4, &lo));
+    TRY(eng_buf(e, "det.masks", (int64_t)N * K * h * w, &masks, 2, {N, K, h, w}));
+    TRY(eng_buf(e, "det.box_int", (int64_t)N * K * 4 * 8, &ib, 3, {N, K, 4}));
+    TRY(yolact_masks_launch((const float*)proto.d, (const float*)e.bufs["det.coeff"].d, (const float*)e.bufs["det.box"].d,
+                            (const int*)e.bufs["det.count"].d, N, PH, PW, md, K, h, w, (float*)lo, (uint8_t*)masks, (int64_t*)ib,
+                            e.stream));
+    eng_mark(e, "masks");
+    return ISEGMI_OK;
+}
+
+}  // namespace isegmi
+
+using namespace isegmi;
+
+struct isegmi_engine {
+    Engine e;
+};
+
+extern "C" int isegmi_engine_create(int model_kind, int max_batch, int H, int W, isegmi_engine** out) {
+    ARG_CHECK(out, "null out");
+    ARG_CHECK(model_kind == 1 || model_kind == 2, "model_kind: 1 yolact, 2 maskrcnn");
+    ARG_CHECK(max_batch > 0 && H > 0 && W > 0, "sizes");
+    isegmi_engine* h = new isegmi_engine();
+    h->e.kind = model_kind; h->e.max_batch = max_batch; h->e.H = H; h->e.W = W;
+    hipError_t er = hipStreamCreate(&h->e.stream);
+    if (er != hipSuccess) { set_error(std::string("hipStreamCreate: ") + hipGetErrorString(er)); delete h; return ISEGMI_ERR_HIP; }
+    *out = h;
+    return ISEGMI_OK;
+}
+
+extern "C" int isegmi_engine_destroy(isegmi_engine* h) {
+    if (!h) return ISEGMI_OK;
+    Engine& e = h->e;
+    hipStreamSynchronize(e.stream);
+    for (auto& kv : e.convs) { hipFree(kv.second.d_w); if (kv.second.d_scale) hipFree(kv.second.d_scale); if (kv.second.d_shift) hipFree(kv.second.d_shift); }
+    for (auto& kv : e.tensors) hipFree(kv.second.d);
+    for (auto& kv : e.bufs) hipFree(kv.second.d);
+    hipStreamDestroy(e.stream);
+    delete h;
+    return ISEGMI_OK;
+}
+
+extern "C" int isegmi_engine_set_param(isegmi_engine* h, const char* name, float value) {
+    ARG_CHECK(h && name, "null");
+    h->e.params[name] = value;
+    if (std::string(name) == "timing") h->e.timing = value != 0.0f;
+    return ISEGMI_OK;
+}
+
+extern "C" int isegmi_engine_set_conv(isegmi_engine* h, const char* name, int Cout, int R, int S, int Cin, const float* h_w_krsc,
+                                      const float* h_scale, const float* h_shift) {
+    ARG_CHECK(h && name && h_w_krsc, "null");
+    isegmi_conv_desc d;
+    memset(&d, 0, sizeof(d));
+    d.N = 1; d.H = R; d.W = S; d.Cin = Cin; d.Cout = Cout; d.R = R; d.S = S; d.stride = 1; d.pad = 0;
+    int64_t nf = 0;
+    TRY(isegmi_conv_packed_floats(&d, &nf));
+    std::vector<float> packed((size_t)nf);
+    TRY(isegmi_pack_conv_weights(&d, h_w_krsc, packed.data()));
+    ConvLayer& L = h->e.convs[name];
+    if (L.d_w) { hipFree(L.d_w); L.d_w = nullptr; }
+    if (L.d_scale) { hipFree(L.d_scale); L.d_scale = nullptr; }
+    if (L.d_shift) { hipFree(L.d_shift); L.d_shift = nullptr; }
+    L.Cout = Cout; L.R = R; L.S = S; L.Cin = Cin;
+    HIP_TRY(hipMalloc((void**)&L.d_w, (size_t)nf * 4));
+    HIP_TRY(hipMemcpy(L.d_w, packed.data(), (size_t)nf * 4, hipMemcpyHostToDevice));
+    if (h_scale) { HIP_TRY(hipMalloc((void**)&L.d_scale, (size_t)Cout * 4)); HIP_TRY(hipMemcpy(L.d_scale, h_scale, (size_t)Cout * 4, hipMemcpyHostToDevice)); }
+    if (h_shift) { HIP_TRY(hipMalloc((void**)&L.d_shift, (size_t)Cout * 4)); HIP_TRY(hipMemcpy(L.d_shift, h_shift, (size_t)Cout * 4, hipMemcpyHostToDevice)); }
+    return ISEGMI_OK;
+}
+
+extern "C" int isegmi_engine_set_tensor(isegmi_engine* h, const char* name, const void* h_data, int64_t bytes) {
+    ARG_CHECK(h && name && h_data && bytes > 0, "args");
+    RawBuf& b = h->e.tensors[name];
+    if (b.d) { hipFree(b.d); b.d = nullptr; }
+    HIP_TRY(hipMalloc(&b.d, (size_t)bytes));
+    HIP_TRY(hipMemcpy(b.d, h_data, (size_t)bytes, hipMemcpyHostToDevice));
+    b.bytes = bytes;
+    return ISEGMI_OK;
+}
+
+extern "C" int isegmi_yolact_forward(isegmi_engine* h, const float* d_images_nhwc3, int N) {
+    ARG_CHECK(h && d_images_nhwc3, "null");
+    ARG_CHECK(h->e.kind == 1, "engine is not a yolact engine");
+    ARG_CHECK(N > 0 && N <= h->e.max_batch, "batch size");
+    return yolact_forward(h->e, d_images_nhwc3, N);
+}
+
+extern "C" int isegmi_yolact_postprocess(isegmi_engine* h, int out_h, int out_w) {
+    ARG_CHECK(h, "null");
+    ARG_CHECK(h->e.kind == 1, "engine is not a yolact engine");
+    ARG_CHECK(out_h > 0 && out_w > 0, "output size");
+    return yolact_postprocess(h->e, out_h, out_w);
+}
+
+extern "C" int isegmi_engine_sync(isegmi_engine* h) {
+    ARG_CHECK(h, "null");
+    HIP_TRY(hipStreamSynchronize(h->e.stream));
+    collect_times(h->e);
+    return ISEGMI_OK;
+}
+
+extern "C" int isegmi_engine_stream(isegmi_engine* h, void** stream) {
+    ARG_CHECK(h && stream, "null");
+    *stream = (void*)h->e.stream;
+    return ISEGMI_OK;
+}
+
+// Query a named engine buffer: device pointer, byte size, dtype (0 f32 1 i32 2 u8 3 i64), shape (up to 4 dims).
+extern "C" int isegmi_engine_buffer_info(isegmi_engine* h, const char* name, void** d_ptr, int64_t* bytes, int32_t* dtype,
+                                         int64_t* shape4, int32_t* ndim) {
+    ARG_CHECK(h && name, "null");
+    auto it = h->e.bufs.find(name);
+    if (it == h->e.bufs.end()) { set_error(std::string("no such buffer: ") + name); return ISEGMI_ERR_ARG; }
+    const RawBuf& b = it->second;
+    if (d_ptr) *d_ptr = b.d;
+    if (bytes) *bytes = b.bytes;
+    if (dtype) *dtype = b.dtype;
+    if (ndim) *ndim = (int32_t)b.shape.size();
+    if (shape4) for (size_t i = 0; i < 4; ++i) shape4[i] = i < b.shape.size() ? b.shape[i] : 1;
+    return ISEGMI_OK;
+}
+
+// Copies the stage timings of the last synchronised forward: names joined by ';' and ms values.
+extern "C" int isegmi_engine_get_timings(isegmi_engine* h, char* names, int names_cap, float* ms, int ms_cap, int* count) {
+    ARG_CHECK(h && names && ms && count, "null");
+    std::string s;
+    int c = 0;
+    for (auto& kv : h->e.last_times) {
+        if (c >= ms_cap) break;
+        if (c) s += ";";
+        s += kv.first;
+        ms[c++] = kv.second;
+    }
+    ARG_CHECK((int)s.size() + 1 <= names_cap, "names buffer too small");
+    memcpy(names, s.c_str(), s.size() + 1);
+    *count = c;
+    return ISEGMI_OK;
+}

@@ -1,0 +1,88 @@
+// engine.h -- model engine: packed-weight registry, named activation buffers, per-model forward graphs.
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/isegmi.h"
+#include "common.h"
+
+namespace isegmi {
+
+struct Tensor {
+    float* d = nullptr;
+    int N = 0, H = 0, W = 0, C = 0;
+    int64_t numel() const { return (int64_t)N * H * W * C; }
+};
+
+struct ConvLayer {
+    int Cout = 0, R = 0, S = 0, Cin = 0;
+    float* d_w = nullptr;      // packed
+    float* d_scale = nullptr;  // may be null (=1)
+    float* d_shift = nullptr;  // may be null (=0)
+};
+
+struct RawBuf {
+    void* d = nullptr;
+    int64_t bytes = 0;
+    std::vector<int64_t> shape;
+    int dtype = 0;  // 0 f32, 1 i32, 2 u8, 3 i64
+};
+
+struct StageTime {
+    std::string name;
+    hipEvent_t ev;
+};
+
+struct Engine {
+    int kind = 0;  // 1 yolact, 2 maskrcnn
+    int max_batch = 0, H = 0, W = 0;
+    hipStream_t stream = nullptr;
+    std::map<std::string, ConvLayer> convs;
+    std::map<std::string, RawBuf> tensors;   // user-set constant tensors (priors, anchors, deconv weights ...)
+    std::map<std::string, RawBuf> bufs;      // activations / workspaces / outputs, allocated on first use
+    std::map<std::string, float> params;
+    bool finalized = false;
+    int last_N = 0;
+    // timing
+    bool timing = false;
+    std::vector<StageTime> marks;
+    std::vector<std::pair<std::string, float>> last_times;
+
+    float param(const std::string& k, float def) const {
+        auto it = params.find(k);
+        return it == params.end() ? def : it->second;
+    }
+};
+
+// engine.cpp helpers
+int eng_buf(Engine& e, const std::string& name, int64_t bytes, void** out, int dtype = 0,
+            std::vector<int64_t> shape = {});
+int eng_act(Engine& e, const std::string& name, int N, int H, int W, int C, Tensor* t);
+int eng_conv(Engine& e, const std::string& layer, const Tensor& in, int stride, int pad, int act, const Tensor* residual,
+             const std::string& out_name, Tensor* out);
+// conv writing into a caller-provided strided destination (heads -> concatenated buffers, deconv parities)
+int eng_conv_into(Engine& e, const std::string& layer, const Tensor& in, int stride, int pad, int act, float* dst, int out_div,
+                  int64_t out_img_stride, int64_t out_pix_stride);
+void eng_mark(Engine& e, const char* name);
+
+int yolact_forward(Engine& e, const float* d_images, int N);
+int yolact_postprocess(Engine& e, int h, int w);
+int maskrcnn_forward(Engine& e, const float* d_images, const int32_t* h_image_hw, int N);
+
+// kernels implemented in other translation units
+int conv2d_launch(const isegmi_conv_desc* d, const float* in, const float* w, const float* scale, const float* shift,
+                  const float* res, float* out, hipStream_t st);
+int maxpool_launch(const float* in, int N, int H, int W, int C, int k, int s, int p, float* out, hipStream_t st);
+int resize_bilinear_launch(const float* in, int N, int H, int W, int C, int Ho, int Wo, const float* add, int relu, float* out,
+                           hipStream_t st);
+int nearest2x_add_launch(const float* coarse, int N, int Hc, int Wc, int C, const float* lat, int H, int W, float* out,
+                         hipStream_t st);
+int pad_c3_c4_launch(const float* in, int64_t npix, float* out, hipStream_t st);
+int topk_launch(const float* keys, int64_t row_stride, int rows, int n, int k, const int* limit, int rows_per_limit,
+                float* out_vals, int* out_idx, int* out_cnt, hipStream_t st);
+int yolact_detect_launch(const isegmi_yolact_detect_args* a, hipStream_t st);
+int yolact_masks_launch(const float* proto, const float* coeffs, const float* boxes, const int* count, int N, int PH, int PW,
+                        int mask_dim, int K, int h, int w, float* ws_lo, uint8_t* out_masks, int64_t* out_boxes, hipStream_t st);
+
+}  // namespace isegmi

@@ -1,0 +1,208 @@
+"""Yolact R50-FPN inference, host side (mirrors Yolact.jittor's eval surface).
+
+Reference surface (README.md:243-249): `python eval.py --trained_model=... --score_threshold=0.15
+--top_k=15 --image=...` -> [UPSTREAM-RECALL, SURVEY 8b] `net(batch) -> [{'detection': {'box','mask',
+'class','score','proto'}, 'net'}]` and `postprocess(dets, w, h, score_threshold) -> (classes, scores,
+boxes, masks)`.  Everything numeric runs in libisegmi.so (HIP); this file only moves config,
+weights and results across the C ABI.
+"""
+import ctypes as C
+import math
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _ffi
+from .weights import fold_batchnorm, to_krsc
+
+MEANS = (103.94, 116.78, 123.68)  # BGR
+STD = (57.38, 57.12, 58.40)
+
+
+@dataclass(frozen=True)
+class YolactConfig:
+    """yolact_resnet50_config constants."""
+    max_size: int = 550
+    num_classes: int = 81
+    mask_dim: int = 32
+    pred_scales: tuple = (24, 48, 96, 192, 384)
+    pred_aspect_ratios: tuple = (1.0, 0.5, 2.0)
+    nms_conf_thresh: float = 0.05
+    nms_thresh: float = 0.5
+    nms_top_k: int = 200
+    max_num_detections: int = 100
+
+
+def make_priors(conv_h, conv_w, scale, max_size, ars):
+    out = np.empty((conv_h, conv_w, len(ars), 4), np.float64)
+    xs = (np.arange(conv_w) + 0.5) / conv_w
+    ys = (np.arange(conv_h) + 0.5) / conv_h
+    out[..., 0] = xs[None, :, None]
+    out[..., 1] = ys[:, None, None]
+    for a, ar in enumerate(ars):
+        w = scale * math.sqrt(ar) / max_size
+        out[..., a, 2] = w
+        out[..., a, 3] = w  # use_square_anchors
+    return out.reshape(-1, 4).astype(np.float32)
+
+
+def fast_base_transform(images_bgr_u8):
+    """FastBaseTransform for already-550x550 BGR uint8 images (Y1): (x-mean)/std then BGR->RGB. NHWC3 fp32."""
+    x = np.asarray(images_bgr_u8, np.float32)
+    x = (x - np.asarray(MEANS, np.float32)) / np.asarray(STD, np.float32)
+    return np.ascontiguousarray(x[..., ::-1])
+
+
+def _level_sizes(size):
+    s = (size + 6 - 7) // 2 + 1      # conv1 7x7/2 p3
+    s = (s + 2 - 3) // 2 + 1         # maxpool 3/2/1
+    c3 = (s + 2 - 3) // 2 + 1        # layer2 stride 2 (3x3 p1)
+    c4 = (c3 + 2 - 3) // 2 + 1
+    c5 = (c4 + 2 - 3) // 2 + 1
+    p6 = (c5 + 2 - 3) // 2 + 1
+    p7 = (p6 + 2 - 3) // 2 + 1
+    return [c3, c4, c5, p6, p7]
+
+
+class Yolact:
+    """`net = Yolact(state_dict); preds = net(batch)`; `postprocess(preds, w, h, score_threshold)`."""
+
+    KIND = 1
+
+    def __init__(self, state_dict, cfg=YolactConfig(), max_batch=8, device=0, input_size=None):
+        self.cfg = cfg
+        self.size = int(input_size or cfg.max_size)
+        self.max_batch = max_batch
+        L = _ffi.lib()
+        _ffi.set_device(device)
+        self._h = C.c_void_p()
+        _ffi.check(L.isegmi_engine_create(self.KIND, max_batch, self.size, self.size, C.byref(self._h)))
+        self._load(state_dict)
+        for k in ("nms_conf_thresh", "nms_thresh", "nms_top_k", "max_num_detections"):
+            self.set_param(k, float(getattr(cfg, k)))
+        self._d_in = _ffi.DeviceBuffer((max_batch, self.size, self.size, 3))
+
+    # -- weights -------------------------------------------------------------------------------
+    def _set_conv(self, name, w_oihw, scale=None, shift=None, pad_cin_to=None):
+        w = to_krsc(w_oihw)
+        if pad_cin_to and w.shape[3] < pad_cin_to:
+            w = np.concatenate([w, np.zeros(w.shape[:3] + (pad_cin_to - w.shape[3],), np.float32)], -1)
+        cout, r, s, cin = w.shape
+        fp = lambda a: None if a is None else np.ascontiguousarray(a, np.float32).ctypes.data_as(C.c_void_p)
+        sc = None if scale is None else np.ascontiguousarray(scale, np.float32)
+        sh = None if shift is None else np.ascontiguousarray(shift, np.float32)
+        _ffi.check(_ffi.lib().isegmi_engine_set_conv(self._h, name.encode(), cout, r, s, cin, fp(w), fp(sc), fp(sh)))
+
+    def _load(self, sd):
+        sc, sh = fold_batchnorm(sd, "backbone.bn1")
+        self._set_conv("backbone.conv1", sd["backbone.conv1.weight"], sc, sh, pad_cin_to=4)
+        for li, nb in enumerate((3, 4, 6, 3)):
+            for b in range(nb):
+                nm = "backbone.layers.%d.%d" % (li, b)
+                for i in (1, 2, 3):
+                    sc, sh = fold_batchnorm(sd, "%s.bn%d" % (nm, i))
+                    self._set_conv("%s.conv%d" % (nm, i), sd["%s.conv%d.weight" % (nm, i)], sc, sh)
+                if b == 0:
+                    sc, sh = fold_batchnorm(sd, nm + ".downsample.1")
+                    self._set_conv(nm + ".downsample.0", sd[nm + ".downsample.0.weight"], sc, sh)
+        biased = ["fpn.lat_layers.%d" % i for i in range(3)] + ["fpn.pred_layers.%d" % i for i in range(3)] + \
+                 ["fpn.downsample_layers.%d" % i for i in range(2)] + ["proto_net.%d" % i for i in (0, 2, 4, 8, 10)] + \
+                 ["prediction_layers.0." + n for n in ("upfeature.0", "bbox_layer", "conf_layer", "mask_layer")]
+        for nm in biased:
+            self._set_conv(nm, sd[nm + ".weight"], None, sd[nm + ".bias"])
+        pri = [make_priors(s, s, sc_, self.cfg.max_size, self.cfg.pred_aspect_ratios)
+               for s, sc_ in zip(_level_sizes(self.size), self.cfg.pred_scales)]
+        self.priors = np.concatenate(pri, 0)
+        _ffi.check(_ffi.lib().isegmi_engine_set_tensor(self._h, b"priors", self.priors.ctypes.data_as(C.c_void_p),
+                                                       C.c_int64(self.priors.nbytes)))
+
+    def set_param(self, name, value):
+        _ffi.check(_ffi.lib().isegmi_engine_set_param(self._h, name.encode(), C.c_float(value)))
+
+    # -- execution -----------------------------------------------------------------------------
+    def upload(self, batch_nhwc3):
+        x = np.ascontiguousarray(batch_nhwc3, np.float32)
+        assert x.ndim == 4 and x.shape[1:] == (self.size, self.size, 3) and x.shape[0] <= self.max_batch, x.shape
+        _ffi.check(_ffi.lib().isegmi_h2d(self._d_in.ptr, x.ctypes.data_as(C.c_void_p), C.c_int64(x.nbytes)))
+        return x.shape[0]
+
+    def forward_device(self, n):
+        """Launch forward on the batch already resident in the engine's input buffer (asynchronous)."""
+        _ffi.check(_ffi.lib().isegmi_yolact_forward(self._h, self._d_in.ptr, n))
+
+    def postprocess_device(self, h, w):
+        _ffi.check(_ffi.lib().isegmi_yolact_postprocess(self._h, h, w))
+
+    def sync(self):
+        _ffi.check(_ffi.lib().isegmi_engine_sync(self._h))
+
+    def fetch(self, name, rows=None):
+        """D2H copy of a named engine buffer (optionally only its first `rows` leading rows)."""
+        p = C.c_void_p(); nb = C.c_int64(); dt = C.c_int32(); nd = C.c_int32(); shp = (C.c_int64 * 4)()
+        _ffi.check(_ffi.lib().isegmi_engine_buffer_info(self._h, name.encode(), C.byref(p), C.byref(nb), C.byref(dt), shp, C.byref(nd)))
+        dtype = [np.float32, np.int32, np.uint8, np.int64][dt.value]
+        shape = tuple(int(shp[i]) for i in range(nd.value))
+        if rows is not None:
+            shape = (rows,) + shape[1:]
+        out = np.empty(shape, dtype)
+        if out.nbytes:
+            _ffi.check(_ffi.lib().isegmi_d2h(out.ctypes.data_as(C.c_void_p), p, C.c_int64(out.nbytes)))
+        return out
+
+    def timings(self):
+        names = C.create_string_buffer(4096); ms = (C.c_float * 64)(); cnt = C.c_int()
+        _ffi.check(_ffi.lib().isegmi_engine_get_timings(self._h, names, 4096, ms, 64, C.byref(cnt)))
+        ns = names.value.decode().split(";") if cnt.value else []
+        return [(ns[i], float(ms[i])) for i in range(cnt.value)]
+
+    def __call__(self, batch_nhwc3):
+        """Upstream-shaped result: list (one per image) of {'detection': {...}|None, 'net': self}."""
+        n = self.upload(batch_nhwc3)
+        self.forward_device(n)
+        self.sync()
+        cnt = self.fetch("det.count", n)
+        box, score, cls, coeff, prior = (self.fetch(k, n) for k in ("det.box", "det.score", "det.class", "det.coeff", "det.prior"))
+        proto = self.fetch("proto", n)
+        out = []
+        for i in range(n):
+            c = int(cnt[i])
+            det = None if c == 0 else dict(box=box[i, :c], mask=coeff[i, :c], score=score[i, :c], proto=proto[i],
+                                           prior=prior[i, :c], **{"class": cls[i, :c]})
+            out.append({"detection": det, "net": self, "_index": i})
+        return out
+
+    def close(self):
+        if self._h:
+            _ffi.lib().isegmi_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def postprocess(det_output, w, h, batch_idx=0, score_threshold=0.0):
+    """Yolact layers/output_utils.postprocess (Y7): (classes, scores, boxes[int64 xyxy], masks[n,h,w] uint8).
+
+    Masks are produced on the GPU for the whole last batch at (h, w); `score_threshold` filters the
+    (score-sorted) detections afterwards, which is equivalent because the filter precedes all
+    arithmetic upstream and every detection's mask is independent."""
+    dets = det_output[batch_idx]
+    net = dets["net"]
+    if dets["detection"] is None:
+        z = np.zeros((0,), np.int32)
+        return z, np.zeros((0,), np.float32), np.zeros((0, 4), np.int64), np.zeros((0, h, w), np.uint8)
+    i = dets["_index"]
+    key = (h, w)
+    if getattr(net, "_pp_key", None) != key:
+        net.postprocess_device(h, w)
+        net.sync()
+        net._pp_key = key
+        net._pp_masks = net.fetch("det.masks")
+        net._pp_boxes = net.fetch("det.box_int")
+    d = dets["detection"]
+    keep = d["score"] > np.float32(score_threshold)
+    c = len(d["score"])
+    return d["class"][keep], d["score"][keep], net._pp_boxes[i, :c][keep], net._pp_masks[i, :c][keep]

@@ -1,0 +1,120 @@
+"""CPU oracle of the Yolact R50-FPN forward + Detect + postprocess (TEST INFRASTRUCTURE ONLY).
+
+numpy graph over the C oracle ops (oracle/ora_ops.c).  Follows SURVEY.md Appendix A.9 / A.1 /
+A.6 ([UPSTREAM-RECALL] of dbolya/yolact, the lineage the reference names at README.md:355; the
+reference's own Yolact.jittor sources are absent -> PARITY UNPINNED).  Takes the SAME upstream-
+named state dict (OIHW weights, BN running stats) as the product and folds BN itself.
+"""
+import math
+
+import numpy as np
+
+from . import ora
+
+
+def _krsc(w_oihw):
+    return np.ascontiguousarray(np.transpose(np.asarray(w_oihw, np.float32), (0, 2, 3, 1)))
+
+
+def _fold_bn(sd, prefix, eps=np.float32(1e-5)):
+    """BatchNorm2d eval (A.1): y = (x-mean)/sqrt(var+eps)*w + b  ==  x*scale + shift."""
+    w = sd[prefix + ".weight"].astype(np.float32); b = sd[prefix + ".bias"].astype(np.float32)
+    m = sd[prefix + ".running_mean"].astype(np.float32); v = sd[prefix + ".running_var"].astype(np.float32)
+    scale = (w / np.sqrt(v + eps)).astype(np.float32)
+    shift = (b - m * scale).astype(np.float32)
+    return scale, shift
+
+
+def make_priors(conv_h, conv_w, scale, max_size, ars=(1.0, 0.5, 2.0)):
+    """A.9 make_priors with use_pixel_scales, preapply_sqrt=False, use_square_anchors=True."""
+    out = []
+    for j in range(conv_h):
+        for i in range(conv_w):
+            x = (i + 0.5) / conv_w
+            y = (j + 0.5) / conv_h
+            for ar in ars:
+                ar = math.sqrt(ar)
+                w = scale * ar / max_size
+                h = w
+                out += [x, y, w, h]
+    return np.asarray(out, np.float64).astype(np.float32).reshape(-1, 4)
+
+
+class YolactRef:
+    def __init__(self, sd, max_size=550):
+        self.sd = sd
+        self.max_size = max_size
+        self.feats = {}
+
+    def _conv_bn(self, x, name, bn, stride, pad, act, residual=None):
+        sc, sh = _fold_bn(self.sd, bn)
+        return ora.conv2d(x, _krsc(self.sd[name + ".weight"]), stride, pad, sc, sh, residual, act)
+
+    def _conv_b(self, x, name, stride, pad, act, **kw):
+        return ora.conv2d(x, _krsc(self.sd[name + ".weight"]), stride, pad, None, self.sd[name + ".bias"], None, act, **kw)
+
+    def forward(self, images_nhwc3):
+        x = np.asarray(images_nhwc3, np.float32)
+        N = x.shape[0]
+        x4 = np.concatenate([x, np.zeros(x.shape[:3] + (1,), np.float32)], -1)
+        w1 = _krsc(self.sd["backbone.conv1.weight"])
+        w1 = np.concatenate([w1, np.zeros(w1.shape[:3] + (1,), np.float32)], -1)
+        sc, sh = _fold_bn(self.sd, "backbone.bn1")
+        x = ora.conv2d(x4, w1, 2, 3, sc, sh, None, 1)
+        x = ora.maxpool(x, 3, 2, 1)
+        outs = []
+        for li, nb in enumerate((3, 4, 6, 3)):
+            for b in range(nb):
+                nm = "backbone.layers.%d.%d" % (li, b)
+                st = 2 if (b == 0 and li > 0) else 1
+                idt = x
+                if b == 0:
+                    idt = self._conv_bn(x, nm + ".downsample.0", nm + ".downsample.1", st, 0, 0)
+                t = self._conv_bn(x, nm + ".conv1", nm + ".bn1", 1, 0, 1)
+                t = self._conv_bn(t, nm + ".conv2", nm + ".bn2", st, 1, 1)
+                x = self._conv_bn(t, nm + ".conv3", nm + ".bn3", 1, 0, 1, residual=idt)
+            outs.append(x)
+        C3, C4, C5 = outs[1], outs[2], outs[3]
+        l5 = self._conv_b(C5, "fpn.lat_layers.0", 1, 0, 0)
+        l4 = self._conv_b(C4, "fpn.lat_layers.1", 1, 0, 0)
+        l3 = self._conv_b(C3, "fpn.lat_layers.2", 1, 0, 0)
+        x4f = ora.resize_bilinear(l5, l4.shape[1], l4.shape[2], add=l4)
+        x3f = ora.resize_bilinear(x4f, l3.shape[1], l3.shape[2], add=l3)
+        P5 = self._conv_b(l5, "fpn.pred_layers.0", 1, 1, 1)
+        P4 = self._conv_b(x4f, "fpn.pred_layers.1", 1, 1, 1)
+        P3 = self._conv_b(x3f, "fpn.pred_layers.2", 1, 1, 1)
+        P6 = self._conv_b(P5, "fpn.downsample_layers.0", 2, 1, 0)
+        P7 = self._conv_b(P6, "fpn.downsample_layers.1", 2, 1, 0)
+        P = [P3, P4, P5, P6, P7]
+        t = self._conv_b(P3, "proto_net.0", 1, 1, 1)
+        t = self._conv_b(t, "proto_net.2", 1, 1, 1)
+        t = self._conv_b(t, "proto_net.4", 1, 1, 1)
+        t = ora.resize_bilinear(t, t.shape[1] * 2, t.shape[2] * 2, relu=1)
+        t = self._conv_b(t, "proto_net.8", 1, 1, 1)
+        proto = self._conv_b(t, "proto_net.10", 1, 0, 1)
+        locs, confs, masks, priors = [], [], [], []
+        scales = (24, 48, 96, 192, 384)
+        for l, p in enumerate(P):
+            u = self._conv_b(p, "prediction_layers.0.upfeature.0", 1, 1, 1)
+            locs.append(self._conv_b(u, "prediction_layers.0.bbox_layer", 1, 1, 0).reshape(N, -1, 4))
+            confs.append(self._conv_b(u, "prediction_layers.0.conf_layer", 1, 1, 0).reshape(N, -1, 81))
+            masks.append(self._conv_b(u, "prediction_layers.0.mask_layer", 1, 1, 2).reshape(N, -1, 32))
+            priors.append(make_priors(p.shape[1], p.shape[2], scales[l], self.max_size))
+        loc = np.concatenate(locs, 1); conf = np.concatenate(confs, 1); mask = np.concatenate(masks, 1)
+        priors = np.concatenate(priors, 0)
+        self.feats = dict(C3=C3, C4=C4, C5=C5, P3=P3, P4=P4, P5=P5, P6=P6, P7=P7, proto=proto, loc=loc, conf=conf,
+                          mask=mask, priors=priors)
+        dets = []
+        for n in range(N):
+            boxes = ora.yolact_decode(loc[n], priors)
+            d = ora.yolact_detect(ora.softmax(conf[n]), boxes, mask[n])
+            d["proto"] = proto[n]
+            dets.append(d)
+        return dets
+
+    @staticmethod
+    def postprocess(det, w, h, score_threshold=0.0):
+        keep = det["score"] > np.float32(score_threshold)
+        box, coeff = det["box"][keep], det["mask"][keep]
+        masks, ib = ora.yolact_masks(det["proto"], coeff, box, h, w)
+        return det["cls"][keep], det["score"][keep], ib, masks
