@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native RoI/mask inference hot path.
+
+`python bench.py --gpus N --steps K --warmup W`  (N>1: launched by torch.distributed.run, one rank per GPU).
+
+A "step" = one pass of the hot path over one batch of synthetic input that is already resident
+in HBM: Yolact R50-FPN 550x550, bs=8 per GPU (BASELINE.json configs[1]): backbone -> FPN ->
+protonet + prediction heads -> Detect (softmax, decode, fast-NMS) -> postprocess (mask assembly
+at 550x550, uint8) [-> RCCL all-gather of detection records when N>1].  `--model maskrcnn`
+switches to Mask R-CNN R50-FPN 1333x800 bs=2 (configs[2]) once that path is built.
+
+Prints ONE JSON line on rank 0 (contract in the task brief) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "instancesegmentation-jittor_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32-input MFMA peak (spec)
+YOLACT_GFLOP_PER_IMAGE = 118.28  # algorithmic conv work per 550x550 image
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
+    ap.add_argument("--model", default="yolact", choices=["yolact"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=4, help="images the CPU oracle is timed on")
+    ap.add_argument("--no-latency", action="store_true", help="skip the extra bs=1 latency pass")
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+
+    dist = None
+    if world > 1:
+        # torch.distributed is plumbing only (rendezvous, barrier, max-reduce of the wall time):
+        # CPU/gloo, so torch never touches the GPU.  The data-path collective is RCCL in libisegmi.
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    from isegmi import _ffi
+    from isegmi.dist import RcclGather, record_bytes
+    from isegmi.weights import yolact_state_dict
+    from isegmi.yolact import Yolact, fast_base_transform
+
+    if _ffi.device_count() < 1:
+        raise SystemExit("no HIP device visible: bench.py measures the HIP path only (no CPU fallback)")
+    sd = yolact_state_dict(1234)
+    net = Yolact(sd, max_batch=a.batch, device=local_rank)
+    size = net.size
+    rng = np.random.default_rng(20261003 + rank)
+    imgs = fast_base_transform(rng.uniform(0, 255, (a.batch, size, size, 3)).astype(np.float32))
+    net.upload(imgs)
+
+    gather = None
+    if world > 1:
+        import torch
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            uid = torch.frombuffer(bytearray(RcclGather.unique_id()), dtype=torch.uint8).clone()
+        dist.broadcast(uid, 0)
+        gather = RcclGather(rank, world, bytes(uid.numpy().tobytes()), record_bytes(a.batch))
+
+    def step():
+        net.forward_device(a.batch)
+        net.postprocess_device(size, size)
+        if gather is not None:
+            gather.gather_from(net)
+
+    def full_sync():
+        net.sync()
+        if gather is not None:
+            gather.wait()
+        _ffi.sync()
+
+    for _ in range(a.warmup):
+        step()
+    full_sync()
+    net.set_param("conv_timing", 1.0)
+    import ctypes as C
+    f, m, l = C.c_double(), C.c_double(), C.c_int64()
+    _ffi.check(_ffi.lib().isegmi_engine_conv_stats(net._h, C.byref(f), C.byref(m), C.byref(l)))  # reset
+
+    if dist is not None:
+        dist.barrier()
+    full_sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    full_sync()
+    if dist is not None:
+        dist.barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if dist is not None:
+        import torch
+        te = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+
+    _ffi.check(_ffi.lib().isegmi_engine_conv_stats(net._h, C.byref(f), C.byref(m), C.byref(l)))
+    net.set_param("conv_timing", 0.0)
+    conv_flops, conv_ms, conv_launches = f.value, m.value, l.value
+
+    counts = net.fetch("det.count", a.batch)
+    total_images = a.batch * world * a.steps
+    value = total_images / elapsed
+
+    out = None
+    if rank == 0:
+        achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        out = {
+            "metric": "images/sec (Yolact R50-FPN 550x550, bs=%d per GPU, fp32)" % a.batch,
+            "value": round(value, 2),
+            "unit": "img/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "Yolact R50-FPN 550x550 bs=%d/GPU random weights: backbone+FPN+protonet+heads+Detect(fast-NMS)+550x550 mask assembly (BASELINE configs[1])" % a.batch,
+                       "global_batch": a.batch * world, "parallelism": "batch-sharded x%d, RCCL all-gather of detections" % world,
+                       "detections_per_image_rank0": [int(c) for c in counts]},
+            "roofline": {
+                "bound": "mfma",
+                "kernel": "conv_mfma_kernel (all %d conv launches of a step, v_mfma_f32_32x32x2_f32)" % (conv_launches // max(a.steps, 1)),
+                "achieved": round(achieved, 2),
+                "peak": PEAK_F32_MFMA_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                "traffic": None,
+                "algorithmic_gflop_per_step": round(conv_flops / max(a.steps, 1) / 1e9, 2),
+                "conv_ms_per_step": round(conv_ms / max(a.steps, 1), 3),
+                "launches_per_step": conv_launches // max(a.steps, 1),
+                "avg_launch_us": round(conv_ms * 1e3 / max(conv_launches, 1), 2),
+            },
+            "p50_ms_per_image": round(elapsed / a.steps * 1e3 / a.batch, 3),
+        }
+
+    # ---- extra: bs=1 latency pass (metric also asks for bs=1 img/s and p50 per-image latency)
+    if rank == 0 and not a.no_latency:
+        lat = []
+        for i in range(13):
+            net.sync()
+            ts = time.perf_counter()
+            net.forward_device(1)
+            net.postprocess_device(size, size)
+            net.sync()
+            lat.append((time.perf_counter() - ts) * 1e3)
+        lat = sorted(lat[3:])
+        out["bs1"] = {"p50_ms_per_image": round(lat[len(lat) // 2], 3), "img_per_s": round(1e3 / lat[len(lat) // 2], 2)}
+        net.set_param("timing", 1.0)
+        net.forward_device(a.batch); net.postprocess_device(size, size); net.sync()
+        out["stage_ms_bs%d" % a.batch] = {k: round(v, 3) for k, v in net.timings()}
+        net.set_param("timing", 0.0)
+
+    # ---- CPU baseline: the oracle restatement on the host cores (rank 0, N=1 only)
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        from oracle.yolact_ref import YolactRef
+        ncpu = len(os.sched_getaffinity(0))
+        os.environ.setdefault("OMP_NUM_THREADS", str(ncpu))
+        ref = YolactRef(sd)
+        k = max(1, min(a.cpu_sample, a.batch))
+        tc = time.perf_counter()
+        dets = ref.forward(imgs[:k])
+        for d in dets:
+            YolactRef.postprocess(d, size, size)
+        tcpu = time.perf_counter() - tc
+        out["cpu_baseline"] = {"value": round(k / tcpu, 4), "unit": "img/s", "cores": ncpu, "kind": "port",
+                               "sample": "%d of the %d images of one batch, oracle/ (C+numpy restatement, AVX2 FMA + OpenMP), %.1f s" % (k, a.batch, tcpu)}
+        # the oracle run doubles as a parity check of this very batch
+        got = net.fetch("det.prior", a.batch)
+        ok = all(np.array_equal(got[i, : len(dets[i]["prior"])], dets[i]["prior"]) for i in range(k))
+        out["parity_vs_oracle_on_bench_batch"] = bool(ok)
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if gather is not None:
+        gather.close()
+    net.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

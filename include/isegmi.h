@@ -159,6 +159,26 @@ int isegmi_engine_buffer_info(isegmi_engine* e, const char* name, void** d_ptr, 
 int isegmi_engine_get_timings(isegmi_engine* e, char* names, int names_cap, float* ms, int ms_cap,
                               int* count);
 
+/* one contiguous record block of the last Yolact forward for the all-gather:
+ * [count i32 N][box f32 N*K*4][score f32 N*K][class i32 N*K][coeff f32 N*K*32]([proto f32 N*PH*PW*32]) */
+int isegmi_yolact_pack_records(isegmi_engine* e, void* d_dst, int64_t cap, int with_proto, int64_t* bytes);
+
+/* conv-kernel statistics since the last call (set_param "conv_timing" 1): algorithmic FLOPs, summed
+ * HIP-event time (ms) of the conv launches on the engine stream, launch count; resets them */
+int isegmi_engine_conv_stats(isegmi_engine* e, double* flops, double* ms, int64_t* launches);
+
+/* ---- multi-GPU: images shard by batch, one process per GPU; the only exchange is one
+ * RCCL all-gather of fixed-size records per batch (upstream analogue: the pickle all_gather of
+ * {image_id: BoxList} in maskrcnn-benchmark engine/inference.py, reached from README.md:344-347). */
+typedef struct isegmi_comm isegmi_comm;
+int isegmi_comm_unique_id(void* out128);                       /* rank 0; ship the 128 bytes to all ranks */
+int isegmi_comm_create(const void* uid128, int rank, int world, isegmi_comm** out);
+int isegmi_comm_destroy(isegmi_comm* c);
+/* d_recv holds world*bytes; ordered after work already queued on producer_stream; own stream */
+int isegmi_comm_allgather(isegmi_comm* c, const void* d_send, void* d_recv, int64_t bytes,
+                          void* producer_stream);
+int isegmi_comm_wait(isegmi_comm* c);
+
 #pragma GCC visibility pop
 #ifdef __cplusplus
 }

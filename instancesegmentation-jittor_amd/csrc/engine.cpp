@@ -39,6 +39,24 @@ static int find_conv(Engine& e, const std::string& layer, const ConvLayer** out)
     return ISEGMI_OK;
 }
 
+static int timed_conv(Engine& e, const isegmi_conv_desc* d, const float* in, const ConvLayer* L, const float* res, float* out) {
+    hipEvent_t a = nullptr, b = nullptr;
+    if (e.conv_timing) {
+        HIP_TRY(hipEventCreate(&a));
+        HIP_TRY(hipEventCreate(&b));
+        HIP_TRY(hipEventRecord(a, e.stream));
+    }
+    int rc = conv2d_launch(d, in, L->d_w, L->d_scale, L->d_shift, res, out, e.stream);
+    if (e.conv_timing) {
+        HIP_TRY(hipEventRecord(b, e.stream));
+        e.conv_evs.push_back({a, b});
+        const int Ho = (d->H + 2 * d->pad - d->R) / d->stride + 1, Wo = (d->W + 2 * d->pad - d->S) / d->stride + 1;
+        const int cin_true = (d->Cin == 4 && d->R == 7) ? 3 : d->Cin;
+        e.conv_flops_pending += 2.0 * d->N * Ho * Wo * (double)d->Cout * d->R * d->S * cin_true;
+    }
+    return rc;
+}
+
 int eng_conv_into(Engine& e, const std::string& layer, const Tensor& in, int stride, int pad, int act, float* dst, int out_div,
                   int64_t out_img_stride, int64_t out_pix_stride) {
     const ConvLayer* L;
@@ -50,7 +68,7 @@ int eng_conv_into(Engine& e, const std::string& layer, const Tensor& in, int str
     d.N = in.N; d.H = in.H; d.W = in.W; d.Cin = in.C; d.Cout = L->Cout; d.R = L->R; d.S = L->S; d.stride = stride; d.pad = pad;
     d.act = act; d.tile = (int)e.param("conv_tile", 0); d.out_div = out_div; d.out_img_stride = out_img_stride;
     d.out_pix_stride = out_pix_stride;
-    return conv2d_launch(&d, in.d, L->d_w, L->d_scale, L->d_shift, nullptr, dst, e.stream);
+    return timed_conv(e, &d, in.d, L, nullptr, dst);
 }
 
 int eng_conv(Engine& e, const std::string& layer, const Tensor& in, int stride, int pad, int act, const Tensor* residual,
@@ -66,7 +84,7 @@ int eng_conv(Engine& e, const std::string& layer, const Tensor& in, int stride, 
     memset(&d, 0, sizeof(d));
     d.N = in.N; d.H = in.H; d.W = in.W; d.Cin = in.C; d.Cout = L->Cout; d.R = L->R; d.S = L->S; d.stride = stride; d.pad = pad;
     d.act = act; d.tile = (int)e.param("conv_tile", 0);
-    return conv2d_launch(&d, in.d, L->d_w, L->d_scale, L->d_shift, residual ? residual->d : nullptr, out->d, e.stream);
+    return timed_conv(e, &d, in.d, L, residual ? residual->d : nullptr, out->d);
 }
 
 void eng_mark(Engine& e, const char* name) {
@@ -74,20 +92,31 @@ void eng_mark(Engine& e, const char* name) {
     StageTime s;
     s.name = name;
     if (hipEventCreate(&s.ev) != hipSuccess) return;
-    hipEventRecord(s.ev, e.stream);
+    (void)hipEventRecord(s.ev, e.stream);
     e.marks.push_back(s);
 }
 
 static void collect_times(Engine& e) {
+    for (auto& pr : e.conv_evs) {
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, pr.first, pr.second);
+        e.conv_ms += ms;
+        e.conv_launches += 1;
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
+    e.conv_evs.clear();
+    e.conv_flops += e.conv_flops_pending;
+    e.conv_flops_pending = 0;
     e.last_times.clear();
     if (!e.timing || e.marks.empty()) return;
-    hipEventSynchronize(e.marks.back().ev);
+    (void)hipEventSynchronize(e.marks.back().ev);
     for (size_t i = 1; i < e.marks.size(); ++i) {
         float ms = 0;
-        hipEventElapsedTime(&ms, e.marks[i - 1].ev, e.marks[i].ev);
+        (void)hipEventElapsedTime(&ms, e.marks[i - 1].ev, e.marks[i].ev);
         e.last_times.push_back({e.marks[i].name, ms});
     }
-    for (auto& m : e.marks) hipEventDestroy(m.ev);
+    for (auto& m : e.marks) (void)hipEventDestroy(m.ev);
     e.marks.clear();
 }
 
@@ -248,11 +277,11 @@ extern "C" int isegmi_engine_create(int model_kind, int max_batch, int H, int W,
 extern "C" int isegmi_engine_destroy(isegmi_engine* h) {
     if (!h) return ISEGMI_OK;
     Engine& e = h->e;
-    hipStreamSynchronize(e.stream);
-    for (auto& kv : e.convs) { hipFree(kv.second.d_w); if (kv.second.d_scale) hipFree(kv.second.d_scale); if (kv.second.d_shift) hipFree(kv.second.d_shift); }
-    for (auto& kv : e.tensors) hipFree(kv.second.d);
-    for (auto& kv : e.bufs) hipFree(kv.second.d);
-    hipStreamDestroy(e.stream);
+    (void)hipStreamSynchronize(e.stream);
+    for (auto& kv : e.convs) { (void)hipFree(kv.second.d_w); if (kv.second.d_scale) (void)hipFree(kv.second.d_scale); if (kv.second.d_shift) (void)hipFree(kv.second.d_shift); }
+    for (auto& kv : e.tensors) (void)hipFree(kv.second.d);
+    for (auto& kv : e.bufs) (void)hipFree(kv.second.d);
+    (void)hipStreamDestroy(e.stream);
     delete h;
     return ISEGMI_OK;
 }
@@ -261,6 +290,7 @@ extern "C" int isegmi_engine_set_param(isegmi_engine* h, const char* name, float
     ARG_CHECK(h && name, "null");
     h->e.params[name] = value;
     if (std::string(name) == "timing") h->e.timing = value != 0.0f;
+    if (std::string(name) == "conv_timing") h->e.conv_timing = value != 0.0f;
     return ISEGMI_OK;
 }
 
@@ -275,9 +305,9 @@ extern "C" int isegmi_engine_set_conv(isegmi_engine* h, const char* name, int Co
     std::vector<float> packed((size_t)nf);
     TRY(isegmi_pack_conv_weights(&d, h_w_krsc, packed.data()));
     ConvLayer& L = h->e.convs[name];
-    if (L.d_w) { hipFree(L.d_w); L.d_w = nullptr; }
-    if (L.d_scale) { hipFree(L.d_scale); L.d_scale = nullptr; }
-    if (L.d_shift) { hipFree(L.d_shift); L.d_shift = nullptr; }
+    if (L.d_w) { (void)hipFree(L.d_w); L.d_w = nullptr; }
+    if (L.d_scale) { (void)hipFree(L.d_scale); L.d_scale = nullptr; }
+    if (L.d_shift) { (void)hipFree(L.d_shift); L.d_shift = nullptr; }
     L.Cout = Cout; L.R = R; L.S = S; L.Cin = Cin;
     HIP_TRY(hipMalloc((void**)&L.d_w, (size_t)nf * 4));
     HIP_TRY(hipMemcpy(L.d_w, packed.data(), (size_t)nf * 4, hipMemcpyHostToDevice));
@@ -289,7 +319,7 @@ extern "C" int isegmi_engine_set_conv(isegmi_engine* h, const char* name, int Co
 extern "C" int isegmi_engine_set_tensor(isegmi_engine* h, const char* name, const void* h_data, int64_t bytes) {
     ARG_CHECK(h && name && h_data && bytes > 0, "args");
     RawBuf& b = h->e.tensors[name];
-    if (b.d) { hipFree(b.d); b.d = nullptr; }
+    if (b.d) { (void)hipFree(b.d); b.d = nullptr; }
     HIP_TRY(hipMalloc(&b.d, (size_t)bytes));
     HIP_TRY(hipMemcpy(b.d, h_data, (size_t)bytes, hipMemcpyHostToDevice));
     b.bytes = bytes;
@@ -352,5 +382,43 @@ extern "C" int isegmi_engine_get_timings(isegmi_engine* h, char* names, int name
     ARG_CHECK((int)s.size() + 1 <= names_cap, "names buffer too small");
     memcpy(names, s.c_str(), s.size() + 1);
     *count = c;
+    return ISEGMI_OK;
+}
+
+// Conv-kernel statistics accumulated over synchronised forwards since the last call (set_param
+// "conv_timing" 1): algorithmic FLOPs (2*M*Cout*R*S*Cin, stem Cin=3), summed HIP-event time of the
+// conv launches on the engine stream, and the number of launches.  Resets the accumulators.
+extern "C" int isegmi_engine_conv_stats(isegmi_engine* h, double* flops, double* ms, int64_t* launches) {
+    ARG_CHECK(h && flops && ms && launches, "null");
+    *flops = h->e.conv_flops; *ms = h->e.conv_ms; *launches = h->e.conv_launches;
+    h->e.conv_flops = 0; h->e.conv_ms = 0; h->e.conv_launches = 0;
+    return ISEGMI_OK;
+}
+
+// Packs the last forward's detections into ONE contiguous record block for the all-gather:
+//   [count i32 x N][box f32 x N*K*4][score f32 x N*K][class i32 x N*K][coeff f32 x N*K*32]
+// (+ [proto f32 x N*PH*PW*32] when with_proto).  D2D copies on the engine stream.
+extern "C" int isegmi_yolact_pack_records(isegmi_engine* h, void* d_dst, int64_t cap, int with_proto, int64_t* bytes) {
+    ARG_CHECK(h && d_dst && bytes, "null");
+    Engine& e = h->e;
+    const int N = e.last_N;
+    ARG_CHECK(N > 0, "pack before forward");
+    const int K = (int)e.param("max_num_detections", 100);
+    const char* names[5] = {"det.count", "det.box", "det.score", "det.class", "det.coeff"};
+    const int64_t sizes[5] = {(int64_t)N * 4, (int64_t)N * K * 16, (int64_t)N * K * 4, (int64_t)N * K * 4, (int64_t)N * K * 32 * 4};
+    int64_t off = 0;
+    for (int i = 0; i < 5; ++i) {
+        ARG_CHECK(off + sizes[i] <= cap, "record buffer too small");
+        HIP_TRY(hipMemcpyAsync((char*)d_dst + off, e.bufs[names[i]].d, (size_t)sizes[i], hipMemcpyDeviceToDevice, e.stream));
+        off += sizes[i];
+    }
+    if (with_proto) {
+        RawBuf& p = e.bufs["proto"];
+        const int64_t pb = (int64_t)N * p.shape[1] * p.shape[2] * p.shape[3] * 4;
+        ARG_CHECK(off + pb <= cap, "record buffer too small (proto)");
+        HIP_TRY(hipMemcpyAsync((char*)d_dst + off, p.d, (size_t)pb, hipMemcpyDeviceToDevice, e.stream));
+        off += pb;
+    }
+    *bytes = off;
     return ISEGMI_OK;
 }

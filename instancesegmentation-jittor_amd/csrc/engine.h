@@ -48,6 +48,11 @@ struct Engine {
     bool timing = false;
     std::vector<StageTime> marks;
     std::vector<std::pair<std::string, float>> last_times;
+    // per-conv-launch HIP-event timing (roofline measurement): accumulated until read
+    bool conv_timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> conv_evs;
+    double conv_flops_pending = 0, conv_flops = 0, conv_ms = 0;
+    int64_t conv_launches = 0;
 
     float param(const std::string& k, float def) const {
         auto it = params.find(k);
