@@ -181,8 +181,8 @@ def main():
     # ---- CPU baseline: the oracle restatement on the host cores (rank 0, N=1 only)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         from oracle.yolact_ref import YolactRef
-        ncpu = len(os.sched_getaffinity(0))
-        os.environ.setdefault("OMP_NUM_THREADS", str(ncpu))
+        ncpu = min(len(os.sched_getaffinity(0)), 16)  # the GPU box's CPU share for one GPU
+        os.environ["OMP_NUM_THREADS"] = str(ncpu)
         ref = YolactRef(sd)
         k = max(1, min(a.cpu_sample, a.batch))
         tc = time.perf_counter()

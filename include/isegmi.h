@@ -167,6 +167,9 @@ int isegmi_yolact_pack_records(isegmi_engine* e, void* d_dst, int64_t cap, int w
  * HIP-event time (ms) of the conv launches on the engine stream, launch count; resets them */
 int isegmi_engine_conv_stats(isegmi_engine* e, double* flops, double* ms, int64_t* launches);
 
+/* per-layer text report (label, GFLOP, ms, TFLOP/s per line) accumulated under conv_timing; clears it */
+int isegmi_engine_conv_report(isegmi_engine* e, char* buf, int cap);
+
 /* ---- multi-GPU: images shard by batch, one process per GPU; the only exchange is one
  * RCCL all-gather of fixed-size records per batch (upstream analogue: the pickle all_gather of
  * {image_id: BoxList} in maskrcnn-benchmark engine/inference.py, reached from README.md:344-347). */

@@ -35,6 +35,7 @@ struct ConvK {
     int N, H, W, Cin, Cout, R, S, stride, pad, Ho, Wo, M;
     int nchunks, cin_chunks;
     int64_t wrow;
+    unsigned in_bytes;
     int act, out_div, contiguous;
     int64_t out_img_stride, out_pix_stride;
     int mtiles, ntiles;
@@ -82,32 +83,40 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvK p) {
     }
     const float* wsrc = p.w + (int64_t)(n0 + lrow) * p.wrow + g * 8;
 
-    float4 ra[APASS][2], rb[BPASS][2];
+    // A is fetched with raw buffer loads: padding taps / rows past M use an out-of-range offset, for
+    // which the hardware returns 0 -- no branch, no select, and the loads stay in flight under the MFMAs.
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 ra[APASS][2];
+    u32x4 rb[BPASS][2];
     int kr = 0, ks = 0, kc = 0;  // (r, s, cin-chunk) of the NEXT chunk to load
 
     auto load_chunk = [&](int chunk) {
 #pragma unroll
         for (int j = 0; j < APASS; ++j) {
-            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
             if (STEM) {
                 const int hi = hi0[j] + chunk, wi = wi0[j] + 2 * g;
                 const bool okh = (unsigned)hi < (unsigned)p.H;
-                const float* src = p.in + ((int64_t)(nb[j] + hi) * p.W + wi) * 4;
-                ra[j][0] = (okh && (unsigned)wi < (unsigned)p.W) ? *(const float4*)src : z;
-                ra[j][1] = (okh && g < 3 && (unsigned)(wi + 1) < (unsigned)p.W) ? *(const float4*)(src + 4) : z;
+                const unsigned off = (unsigned)(((nb[j] + hi) * p.W + wi) * 16);
+                const unsigned o0 = (okh && (unsigned)wi < (unsigned)p.W) ? off : OOB;
+                const unsigned o1 = (okh && g < 3 && (unsigned)(wi + 1) < (unsigned)p.W) ? off + 16u : OOB;
+                ra[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, o0, 0, 0);
+                ra[j][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, o1, 0, 0);
             } else {
                 const int hi = hi0[j] + kr, wi = wi0[j] + ks;
                 const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-                const float* src = p.in + ((int64_t)(nb[j] + hi) * p.W + wi) * p.Cin + kc * 32 + g * 8;
-                ra[j][0] = ok ? *(const float4*)src : z;
-                ra[j][1] = ok ? *(const float4*)(src + 4) : z;
+                const unsigned off = ((unsigned)((nb[j] + hi) * p.W + wi) * (unsigned)p.Cin + (unsigned)(kc * 32 + g * 8)) * 4u;
+                const unsigned o0 = ok ? off : OOB;
+                ra[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, o0, 0, 0);
+                ra[j][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, ok ? off + 16u : OOB, 0, 0);
             }
         }
 #pragma unroll
         for (int j = 0; j < BPASS; ++j) {
             const float* src = wsrc + (int64_t)(64 * j) * p.wrow + chunk * 32;
-            rb[j][0] = *(const float4*)src;
-            rb[j][1] = *(const float4*)(src + 4);
+            rb[j][0] = *(const u32x4*)src;
+            rb[j][1] = *(const u32x4*)(src + 4);
         }
         if (!STEM) {
             if (++kc == p.cin_chunks) { kc = 0; if (++ks == p.S) { ks = 0; ++kr; } }
@@ -119,14 +128,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvK p) {
 #pragma unroll
         for (int j = 0; j < APASS; ++j) {
             float* d = As + (lrow + 64 * j) * LDS_ROW + g * 8;
-            *(float4*)d = make_float4(ra[j][0].x, ra[j][0].z, ra[j][1].x, ra[j][1].z);
-            *(float4*)(d + 4) = make_float4(ra[j][0].y, ra[j][0].w, ra[j][1].y, ra[j][1].w);
+            *(u32x4*)d = u32x4{ra[j][0].x, ra[j][0].z, ra[j][1].x, ra[j][1].z};
+            *(u32x4*)(d + 4) = u32x4{ra[j][0].y, ra[j][0].w, ra[j][1].y, ra[j][1].w};
         }
 #pragma unroll
         for (int j = 0; j < BPASS; ++j) {
             float* d = Bs + (lrow + 64 * j) * LDS_ROW + g * 8;
-            *(float4*)d = rb[j][0];
-            *(float4*)(d + 4) = rb[j][1];
+            *(u32x4*)d = rb[j][0];
+            *(u32x4*)(d + 4) = rb[j][1];
         }
     };
 
@@ -146,11 +155,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvK p) {
     store_chunk(0);
     __syncthreads();
 
-    int cur = 0;
-    for (int t = 0; t < p.nchunks; ++t) {
-        const bool more = (t + 1) < p.nchunks;
-        if (more) load_chunk(t + 1);
-        const float* sb = smem + cur * STAGE;
+    auto compute = [&](int stage) {
+        const float* sb = smem + stage * STAGE;
 #pragma unroll
         for (int gg = 0; gg < 4; ++gg) {
             float4 fa[TM], fb[TN];
@@ -168,10 +174,21 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvK p) {
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].w, fb[b].w, acc[a][b], 0, 0, 0);
                 }
         }
-        if (more) store_chunk(cur ^ 1);
+    };
+
+    // Steady state (last chunk peeled so the loop body is branch-free): issue chunk t+1's loads, run
+    // chunk t's 16*TM*TN MFMAs under them, then write t+1 to the other LDS stage; one barrier per chunk.
+    int cur = 0;
+    for (int t = 0; t + 1 < p.nchunks; ++t) {
+        load_chunk(t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(cur);
+        __builtin_amdgcn_sched_barrier(0);  // keep the LDS write (and its vmcnt wait) BELOW the MFMAs
+        store_chunk(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
+    compute(cur);
 
     // ---- epilogue: y = fmaf(acc, scale, shift) (+res) -> act -> NHWC store.
     // D layout: col (cout) = lane&31, row (pixel) = (e&3) + 8*(e>>2) + 4*(lane>>5).
@@ -256,6 +273,9 @@ int conv2d_launch(const isegmi_conv_desc* d, const float* in, const float* w, co
     k.nchunks = n_chunks(d);
     k.cin_chunks = is_stem(d) ? 1 : d->Cin / 32;
     k.wrow = (int64_t)k.nchunks * 32;
+    const int64_t in_bytes = (int64_t)d->N * d->H * d->W * d->Cin * 4;
+    ARG_CHECK(in_bytes < (1ll << 31), "conv input must be < 2 GiB (32-bit buffer offsets)");
+    k.in_bytes = (unsigned)in_bytes;
     k.act = d->act;
     k.out_div = d->out_div > 0 ? d->out_div : k.Ho * k.Wo;
     k.out_pix_stride = d->out_pix_stride > 0 ? d->out_pix_stride : d->Cout;

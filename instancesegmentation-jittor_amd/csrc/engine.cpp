@@ -39,7 +39,7 @@ static int find_conv(Engine& e, const std::string& layer, const ConvLayer** out)
     return ISEGMI_OK;
 }
 
-static int timed_conv(Engine& e, const isegmi_conv_desc* d, const float* in, const ConvLayer* L, const float* res, float* out) {
+static int timed_conv(Engine& e, const std::string& label, const isegmi_conv_desc* d, const float* in, const ConvLayer* L, const float* res, float* out) {
     hipEvent_t a = nullptr, b = nullptr;
     if (e.conv_timing) {
         HIP_TRY(hipEventCreate(&a));
@@ -52,7 +52,11 @@ static int timed_conv(Engine& e, const isegmi_conv_desc* d, const float* in, con
         e.conv_evs.push_back({a, b});
         const int Ho = (d->H + 2 * d->pad - d->R) / d->stride + 1, Wo = (d->W + 2 * d->pad - d->S) / d->stride + 1;
         const int cin_true = (d->Cin == 4 && d->R == 7) ? 3 : d->Cin;
-        e.conv_flops_pending += 2.0 * d->N * Ho * Wo * (double)d->Cout * d->R * d->S * cin_true;
+        const double fl = 2.0 * d->N * Ho * Wo * (double)d->Cout * d->R * d->S * cin_true;
+        e.conv_flops_pending += fl;
+        char geo[160];
+        snprintf(geo, sizeof(geo), "%s [M=%d K=%d Cout=%d %dx%d/%d]", label.c_str(), d->N * Ho * Wo, d->R * d->S * d->Cin, d->Cout, d->R, d->S, d->stride);
+        e.conv_ev_info.push_back({geo, fl});
     }
     return rc;
 }
@@ -68,7 +72,7 @@ int eng_conv_into(Engine& e, const std::string& layer, const Tensor& in, int str
     d.N = in.N; d.H = in.H; d.W = in.W; d.Cin = in.C; d.Cout = L->Cout; d.R = L->R; d.S = L->S; d.stride = stride; d.pad = pad;
     d.act = act; d.tile = (int)e.param("conv_tile", 0); d.out_div = out_div; d.out_img_stride = out_img_stride;
     d.out_pix_stride = out_pix_stride;
-    return timed_conv(e, &d, in.d, L, nullptr, dst);
+    return timed_conv(e, layer, &d, in.d, L, nullptr, dst);
 }
 
 int eng_conv(Engine& e, const std::string& layer, const Tensor& in, int stride, int pad, int act, const Tensor* residual,
@@ -84,7 +88,7 @@ int eng_conv(Engine& e, const std::string& layer, const Tensor& in, int stride, 
     memset(&d, 0, sizeof(d));
     d.N = in.N; d.H = in.H; d.W = in.W; d.Cin = in.C; d.Cout = L->Cout; d.R = L->R; d.S = L->S; d.stride = stride; d.pad = pad;
     d.act = act; d.tile = (int)e.param("conv_tile", 0);
-    return timed_conv(e, &d, in.d, L, residual ? residual->d : nullptr, out->d);
+    return timed_conv(e, layer, &d, in.d, L, residual ? residual->d : nullptr, out->d);
 }
 
 void eng_mark(Engine& e, const char* name) {
@@ -97,15 +101,20 @@ void eng_mark(Engine& e, const char* name) {
 }
 
 static void collect_times(Engine& e) {
-    for (auto& pr : e.conv_evs) {
+    for (size_t i = 0; i < e.conv_evs.size(); ++i) {
+        auto& pr = e.conv_evs[i];
         float ms = 0;
         (void)hipEventElapsedTime(&ms, pr.first, pr.second);
+        auto& acc = e.conv_layers[e.conv_ev_info[i].first];
+        acc.first += e.conv_ev_info[i].second;
+        acc.second += ms;
         e.conv_ms += ms;
         e.conv_launches += 1;
         (void)hipEventDestroy(pr.first);
         (void)hipEventDestroy(pr.second);
     }
     e.conv_evs.clear();
+    e.conv_ev_info.clear();
     e.conv_flops += e.conv_flops_pending;
     e.conv_flops_pending = 0;
     e.last_times.clear();
@@ -420,5 +429,21 @@ extern "C" int isegmi_yolact_pack_records(isegmi_engine* h, void* d_dst, int64_t
         off += pb;
     }
     *bytes = off;
+    return ISEGMI_OK;
+}
+
+// Text report "label\tGFLOP\tms\tTFLOP/s" per conv layer accumulated under conv_timing; clears it.
+extern "C" int isegmi_engine_conv_report(isegmi_engine* h, char* buf, int cap) {
+    ARG_CHECK(h && buf && cap > 0, "args");
+    std::string s;
+    for (auto& kv : h->e.conv_layers) {
+        char line[256];
+        snprintf(line, sizeof(line), "%s\t%.3f\t%.4f\t%.2f\n", kv.first.c_str(), kv.second.first / 1e9, kv.second.second,
+                 kv.second.second > 0 ? kv.second.first / (kv.second.second * 1e-3) / 1e12 : 0.0);
+        s += line;
+    }
+    h->e.conv_layers.clear();
+    ARG_CHECK((int)s.size() + 1 <= cap, "report buffer too small");
+    memcpy(buf, s.c_str(), s.size() + 1);
     return ISEGMI_OK;
 }
