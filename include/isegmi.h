@@ -130,6 +130,55 @@ int isegmi_op_yolact_masks(const float* d_proto, const float* d_coeffs, const fl
                            int w, float* d_ws_lo, uint8_t* d_out_masks, int64_t* d_out_boxes,
                            void* stream);
 
+/* ---- Mask R-CNN RoI ops (M6 M7 M9 M10 M11 M12; App. A.4-A.8; all reached from README.md:331) ---- */
+/* greedy NMS (A.6): `problems` independent sets of n <= 1024 boxes; visiting order (score desc, index
+ * asc); IoU with legacy +1 areas when plus_one; suppress on iou > thr (ge: >=).  d_keep [problems][n]
+ * receives ORIGINAL indices in score order, d_cnt [problems] the count (<= max_keep when max_keep > 0). */
+int isegmi_op_nms(const float* d_boxes, const float* d_scores, int problems, int n, float thr,
+                  int plus_one, int ge, int max_keep, int32_t* d_keep, int32_t* d_cnt, void* stream);
+/* LevelMapper + RoIAlign (A.7, legacy aligned=False).  d_feats: host array of nlevels device pointers
+ * (NHWC, level k_min first); rois [N][K][4] image coords; counts [N]; out [N*K][PH][PW][C] (rows past
+ * count zero-filled).  fixed_level >= 0 bypasses the LevelMapper.  d_out_level [N][K] optional. */
+int isegmi_op_roi_align(const float* const* d_feats, const int32_t* Hs, const int32_t* Ws,
+                        const float* scales, int nlevels, const float* d_rois, const int32_t* d_counts,
+                        int N, int K, int C, int PH, int PW, int sampling, int k_min, int fixed_level,
+                        float* d_out, int32_t* d_out_level, void* stream);
+/* PostProcessor.filter_results (A.5): softmax, per-class decode(10,10,5,5)+clip, score filter, NMS,
+ * kth-value cut to det_per_img.  Output order: class ascending, NMS order inside a class. */
+typedef struct isegmi_box_post_args {
+    int32_t N, R, ncls, det_per_img, cap, nms_ge;
+    float score_thresh, nms_thresh;
+    int64_t logits_stride, regr_stride;   /* floats between consecutive rois */
+    const float* d_logits;     /* [N*R] rows of ncls */
+    const float* d_regr;       /* [N*R] rows; class j deltas at 4j..4j+3 */
+    const float* d_props;      /* [N][R][4] */
+    const int32_t* d_prop_cnt; /* [N] */
+    const int32_t* d_image_hw; /* [N][2] unpadded (h, w) */
+    float* d_ws_prob;          /* [N][R][ncls] */
+    float* d_ws_cand_scores;   /* [N][ncls-1][R] */
+    float* d_ws_cand_boxes;    /* [N][ncls-1][R][4] */
+    int32_t* d_ws_kept_total;  /* [N] */
+    float* d_ws_top_vals;      /* [N][det_per_img] */
+    int32_t* d_ws_top_idx;     /* [N][det_per_img] */
+    int32_t* d_out_count;      /* [N] */
+    float* d_out_boxes;        /* [N][cap][4] */
+    float* d_out_scores;       /* [N][cap] */
+    int32_t* d_out_labels;     /* [N][cap] 1..ncls-1 (0 = empty) */
+} isegmi_box_post_args;
+int isegmi_op_box_postprocess(const isegmi_box_post_args* a, void* stream);
+/* mask predictor tail (A.8): out[r,p] = sigmoid(<feat[r,p,:], w[label_r,:]> + b[label_r]); label 0 -> zeros */
+int isegmi_op_mask_logits_select(const float* d_feat, int R, int HW, int C, const float* d_w,
+                                 const float* d_b, const int32_t* d_labels, float* d_out, void* stream);
+/* Masker(threshold, padding=1) paste (A.8): masks [N][K][M][M], boxes [N][K][4] -> u8 [N][K][im_h][im_w] */
+int isegmi_op_paste_masks(const float* d_masks, const float* d_boxes, const int32_t* d_counts, int N,
+                          int K, int M, int im_h, int im_w, float thr, uint8_t* d_out, void* stream);
+/* one RPN level (A.4) for N images: fused head [N][HW][A*5] (A logits then A*4 deltas per pixel) */
+int isegmi_op_rpn_level(const float* d_head, const float* d_anchors, const int32_t* d_image_hw, int N,
+                        int HW, int A, int pre_nms, int post_nms, float nms_thr, float min_size,
+                        int nms_ge, float* d_ws_prob, float* d_ws_tk_vals, int32_t* d_ws_tk_idx,
+                        int32_t* d_ws_tk_cnt, float* d_out_boxes, float* d_out_scores,
+                        int32_t* d_out_cnt, void* stream);
+
 /* ---- model engine ----
  * Replaces the model object the reference builds inside COCODemo(cfg, ...) (README.md:320-324)
  * and Yolact eval.py (README.md:243): weights are pushed per layer under their upstream
@@ -148,6 +197,13 @@ int isegmi_engine_set_tensor(isegmi_engine* e, const char* name, const void* h_d
 /* Yolact.forward (Y2-Y6): d_images NHWC3 fp32 [N][H][W][3] already normalised (Y1). Asynchronous
  * on the engine stream; results in buffers det.count/box/score/class/coeff/prior and proto. */
 int isegmi_yolact_forward(isegmi_engine* e, const float* d_images_nhwc3, int N);
+/* GeneralizedRCNN.forward (M2-M11): d_images NHWC3 fp32 [N][H][W][3], normalised and zero-padded to the
+ * engine's (H,W); h_image_hw [N][2] = unpadded (h,w).  Results: det.count/box/score/label [N][cap],
+ * det.mask28 [N][cap][28][28], proposals, rpn.* ... in named buffers. */
+int isegmi_maskrcnn_forward(isegmi_engine* e, const float* d_images_nhwc3, const int32_t* h_image_hw, int N);
+/* Masker paste of the last forward into (out_h,out_w) planes; boxes first scaled by h_ratios_wh [N][2] =
+ * (out_w/w_i, out_h/h_i) like BoxList.resize -> det.masks u8 [N][cap][out_h][out_w], det.box_resized */
+int isegmi_maskrcnn_paste(isegmi_engine* e, const float* h_ratios_wh, int out_h, int out_w);
 /* postprocess (Y7): masks of the last forward at (out_h,out_w) -> det.masks u8, det.box_int i64 */
 int isegmi_yolact_postprocess(isegmi_engine* e, int out_h, int out_w);
 int isegmi_engine_sync(isegmi_engine* e);

@@ -267,9 +267,6 @@ int yolact_postprocess(Engine& e, int h, int w) {
 
 using namespace isegmi;
 
-struct isegmi_engine {
-    Engine e;
-};
 
 extern "C" int isegmi_engine_create(int model_kind, int max_batch, int H, int W, isegmi_engine** out) {
     ARG_CHECK(out, "null out");

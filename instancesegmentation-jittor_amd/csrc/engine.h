@@ -76,6 +76,7 @@ void eng_mark(Engine& e, const char* name);
 int yolact_forward(Engine& e, const float* d_images, int N);
 int yolact_postprocess(Engine& e, int h, int w);
 int maskrcnn_forward(Engine& e, const float* d_images, const int32_t* h_image_hw, int N);
+int maskrcnn_paste(Engine& e, const float* h_ratios_wh, int out_h, int out_w);
 
 // kernels implemented in other translation units
 int conv2d_launch(const isegmi_conv_desc* d, const float* in, const float* w, const float* scale, const float* shift,
@@ -93,3 +94,7 @@ int yolact_masks_launch(const float* proto, const float* coeffs, const float* bo
                         int mask_dim, int K, int h, int w, float* ws_lo, uint8_t* out_masks, int64_t* out_boxes, hipStream_t st);
 
 }  // namespace isegmi
+
+struct isegmi_engine {
+    isegmi::Engine e;
+};

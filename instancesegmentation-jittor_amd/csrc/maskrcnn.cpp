@@ -1,0 +1,250 @@
+// maskrcnn.cpp -- Mask R-CNN R50/R101-FPN forward graph.
+//
+// GeneralizedRCNN: ResNet (stride in the first 1x1, FrozenBN folded by the host) -> FPN (nearest
+// top-down, no activation, P6 = P5[::2,::2]) -> RPN head (shared 3x3 + fused 1x1 cls|bbox) ->
+// per-level top-k/decode/clip/NMS -> per-image top-1000 -> RoIAlign 7x7 -> FC6/FC7/predictors ->
+// per-class NMS + kth-value cut -> RoIAlign 14x14 on detections -> 4x conv3x3 -> deconv2x2 (as four
+// strided 1x1 convolutions) -> class-selected 1x1 + sigmoid.  Reached from
+// COCODemo.run_on_opencv_image (README.md:331) and tools/test_net.py (README.md:344-347).
+#include <string.h>
+
+#include "engine.h"
+
+namespace isegmi {
+
+int nms_launch(const float*, const float*, int, int, float, int, int, int, int*, int*, hipStream_t);
+int rpn_sigmoid_launch(const float* head, int64_t total, int A, int CH, float* prob, hipStream_t st);
+int rpn_decode_nms_launch(const float* head, const float* anchors, const float* tk_vals, const int* tk_idx, const int* tk_cnt,
+                          const int* image_hw, int N, int HWA, int A, int CH, int pre_nms, int post_nms, float thr, float min_size,
+                          int ge, int level, int L, int post_cap, float* out_boxes, float* out_scores, int* out_cnt, hipStream_t st);
+int sum_counts_launch(const int* cnt, int N, int L, int* total, hipStream_t st);
+int gather_proposals_launch(const float* cand_boxes, const float* fin_vals, const int* fin_idx, const int* fin_cnt, int N,
+                            int cand_per_img, int K, float* props, float* prop_scores, int* prop_cnt, hipStream_t st);
+int roi_align_launch(const float* const* feats, const int* Hs, const int* Ws, const float* scales, int nlevels, const float* rois,
+                     const int* counts, int N, int K, int C, int PH, int PW, int g, int k_min, int fixed_level, float* out,
+                     int* out_level, hipStream_t st);
+int box_postprocess_launch(const isegmi_box_post_args* a, hipStream_t st);
+int mask_logits_select_launch(const float* feat, int R, int HW, int C, const float* w, const float* b, const int* labels, float* out,
+                              hipStream_t st);
+int paste_masks_launch(const float* masks, const float* boxes, const int* counts, int N, int K, int M, int im_h, int im_w, float thr,
+                       uint8_t* out, hipStream_t st);
+int scale_boxes_launch(const float* boxes, const float* ratios, int N, int K, float* out, hipStream_t st);
+
+#define TRY(x)               \
+    do {                     \
+        int _rc = (x);       \
+        if (_rc) return _rc; \
+    } while (0)
+
+static int need_tensor(Engine& e, const std::string& name, int64_t bytes, const RawBuf** out) {
+    auto it = e.tensors.find(name);
+    if (it == e.tensors.end()) { set_error("tensor not set: " + name); return ISEGMI_ERR_STATE; }
+    if (bytes > 0 && it->second.bytes != bytes) { set_error("tensor " + name + " has the wrong size"); return ISEGMI_ERR_STATE; }
+    *out = &it->second;
+    return ISEGMI_OK;
+}
+
+int maskrcnn_forward(Engine& e, const float* d_images, const int32_t* h_image_hw, int N) {
+    const int H = e.H, W = e.W;
+    if (H % 32 || W % 32) { set_error("Mask R-CNN input must be padded to a multiple of 32"); return ISEGMI_ERR_ARG; }
+    hipStream_t st = e.stream;
+    eng_mark(e, "start");
+    void* p;
+    TRY(eng_buf(e, "image_hw", (int64_t)N * 8, &p, 1, {N, 2}));
+    int* d_hw = (int*)p;
+    HIP_TRY(hipMemcpyAsync(d_hw, h_image_hw, (size_t)N * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));  // h_image_hw is caller memory: do not keep reading it after return
+
+    Tensor x4, s, x;
+    TRY(eng_act(e, "input4", N, H, W, 4, &x4));
+    TRY(pad_c3_c4_launch(d_images, (int64_t)N * H * W, x4.d, st));
+    TRY(eng_conv(e, "backbone.body.stem.conv1", x4, 2, 3, 1, nullptr, "stem", &s));
+    {
+        const int Ho = (s.H + 2 - 3) / 2 + 1, Wo = (s.W + 2 - 3) / 2 + 1;
+        TRY(eng_act(e, "pool", N, Ho, Wo, s.C, &x));
+        TRY(maxpool_launch(s.d, N, s.H, s.W, s.C, 3, 2, 1, x.d, st));
+    }
+    eng_mark(e, "stem");
+    const int depth = (int)e.param("resnet_depth", 50);
+    const int blocks[4] = {3, 4, depth == 101 ? 23 : 6, 3};
+    Tensor C[4];
+    for (int li = 0; li < 4; ++li) {
+        for (int b = 0; b < blocks[li]; ++b) {
+            const std::string nm = "backbone.body.layer" + std::to_string(li + 1) + "." + std::to_string(b);
+            const int sd = (b == 0 && li > 0) ? 2 : 1;
+            Tensor idt = x, t1, t2, y;
+            if (b == 0) TRY(eng_conv(e, nm + ".downsample.0", x, sd, 0, 0, nullptr, nm + ".ds", &idt));
+            TRY(eng_conv(e, nm + ".conv1", x, sd, 0, 1, nullptr, nm + ".t1", &t1));  // STRIDE_IN_1X1
+            TRY(eng_conv(e, nm + ".conv2", t1, 1, 1, 1, nullptr, nm + ".t2", &t2));
+            TRY(eng_conv(e, nm + ".conv3", t2, 1, 0, 1, &idt, nm + ".out", &y));
+            x = y;
+        }
+        C[li] = x;
+        eng_mark(e, li == 0 ? "res2" : li == 1 ? "res3" : li == 2 ? "res4" : "res5");
+    }
+    // ---- FPN
+    Tensor P[5], last, lat;
+    TRY(eng_conv(e, "backbone.fpn.fpn_inner4", C[3], 1, 0, 0, nullptr, "fpn.last4", &last));
+    TRY(eng_conv(e, "backbone.fpn.fpn_layer4", last, 1, 1, 0, nullptr, "P5", &P[3]));
+    for (int l = 2; l >= 0; --l) {
+        const std::string ls = std::to_string(l + 1);
+        TRY(eng_conv(e, "backbone.fpn.fpn_inner" + ls, C[l], 1, 0, 0, nullptr, "fpn.lat" + ls, &lat));
+        Tensor nl;
+        TRY(eng_act(e, "fpn.last" + ls, N, lat.H, lat.W, lat.C, &nl));
+        TRY(nearest2x_add_launch(last.d, N, last.H, last.W, last.C, lat.d, lat.H, lat.W, nl.d, st));
+        last = nl;
+        TRY(eng_conv(e, "backbone.fpn.fpn_layer" + ls, last, 1, 1, 0, nullptr, "P" + std::to_string(l + 2), &P[l]));
+    }
+    {
+        const int Ho = (P[3].H - 1) / 2 + 1, Wo = (P[3].W - 1) / 2 + 1;
+        TRY(eng_act(e, "P6", N, Ho, Wo, P[3].C, &P[4]));
+        TRY(maxpool_launch(P[3].d, N, P[3].H, P[3].W, P[3].C, 1, 2, 0, P[4].d, st));
+    }
+    eng_mark(e, "fpn");
+
+    // ---- RPN
+    const int A = 3, CH = 15, L = 5;
+    const int pre_nms = (int)e.param("rpn_pre_nms_top_n", 1000), post_nms = (int)e.param("rpn_post_nms_top_n", 1000);
+    const int fpn_post = (int)e.param("rpn_fpn_post_nms_top_n", 1000);
+    const float rpn_thr = e.param("rpn_nms_thresh", 0.7f), rpn_min = e.param("rpn_min_size", 0.0f);
+    const int ge = (int)e.param("nms_ge", 0);
+    if (pre_nms > 1024 || post_nms > 1024 || fpn_post > 1024) { set_error("RPN top-n values above 1024 are not supported"); return ISEGMI_ERR_ARG; }
+    float *cand_boxes, *cand_scores;
+    int *cand_cnt, *cand_total;
+    TRY(eng_buf(e, "rpn.cand_boxes", (int64_t)N * L * post_nms * 16, &p, 0, {N, L * post_nms, 4})); cand_boxes = (float*)p;
+    TRY(eng_buf(e, "rpn.cand_scores", (int64_t)N * L * post_nms * 4, &p, 0, {N, L * post_nms})); cand_scores = (float*)p;
+    TRY(eng_buf(e, "rpn.cand_cnt", (int64_t)N * L * 4, &p, 1, {N, L})); cand_cnt = (int*)p;
+    TRY(eng_buf(e, "rpn.cand_total", (int64_t)N * 4, &p, 1, {N})); cand_total = (int*)p;
+    for (int l = 0; l < L; ++l) {
+        const std::string ls = std::to_string(l);
+        Tensor t, head;
+        TRY(eng_conv(e, "rpn.head.conv", P[l], 1, 1, 1, nullptr, "rpn.t" + ls, &t));
+        TRY(eng_conv(e, "rpn.head.cls_bbox", t, 1, 0, 0, nullptr, "rpn.head" + ls, &head));
+        const int HW = head.H * head.W, HWA = HW * A;
+        const RawBuf* anc;
+        TRY(need_tensor(e, "anchors." + ls, (int64_t)HWA * 16, &anc));
+        float *prob, *tkv;
+        int *tki, *tkc;
+        TRY(eng_buf(e, "rpn.prob" + ls, (int64_t)N * HWA * 4, &p)); prob = (float*)p;
+        TRY(eng_buf(e, "rpn.tk_vals" + ls, (int64_t)N * pre_nms * 4, &p)); tkv = (float*)p;
+        TRY(eng_buf(e, "rpn.tk_idx" + ls, (int64_t)N * pre_nms * 4, &p, 1)); tki = (int*)p;
+        TRY(eng_buf(e, "rpn.tk_cnt" + ls, (int64_t)N * 4, &p, 1)); tkc = (int*)p;
+        TRY(rpn_sigmoid_launch(head.d, (int64_t)N * HWA, A, CH, prob, st));
+        TRY(topk_launch(prob, HWA, N, HWA, pre_nms, nullptr, 1, tkv, tki, tkc, st));
+        TRY(rpn_decode_nms_launch(head.d, (const float*)anc->d, tkv, tki, tkc, d_hw, N, HWA, A, CH, pre_nms, post_nms, rpn_thr, rpn_min,
+                                  ge, l, L, post_nms, cand_boxes, cand_scores, cand_cnt, st));
+    }
+    TRY(sum_counts_launch(cand_cnt, N, L, cand_total, st));
+    float *fin_vals, *props, *prop_scores;
+    int *fin_idx, *fin_cnt, *prop_cnt;
+    const int R = fpn_post;
+    TRY(eng_buf(e, "rpn.fin_vals", (int64_t)N * R * 4, &p)); fin_vals = (float*)p;
+    TRY(eng_buf(e, "rpn.fin_idx", (int64_t)N * R * 4, &p, 1)); fin_idx = (int*)p;
+    TRY(eng_buf(e, "rpn.fin_cnt", (int64_t)N * 4, &p, 1)); fin_cnt = (int*)p;
+    TRY(eng_buf(e, "proposals", (int64_t)N * R * 16, &p, 0, {N, R, 4})); props = (float*)p;
+    TRY(eng_buf(e, "proposal_scores", (int64_t)N * R * 4, &p, 0, {N, R})); prop_scores = (float*)p;
+    TRY(eng_buf(e, "proposal_count", (int64_t)N * 4, &p, 1, {N})); prop_cnt = (int*)p;
+    TRY(topk_launch(cand_scores, (int64_t)L * post_nms, N, L * post_nms, R, cand_total, 1, fin_vals, fin_idx, fin_cnt, st));
+    TRY(gather_proposals_launch(cand_boxes, fin_vals, fin_idx, fin_cnt, N, L * post_nms, R, props, prop_scores, prop_cnt, st));
+    eng_mark(e, "rpn");
+
+    // ---- box head
+    const float* feats[4] = {P[0].d, P[1].d, P[2].d, P[3].d};
+    const int Hs[4] = {P[0].H, P[1].H, P[2].H, P[3].H}, Ws[4] = {P[0].W, P[1].W, P[2].W, P[3].W};
+    const float scales[4] = {0.25f, 0.125f, 0.0625f, 0.03125f};
+    Tensor roi7, f6, f7, cb;
+    TRY(eng_act(e, "box.roi_feat", N * R, 7, 7, 256, &roi7));
+    TRY(roi_align_launch(feats, Hs, Ws, scales, 4, props, prop_cnt, N, R, 256, 7, 7, 2, 2, -1, roi7.d, nullptr, st));
+    TRY(eng_conv(e, "roi_heads.box.feature_extractor.fc6", roi7, 1, 0, 1, nullptr, "box.fc6", &f6));
+    TRY(eng_conv(e, "roi_heads.box.feature_extractor.fc7", f6, 1, 0, 1, nullptr, "box.fc7", &f7));
+    TRY(eng_conv(e, "roi_heads.box.predictor.cls_bbox", f7, 1, 0, 0, nullptr, "box.cls_bbox", &cb));
+    const int ncls = 81, cap = (int)e.param("detections_per_img", 100), dpi = cap;
+    if (cb.C != ncls * 5) { set_error("cls_bbox layer must have 81+324 outputs"); return ISEGMI_ERR_STATE; }
+    isegmi_box_post_args a;
+    memset(&a, 0, sizeof(a));
+    a.N = N; a.R = R; a.ncls = ncls; a.det_per_img = dpi; a.cap = cap; a.nms_ge = ge;
+    a.score_thresh = e.param("roi_score_thresh", 0.05f);
+    a.nms_thresh = e.param("roi_nms_thresh", 0.5f);
+    a.logits_stride = cb.C; a.regr_stride = cb.C;
+    a.d_logits = cb.d; a.d_regr = cb.d + ncls; a.d_props = props; a.d_prop_cnt = prop_cnt; a.d_image_hw = d_hw;
+    TRY(eng_buf(e, "box.prob", (int64_t)N * R * ncls * 4, &p, 0, {N, R, ncls})); a.d_ws_prob = (float*)p;
+    TRY(eng_buf(e, "box.cand_scores", (int64_t)N * (ncls - 1) * R * 4, &p)); a.d_ws_cand_scores = (float*)p;
+    TRY(eng_buf(e, "box.cand_boxes", (int64_t)N * (ncls - 1) * R * 16, &p)); a.d_ws_cand_boxes = (float*)p;
+    TRY(eng_buf(e, "box.kept_total", (int64_t)N * 4, &p, 1, {N})); a.d_ws_kept_total = (int*)p;
+    TRY(eng_buf(e, "box.top_vals", (int64_t)N * dpi * 4, &p)); a.d_ws_top_vals = (float*)p;
+    TRY(eng_buf(e, "box.top_idx", (int64_t)N * dpi * 4, &p, 1)); a.d_ws_top_idx = (int*)p;
+    TRY(eng_buf(e, "det.count", (int64_t)N * 4, &p, 1, {N})); a.d_out_count = (int*)p;
+    TRY(eng_buf(e, "det.box", (int64_t)N * cap * 16, &p, 0, {N, cap, 4})); a.d_out_boxes = (float*)p;
+    TRY(eng_buf(e, "det.score", (int64_t)N * cap * 4, &p, 0, {N, cap})); a.d_out_scores = (float*)p;
+    TRY(eng_buf(e, "det.label", (int64_t)N * cap * 4, &p, 1, {N, cap})); a.d_out_labels = (int*)p;
+    TRY(box_postprocess_launch(&a, st));
+    eng_mark(e, "box_head");
+
+    // ---- mask head
+    Tensor m;
+    TRY(eng_act(e, "mask.roi_feat", N * cap, 14, 14, 256, &m));
+    TRY(roi_align_launch(feats, Hs, Ws, scales, 4, a.d_out_boxes, a.d_out_count, N, cap, 256, 14, 14, 2, 2, -1, m.d, nullptr, st));
+    for (int i = 1; i <= 4; ++i) {
+        Tensor o;
+        TRY(eng_conv(e, "roi_heads.mask.feature_extractor.mask_fcn" + std::to_string(i), m, 1, 1, 1, nullptr, "mask.fcn" + std::to_string(i), &o));
+        m = o;
+    }
+    Tensor up;
+    TRY(eng_act(e, "mask.deconv", N * cap, 28, 28, 256, &up));
+    {
+        // ConvTranspose2d(2,2,s2): out[r, 2i+a, 2j+b, :] = W_ab * in[r, i, j, :] + bias  -> four strided 1x1 convs.
+        Tensor rows;  // view: (r, i) as "images" of 1 x 14 pixels
+        rows.d = m.d; rows.N = N * cap * 14; rows.H = 1; rows.W = 14; rows.C = 256;
+        for (int ab = 0; ab < 4; ++ab) {
+            const int aa = ab >> 1, bb = ab & 1;
+            TRY(eng_conv_into(e, "roi_heads.mask.predictor.conv5_mask." + std::to_string(ab), rows, 1, 0, 1,
+                              up.d + (int64_t)(aa * 28 + bb) * 256, 14, (int64_t)2 * 28 * 256, 2 * 256));
+        }
+    }
+    const RawBuf *lw, *lb;
+    TRY(need_tensor(e, "mask_logits.w", (int64_t)ncls * 256 * 4, &lw));
+    TRY(need_tensor(e, "mask_logits.b", (int64_t)ncls * 4, &lb));
+    TRY(eng_buf(e, "det.mask28", (int64_t)N * cap * 784 * 4, &p, 0, {N, cap, 28, 28}));
+    TRY(mask_logits_select_launch(up.d, N * cap, 784, 256, (const float*)lw->d, (const float*)lb->d, a.d_out_labels, (float*)p, st));
+    eng_mark(e, "mask_head");
+    e.last_N = N;
+    return ISEGMI_OK;
+}
+
+int maskrcnn_paste(Engine& e, const float* h_ratios_wh, int out_h, int out_w) {
+    const int N = e.last_N;
+    if (N <= 0) { set_error("paste before forward"); return ISEGMI_ERR_STATE; }
+    const int cap = (int)e.param("detections_per_img", 100);
+    void *p, *rb, *rt;
+    TRY(eng_buf(e, "ws.ratios", (int64_t)N * 8, &rt));
+    HIP_TRY(hipMemcpyAsync(rt, h_ratios_wh, (size_t)N * 8, hipMemcpyHostToDevice, e.stream));
+    HIP_TRY(hipStreamSynchronize(e.stream));
+    TRY(eng_buf(e, "det.box_resized", (int64_t)N * cap * 16, &rb, 0, {N, cap, 4}));
+    TRY(scale_boxes_launch((const float*)e.bufs["det.box"].d, (const float*)rt, N, cap, (float*)rb, e.stream));
+    TRY(eng_buf(e, "det.masks", (int64_t)N * cap * out_h * out_w, &p, 2, {N, cap, out_h, out_w}));
+    TRY(paste_masks_launch((const float*)e.bufs["det.mask28"].d, (const float*)rb, (const int*)e.bufs["det.count"].d, N, cap, 28, out_h,
+                           out_w, e.param("mask_threshold", 0.5f), (uint8_t*)p, e.stream));
+    eng_mark(e, "paste");
+    return ISEGMI_OK;
+}
+
+}  // namespace isegmi
+
+using namespace isegmi;
+
+extern "C" int isegmi_maskrcnn_forward(isegmi_engine* h, const float* d_images, const int32_t* h_image_hw, int N) {
+    ARG_CHECK(h && d_images && h_image_hw, "null");
+    ARG_CHECK(h->e.kind == 2, "engine is not a Mask R-CNN engine");
+    ARG_CHECK(N > 0 && N <= h->e.max_batch, "batch size");
+    for (int i = 0; i < N; ++i)
+        ARG_CHECK(h_image_hw[2 * i] > 0 && h_image_hw[2 * i] <= h->e.H && h_image_hw[2 * i + 1] > 0 && h_image_hw[2 * i + 1] <= h->e.W,
+                  "image_hw must fit inside the padded input");
+    return maskrcnn_forward(h->e, d_images, h_image_hw, N);
+}
+
+// h_ratios_wh [N][2] = (out_w / w_i, out_h / h_i) as float, computed by the host like BoxList.resize
+extern "C" int isegmi_maskrcnn_paste(isegmi_engine* h, const float* h_ratios_wh, int out_h, int out_w) {
+    ARG_CHECK(h && h_ratios_wh && out_h > 0 && out_w > 0, "paste args");
+    ARG_CHECK(h->e.kind == 2, "engine is not a Mask R-CNN engine");
+    return maskrcnn_paste(h->e, h_ratios_wh, out_h, out_w);
+}

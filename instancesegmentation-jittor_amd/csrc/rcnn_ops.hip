@@ -1,0 +1,684 @@
+// rcnn_ops.hip -- Mask R-CNN RoI / selection kernels (App. A.4-A.8).
+//
+//   rpn_sigmoid        : fused RPN head output [N][HW][A*5] -> objectness probabilities [N][HW*A]
+//   rpn_decode_nms     : per (image, level): decode(1,1,1,1) + clip + min-size + greedy NMS on the
+//                        score-sorted top-k; wavefront-64 ballots resolve each 64-box chunk
+//   gather_proposals   : per-image top post_nms over all levels -> proposals
+//   roi_align          : LevelMapper + legacy RoIAlign (aligned=False, sampling 2), NHWC gather
+//   softmax_rows       : class probabilities
+//   box_cls_nms        : per (image, class): score filter (proposal order) -> bitonic sort ->
+//                        decode(10,10,5,5) + clip -> greedy NMS
+//   finalize_dets      : kth-value cut to detections_per_img, order preserved
+//   mask_logits_select : 1x1 conv to the detection's own class + sigmoid
+//   paste_masks        : Masker(threshold, padding=1) into the image plane
+// All arithmetic follows oracle/ora_ops.c operation for operation (bit-exact contract).
+// Reference anchor: COCODemo.run_on_opencv_image (README.md:331) reaches every one of these.
+#include "../../include/isegmi.h"
+#include "common.h"
+#include "detmath.h"
+
+namespace isegmi {
+
+__device__ __forceinline__ unsigned f2ord_(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f_(unsigned o) {
+    const unsigned u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    return __uint_as_float(u);
+}
+
+// ------------------------------------------------------------------ box coder
+__device__ __forceinline__ float4 decode_box(const float4 a, const float4 d, float wx, float wy, float ww, float wh) {
+    const float clipv = 4.135166556742356f;
+    const float widths = a.z - a.x + 1.0f, heights = a.w - a.y + 1.0f;
+    const float ctr_x = a.x + 0.5f * widths, ctr_y = a.y + 0.5f * heights;
+    const float dx = dm_div(d.x, wx), dy = dm_div(d.y, wy);
+    float dw = dm_div(d.z, ww), dh = dm_div(d.w, wh);
+    dw = dw < clipv ? dw : clipv;
+    dh = dh < clipv ? dh : clipv;
+    const float pcx = dx * widths + ctr_x, pcy = dy * heights + ctr_y;
+    const float pw = dm_exp(dw) * widths, ph = dm_exp(dh) * heights;
+    float4 o;
+    o.x = pcx - 0.5f * pw;
+    o.y = pcy - 0.5f * ph;
+    o.z = pcx + 0.5f * pw - 1.0f;
+    o.w = pcy + 0.5f * ph - 1.0f;
+    return o;
+}
+__device__ __forceinline__ float clampf(float v, float hi) { return v < 0.0f ? 0.0f : (v > hi ? hi : v); }
+__device__ __forceinline__ float4 clip_box(float4 b, float im_w, float im_h) {
+    const float mx = im_w - 1.0f, my = im_h - 1.0f;
+    b.x = clampf(b.x, mx); b.y = clampf(b.y, my); b.z = clampf(b.z, mx); b.w = clampf(b.w, my);
+    return b;
+}
+__device__ __forceinline__ float iou_one(const float4 a, const float4 b, float one) {
+    const float aa = (a.z - a.x + one) * (a.w - a.y + one);
+    const float ab = (b.z - b.x + one) * (b.w - b.y + one);
+    const float xx1 = a.x > b.x ? a.x : b.x, yy1 = a.y > b.y ? a.y : b.y;
+    const float xx2 = a.z < b.z ? a.z : b.z, yy2 = a.w < b.w ? a.w : b.w;
+    float w = xx2 - xx1 + one, h = yy2 - yy1 + one;
+    w = w > 0.0f ? w : 0.0f;
+    h = h > 0.0f ? h : 0.0f;
+    const float inter = w * h;
+    return dm_div(inter, aa + ab - inter);
+}
+
+// ------------------------------------------------------------------ greedy NMS core (block = 256 threads)
+// sb[0..n) boxes in visiting order (score desc, index asc); pre_dead[i] != 0 marks boxes removed beforehand.
+// Writes kept positions (indices into sb) to kept[] in visiting order; returns the count (<= max_keep).
+// Chunk of 64: (1) 4 waves test the chunk against the kept list; (2) wave 0 resolves the chunk with one
+// ballot per surviving box.
+constexpr int NMS_CAP = 1024;
+struct NmsShared {
+    float4 sb[NMS_CAP];
+    unsigned short kept[NMS_CAP];
+    unsigned long long supp[4];
+    int kc;
+};
+__device__ int nms_block(NmsShared& S, int n, float thr, float one, int ge, int max_keep, const unsigned char* pre_dead) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) S.kc = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const int kc = S.kc;
+        if (max_keep > 0 && kc >= max_keep) break;
+        const int i = c0 + lane;
+        const bool valid = i < n;
+        const float4 mine = S.sb[valid ? i : 0];
+        bool sup = false;
+        for (int j = wave; j < kc; j += 4) {
+            const float o = iou_one(S.sb[S.kept[j]], mine, one);
+            sup = sup || (ge ? (o >= thr) : (o > thr));
+        }
+        const unsigned long long sm = __ballot(sup);
+        if (lane == 0) S.supp[wave] = sm;
+        __syncthreads();
+        if (wave == 0) {
+            unsigned long long alive = __ballot(valid && !(pre_dead && pre_dead[i]));
+            alive &= ~(S.supp[0] | S.supp[1] | S.supp[2] | S.supp[3]);
+            unsigned long long keepm = 0ull;
+            int cnt = kc;
+            for (int b = 0; b < 64; ++b) {
+                if (!((alive >> b) & 1ull)) continue;     // wave-uniform
+                keepm |= 1ull << b;
+                ++cnt;
+                if (max_keep > 0 && cnt >= max_keep) break;
+                const float o = iou_one(S.sb[c0 + b], mine, one);
+                const unsigned long long m = __ballot(ge ? (o >= thr) : (o > thr));
+                const unsigned long long later = b == 63 ? 0ull : (~0ull << (b + 1));
+                alive &= ~(m & later);
+            }
+            if ((keepm >> lane) & 1ull) {
+                const int pos = kc + __popcll(keepm & ((1ull << lane) - 1ull));
+                S.kept[pos] = (unsigned short)i;
+            }
+            if (lane == 0) S.kc = kc + __popcll(keepm);
+        }
+        __syncthreads();
+    }
+    return S.kc;
+}
+
+// Generic op: one problem per block; boxes pre-sorted by the caller? No: sorts here (n <= 1024).
+// keys: (score desc, idx asc) bitonic in LDS.
+__device__ void sort_desc_1024(unsigned long long* keys, int npow2) {
+    for (int size = 2; size <= npow2; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = threadIdx.x; t < npow2 / 2; t += blockDim.x) {
+                const int lo = ((t / stride) * stride * 2) + (t % stride), hi = lo + stride;
+                const bool desc = ((lo & size) == 0);
+                const unsigned long long x = keys[lo], y = keys[hi];
+                if (desc ? (x < y) : (x > y)) { keys[lo] = y; keys[hi] = x; }
+            }
+            __syncthreads();
+        }
+}
+__device__ __forceinline__ int next_pow2(int n) { int p = 2; while (p < n) p <<= 1; return p; }
+
+// boxes [P][n][4], scores [P][n] (any order); keep [P][n] original indices in score order; cnt [P]
+__global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ boxes, const float* __restrict__ scores, int n,
+                                                   float thr, int plus_one, int ge, int max_keep, int* __restrict__ keep,
+                                                   int* __restrict__ cnt) {
+    __shared__ NmsShared S;
+    __shared__ unsigned long long keys[NMS_CAP];
+    const int pb = blockIdx.x;
+    const float* b = boxes + (int64_t)pb * n * 4;
+    const float* s = scores + (int64_t)pb * n;
+    const int np2 = next_pow2(n);
+    for (int i = threadIdx.x; i < np2; i += 256)
+        keys[i] = i < n ? (((unsigned long long)f2ord_(s[i]) << 32) | (unsigned long long)(0xffffffffu - (unsigned)i)) : 0ull;
+    __syncthreads();
+    sort_desc_1024(keys, np2);
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int src = (int)(0xffffffffu - (unsigned)(keys[i] & 0xffffffffull));
+        S.sb[i] = *(const float4*)(b + (int64_t)src * 4);
+    }
+    __syncthreads();
+    const int kc = nms_block(S, n, thr, plus_one ? 1.0f : 0.0f, ge, max_keep, nullptr);
+    for (int i = threadIdx.x; i < kc; i += 256)
+        keep[(int64_t)pb * n + i] = (int)(0xffffffffu - (unsigned)(keys[S.kept[i]] & 0xffffffffull));
+    if (threadIdx.x == 0) cnt[pb] = kc;
+}
+
+// ------------------------------------------------------------------ RPN
+// head [N][HW][CH] with CH = A*5: channel a = objectness logit of anchor a, channel A + a*4 + c = delta c.
+__global__ void rpn_sigmoid_kernel(const float* __restrict__ head, int64_t total, int A, int CH, float* __restrict__ prob) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = i / A;
+        const int a = (int)(i - pix * A);
+        prob[i] = dm_sigmoid(head[pix * CH + a]);
+    }
+}
+
+// grid (N); one (image, level) per block.  tk_vals/tk_idx [N][pre_nms] sorted; tk_cnt [N].
+// out_boxes [N][L][post_cap][4], out_scores [N][L][post_cap] (-1 beyond count), out_cnt [N][L].
+__global__ __launch_bounds__(256) void rpn_decode_nms_kernel(const float* __restrict__ head, const float* __restrict__ anchors,
+                                                              const float* __restrict__ tk_vals, const int* __restrict__ tk_idx,
+                                                              const int* __restrict__ tk_cnt, const int* __restrict__ image_hw,
+                                                              int HWA, int A, int CH, int pre_nms, int post_nms, float thr,
+                                                              float min_size, int ge, int level, int L, int post_cap,
+                                                              float* __restrict__ out_boxes, float* __restrict__ out_scores,
+                                                              int* __restrict__ out_cnt) {
+    __shared__ NmsShared S;
+    __shared__ unsigned char dead[NMS_CAP];
+    const int n = blockIdx.x;
+    const int cnt = tk_cnt[n];
+    const float im_h = (float)image_hw[2 * n], im_w = (float)image_hw[2 * n + 1];
+    for (int j = threadIdx.x; j < cnt; j += 256) {
+        const int idx = tk_idx[(int64_t)n * pre_nms + j];
+        const int pix = idx / A, a = idx - pix * A;
+        const float* hp = head + ((int64_t)n * (HWA / A) + pix) * CH + A + a * 4;
+        const float4 d = make_float4(hp[0], hp[1], hp[2], hp[3]);
+        const float4 an = *(const float4*)(anchors + (int64_t)idx * 4);
+        float4 b = clip_box(decode_box(an, d, 1.f, 1.f, 1.f, 1.f), im_w, im_h);
+        S.sb[j] = b;
+        const float ws = b.z - b.x + 1.0f, hs = b.w - b.y + 1.0f;
+        dead[j] = (ws >= min_size && hs >= min_size) ? 0 : 1;
+    }
+    __syncthreads();
+    const int kc = nms_block(S, cnt, thr, 1.0f, ge, post_nms, dead);
+    const int64_t ob = ((int64_t)n * L + level) * post_cap;
+    for (int i = threadIdx.x; i < post_cap; i += 256) {
+        if (i < kc) {
+            const int src = S.kept[i];
+            *(float4*)(out_boxes + (ob + i) * 4) = S.sb[src];
+            out_scores[ob + i] = tk_vals[(int64_t)n * pre_nms + src];
+        } else {
+            *(float4*)(out_boxes + (ob + i) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            out_scores[ob + i] = -1.0f;
+        }
+    }
+    if (threadIdx.x == 0) out_cnt[n * L + level] = kc;
+}
+
+__global__ void sum_counts_kernel(const int* __restrict__ cnt, int L, int* __restrict__ total) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= (int)gridDim.x * (int)blockDim.x) return;
+    int s = 0;
+    for (int l = 0; l < L; ++l) s += cnt[n * L + l];
+    total[n] = s;
+}
+
+// proposals [N][K][4] (+ batch index implied), from level-major candidate boxes via the final top-k indices
+__global__ void gather_proposals_kernel(const float* __restrict__ cand_boxes, const float* __restrict__ fin_vals,
+                                        const int* __restrict__ fin_idx, const int* __restrict__ fin_cnt, int cand_per_img, int K,
+                                        float* __restrict__ props, float* __restrict__ prop_scores, int* __restrict__ prop_cnt) {
+    const int n = blockIdx.x;
+    const int cnt = fin_cnt[n];
+    if (threadIdx.x == 0) prop_cnt[n] = cnt;
+    for (int q = threadIdx.x; q < K; q += blockDim.x) {
+        const int64_t o = (int64_t)n * K + q;
+        if (q < cnt) {
+            *(float4*)(props + o * 4) = *(const float4*)(cand_boxes + ((int64_t)n * cand_per_img + fin_idx[o]) * 4);
+            prop_scores[o] = fin_vals[o];
+        } else {
+            *(float4*)(props + o * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            prop_scores[o] = -1.0f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ RoIAlign
+struct RoiLevels {
+    const float* feat[4];
+    int H[4], W[4];
+    float scale[4];
+};
+__device__ __forceinline__ int level_of(const float4 b, int k_min, int k_max) {
+    const float area = (b.z - b.x + 1.0f) * (b.w - b.y + 1.0f);
+    const float s = dm_sqrt(area);
+    const float t = floorf(4.0f + dm_log2(dm_div(s, 224.0f) + 1e-6f));
+    int l = (int)t;
+    return l < k_min ? k_min : (l > k_max ? k_max : l);
+}
+__device__ __forceinline__ float4 roi_bilinear4(const float* f, int H, int W, int C, float y, float x) {
+    float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) return z;
+    if (y <= 0.0f) y = 0.0f;
+    if (x <= 0.0f) x = 0.0f;
+    int yl = (int)y, xl = (int)x, yh, xh;
+    if (yl >= H - 1) { yh = yl = H - 1; y = (float)yl; } else yh = yl + 1;
+    if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else xh = xl + 1;
+    const float ly = y - (float)yl, lx = x - (float)xl, hy = 1.0f - ly, hx = 1.0f - lx;
+    const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+    const float4 v1 = *(const float4*)(f + ((int64_t)yl * W + xl) * C), v2 = *(const float4*)(f + ((int64_t)yl * W + xh) * C);
+    const float4 v3 = *(const float4*)(f + ((int64_t)yh * W + xl) * C), v4 = *(const float4*)(f + ((int64_t)yh * W + xh) * C);
+    float4 v;
+    v.x = w1 * v1.x; v.x = v.x + w2 * v2.x; v.x = v.x + w3 * v3.x; v.x = v.x + w4 * v4.x;
+    v.y = w1 * v1.y; v.y = v.y + w2 * v2.y; v.y = v.y + w3 * v3.y; v.y = v.y + w4 * v4.y;
+    v.z = w1 * v1.z; v.z = v.z + w2 * v2.z; v.z = v.z + w3 * v3.z; v.z = v.z + w4 * v4.z;
+    v.w = w1 * v1.w; v.w = v.w + w2 * v2.w; v.w = v.w + w3 * v3.w; v.w = v.w + w4 * v4.w;
+    return v;
+}
+// rois [N][K][4] image coords; counts [N]; out [N*K][PH][PW][C]; rows beyond count are zero-filled.
+// fixed_level >= 0 forces that level index (unit tests of a single map); else LevelMapper(k_min..k_max).
+__global__ __launch_bounds__(256) void roi_align_kernel(const RoiLevels lv, const float* __restrict__ rois, const int* __restrict__ counts,
+                                                         int N, int K, int C, int PH, int PW, int g, int k_min, int k_max,
+                                                         int fixed_level, float* __restrict__ out, int* __restrict__ out_level) {
+    const int c4n = C >> 2;
+    const int64_t total = (int64_t)N * K * PH * PW * c4n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n);
+        int64_t t = i / c4n;
+        const int pw = (int)(t % PW); t /= PW;
+        const int ph = (int)(t % PH); t /= PH;
+        const int k = (int)(t % K);
+        const int n = (int)(t / K);
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < counts[n]) {
+            const float4 b = *(const float4*)(rois + ((int64_t)n * K + k) * 4);
+            const int li = fixed_level >= 0 ? fixed_level : level_of(b, k_min, k_max) - k_min;
+            if (out_level && c4 == 0 && ph == 0 && pw == 0) out_level[n * K + k] = li + k_min;
+            const int H = lv.H[li], W = lv.W[li];
+            const float sc = lv.scale[li];
+            const float* f = lv.feat[li] + (int64_t)n * H * W * C + c4 * 4;
+            const float sw = b.x * sc, sh = b.y * sc, ew = b.z * sc, eh = b.w * sc;
+            float rw = ew - sw, rh = eh - sh;
+            rw = rw > 1.0f ? rw : 1.0f;
+            rh = rh > 1.0f ? rh : 1.0f;
+            const float bh = dm_div(rh, (float)PH), bw = dm_div(rw, (float)PW);
+            for (int iy = 0; iy < g; ++iy) {
+                const float y = sh + (float)ph * bh + dm_div(((float)iy + 0.5f) * bh, (float)g);
+                for (int ix = 0; ix < g; ++ix) {
+                    const float x = sw + (float)pw * bw + dm_div(((float)ix + 0.5f) * bw, (float)g);
+                    const float4 v = roi_bilinear4(f, H, W, C, y, x);
+                    o.x = o.x + v.x; o.y = o.y + v.y; o.z = o.z + v.z; o.w = o.w + v.w;
+                }
+            }
+            const float cnt = (float)(g * g);
+            o.x = dm_div(o.x, cnt); o.y = dm_div(o.y, cnt); o.z = dm_div(o.z, cnt); o.w = dm_div(o.w, cnt);
+        }
+        *(float4*)(out + i * 4) = o;
+    }
+}
+
+// ------------------------------------------------------------------ box head post-processing
+__global__ void softmax_rows_kernel(const float* __restrict__ x, int64_t rows, int C, int64_t in_stride, float* __restrict__ y) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
+        const float* a = x + r * in_stride;
+        float* o = y + r * C;
+        float m = a[0];
+        for (int c = 1; c < C; ++c) m = a[c] > m ? a[c] : m;
+        float s = 0.0f;
+        for (int c = 0; c < C; ++c) { const float e = dm_exp(a[c] - m); o[c] = e; s = s + e; }
+        for (int c = 0; c < C; ++c) o[c] = dm_div(o[c], s);
+    }
+}
+
+// grid (ncls-1, N).  prob [N][R][ncls]; regr [N][R][regr_stride] (class j deltas at 4j..4j+3); props [N][R][4];
+// prop_cnt [N].  cand_scores/cand_boxes [N][ncls-1][R] in NMS (score) order, -1 beyond the kept count.
+__global__ __launch_bounds__(256) void box_cls_nms_kernel(const float* __restrict__ prob, const float* __restrict__ regr,
+                                                           int64_t regr_stride, const float* __restrict__ props,
+                                                           const int* __restrict__ prop_cnt, const int* __restrict__ image_hw, int R,
+                                                           int ncls, float score_thr, float nms_thr, int ge,
+                                                           float* __restrict__ cand_scores, float* __restrict__ cand_boxes,
+                                                           int* __restrict__ kept_total) {
+    __shared__ NmsShared S;
+    __shared__ unsigned long long keys[NMS_CAP];
+    __shared__ int wcnt[4];
+    const int j = blockIdx.x + 1, n = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Rn = prop_cnt[n];
+    // ordered compaction of candidates (proposal order): wave w owns a contiguous quarter
+    const int seg = ((Rn + 3) / 4 + 63) & ~63;
+    const int s0 = wave * seg, s1 = (s0 + seg) < Rn ? (s0 + seg) : Rn;
+    int c = 0;
+    for (int i = s0 + lane; (i - lane) < s1; i += 64) {
+        const bool ok = i < s1 && prob[((int64_t)n * R + i) * ncls + j] > score_thr;
+        c += __popcll(__ballot(ok));
+    }
+    if (lane == 0) wcnt[wave] = c;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += wcnt[w];
+    const int m = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    int run = base;
+    for (int i = s0 + lane; (i - lane) < s1; i += 64) {
+        float p = 0.0f;
+        const bool ok = i < s1 && (p = prob[((int64_t)n * R + i) * ncls + j]) > score_thr;
+        const unsigned long long bm = __ballot(ok);
+        if (ok) {
+            const int pos = run + __popcll(bm & ((1ull << lane) - 1ull));
+            keys[pos] = ((unsigned long long)f2ord_(p) << 32) | (unsigned long long)(0xffffffffu - (unsigned)i);
+        }
+        run += __popcll(bm);
+    }
+    const int np2 = next_pow2(m > 1 ? m : 2);
+    for (int i = m + tid; i < np2; i += 256) keys[i] = 0ull;
+    __syncthreads();
+    sort_desc_1024(keys, np2);
+    const float im_h = (float)image_hw[2 * n], im_w = (float)image_hw[2 * n + 1];
+    for (int q = tid; q < m; q += 256) {
+        const int i = (int)(0xffffffffu - (unsigned)(keys[q] & 0xffffffffull));
+        const float4 pr = *(const float4*)(props + ((int64_t)n * R + i) * 4);
+        const float* dp = regr + ((int64_t)n * R + i) * regr_stride + 4 * j;
+        const float4 d = make_float4(dp[0], dp[1], dp[2], dp[3]);
+        S.sb[q] = clip_box(decode_box(pr, d, 10.f, 10.f, 5.f, 5.f), im_w, im_h);
+    }
+    __syncthreads();
+    const int kc = nms_block(S, m, nms_thr, 1.0f, ge, 0, nullptr);
+    const int64_t ob = ((int64_t)n * (ncls - 1) + (j - 1)) * R;
+    for (int q = tid; q < R; q += 256) {
+        if (q < kc) {
+            const int src = S.kept[q];
+            cand_scores[ob + q] = ord2f_((unsigned)(keys[src] >> 32));
+            *(float4*)(cand_boxes + (ob + q) * 4) = S.sb[src];
+        } else cand_scores[ob + q] = -1.0f;
+    }
+    if (tid == 0 && kc) atomicAdd(&kept_total[n], kc);
+}
+
+// grid (N), block 256.  Walks cand_scores [nc][R] in class-major order, keeps score >= thr (thr = the
+// det_per_img-th largest when more than det_per_img survive), order preserved, at most cap rows.
+__global__ __launch_bounds__(256) void finalize_dets_kernel(const float* __restrict__ cand_scores, const float* __restrict__ cand_boxes,
+                                                             const int* __restrict__ kept_total, const float* __restrict__ top_vals,
+                                                             int nc, int R, int det_per_img, int cap, int* __restrict__ out_cnt,
+                                                             float* __restrict__ out_boxes, float* __restrict__ out_scores,
+                                                             int* __restrict__ out_labels) {
+    __shared__ int wtot[4];
+    __shared__ int run_s;
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tot = kept_total[n];
+    const bool cut = det_per_img > 0 && tot > det_per_img;
+    const float thr = cut ? top_vals[(int64_t)n * det_per_img + det_per_img - 1] : -1e30f;
+    const float* cs = cand_scores + (int64_t)n * nc * R;
+    if (tid == 0) run_s = 0;
+    __syncthreads();
+    const int total = nc * R;
+    for (int base = 0; base < total; base += 256) {
+        const int i = base + tid;
+        const float s = i < total ? cs[i] : -1.0f;
+        const bool ok = s >= 0.0f && s >= thr;
+        const unsigned long long bm = __ballot(ok);
+        if (lane == 0) wtot[wave] = __popcll(bm);
+        __syncthreads();
+        int pre = run_s;
+        for (int w = 0; w < wave; ++w) pre += wtot[w];
+        const int pos = pre + __popcll(bm & ((1ull << lane) - 1ull));
+        if (ok && pos < cap) {
+            const int64_t o = (int64_t)n * cap + pos;
+            out_scores[o] = s;
+            out_labels[o] = i / R + 1;
+            *(float4*)(out_boxes + o * 4) = *(const float4*)(cand_boxes + ((int64_t)n * nc * R + i) * 4);
+        }
+        __syncthreads();
+        if (tid == 0) run_s += wtot[0] + wtot[1] + wtot[2] + wtot[3];
+        __syncthreads();
+    }
+    const int cnt = run_s < cap ? run_s : cap;
+    if (tid == 0) out_cnt[n] = cnt;
+    for (int q = cnt + tid; q < cap; q += 256) {
+        const int64_t o = (int64_t)n * cap + q;
+        out_scores[o] = 0.0f; out_labels[o] = 0;
+        *(float4*)(out_boxes + o * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+// ------------------------------------------------------------------ mask head tail
+// feat [R][HW][C]; w [ncls][C]; b [ncls]; labels [R] (0 = empty row -> zeros); out [R][HW].  grid (R).
+__global__ __launch_bounds__(256) void mask_logits_select_kernel(const float* __restrict__ feat, int HW, int C, const float* __restrict__ w,
+                                                                  const float* __restrict__ b, const int* __restrict__ labels,
+                                                                  float* __restrict__ out) {
+    extern __shared__ float wr[];
+    const int r = blockIdx.x;
+    const int lab = labels[r];
+    if (lab <= 0) {
+        for (int p = threadIdx.x; p < HW; p += 256) out[(int64_t)r * HW + p] = 0.0f;
+        return;
+    }
+    for (int c = threadIdx.x; c < C; c += 256) wr[c] = w[(int64_t)lab * C + c];
+    __syncthreads();
+    const float bias = b[lab];
+    for (int p = threadIdx.x; p < HW; p += 256) {
+        const float4* x = (const float4*)(feat + ((int64_t)r * HW + p) * C);
+        float acc = 0.0f;
+        for (int c4 = 0; c4 < C / 4; ++c4) {
+            const float4 v = x[c4];
+            acc = fmaf(v.x, wr[4 * c4], acc); acc = fmaf(v.y, wr[4 * c4 + 1], acc);
+            acc = fmaf(v.z, wr[4 * c4 + 2], acc); acc = fmaf(v.w, wr[4 * c4 + 3], acc);
+        }
+        out[(int64_t)r * HW + p] = dm_sigmoid(fmaf(acc, 1.0f, bias));
+    }
+}
+
+// masks [N][K][M][M]; boxes [N][K][4] in output-image coordinates; counts [N]; out [N][K][im_h][im_w] u8.
+__global__ __launch_bounds__(256) void paste_masks_kernel(const float* __restrict__ masks, const float* __restrict__ boxes,
+                                                           const int* __restrict__ counts, int K, int M, int im_h, int im_w, float thr,
+                                                           uint8_t* __restrict__ out) {
+    const int n = blockIdx.z, d = blockIdx.y;
+    if (d >= counts[n]) return;
+    const float4 b = *(const float4*)(boxes + ((int64_t)n * K + d) * 4);
+    const int P = M + 2;
+    const float scale = dm_div((float)P, (float)M);
+    float w_half = (b.z - b.x) * 0.5f, h_half = (b.w - b.y) * 0.5f;
+    const float x_c = (b.z + b.x) * 0.5f, y_c = (b.w + b.y) * 0.5f;
+    w_half = w_half * scale;
+    h_half = h_half * scale;
+    const int x1 = (int)(x_c - w_half), x2 = (int)(x_c + w_half);
+    const int y1 = (int)(y_c - h_half), y2 = (int)(y_c + h_half);
+    int w = x2 - x1 + 1, h = y2 - y1 + 1;
+    w = w > 1 ? w : 1;
+    h = h > 1 ? h : 1;
+    const int x_0 = x1 > 0 ? x1 : 0, x_1 = (x2 + 1) < im_w ? (x2 + 1) : im_w;
+    const int y_0 = y1 > 0 ? y1 : 0, y_1 = (y2 + 1) < im_h ? (y2 + 1) : im_h;
+    const float* m = masks + ((int64_t)n * K + d) * M * M;
+    uint8_t* o = out + ((int64_t)n * K + d) * im_h * im_w;
+    const int64_t total = (int64_t)im_h * im_w;
+    for (int64_t q = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; q < total; q += (int64_t)gridDim.x * 256 * 4) {
+        uint32_t word = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int64_t f = q + e;
+            if (f >= total) break;
+            const int y = (int)(f / im_w), x = (int)(f - (int64_t)y * im_w);
+            if (y < y_0 || y >= y_1 || x < x_0 || x >= x_1) continue;
+            int sy0, sy1, sx0, sx1; float ly0, ly1, lx0, lx1;
+            dm_bil_coef(y - y1, P, h, sy0, sy1, ly0, ly1);
+            dm_bil_coef(x - x1, P, w, sx0, sx1, lx0, lx1);
+            auto padv = [&](int yy, int xx) -> float { return (yy >= 1 && yy <= M && xx >= 1 && xx <= M) ? m[(yy - 1) * M + (xx - 1)] : 0.0f; };
+            float top = lx0 * padv(sy0, sx0); top = fmaf(lx1, padv(sy0, sx1), top);
+            float bot = lx0 * padv(sy1, sx0); bot = fmaf(lx1, padv(sy1, sx1), bot);
+            float v = ly0 * top; v = fmaf(ly1, bot, v);
+            if (v > thr) word |= (1u << (8 * e));
+        }
+        if (q + 3 < total) *(uint32_t*)(o + q) = word;
+        else for (int e = 0; e < 4 && q + e < total; ++e) o[q + e] = (uint8_t)((word >> (8 * e)) & 0xff);
+    }
+}
+
+__global__ void scale_boxes_kernel(const float* __restrict__ boxes, const float* __restrict__ ratios, int K, float* __restrict__ out) {
+    const int n = blockIdx.x;
+    const float rw = ratios[2 * n], rh = ratios[2 * n + 1];
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        const float4 b = *(const float4*)(boxes + ((int64_t)n * K + k) * 4);
+        *(float4*)(out + ((int64_t)n * K + k) * 4) = make_float4(b.x * rw, b.y * rh, b.z * rw, b.w * rh);
+    }
+}
+
+// ------------------------------------------------------------------ launchers
+static inline unsigned grid_for(int64_t total, int per = 256) {
+    int64_t b = cdiv64(total, per);
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+int scale_boxes_launch(const float* boxes, const float* ratios, int N, int K, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(scale_boxes_kernel, dim3(N), dim3(128), 0, st, boxes, ratios, K, out);
+    HIP_TRY(hipGetLastError());
+    return ISEGMI_OK;
+}
+
+int nms_launch(const float* boxes, const float* scores, int problems, int n, float thr, int plus_one, int ge, int max_keep, int* keep,
+               int* cnt, hipStream_t st) {
+    ARG_CHECK(n > 0 && n <= NMS_CAP, "nms n must be in 1..1024");
+    if (problems == 0) return ISEGMI_OK;
+    hipLaunchKernelGGL(nms_kernel, dim3(problems), dim3(256), 0, st, boxes, scores, n, thr, plus_one, ge, max_keep, keep, cnt);
+    HIP_TRY(hipGetLastError());
+    return ISEGMI_OK;
+}
+
+int rpn_sigmoid_launch(const float* head, int64_t total, int A, int CH, float* prob, hipStream_t st) {
+    hipLaunchKernelGGL(rpn_sigmoid_kernel, dim3(grid_for(total)), dim3(256), 0, st, head, total, A, CH, prob);
+    HIP_TRY(hipGetLastError());
+    return ISEGMI_OK;
+}
+
+int rpn_decode_nms_launch(const float* head, const float* anchors, const float* tk_vals, const int* tk_idx, const int* tk_cnt,
+                          const int* image_hw, int N, int HWA, int A, int CH, int pre_nms, int post_nms, float thr, float min_size,
+                          int ge, int level, int L, int post_cap, float* out_boxes, float* out_scores, int* out_cnt, hipStream_t st) {
+    ARG_CHECK(pre_nms <= NMS_CAP && post_nms <= post_cap, "rpn sizes");
+    hipLaunchKernelGGL(rpn_decode_nms_kernel, dim3(N), dim3(256), 0, st, head, anchors, tk_vals, tk_idx, tk_cnt, image_hw, HWA, A, CH,
+                       pre_nms, post_nms, thr, min_size, ge, level, L, post_cap, out_boxes, out_scores, out_cnt);
+    HIP_TRY(hipGetLastError());
+    return ISEGMI_OK;
+}
+
+int sum_counts_launch(const int* cnt, int N, int L, int* total, hipStream_t st) {
+    hipLaunchKernelGGL(sum_counts_kernel, dim3(1), dim3(N), 0, st, cnt, L, total);
+    HIP_TRY(hipGetLastError());
+    return ISEGMI_OK;
+}
+
+int gather_proposals_launch(const float* cand_boxes, const float* fin_vals, const int* fin_idx, const int* fin_cnt, int N,
+                            int cand_per_img, int K, float* props, float* prop_scores, int* prop_cnt, hipStream_t st) {
+    hipLaunchKernelGGL(gather_proposals_kernel, dim3(N), dim3(256), 0, st, cand_boxes, fin_vals, fin_idx, fin_cnt, cand_per_img, K,
+                       props, prop_scores, prop_cnt);
+    HIP_TRY(hipGetLastError());
+    return ISEGMI_OK;
+}
+
+int roi_align_launch(const float* const* feats, const int* Hs, const int* Ws, const float* scales, int nlevels, const float* rois,
+                     const int* counts, int N, int K, int C, int PH, int PW, int g, int k_min, int fixed_level, float* out,
+                     int* out_level, hipStream_t st) {
+    ARG_CHECK(nlevels >= 1 && nlevels <= 4 && C % 4 == 0, "roi_align levels/C");
+    RoiLevels lv;
+    for (int i = 0; i < 4; ++i) {
+        const int s = i < nlevels ? i : nlevels - 1;
+        lv.feat[i] = feats[s]; lv.H[i] = Hs[s]; lv.W[i] = Ws[s]; lv.scale[i] = scales[s];
+    }
+    const int64_t total = (int64_t)N * K * PH * PW * (C / 4);
+    hipLaunchKernelGGL(roi_align_kernel, dim3(grid_for(total)), dim3(256), 0, st, lv, rois, counts, N, K, C, PH, PW, g, k_min,
+                       k_min + nlevels - 1, fixed_level, out, out_level);
+    HIP_TRY(hipGetLastError());
+    return ISEGMI_OK;
+}
+
+int softmax_rows_launch(const float* x, int64_t rows, int C, int64_t in_stride, float* y, hipStream_t st) {
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(grid_for(rows, 64)), dim3(64), 0, st, x, rows, C, in_stride, y);
+    HIP_TRY(hipGetLastError());
+    return ISEGMI_OK;
+}
+
+int topk_launch(const float* keys, int64_t row_stride, int rows, int n, int k, const int* limit, int rows_per_limit,
+                float* out_vals, int* out_idx, int* out_cnt, hipStream_t st);
+
+// box post-processing for N images: logits -> detections.  Workspaces are caller-provided.
+int box_postprocess_launch(const isegmi_box_post_args* a, hipStream_t st) {
+    ARG_CHECK(a->N > 0 && a->R > 0 && a->R <= NMS_CAP && a->ncls >= 2, "box post sizes (R <= 1024)");
+    ARG_CHECK(a->det_per_img > 0 && a->det_per_img <= 1024 && a->cap >= a->det_per_img, "det_per_img / cap");
+    const int nc = a->ncls - 1;
+    int rc = softmax_rows_launch(a->d_logits, (int64_t)a->N * a->R, a->ncls, a->logits_stride, a->d_ws_prob, st);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(a->d_ws_kept_total, 0, sizeof(int) * (size_t)a->N, st));
+    hipLaunchKernelGGL(box_cls_nms_kernel, dim3(nc, a->N), dim3(256), 0, st, a->d_ws_prob, a->d_regr, a->regr_stride, a->d_props,
+                       a->d_prop_cnt, a->d_image_hw, a->R, a->ncls, a->score_thresh, a->nms_thresh, a->nms_ge, a->d_ws_cand_scores,
+                       a->d_ws_cand_boxes, a->d_ws_kept_total);
+    HIP_TRY(hipGetLastError());
+    rc = topk_launch(a->d_ws_cand_scores, (int64_t)nc * a->R, a->N, nc * a->R, a->det_per_img, a->d_ws_kept_total, 1, a->d_ws_top_vals,
+                     a->d_ws_top_idx, nullptr, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(finalize_dets_kernel, dim3(a->N), dim3(256), 0, st, a->d_ws_cand_scores, a->d_ws_cand_boxes, a->d_ws_kept_total,
+                       a->d_ws_top_vals, nc, a->R, a->det_per_img, a->cap, a->d_out_count, a->d_out_boxes, a->d_out_scores,
+                       a->d_out_labels);
+    HIP_TRY(hipGetLastError());
+    return ISEGMI_OK;
+}
+
+int mask_logits_select_launch(const float* feat, int R, int HW, int C, const float* w, const float* b, const int* labels, float* out,
+                              hipStream_t st) {
+    ARG_CHECK(C % 4 == 0, "C % 4");
+    if (R == 0) return ISEGMI_OK;
+    hipLaunchKernelGGL(mask_logits_select_kernel, dim3(R), dim3(256), (size_t)C * sizeof(float), st, feat, HW, C, w, b, labels, out);
+    HIP_TRY(hipGetLastError());
+    return ISEGMI_OK;
+}
+
+int paste_masks_launch(const float* masks, const float* boxes, const int* counts, int N, int K, int M, int im_h, int im_w, float thr,
+                       uint8_t* out, hipStream_t st) {
+    HIP_TRY(hipMemsetAsync(out, 0, (size_t)N * K * im_h * im_w, st));
+    const unsigned bx = grid_for((int64_t)im_h * im_w, 1024) > 64 ? 64 : grid_for((int64_t)im_h * im_w, 1024);
+    hipLaunchKernelGGL(paste_masks_kernel, dim3(bx, K, N), dim3(256), 0, st, masks, boxes, counts, K, M, im_h, im_w, thr, out);
+    HIP_TRY(hipGetLastError());
+    return ISEGMI_OK;
+}
+
+}  // namespace isegmi
+
+using namespace isegmi;
+
+extern "C" int isegmi_op_nms(const float* d_boxes, const float* d_scores, int problems, int n, float thr, int plus_one, int ge,
+                             int max_keep, int32_t* d_keep, int32_t* d_cnt, void* stream) {
+    return nms_launch(d_boxes, d_scores, problems, n, thr, plus_one, ge, max_keep, d_keep, d_cnt, (hipStream_t)stream);
+}
+
+extern "C" int isegmi_op_roi_align(const float* const* d_feats, const int32_t* Hs, const int32_t* Ws, const float* scales, int nlevels,
+                                   const float* d_rois, const int32_t* d_counts, int N, int K, int C, int PH, int PW, int sampling,
+                                   int k_min, int fixed_level, float* d_out, int32_t* d_out_level, void* stream) {
+    return roi_align_launch(d_feats, Hs, Ws, scales, nlevels, d_rois, d_counts, N, K, C, PH, PW, sampling, k_min, fixed_level, d_out,
+                            d_out_level, (hipStream_t)stream);
+}
+
+extern "C" int isegmi_op_box_postprocess(const isegmi_box_post_args* a, void* stream) {
+    ARG_CHECK(a, "null");
+    return box_postprocess_launch(a, (hipStream_t)stream);
+}
+
+extern "C" int isegmi_op_mask_logits_select(const float* d_feat, int R, int HW, int C, const float* d_w, const float* d_b,
+                                            const int32_t* d_labels, float* d_out, void* stream) {
+    return mask_logits_select_launch(d_feat, R, HW, C, d_w, d_b, d_labels, d_out, (hipStream_t)stream);
+}
+
+extern "C" int isegmi_op_paste_masks(const float* d_masks, const float* d_boxes, const int32_t* d_counts, int N, int K, int M,
+                                     int im_h, int im_w, float thr, uint8_t* d_out, void* stream) {
+    return paste_masks_launch(d_masks, d_boxes, d_counts, N, K, M, im_h, im_w, thr, d_out, (hipStream_t)stream);
+}
+
+// One RPN level for N images (parity-test entry; the engine calls the same launchers):
+// head [N][HW][A*5] -> boxes/scores [N][post_nms] (+count).  Workspaces: prob [N][HWA], tk_* [N][pre_nms].
+extern "C" int isegmi_op_rpn_level(const float* d_head, const float* d_anchors, const int32_t* d_image_hw, int N, int HW, int A,
+                                   int pre_nms, int post_nms, float nms_thr, float min_size, int nms_ge, float* d_ws_prob,
+                                   float* d_ws_tk_vals, int32_t* d_ws_tk_idx, int32_t* d_ws_tk_cnt, float* d_out_boxes,
+                                   float* d_out_scores, int32_t* d_out_cnt, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int HWA = HW * A, CH = A * 5;
+    int rc = rpn_sigmoid_launch(d_head, (int64_t)N * HWA, A, CH, d_ws_prob, st);
+    if (rc) return rc;
+    const int k = pre_nms < HWA ? pre_nms : HWA;
+    rc = topk_launch(d_ws_prob, HWA, N, HWA, pre_nms, nullptr, 1, d_ws_tk_vals, d_ws_tk_idx, d_ws_tk_cnt, st);
+    if (rc) return rc;
+    (void)k;
+    return rpn_decode_nms_launch(d_head, d_anchors, d_ws_tk_vals, d_ws_tk_idx, d_ws_tk_cnt, d_image_hw, N, HWA, A, CH, pre_nms, post_nms,
+                                 nms_thr, min_size, nms_ge, 0, 1, post_nms, d_out_boxes, d_out_scores, d_out_cnt, st);
+}

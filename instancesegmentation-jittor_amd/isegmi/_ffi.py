@@ -243,3 +243,92 @@ def yolact_masks(proto, coeffs, boxes, counts, h, w):
     dob = DeviceBuffer((N, K, 4), np.int64)
     check(lib().isegmi_op_yolact_masks(dp.ptr, dc.ptr, db.ptr, dn.ptr, N, PH, PW, md, K, h, w, dlo.ptr, dm.ptr, dob.ptr, None))
     return dm.numpy(), dob.numpy()
+
+
+# ---------------------------------------------------------------- Mask R-CNN op wrappers (tests / small inputs)
+def nms(boxes, scores, thr, plus_one=1, ge=0, max_keep=0):
+    """boxes [P,n,4], scores [P,n] -> list of kept original indices (score order) per problem."""
+    boxes = np.ascontiguousarray(boxes, np.float32); scores = np.ascontiguousarray(scores, np.float32)
+    P, n = scores.shape
+    db = DeviceBuffer.from_numpy(boxes); ds = DeviceBuffer.from_numpy(scores)
+    dk = DeviceBuffer((P, n), np.int32); dc = DeviceBuffer((P,), np.int32)
+    check(lib().isegmi_op_nms(db.ptr, ds.ptr, P, n, C.c_float(thr), plus_one, ge, max_keep, dk.ptr, dc.ptr, None))
+    k, c = dk.numpy(), dc.numpy()
+    return [k[i, : c[i]].copy() for i in range(P)]
+
+
+def roi_align(feats, scales, rois, counts, PH, PW, sampling=2, k_min=2, fixed_level=-1):
+    """feats: list of [N,H,W,C]; rois [N,K,4]; counts [N] -> (out [N*K,PH,PW,C], levels [N,K])"""
+    fb = [DeviceBuffer.from_numpy(np.ascontiguousarray(f, np.float32)) for f in feats]
+    N, K = rois.shape[:2]
+    Cc = feats[0].shape[3]
+    ptrs = (C.c_void_p * len(fb))(*[b.ptr.value for b in fb])
+    Hs = (C.c_int32 * len(fb))(*[f.shape[1] for f in feats]); Ws = (C.c_int32 * len(fb))(*[f.shape[2] for f in feats])
+    sc = (C.c_float * len(fb))(*scales)
+    dr = DeviceBuffer.from_numpy(np.ascontiguousarray(rois, np.float32)); dcnt = DeviceBuffer.from_numpy(np.ascontiguousarray(counts, np.int32))
+    do = DeviceBuffer((N * K, PH, PW, Cc)); dl = DeviceBuffer((N, K), np.int32); dl.zero()
+    check(lib().isegmi_op_roi_align(ptrs, Hs, Ws, sc, len(fb), dr.ptr, dcnt.ptr, N, K, Cc, PH, PW, sampling, k_min, fixed_level,
+                                    do.ptr, dl.ptr, None))
+    return do.numpy(), dl.numpy()
+
+
+class BoxPostArgs(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("N", "R", "ncls", "det_per_img", "cap", "nms_ge")] + \
+               [("score_thresh", C.c_float), ("nms_thresh", C.c_float), ("logits_stride", C.c_int64), ("regr_stride", C.c_int64)] + \
+               [(n, C.c_void_p) for n in ("d_logits", "d_regr", "d_props", "d_prop_cnt", "d_image_hw", "d_ws_prob", "d_ws_cand_scores",
+                                          "d_ws_cand_boxes", "d_ws_kept_total", "d_ws_top_vals", "d_ws_top_idx", "d_out_count",
+                                          "d_out_boxes", "d_out_scores", "d_out_labels")]
+
+
+def box_postprocess(logits, regr, props, prop_cnt, image_hw, score_thr=0.05, nms_thr=0.5, det_per_img=100, nms_ge=0):
+    """logits [N,R,ncls], regr [N,R,4*ncls], props [N,R,4] -> list of (boxes, scores, labels)."""
+    logits = np.ascontiguousarray(logits, np.float32)
+    N, R, ncls = logits.shape
+    cap = det_per_img
+    b = dict(d_logits=DeviceBuffer.from_numpy(logits), d_regr=DeviceBuffer.from_numpy(np.ascontiguousarray(regr, np.float32)),
+             d_props=DeviceBuffer.from_numpy(np.ascontiguousarray(props, np.float32)),
+             d_prop_cnt=DeviceBuffer.from_numpy(np.ascontiguousarray(prop_cnt, np.int32)),
+             d_image_hw=DeviceBuffer.from_numpy(np.ascontiguousarray(image_hw, np.int32)),
+             d_ws_prob=DeviceBuffer((N, R, ncls)), d_ws_cand_scores=DeviceBuffer((N, ncls - 1, R)),
+             d_ws_cand_boxes=DeviceBuffer((N, ncls - 1, R, 4)), d_ws_kept_total=DeviceBuffer((N,), np.int32),
+             d_ws_top_vals=DeviceBuffer((N, det_per_img)), d_ws_top_idx=DeviceBuffer((N, det_per_img), np.int32),
+             d_out_count=DeviceBuffer((N,), np.int32), d_out_boxes=DeviceBuffer((N, cap, 4)), d_out_scores=DeviceBuffer((N, cap)),
+             d_out_labels=DeviceBuffer((N, cap), np.int32))
+    a = BoxPostArgs(N, R, ncls, det_per_img, cap, nms_ge, score_thr, nms_thr, ncls, 4 * ncls, *[b[n].ptr for n, _ in BoxPostArgs._fields_[10:]])
+    check(lib().isegmi_op_box_postprocess(C.byref(a), None))
+    cnt = b["d_out_count"].numpy(); B = b["d_out_boxes"].numpy(); S = b["d_out_scores"].numpy(); Lb = b["d_out_labels"].numpy()
+    return [(B[i, : cnt[i]], S[i, : cnt[i]], Lb[i, : cnt[i]]) for i in range(N)]
+
+
+def mask_logits_select(feat, w, b, labels):
+    feat = np.ascontiguousarray(feat, np.float32)
+    R, HW, Cc = feat.shape
+    df = DeviceBuffer.from_numpy(feat); dw = DeviceBuffer.from_numpy(np.ascontiguousarray(w, np.float32))
+    db = DeviceBuffer.from_numpy(np.ascontiguousarray(b, np.float32)); dl = DeviceBuffer.from_numpy(np.ascontiguousarray(labels, np.int32))
+    do = DeviceBuffer((R, HW))
+    check(lib().isegmi_op_mask_logits_select(df.ptr, R, HW, Cc, dw.ptr, db.ptr, dl.ptr, do.ptr, None))
+    return do.numpy()
+
+
+def paste_masks(masks, boxes, counts, im_h, im_w, thr=0.5):
+    masks = np.ascontiguousarray(masks, np.float32)
+    N, K, M, _ = masks.shape
+    dm = DeviceBuffer.from_numpy(masks); db = DeviceBuffer.from_numpy(np.ascontiguousarray(boxes, np.float32))
+    dc = DeviceBuffer.from_numpy(np.ascontiguousarray(counts, np.int32)); do = DeviceBuffer((N, K, im_h, im_w), np.uint8)
+    check(lib().isegmi_op_paste_masks(dm.ptr, db.ptr, dc.ptr, N, K, M, im_h, im_w, C.c_float(thr), do.ptr, None))
+    return do.numpy()
+
+
+def rpn_level(head, anchors, image_hw, A, pre_nms, post_nms, nms_thr=0.7, min_size=0.0, nms_ge=0):
+    """head [N,H,W,A*5] fused (A logits, A*4 deltas) -> list of (boxes, scores)."""
+    head = np.ascontiguousarray(head, np.float32)
+    N, H, W, CH = head.shape
+    HW = H * W
+    dh = DeviceBuffer.from_numpy(head); da = DeviceBuffer.from_numpy(np.ascontiguousarray(anchors, np.float32))
+    dhw = DeviceBuffer.from_numpy(np.ascontiguousarray(image_hw, np.int32))
+    wp = DeviceBuffer((N, HW * A)); tv = DeviceBuffer((N, pre_nms)); ti = DeviceBuffer((N, pre_nms), np.int32); tc = DeviceBuffer((N,), np.int32)
+    ob = DeviceBuffer((N, post_nms, 4)); os_ = DeviceBuffer((N, post_nms)); oc = DeviceBuffer((N,), np.int32)
+    check(lib().isegmi_op_rpn_level(dh.ptr, da.ptr, dhw.ptr, N, HW, A, pre_nms, post_nms, C.c_float(nms_thr), C.c_float(min_size), nms_ge,
+                                    wp.ptr, tv.ptr, ti.ptr, tc.ptr, ob.ptr, os_.ptr, oc.ptr, None))
+    c = oc.numpy(); B = ob.numpy(); S = os_.numpy()
+    return [(B[i, : c[i]], S[i, : c[i]]) for i in range(N)]

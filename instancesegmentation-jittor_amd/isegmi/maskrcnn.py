@@ -1,0 +1,279 @@
+"""Mask R-CNN R50/R101-FPN inference, host side (mirrors detectron.jittor's predictor surface).
+
+Reference surface (README.md:288-335): `cfg.merge_from_file(...)`; `COCODemo(cfg, min_image_size=800,
+confidence_threshold=0.5)`; `coco_demo.run_on_opencv_image(image)`; [UPSTREAM-RECALL, SURVEY 8b]
+`compute_prediction(image) -> BoxList` with fields scores / labels / mask.  All numerics run in
+libisegmi.so; this module moves config, weights, anchors and results across the C ABI.
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _ffi
+from .weights import fold_frozen_batchnorm, to_krsc
+
+PIXEL_MEAN = (102.9801, 115.9465, 122.7717)  # BGR, TO_BGR255
+
+
+@dataclass(frozen=True)
+class MaskRCNNConfig:
+    """e2e_mask_rcnn_R_50_FPN_1x inference constants; key names follow the yaml."""
+    depth: int = 50
+    MIN_SIZE_TEST: int = 800
+    MAX_SIZE_TEST: int = 1333
+    SIZE_DIVISIBILITY: int = 32
+    ANCHOR_SIZES: tuple = (32, 64, 128, 256, 512)
+    ANCHOR_STRIDE: tuple = (4, 8, 16, 32, 64)
+    ASPECT_RATIOS: tuple = (0.5, 1.0, 2.0)
+    RPN_PRE_NMS_TOP_N_TEST: int = 1000
+    RPN_POST_NMS_TOP_N_TEST: int = 1000
+    RPN_FPN_POST_NMS_TOP_N_TEST: int = 1000
+    RPN_NMS_THRESH: float = 0.7
+    RPN_MIN_SIZE: float = 0.0
+    ROI_SCORE_THRESH: float = 0.05
+    ROI_NMS: float = 0.5
+    DETECTIONS_PER_IMG: int = 100
+    NMS_GE: int = 0  # SURVEY App. A.6 switch: 0 suppress on iou > thr (CUDA kernel), 1 on >= (CPU loop)
+
+
+# ---------------------------------------------------------------------------------------- anchors (A.3)
+def _whctrs(a):
+    w = a[2] - a[0] + 1
+    h = a[3] - a[1] + 1
+    return w, h, a[0] + 0.5 * (w - 1), a[1] + 0.5 * (h - 1)
+
+
+def _mkanchors(ws, hs, xc, yc):
+    ws = ws[:, None]; hs = hs[:, None]
+    return np.hstack((xc - 0.5 * (ws - 1), yc - 0.5 * (hs - 1), xc + 0.5 * (ws - 1), yc + 0.5 * (hs - 1)))
+
+
+def generate_anchors(stride, size, aspect_ratios):
+    anchor = np.array([1, 1, stride, stride], np.float64) - 1
+    w, h, xc, yc = _whctrs(anchor)
+    ratios = np.asarray(aspect_ratios, np.float64)
+    ws = np.round(np.sqrt(w * h / ratios)); hs = np.round(ws * ratios)
+    ra = _mkanchors(ws, hs, xc, yc)
+    scales = np.array([size / stride], np.float64)
+    out = []
+    for i in range(ra.shape[0]):
+        w, h, xc, yc = _whctrs(ra[i])
+        out.append(_mkanchors(w * scales, h * scales, xc, yc))
+    return np.vstack(out).astype(np.float32)
+
+
+def grid_anchors(grid_h, grid_w, stride, base):
+    sx = np.arange(0, grid_w * stride, stride, dtype=np.float32)
+    sy = np.arange(0, grid_h * stride, stride, dtype=np.float32)
+    yy, xx = np.meshgrid(sy, sx, indexing="ij")
+    shifts = np.stack([xx.ravel(), yy.ravel(), xx.ravel(), yy.ravel()], 1)
+    return (shifts[:, None, :] + base[None, :, :]).reshape(-1, 4).astype(np.float32)
+
+
+def level_shapes(H, W):
+    s = ((H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1)
+    s = ((s[0] + 2 - 3) // 2 + 1, (s[1] + 2 - 3) // 2 + 1)  # C2 (stride 4)
+    out = [s]
+    for _ in range(3):
+        s = ((s[0] - 1) // 2 + 1, (s[1] - 1) // 2 + 1)      # 1x1 stride 2
+        out.append(s)
+    out.append(((s[0] - 1) // 2 + 1, (s[1] - 1) // 2 + 1))  # P6
+    return out
+
+
+def prepare_images(images_bgr_f32, divisibility=32):
+    """to_image_list (M1) for already-resized BGR 0..255 float images: subtract PIXEL_MEAN, zero-pad to a
+    common size divisible by 32.  Returns (batch NHWC3 fp32, image_hw [N,2] int32)."""
+    hw = np.array([im.shape[:2] for im in images_bgr_f32], np.int32)
+    H = int(-(-hw[:, 0].max() // divisibility) * divisibility)
+    W = int(-(-hw[:, 1].max() // divisibility) * divisibility)
+    out = np.zeros((len(images_bgr_f32), H, W, 3), np.float32)
+    mean = np.asarray(PIXEL_MEAN, np.float32)
+    for i, im in enumerate(images_bgr_f32):
+        out[i, : im.shape[0], : im.shape[1]] = np.asarray(im, np.float32) - mean
+    return out, hw
+
+
+class BoxList:
+    """Minimal structures/bounding_box.BoxList (M13): xyxy boxes, size=(w,h), named fields."""
+
+    def __init__(self, bbox, image_size, mode="xyxy"):
+        self.bbox = np.asarray(bbox, np.float32).reshape(-1, 4)
+        self.size = tuple(image_size)
+        self.mode = mode
+        self.extra_fields = {}
+
+    def add_field(self, k, v):
+        self.extra_fields[k] = v
+
+    def get_field(self, k):
+        return self.extra_fields[k]
+
+    def has_field(self, k):
+        return k in self.extra_fields
+
+    def fields(self):
+        return list(self.extra_fields)
+
+    def __len__(self):
+        return self.bbox.shape[0]
+
+    def __getitem__(self, item):
+        b = BoxList(self.bbox[item], self.size, self.mode)
+        for k, v in self.extra_fields.items():
+            b.add_field(k, v[item])
+        return b
+
+    def resize(self, size):
+        rw, rh = (float(s) / float(o) for s, o in zip(size, self.size))
+        r = np.array([rw, rh, rw, rh], np.float32)
+        b = BoxList(self.bbox * r, size, self.mode)
+        for k, v in self.extra_fields.items():
+            b.add_field(k, v)
+        return b
+
+
+class MaskRCNN:
+    """GeneralizedRCNN engine wrapper: `model = MaskRCNN(sd, H, W)`; `preds = model(batch, image_hw)`."""
+
+    KIND = 2
+
+    def __init__(self, state_dict, H, W, cfg=MaskRCNNConfig(), max_batch=2, device=0):
+        assert H % 32 == 0 and W % 32 == 0
+        self.cfg, self.H, self.W, self.max_batch = cfg, H, W, max_batch
+        _ffi.lib()
+        _ffi.set_device(device)
+        self._h = C.c_void_p()
+        _ffi.check(_ffi.lib().isegmi_engine_create(self.KIND, max_batch, H, W, C.byref(self._h)))
+        self._load(state_dict)
+        for k, v in (("resnet_depth", cfg.depth), ("rpn_pre_nms_top_n", cfg.RPN_PRE_NMS_TOP_N_TEST),
+                     ("rpn_post_nms_top_n", cfg.RPN_POST_NMS_TOP_N_TEST), ("rpn_fpn_post_nms_top_n", cfg.RPN_FPN_POST_NMS_TOP_N_TEST),
+                     ("rpn_nms_thresh", cfg.RPN_NMS_THRESH), ("rpn_min_size", cfg.RPN_MIN_SIZE), ("roi_score_thresh", cfg.ROI_SCORE_THRESH),
+                     ("roi_nms_thresh", cfg.ROI_NMS), ("detections_per_img", cfg.DETECTIONS_PER_IMG), ("nms_ge", cfg.NMS_GE)):
+            self.set_param(k, float(v))
+        self._d_in = _ffi.DeviceBuffer((max_batch, H, W, 3))
+        self._hw = None
+
+    def set_param(self, name, value):
+        _ffi.check(_ffi.lib().isegmi_engine_set_param(self._h, name.encode(), C.c_float(value)))
+
+    def _set_conv_krsc(self, name, w, scale=None, shift=None):
+        w = np.ascontiguousarray(w, np.float32)
+        cout, r, s, cin = w.shape
+        fp = lambda a: None if a is None else np.ascontiguousarray(a, np.float32).ctypes.data_as(C.c_void_p)
+        sc = None if scale is None else np.ascontiguousarray(scale, np.float32)
+        sh = None if shift is None else np.ascontiguousarray(shift, np.float32)
+        _ffi.check(_ffi.lib().isegmi_engine_set_conv(self._h, name.encode(), cout, r, s, cin, fp(w), fp(sc), fp(sh)))
+
+    def _set_tensor(self, name, a):
+        a = np.ascontiguousarray(a)
+        _ffi.check(_ffi.lib().isegmi_engine_set_tensor(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), C.c_int64(a.nbytes)))
+
+    def _load(self, sd):
+        cfg = self.cfg
+        w = to_krsc(sd["backbone.body.stem.conv1.weight"])
+        w = np.concatenate([w, np.zeros(w.shape[:3] + (1,), np.float32)], -1)
+        self._set_conv_krsc("backbone.body.stem.conv1", w, *fold_frozen_batchnorm(sd, "backbone.body.stem.bn1"))
+        blocks = (3, 4, 23 if cfg.depth == 101 else 6, 3)
+        for li, nb in enumerate(blocks, 1):
+            for b in range(nb):
+                nm = "backbone.body.layer%d.%d" % (li, b)
+                for i in (1, 2, 3):
+                    self._set_conv_krsc("%s.conv%d" % (nm, i), to_krsc(sd["%s.conv%d.weight" % (nm, i)]),
+                                        *fold_frozen_batchnorm(sd, "%s.bn%d" % (nm, i)))
+                if b == 0:
+                    self._set_conv_krsc(nm + ".downsample.0", to_krsc(sd[nm + ".downsample.0.weight"]),
+                                        *fold_frozen_batchnorm(sd, nm + ".downsample.1"))
+        for i in range(1, 5):
+            for k in ("inner", "layer"):
+                nm = "backbone.fpn.fpn_%s%d" % (k, i)
+                self._set_conv_krsc(nm, to_krsc(sd[nm + ".weight"]), None, sd[nm + ".bias"])
+        self._set_conv_krsc("rpn.head.conv", to_krsc(sd["rpn.head.conv.weight"]), None, sd["rpn.head.conv.bias"])
+        # fused 1x1: A objectness logits followed by A*4 deltas
+        wcb = np.concatenate([to_krsc(sd["rpn.head.cls_logits.weight"]), to_krsc(sd["rpn.head.bbox_pred.weight"])], 0)
+        bcb = np.concatenate([sd["rpn.head.cls_logits.bias"], sd["rpn.head.bbox_pred.bias"]])
+        self._set_conv_krsc("rpn.head.cls_bbox", wcb, None, bcb)
+        # FC6 consumes NHWC RoI features: permute its (c,h,w) input ordering to (h,w,c) -> a 7x7 'valid' conv
+        w6 = sd["roi_heads.box.feature_extractor.fc6.weight"].reshape(1024, 256, 7, 7).transpose(0, 2, 3, 1)
+        self._set_conv_krsc("roi_heads.box.feature_extractor.fc6", w6, None, sd["roi_heads.box.feature_extractor.fc6.bias"])
+        w7 = sd["roi_heads.box.feature_extractor.fc7.weight"].reshape(1024, 1, 1, 1024)
+        self._set_conv_krsc("roi_heads.box.feature_extractor.fc7", w7, None, sd["roi_heads.box.feature_extractor.fc7.bias"])
+        wp = np.concatenate([sd["roi_heads.box.predictor.cls_score.weight"], sd["roi_heads.box.predictor.bbox_pred.weight"]], 0)
+        bp = np.concatenate([sd["roi_heads.box.predictor.cls_score.bias"], sd["roi_heads.box.predictor.bbox_pred.bias"]])
+        self._set_conv_krsc("roi_heads.box.predictor.cls_bbox", wp.reshape(405, 1, 1, 1024), None, bp)
+        for i in range(1, 5):
+            nm = "roi_heads.mask.feature_extractor.mask_fcn%d" % i
+            self._set_conv_krsc(nm, to_krsc(sd[nm + ".weight"]), None, sd[nm + ".bias"])
+        wd = sd["roi_heads.mask.predictor.conv5_mask.weight"]  # [Cin][Cout][2][2]
+        for ab in range(4):
+            wab = np.ascontiguousarray(wd[:, :, ab >> 1, ab & 1].T).reshape(256, 1, 1, 256)
+            self._set_conv_krsc("roi_heads.mask.predictor.conv5_mask.%d" % ab, wab, None, sd["roi_heads.mask.predictor.conv5_mask.bias"])
+        self._set_tensor("mask_logits.w", sd["roi_heads.mask.predictor.mask_fcn_logits.weight"].reshape(81, 256).astype(np.float32))
+        self._set_tensor("mask_logits.b", sd["roi_heads.mask.predictor.mask_fcn_logits.bias"].astype(np.float32))
+        self.anchors = []
+        for l, ((gh, gw), stride, size) in enumerate(zip(level_shapes(self.H, self.W), cfg.ANCHOR_STRIDE, cfg.ANCHOR_SIZES)):
+            a = grid_anchors(gh, gw, stride, generate_anchors(stride, size, cfg.ASPECT_RATIOS))
+            self.anchors.append(a)
+            self._set_tensor("anchors.%d" % l, a)
+
+    # -- execution -----------------------------------------------------------------------------
+    def upload(self, batch_nhwc3, image_hw):
+        x = np.ascontiguousarray(batch_nhwc3, np.float32)
+        assert x.ndim == 4 and x.shape[1:] == (self.H, self.W, 3) and x.shape[0] <= self.max_batch, x.shape
+        _ffi.check(_ffi.lib().isegmi_h2d(self._d_in.ptr, x.ctypes.data_as(C.c_void_p), C.c_int64(x.nbytes)))
+        self._hw = np.ascontiguousarray(image_hw, np.int32).reshape(-1, 2)
+        assert self._hw.shape[0] == x.shape[0]
+        return x.shape[0]
+
+    def forward_device(self, n):
+        _ffi.check(_ffi.lib().isegmi_maskrcnn_forward(self._h, self._d_in.ptr, self._hw.ctypes.data_as(C.c_void_p), n))
+
+    def paste_device(self, out_h, out_w, orig_sizes_wh=None):
+        """Masker paste into (out_h, out_w); orig_sizes_wh [N,2] are the sizes boxes are resized to (default: no resize)."""
+        n = self._hw.shape[0]
+        if orig_sizes_wh is None:
+            ratios = np.ones((n, 2), np.float32)
+        else:
+            o = np.asarray(orig_sizes_wh, np.float64).reshape(n, 2)
+            ratios = np.stack([o[:, 0] / self._hw[:, 1], o[:, 1] / self._hw[:, 0]], 1).astype(np.float32)
+        _ffi.check(_ffi.lib().isegmi_maskrcnn_paste(self._h, ratios.ctypes.data_as(C.c_void_p), out_h, out_w))
+
+    def sync(self):
+        _ffi.check(_ffi.lib().isegmi_engine_sync(self._h))
+
+    fetch = None  # bound below (shared with Yolact)
+    timings = None
+
+    def __call__(self, batch_nhwc3, image_hw):
+        """-> list of BoxList (one per image, in network-input coordinates) with scores, labels, mask [n,1,28,28]."""
+        n = self.upload(batch_nhwc3, image_hw)
+        self.forward_device(n)
+        self.sync()
+        cnt = self.fetch("det.count", n)
+        box, score, label, m28 = (self.fetch(k, n) for k in ("det.box", "det.score", "det.label", "det.mask28"))
+        out = []
+        for i in range(n):
+            c = int(cnt[i])
+            bl = BoxList(box[i, :c], (int(self._hw[i, 1]), int(self._hw[i, 0])))
+            bl.add_field("scores", score[i, :c]); bl.add_field("labels", label[i, :c].astype(np.int64))
+            bl.add_field("mask", m28[i, :c, None])
+            out.append(bl)
+        return out
+
+    def close(self):
+        if self._h:
+            _ffi.lib().isegmi_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+from .yolact import Yolact as _Y  # noqa: E402
+
+MaskRCNN.fetch = _Y.fetch
+MaskRCNN.timings = _Y.timings

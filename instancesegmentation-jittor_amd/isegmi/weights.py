@@ -93,3 +93,50 @@ def fold_frozen_batchnorm(sd, prefix):
     m = sd[prefix + ".running_mean"].astype(np.float32); v = sd[prefix + ".running_var"].astype(np.float32)
     scale = (w * (np.float32(1.0) / np.sqrt(v))).astype(np.float32)
     return scale, (b - m * scale).astype(np.float32)
+
+
+# Recorded calibration of the Mask R-CNN predictors (found with the CPU oracle on the seeded image):
+# enough RPN proposals survive NMS and roughly 100 detections per image pass SCORE_THRESH 0.05.
+MRCNN_RPN_CLS_GAIN = 0.0012
+MRCNN_RPN_BBOX_GAIN = 0.0001
+MRCNN_CLS_GAIN = 0.0008
+MRCNN_BG_BIAS = 4.5
+MRCNN_BBOX_GAIN = 0.0002
+MRCNN_MASK_LOGIT_GAIN = 0.0005
+
+
+def maskrcnn_state_dict(seed=1234, depth=50):
+    """maskrcnn-benchmark e2e_mask_rcnn_R_50/101_FPN state-dict names."""
+    rng = np.random.default_rng(seed)
+    sd = {}
+    blocks = (3, 4, 23 if depth == 101 else 6, 3)
+    # ResNet body: same tensors as torchvision but under backbone.body.{stem,layerN}
+    tmp = {}
+    resnet_state_dict(rng, tmp, "", blocks=blocks)
+    for k, v in tmp.items():
+        if k.startswith("conv1.") or k.startswith("bn1."):
+            sd["backbone.body.stem." + k] = v
+        else:  # layers.L.B.xxx -> layer{L+1}.B.xxx
+            parts = k.split(".")
+            sd["backbone.body.layer%d.%s" % (int(parts[1]) + 1, ".".join(parts[2:]))] = v
+    for i, cin in enumerate((256, 512, 1024, 2048), 1):
+        _conv_bias(rng, sd, "backbone.fpn.fpn_inner%d" % i, 256, cin, 1)
+        _conv_bias(rng, sd, "backbone.fpn.fpn_layer%d" % i, 256, 256, 3)
+    _conv_bias(rng, sd, "rpn.head.conv", 256, 256, 3)
+    _conv_bias(rng, sd, "rpn.head.cls_logits", 3, 256, 1, gain=MRCNN_RPN_CLS_GAIN)
+    _conv_bias(rng, sd, "rpn.head.bbox_pred", 12, 256, 1, gain=MRCNN_RPN_BBOX_GAIN)
+
+    def fc(name, cout, cin, gain=1.0):
+        sd[name + ".weight"] = (rng.standard_normal((cout, cin)) * gain * np.sqrt(2.0 / cin)).astype(np.float32)
+        sd[name + ".bias"] = (rng.standard_normal(cout) * 0.01).astype(np.float32)
+    fc("roi_heads.box.feature_extractor.fc6", 1024, 256 * 7 * 7)
+    fc("roi_heads.box.feature_extractor.fc7", 1024, 1024)
+    fc("roi_heads.box.predictor.cls_score", 81, 1024, MRCNN_CLS_GAIN)
+    fc("roi_heads.box.predictor.bbox_pred", 324, 1024, MRCNN_BBOX_GAIN)
+    sd["roi_heads.box.predictor.cls_score.bias"][0] += MRCNN_BG_BIAS
+    for i in range(1, 5):
+        _conv_bias(rng, sd, "roi_heads.mask.feature_extractor.mask_fcn%d" % i, 256, 256, 3)
+    sd["roi_heads.mask.predictor.conv5_mask.weight"] = (rng.standard_normal((256, 256, 2, 2)) * np.sqrt(2.0 / 256)).astype(np.float32)
+    sd["roi_heads.mask.predictor.conv5_mask.bias"] = (rng.standard_normal(256) * 0.01).astype(np.float32)
+    _conv_bias(rng, sd, "roi_heads.mask.predictor.mask_fcn_logits", 81, 256, 1, gain=MRCNN_MASK_LOGIT_GAIN)
+    return sd

@@ -1,0 +1,160 @@
+"""CPU oracle of the Mask R-CNN R50/R101-FPN forward (TEST INFRASTRUCTURE ONLY).
+
+numpy graph over the C oracle ops.  Follows SURVEY.md Appendix A.2-A.8 ([UPSTREAM-RECALL] of
+facebookresearch/maskrcnn-benchmark, the lineage the reference names at README.md:358; the
+reference's detectron.jittor sources are absent -> PARITY UNPINNED).  Consumes the upstream-named
+state dict (OIHW conv weights, FrozenBN stats, [out,in] FC weights, [in,out,2,2] deconv) as is.
+"""
+import numpy as np
+
+from . import ora
+
+
+def _krsc(w):
+    return np.ascontiguousarray(np.transpose(np.asarray(w, np.float32), (0, 2, 3, 1)))
+
+
+def _frozen_bn(sd, p):
+    """FrozenBatchNorm2d (A.1): scale = w * rsqrt(var) (no eps); shift = b - mean*scale."""
+    w, b, m, v = (sd[p + k].astype(np.float32) for k in (".weight", ".bias", ".running_mean", ".running_var"))
+    scale = (w * (np.float32(1.0) / np.sqrt(v))).astype(np.float32)
+    return scale, (b - m * scale).astype(np.float32)
+
+
+def cell_anchors(stride, size, ratios=(0.5, 1.0, 2.0)):
+    """A.3 generate_anchors: ratio enumeration with np.round, then scale enumeration."""
+    def whctrs(a):
+        w = a[2] - a[0] + 1; h = a[3] - a[1] + 1
+        return w, h, a[0] + 0.5 * (w - 1), a[1] + 0.5 * (h - 1)
+
+    def mk(ws, hs, xc, yc):
+        return np.stack([xc - 0.5 * (ws - 1), yc - 0.5 * (hs - 1), xc + 0.5 * (ws - 1), yc + 0.5 * (hs - 1)], -1)
+    base = np.array([0, 0, stride - 1, stride - 1], np.float64)
+    w, h, xc, yc = whctrs(base)
+    out = []
+    for r in ratios:
+        ws = np.round(np.sqrt(w * h / r)); hs = np.round(ws * r)
+        a = mk(ws, hs, xc, yc)
+        w2, h2, xc2, yc2 = whctrs(a)
+        out.append(mk(w2 * (size / stride), h2 * (size / stride), xc2, yc2))
+    return np.asarray(out, np.float64).astype(np.float32)
+
+
+def grid_anchors(gh, gw, stride, cell):
+    out = np.empty((gh, gw, cell.shape[0], 4), np.float32)
+    for y in range(gh):
+        for x in range(gw):
+            sh = np.array([x * stride, y * stride, x * stride, y * stride], np.float32)
+            out[y, x] = sh[None, :] + cell
+    return out.reshape(-1, 4)
+
+
+class MaskRCNNRef:
+    def __init__(self, sd, depth=50, pre_nms=1000, post_nms=1000, fpn_post=1000, det_per_img=100, nms_ge=0):
+        self.sd, self.depth = sd, depth
+        self.pre_nms, self.post_nms, self.fpn_post, self.dpi, self.ge = pre_nms, post_nms, fpn_post, det_per_img, nms_ge
+        self.feats = {}
+
+    def _cbn(self, x, conv, bn, stride, pad, act, residual=None):
+        sc, sh = _frozen_bn(self.sd, bn)
+        return ora.conv2d(x, _krsc(self.sd[conv + ".weight"]), stride, pad, sc, sh, residual, act)
+
+    def _cb(self, x, name, stride, pad, act):
+        return ora.conv2d(x, _krsc(self.sd[name + ".weight"]), stride, pad, None, self.sd[name + ".bias"], None, act)
+
+    def forward(self, images_nhwc3, image_hw):
+        sd = self.sd
+        x = np.asarray(images_nhwc3, np.float32)
+        N = x.shape[0]
+        x4 = np.concatenate([x, np.zeros(x.shape[:3] + (1,), np.float32)], -1)
+        w1 = _krsc(sd["backbone.body.stem.conv1.weight"])
+        w1 = np.concatenate([w1, np.zeros(w1.shape[:3] + (1,), np.float32)], -1)
+        sc, sh = _frozen_bn(sd, "backbone.body.stem.bn1")
+        x = ora.maxpool(ora.conv2d(x4, w1, 2, 3, sc, sh, None, 1), 3, 2, 1)
+        Cs = []
+        for li, nb in enumerate((3, 4, 23 if self.depth == 101 else 6, 3), 1):
+            for b in range(nb):
+                nm = "backbone.body.layer%d.%d" % (li, b)
+                st = 2 if (b == 0 and li > 1) else 1
+                idt = self._cbn(x, nm + ".downsample.0", nm + ".downsample.1", st, 0, 0) if b == 0 else x
+                t = self._cbn(x, nm + ".conv1", nm + ".bn1", st, 0, 1)
+                t = self._cbn(t, nm + ".conv2", nm + ".bn2", 1, 1, 1)
+                x = self._cbn(t, nm + ".conv3", nm + ".bn3", 1, 0, 1, residual=idt)
+            Cs.append(x)
+        last = self._cb(Cs[3], "backbone.fpn.fpn_inner4", 1, 0, 0)
+        P = [None, None, None, self._cb(last, "backbone.fpn.fpn_layer4", 1, 1, 0)]
+        for l in (2, 1, 0):
+            lat = self._cb(Cs[l], "backbone.fpn.fpn_inner%d" % (l + 1), 1, 0, 0)
+            last = ora.upsample_nearest2x_add(last, lat)
+            P[l] = self._cb(last, "backbone.fpn.fpn_layer%d" % (l + 1), 1, 1, 0)
+        P.append(ora.maxpool(P[3], 1, 2, 0))
+        # RPN
+        strides, sizes = (4, 8, 16, 32, 64), (32, 64, 128, 256, 512)
+        props, pscores = [], []
+        lvl_out = [[] for _ in range(N)]
+        self.dbg = dict(rpn_logits=[], rpn_deltas=[], cls=[], reg=[], f7=[])
+        for l, p in enumerate(P):
+            t = self._cb(p, "rpn.head.conv", 1, 1, 1)
+            logits = self._cb(t, "rpn.head.cls_logits", 1, 0, 0)  # [N,H,W,A]
+            deltas = self._cb(t, "rpn.head.bbox_pred", 1, 0, 0)   # [N,H,W,A*4]
+            anc = grid_anchors(p.shape[1], p.shape[2], strides[l], cell_anchors(strides[l], sizes[l]))
+            self.dbg['rpn_logits'].append(logits); self.dbg['rpn_deltas'].append(deltas)
+            for n in range(N):
+                b, s = ora.rpn_level(logits[n].reshape(-1), deltas[n].reshape(-1, 4), anc, self.pre_nms, self.post_nms, 0.7, 0.0,
+                                     float(image_hw[n][1]), float(image_hw[n][0]), self.ge)
+                lvl_out[n].append((b, s))
+        for n in range(N):
+            b = np.concatenate([q[0] for q in lvl_out[n]], 0); s = np.concatenate([q[1] for q in lvl_out[n]], 0)
+            ts, ti = ora.topk(s, min(self.fpn_post, len(s)))
+            props.append(b[ti]); pscores.append(ts)
+        # box head
+        dets = []
+        w6 = sd["roi_heads.box.feature_extractor.fc6.weight"].astype(np.float32)
+        w7 = sd["roi_heads.box.feature_extractor.fc7.weight"].astype(np.float32)
+        for n in range(N):
+            pr = props[n]
+            R = pr.shape[0]
+            lv = ora.level_map(pr)
+            feat = np.zeros((R, 7, 7, 256), np.float32)
+            for k in range(2, 6):
+                idx = np.nonzero(lv == k)[0]
+                if len(idx) == 0:
+                    continue
+                rois = np.concatenate([np.full((len(idx), 1), n, np.float32), pr[idx]], 1)
+                feat[idx] = ora.roi_align(P[k - 2], rois, 1.0 / strides[k - 2], 7, 7, 2)
+            # FC6 on the flattened (C,H,W) vector == 7x7 valid conv with weights permuted to (H,W,C)
+            w6k = np.ascontiguousarray(w6.reshape(1024, 256, 7, 7).transpose(0, 2, 3, 1))
+            f6 = ora.conv2d(feat, w6k, 1, 0, None, sd["roi_heads.box.feature_extractor.fc6.bias"], None, 1)
+            f7 = ora.conv2d(f6, w7.reshape(1024, 1, 1, 1024), 1, 0, None, sd["roi_heads.box.feature_extractor.fc7.bias"], None, 1)
+            cls = ora.conv2d(f7, sd["roi_heads.box.predictor.cls_score.weight"].reshape(81, 1, 1, 1024), 1, 0, None,
+                             sd["roi_heads.box.predictor.cls_score.bias"], None, 0).reshape(R, 81)
+            reg = ora.conv2d(f7, sd["roi_heads.box.predictor.bbox_pred.weight"].reshape(324, 1, 1, 1024), 1, 0, None,
+                             sd["roi_heads.box.predictor.bbox_pred.bias"], None, 0).reshape(R, 324)
+            self.dbg['cls'].append(cls); self.dbg['reg'].append(reg); self.dbg['f7'].append(f7)
+            db, ds, dl = ora.box_postprocess(cls, reg, pr, float(image_hw[n][1]), float(image_hw[n][0]), 0.05, 0.5, self.dpi, self.ge, self.dpi)
+            # mask head
+            D = db.shape[0]
+            m28 = np.zeros((D, 28, 28), np.float32)
+            if D:
+                lv = ora.level_map(db)
+                mf = np.zeros((D, 14, 14, 256), np.float32)
+                for k in range(2, 6):
+                    idx = np.nonzero(lv == k)[0]
+                    if len(idx) == 0:
+                        continue
+                    rois = np.concatenate([np.full((len(idx), 1), n, np.float32), db[idx]], 1)
+                    mf[idx] = ora.roi_align(P[k - 2], rois, 1.0 / strides[k - 2], 14, 14, 2)
+                for i in range(1, 5):
+                    mf = self._cb(mf, "roi_heads.mask.feature_extractor.mask_fcn%d" % i, 1, 1, 1)
+                up = ora.deconv2x2(mf, sd["roi_heads.mask.predictor.conv5_mask.weight"], sd["roi_heads.mask.predictor.conv5_mask.bias"], 1)
+                m28 = ora.mask_logits_select(up.reshape(D, 784, 256), sd["roi_heads.mask.predictor.mask_fcn_logits.weight"].reshape(81, 256),
+                                             sd["roi_heads.mask.predictor.mask_fcn_logits.bias"], dl).reshape(D, 28, 28)
+            dets.append(dict(box=db, score=ds, label=dl, mask28=m28, proposals=pr, proposal_scores=pscores[n]))
+        self.feats = dict(C2=Cs[0], C5=Cs[3], P2=P[0], P3=P[1], P4=P[2], P5=P[3], P6=P[4])
+        return dets
+
+    @staticmethod
+    def paste(det, out_h, out_w, ratio_wh=(1.0, 1.0), thr=0.5):
+        r = np.array([ratio_wh[0], ratio_wh[1], ratio_wh[0], ratio_wh[1]], np.float32)
+        boxes = (det["box"] * r).astype(np.float32)
+        return ora.paste_masks(det["mask28"], boxes, out_h, out_w, thr), boxes

@@ -1,0 +1,136 @@
+"""Mask R-CNN RoI kernels vs the CPU oracle: indices, boxes, scores, features, masks all bit-exact."""
+import numpy as np
+import pytest
+
+from oracle import ora
+
+pytestmark = pytest.mark.gpu
+
+
+def _boxes(rng, n, W=1333, H=800, clustered=True):
+    c = rng.uniform(0, 1, (n, 2)) * [W, H]
+    if clustered:
+        c[n // 2:] = c[: n - n // 2] + rng.normal(0, 6, (n - n // 2, 2))
+    wh = np.exp(rng.uniform(np.log(16), np.log(512), (n, 2)))
+    b = np.concatenate([c - wh / 2, c + wh / 2], 1)
+    return np.clip(b, 0, [W - 1, H - 1, W - 1, H - 1]).astype(np.float32)
+
+
+@pytest.mark.parametrize("n", [3, 64, 200, 1000])
+@pytest.mark.parametrize("plus_one,ge", [(1, 0), (1, 1), (0, 0)])
+def test_nms_matches_oracle(ffi, n, plus_one, ge):
+    rng = np.random.default_rng(n + plus_one * 10 + ge)
+    P = 4
+    boxes = np.stack([_boxes(rng, n) for _ in range(P)])
+    scores = rng.uniform(0, 1, (P, n)).astype(np.float32)
+    scores[:, ::7] = scores[:, :1]  # ties
+    for thr, mk in ((0.7, 0), (0.5, 0), (0.5, max(1, n // 3))):
+        got = ffi.nms(boxes, scores, thr, plus_one, ge, mk)
+        for p in range(P):
+            ref = ora.nms(boxes[p], scores[p], thr, plus_one, ge, mk)
+            assert np.array_equal(got[p], ref), (p, thr, mk)
+
+
+def test_nms_known_answers(ffi):
+    # App. A.6 KATs: identical boxes; IoU exactly == thr; chain where a suppressed box must not suppress.
+    b = np.array([[[0, 0, 9, 9], [0, 0, 9, 9], [0, 0, 9, 4], [100, 100, 120, 120]]], np.float32)
+    s = np.array([[0.9, 0.8, 0.7, 0.6]], np.float32)
+    assert list(ffi.nms(b, s, 0.5, 1, 0)[0]) == [0, 2, 3]  # iou(0,2) = 50/100 = 0.5, not > 0.5
+    assert list(ffi.nms(b, s, 0.5, 1, 1)[0]) == [0, 3]     # >= suppresses it
+    chain = np.array([[[0, 0, 99, 99], [0, 0, 99, 59], [0, 0, 99, 35]]], np.float32)  # A-B .6, B-C .6, A-C .36
+    assert list(ffi.nms(chain, np.array([[0.9, 0.8, 0.7]], np.float32), 0.5, 1, 0)[0]) == [0, 2]
+
+
+def test_roi_align_matches_oracle(ffi):
+    rng = np.random.default_rng(11)
+    N, K, Cc = 2, 150, 64
+    shapes = [(50, 84), (25, 42), (13, 21), (7, 11)]
+    feats = [rng.standard_normal((N, h, w, Cc)).astype(np.float32) for h, w in shapes]
+    scales = [0.25, 0.125, 0.0625, 0.03125]
+    rois = np.stack([_boxes(rng, K, 336, 200, False) for _ in range(N)])
+    rois[0, 0] = [-50, -40, -10, -5]        # fully outside -> zeros
+    rois[0, 1] = [10, 10, 10.2, 10.1]       # tiny -> roi size clamp to 1
+    rois[1, 2] = [0, 0, 335, 199]
+    counts = np.array([K, 97], np.int32)
+    for PH in (7, 14):
+        out, lv = ffi.roi_align(feats, scales, rois, counts, PH, PH)
+        out = out.reshape(N, K, PH, PH, Cc)
+        for n in range(N):
+            k = counts[n]
+            ref_lv = ora.level_map(rois[n, :k])
+            assert np.array_equal(lv[n, :k], ref_lv)
+            for L in range(2, 6):
+                idx = np.nonzero(ref_lv == L)[0]
+                if len(idx) == 0:
+                    continue
+                r5 = np.concatenate([np.full((len(idx), 1), n, np.float32), rois[n, idx]], 1)
+                ref = ora.roi_align(feats[L - 2], r5, scales[L - 2], PH, PH, 2)
+                assert np.array_equal(out[n, idx], ref), (PH, n, L)
+            assert not out[n, k:].any()
+    # known answers: constant map -> constant; ramp f[y,x]=x -> sample-x mean
+    const = [np.full((1, 20, 30, 4), 3.5, np.float32)]
+    o, _ = ffi.roi_align(const, [0.5], np.array([[[4, 6, 30, 28]]], np.float32), np.array([1], np.int32), 7, 7, fixed_level=0)
+    assert np.all(o == 3.5)
+
+
+def test_rpn_level_matches_oracle(ffi):
+    from isegmi.maskrcnn import generate_anchors, grid_anchors
+    rng = np.random.default_rng(5)
+    N, H, W, A = 2, 40, 56, 3
+    head = np.concatenate([rng.normal(-2, 2, (N, H, W, A)), rng.normal(0, 0.3, (N, H, W, 4 * A))], -1).astype(np.float32)
+    head[0, :4, :4, :A] = 1.25  # ties in the top-k
+    anchors = grid_anchors(H, W, 8, generate_anchors(8, 64, (0.5, 1.0, 2.0)))
+    hw = np.array([[300, 440], [320, 448]], np.int32)
+    for pre, post in ((1000, 1000), (300, 50)):
+        got = ffi.rpn_level(head, anchors, hw, A, pre, post)
+        for n in range(N):
+            rb, rs = ora.rpn_level(head[n, ..., :A].reshape(-1), head[n, ..., A:].reshape(-1, 4), anchors, pre, post, 0.7, 0.0,
+                                   float(hw[n, 1]), float(hw[n, 0]))
+            assert np.array_equal(got[n][1], rs) and np.array_equal(got[n][0], rb), (pre, n)
+            assert len(rs) > 10
+
+
+def test_box_postprocess_matches_oracle(ffi):
+    rng = np.random.default_rng(9)
+    N, R, ncls = 2, 1000, 81
+    logits = rng.normal(0, 1.0, (N, R, ncls)).astype(np.float32)
+    logits[..., 0] += 2.0
+    logits[..., [7, 31, 56]] += 2.5
+    regr = rng.normal(0, 0.5, (N, R, 4 * ncls)).astype(np.float32)
+    props = np.stack([_boxes(rng, R) for _ in range(N)])
+    cnt = np.array([R, 613], np.int32)
+    hw = np.array([[800, 1333], [750, 1200]], np.int32)
+    got = ffi.box_postprocess(logits, regr, props, cnt, hw)
+    for n in range(N):
+        k = cnt[n]
+        rb, rs, rl = ora.box_postprocess(logits[n, :k], regr[n, :k], props[n, :k], float(hw[n, 1]), float(hw[n, 0]), cap=100)
+        assert len(rs) == 100
+        assert np.array_equal(got[n][2], rl) and np.array_equal(got[n][1], rs) and np.array_equal(got[n][0], rb)
+    # fewer than det_per_img survivors: everything kept, order preserved
+    logits2 = logits.copy(); logits2[..., 0] += 6.0
+    got = ffi.box_postprocess(logits2, regr, props, cnt, hw)
+    for n in range(N):
+        k = cnt[n]
+        rb, rs, rl = ora.box_postprocess(logits2[n, :k], regr[n, :k], props[n, :k], float(hw[n, 1]), float(hw[n, 0]), cap=100)
+        assert 0 < len(rs) < 100
+        assert np.array_equal(got[n][2], rl) and np.array_equal(got[n][1], rs) and np.array_equal(got[n][0], rb)
+
+
+def test_mask_tail_and_paste_match_oracle(ffi):
+    rng = np.random.default_rng(13)
+    R, HW, Cc = 37, 784, 256
+    feat = np.maximum(rng.standard_normal((R, HW, Cc)), 0).astype(np.float32)
+    w = (rng.standard_normal((81, Cc)) * 0.1).astype(np.float32); b = rng.standard_normal(81).astype(np.float32)
+    labels = rng.integers(1, 81, R).astype(np.int32)
+    got = ffi.mask_logits_select(feat, w, b, labels)
+    assert np.array_equal(got, ora.mask_logits_select(feat, w, b, labels))
+    N, K, im_h, im_w = 2, 20, 203, 317
+    masks = rng.uniform(0, 1, (N, K, 28, 28)).astype(np.float32)
+    boxes = np.stack([_boxes(rng, K, im_w, im_h, False) for _ in range(N)])
+    boxes[0, 0] = [-30.5, -20.2, 40.7, 60.1]; boxes[0, 1] = [250.3, 150.9, 400.0, 300.0]; boxes[0, 2] = [10, 10, 10.4, 10.2]
+    cnt = np.array([K, 11], np.int32)
+    out = ffi.paste_masks(masks, boxes, cnt, im_h, im_w)
+    for n in range(N):
+        ref = ora.paste_masks(masks[n, : cnt[n]], boxes[n, : cnt[n]], im_h, im_w)
+        assert np.array_equal(out[n, : cnt[n]], ref)
+        assert not out[n, cnt[n]:].any()
