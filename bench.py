@@ -34,8 +34,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
-    ap.add_argument("--model", default="yolact", choices=["yolact"])
+    ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (default 8 yolact, 2 maskrcnn)")
+    ap.add_argument("--model", default="yolact", choices=["yolact", "maskrcnn"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8, help="images the CPU oracle is timed on")
     ap.add_argument("--no-latency", action="store_true", help="skip the extra bs=1 latency pass")
@@ -44,6 +44,9 @@ def parse():
 
 def main():
     a = parse()
+    if a.model == "maskrcnn":
+        return main_maskrcnn(a)
+    a.batch = a.batch or 8
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -212,6 +215,101 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main_maskrcnn(a):
+    """Mask R-CNN R50-FPN 1333x800 (padded 800x1344), bs=2 per GPU: BASELINE configs[2]; step = forward + Masker paste."""
+    import ctypes as C
+    a.batch = a.batch or 2
+    rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from isegmi import _ffi
+    from isegmi.maskrcnn import MaskRCNN, prepare_images
+    from isegmi.weights import maskrcnn_state_dict
+    if _ffi.device_count() < 1:
+        raise SystemExit("no HIP device visible: bench.py measures the HIP path only (no CPU fallback)")
+    sd = maskrcnn_state_dict(1234)
+    rng = np.random.default_rng(20261003 + rank)
+    imgs = [rng.uniform(0, 255, (800, 1333, 3)).astype(np.float32) for _ in range(a.batch)]
+    x, hw = prepare_images(imgs)
+    model = MaskRCNN(sd, x.shape[1], x.shape[2], max_batch=a.batch, device=local_rank)
+    model.upload(x, hw)
+
+    def step():
+        model.forward_device(a.batch)
+        model.paste_device(800, 1333)
+
+    for _ in range(a.warmup):
+        step()
+    model.sync(); _ffi.sync()
+    model.set_param("conv_timing", 1.0)
+    f, m, l = C.c_double(), C.c_double(), C.c_int64()
+    _ffi.check(_ffi.lib().isegmi_engine_conv_stats(model._h, C.byref(f), C.byref(m), C.byref(l)))
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    model.sync(); _ffi.sync()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        te = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    _ffi.check(_ffi.lib().isegmi_engine_conv_stats(model._h, C.byref(f), C.byref(m), C.byref(l)))
+    model.set_param("conv_timing", 0.0)
+    if rank == 0:
+        achieved = f.value / (m.value * 1e-3) / 1e12 if m.value > 0 else 0.0
+        cnt = model.fetch("det.count", a.batch); pc = model.fetch("proposal_count", a.batch)
+        out = {"metric": "images/sec (Mask R-CNN R50-FPN 1333x800, bs=%d per GPU, fp32)" % a.batch,
+               "value": round(a.batch * world * a.steps / elapsed, 3), "unit": "img/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "Mask R-CNN R50-FPN 1333x800 (padded 800x1344) bs=%d/GPU random weights: backbone+FPN+RPN+RoIAlign+box head+NMS+mask head+paste (BASELINE configs[2])" % a.batch,
+                          "global_batch": a.batch * world, "parallelism": "batch-sharded x%d" % world,
+                          "proposals_per_image": [int(c) for c in pc], "detections_per_image": [int(c) for c in cnt]},
+               "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel (all conv launches of a step)", "achieved": round(achieved, 2),
+                            "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                            "algorithmic_gflop_per_step": round(f.value / a.steps / 1e9, 2), "conv_ms_per_step": round(m.value / a.steps, 3),
+                            "launches_per_step": l.value // a.steps, "avg_launch_us": round(m.value * 1e3 / max(l.value, 1), 2)},
+               "p50_ms_per_image": round(elapsed / a.steps * 1e3 / a.batch, 3)}
+        if not a.no_latency:
+            lat = []
+            model.upload(x[:1], hw[:1])
+            for i in range(9):
+                model.sync(); ts = time.perf_counter()
+                model.forward_device(1); model.paste_device(800, 1333); model.sync()
+                lat.append((time.perf_counter() - ts) * 1e3)
+            lat = sorted(lat[2:])
+            out["bs1"] = {"p50_ms_per_image": round(lat[len(lat) // 2], 3), "img_per_s": round(1e3 / lat[len(lat) // 2], 2)}
+            model.upload(x, hw)
+            model.set_param("timing", 1.0)
+            step(); model.sync()
+            out["stage_ms_bs%d" % a.batch] = {k: round(v, 3) for k, v in model.timings()}
+            model.set_param("timing", 0.0)
+        if world == 1 and not a.no_cpu_baseline:
+            from oracle.maskrcnn_ref import MaskRCNNRef
+            ncpu = min(len(os.sched_getaffinity(0)), 16)
+            os.environ["OMP_NUM_THREADS"] = str(ncpu)
+            ref = MaskRCNNRef(sd)
+            tc = time.perf_counter()
+            d = ref.forward(x[:1], hw[:1])
+            MaskRCNNRef.paste(d[0], 800, 1333)
+            tcpu = time.perf_counter() - tc
+            out["cpu_baseline"] = {"value": round(1 / tcpu, 4), "unit": "img/s", "cores": ncpu, "kind": "port",
+                                   "sample": "1 image of the bench batch, oracle/ C+numpy restatement (AVX2 FMA + OpenMP, %d threads), %.1f s" % (ncpu, tcpu)}
+            got = model.fetch("det.box", 1)[0]
+            out["parity_vs_oracle_on_bench_batch"] = bool(np.array_equal(got[: len(d[0]["box"])], d[0]["box"]))
+        print(json.dumps(out), flush=True)
+    model.close()
+    if dist is not None:
+        dist.barrier(); dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,134 @@
+"""Host-side logic (no GPU): priors, anchors, image preparation, BoxList, record packing, batch sharding,
+and a world_size-2 gloo run of the multi-rank detection gather."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_yolact_priors_match_oracle_and_count():
+    from isegmi.yolact import YolactConfig, _level_sizes, make_priors
+    from oracle.yolact_ref import make_priors as ref_priors
+    cfg = YolactConfig()
+    sizes = _level_sizes(550)
+    assert sizes == [69, 35, 18, 9, 5]
+    tot = 0
+    for s, sc in zip(sizes, cfg.pred_scales):
+        a = make_priors(s, s, sc, 550, cfg.pred_aspect_ratios); b = ref_priors(s, s, sc, 550)
+        assert np.array_equal(a, b)
+        tot += len(a)
+    assert tot == 19248
+
+
+def test_maskrcnn_anchors_and_shapes():
+    from isegmi.maskrcnn import generate_anchors, grid_anchors, level_shapes
+    from oracle.maskrcnn_ref import cell_anchors, grid_anchors as ref_grid
+    assert level_shapes(800, 1344) == [(200, 336), (100, 168), (50, 84), (25, 42), (13, 21)]
+    assert sum(h * w * 3 for h, w in level_shapes(800, 1344)) == 268569
+    for stride, size in zip((4, 8, 16, 32, 64), (32, 64, 128, 256, 512)):
+        a = generate_anchors(stride, size, (0.5, 1.0, 2.0))
+        assert np.array_equal(a, cell_anchors(stride, size))
+        assert np.array_equal(grid_anchors(3, 4, stride, a), ref_grid(3, 4, stride, a))
+    assert np.array_equal(generate_anchors(16, 128, (0.5, 1.0, 2.0))[1], [-56, -56, 71, 71])
+
+
+def test_prepare_images_and_boxlist():
+    from isegmi.maskrcnn import PIXEL_MEAN, BoxList, prepare_images
+    ims = [np.full((30, 50, 3), 128, np.float32), np.full((40, 33, 3), 10, np.float32)]
+    x, hw = prepare_images(ims)
+    assert x.shape == (2, 64, 64, 3) and hw.tolist() == [[30, 50], [40, 33]]
+    assert np.allclose(x[0, 0, 0], 128 - np.asarray(PIXEL_MEAN, np.float32)) and not x[0, 30:].any() and not x[1, :, 33:].any()
+    bl = BoxList(np.array([[10, 20, 30, 40]], np.float32), (100, 50))
+    bl.add_field("scores", np.array([0.9], np.float32))
+    r = bl.resize((200, 150))
+    assert np.allclose(r.bbox, [[20, 60, 60, 120]]) and r.size == (200, 150) and r.get_field("scores")[0] == np.float32(0.9)
+    assert len(bl[np.array([False])]) == 0
+
+
+def test_bn_folding_matches_oracle_formulae():
+    from isegmi.weights import fold_batchnorm, fold_frozen_batchnorm, yolact_state_dict
+    from oracle.maskrcnn_ref import _frozen_bn
+    from oracle.yolact_ref import _fold_bn
+    sd = yolact_state_dict(7)
+    a = fold_batchnorm(sd, "backbone.bn1"); b = _fold_bn(sd, "backbone.bn1")
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    a = fold_frozen_batchnorm(sd, "backbone.bn1"); b = _frozen_bn(sd, "backbone.bn1")
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_record_pack_roundtrip_and_sharding():
+    from isegmi.dist import pack_records, record_bytes, shard_batch, unpack_records
+    rng = np.random.default_rng(0)
+    n, K = 3, 100
+    rec = dict(count=rng.integers(0, 101, n).astype(np.int32), box=rng.standard_normal((n, K, 4)).astype(np.float32),
+               score=rng.uniform(0, 1, (n, K)).astype(np.float32), cls=rng.integers(0, 80, (n, K)).astype(np.int32),
+               coeff=rng.standard_normal((n, K, 32)).astype(np.float32))
+    buf = pack_records(rec["count"], rec["box"], rec["score"], rec["cls"], rec["coeff"])
+    assert buf.nbytes == record_bytes(n)
+    back = unpack_records(buf, n)
+    assert all(np.array_equal(back[k], rec[k]) for k in rec)
+    for world in (1, 2, 3, 8):
+        spans = [shard_batch(16, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == 16 and all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+        assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+    assert [shard_batch(5, r, 2) for r in range(2)] == [(0, 3), (3, 5)]
+
+
+WORKER = r'''
+import os, sys
+sys.path[:0] = [sys.argv[1], os.path.join(sys.argv[1], "instancesegmentation-jittor_amd")]
+import numpy as np, torch, torch.distributed as dist
+from isegmi.dist import pack_records, unpack_records, shard_batch, gather_records
+from oracle import ora
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+GLOBAL, K, P = 6, 100, 400
+def detect_image(i):   # the oracle stands in for the device path: same record layout
+    rng = np.random.default_rng(1000 + i)
+    conf = rng.standard_normal((P, 81)).astype(np.float32); conf[:, 0] += 3; conf[rng.integers(0, P, 40), rng.integers(1, 81, 40)] += 7
+    pri = np.concatenate([rng.uniform(0.1, 0.9, (P, 2)), rng.uniform(0.05, 0.4, (P, 2))], 1).astype(np.float32)
+    loc = (rng.standard_normal((P, 4)) * 0.5).astype(np.float32); msk = np.tanh(rng.standard_normal((P, 32))).astype(np.float32)
+    return ora.yolact_detect(ora.softmax(conf), ora.yolact_decode(loc, pri), msk)
+def records(lo, hi):
+    n = hi - lo
+    cnt = np.zeros(n, np.int32); box = np.zeros((n, K, 4), np.float32); sc = np.zeros((n, K), np.float32)
+    cl = np.full((n, K), -1, np.int32); co = np.zeros((n, K, 32), np.float32)
+    for j, i in enumerate(range(lo, hi)):
+        d = detect_image(i); c = len(d["score"]); cnt[j] = c
+        box[j, :c] = d["box"]; sc[j, :c] = d["score"]; cl[j, :c] = d["cls"]; co[j, :c] = d["mask"]
+    return pack_records(cnt, box, sc, cl, co)
+lo, hi = shard_batch(GLOBAL, rank, world)
+mine = records(lo, hi)
+def allgather(buf):
+    t = torch.from_numpy(buf.copy()); outs = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(outs, t)
+    return [o.numpy() for o in outs]
+parts = gather_records(mine, world, allgather)
+full = unpack_records(records(0, GLOBAL), GLOBAL)
+off = 0
+for r in range(world):
+    a, b = shard_batch(GLOBAL, r, world)
+    got = unpack_records(parts[r], b - a)
+    for k in got:
+        assert np.array_equal(got[k], full[k][a:b]), (rank, r, k)
+    off += b - a
+assert off == GLOBAL
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_world2_gloo_detection_gather(tmp_path):
+    pytest.importorskip("torch")
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29617", str(script), ROOT]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout

@@ -1,0 +1,168 @@
+"""CPU tests of the oracle: hand-derived known answers, cross-checks against torch-CPU /
+numpy where an independent implementation exists, and the committed golden vectors (drift guard)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ora
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def gold(name):
+    return np.load(os.path.join(G, name + ".npz"))
+
+
+def test_detmath_accuracy():
+    x = np.linspace(-30, 30, 20001).astype(np.float32)
+    x64 = x.astype(np.float64)
+    assert np.max(np.abs(ora.map_f32(x, 0) / np.exp(x64) - 1)) < 2.5e-7
+    assert np.max(np.abs(ora.map_f32(x, 1) - 1 / (1 + np.exp(-x64)))) < 1.5e-7
+    assert np.max(np.abs(ora.map_f32(x, 2) - np.tanh(x64))) < 2e-7
+    xp = np.abs(x) + 1e-4
+    assert np.max(np.abs(ora.map_f32(xp, 3) - np.log2(xp.astype(np.float64)))) < 1e-6
+    assert ora.map_f32(np.array([-200.0], np.float32), 0)[0] == 0.0 and ora.map_f32(np.array([0.0], np.float32), 0)[0] == 1.0
+
+
+def test_conv_vs_torch_and_fma_chain():
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((2, 10, 13, 32)).astype(np.float32); w = (rng.standard_normal((24, 3, 3, 32)) * 0.1).astype(np.float32)
+    for stride, pad in ((1, 1), (2, 1), (1, 0)):
+        y = ora.conv2d(x, w, stride, pad)
+        t = torch.nn.functional.conv2d(torch.from_numpy(x).permute(0, 3, 1, 2).double(), torch.from_numpy(w).permute(0, 3, 1, 2).double(),
+                                       stride=stride, padding=pad).permute(0, 2, 3, 1).numpy()
+        assert np.max(np.abs(y - t)) < 2e-5
+    # the documented rounding sequence: k-ordered fmaf chain over (r, s, c) from +0
+    y = ora.conv2d(x, w, 1, 1)
+    xp = np.pad(x, ((0, 0), (1, 1), (1, 1), (0, 0)))
+    import math
+    for (n, ho, wo, co) in ((0, 0, 0, 0), (1, 4, 7, 13), (1, 9, 12, 23)):
+        acc = np.float32(0)
+        for r in range(3):
+            for s in range(3):
+                for c in range(32):
+                    a, b = float(xp[n, ho + r, wo + s, c]), float(w[co, r, s, c])
+                    acc = np.float32(math.fma(a, b, float(acc))) if hasattr(math, "fma") else np.float32(np.float64(a) * np.float64(b) + np.float64(acc))
+        assert y[n, ho, wo, co] == acc
+
+
+def test_pool_resize_deconv_vs_torch():
+    torch = pytest.importorskip("torch")
+    F = torch.nn.functional
+    rng = np.random.default_rng(1)
+    a = rng.standard_normal((2, 19, 23, 8)).astype(np.float32)
+    t = torch.from_numpy(a).permute(0, 3, 1, 2)
+    assert np.array_equal(ora.maxpool(a, 3, 2, 1), F.max_pool2d(t, 3, 2, 1).permute(0, 2, 3, 1).numpy())
+    assert np.array_equal(ora.maxpool(a, 1, 2, 0), a[:, ::2, ::2])
+    y = ora.resize_bilinear(a, 35, 41)
+    assert np.max(np.abs(y - F.interpolate(t, size=(35, 41), mode="bilinear", align_corners=False).permute(0, 2, 3, 1).numpy())) < 1e-5
+    lat = rng.standard_normal((2, 38, 46, 8)).astype(np.float32)
+    assert np.array_equal(ora.upsample_nearest2x_add(a, lat), lat + np.repeat(np.repeat(a, 2, 1), 2, 2))
+    wd = rng.standard_normal((8, 6, 2, 2)).astype(np.float32); b = rng.standard_normal(6).astype(np.float32)
+    ref = torch.relu(F.conv_transpose2d(t, torch.from_numpy(wd), torch.from_numpy(b), stride=2)).permute(0, 2, 3, 1).numpy()
+    assert np.max(np.abs(ora.deconv2x2(a, wd, b, 1) - ref)) < 1e-5
+
+
+def test_topk_total_order():
+    s = np.array([0.5, 0.9, 0.5, 0.1, 0.9, 0.5], np.float32)
+    v, i = ora.topk(s, 4)
+    assert list(i) == [1, 4, 0, 2] and list(v) == [np.float32(0.9)] * 2 + [np.float32(0.5)] * 2
+    v, i = ora.topk(s, 10)
+    assert list(i) == [1, 4, 0, 2, 5, 3]
+
+
+def test_nms_known_answers():
+    b = np.array([[0, 0, 9, 9], [0, 0, 9, 9], [0, 0, 9, 4], [100, 100, 120, 120]], np.float32)
+    s = np.array([0.9, 0.8, 0.7, 0.6], np.float32)
+    assert list(ora.nms(b, s, 0.5, 1, 0)) == [0, 2, 3]   # IoU(0,2) = 50/100 exactly = thr: '>' keeps it
+    assert list(ora.nms(b, s, 0.5, 1, 1)) == [0, 3]      # '>=' suppresses it
+    chain = np.array([[0, 0, 99, 99], [0, 0, 99, 59], [0, 0, 99, 35]], np.float32)
+    assert list(ora.nms(chain, np.array([0.9, 0.8, 0.7], np.float32), 0.5, 1, 0)) == [0, 2]  # suppressed B must not suppress C
+    assert list(ora.nms(b, s[::-1].copy(), 0.5, 1, 0)) == [3, 2, 1]  # visiting order follows the scores
+    assert list(ora.nms(b, s, 0.5, 1, 0, max_keep=2)) == [0, 2]
+
+
+def test_box_decode_known_answer():
+    a = np.array([[0, 0, 9, 19]], np.float32)  # w=10 h=20 ctr (5,10)
+    d = np.array([[0.1, -0.1, 0.0, np.log(2.0)]], np.float32)
+    o = ora.decode_boxes(a, d, (1, 1, 1, 1), 1000, 1000, clip=False)[0]
+    assert np.allclose(o, [6 - 5, 8 - 20, 6 + 5 - 1, 8 + 20 - 1], atol=1e-4)
+    big = ora.decode_boxes(a, np.array([[0, 0, 50.0, 50.0]], np.float32), (1, 1, 1, 1), 100, 100, clip=True)[0]
+    assert np.array_equal(big, [0, 0, 99, 99])  # dw clamp log(1000/16) then clip to (w-1,h-1)
+
+
+def test_roi_align_known_answers():
+    const = np.full((1, 20, 30, 3), 2.25, np.float32)
+    r = np.array([[0, 4, 6, 30, 28]], np.float32)
+    assert np.allclose(ora.roi_align(const, r, 0.5, 7, 7, 2), 2.25, atol=1e-6)
+    ramp = np.tile(np.arange(30, dtype=np.float32)[None, None, :, None], (1, 30, 1, 1))
+    o = ora.roi_align(ramp, np.array([[0, 8, 8, 24, 24]], np.float32), 1.0, 4, 4, 2)[0, :, :, 0]
+    # bin width 4, samples at x = 8 + 4*pw + {1, 3} -> mean = 10 + 4*pw
+    assert np.allclose(o, np.tile(10 + 4 * np.arange(4, dtype=np.float32), (4, 1)), atol=1e-5)
+    assert not ora.roi_align(ramp, np.array([[0, -50, -40, -10, -5]], np.float32), 1.0, 7, 7, 2).any()
+    assert list(ora.level_map(np.array([[0, 0, 223, 223], [0, 0, 111, 111], [0, 0, 10, 10], [0, 0, 1000, 1000]], np.float32))) == [4, 3, 2, 5]
+
+
+def test_yolact_decode_and_fast_nms_known_answers():
+    pri = np.array([[0.5, 0.5, 0.2, 0.2]], np.float32)
+    assert np.allclose(ora.yolact_decode(np.zeros((1, 4), np.float32), pri), [[0.4, 0.4, 0.6, 0.6]], atol=1e-7)
+    # three priors of class 1: A and B overlap heavily (B dropped), C suppressed only by B in greedy NMS but fast-NMS drops it too
+    boxes = np.array([[0, 0, 1, 1], [0, 0, 1, 0.9], [0, 0, 1, 0.5]], np.float32)  # iou(A,B)=.9 iou(A,C)=.5 iou(B,C)=.556
+    conf = np.zeros((3, 3), np.float32); conf[:, 1] = [0.9, 0.8, 0.7]; conf[:, 0] = 0.05; conf[:, 2] = 0.01
+    d = ora.yolact_detect(conf, boxes, np.zeros((3, 4), np.float32), 0.05, 0.5, 200, 100)
+    keep1 = d["prior"][d["cls"] == 0]
+    assert list(keep1) == [0]  # C has iou .556 > .5 with the (already suppressed) B: fast-NMS still removes it
+    empty = ora.yolact_detect(np.tile(np.array([[0.99, 0.005, 0.005]], np.float32), (3, 1)), boxes, np.zeros((3, 4), np.float32))
+    assert len(empty["score"]) == 0
+
+
+def test_paste_known_answer():
+    m = np.full((1, 28, 28), 0.9, np.float32)
+    o = ora.paste_masks(m, np.array([[50, 60, 250, 300]], np.float32), 384, 500)[0]
+    ys, xs = np.nonzero(o.any(1))[0], np.nonzero(o.any(0))[0]
+    assert (ys[0], ys[-1], xs[0], xs[-1]) == (60, 299, 50, 249)  # the 1-px zero border of the padded mask trims the box edge
+    assert o.sum() > 0.95 * 200 * 240
+
+
+def test_box_postprocess_kth_value_cut():
+    rng = np.random.default_rng(3)
+    R = 300
+    logits = rng.normal(0, 1, (R, 81)).astype(np.float32); logits[:, 5] += 4
+    regr = np.zeros((R, 324), np.float32)
+    c = rng.uniform(50, 900, (R, 2)); props = np.concatenate([c, c + 20], 1).astype(np.float32)  # mostly disjoint boxes
+    b, s, l = ora.box_postprocess(logits, regr, props, 1333, 800, cap=128)
+    assert len(s) == 100 and np.all(np.diff(l) >= 0)  # class-major order, exactly det_per_img without ties
+    b2, s2, l2 = ora.box_postprocess(logits, regr, props, 1333, 800, det_per_img=1000, cap=1000)
+    thr = np.sort(s2)[::-1][99]
+    assert np.array_equal(s, s2[s2 >= thr])
+
+
+@pytest.mark.parametrize("name", ["conv", "conv1x1s2", "detmath", "nms", "roi_align", "yolact", "paste"])
+def test_oracle_reproduces_golden(name):
+    g = gold(name)
+    if name == "conv":
+        assert np.array_equal(ora.conv2d(g["x"], g["w"], 1, 1, g["scale"], g["shift"], g["res"], 1), g["y"])
+    elif name == "conv1x1s2":
+        assert np.array_equal(ora.conv2d(g["x"], g["w"], 2, 0), g["y"])
+    elif name == "detmath":
+        for i, k in enumerate(("exp", "sigmoid", "tanh")):
+            assert np.array_equal(ora.map_f32(g["x"], i), g[k])
+        assert np.array_equal(ora.map_f32(np.abs(g["x"]) + np.float32(1e-3), 3), g["log2"])
+    elif name == "nms":
+        assert np.array_equal(ora.nms(g["boxes"], g["scores"], 0.5, 1, 0), g["keep_gt"])
+        assert np.array_equal(ora.nms(g["boxes"], g["scores"], 0.5, 1, 1), g["keep_ge"])
+        assert np.array_equal(ora.nms(g["boxes"], g["scores"], 0.5, 0, 0), g["keep_noplus"])
+    elif name == "roi_align":
+        assert np.array_equal(ora.roi_align(g["feat"], g["rois"], 0.125, 7, 7, 2), g["out7"])
+        assert np.array_equal(ora.level_map(g["rois"][:, 1:]), g["levels"])
+    elif name == "yolact":
+        bx = ora.yolact_decode(g["loc"], g["priors"])
+        assert np.array_equal(bx, g["boxes"])
+        d = ora.yolact_detect(ora.softmax(g["conf"]), bx, g["mask"])
+        assert np.array_equal(d["prior"], g["det_prior"]) and np.array_equal(d["score"], g["det_score"]) and np.array_equal(d["cls"], g["det_cls"])
+        mm, ib = ora.yolact_masks(g["proto"], d["mask"], d["box"], 50, 60)
+        assert np.array_equal(np.packbits(mm), g["masks"]) and np.array_equal(ib, g["int_boxes"])
+    elif name == "paste":
+        assert np.array_equal(np.packbits(ora.paste_masks(g["masks"], g["boxes"], 120, 160)), g["out"])
