@@ -35,7 +35,7 @@ struct ConvK {
     int N, H, W, Cin, Cout, R, S, stride, pad, Ho, Wo, M;
     int nchunks, cin_chunks;
     int64_t wrow;
-    unsigned in_bytes;
+    unsigned in_bytes, out_bytes, res_bytes;
     int act, out_div, contiguous;
     int64_t out_img_stride, out_pix_stride;
     int mtiles, ntiles;
@@ -43,8 +43,10 @@ struct ConvK {
 
 constexpr int LDS_ROW = 36;
 
+
+
 template <int BM, int BN, int WM, int WN, bool STEM>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvK p) {
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK p) {
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
     constexpr int APASS = BM / 64, BPASS = BN / 64;
     constexpr int STAGE = (BM + BN) * LDS_ROW;
@@ -192,32 +194,54 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvK p) {
 
     // ---- epilogue: y = fmaf(acc, scale, shift) (+res) -> act -> NHWC store.
     // D layout: col (cout) = lane&31, row (pixel) = (e&3) + 8*(e>>2) + 4*(lane>>5).
+    // Branch-free: residual loads and output stores are raw buffer ops whose offset is pushed out of range
+    // for rows >= M / couts >= Cout (hardware returns 0 / drops the store), so all 16 loads of a tile are
+    // in flight together instead of 16 guarded round trips.
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, p.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? p.res : p.out), 0, p.res ? p.res_bytes : 0u, 0x00020000);
 #pragma unroll
-    for (int b = 0; b < TN; ++b) {
-        const int co = n0 + (wn * TN + b) * 32 + lr;
-        const bool cok = co < p.Cout;
-        const float sc = (cok && p.scale) ? p.scale[co] : 1.0f;
-        const float sh = (cok && p.shift) ? p.shift[co] : 0.0f;
+    for (int a = 0; a < TM; ++a) {
+        unsigned rowoff[16], resoff[16];
 #pragma unroll
-        for (int a = 0; a < TM; ++a) {
+        for (int e = 0; e < 16; ++e) {
+            const int m = m0 + (wm * TM + a) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            rowoff[e] = m < p.M ? (unsigned)m * (unsigned)p.out_pix_stride * 4u : OOB;
+            resoff[e] = m < p.M ? (unsigned)m * (unsigned)p.Cout * 4u : OOB;
+        }
+        if (!p.contiguous) {  // strided destination (concatenated head buffers, deconv parities): uniform branch
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int row = (wm * TM + a) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                const int m = m0 + row;
-                if (cok && m < p.M) {
-                    float y = fmaf(acc[a][b][e], sc, sh);
-                    if (p.res) y = y + p.res[(int64_t)m * p.Cout + co];
-                    if (p.act == 1) y = y > 0.0f ? y : 0.0f;
-                    else if (p.act == 2) y = dm_tanh(y);
-                    int64_t off;
-                    if (p.contiguous) off = (int64_t)m * p.out_pix_stride + co;
-                    else {
-                        const int ni = m / p.out_div, pi = m - ni * p.out_div;
-                        off = (int64_t)ni * p.out_img_stride + (int64_t)pi * p.out_pix_stride + co;
-                    }
-                    p.out[off] = y;
-                }
+                const int m = m0 + (wm * TM + a) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                const int ni = m / p.out_div, pi = m - ni * p.out_div;
+                rowoff[e] = m < p.M ? (unsigned)(((int64_t)ni * p.out_img_stride + (int64_t)pi * p.out_pix_stride) * 4) : OOB;
             }
+        }
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int co = n0 + (wn * TN + b) * 32 + lr;
+            const bool cok = co < p.Cout;
+            const float sc = (cok && p.scale) ? p.scale[co] : 1.0f;
+            const float sh = (cok && p.shift) ? p.shift[co] : 0.0f;
+            const unsigned cooff = cok ? (unsigned)co * 4u : OOB;  // OOB + anything stays out of range (< 2^32)
+            float rv[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                rv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_res, (resoff[e] | cooff) >= OOB ? OOB : resoff[e] + cooff, 0, 0));
+            float yv[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float y = fmaf(acc[a][b][e], sc, sh);
+                y = y + rv[e];            // rv is +0 without a residual: y + 0 == y for every y we can produce
+                yv[e] = p.act == 1 ? (y > 0.0f ? y : 0.0f) : y;
+            }
+            if (p.act == 2) {  // uniform; tanh only on the Yolact coefficient head
+#pragma unroll
+                for (int e = 0; e < 16; ++e) yv[e] = dm_tanh(yv[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yv[e]), rs_out, (rowoff[e] | cooff) >= OOB ? OOB : rowoff[e] + cooff, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);  // one 32x32 tile's loads in flight at a time (register budget)
         }
     }
 }
@@ -281,15 +305,19 @@ int conv2d_launch(const isegmi_conv_desc* d, const float* in, const float* w, co
     k.out_pix_stride = d->out_pix_stride > 0 ? d->out_pix_stride : d->Cout;
     k.out_img_stride = d->out_img_stride > 0 ? d->out_img_stride : (int64_t)k.out_div * k.out_pix_stride;
     k.contiguous = (k.out_img_stride == (int64_t)k.out_div * k.out_pix_stride) ? 1 : 0;
-    ARG_CHECK(res == nullptr || (k.contiguous && k.out_pix_stride == d->Cout) || true, "residual layout");
+    // extent of the destination reachable by this launch (for the store descriptor's range check)
+    const int64_t n_img = (k.M + k.out_div - 1) / k.out_div;
+    const int64_t out_extent = ((n_img - 1) * k.out_img_stride + (int64_t)(k.out_div - 1) * k.out_pix_stride + d->Cout) * 4;
+    ARG_CHECK(out_extent < (1ll << 31), "conv output span must be < 2 GiB (32-bit buffer offsets)");
+    k.out_bytes = (unsigned)out_extent;
+    k.res_bytes = (unsigned)((int64_t)k.M * d->Cout * 4);
+    ARG_CHECK(res == nullptr || (int64_t)k.M * d->Cout * 4 < (1ll << 31), "residual must be < 2 GiB");
     int tile = d->tile;
     if (tile == 0) {
-        // enough 128x128 tiles to fill 256 CUs x 2 blocks? else shrink the tile.
-        const int64_t t128 = (int64_t)cdiv(k.M, 128) * cdiv(d->Cout, 128);
-        const int64_t t12864 = (int64_t)cdiv(k.M, 128) * cdiv(d->Cout, 64);
-        if (d->Cout > 64 && t128 >= 384) tile = 1;
-        else if (t12864 >= 384) tile = 2;
-        else tile = 3;
+        // Measured on MI355X (profiles/r01_conv_tiles_bs8.txt): the 64x64 tile (4 blocks/CU = 4 waves/SIMD,
+        // 36.9 KB LDS) matches 128x128 at full occupancy (124 TF/s) and wins everywhere else through finer
+        // wave quantisation, so it is the default; 128-wide tiles stay selectable for experiments.
+        tile = 3;
     }
     switch (tile) {
         case 1: return launch<128, 128, 2, 2>(d, k, st);
