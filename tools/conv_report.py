@@ -1,6 +1,6 @@
 """Per-layer conv report on the GPU (dev tool): python tools_conv_report.py [batch] [tile]"""
 import ctypes as C, sys, os
-ROOT = os.path.dirname(os.path.abspath(__file__)); sys.path[:0] = [ROOT, os.path.join(ROOT, "instancesegmentation-jittor_amd")]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path[:0] = [ROOT, os.path.join(ROOT, "instancesegmentation-jittor_amd")]
 import numpy as np
 from isegmi import _ffi
 from isegmi.weights import yolact_state_dict
