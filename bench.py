@@ -29,6 +29,15 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32-input MFMA peak (
 YOLACT_GFLOP_PER_IMAGE = 118.28  # algorithmic conv work per 550x550 image
 
 
+def pmc_traffic(name):
+    """HBM bytes per conv launch from the committed PMC summary (tools/pmc_summary.py), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            return json.load(f)["conv_mfma_kernel_all"]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -155,7 +164,8 @@ def main():
                 "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                "traffic": None,
+                "traffic": pmc_traffic("r01_pmc_yolact_bs8.json"),
+                "traffic_note": "HBM bytes per conv launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (profiles/r01_pmc_yolact_bs8.json; FETCH x2 gfx950 correction); not collected live",
                 "algorithmic_gflop_per_step": round(conv_flops / max(a.steps, 1) / 1e9, 2),
                 "conv_ms_per_step": round(conv_ms / max(a.steps, 1), 3),
                 "launches_per_step": conv_launches // max(a.steps, 1),
