@@ -62,8 +62,9 @@ def main():
     if a.gpus != world and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
 
+    force_dist = os.environ.get("ISEGMI_BENCH_FORCE_DIST") == "1"  # exercise the N>1 code path on a 1-GPU box
     dist = None
-    if world > 1:
+    if world > 1 or force_dist:
         # torch.distributed is plumbing only (rendezvous, barrier, max-reduce of the wall time):
         # CPU/gloo, so torch never touches the GPU.  The data-path collective is RCCL in libisegmi.
         import torch
@@ -85,7 +86,7 @@ def main():
     net.upload(imgs)
 
     gather = None
-    if world > 1:
+    if world > 1 or force_dist:
         import torch
         uid = torch.zeros(128, dtype=torch.uint8)
         if rank == 0:

@@ -1,0 +1,33 @@
+"""RCCL path with world_size 1 on the GPU box (the only size a 1-GPU box allows): device-side record packing
+equals the host-side layout, and the all-gather round-trips it.  N>1 is covered by the gloo CPU test."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_rccl_world1_gather_matches_host_pack(ffi):
+    from isegmi.dist import RcclGather, pack_records, record_bytes, unpack_records
+    from isegmi.weights import yolact_state_dict
+    from isegmi.yolact import Yolact, fast_base_transform
+    size, n = 200, 2
+    net = Yolact(yolact_state_dict(1234), max_batch=n, input_size=size)
+    rng = np.random.default_rng(3)
+    x = fast_base_transform(rng.uniform(0, 255, (n, size, size, 3)).astype(np.float32))
+    net(x)
+    g = RcclGather(0, 1, RcclGather.unique_id(), record_bytes(n))
+    g.gather_from(net)
+    got = g.fetch()
+    assert got.shape == (1, record_bytes(n))
+    host = pack_records(net.fetch("det.count", n), net.fetch("det.box", n), net.fetch("det.score", n), net.fetch("det.class", n),
+                        net.fetch("det.coeff", n))
+    assert np.array_equal(got[0], host)
+    rec = unpack_records(got[0], n)
+    assert rec["count"].sum() > 0 and np.array_equal(rec["score"], net.fetch("det.score", n))
+    # with the prototypes attached
+    ph = net.fetch("proto", n).shape[1:3]
+    g2 = RcclGather(0, 1, RcclGather.unique_id(), record_bytes(n, proto_hw=ph))
+    g2.gather_from(net, with_proto=True)
+    rec2 = unpack_records(g2.fetch()[0], n, proto_hw=ph)
+    assert np.array_equal(rec2["proto"], net.fetch("proto", n))
+    g.close(); g2.close(); net.close()
