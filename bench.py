@@ -92,7 +92,16 @@ def main():
         if rank == 0:
             uid = torch.frombuffer(bytearray(RcclGather.unique_id()), dtype=torch.uint8).clone()
         dist.broadcast(uid, 0)
-        gather = RcclGather(rank, world, bytes(uid.numpy().tobytes()), record_bytes(a.batch))
+        # RCCL prints a version banner on stdout at communicator creation; keep stdout to the ONE JSON line
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            gather = RcclGather(rank, world, bytes(uid.numpy().tobytes()), record_bytes(a.batch))
+            gather.gather_from  # noqa: B018
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
 
     def step():
         net.forward_device(a.batch)
