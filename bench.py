@@ -93,15 +93,11 @@ def main():
             uid = torch.frombuffer(bytearray(RcclGather.unique_id()), dtype=torch.uint8).clone()
         dist.broadcast(uid, 0)
         # RCCL prints a version banner on stdout at communicator creation; keep stdout to the ONE JSON line
+        # (printed at init or at the first collective: stdout stays redirected until warm-up is done)
         sys.stdout.flush()
-        saved = os.dup(1)
+        saved_stdout = os.dup(1)
         os.dup2(2, 1)
-        try:
-            gather = RcclGather(rank, world, bytes(uid.numpy().tobytes()), record_bytes(a.batch))
-            gather.gather_from  # noqa: B018
-        finally:
-            os.dup2(saved, 1)
-            os.close(saved)
+        gather = RcclGather(rank, world, bytes(uid.numpy().tobytes()), record_bytes(a.batch))
 
     def step():
         net.forward_device(a.batch)
@@ -115,9 +111,12 @@ def main():
             gather.wait()
         _ffi.sync()
 
-    for _ in range(a.warmup):
+    for _ in range(max(a.warmup, 1 if gather is not None else 0)):
         step()
     full_sync()
+    if gather is not None:
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
     net.set_param("conv_timing", 1.0)
     import ctypes as C
     f, m, l = C.c_double(), C.c_double(), C.c_int64()
