@@ -44,11 +44,11 @@ static int timed_conv(Engine& e, const std::string& label, const isegmi_conv_des
     if (e.conv_timing) {
         HIP_TRY(hipEventCreate(&a));
         HIP_TRY(hipEventCreate(&b));
-        HIP_TRY(hipEventRecord(a, e.stream));
+        HIP_TRY(hipEventRecord(a, e.cur));
     }
-    int rc = conv2d_launch(d, in, L->d_w, L->d_scale, L->d_shift, res, out, e.stream);
+    int rc = conv2d_launch(d, in, L->d_w, L->d_scale, L->d_shift, res, out, e.cur);
     if (e.conv_timing) {
-        HIP_TRY(hipEventRecord(b, e.stream));
+        HIP_TRY(hipEventRecord(b, e.cur));
         e.conv_evs.push_back({a, b});
         const int Ho = (d->H + 2 * d->pad - d->R) / d->stride + 1, Wo = (d->W + 2 * d->pad - d->S) / d->stride + 1;
         const int cin_true = (d->Cin == 4 && d->R == 7) ? 3 : d->Cin;
@@ -89,6 +89,33 @@ int eng_conv(Engine& e, const std::string& layer, const Tensor& in, int stride, 
     d.N = in.N; d.H = in.H; d.W = in.W; d.Cin = in.C; d.Cout = L->Cout; d.R = L->R; d.S = L->S; d.stride = stride; d.pad = pad;
     d.act = act; d.tile = (int)e.param("conv_tile", 0);
     return timed_conv(e, layer, &d, in.d, L, residual ? residual->d : nullptr, out->d);
+}
+
+static int next_event(Engine& e, hipEvent_t* ev) {
+    if (e.ev_pool.empty()) {
+        e.ev_pool.resize(128);
+        for (auto& x : e.ev_pool) HIP_TRY(hipEventCreateWithFlags(&x, hipEventDisableTiming));
+    }
+    *ev = e.ev_pool[e.ev_next++ % e.ev_pool.size()];
+    return ISEGMI_OK;
+}
+int eng_fork(Engine& e, int k) {
+    if (!e.multi_stream) return ISEGMI_OK;
+    hipEvent_t ev;
+    int rc = next_event(e, &ev);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(ev, e.stream));
+    HIP_TRY(hipStreamWaitEvent(e.side[k], ev, 0));
+    return ISEGMI_OK;
+}
+int eng_join(Engine& e, int k) {
+    if (!e.multi_stream) return ISEGMI_OK;
+    hipEvent_t ev;
+    int rc = next_event(e, &ev);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(ev, e.side[k]));
+    HIP_TRY(hipStreamWaitEvent(e.stream, ev, 0));
+    return ISEGMI_OK;
 }
 
 void eng_mark(Engine& e, const char* name) {
@@ -137,16 +164,17 @@ static void collect_times(Engine& e) {
 
 int yolact_forward(Engine& e, const float* d_images, int N) {
     const int H = e.H, W = e.W;
+    e.cur = e.stream;
     eng_mark(e, "start");
     Tensor x4;
     TRY(eng_act(e, "input4", N, H, W, 4, &x4));
-    TRY(pad_c3_c4_launch(d_images, (int64_t)N * H * W, x4.d, e.stream));
+    TRY(pad_c3_c4_launch(d_images, (int64_t)N * H * W, x4.d, e.cur));
     Tensor s, x;
     TRY(eng_conv(e, "backbone.conv1", x4, 2, 3, 1, nullptr, "stem", &s));
     {
         const int Ho = (s.H + 2 - 3) / 2 + 1, Wo = (s.W + 2 - 3) / 2 + 1;
         TRY(eng_act(e, "pool", N, Ho, Wo, s.C, &x));
-        TRY(maxpool_launch(s.d, N, s.H, s.W, s.C, 3, 2, 1, x.d, e.stream));
+        TRY(maxpool_launch(s.d, N, s.H, s.W, s.C, 3, 2, 1, x.d, e.cur));
     }
     eng_mark(e, "stem");
     const int blocks[4] = {3, 4, 6, 3};
@@ -156,9 +184,14 @@ int yolact_forward(Engine& e, const float* d_images, int N) {
             const std::string nm = "backbone.layers." + std::to_string(li) + "." + std::to_string(b);
             const int st = (b == 0 && li > 0) ? 2 : 1;
             Tensor idt = x, t1, t2, y;
-            if (b == 0) TRY(eng_conv(e, nm + ".downsample.0", x, st, 0, 0, nullptr, nm + ".ds", &idt));
+            if (b == 0) {  // the projection shortcut is independent of conv1 -> conv2: side stream
+                TRY(eng_fork(e, 0));
+                SideScope sc(e, 0);
+                TRY(eng_conv(e, nm + ".downsample.0", x, st, 0, 0, nullptr, nm + ".ds", &idt));
+            }
             TRY(eng_conv(e, nm + ".conv1", x, 1, 0, 1, nullptr, nm + ".t1", &t1));
             TRY(eng_conv(e, nm + ".conv2", t1, st, 1, 1, nullptr, nm + ".t2", &t2));
+            if (b == 0) TRY(eng_join(e, 0));
             TRY(eng_conv(e, nm + ".conv3", t2, 1, 0, 1, &idt, nm + ".out", &y));
             x = y;
         }
@@ -166,32 +199,33 @@ int yolact_forward(Engine& e, const float* d_images, int N) {
         eng_mark(e, li == 0 ? "layer1" : li == 1 ? "layer2" : li == 2 ? "layer3" : "layer4");
     }
     const Tensor C3 = outs[1], C4 = outs[2], C5 = outs[3];
-    // FPN
+    // FPN: the three laterals are independent; so are the three prediction convs
     Tensor l5, l4, l3, x4f, x3f, P[5];
+    TRY(eng_fork(e, 0));
+    TRY(eng_fork(e, 1));
+    { SideScope sc(e, 0); TRY(eng_conv(e, "fpn.lat_layers.1", C4, 1, 0, 0, nullptr, "fpn.lat4", &l4)); }
+    { SideScope sc(e, 1); TRY(eng_conv(e, "fpn.lat_layers.2", C3, 1, 0, 0, nullptr, "fpn.lat3", &l3)); }
     TRY(eng_conv(e, "fpn.lat_layers.0", C5, 1, 0, 0, nullptr, "fpn.lat5", &l5));
-    TRY(eng_conv(e, "fpn.lat_layers.1", C4, 1, 0, 0, nullptr, "fpn.lat4", &l4));
-    TRY(eng_conv(e, "fpn.lat_layers.2", C3, 1, 0, 0, nullptr, "fpn.lat3", &l3));
+    TRY(eng_join(e, 0));
+    TRY(eng_join(e, 1));
     TRY(eng_act(e, "fpn.x4", N, l4.H, l4.W, l4.C, &x4f));
-    TRY(resize_bilinear_launch(l5.d, N, l5.H, l5.W, l5.C, l4.H, l4.W, l4.d, 0, x4f.d, e.stream));
+    TRY(resize_bilinear_launch(l5.d, N, l5.H, l5.W, l5.C, l4.H, l4.W, l4.d, 0, x4f.d, e.cur));
     TRY(eng_act(e, "fpn.x3", N, l3.H, l3.W, l3.C, &x3f));
-    TRY(resize_bilinear_launch(x4f.d, N, x4f.H, x4f.W, x4f.C, l3.H, l3.W, l3.d, 0, x3f.d, e.stream));
-    TRY(eng_conv(e, "fpn.pred_layers.0", l5, 1, 1, 1, nullptr, "P5", &P[2]));
-    TRY(eng_conv(e, "fpn.pred_layers.1", x4f, 1, 1, 1, nullptr, "P4", &P[1]));
+    TRY(resize_bilinear_launch(x4f.d, N, x4f.H, x4f.W, x4f.C, l3.H, l3.W, l3.d, 0, x3f.d, e.cur));
+    TRY(eng_fork(e, 0));
+    TRY(eng_fork(e, 1));
+    {
+        SideScope sc(e, 0);  // P5 -> P6 -> P7 chain
+        TRY(eng_conv(e, "fpn.pred_layers.0", l5, 1, 1, 1, nullptr, "P5", &P[2]));
+        TRY(eng_conv(e, "fpn.downsample_layers.0", P[2], 2, 1, 0, nullptr, "P6", &P[3]));
+        TRY(eng_conv(e, "fpn.downsample_layers.1", P[3], 2, 1, 0, nullptr, "P7", &P[4]));
+    }
+    { SideScope sc(e, 1); TRY(eng_conv(e, "fpn.pred_layers.1", x4f, 1, 1, 1, nullptr, "P4", &P[1])); }
     TRY(eng_conv(e, "fpn.pred_layers.2", x3f, 1, 1, 1, nullptr, "P3", &P[0]));
-    TRY(eng_conv(e, "fpn.downsample_layers.0", P[2], 2, 1, 0, nullptr, "P6", &P[3]));
-    TRY(eng_conv(e, "fpn.downsample_layers.1", P[3], 2, 1, 0, nullptr, "P7", &P[4]));
+    TRY(eng_join(e, 0));
+    TRY(eng_join(e, 1));
     eng_mark(e, "fpn");
-    // protonet
-    Tensor t, u, proto;
-    TRY(eng_conv(e, "proto_net.0", P[0], 1, 1, 1, nullptr, "proto.t0", &t));
-    TRY(eng_conv(e, "proto_net.2", t, 1, 1, 1, nullptr, "proto.t1", &u));
-    TRY(eng_conv(e, "proto_net.4", u, 1, 1, 1, nullptr, "proto.t2", &t));
-    TRY(eng_act(e, "proto.up", N, t.H * 2, t.W * 2, t.C, &u));
-    TRY(resize_bilinear_launch(t.d, N, t.H, t.W, t.C, t.H * 2, t.W * 2, nullptr, 1, u.d, e.stream));
-    TRY(eng_conv(e, "proto_net.8", u, 1, 1, 1, nullptr, "proto.t3", &t));
-    TRY(eng_conv(e, "proto_net.10", t, 1, 0, 1, nullptr, "proto", &proto));
-    eng_mark(e, "protonet");
-    // shared prediction head
+    // shared prediction head geometry
     const int A = 3, ncls = 81, md = 32;
     int Ptot = 0, off[5];
     for (int l = 0; l < 5; ++l) { off[l] = Ptot; Ptot += P[l].H * P[l].W * A; }
@@ -203,7 +237,7 @@ int yolact_forward(Engine& e, const float* d_images, int N) {
     TRY(eng_buf(e, "loc", (int64_t)N * Ptot * 4 * 4, &loc, 0, {N, Ptot, 4}));
     TRY(eng_buf(e, "conf", (int64_t)N * Ptot * ncls * 4, &conf, 0, {N, Ptot, ncls}));
     TRY(eng_buf(e, "mask", (int64_t)N * Ptot * md * 4, &mask, 0, {N, Ptot, md}));
-    for (int l = 0; l < 5; ++l) {
+    auto head_level = [&](int l) -> int {
         Tensor uf;
         const std::string ln = "head.up" + std::to_string(l);
         TRY(eng_conv(e, "prediction_layers.0.upfeature.0", P[l], 1, 1, 1, nullptr, ln, &uf));
@@ -211,8 +245,31 @@ int yolact_forward(Engine& e, const float* d_images, int N) {
         TRY(eng_conv_into(e, "prediction_layers.0.bbox_layer", uf, 1, 1, 0, (float*)loc + (int64_t)off[l] * 4, hw, (int64_t)Ptot * 4, A * 4));
         TRY(eng_conv_into(e, "prediction_layers.0.conf_layer", uf, 1, 1, 0, (float*)conf + (int64_t)off[l] * ncls, hw, (int64_t)Ptot * ncls, A * ncls));
         TRY(eng_conv_into(e, "prediction_layers.0.mask_layer", uf, 1, 1, 2, (float*)mask + (int64_t)off[l] * md, hw, (int64_t)Ptot * md, A * md));
+        return ISEGMI_OK;
+    };
+    // protonet (side 0) || heads on P3 (main) || heads on P4,P6 (side 1) || heads on P5,P7 (side 2)
+    Tensor proto;
+    TRY(eng_fork(e, 0));
+    TRY(eng_fork(e, 1));
+    TRY(eng_fork(e, 2));
+    {
+        SideScope sc(e, 0);
+        Tensor t, u;
+        TRY(eng_conv(e, "proto_net.0", P[0], 1, 1, 1, nullptr, "proto.t0", &t));
+        TRY(eng_conv(e, "proto_net.2", t, 1, 1, 1, nullptr, "proto.t1", &u));
+        TRY(eng_conv(e, "proto_net.4", u, 1, 1, 1, nullptr, "proto.t2", &t));
+        TRY(eng_act(e, "proto.up", N, t.H * 2, t.W * 2, t.C, &u));
+        TRY(resize_bilinear_launch(t.d, N, t.H, t.W, t.C, t.H * 2, t.W * 2, nullptr, 1, u.d, e.cur));
+        TRY(eng_conv(e, "proto_net.8", u, 1, 1, 1, nullptr, "proto.t3", &t));
+        TRY(eng_conv(e, "proto_net.10", t, 1, 0, 1, nullptr, "proto", &proto));
     }
-    eng_mark(e, "heads");
+    { SideScope sc(e, 1); TRY(head_level(1)); TRY(head_level(3)); }
+    { SideScope sc(e, 2); TRY(head_level(2)); TRY(head_level(4)); }
+    TRY(head_level(0));
+    TRY(eng_join(e, 0));
+    TRY(eng_join(e, 1));
+    TRY(eng_join(e, 2));
+    eng_mark(e, "proto+heads");
     // Detect
     const int top_k = (int)e.param("nms_top_k", 200), max_det = (int)e.param("max_num_detections", 100);
     const int nc = ncls - 1;
@@ -240,7 +297,7 @@ int yolact_forward(Engine& e, const float* d_images, int N) {
     TRY(eng_buf(e, "det.class", (int64_t)N * max_det * 4, &p, 1, {N, max_det})); a.d_out_classes = (int32_t*)p;
     TRY(eng_buf(e, "det.coeff", (int64_t)N * max_det * md * 4, &p, 0, {N, max_det, md})); a.d_out_coeffs = (float*)p;
     TRY(eng_buf(e, "det.prior", (int64_t)N * max_det * 4, &p, 1, {N, max_det})); a.d_out_prior = (int32_t*)p;
-    TRY(yolact_detect_launch(&a, e.stream));
+    TRY(yolact_detect_launch(&a, e.cur));
     eng_mark(e, "detect");
     e.last_N = N;
     return ISEGMI_OK;
@@ -258,7 +315,7 @@ int yolact_postprocess(Engine& e, int h, int w) {
     TRY(eng_buf(e, "det.box_int", (int64_t)N * K * 4 * 8, &ib, 3, {N, K, 4}));
     TRY(yolact_masks_launch((const float*)proto.d, (const float*)e.bufs["det.coeff"].d, (const float*)e.bufs["det.box"].d,
                             (const int*)e.bufs["det.count"].d, N, PH, PW, md, K, h, w, (float*)lo, (uint8_t*)masks, (int64_t*)ib,
-                            e.stream));
+                            e.cur));
     eng_mark(e, "masks");
     return ISEGMI_OK;
 }
@@ -275,7 +332,9 @@ extern "C" int isegmi_engine_create(int model_kind, int max_batch, int H, int W,
     isegmi_engine* h = new isegmi_engine();
     h->e.kind = model_kind; h->e.max_batch = max_batch; h->e.H = H; h->e.W = W;
     hipError_t er = hipStreamCreate(&h->e.stream);
+    for (int i = 0; i < 3 && er == hipSuccess; ++i) er = hipStreamCreateWithFlags(&h->e.side[i], hipStreamNonBlocking);
     if (er != hipSuccess) { set_error(std::string("hipStreamCreate: ") + hipGetErrorString(er)); delete h; return ISEGMI_ERR_HIP; }
+    h->e.cur = h->e.stream;
     *out = h;
     return ISEGMI_OK;
 }
@@ -287,6 +346,8 @@ extern "C" int isegmi_engine_destroy(isegmi_engine* h) {
     for (auto& kv : e.convs) { (void)hipFree(kv.second.d_w); if (kv.second.d_scale) (void)hipFree(kv.second.d_scale); if (kv.second.d_shift) (void)hipFree(kv.second.d_shift); }
     for (auto& kv : e.tensors) (void)hipFree(kv.second.d);
     for (auto& kv : e.bufs) (void)hipFree(kv.second.d);
+    for (auto& ev : e.ev_pool) (void)hipEventDestroy(ev);
+    for (int i = 0; i < 3; ++i) if (e.side[i]) (void)hipStreamDestroy(e.side[i]);
     (void)hipStreamDestroy(e.stream);
     delete h;
     return ISEGMI_OK;
@@ -297,6 +358,7 @@ extern "C" int isegmi_engine_set_param(isegmi_engine* h, const char* name, float
     h->e.params[name] = value;
     if (std::string(name) == "timing") h->e.timing = value != 0.0f;
     if (std::string(name) == "conv_timing") h->e.conv_timing = value != 0.0f;
+    if (std::string(name) == "multi_stream") h->e.multi_stream = value != 0.0f;
     return ISEGMI_OK;
 }
 

@@ -37,12 +37,21 @@ struct StageTime {
 struct Engine {
     int kind = 0;  // 1 yolact, 2 maskrcnn
     int max_batch = 0, H = 0, W = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;          // main stream (all results are complete on it when a forward returns)
+    hipStream_t side[3] = {nullptr, nullptr, nullptr};  // side streams for independent branches
+    hipStream_t cur = nullptr;             // stream the next launch goes to
+    bool multi_stream = true;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_next = 0;
     std::map<std::string, ConvLayer> convs;
     std::map<std::string, RawBuf> tensors;   // user-set constant tensors (priors, anchors, deconv weights ...)
     std::map<std::string, RawBuf> bufs;      // activations / workspaces / outputs, allocated on first use
     std::map<std::string, float> params;
     bool finalized = false;
+    std::vector<int32_t> last_hw;      // host copies of the small per-batch inputs already resident on the device
+    const void* last_hw_ptr = nullptr;
+    std::vector<float> last_ratios;
+    const void* last_ratios_ptr = nullptr;
     int last_N = 0;
     // timing
     bool timing = false;
@@ -72,6 +81,16 @@ int eng_conv(Engine& e, const std::string& layer, const Tensor& in, int stride, 
 int eng_conv_into(Engine& e, const std::string& layer, const Tensor& in, int stride, int pad, int act, float* dst, int out_div,
                   int64_t out_img_stride, int64_t out_pix_stride);
 void eng_mark(Engine& e, const char* name);
+// fork(k): side stream k waits for everything queued on the main stream so far; join(k): main waits for side k.
+int eng_fork(Engine& e, int k);
+int eng_join(Engine& e, int k);
+// RAII: launches inside the scope go to side stream k (no-op when multi_stream is off)
+struct SideScope {
+    Engine& e;
+    hipStream_t saved;
+    SideScope(Engine& e_, int k) : e(e_), saved(e_.cur) { if (e.multi_stream) e.cur = e.side[k]; }
+    ~SideScope() { e.cur = saved; }
+};
 
 int yolact_forward(Engine& e, const float* d_images, int N);
 int yolact_postprocess(Engine& e, int h, int w);

@@ -47,13 +47,22 @@ static int need_tensor(Engine& e, const std::string& name, int64_t bytes, const 
 int maskrcnn_forward(Engine& e, const float* d_images, const int32_t* h_image_hw, int N) {
     const int H = e.H, W = e.W;
     if (H % 32 || W % 32) { set_error("Mask R-CNN input must be padded to a multiple of 32"); return ISEGMI_ERR_ARG; }
-    hipStream_t st = e.stream;
+    e.cur = e.stream;
+#define st e.cur
     eng_mark(e, "start");
     void* p;
     TRY(eng_buf(e, "image_hw", (int64_t)N * 8, &p, 1, {N, 2}));
     int* d_hw = (int*)p;
-    HIP_TRY(hipMemcpyAsync(d_hw, h_image_hw, (size_t)N * 8, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));  // h_image_hw is caller memory: do not keep reading it after return
+    {
+        // image_hw is caller memory: copy synchronously, but only when it changed (steady-state batches skip it)
+        std::vector<int32_t> now(h_image_hw, h_image_hw + 2 * N);
+        if (now != e.last_hw || e.last_hw_ptr != (const void*)d_hw) {
+            HIP_TRY(hipMemcpyAsync(d_hw, h_image_hw, (size_t)N * 8, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            e.last_hw = now;
+            e.last_hw_ptr = d_hw;
+        }
+    }
 
     Tensor x4, s, x;
     TRY(eng_act(e, "input4", N, H, W, 4, &x4));
@@ -73,36 +82,33 @@ int maskrcnn_forward(Engine& e, const float* d_images, const int32_t* h_image_hw
             const std::string nm = "backbone.body.layer" + std::to_string(li + 1) + "." + std::to_string(b);
             const int sd = (b == 0 && li > 0) ? 2 : 1;
             Tensor idt = x, t1, t2, y;
-            if (b == 0) TRY(eng_conv(e, nm + ".downsample.0", x, sd, 0, 0, nullptr, nm + ".ds", &idt));
+            if (b == 0) {  // projection shortcut on a side stream, concurrent with conv1 -> conv2
+                TRY(eng_fork(e, 0));
+                SideScope sc(e, 0);
+                TRY(eng_conv(e, nm + ".downsample.0", x, sd, 0, 0, nullptr, nm + ".ds", &idt));
+            }
             TRY(eng_conv(e, nm + ".conv1", x, sd, 0, 1, nullptr, nm + ".t1", &t1));  // STRIDE_IN_1X1
             TRY(eng_conv(e, nm + ".conv2", t1, 1, 1, 1, nullptr, nm + ".t2", &t2));
+            if (b == 0) TRY(eng_join(e, 0));
             TRY(eng_conv(e, nm + ".conv3", t2, 1, 0, 1, &idt, nm + ".out", &y));
             x = y;
         }
         C[li] = x;
         eng_mark(e, li == 0 ? "res2" : li == 1 ? "res3" : li == 2 ? "res4" : "res5");
     }
-    // ---- FPN
-    Tensor P[5], last, lat;
-    TRY(eng_conv(e, "backbone.fpn.fpn_inner4", C[3], 1, 0, 0, nullptr, "fpn.last4", &last));
-    TRY(eng_conv(e, "backbone.fpn.fpn_layer4", last, 1, 1, 0, nullptr, "P5", &P[3]));
+
+    // ---- FPN top-down chain (main stream); leaves (3x3 output convs) and the RPN follow per level
+    Tensor P[5], last[4], lat;
+    TRY(eng_conv(e, "backbone.fpn.fpn_inner4", C[3], 1, 0, 0, nullptr, "fpn.last4", &last[3]));
     for (int l = 2; l >= 0; --l) {
         const std::string ls = std::to_string(l + 1);
         TRY(eng_conv(e, "backbone.fpn.fpn_inner" + ls, C[l], 1, 0, 0, nullptr, "fpn.lat" + ls, &lat));
-        Tensor nl;
-        TRY(eng_act(e, "fpn.last" + ls, N, lat.H, lat.W, lat.C, &nl));
-        TRY(nearest2x_add_launch(last.d, N, last.H, last.W, last.C, lat.d, lat.H, lat.W, nl.d, st));
-        last = nl;
-        TRY(eng_conv(e, "backbone.fpn.fpn_layer" + ls, last, 1, 1, 0, nullptr, "P" + std::to_string(l + 2), &P[l]));
+        TRY(eng_act(e, "fpn.last" + ls, N, lat.H, lat.W, lat.C, &last[l]));
+        TRY(nearest2x_add_launch(last[l + 1].d, N, last[l + 1].H, last[l + 1].W, last[l + 1].C, lat.d, lat.H, lat.W, last[l].d, st));
     }
-    {
-        const int Ho = (P[3].H - 1) / 2 + 1, Wo = (P[3].W - 1) / 2 + 1;
-        TRY(eng_act(e, "P6", N, Ho, Wo, P[3].C, &P[4]));
-        TRY(maxpool_launch(P[3].d, N, P[3].H, P[3].W, P[3].C, 1, 2, 0, P[4].d, st));
-    }
-    eng_mark(e, "fpn");
+    eng_mark(e, "fpn_topdown");
 
-    // ---- RPN
+    // ---- RPN config
     const int A = 3, CH = 15, L = 5;
     const int pre_nms = (int)e.param("rpn_pre_nms_top_n", 1000), post_nms = (int)e.param("rpn_post_nms_top_n", 1000);
     const int fpn_post = (int)e.param("rpn_fpn_post_nms_top_n", 1000);
@@ -115,7 +121,11 @@ int maskrcnn_forward(Engine& e, const float* d_images, const int32_t* h_image_hw
     TRY(eng_buf(e, "rpn.cand_scores", (int64_t)N * L * post_nms * 4, &p, 0, {N, L * post_nms})); cand_scores = (float*)p;
     TRY(eng_buf(e, "rpn.cand_cnt", (int64_t)N * L * 4, &p, 1, {N, L})); cand_cnt = (int*)p;
     TRY(eng_buf(e, "rpn.cand_total", (int64_t)N * 4, &p, 1, {N})); cand_total = (int*)p;
-    for (int l = 0; l < L; ++l) {
+
+    // Per level, finest first: FPN output conv -> RPN head convs on the main stream, then that level's
+    // selection (sigmoid, top-k, decode, NMS: small latency-bound grids) on a side stream so it hides under the
+    // next level's convolutions.  P2's selection (201 600 anchors) gets all the remaining levels to hide under.
+    auto rpn_level = [&](int l) -> int {
         const std::string ls = std::to_string(l);
         Tensor t, head;
         TRY(eng_conv(e, "rpn.head.conv", P[l], 1, 1, 1, nullptr, "rpn.t" + ls, &t));
@@ -125,15 +135,34 @@ int maskrcnn_forward(Engine& e, const float* d_images, const int32_t* h_image_hw
         TRY(need_tensor(e, "anchors." + ls, (int64_t)HWA * 16, &anc));
         float *prob, *tkv;
         int *tki, *tkc;
-        TRY(eng_buf(e, "rpn.prob" + ls, (int64_t)N * HWA * 4, &p)); prob = (float*)p;
-        TRY(eng_buf(e, "rpn.tk_vals" + ls, (int64_t)N * pre_nms * 4, &p)); tkv = (float*)p;
-        TRY(eng_buf(e, "rpn.tk_idx" + ls, (int64_t)N * pre_nms * 4, &p, 1)); tki = (int*)p;
-        TRY(eng_buf(e, "rpn.tk_cnt" + ls, (int64_t)N * 4, &p, 1)); tkc = (int*)p;
+        void* q;
+        TRY(eng_buf(e, "rpn.prob" + ls, (int64_t)N * HWA * 4, &q)); prob = (float*)q;
+        TRY(eng_buf(e, "rpn.tk_vals" + ls, (int64_t)N * pre_nms * 4, &q)); tkv = (float*)q;
+        TRY(eng_buf(e, "rpn.tk_idx" + ls, (int64_t)N * pre_nms * 4, &q, 1)); tki = (int*)q;
+        TRY(eng_buf(e, "rpn.tk_cnt" + ls, (int64_t)N * 4, &q, 1)); tkc = (int*)q;
+        const int sk = l % 3;
+        TRY(eng_fork(e, sk));
+        SideScope sc(e, sk);
         TRY(rpn_sigmoid_launch(head.d, (int64_t)N * HWA, A, CH, prob, st));
         TRY(topk_launch(prob, HWA, N, HWA, pre_nms, nullptr, 1, tkv, tki, tkc, st));
         TRY(rpn_decode_nms_launch(head.d, (const float*)anc->d, tkv, tki, tkc, d_hw, N, HWA, A, CH, pre_nms, post_nms, rpn_thr, rpn_min,
                                   ge, l, L, post_nms, cand_boxes, cand_scores, cand_cnt, st));
+        return ISEGMI_OK;
+    };
+    for (int l = 0; l < 4; ++l) {
+        TRY(eng_conv(e, "backbone.fpn.fpn_layer" + std::to_string(l + 1), last[l], 1, 1, 0, nullptr, "P" + std::to_string(l + 2), &P[l]));
+        TRY(rpn_level(l));
     }
+    {
+        const int Ho = (P[3].H - 1) / 2 + 1, Wo = (P[3].W - 1) / 2 + 1;
+        TRY(eng_act(e, "P6", N, Ho, Wo, P[3].C, &P[4]));
+        TRY(maxpool_launch(P[3].d, N, P[3].H, P[3].W, P[3].C, 1, 2, 0, P[4].d, st));
+        TRY(rpn_level(4));
+    }
+    TRY(eng_join(e, 0));
+    TRY(eng_join(e, 1));
+    TRY(eng_join(e, 2));
+    eng_mark(e, "fpn_out+rpn");
     TRY(sum_counts_launch(cand_cnt, N, L, cand_total, st));
     float *fin_vals, *props, *prop_scores;
     int *fin_idx, *fin_cnt, *prop_cnt;
@@ -146,7 +175,7 @@ int maskrcnn_forward(Engine& e, const float* d_images, const int32_t* h_image_hw
     TRY(eng_buf(e, "proposal_count", (int64_t)N * 4, &p, 1, {N})); prop_cnt = (int*)p;
     TRY(topk_launch(cand_scores, (int64_t)L * post_nms, N, L * post_nms, R, cand_total, 1, fin_vals, fin_idx, fin_cnt, st));
     TRY(gather_proposals_launch(cand_boxes, fin_vals, fin_idx, fin_cnt, N, L * post_nms, R, props, prop_scores, prop_cnt, st));
-    eng_mark(e, "rpn");
+    eng_mark(e, "proposals");
 
     // ---- box head
     const float* feats[4] = {P[0].d, P[1].d, P[2].d, P[3].d};
@@ -209,6 +238,7 @@ int maskrcnn_forward(Engine& e, const float* d_images, const int32_t* h_image_hw
     eng_mark(e, "mask_head");
     e.last_N = N;
     return ISEGMI_OK;
+#undef st
 }
 
 int maskrcnn_paste(Engine& e, const float* h_ratios_wh, int out_h, int out_w) {
@@ -217,8 +247,16 @@ int maskrcnn_paste(Engine& e, const float* h_ratios_wh, int out_h, int out_w) {
     const int cap = (int)e.param("detections_per_img", 100);
     void *p, *rb, *rt;
     TRY(eng_buf(e, "ws.ratios", (int64_t)N * 8, &rt));
-    HIP_TRY(hipMemcpyAsync(rt, h_ratios_wh, (size_t)N * 8, hipMemcpyHostToDevice, e.stream));
-    HIP_TRY(hipStreamSynchronize(e.stream));
+    e.cur = e.stream;
+    {
+        std::vector<float> now(h_ratios_wh, h_ratios_wh + 2 * N);
+        if (now != e.last_ratios || e.last_ratios_ptr != (const void*)rt) {
+            HIP_TRY(hipMemcpyAsync(rt, h_ratios_wh, (size_t)N * 8, hipMemcpyHostToDevice, e.stream));
+            HIP_TRY(hipStreamSynchronize(e.stream));
+            e.last_ratios = now;
+            e.last_ratios_ptr = rt;
+        }
+    }
     TRY(eng_buf(e, "det.box_resized", (int64_t)N * cap * 16, &rb, 0, {N, cap, 4}));
     TRY(scale_boxes_launch((const float*)e.bufs["det.box"].d, (const float*)rt, N, cap, (float*)rb, e.stream));
     TRY(eng_buf(e, "det.masks", (int64_t)N * cap * out_h * out_w, &p, 2, {N, cap, out_h, out_w}));
