@@ -64,3 +64,41 @@ def test_maskrcnn_small_batch2_bit_exact(ffi, sd):
         rm, rbox = MaskRCNNRef.paste(rd[n], 520, 700, ratio)
         assert np.array_equal(rb[n, : len(rm)], rbox) and np.array_equal(masks[n, : len(rm)], rm)
     model.close()
+
+
+def test_maskrcnn_r101_bit_exact(ffi):
+    """R101-FPN graph (23-block res4, BASELINE configs[4] backbone) on one small image."""
+    from isegmi.maskrcnn import MaskRCNN, MaskRCNNConfig, prepare_images
+    from isegmi.weights import maskrcnn_state_dict
+    sd101 = maskrcnn_state_dict(77, depth=101)
+    rng = np.random.default_rng(5)
+    x, hw = prepare_images([rng.uniform(0, 255, (200, 260, 3)).astype(np.float32)])
+    model = MaskRCNN(sd101, x.shape[1], x.shape[2], cfg=MaskRCNNConfig(depth=101), max_batch=1)
+    out = model(x, hw)
+    ref = MaskRCNNRef(sd101, depth=101)
+    rd = ref.forward(x, hw)
+    assert np.array_equal(model.fetch("P2", 1), ref.feats["P2"])
+    bl = out[0]
+    assert len(bl) == len(rd[0]["score"]) and len(bl) > 0
+    assert np.array_equal(bl.bbox, rd[0]["box"]) and np.array_equal(bl.get_field("scores"), rd[0]["score"])
+    assert np.array_equal(bl.get_field("labels"), rd[0]["label"].astype(np.int64))
+    assert np.array_equal(bl.get_field("mask")[:, 0], rd[0]["mask28"])
+    model.close()
+
+
+def test_maskrcnn_no_detections(ffi, sd):
+    """Edge case: nothing passes SCORE_THRESH -> empty BoxList, mask head runs on zero rows, paste writes nothing."""
+    from isegmi.maskrcnn import MaskRCNN, prepare_images
+    sd2 = dict(sd)
+    b = sd["roi_heads.box.predictor.cls_score.bias"].copy(); b[0] += 50.0
+    sd2["roi_heads.box.predictor.cls_score.bias"] = b
+    rng = np.random.default_rng(9)
+    x, hw = prepare_images([rng.uniform(0, 255, (200, 230, 3)).astype(np.float32)])
+    model = MaskRCNN(sd2, x.shape[1], x.shape[2], max_batch=1)
+    out = model(x, hw)
+    assert len(out[0]) == 0
+    rd = MaskRCNNRef(sd2).forward(x, hw)
+    assert len(rd[0]["score"]) == 0
+    model.paste_device(x.shape[1], x.shape[2]); model.sync()
+    assert not model.fetch("det.masks", 1).any()
+    model.close()
