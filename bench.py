@@ -264,21 +264,38 @@ def main_maskrcnn(a):
     x, hw = prepare_images(imgs)
     model = MaskRCNN(sd, x.shape[1], x.shape[2], max_batch=a.batch, device=local_rank)
     model.upload(x, hw)
+    gather = None
+    if world > 1:
+        import torch
+        from isegmi.dist import RcclGather, maskrcnn_record_bytes
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            uid = torch.frombuffer(bytearray(RcclGather.unique_id()), dtype=torch.uint8).clone()
+        dist.broadcast(uid, 0)
+        sys.stdout.flush(); saved_stdout = os.dup(1); os.dup2(2, 1)
+        gather = RcclGather(rank, world, bytes(uid.numpy().tobytes()), maskrcnn_record_bytes(a.batch))
 
     def step():
         model.forward_device(a.batch)
         model.paste_device(800, 1333)
+        if gather is not None:
+            gather.gather_from(model)
 
-    for _ in range(a.warmup):
+    for _ in range(max(a.warmup, 1 if gather is not None else 0)):
         step()
     model.sync(); _ffi.sync()
+    if gather is not None:
+        gather.wait(); os.dup2(saved_stdout, 1); os.close(saved_stdout)
     f, m, l = C.c_double(), C.c_double(), C.c_int64()
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
-    model.sync(); _ffi.sync()
+    model.sync()
+    if gather is not None:
+        gather.wait()
+    _ffi.sync()
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0

@@ -219,6 +219,10 @@ int isegmi_engine_get_timings(isegmi_engine* e, char* names, int names_cap, floa
  * [count i32 N][box f32 N*K*4][score f32 N*K][class i32 N*K][coeff f32 N*K*32]([proto f32 N*PH*PW*32]) */
 int isegmi_yolact_pack_records(isegmi_engine* e, void* d_dst, int64_t cap, int with_proto, int64_t* bytes);
 
+/* Mask R-CNN record block for the all-gather:
+ * [count i32 N][box f32 N*K*4][score f32 N*K][label i32 N*K][mask28 f32 N*K*784] */
+int isegmi_maskrcnn_pack_records(isegmi_engine* e, void* d_dst, int64_t cap, int64_t* bytes);
+
 /* conv-kernel statistics since the last call (set_param "conv_timing" 1): algorithmic FLOPs, summed
  * HIP-event time (ms) of the conv launches on the engine stream, launch count; resets them */
 int isegmi_engine_conv_stats(isegmi_engine* e, double* flops, double* ms, int64_t* launches);

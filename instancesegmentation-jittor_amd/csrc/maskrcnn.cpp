@@ -286,3 +286,25 @@ extern "C" int isegmi_maskrcnn_paste(isegmi_engine* h, const float* h_ratios_wh,
     ARG_CHECK(h->e.kind == 2, "engine is not a Mask R-CNN engine");
     return maskrcnn_paste(h->e, h_ratios_wh, out_h, out_w);
 }
+
+// One contiguous record block of the last Mask R-CNN forward for the all-gather:
+//   [count i32 x N][box f32 x N*K*4][score f32 x N*K][label i32 x N*K][mask28 f32 x N*K*784]
+// (the 28x28 masks travel; the consumer pastes them).  D2D copies on the engine stream.
+extern "C" int isegmi_maskrcnn_pack_records(isegmi_engine* h, void* d_dst, int64_t cap, int64_t* bytes) {
+    ARG_CHECK(h && d_dst && bytes, "null");
+    Engine& e = h->e;
+    ARG_CHECK(e.kind == 2, "engine is not a Mask R-CNN engine");
+    const int N = e.last_N;
+    ARG_CHECK(N > 0, "pack before forward");
+    const int K = (int)e.param("detections_per_img", 100);
+    const char* names[5] = {"det.count", "det.box", "det.score", "det.label", "det.mask28"};
+    const int64_t sizes[5] = {(int64_t)N * 4, (int64_t)N * K * 16, (int64_t)N * K * 4, (int64_t)N * K * 4, (int64_t)N * K * 784 * 4};
+    int64_t off = 0;
+    for (int i = 0; i < 5; ++i) {
+        ARG_CHECK(off + sizes[i] <= cap, "record buffer too small");
+        HIP_TRY(hipMemcpyAsync((char*)d_dst + off, e.bufs[names[i]].d, (size_t)sizes[i], hipMemcpyDeviceToDevice, e.stream));
+        off += sizes[i];
+    }
+    *bytes = off;
+    return ISEGMI_OK;
+}

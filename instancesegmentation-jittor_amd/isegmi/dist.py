@@ -57,6 +57,26 @@ def unpack_records(buf, n, K=K_DEFAULT, md=MD, proto_hw=None):
     return out
 
 
+def maskrcnn_record_bytes(n, K=K_DEFAULT):
+    return n * 4 + n * K * 16 + n * K * 4 + n * K * 4 + n * K * 784 * 4
+
+
+def pack_maskrcnn_records(count, box, score, label, mask28):
+    parts = [np.ascontiguousarray(count, np.int32), np.ascontiguousarray(box, np.float32), np.ascontiguousarray(score, np.float32),
+             np.ascontiguousarray(label, np.int32), np.ascontiguousarray(mask28, np.float32)]
+    return np.concatenate([p.view(np.uint8).ravel() for p in parts])
+
+
+def unpack_maskrcnn_records(buf, n, K=K_DEFAULT):
+    buf = np.ascontiguousarray(buf, np.uint8)
+    sizes = [(n * 4, np.int32, (n,)), (n * K * 16, np.float32, (n, K, 4)), (n * K * 4, np.float32, (n, K)), (n * K * 4, np.int32, (n, K)),
+             (n * K * 784 * 4, np.float32, (n, K, 28, 28))]
+    out, off = [], 0
+    for nb, dt, shp in sizes:
+        out.append(buf[off:off + nb].view(dt).reshape(shp)); off += nb
+    return dict(zip(("count", "box", "score", "label", "mask28"), out))
+
+
 def gather_records(local_record, world, allgather):
     """allgather(np.uint8[nbytes]) -> list of `world` arrays.  Returns them in rank order."""
     parts = allgather(local_record)
@@ -84,7 +104,10 @@ class RcclGather:
     def gather_from(self, net, with_proto=False):
         """Pack the last forward's records on the engine stream, then all-gather on the comm stream (async)."""
         nb = C.c_int64()
-        _ffi.check(_ffi.lib().isegmi_yolact_pack_records(net._h, self.send.ptr, C.c_int64(self.nbytes), int(with_proto), C.byref(nb)))
+        if getattr(net, "KIND", 1) == 2:
+            _ffi.check(_ffi.lib().isegmi_maskrcnn_pack_records(net._h, self.send.ptr, C.c_int64(self.nbytes), C.byref(nb)))
+        else:
+            _ffi.check(_ffi.lib().isegmi_yolact_pack_records(net._h, self.send.ptr, C.c_int64(self.nbytes), int(with_proto), C.byref(nb)))
         assert nb.value == self.nbytes, (nb.value, self.nbytes)
         st = C.c_void_p()
         _ffi.check(_ffi.lib().isegmi_engine_stream(net._h, C.byref(st)))

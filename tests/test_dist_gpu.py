@@ -31,3 +31,22 @@ def test_rccl_world1_gather_matches_host_pack(ffi):
     rec2 = unpack_records(g2.fetch()[0], n, proto_hw=ph)
     assert np.array_equal(rec2["proto"], net.fetch("proto", n))
     g.close(); g2.close(); net.close()
+
+
+def test_rccl_world1_maskrcnn_records(ffi):
+    from isegmi.dist import RcclGather, maskrcnn_record_bytes, pack_maskrcnn_records, unpack_maskrcnn_records
+    from isegmi.maskrcnn import MaskRCNN, prepare_images
+    from isegmi.weights import maskrcnn_state_dict
+    rng = np.random.default_rng(2)
+    x, hw = prepare_images([rng.uniform(0, 255, (200, 230, 3)).astype(np.float32)])
+    model = MaskRCNN(maskrcnn_state_dict(1234), x.shape[1], x.shape[2], max_batch=1)
+    model(x, hw)
+    g = RcclGather(0, 1, RcclGather.unique_id(), maskrcnn_record_bytes(1))
+    g.gather_from(model)
+    got = g.fetch()[0]
+    host = pack_maskrcnn_records(model.fetch("det.count", 1), model.fetch("det.box", 1), model.fetch("det.score", 1),
+                                 model.fetch("det.label", 1), model.fetch("det.mask28", 1))
+    assert np.array_equal(got, host)
+    rec = unpack_maskrcnn_records(got, 1)
+    assert rec["count"][0] > 0 and np.array_equal(rec["mask28"], model.fetch("det.mask28", 1))
+    g.close(); model.close()
