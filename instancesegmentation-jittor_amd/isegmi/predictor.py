@@ -1,0 +1,97 @@
+"""COCODemo -- the predictor object of README.md:288-335, backed by libisegmi.
+
+    coco_demo = COCODemo(cfg, min_image_size=800, confidence_threshold=0.5, state_dict=sd)
+    predictions = coco_demo.run_on_opencv_image(image)     # image: HxWx3 uint8 BGR -> annotated HxWx3 uint8
+
+`cfg` is a MaskRCNNConfig (the handful of inference constants the path needs, keyed like the yaml).
+compute_prediction / select_top_predictions follow the upstream demo ([UPSTREAM-RECALL]);
+overlay drawing is plain numpy (cv2 is not in the image): mask tint + box outline, no text.
+"""
+import numpy as np
+
+from .coco import COCO_CLASSES
+from .maskrcnn import BoxList, MaskRCNN, MaskRCNNConfig, prepare_images
+from .transforms import maskrcnn_resize
+
+
+class COCODemo:
+    CATEGORIES = ("__background",) + COCO_CLASSES
+
+    def __init__(self, cfg=None, min_image_size=800, confidence_threshold=0.5, state_dict=None, max_image_size=1333, device=0):
+        if state_dict is None:
+            raise ValueError("COCODemo needs a state_dict (cfg.MODEL.WEIGHT cannot be downloaded here)")
+        self.cfg = cfg or MaskRCNNConfig()
+        self.min_image_size, self.max_image_size = min_image_size, max_image_size
+        self.confidence_threshold = confidence_threshold
+        self.state_dict, self.device = state_dict, device
+        self._models = {}
+
+    def _model(self, H, W):
+        key = (H, W)
+        if key not in self._models:
+            self._models[key] = MaskRCNN(self.state_dict, H, W, cfg=self.cfg, max_batch=1, device=self.device)
+        return self._models[key]
+
+    def compute_prediction(self, original_image):
+        """-> BoxList in ORIGINAL image coordinates with scores, labels and mask [n,1,H,W] uint8 (Masker output)."""
+        h, w = original_image.shape[:2]
+        resized = maskrcnn_resize(original_image, self.min_image_size, self.max_image_size)
+        x, hw = prepare_images([resized])
+        model = self._model(x.shape[1], x.shape[2])
+        (pred,) = model(x, hw)
+        model.paste_device(h, w, [(w, h)])
+        model.sync()
+        n = len(pred)
+        masks = model.fetch("det.masks", 1)[0, :n]
+        out = pred.resize((w, h))
+        out.add_field("mask", masks[:, None])
+        return out
+
+    def select_top_predictions(self, predictions):
+        scores = predictions.get_field("scores")
+        keep = np.nonzero(scores > self.confidence_threshold)[0]
+        predictions = predictions[keep]
+        order = np.argsort(-predictions.get_field("scores"), kind="stable")
+        return predictions[order]
+
+    def run_on_opencv_image(self, image):
+        predictions = self.select_top_predictions(self.compute_prediction(image))
+        return self.overlay(image.copy(), predictions)
+
+    @staticmethod
+    def compute_colors_for_labels(labels):
+        palette = np.array([2 ** 25 - 1, 2 ** 15 - 1, 2 ** 21 - 1], np.int64)
+        return ((np.asarray(labels, np.int64)[:, None] * palette) % 255).astype(np.uint8)
+
+    def overlay(self, image, predictions):
+        colors = self.compute_colors_for_labels(predictions.get_field("labels")) if len(predictions) else []
+        masks = predictions.get_field("mask") if predictions.has_field("mask") else None
+        H, W = image.shape[:2]
+        for k in range(len(predictions)):
+            c = colors[k].astype(np.float32)
+            if masks is not None:
+                m = masks[k, 0].astype(bool)
+                image[m] = (0.5 * image[m] + 0.5 * c).astype(np.uint8)
+            x1, y1, x2, y2 = (int(v) for v in predictions.bbox[k])
+            x1, x2 = max(0, min(W - 1, x1)), max(0, min(W - 1, x2))
+            y1, y2 = max(0, min(H - 1, y1)), max(0, min(H - 1, y2))
+            image[y1:y2 + 1, [x1, x2]] = colors[k]
+            image[[y1, y2], x1:x2 + 1] = colors[k]
+        return image
+
+    def close(self):
+        for m in self._models.values():
+            m.close()
+        self._models = {}
+
+
+def inference(predictor, images, image_ids=None):
+    """engine/inference.py-shaped evaluation loop: images (HxWx3 uint8 BGR) -> COCO-format result list
+    (bbox + segm) ready for json.dump (README.md:344-347)."""
+    from .coco import maskrcnn_results
+    results = []
+    for i, im in enumerate(images):
+        p = predictor.compute_prediction(im)
+        iid = image_ids[i] if image_ids is not None else i
+        results += maskrcnn_results(iid, p.bbox, p.get_field("scores"), p.get_field("labels"), p.get_field("mask")[:, 0])
+    return results

@@ -1,0 +1,61 @@
+"""COCODemo / inference() / Yolact eval-style output on the GPU: API shape of README.md:288-335 and 243-249,
+results consistent with the oracle pipeline run on the same transformed input."""
+import json
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_cocodemo_run_and_inference(ffi, tmp_path):
+    from isegmi.coco import rle_decode
+    from isegmi.maskrcnn import prepare_images
+    from isegmi.predictor import COCODemo, inference
+    from isegmi.transforms import maskrcnn_resize
+    from isegmi.weights import maskrcnn_state_dict
+    from oracle.maskrcnn_ref import MaskRCNNRef
+    sd = maskrcnn_state_dict(1234)
+    rng = np.random.default_rng(4)
+    image = rng.integers(0, 256, (150, 200, 3)).astype(np.uint8)      # HxWx3 uint8 BGR, as README.md:327-328 builds it
+    demo = COCODemo(None, min_image_size=192, confidence_threshold=0.2, state_dict=sd, max_image_size=320)
+    pred = demo.compute_prediction(image)
+    assert pred.size == (200, 150) and pred.get_field("mask").shape[1:] == (1, 150, 200)
+    # oracle on the same transformed input
+    x, hw = prepare_images([maskrcnn_resize(image, 192, 320)])
+    rd = MaskRCNNRef(sd).forward(x, hw)[0]
+    ratio = (np.float32(200 / hw[0, 1]), np.float32(150 / hw[0, 0]))
+    rm, rb = MaskRCNNRef.paste(rd, 150, 200, ratio)
+    assert np.array_equal(pred.bbox, rb) and np.array_equal(pred.get_field("scores"), rd["score"])
+    assert np.array_equal(pred.get_field("mask")[:, 0], rm)
+    top = demo.select_top_predictions(pred)
+    s = top.get_field("scores")
+    assert np.all(s > 0.2) and np.all(np.diff(s) <= 0)
+    out = demo.run_on_opencv_image(image)
+    assert out.shape == image.shape and out.dtype == np.uint8 and (len(top) == 0 or np.any(out != image))
+    res = inference(demo, [image], image_ids=[17])
+    assert len(res) == len(pred)
+    (tmp_path / "r.json").write_text(json.dumps(res))
+    k = int(np.argmax([r["score"] for r in res]))
+    assert res[k]["image_id"] == 17 and np.array_equal(rle_decode(res[k]["segmentation"]), pred.get_field("mask")[k, 0])
+    demo.close()
+
+
+def test_yolact_eval_style_output(ffi):
+    from isegmi.coco import rle_decode, yolact_results
+    from isegmi.transforms import yolact_transform
+    from isegmi.weights import yolact_state_dict
+    from isegmi.yolact import Yolact, postprocess
+    rng = np.random.default_rng(8)
+    frame = rng.integers(0, 256, (120, 160, 3)).astype(np.uint8)
+    net = Yolact(yolact_state_dict(1234), max_batch=1, input_size=200)
+    preds = net(yolact_transform(frame, 200))
+    classes, scores, boxes, masks = postprocess(preds, 160, 120, score_threshold=0.15)   # --score_threshold=0.15 (README.md:243)
+    top_k = 15                                                                          # --top_k=15
+    classes, scores, boxes, masks = classes[:top_k], scores[:top_k], boxes[:top_k], masks[:top_k]
+    assert masks.shape[1:] == (120, 160) and boxes.dtype == np.int64 and np.all(scores > 0.15) and np.all(np.diff(scores) <= 0)
+    res = yolact_results(3, classes, scores, boxes, masks)
+    assert len(res) == len(scores)
+    if res:
+        assert np.array_equal(rle_decode(res[0]["segmentation"]), masks[0])
+    net.close()
