@@ -118,7 +118,7 @@ for r in range(world):
     off += b - a
 assert off == GLOBAL
 dist.barrier(); dist.destroy_process_group()
-print("rank", rank, "ok")
+open(os.path.join(sys.argv[2], "ok_%d" % rank), "w").write("ok")
 '''
 
 
@@ -132,7 +132,7 @@ def test_world2_gloo_detection_gather(tmp_path):
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), str(script), ROOT]
+           "--master-port", str(port), str(script), ROOT, str(tmp_path)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+    assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists()
