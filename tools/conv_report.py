@@ -7,6 +7,7 @@ from isegmi.weights import yolact_state_dict
 from isegmi.yolact import Yolact, fast_base_transform
 bs = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 net = Yolact(yolact_state_dict(1234), max_batch=bs)
+net.set_param("multi_stream", 0.0)
 if len(sys.argv) > 2: net.set_param("conv_tile", float(sys.argv[2]))
 rng = np.random.default_rng(1)
 net.upload(fast_base_transform(rng.uniform(0, 255, (bs, 550, 550, 3)).astype(np.float32)))
