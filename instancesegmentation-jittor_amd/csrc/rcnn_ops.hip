@@ -64,7 +64,44 @@ __device__ __forceinline__ float iou_one(const float4 a, const float4 b, float o
     return dm_div(inter, aa + ab - inter);
 }
 
-// ------------------------------------------------------------------ greedy NMS core (block = 256 threads)
+// Division-free, EXACT form of `RN(inter / uni) > thr` (ge: `>= thr`).  RN is monotone, so the fp32 quotient
+// exceeds thr iff the real quotient lies beyond the midpoint between thr and its fp32 neighbour (ties go to the
+// even mantissa).  inter, uni are 24-bit, the midpoint 25-bit: their product is exact in fp64.  ~6 instructions
+// instead of an IEEE-correct fp32 division (~40) in the innermost NMS loop; bit-identical to the oracle's division.
+struct IouThr {
+    double m;       // midpoint
+    bool tie_true;  // result when inter == m * uni exactly
+};
+__device__ __forceinline__ IouThr make_iou_thr(float thr, int ge) {
+    IouThr t;
+    const unsigned b = __float_as_uint(thr);  // thr > 0
+    if (ge) {  // q >= thr  <=>  x >= mid(pred(thr), thr) (tie -> thr iff thr's mantissa is even)
+        const float lo = __uint_as_float(b - 1u);
+        t.m = 0.5 * ((double)lo + (double)thr);
+        t.tie_true = (b & 1u) == 0u;
+    } else {   // q > thr   <=>  x >= mid(thr, succ(thr)) (tie -> succ iff succ's mantissa is even)
+        const float hi = __uint_as_float(b + 1u);
+        t.m = 0.5 * ((double)thr + (double)hi);
+        t.tie_true = ((b + 1u) & 1u) == 0u;
+    }
+    return t;
+}
+__device__ __forceinline__ bool iou_exceeds(const float4 a, const float4 b, float one, const IouThr t) {
+    const float aa = (a.z - a.x + one) * (a.w - a.y + one);
+    const float ab = (b.z - b.x + one) * (b.w - b.y + one);
+    const float xx1 = a.x > b.x ? a.x : b.x, yy1 = a.y > b.y ? a.y : b.y;
+    const float xx2 = a.z < b.z ? a.z : b.z, yy2 = a.w < b.w ? a.w : b.w;
+    float w = xx2 - xx1 + one, h = yy2 - yy1 + one;
+    w = w > 0.0f ? w : 0.0f;
+    h = h > 0.0f ? h : 0.0f;
+    const float inter = w * h;
+    const float uni = aa + ab - inter;
+    if (!(uni > 0.0f)) return false;  // 0/0 or negative union: NaN / non-positive quotient never exceeds thr > 0
+    const double lhs = (double)inter, rhs = t.m * (double)uni;
+    return lhs > rhs || (lhs == rhs && t.tie_true);
+}
+
+// ------------------------------------------------------------------ greedy NMS core (block = NT threads)
 // sb[0..n) boxes in visiting order (score desc, index asc); pre_dead[i] != 0 marks boxes removed beforehand.
 // Writes kept positions (indices into sb) to kept[] in visiting order; returns the count (<= max_keep).
 // Chunk of 64: (1) 4 waves test the chunk against the kept list; (2) wave 0 resolves the chunk with one
@@ -73,11 +110,13 @@ constexpr int NMS_CAP = 1024;
 struct NmsShared {
     float4 sb[NMS_CAP];
     unsigned short kept[NMS_CAP];
-    unsigned long long supp[4];
+    unsigned long long supp[16];
     int kc;
 };
 __device__ int nms_block(NmsShared& S, int n, float thr, float one, int ge, int max_keep, const unsigned char* pre_dead) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nw = blockDim.x >> 6;
+    const IouThr T = make_iou_thr(thr, ge);
     if (tid == 0) S.kc = 0;
     __syncthreads();
     for (int c0 = 0; c0 < n; c0 += 64) {
@@ -87,16 +126,15 @@ __device__ int nms_block(NmsShared& S, int n, float thr, float one, int ge, int 
         const bool valid = i < n;
         const float4 mine = S.sb[valid ? i : 0];
         bool sup = false;
-        for (int j = wave; j < kc; j += 4) {
-            const float o = iou_one(S.sb[S.kept[j]], mine, one);
-            sup = sup || (ge ? (o >= thr) : (o > thr));
-        }
+        for (int j = wave; j < kc; j += nw) sup = sup || iou_exceeds(S.sb[S.kept[j]], mine, one, T);
         const unsigned long long sm = __ballot(sup);
         if (lane == 0) S.supp[wave] = sm;
         __syncthreads();
         if (wave == 0) {
             unsigned long long alive = __ballot(valid && !(pre_dead && pre_dead[i]));
-            alive &= ~(S.supp[0] | S.supp[1] | S.supp[2] | S.supp[3]);
+            unsigned long long sall = 0ull;
+            for (int q = 0; q < nw; ++q) sall |= S.supp[q];
+            alive &= ~sall;
             unsigned long long keepm = 0ull;
             int cnt = kc;
             for (int b = 0; b < 64; ++b) {
@@ -104,8 +142,7 @@ __device__ int nms_block(NmsShared& S, int n, float thr, float one, int ge, int 
                 keepm |= 1ull << b;
                 ++cnt;
                 if (max_keep > 0 && cnt >= max_keep) break;
-                const float o = iou_one(S.sb[c0 + b], mine, one);
-                const unsigned long long m = __ballot(ge ? (o >= thr) : (o > thr));
+                const unsigned long long m = __ballot(iou_exceeds(S.sb[c0 + b], mine, one, T));
                 const unsigned long long later = b == 63 ? 0ull : (~0ull << (b + 1));
                 alive &= ~(m & later);
             }
@@ -173,7 +210,7 @@ __global__ void rpn_sigmoid_kernel(const float* __restrict__ head, int64_t total
 
 // grid (N); one (image, level) per block.  tk_vals/tk_idx [N][pre_nms] sorted; tk_cnt [N].
 // out_boxes [N][L][post_cap][4], out_scores [N][L][post_cap] (-1 beyond count), out_cnt [N][L].
-__global__ __launch_bounds__(256) void rpn_decode_nms_kernel(const float* __restrict__ head, const float* __restrict__ anchors,
+__global__ __launch_bounds__(1024) void rpn_decode_nms_kernel(const float* __restrict__ head, const float* __restrict__ anchors,
                                                               const float* __restrict__ tk_vals, const int* __restrict__ tk_idx,
                                                               const int* __restrict__ tk_cnt, const int* __restrict__ image_hw,
                                                               int HWA, int A, int CH, int pre_nms, int post_nms, float thr,
@@ -185,7 +222,7 @@ __global__ __launch_bounds__(256) void rpn_decode_nms_kernel(const float* __rest
     const int n = blockIdx.x;
     const int cnt = tk_cnt[n];
     const float im_h = (float)image_hw[2 * n], im_w = (float)image_hw[2 * n + 1];
-    for (int j = threadIdx.x; j < cnt; j += 256) {
+    for (int j = threadIdx.x; j < cnt; j += blockDim.x) {
         const int idx = tk_idx[(int64_t)n * pre_nms + j];
         const int pix = idx / A, a = idx - pix * A;
         const float* hp = head + ((int64_t)n * (HWA / A) + pix) * CH + A + a * 4;
@@ -199,7 +236,7 @@ __global__ __launch_bounds__(256) void rpn_decode_nms_kernel(const float* __rest
     __syncthreads();
     const int kc = nms_block(S, cnt, thr, 1.0f, ge, post_nms, dead);
     const int64_t ob = ((int64_t)n * L + level) * post_cap;
-    for (int i = threadIdx.x; i < post_cap; i += 256) {
+    for (int i = threadIdx.x; i < post_cap; i += blockDim.x) {
         if (i < kc) {
             const int src = S.kept[i];
             *(float4*)(out_boxes + (ob + i) * 4) = S.sb[src];
@@ -533,6 +570,7 @@ int scale_boxes_launch(const float* boxes, const float* ratios, int N, int K, fl
 int nms_launch(const float* boxes, const float* scores, int problems, int n, float thr, int plus_one, int ge, int max_keep, int* keep,
                int* cnt, hipStream_t st) {
     ARG_CHECK(n > 0 && n <= NMS_CAP, "nms n must be in 1..1024");
+    ARG_CHECK(thr > 0.0f, "nms threshold must be > 0");
     if (problems == 0) return ISEGMI_OK;
     hipLaunchKernelGGL(nms_kernel, dim3(problems), dim3(256), 0, st, boxes, scores, n, thr, plus_one, ge, max_keep, keep, cnt);
     HIP_TRY(hipGetLastError());
@@ -549,7 +587,8 @@ int rpn_decode_nms_launch(const float* head, const float* anchors, const float* 
                           const int* image_hw, int N, int HWA, int A, int CH, int pre_nms, int post_nms, float thr, float min_size,
                           int ge, int level, int L, int post_cap, float* out_boxes, float* out_scores, int* out_cnt, hipStream_t st) {
     ARG_CHECK(pre_nms <= NMS_CAP && post_nms <= post_cap, "rpn sizes");
-    hipLaunchKernelGGL(rpn_decode_nms_kernel, dim3(N), dim3(256), 0, st, head, anchors, tk_vals, tk_idx, tk_cnt, image_hw, HWA, A, CH,
+    ARG_CHECK(thr > 0.0f, "nms threshold must be > 0");
+    hipLaunchKernelGGL(rpn_decode_nms_kernel, dim3(N), dim3(1024), 0, st, head, anchors, tk_vals, tk_idx, tk_cnt, image_hw, HWA, A, CH,
                        pre_nms, post_nms, thr, min_size, ge, level, L, post_cap, out_boxes, out_scores, out_cnt);
     HIP_TRY(hipGetLastError());
     return ISEGMI_OK;
@@ -598,6 +637,7 @@ int topk_launch(const float* keys, int64_t row_stride, int rows, int n, int k, c
 int box_postprocess_launch(const isegmi_box_post_args* a, hipStream_t st) {
     ARG_CHECK(a->N > 0 && a->R > 0 && a->R <= NMS_CAP && a->ncls >= 2, "box post sizes (R <= 1024)");
     ARG_CHECK(a->det_per_img > 0 && a->det_per_img <= 1024 && a->cap >= a->det_per_img, "det_per_img / cap");
+    ARG_CHECK(a->nms_thresh > 0.0f, "nms threshold must be > 0");
     const int nc = a->ncls - 1;
     int rc = softmax_rows_launch(a->d_logits, (int64_t)a->N * a->R, a->ncls, a->logits_stride, a->d_ws_prob, st);
     if (rc) return rc;
