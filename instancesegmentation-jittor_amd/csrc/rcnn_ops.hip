@@ -426,46 +426,62 @@ __global__ __launch_bounds__(256) void box_cls_nms_kernel(const float* __restric
     if (tid == 0 && kc) atomicAdd(&kept_total[n], kc);
 }
 
-// grid (N), block 256.  Walks cand_scores [nc][R] in class-major order, keeps score >= thr (thr = the
-// det_per_img-th largest when more than det_per_img survive), order preserved, at most cap rows.
-__global__ __launch_bounds__(256) void finalize_dets_kernel(const float* __restrict__ cand_scores, const float* __restrict__ cand_boxes,
-                                                             const int* __restrict__ kept_total, const float* __restrict__ top_vals,
-                                                             int nc, int R, int det_per_img, int cap, int* __restrict__ out_cnt,
-                                                             float* __restrict__ out_boxes, float* __restrict__ out_scores,
-                                                             int* __restrict__ out_labels) {
-    __shared__ int wtot[4];
-    __shared__ int run_s;
-    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// grid (N), block 1024 (16 waves).  Keeps score >= thr (thr = the det_per_img-th largest when more than det_per_img
+// survive), class-major order preserved, at most cap rows.  Kept entries of a class are contiguous from rank 0
+// (-1 beyond), so wave w walks classes w, w+16, ... 64 ranks at a time and stops at the first -1: work ~ sum of kept
+// counts, not nc*R.  Two passes (count, then place) with ballot/popcount ranks keep the output order deterministic.
+__global__ __launch_bounds__(1024) void finalize_dets_kernel(const float* __restrict__ cand_scores, const float* __restrict__ cand_boxes,
+                                                              const int* __restrict__ kept_total, const float* __restrict__ top_vals,
+                                                              int nc, int R, int det_per_img, int cap, int* __restrict__ out_cnt,
+                                                              float* __restrict__ out_boxes, float* __restrict__ out_scores,
+                                                              int* __restrict__ out_labels) {
+    __shared__ int cls_pass[256];
+    __shared__ int cls_base[256];
+    __shared__ int total_s;
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     const int tot = kept_total[n];
     const bool cut = det_per_img > 0 && tot > det_per_img;
     const float thr = cut ? top_vals[(int64_t)n * det_per_img + det_per_img - 1] : -1e30f;
     const float* cs = cand_scores + (int64_t)n * nc * R;
-    if (tid == 0) run_s = 0;
-    __syncthreads();
-    const int total = nc * R;
-    for (int base = 0; base < total; base += 256) {
-        const int i = base + tid;
-        const float s = i < total ? cs[i] : -1.0f;
-        const bool ok = s >= 0.0f && s >= thr;
-        const unsigned long long bm = __ballot(ok);
-        if (lane == 0) wtot[wave] = __popcll(bm);
-        __syncthreads();
-        int pre = run_s;
-        for (int w = 0; w < wave; ++w) pre += wtot[w];
-        const int pos = pre + __popcll(bm & ((1ull << lane) - 1ull));
-        if (ok && pos < cap) {
-            const int64_t o = (int64_t)n * cap + pos;
-            out_scores[o] = s;
-            out_labels[o] = i / R + 1;
-            *(float4*)(out_boxes + o * 4) = *(const float4*)(cand_boxes + ((int64_t)n * nc * R + i) * 4);
+    for (int c = wave; c < nc; c += nw) {
+        int cnt = 0;
+        for (int r0 = 0; r0 < R; r0 += 64) {
+            const int r = r0 + lane;
+            const float s = r < R ? cs[(int64_t)c * R + r] : -1.0f;
+            cnt += __popcll(__ballot(s >= 0.0f && s >= thr));
+            if (__ballot(s < 0.0f)) break;  // end of this class's kept list (wave-uniform)
         }
-        __syncthreads();
-        if (tid == 0) run_s += wtot[0] + wtot[1] + wtot[2] + wtot[3];
-        __syncthreads();
+        if (lane == 0) cls_pass[c] = cnt;
     }
-    const int cnt = run_s < cap ? run_s : cap;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int c = 0; c < nc; ++c) { cls_base[c] = run; run += cls_pass[c]; }
+        total_s = run;
+    }
+    __syncthreads();
+    for (int c = wave; c < nc; c += nw) {
+        int run = cls_base[c];
+        if (cls_pass[c] == 0) continue;
+        for (int r0 = 0; r0 < R; r0 += 64) {
+            const int r = r0 + lane;
+            const float s = r < R ? cs[(int64_t)c * R + r] : -1.0f;
+            const bool ok = s >= 0.0f && s >= thr;
+            const unsigned long long bm = __ballot(ok);
+            const int pos = run + __popcll(bm & ((1ull << lane) - 1ull));
+            if (ok && pos < cap) {
+                const int64_t o = (int64_t)n * cap + pos;
+                out_scores[o] = s;
+                out_labels[o] = c + 1;
+                *(float4*)(out_boxes + o * 4) = *(const float4*)(cand_boxes + ((int64_t)n * nc * R + (int64_t)c * R + r) * 4);
+            }
+            run += __popcll(bm);
+            if (__ballot(s < 0.0f)) break;
+        }
+    }
+    const int cnt = total_s < cap ? total_s : cap;
     if (tid == 0) out_cnt[n] = cnt;
-    for (int q = cnt + tid; q < cap; q += 256) {
+    for (int q = cnt + tid; q < cap; q += blockDim.x) {
         const int64_t o = (int64_t)n * cap + q;
         out_scores[o] = 0.0f; out_labels[o] = 0;
         *(float4*)(out_boxes + o * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -635,7 +651,7 @@ int topk_launch(const float* keys, int64_t row_stride, int rows, int n, int k, c
 
 // box post-processing for N images: logits -> detections.  Workspaces are caller-provided.
 int box_postprocess_launch(const isegmi_box_post_args* a, hipStream_t st) {
-    ARG_CHECK(a->N > 0 && a->R > 0 && a->R <= NMS_CAP && a->ncls >= 2, "box post sizes (R <= 1024)");
+    ARG_CHECK(a->N > 0 && a->R > 0 && a->R <= NMS_CAP && a->ncls >= 2 && a->ncls <= 257, "box post sizes (R <= 1024, ncls <= 257)");
     ARG_CHECK(a->det_per_img > 0 && a->det_per_img <= 1024 && a->cap >= a->det_per_img, "det_per_img / cap");
     ARG_CHECK(a->nms_thresh > 0.0f, "nms threshold must be > 0");
     const int nc = a->ncls - 1;
@@ -649,7 +665,7 @@ int box_postprocess_launch(const isegmi_box_post_args* a, hipStream_t st) {
     rc = topk_launch(a->d_ws_cand_scores, (int64_t)nc * a->R, a->N, nc * a->R, a->det_per_img, a->d_ws_kept_total, 1, a->d_ws_top_vals,
                      a->d_ws_top_idx, nullptr, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(finalize_dets_kernel, dim3(a->N), dim3(256), 0, st, a->d_ws_cand_scores, a->d_ws_cand_boxes, a->d_ws_kept_total,
+    hipLaunchKernelGGL(finalize_dets_kernel, dim3(a->N), dim3(1024), 0, st, a->d_ws_cand_scores, a->d_ws_cand_boxes, a->d_ws_kept_total,
                        a->d_ws_top_vals, nc, a->R, a->det_per_img, a->cap, a->d_out_count, a->d_out_boxes, a->d_out_scores,
                        a->d_out_labels);
     HIP_TRY(hipGetLastError());
