@@ -325,7 +325,8 @@ def main_maskrcnn(a):
                           "proposals_per_image": [int(c) for c in pc], "detections_per_image": [int(c) for c in cnt]},
                "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel (all conv launches of a step)",
                             "pass": "K single-stream steps right after the timed region, HIP events around every conv launch", "achieved": round(achieved, 2),
-                            "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                            "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic("r01_pmc_maskrcnn.json"),
+                            "traffic_note": "HBM bytes per conv launch from separate rocprofv3 --pmc passes (profiles/r01_pmc_maskrcnn.json; FETCH x2 gfx950 correction); not collected live",
                             "algorithmic_gflop_per_step": round(f.value / a.steps / 1e9, 2), "conv_ms_per_step": round(m.value / a.steps, 3),
                             "launches_per_step": l.value // a.steps, "avg_launch_us": round(m.value * 1e3 / max(l.value, 1), 2)},
                "p50_ms_per_image": round(elapsed / a.steps * 1e3 / a.batch, 3)}
@@ -349,11 +350,18 @@ def main_maskrcnn(a):
             os.environ["OMP_NUM_THREADS"] = str(ncpu)
             ref = MaskRCNNRef(sd)
             tc = time.perf_counter()
-            d = ref.forward(x[:1], hw[:1])
-            MaskRCNNRef.paste(d[0], 800, 1333)
-            tcpu = time.perf_counter() - tc
-            out["cpu_baseline"] = {"value": round(1 / tcpu, 4), "unit": "img/s", "cores": ncpu, "kind": "port",
-                                   "sample": "1 image of the bench batch, oracle/ C+numpy restatement (AVX2 FMA + OpenMP, %d threads), %.1f s" % (ncpu, tcpu)}
+            done = 0
+            d = None
+            while True:  # bounded sample: whole images until ~10 s of CPU work (cap 6)
+                d_ = ref.forward(x[:1], hw[:1])
+                MaskRCNNRef.paste(d_[0], 800, 1333)
+                d = d or d_
+                done += 1
+                tcpu = time.perf_counter() - tc
+                if tcpu >= 10.0 or done >= 6:
+                    break
+            out["cpu_baseline"] = {"value": round(done / tcpu, 4), "unit": "img/s", "cores": ncpu, "kind": "port",
+                                   "sample": "%d passes over 1 image of the bench batch, oracle/ C+numpy restatement (AVX2 FMA + OpenMP, %d threads), %.1f s" % (done, ncpu, tcpu)}
             got = model.fetch("det.box", 1)[0]
             out["parity_vs_oracle_on_bench_batch"] = bool(np.array_equal(got[: len(d[0]["box"])], d[0]["box"]))
         print(json.dumps(out), flush=True)
