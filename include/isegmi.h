@@ -66,6 +66,15 @@ int isegmi_op_conv2d(const isegmi_conv_desc* d, const float* d_in, const float* 
                      const float* d_scale, const float* d_shift, const float* d_residual,
                      float* d_out, void* stream);
 
+/* fp16 variant (BASELINE configs[4]: "fp16 MFMA conv"): fp16 storage, v_mfma_f32_32x32x16_f16, fp32 accumulate
+ * and epilogue.  Cin % 64 == 0; act none/relu; d_in / d_wpacked / d_residual are fp16, d_out fp16 or (out_f32)
+ * fp32.  The 16-term sum inside one MFMA is not an ordered chain: parity with the oracle is tolerance-based. */
+int isegmi_conv_packed_halfs(const isegmi_conv_desc* d, int64_t* n);
+int isegmi_pack_conv_weights_f16(const isegmi_conv_desc* d, const float* h_w_krsc, uint16_t* h_packed);
+int isegmi_op_conv2d_f16(const isegmi_conv_desc* d, const void* d_in, const void* d_wpacked,
+                         const float* d_scale, const float* d_shift, const void* d_residual, void* d_out,
+                         int out_f32, void* stream);
+
 /* max_pool2d(k,s,p), -inf padding (M2/Y2 stem; k=1,s=2 = LastLevelMaxPool M3) */
 int isegmi_op_maxpool(const float* d_in, int N, int H, int W, int C, int k, int s, int p,
                       float* d_out, void* stream);

@@ -24,11 +24,11 @@ int eng_buf(Engine& e, const std::string& name, int64_t bytes, void** out, int d
     return ISEGMI_OK;
 }
 
-int eng_act(Engine& e, const std::string& name, int N, int H, int W, int C, Tensor* t) {
+int eng_act(Engine& e, const std::string& name, int N, int H, int W, int C, Tensor* t, int dt) {
     void* p = nullptr;
-    int rc = eng_buf(e, name, (int64_t)N * H * W * C * (int64_t)sizeof(float), &p, 0, {N, H, W, C});
+    int rc = eng_buf(e, name, (int64_t)N * H * W * C * (dt ? 2 : 4), &p, dt ? 4 : 0, {N, H, W, C});
     if (rc) return rc;
-    t->d = (float*)p; t->N = N; t->H = H; t->W = W; t->C = C;
+    t->d = (float*)p; t->N = N; t->H = H; t->W = W; t->C = C; t->dt = dt;
     return ISEGMI_OK;
 }
 
@@ -39,14 +39,16 @@ static int find_conv(Engine& e, const std::string& layer, const ConvLayer** out)
     return ISEGMI_OK;
 }
 
-static int timed_conv(Engine& e, const std::string& label, const isegmi_conv_desc* d, const float* in, const ConvLayer* L, const float* res, float* out) {
+static int timed_conv(Engine& e, const std::string& label, const isegmi_conv_desc* d, const float* in, const ConvLayer* L, const float* res, void* out,
+                      bool out_f32 = false) {
     hipEvent_t a = nullptr, b = nullptr;
     if (e.conv_timing) {
         HIP_TRY(hipEventCreate(&a));
         HIP_TRY(hipEventCreate(&b));
         HIP_TRY(hipEventRecord(a, e.cur));
     }
-    int rc = conv2d_launch(d, in, L->d_w, L->d_scale, L->d_shift, res, out, e.cur);
+    int rc = L->f16 ? conv2d_f16_launch(d, in, L->d_w, L->d_scale, L->d_shift, res, out, out_f32 ? 1 : 0, e.cur)
+                    : conv2d_launch(d, in, L->d_w, L->d_scale, L->d_shift, res, (float*)out, e.cur);
     if (e.conv_timing) {
         HIP_TRY(hipEventRecord(b, e.cur));
         e.conv_evs.push_back({a, b});
@@ -61,34 +63,37 @@ static int timed_conv(Engine& e, const std::string& label, const isegmi_conv_des
     return rc;
 }
 
-int eng_conv_into(Engine& e, const std::string& layer, const Tensor& in, int stride, int pad, int act, float* dst, int out_div,
-                  int64_t out_img_stride, int64_t out_pix_stride) {
+int eng_conv_into(Engine& e, const std::string& layer, const Tensor& in, int stride, int pad, int act, void* dst, int out_div,
+                  int64_t out_img_stride, int64_t out_pix_stride, bool out_f32) {
     const ConvLayer* L;
     int rc = find_conv(e, layer, &L);
     if (rc) return rc;
     if (L->Cin != in.C) { set_error("conv " + layer + ": Cin mismatch"); return ISEGMI_ERR_ARG; }
+    if ((in.dt == 1) != L->f16) { set_error("conv " + layer + ": activation / weight precision mismatch"); return ISEGMI_ERR_STATE; }
     isegmi_conv_desc d;
     memset(&d, 0, sizeof(d));
     d.N = in.N; d.H = in.H; d.W = in.W; d.Cin = in.C; d.Cout = L->Cout; d.R = L->R; d.S = L->S; d.stride = stride; d.pad = pad;
     d.act = act; d.tile = (int)e.param("conv_tile", 0); d.out_div = out_div; d.out_img_stride = out_img_stride;
     d.out_pix_stride = out_pix_stride;
-    return timed_conv(e, layer, &d, in.d, L, nullptr, dst);
+    return timed_conv(e, layer, &d, in.d, L, nullptr, dst, out_f32);
 }
 
 int eng_conv(Engine& e, const std::string& layer, const Tensor& in, int stride, int pad, int act, const Tensor* residual,
-             const std::string& out_name, Tensor* out) {
+             const std::string& out_name, Tensor* out, bool out_f32) {
     const ConvLayer* L;
     int rc = find_conv(e, layer, &L);
     if (rc) return rc;
     if (L->Cin != in.C) { set_error("conv " + layer + ": Cin mismatch"); return ISEGMI_ERR_ARG; }
+    if ((in.dt == 1) != L->f16) { set_error("conv " + layer + ": activation / weight precision mismatch"); return ISEGMI_ERR_STATE; }
+    if (residual && residual->dt != in.dt) { set_error("conv " + layer + ": residual precision mismatch"); return ISEGMI_ERR_STATE; }
     const int Ho = (in.H + 2 * pad - L->R) / stride + 1, Wo = (in.W + 2 * pad - L->S) / stride + 1;
-    rc = eng_act(e, out_name, in.N, Ho, Wo, L->Cout, out);
+    rc = eng_act(e, out_name, in.N, Ho, Wo, L->Cout, out, (L->f16 && !out_f32) ? 1 : 0);
     if (rc) return rc;
     isegmi_conv_desc d;
     memset(&d, 0, sizeof(d));
     d.N = in.N; d.H = in.H; d.W = in.W; d.Cin = in.C; d.Cout = L->Cout; d.R = L->R; d.S = L->S; d.stride = stride; d.pad = pad;
     d.act = act; d.tile = (int)e.param("conv_tile", 0);
-    return timed_conv(e, layer, &d, in.d, L, residual ? residual->d : nullptr, out->d);
+    return timed_conv(e, layer, &d, in.d, L, residual ? residual->d : nullptr, out->d, out_f32);
 }
 
 static int next_event(Engine& e, hipEvent_t* ev) {
@@ -359,6 +364,7 @@ extern "C" int isegmi_engine_set_param(isegmi_engine* h, const char* name, float
     if (std::string(name) == "timing") h->e.timing = value != 0.0f;
     if (std::string(name) == "conv_timing") h->e.conv_timing = value != 0.0f;
     if (std::string(name) == "multi_stream") h->e.multi_stream = value != 0.0f;
+    if (std::string(name) == "fp16") h->e.fp16 = value != 0.0f;
     return ISEGMI_OK;
 }
 
@@ -368,17 +374,27 @@ extern "C" int isegmi_engine_set_conv(isegmi_engine* h, const char* name, int Co
     isegmi_conv_desc d;
     memset(&d, 0, sizeof(d));
     d.N = 1; d.H = R; d.W = S; d.Cin = Cin; d.Cout = Cout; d.R = R; d.S = S; d.stride = 1; d.pad = 0;
-    int64_t nf = 0;
-    TRY(isegmi_conv_packed_floats(&d, &nf));
-    std::vector<float> packed((size_t)nf);
-    TRY(isegmi_pack_conv_weights(&d, h_w_krsc, packed.data()));
+    const bool f16 = h->e.fp16 && Cin % 64 == 0;  // the Cin=4 stem stays on the fp32 kernel
     ConvLayer& L = h->e.convs[name];
     if (L.d_w) { (void)hipFree(L.d_w); L.d_w = nullptr; }
     if (L.d_scale) { (void)hipFree(L.d_scale); L.d_scale = nullptr; }
     if (L.d_shift) { (void)hipFree(L.d_shift); L.d_shift = nullptr; }
-    L.Cout = Cout; L.R = R; L.S = S; L.Cin = Cin;
-    HIP_TRY(hipMalloc((void**)&L.d_w, (size_t)nf * 4));
-    HIP_TRY(hipMemcpy(L.d_w, packed.data(), (size_t)nf * 4, hipMemcpyHostToDevice));
+    L.Cout = Cout; L.R = R; L.S = S; L.Cin = Cin; L.f16 = f16;
+    if (f16) {
+        int64_t nh = 0;
+        TRY(isegmi_conv_packed_halfs(&d, &nh));
+        std::vector<uint16_t> packed((size_t)nh);
+        TRY(isegmi_pack_conv_weights_f16(&d, h_w_krsc, packed.data()));
+        HIP_TRY(hipMalloc((void**)&L.d_w, (size_t)nh * 2));
+        HIP_TRY(hipMemcpy(L.d_w, packed.data(), (size_t)nh * 2, hipMemcpyHostToDevice));
+    } else {
+        int64_t nf = 0;
+        TRY(isegmi_conv_packed_floats(&d, &nf));
+        std::vector<float> packed((size_t)nf);
+        TRY(isegmi_pack_conv_weights(&d, h_w_krsc, packed.data()));
+        HIP_TRY(hipMalloc((void**)&L.d_w, (size_t)nf * 4));
+        HIP_TRY(hipMemcpy(L.d_w, packed.data(), (size_t)nf * 4, hipMemcpyHostToDevice));
+    }
     if (h_scale) { HIP_TRY(hipMalloc((void**)&L.d_scale, (size_t)Cout * 4)); HIP_TRY(hipMemcpy(L.d_scale, h_scale, (size_t)Cout * 4, hipMemcpyHostToDevice)); }
     if (h_shift) { HIP_TRY(hipMalloc((void**)&L.d_shift, (size_t)Cout * 4)); HIP_TRY(hipMemcpy(L.d_shift, h_shift, (size_t)Cout * 4, hipMemcpyHostToDevice)); }
     return ISEGMI_OK;

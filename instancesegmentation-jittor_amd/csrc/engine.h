@@ -12,12 +12,14 @@ namespace isegmi {
 struct Tensor {
     float* d = nullptr;
     int N = 0, H = 0, W = 0, C = 0;
+    int dt = 0;  // 0 fp32, 1 fp16 storage
     int64_t numel() const { return (int64_t)N * H * W * C; }
 };
 
 struct ConvLayer {
     int Cout = 0, R = 0, S = 0, Cin = 0;
-    float* d_w = nullptr;      // packed
+    float* d_w = nullptr;      // packed (fp32 image, or fp16 image when f16)
+    bool f16 = false;
     float* d_scale = nullptr;  // may be null (=1)
     float* d_shift = nullptr;  // may be null (=0)
 };
@@ -41,6 +43,7 @@ struct Engine {
     hipStream_t side[3] = {nullptr, nullptr, nullptr};  // side streams for independent branches
     hipStream_t cur = nullptr;             // stream the next launch goes to
     bool multi_stream = true;
+    bool fp16 = false;                     // fp16 storage + f16 MFMA convs (BASELINE configs[4]); set before loading weights
     std::vector<hipEvent_t> ev_pool;
     size_t ev_next = 0;
     std::map<std::string, ConvLayer> convs;
@@ -74,12 +77,12 @@ struct Engine {
 // engine.cpp helpers
 int eng_buf(Engine& e, const std::string& name, int64_t bytes, void** out, int dtype = 0,
             std::vector<int64_t> shape = {});
-int eng_act(Engine& e, const std::string& name, int N, int H, int W, int C, Tensor* t);
+int eng_act(Engine& e, const std::string& name, int N, int H, int W, int C, Tensor* t, int dt = 0);
 int eng_conv(Engine& e, const std::string& layer, const Tensor& in, int stride, int pad, int act, const Tensor* residual,
-             const std::string& out_name, Tensor* out);
+             const std::string& out_name, Tensor* out, bool out_f32 = false);
 // conv writing into a caller-provided strided destination (heads -> concatenated buffers, deconv parities)
-int eng_conv_into(Engine& e, const std::string& layer, const Tensor& in, int stride, int pad, int act, float* dst, int out_div,
-                  int64_t out_img_stride, int64_t out_pix_stride);
+int eng_conv_into(Engine& e, const std::string& layer, const Tensor& in, int stride, int pad, int act, void* dst, int out_div,
+                  int64_t out_img_stride, int64_t out_pix_stride, bool out_f32 = false);
 void eng_mark(Engine& e, const char* name);
 // fork(k): side stream k waits for everything queued on the main stream so far; join(k): main waits for side k.
 int eng_fork(Engine& e, int k);
@@ -100,6 +103,14 @@ int maskrcnn_paste(Engine& e, const float* h_ratios_wh, int out_h, int out_w);
 // kernels implemented in other translation units
 int conv2d_launch(const isegmi_conv_desc* d, const float* in, const float* w, const float* scale, const float* shift,
                   const float* res, float* out, hipStream_t st);
+int conv2d_f16_launch(const isegmi_conv_desc* d, const void* in, const void* w, const float* scale, const float* shift, const void* res,
+                      void* out, int out_f32, hipStream_t st);
+int maxpool_to_f16_launch(const void* in, int in_f16, int N, int H, int W, int C, int k, int s, int p, void* out, hipStream_t st);
+int nearest2x_add_f16_launch(const void* coarse, int N, int Hc, int Wc, int C, const void* lat, int H, int W, void* out, hipStream_t st);
+int roi_align_f16_launch(const void* const* feats, const int* Hs, const int* Ws, const float* scales, int nlevels, const float* rois,
+                         const int* counts, int N, int K, int C, int PH, int PW, int g, int k_min, void* out, hipStream_t st);
+int mask_logits_select_f16_launch(const void* feat, int R, int HW, int C, const float* w, const float* b, const int* labels, float* out,
+                                  hipStream_t st);
 int maxpool_launch(const float* in, int N, int H, int W, int C, int k, int s, int p, float* out, hipStream_t st);
 int resize_bilinear_launch(const float* in, int N, int H, int W, int C, int Ho, int Wo, const float* add, int relu, float* out,
                            hipStream_t st);

@@ -64,14 +64,16 @@ int maskrcnn_forward(Engine& e, const float* d_images, const int32_t* h_image_hw
         }
     }
 
+    const int dt = e.fp16 ? 1 : 0;  // storage type of everything after the stem
     Tensor x4, s, x;
     TRY(eng_act(e, "input4", N, H, W, 4, &x4));
     TRY(pad_c3_c4_launch(d_images, (int64_t)N * H * W, x4.d, st));
     TRY(eng_conv(e, "backbone.body.stem.conv1", x4, 2, 3, 1, nullptr, "stem", &s));
     {
         const int Ho = (s.H + 2 - 3) / 2 + 1, Wo = (s.W + 2 - 3) / 2 + 1;
-        TRY(eng_act(e, "pool", N, Ho, Wo, s.C, &x));
-        TRY(maxpool_launch(s.d, N, s.H, s.W, s.C, 3, 2, 1, x.d, st));
+        TRY(eng_act(e, "pool", N, Ho, Wo, s.C, &x, dt));
+        if (dt) TRY(maxpool_to_f16_launch(s.d, 0, N, s.H, s.W, s.C, 3, 2, 1, x.d, st));  // fp32 stem -> fp16 trunk
+        else TRY(maxpool_launch(s.d, N, s.H, s.W, s.C, 3, 2, 1, x.d, st));
     }
     eng_mark(e, "stem");
     const int depth = (int)e.param("resnet_depth", 50);
@@ -103,8 +105,9 @@ int maskrcnn_forward(Engine& e, const float* d_images, const int32_t* h_image_hw
     for (int l = 2; l >= 0; --l) {
         const std::string ls = std::to_string(l + 1);
         TRY(eng_conv(e, "backbone.fpn.fpn_inner" + ls, C[l], 1, 0, 0, nullptr, "fpn.lat" + ls, &lat));
-        TRY(eng_act(e, "fpn.last" + ls, N, lat.H, lat.W, lat.C, &last[l]));
-        TRY(nearest2x_add_launch(last[l + 1].d, N, last[l + 1].H, last[l + 1].W, last[l + 1].C, lat.d, lat.H, lat.W, last[l].d, st));
+        TRY(eng_act(e, "fpn.last" + ls, N, lat.H, lat.W, lat.C, &last[l], dt));
+        if (dt) TRY(nearest2x_add_f16_launch(last[l + 1].d, N, last[l + 1].H, last[l + 1].W, last[l + 1].C, lat.d, lat.H, lat.W, last[l].d, st));
+        else TRY(nearest2x_add_launch(last[l + 1].d, N, last[l + 1].H, last[l + 1].W, last[l + 1].C, lat.d, lat.H, lat.W, last[l].d, st));
     }
     eng_mark(e, "fpn_topdown");
 
@@ -129,7 +132,7 @@ int maskrcnn_forward(Engine& e, const float* d_images, const int32_t* h_image_hw
         const std::string ls = std::to_string(l);
         Tensor t, head;
         TRY(eng_conv(e, "rpn.head.conv", P[l], 1, 1, 1, nullptr, "rpn.t" + ls, &t));
-        TRY(eng_conv(e, "rpn.head.cls_bbox", t, 1, 0, 0, nullptr, "rpn.head" + ls, &head));
+        TRY(eng_conv(e, "rpn.head.cls_bbox", t, 1, 0, 0, nullptr, "rpn.head" + ls, &head, /*out_f32=*/true));
         const int HW = head.H * head.W, HWA = HW * A;
         const RawBuf* anc;
         TRY(need_tensor(e, "anchors." + ls, (int64_t)HWA * 16, &anc));
@@ -155,8 +158,9 @@ int maskrcnn_forward(Engine& e, const float* d_images, const int32_t* h_image_hw
     }
     {
         const int Ho = (P[3].H - 1) / 2 + 1, Wo = (P[3].W - 1) / 2 + 1;
-        TRY(eng_act(e, "P6", N, Ho, Wo, P[3].C, &P[4]));
-        TRY(maxpool_launch(P[3].d, N, P[3].H, P[3].W, P[3].C, 1, 2, 0, P[4].d, st));
+        TRY(eng_act(e, "P6", N, Ho, Wo, P[3].C, &P[4], dt));
+        if (dt) TRY(maxpool_to_f16_launch(P[3].d, 1, N, P[3].H, P[3].W, P[3].C, 1, 2, 0, P[4].d, st));
+        else TRY(maxpool_launch(P[3].d, N, P[3].H, P[3].W, P[3].C, 1, 2, 0, P[4].d, st));
         TRY(rpn_level(4));
     }
     TRY(eng_join(e, 0));
@@ -182,11 +186,12 @@ int maskrcnn_forward(Engine& e, const float* d_images, const int32_t* h_image_hw
     const int Hs[4] = {P[0].H, P[1].H, P[2].H, P[3].H}, Ws[4] = {P[0].W, P[1].W, P[2].W, P[3].W};
     const float scales[4] = {0.25f, 0.125f, 0.0625f, 0.03125f};
     Tensor roi7, f6, f7, cb;
-    TRY(eng_act(e, "box.roi_feat", N * R, 7, 7, 256, &roi7));
-    TRY(roi_align_launch(feats, Hs, Ws, scales, 4, props, prop_cnt, N, R, 256, 7, 7, 2, 2, -1, roi7.d, nullptr, st));
+    TRY(eng_act(e, "box.roi_feat", N * R, 7, 7, 256, &roi7, dt));
+    if (dt) TRY(roi_align_f16_launch((const void* const*)feats, Hs, Ws, scales, 4, props, prop_cnt, N, R, 256, 7, 7, 2, 2, roi7.d, st));
+    else TRY(roi_align_launch(feats, Hs, Ws, scales, 4, props, prop_cnt, N, R, 256, 7, 7, 2, 2, -1, roi7.d, nullptr, st));
     TRY(eng_conv(e, "roi_heads.box.feature_extractor.fc6", roi7, 1, 0, 1, nullptr, "box.fc6", &f6));
     TRY(eng_conv(e, "roi_heads.box.feature_extractor.fc7", f6, 1, 0, 1, nullptr, "box.fc7", &f7));
-    TRY(eng_conv(e, "roi_heads.box.predictor.cls_bbox", f7, 1, 0, 0, nullptr, "box.cls_bbox", &cb));
+    TRY(eng_conv(e, "roi_heads.box.predictor.cls_bbox", f7, 1, 0, 0, nullptr, "box.cls_bbox", &cb, /*out_f32=*/true));
     const int ncls = 81, cap = (int)e.param("detections_per_img", 100), dpi = cap;
     if (cb.C != ncls * 5) { set_error("cls_bbox layer must have 81+324 outputs"); return ISEGMI_ERR_STATE; }
     isegmi_box_post_args a;
@@ -211,30 +216,32 @@ int maskrcnn_forward(Engine& e, const float* d_images, const int32_t* h_image_hw
 
     // ---- mask head
     Tensor m;
-    TRY(eng_act(e, "mask.roi_feat", N * cap, 14, 14, 256, &m));
-    TRY(roi_align_launch(feats, Hs, Ws, scales, 4, a.d_out_boxes, a.d_out_count, N, cap, 256, 14, 14, 2, 2, -1, m.d, nullptr, st));
+    TRY(eng_act(e, "mask.roi_feat", N * cap, 14, 14, 256, &m, dt));
+    if (dt) TRY(roi_align_f16_launch((const void* const*)feats, Hs, Ws, scales, 4, a.d_out_boxes, a.d_out_count, N, cap, 256, 14, 14, 2, 2, m.d, st));
+    else TRY(roi_align_launch(feats, Hs, Ws, scales, 4, a.d_out_boxes, a.d_out_count, N, cap, 256, 14, 14, 2, 2, -1, m.d, nullptr, st));
     for (int i = 1; i <= 4; ++i) {
         Tensor o;
         TRY(eng_conv(e, "roi_heads.mask.feature_extractor.mask_fcn" + std::to_string(i), m, 1, 1, 1, nullptr, "mask.fcn" + std::to_string(i), &o));
         m = o;
     }
     Tensor up;
-    TRY(eng_act(e, "mask.deconv", N * cap, 28, 28, 256, &up));
+    TRY(eng_act(e, "mask.deconv", N * cap, 28, 28, 256, &up, dt));
     {
         // ConvTranspose2d(2,2,s2): out[r, 2i+a, 2j+b, :] = W_ab * in[r, i, j, :] + bias  -> four strided 1x1 convs.
         Tensor rows;  // view: (r, i) as "images" of 1 x 14 pixels
-        rows.d = m.d; rows.N = N * cap * 14; rows.H = 1; rows.W = 14; rows.C = 256;
+        rows.d = m.d; rows.N = N * cap * 14; rows.H = 1; rows.W = 14; rows.C = 256; rows.dt = dt;
         for (int ab = 0; ab < 4; ++ab) {
             const int aa = ab >> 1, bb = ab & 1;
             TRY(eng_conv_into(e, "roi_heads.mask.predictor.conv5_mask." + std::to_string(ab), rows, 1, 0, 1,
-                              up.d + (int64_t)(aa * 28 + bb) * 256, 14, (int64_t)2 * 28 * 256, 2 * 256));
+                              (char*)up.d + (int64_t)(aa * 28 + bb) * 256 * (dt ? 2 : 4), 14, (int64_t)2 * 28 * 256, 2 * 256));
         }
     }
     const RawBuf *lw, *lb;
     TRY(need_tensor(e, "mask_logits.w", (int64_t)ncls * 256 * 4, &lw));
     TRY(need_tensor(e, "mask_logits.b", (int64_t)ncls * 4, &lb));
     TRY(eng_buf(e, "det.mask28", (int64_t)N * cap * 784 * 4, &p, 0, {N, cap, 28, 28}));
-    TRY(mask_logits_select_launch(up.d, N * cap, 784, 256, (const float*)lw->d, (const float*)lb->d, a.d_out_labels, (float*)p, st));
+    if (dt) TRY(mask_logits_select_f16_launch(up.d, N * cap, 784, 256, (const float*)lw->d, (const float*)lb->d, a.d_out_labels, (float*)p, st));
+    else TRY(mask_logits_select_launch(up.d, N * cap, 784, 256, (const float*)lw->d, (const float*)lb->d, a.d_out_labels, (float*)p, st));
     eng_mark(e, "mask_head");
     e.last_N = N;
     return ISEGMI_OK;

@@ -1,0 +1,204 @@
+// spatial_f16.hip -- fp16-storage variants of the HBM-bound NHWC ops used by the fp16 Mask R-CNN path
+// (BASELINE configs[4]): max-pool (fp32 or fp16 in -> fp16 out), nearest2x + add, LevelMapper + RoIAlign and the
+// class-selected mask 1x1.  All arithmetic is fp32 (same operation order as the fp32 kernels / the oracle); only
+// loads and stores convert, 4 channels (8 B) per lane.
+#include "../../include/isegmi.h"
+#include "common.h"
+#include "detmath.h"
+
+namespace isegmi {
+
+typedef _Float16 half_t;
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float4 ld4(const half_t* p) { const h4 v = *(const h4*)p; return make_float4((float)v.x, (float)v.y, (float)v.z, (float)v.w); }
+__device__ __forceinline__ float4 ld4(const float* p) { return *(const float4*)p; }
+__device__ __forceinline__ void st4(half_t* p, float4 v) { h4 o; o.x = (half_t)v.x; o.y = (half_t)v.y; o.z = (half_t)v.z; o.w = (half_t)v.w; *(h4*)p = o; }
+
+template <typename TI>
+__global__ void maxpool_to_f16_kernel(const TI* __restrict__ in, int N, int H, int W, int C, int k, int s, int p, int Ho, int Wo,
+                                      half_t* __restrict__ out) {
+    const int c4n = C >> 2;
+    const int64_t total = (int64_t)N * Ho * Wo * c4n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n);
+        int64_t t = i / c4n;
+        const int wo = (int)(t % Wo); t /= Wo;
+        const int ho = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        for (int r = 0; r < k; ++r) {
+            const int hi = ho * s + r - p;
+            if ((unsigned)hi >= (unsigned)H) continue;
+            for (int q = 0; q < k; ++q) {
+                const int wi = wo * s + q - p;
+                if ((unsigned)wi >= (unsigned)W) continue;
+                const float4 v = ld4(in + (((int64_t)n * H + hi) * W + wi) * C + c4 * 4);
+                m.x = v.x > m.x ? v.x : m.x; m.y = v.y > m.y ? v.y : m.y;
+                m.z = v.z > m.z ? v.z : m.z; m.w = v.w > m.w ? v.w : m.w;
+            }
+        }
+        st4(out + (((int64_t)n * Ho + ho) * Wo + wo) * C + c4 * 4, m);
+    }
+}
+
+__global__ void nearest2x_add_f16_kernel(const half_t* __restrict__ coarse, int N, int Hc, int Wc, int C, const half_t* __restrict__ lat,
+                                         int H, int W, half_t* __restrict__ out) {
+    const int c4n = C >> 2;
+    const int64_t total = (int64_t)N * H * W * c4n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n);
+        int64_t t = i / c4n;
+        const int x = (int)(t % W); t /= W;
+        const int y = (int)(t % H);
+        const int n = (int)(t / H);
+        int yc = y >> 1, xc = x >> 1;
+        yc = yc > Hc - 1 ? Hc - 1 : yc;
+        xc = xc > Wc - 1 ? Wc - 1 : xc;
+        const float4 a = ld4(lat + i * 4);
+        const float4 b = ld4(coarse + (((int64_t)n * Hc + yc) * Wc + xc) * C + c4 * 4);
+        st4(out + i * 4, make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w));
+    }
+}
+
+struct RoiLevelsH {
+    const half_t* feat[4];
+    int H[4], W[4];
+    float scale[4];
+};
+__device__ __forceinline__ int level_of_h(const float4 b, int k_min, int k_max) {
+    const float area = (b.z - b.x + 1.0f) * (b.w - b.y + 1.0f);
+    const float s = dm_sqrt(area);
+    const float t = floorf(4.0f + dm_log2(dm_div(s, 224.0f) + 1e-6f));
+    int l = (int)t;
+    return l < k_min ? k_min : (l > k_max ? k_max : l);
+}
+__device__ __forceinline__ float4 roi_bilinear4_h(const half_t* f, int H, int W, int C, float y, float x) {
+    float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) return z;
+    if (y <= 0.0f) y = 0.0f;
+    if (x <= 0.0f) x = 0.0f;
+    int yl = (int)y, xl = (int)x, yh, xh;
+    if (yl >= H - 1) { yh = yl = H - 1; y = (float)yl; } else yh = yl + 1;
+    if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else xh = xl + 1;
+    const float ly = y - (float)yl, lx = x - (float)xl, hy = 1.0f - ly, hx = 1.0f - lx;
+    const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+    const float4 v1 = ld4(f + ((int64_t)yl * W + xl) * C), v2 = ld4(f + ((int64_t)yl * W + xh) * C);
+    const float4 v3 = ld4(f + ((int64_t)yh * W + xl) * C), v4 = ld4(f + ((int64_t)yh * W + xh) * C);
+    float4 v;
+    v.x = w1 * v1.x; v.x = v.x + w2 * v2.x; v.x = v.x + w3 * v3.x; v.x = v.x + w4 * v4.x;
+    v.y = w1 * v1.y; v.y = v.y + w2 * v2.y; v.y = v.y + w3 * v3.y; v.y = v.y + w4 * v4.y;
+    v.z = w1 * v1.z; v.z = v.z + w2 * v2.z; v.z = v.z + w3 * v3.z; v.z = v.z + w4 * v4.z;
+    v.w = w1 * v1.w; v.w = v.w + w2 * v2.w; v.w = v.w + w3 * v3.w; v.w = v.w + w4 * v4.w;
+    return v;
+}
+__global__ __launch_bounds__(256) void roi_align_f16_kernel(const RoiLevelsH lv, const float* __restrict__ rois, const int* __restrict__ counts,
+                                                             int N, int K, int C, int PH, int PW, int g, int k_min, int k_max,
+                                                             half_t* __restrict__ out) {
+    const int c4n = C >> 2;
+    const int64_t total = (int64_t)N * K * PH * PW * c4n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n);
+        int64_t t = i / c4n;
+        const int pw = (int)(t % PW); t /= PW;
+        const int ph = (int)(t % PH); t /= PH;
+        const int k = (int)(t % K);
+        const int n = (int)(t / K);
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < counts[n]) {
+            const float4 b = *(const float4*)(rois + ((int64_t)n * K + k) * 4);
+            const int li = level_of_h(b, k_min, k_max) - k_min;
+            const int H = lv.H[li], W = lv.W[li];
+            const float sc = lv.scale[li];
+            const half_t* f = lv.feat[li] + (int64_t)n * H * W * C + c4 * 4;
+            const float sw = b.x * sc, sh = b.y * sc, ew = b.z * sc, eh = b.w * sc;
+            float rw = ew - sw, rh = eh - sh;
+            rw = rw > 1.0f ? rw : 1.0f;
+            rh = rh > 1.0f ? rh : 1.0f;
+            const float bh = dm_div(rh, (float)PH), bw = dm_div(rw, (float)PW);
+            for (int iy = 0; iy < g; ++iy) {
+                const float y = sh + (float)ph * bh + dm_div(((float)iy + 0.5f) * bh, (float)g);
+                for (int ix = 0; ix < g; ++ix) {
+                    const float x = sw + (float)pw * bw + dm_div(((float)ix + 0.5f) * bw, (float)g);
+                    const float4 v = roi_bilinear4_h(f, H, W, C, y, x);
+                    o.x = o.x + v.x; o.y = o.y + v.y; o.z = o.z + v.z; o.w = o.w + v.w;
+                }
+            }
+            const float cnt = (float)(g * g);
+            o.x = dm_div(o.x, cnt); o.y = dm_div(o.y, cnt); o.z = dm_div(o.z, cnt); o.w = dm_div(o.w, cnt);
+        }
+        st4(out + i * 4, o);
+    }
+}
+
+__global__ __launch_bounds__(256) void mask_logits_select_f16_kernel(const half_t* __restrict__ feat, int HW, int C, const float* __restrict__ w,
+                                                                      const float* __restrict__ b, const int* __restrict__ labels,
+                                                                      float* __restrict__ out) {
+    extern __shared__ float wr[];
+    const int r = blockIdx.x;
+    const int lab = labels[r];
+    if (lab <= 0) {
+        for (int p = threadIdx.x; p < HW; p += 256) out[(int64_t)r * HW + p] = 0.0f;
+        return;
+    }
+    for (int c = threadIdx.x; c < C; c += 256) wr[c] = w[(int64_t)lab * C + c];
+    __syncthreads();
+    const float bias = b[lab];
+    for (int p = threadIdx.x; p < HW; p += 256) {
+        const half_t* x = feat + ((int64_t)r * HW + p) * C;
+        float acc = 0.0f;
+        for (int c4 = 0; c4 < C / 4; ++c4) {
+            const float4 v = ld4(x + 4 * c4);
+            acc = fmaf(v.x, wr[4 * c4], acc); acc = fmaf(v.y, wr[4 * c4 + 1], acc);
+            acc = fmaf(v.z, wr[4 * c4 + 2], acc); acc = fmaf(v.w, wr[4 * c4 + 3], acc);
+        }
+        out[(int64_t)r * HW + p] = dm_sigmoid(fmaf(acc, 1.0f, bias));
+    }
+}
+
+static inline unsigned gridf(int64_t total) {
+    int64_t b = cdiv64(total, 256);
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+int maxpool_to_f16_launch(const void* in, int in_f16, int N, int H, int W, int C, int k, int s, int p, void* out, hipStream_t st) {
+    ARG_CHECK(C % 4 == 0, "C % 4");
+    const int Ho = (H + 2 * p - k) / s + 1, Wo = (W + 2 * p - k) / s + 1;
+    const unsigned g = gridf((int64_t)N * Ho * Wo * (C / 4));
+    if (in_f16) hipLaunchKernelGGL(maxpool_to_f16_kernel<half_t>, dim3(g), dim3(256), 0, st, (const half_t*)in, N, H, W, C, k, s, p, Ho, Wo, (half_t*)out);
+    else hipLaunchKernelGGL(maxpool_to_f16_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)in, N, H, W, C, k, s, p, Ho, Wo, (half_t*)out);
+    HIP_TRY(hipGetLastError());
+    return ISEGMI_OK;
+}
+int nearest2x_add_f16_launch(const void* coarse, int N, int Hc, int Wc, int C, const void* lat, int H, int W, void* out, hipStream_t st) {
+    ARG_CHECK(C % 4 == 0, "C % 4");
+    hipLaunchKernelGGL(nearest2x_add_f16_kernel, dim3(gridf((int64_t)N * H * W * (C / 4))), dim3(256), 0, st, (const half_t*)coarse, N, Hc, Wc, C,
+                       (const half_t*)lat, H, W, (half_t*)out);
+    HIP_TRY(hipGetLastError());
+    return ISEGMI_OK;
+}
+int roi_align_f16_launch(const void* const* feats, const int* Hs, const int* Ws, const float* scales, int nlevels, const float* rois,
+                         const int* counts, int N, int K, int C, int PH, int PW, int g, int k_min, void* out, hipStream_t st) {
+    ARG_CHECK(nlevels >= 1 && nlevels <= 4 && C % 4 == 0, "roi_align levels/C");
+    RoiLevelsH lv;
+    for (int i = 0; i < 4; ++i) {
+        const int s = i < nlevels ? i : nlevels - 1;
+        lv.feat[i] = (const half_t*)feats[s]; lv.H[i] = Hs[s]; lv.W[i] = Ws[s]; lv.scale[i] = scales[s];
+    }
+    hipLaunchKernelGGL(roi_align_f16_kernel, dim3(gridf((int64_t)N * K * PH * PW * (C / 4))), dim3(256), 0, st, lv, rois, counts, N, K, C, PH, PW,
+                       g, k_min, k_min + nlevels - 1, (half_t*)out);
+    HIP_TRY(hipGetLastError());
+    return ISEGMI_OK;
+}
+int mask_logits_select_f16_launch(const void* feat, int R, int HW, int C, const float* w, const float* b, const int* labels, float* out,
+                                  hipStream_t st) {
+    ARG_CHECK(C % 4 == 0, "C % 4");
+    if (R == 0) return ISEGMI_OK;
+    hipLaunchKernelGGL(mask_logits_select_f16_kernel, dim3(R), dim3(256), (size_t)C * sizeof(float), st, (const half_t*)feat, HW, C, w, b, labels, out);
+    HIP_TRY(hipGetLastError());
+    return ISEGMI_OK;
+}
+
+}  // namespace isegmi

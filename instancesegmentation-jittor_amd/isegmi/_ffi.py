@@ -332,3 +332,29 @@ def rpn_level(head, anchors, image_hw, A, pre_nms, post_nms, nms_thr=0.7, min_si
                                     wp.ptr, tv.ptr, ti.ptr, tc.ptr, ob.ptr, os_.ptr, oc.ptr, None))
     c = oc.numpy(); B = ob.numpy(); S = os_.numpy()
     return [(B[i, : c[i]], S[i, : c[i]]) for i in range(N)]
+
+
+# ---------------------------------------------------------------- fp16 conv (configs[4])
+def pack_conv_weights_f16(desc, w_krsc):
+    w = np.ascontiguousarray(w_krsc, np.float32)
+    n = C.c_int64()
+    check(lib().isegmi_conv_packed_halfs(C.byref(desc), C.byref(n)))
+    out = np.empty(n.value, np.uint16)
+    check(lib().isegmi_pack_conv_weights_f16(C.byref(desc), w.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)))
+    return out.view(np.float16)
+
+
+def conv2d_f16(x, w_krsc, stride=1, pad=0, scale=None, shift=None, residual=None, act=0, tile=0, out_f32=False):
+    """x fp16-representable NHWC (any float dtype; cast to fp16), returns fp16 (or fp32 when out_f32) as numpy."""
+    x = np.ascontiguousarray(x, np.float16)
+    N, H, W, Cin = x.shape
+    Cout, R, S, _ = w_krsc.shape
+    d = make_conv_desc(N, H, W, Cin, Cout, R, S, stride, pad, act, tile)
+    ho, wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
+    dx = DeviceBuffer.from_numpy(x); dw = DeviceBuffer.from_numpy(pack_conv_weights_f16(d, w_krsc))
+    ds = None if scale is None else DeviceBuffer.from_numpy(np.asarray(scale, np.float32))
+    dh = None if shift is None else DeviceBuffer.from_numpy(np.asarray(shift, np.float32))
+    dr = None if residual is None else DeviceBuffer.from_numpy(np.ascontiguousarray(residual, np.float16))
+    do = DeviceBuffer((N, ho, wo, Cout), np.float32 if out_f32 else np.float16)
+    check(lib().isegmi_op_conv2d_f16(C.byref(d), dx.ptr, dw.ptr, _ptr(ds), _ptr(dh), _ptr(dr), do.ptr, int(out_f32), None))
+    return do.numpy()

@@ -139,13 +139,16 @@ class MaskRCNN:
 
     KIND = 2
 
-    def __init__(self, state_dict, H, W, cfg=MaskRCNNConfig(), max_batch=2, device=0):
+    def __init__(self, state_dict, H, W, cfg=MaskRCNNConfig(), max_batch=2, device=0, fp16=False):
         assert H % 32 == 0 and W % 32 == 0
         self.cfg, self.H, self.W, self.max_batch = cfg, H, W, max_batch
         _ffi.lib()
         _ffi.set_device(device)
         self._h = C.c_void_p()
         _ffi.check(_ffi.lib().isegmi_engine_create(self.KIND, max_batch, H, W, C.byref(self._h)))
+        self.fp16 = bool(fp16)
+        if self.fp16:  # fp16 storage + f16 MFMA convs (BASELINE configs[4]); must precede weight loading
+            self.set_param("fp16", 1.0)
         self._load(state_dict)
         for k, v in (("resnet_depth", cfg.depth), ("rpn_pre_nms_top_n", cfg.RPN_PRE_NMS_TOP_N_TEST),
                      ("rpn_post_nms_top_n", cfg.RPN_POST_NMS_TOP_N_TEST), ("rpn_fpn_post_nms_top_n", cfg.RPN_FPN_POST_NMS_TOP_N_TEST),

@@ -140,7 +140,7 @@ class Yolact:
         """D2H copy of a named engine buffer (optionally only its first `rows` leading rows)."""
         p = C.c_void_p(); nb = C.c_int64(); dt = C.c_int32(); nd = C.c_int32(); shp = (C.c_int64 * 4)()
         _ffi.check(_ffi.lib().isegmi_engine_buffer_info(self._h, name.encode(), C.byref(p), C.byref(nb), C.byref(dt), shp, C.byref(nd)))
-        dtype = [np.float32, np.int32, np.uint8, np.int64][dt.value]
+        dtype = [np.float32, np.int32, np.uint8, np.int64, np.float16][dt.value]
         shape = tuple(int(shp[i]) for i in range(nd.value))
         if rows is not None:
             shape = (rows,) + shape[1:]

@@ -50,17 +50,24 @@ def grid_anchors(gh, gw, stride, cell):
 
 
 class MaskRCNNRef:
-    def __init__(self, sd, depth=50, pre_nms=1000, post_nms=1000, fpn_post=1000, det_per_img=100, nms_ge=0):
+    def __init__(self, sd, depth=50, pre_nms=1000, post_nms=1000, fpn_post=1000, det_per_img=100, nms_ge=0, fp16=False):
         self.sd, self.depth = sd, depth
+        # fp16=True emulates the product's fp16-storage path (BASELINE configs[4]): conv weights and every stored
+        # activation after the stem are rounded to fp16, all arithmetic stays fp32 (ordered fmaf chain).
+        self.fp16 = fp16
         self.pre_nms, self.post_nms, self.fpn_post, self.dpi, self.ge = pre_nms, post_nms, fpn_post, det_per_img, nms_ge
         self.feats = {}
 
+    def _h(self, x):
+        return x.astype(np.float16).astype(np.float32) if self.fp16 else x
+
     def _cbn(self, x, conv, bn, stride, pad, act, residual=None):
         sc, sh = _frozen_bn(self.sd, bn)
-        return ora.conv2d(x, _krsc(self.sd[conv + ".weight"]), stride, pad, sc, sh, residual, act)
+        return self._h(ora.conv2d(x, self._h(_krsc(self.sd[conv + ".weight"])), stride, pad, sc, sh, residual, act))
 
-    def _cb(self, x, name, stride, pad, act):
-        return ora.conv2d(x, _krsc(self.sd[name + ".weight"]), stride, pad, None, self.sd[name + ".bias"], None, act)
+    def _cb(self, x, name, stride, pad, act, keep_f32=False):
+        y = ora.conv2d(x, self._h(_krsc(self.sd[name + ".weight"])), stride, pad, None, self.sd[name + ".bias"], None, act)
+        return y if keep_f32 else self._h(y)
 
     def forward(self, images_nhwc3, image_hw):
         sd = self.sd
@@ -70,7 +77,7 @@ class MaskRCNNRef:
         w1 = _krsc(sd["backbone.body.stem.conv1.weight"])
         w1 = np.concatenate([w1, np.zeros(w1.shape[:3] + (1,), np.float32)], -1)
         sc, sh = _frozen_bn(sd, "backbone.body.stem.bn1")
-        x = ora.maxpool(ora.conv2d(x4, w1, 2, 3, sc, sh, None, 1), 3, 2, 1)
+        x = self._h(ora.maxpool(ora.conv2d(x4, w1, 2, 3, sc, sh, None, 1), 3, 2, 1))  # fp32 stem, fp16 trunk
         Cs = []
         for li, nb in enumerate((3, 4, 23 if self.depth == 101 else 6, 3), 1):
             for b in range(nb):
@@ -85,7 +92,7 @@ class MaskRCNNRef:
         P = [None, None, None, self._cb(last, "backbone.fpn.fpn_layer4", 1, 1, 0)]
         for l in (2, 1, 0):
             lat = self._cb(Cs[l], "backbone.fpn.fpn_inner%d" % (l + 1), 1, 0, 0)
-            last = ora.upsample_nearest2x_add(last, lat)
+            last = self._h(ora.upsample_nearest2x_add(last, lat))
             P[l] = self._cb(last, "backbone.fpn.fpn_layer%d" % (l + 1), 1, 1, 0)
         P.append(ora.maxpool(P[3], 1, 2, 0))
         # RPN
@@ -95,8 +102,8 @@ class MaskRCNNRef:
         self.dbg = dict(rpn_logits=[], rpn_deltas=[], cls=[], reg=[], f7=[])
         for l, p in enumerate(P):
             t = self._cb(p, "rpn.head.conv", 1, 1, 1)
-            logits = self._cb(t, "rpn.head.cls_logits", 1, 0, 0)  # [N,H,W,A]
-            deltas = self._cb(t, "rpn.head.bbox_pred", 1, 0, 0)   # [N,H,W,A*4]
+            logits = self._cb(t, "rpn.head.cls_logits", 1, 0, 0, keep_f32=True)  # [N,H,W,A]
+            deltas = self._cb(t, "rpn.head.bbox_pred", 1, 0, 0, keep_f32=True)   # [N,H,W,A*4]
             anc = grid_anchors(p.shape[1], p.shape[2], strides[l], cell_anchors(strides[l], sizes[l]))
             self.dbg['rpn_logits'].append(logits); self.dbg['rpn_deltas'].append(deltas)
             for n in range(N):
@@ -121,14 +128,14 @@ class MaskRCNNRef:
                 if len(idx) == 0:
                     continue
                 rois = np.concatenate([np.full((len(idx), 1), n, np.float32), pr[idx]], 1)
-                feat[idx] = ora.roi_align(P[k - 2], rois, 1.0 / strides[k - 2], 7, 7, 2)
+                feat[idx] = self._h(ora.roi_align(P[k - 2], rois, 1.0 / strides[k - 2], 7, 7, 2))
             # FC6 on the flattened (C,H,W) vector == 7x7 valid conv with weights permuted to (H,W,C)
             w6k = np.ascontiguousarray(w6.reshape(1024, 256, 7, 7).transpose(0, 2, 3, 1))
-            f6 = ora.conv2d(feat, w6k, 1, 0, None, sd["roi_heads.box.feature_extractor.fc6.bias"], None, 1)
-            f7 = ora.conv2d(f6, w7.reshape(1024, 1, 1, 1024), 1, 0, None, sd["roi_heads.box.feature_extractor.fc7.bias"], None, 1)
-            cls = ora.conv2d(f7, sd["roi_heads.box.predictor.cls_score.weight"].reshape(81, 1, 1, 1024), 1, 0, None,
+            f6 = self._h(ora.conv2d(feat, self._h(w6k), 1, 0, None, sd["roi_heads.box.feature_extractor.fc6.bias"], None, 1))
+            f7 = self._h(ora.conv2d(f6, self._h(w7.reshape(1024, 1, 1, 1024)), 1, 0, None, sd["roi_heads.box.feature_extractor.fc7.bias"], None, 1))
+            cls = ora.conv2d(f7, self._h(sd["roi_heads.box.predictor.cls_score.weight"].reshape(81, 1, 1, 1024)), 1, 0, None,
                              sd["roi_heads.box.predictor.cls_score.bias"], None, 0).reshape(R, 81)
-            reg = ora.conv2d(f7, sd["roi_heads.box.predictor.bbox_pred.weight"].reshape(324, 1, 1, 1024), 1, 0, None,
+            reg = ora.conv2d(f7, self._h(sd["roi_heads.box.predictor.bbox_pred.weight"].reshape(324, 1, 1, 1024)), 1, 0, None,
                              sd["roi_heads.box.predictor.bbox_pred.bias"], None, 0).reshape(R, 324)
             self.dbg['cls'].append(cls); self.dbg['reg'].append(reg); self.dbg['f7'].append(f7)
             db, ds, dl = ora.box_postprocess(cls, reg, pr, float(image_hw[n][1]), float(image_hw[n][0]), 0.05, 0.5, self.dpi, self.ge, self.dpi)
@@ -143,10 +150,11 @@ class MaskRCNNRef:
                     if len(idx) == 0:
                         continue
                     rois = np.concatenate([np.full((len(idx), 1), n, np.float32), db[idx]], 1)
-                    mf[idx] = ora.roi_align(P[k - 2], rois, 1.0 / strides[k - 2], 14, 14, 2)
+                    mf[idx] = self._h(ora.roi_align(P[k - 2], rois, 1.0 / strides[k - 2], 14, 14, 2))
                 for i in range(1, 5):
                     mf = self._cb(mf, "roi_heads.mask.feature_extractor.mask_fcn%d" % i, 1, 1, 1)
-                up = ora.deconv2x2(mf, sd["roi_heads.mask.predictor.conv5_mask.weight"], sd["roi_heads.mask.predictor.conv5_mask.bias"], 1)
+                up = self._h(ora.deconv2x2(mf, self._h(sd["roi_heads.mask.predictor.conv5_mask.weight"].astype(np.float32)),
+                                           sd["roi_heads.mask.predictor.conv5_mask.bias"], 1))
                 m28 = ora.mask_logits_select(up.reshape(D, 784, 256), sd["roi_heads.mask.predictor.mask_fcn_logits.weight"].reshape(81, 256),
                                              sd["roi_heads.mask.predictor.mask_fcn_logits.bias"], dl).reshape(D, 28, 28)
             dets.append(dict(box=db, score=ds, label=dl, mask28=m28, proposals=pr, proposal_scores=pscores[n]))

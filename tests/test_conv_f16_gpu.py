@@ -1,0 +1,35 @@
+"""fp16 MFMA conv (configs[4]) vs the oracle run on fp16-rounded operands with fp32 accumulation.
+TOLERANCE (stated): the f16 MFMA sums 16 exact products per instruction in an unspecified order, so fp32
+accumulators can differ from the ordered chain in the last bits; after rounding the result to fp16 we require
+|got - ref| <= 1 fp16 ulp of the reference (2^-10 relative) + 1e-3 absolute, and >= 99 % exactly equal."""
+import numpy as np
+import pytest
+
+from oracle import ora
+
+pytestmark = pytest.mark.gpu
+
+CASES = [(2, 19, 23, 64, 48, 3, 1, 1), (1, 35, 35, 64, 64, 1, 1, 0), (2, 35, 33, 128, 128, 3, 2, 1), (1, 18, 18, 256, 405, 1, 1, 0),
+         (1, 7, 7, 256, 1024, 7, 1, 0), (1, 40, 56, 256, 256, 3, 1, 1)]
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("tile", [0, 1, 3])
+def test_conv_f16_close_to_oracle(ffi, case, tile):
+    N, H, W, Cin, Cout, R, stride, pad = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 32))
+    x = rng.standard_normal((N, H, W, Cin)).astype(np.float16)
+    w = (rng.standard_normal((Cout, R, R, Cin)) * (2.0 / (R * R * Cin)) ** 0.5).astype(np.float16)
+    sc = rng.uniform(0.5, 1.5, Cout).astype(np.float32); sh = (rng.standard_normal(Cout) * 0.1).astype(np.float32)
+    Ho = (H + 2 * pad - R) // stride + 1; Wo = (W + 2 * pad - R) // stride + 1
+    res = rng.standard_normal((N, Ho, Wo, Cout)).astype(np.float16)
+    for act, use_res, f32 in ((1, True, False), (0, False, False), (0, False, True)):
+        ref = ora.conv2d(x.astype(np.float32), w.astype(np.float32), stride, pad, sc, sh, res.astype(np.float32) if use_res else None, act)
+        got = ffi.conv2d_f16(x, w.astype(np.float32), stride, pad, sc, sh, res if use_res else None, act, tile, out_f32=f32)
+        if f32:
+            assert got.dtype == np.float32 and np.max(np.abs(got - ref)) <= 2e-5 * max(1.0, np.abs(ref).max())
+        else:
+            ref16 = ref.astype(np.float16)
+            d = np.abs(got.astype(np.float32) - ref16.astype(np.float32))
+            assert np.all(d <= np.abs(ref16.astype(np.float32)) * 2.0 ** -10 + 1e-3)
+            assert np.mean(got == ref16) >= 0.99

@@ -1,0 +1,33 @@
+"""Micro-benchmark of the fp16 / fp32 conv kernels on Mask R-CNN shapes (dev tool)."""
+import ctypes as C, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path[:0] = [ROOT, os.path.join(ROOT, "instancesegmentation-jittor_amd")]
+import numpy as np
+from isegmi import _ffi
+_ffi.set_device(0)
+rng = np.random.default_rng(0)
+shapes = [(2, 200, 336, 256, 256, 3, 1, 1), (2, 100, 168, 256, 256, 3, 1, 1), (2, 200, 336, 64, 256, 1, 1, 0), (2, 50, 84, 1024, 256, 1, 1, 0),
+          (200, 14, 14, 256, 256, 3, 1, 1), (2000, 7, 7, 256, 1024, 7, 1, 0), (8, 200, 336, 256, 256, 3, 1, 1)]
+for (N, H, W, Cin, Cout, R, st, pad) in shapes:
+    x = rng.standard_normal((N, H, W, Cin)).astype(np.float16)
+    w = (rng.standard_normal((Cout, R, R, Cin)) * 0.05).astype(np.float32)
+    ho, wo = (H + 2 * pad - R) // st + 1, (W + 2 * pad - R) // st + 1
+    fl = 2.0 * N * ho * wo * Cout * R * R * Cin
+    line = "N%d %dx%d Cin%d Cout%d %dx%d/%d  %.1f GF:" % (N, H, W, Cin, Cout, R, R, st, fl / 1e9)
+    for tile in (1, 3):
+        d = _ffi.make_conv_desc(N, H, W, Cin, Cout, R, R, st, pad, 1, tile)
+        dx = _ffi.DeviceBuffer.from_numpy(x); dw = _ffi.DeviceBuffer.from_numpy(_ffi.pack_conv_weights_f16(d, w)); do = _ffi.DeviceBuffer((N, ho, wo, Cout), np.float16)
+        run = lambda: _ffi.check(_ffi.lib().isegmi_op_conv2d_f16(C.byref(d), dx.ptr, dw.ptr, None, None, None, do.ptr, 0, None))
+        for _ in range(3): run()
+        _ffi.sync(); t0 = time.perf_counter()
+        for _ in range(20): run()
+        _ffi.sync(); dt = (time.perf_counter() - t0) / 20
+        line += "  f16 tile%d %.3f ms %.0f TF/s" % (tile, dt * 1e3, fl / dt / 1e12)
+    x32 = x.astype(np.float32)
+    d = _ffi.make_conv_desc(N, H, W, Cin, Cout, R, R, st, pad, 1, 0)
+    dx = _ffi.DeviceBuffer.from_numpy(x32); dw = _ffi.DeviceBuffer.from_numpy(_ffi.pack_conv_weights(d, w)); do = _ffi.DeviceBuffer((N, ho, wo, Cout))
+    run = lambda: _ffi.op_conv2d(d, dx, dw, None, None, None, do)
+    for _ in range(3): run()
+    _ffi.sync(); t0 = time.perf_counter()
+    for _ in range(10): run()
+    _ffi.sync(); dt = (time.perf_counter() - t0) / 10
+    print(line + "  | f32 %.3f ms %.0f TF/s" % (dt * 1e3, fl / dt / 1e12), flush=True)
