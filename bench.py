@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (default 8 yolact, 2 maskrcnn)")
     ap.add_argument("--model", default="yolact", choices=["yolact", "maskrcnn"])
+    ap.add_argument("--depth", type=int, default=50, choices=[50, 101], help="maskrcnn: ResNet depth")
+    ap.add_argument("--fp16", action="store_true", help="maskrcnn: fp16 storage + f16 MFMA convs (BASELINE configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8, help="images the CPU oracle is timed on")
     ap.add_argument("--no-latency", action="store_true", help="skip the extra bs=1 latency pass")
@@ -254,15 +256,18 @@ def main_maskrcnn(a):
         import torch.distributed as dist
         dist.init_process_group("gloo", rank=rank, world_size=world)
     from isegmi import _ffi
-    from isegmi.maskrcnn import MaskRCNN, prepare_images
+    from isegmi.maskrcnn import MaskRCNN, MaskRCNNConfig, prepare_images
     from isegmi.weights import maskrcnn_state_dict
     if _ffi.device_count() < 1:
         raise SystemExit("no HIP device visible: bench.py measures the HIP path only (no CPU fallback)")
-    sd = maskrcnn_state_dict(1234)
+    sd = maskrcnn_state_dict(1234, depth=a.depth)
     rng = np.random.default_rng(20261003 + rank)
     imgs = [rng.uniform(0, 255, (800, 1333, 3)).astype(np.float32) for _ in range(a.batch)]
     x, hw = prepare_images(imgs)
-    model = MaskRCNN(sd, x.shape[1], x.shape[2], max_batch=a.batch, device=local_rank)
+    model = MaskRCNN(sd, x.shape[1], x.shape[2], cfg=MaskRCNNConfig(depth=a.depth), max_batch=a.batch, device=local_rank, fp16=a.fp16)
+    tag = "R%d-FPN" % a.depth
+    prec = "fp16 storage / f16 MFMA, fp32 accumulate" if a.fp16 else "fp32"
+    peak = 2500.0 if a.fp16 else PEAK_F32_MFMA_TFLOPS  # dense f16 MFMA peak (MI355X_MICROARCH.md) vs f32 MFMA peak
     model.upload(x, hw)
     gather = None
     if world > 1:
@@ -316,16 +321,16 @@ def main_maskrcnn(a):
     if rank == 0:
         achieved = f.value / (m.value * 1e-3) / 1e12 if m.value > 0 else 0.0
         cnt = model.fetch("det.count", a.batch); pc = model.fetch("proposal_count", a.batch)
-        out = {"metric": "images/sec (Mask R-CNN R50-FPN 1333x800, bs=%d per GPU, fp32)" % a.batch,
+        out = {"metric": "images/sec (Mask R-CNN %s 1333x800, bs=%d per GPU, %s)" % (tag, a.batch, prec),
                "value": round(a.batch * world * a.steps / elapsed, 3), "unit": "img/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "Mask R-CNN R50-FPN 1333x800 (padded 800x1344) bs=%d/GPU random weights: backbone+FPN+RPN+RoIAlign+box head+NMS+mask head+paste (BASELINE configs[2])" % a.batch,
+               "dtype": "f16" if a.fp16 else "f32", "data": "synthetic",
+               "config": {"workload": "Mask R-CNN %s 1333x800 (padded 800x1344) bs=%d/GPU random weights, %s: backbone+FPN+RPN+RoIAlign+box head+NMS+mask head+paste (BASELINE configs[%d])" % (tag, a.batch, prec, 4 if a.fp16 else 2),
                           "global_batch": a.batch * world, "parallelism": "batch-sharded x%d" % world,
                           "proposals_per_image": [int(c) for c in pc], "detections_per_image": [int(c) for c in cnt]},
                "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel (all conv launches of a step)",
                             "pass": "K single-stream steps right after the timed region, HIP events around every conv launch", "achieved": round(achieved, 2),
-                            "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic("r01_pmc_maskrcnn.json"),
+                            "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None if (a.fp16 or a.depth != 50) else pmc_traffic("r01_pmc_maskrcnn.json"),
                             "traffic_note": "HBM bytes per conv launch from separate rocprofv3 --pmc passes (profiles/r01_pmc_maskrcnn.json; FETCH x2 gfx950 correction); not collected live",
                             "algorithmic_gflop_per_step": round(f.value / a.steps / 1e9, 2), "conv_ms_per_step": round(m.value / a.steps, 3),
                             "launches_per_step": l.value // a.steps, "avg_launch_us": round(m.value * 1e3 / max(l.value, 1), 2)},
@@ -344,7 +349,7 @@ def main_maskrcnn(a):
             step(); model.sync()
             out["stage_ms_bs%d" % a.batch] = {k: round(v, 3) for k, v in model.timings()}
             model.set_param("timing", 0.0)
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and not a.fp16 and a.depth == 50:
             from oracle.maskrcnn_ref import MaskRCNNRef
             ncpu = min(len(os.sched_getaffinity(0)), 16)
             os.environ["OMP_NUM_THREADS"] = str(ncpu)
