@@ -252,6 +252,9 @@ int yolact_forward(Engine& e, const float* d_images, int N) {
         TRY(eng_conv_into(e, "prediction_layers.0.mask_layer", uf, 1, 1, 2, (float*)mask + (int64_t)off[l] * md, hw, (int64_t)Ptot * md, A * md));
         return ISEGMI_OK;
     };
+    // WAR: the previous forward's Detect / postprocess (tail stream) still reads loc/conf/mask/proto and the det.*
+    // buffers; everything before this point touched only backbone/FPN buffers and was free to overlap with it.
+    if (e.multi_stream && e.tail_pending) HIP_TRY(hipStreamWaitEvent(e.stream, e.tail_done, 0));
     // protonet (side 0) || heads on P3 (main) || heads on P4,P6 (side 1) || heads on P5,P7 (side 2)
     Tensor proto;
     TRY(eng_fork(e, 0));
@@ -302,7 +305,18 @@ int yolact_forward(Engine& e, const float* d_images, int N) {
     TRY(eng_buf(e, "det.class", (int64_t)N * max_det * 4, &p, 1, {N, max_det})); a.d_out_classes = (int32_t*)p;
     TRY(eng_buf(e, "det.coeff", (int64_t)N * max_det * md * 4, &p, 0, {N, max_det, md})); a.d_out_coeffs = (float*)p;
     TRY(eng_buf(e, "det.prior", (int64_t)N * max_det * 4, &p, 1, {N, max_det})); a.d_out_prior = (int32_t*)p;
-    TRY(yolact_detect_launch(&a, e.cur));
+    // Detect is a chain of small latency-bound grids: run it (and postprocess) on the tail stream so the NEXT
+    // forward's MFMA-bound backbone can start underneath it.
+    hipStream_t ds = e.stream;
+    if (e.multi_stream) {
+        hipEvent_t ev;
+        TRY(next_event(e, &ev));
+        HIP_TRY(hipEventRecord(ev, e.stream));
+        HIP_TRY(hipStreamWaitEvent(e.tail, ev, 0));
+        ds = e.tail;
+    }
+    TRY(yolact_detect_launch(&a, ds));
+    if (e.multi_stream) { HIP_TRY(hipEventRecord(e.tail_done, e.tail)); e.tail_pending = true; }
     eng_mark(e, "detect");
     e.last_N = N;
     return ISEGMI_OK;
@@ -320,7 +334,8 @@ int yolact_postprocess(Engine& e, int h, int w) {
     TRY(eng_buf(e, "det.box_int", (int64_t)N * K * 4 * 8, &ib, 3, {N, K, 4}));
     TRY(yolact_masks_launch((const float*)proto.d, (const float*)e.bufs["det.coeff"].d, (const float*)e.bufs["det.box"].d,
                             (const int*)e.bufs["det.count"].d, N, PH, PW, md, K, h, w, (float*)lo, (uint8_t*)masks, (int64_t*)ib,
-                            e.cur));
+                            e.multi_stream ? e.tail : e.stream));
+    if (e.multi_stream) { HIP_TRY(hipEventRecord(e.tail_done, e.tail)); e.tail_pending = true; }
     eng_mark(e, "masks");
     return ISEGMI_OK;
 }
@@ -339,6 +354,9 @@ extern "C" int isegmi_engine_create(int model_kind, int max_batch, int H, int W,
     hipError_t er = hipStreamCreate(&h->e.stream);
     for (int i = 0; i < 3 && er == hipSuccess; ++i) er = hipStreamCreateWithFlags(&h->e.side[i], hipStreamNonBlocking);
     if (er != hipSuccess) { set_error(std::string("hipStreamCreate: ") + hipGetErrorString(er)); delete h; return ISEGMI_ERR_HIP; }
+    if (er == hipSuccess) er = hipStreamCreateWithFlags(&h->e.tail, hipStreamNonBlocking);
+    if (er == hipSuccess) er = hipEventCreateWithFlags(&h->e.tail_done, hipEventDisableTiming);
+    if (er != hipSuccess) { set_error(std::string("tail stream: ") + hipGetErrorString(er)); delete h; return ISEGMI_ERR_HIP; }
     h->e.cur = h->e.stream;
     *out = h;
     return ISEGMI_OK;
@@ -348,6 +366,8 @@ extern "C" int isegmi_engine_destroy(isegmi_engine* h) {
     if (!h) return ISEGMI_OK;
     Engine& e = h->e;
     (void)hipStreamSynchronize(e.stream);
+    if (e.tail) { (void)hipStreamSynchronize(e.tail); (void)hipStreamDestroy(e.tail); }
+    if (e.tail_done) (void)hipEventDestroy(e.tail_done);
     for (auto& kv : e.convs) { (void)hipFree(kv.second.d_w); if (kv.second.d_scale) (void)hipFree(kv.second.d_scale); if (kv.second.d_shift) (void)hipFree(kv.second.d_shift); }
     for (auto& kv : e.tensors) (void)hipFree(kv.second.d);
     for (auto& kv : e.bufs) (void)hipFree(kv.second.d);
@@ -427,13 +447,16 @@ extern "C" int isegmi_yolact_postprocess(isegmi_engine* h, int out_h, int out_w)
 extern "C" int isegmi_engine_sync(isegmi_engine* h) {
     ARG_CHECK(h, "null");
     HIP_TRY(hipStreamSynchronize(h->e.stream));
+    if (h->e.tail) HIP_TRY(hipStreamSynchronize(h->e.tail));
+    h->e.tail_pending = false;
     collect_times(h->e);
     return ISEGMI_OK;
 }
 
 extern "C" int isegmi_engine_stream(isegmi_engine* h, void** stream) {
     ARG_CHECK(h && stream, "null");
-    *stream = (void*)h->e.stream;
+    // the stream on which the last forward's RESULTS complete (Yolact: the tail stream)
+    *stream = (void*)((h->e.kind == 1 && h->e.multi_stream && h->e.tail_pending) ? h->e.tail : h->e.stream);
     return ISEGMI_OK;
 }
 
@@ -488,21 +511,23 @@ extern "C" int isegmi_yolact_pack_records(isegmi_engine* h, void* d_dst, int64_t
     const int N = e.last_N;
     ARG_CHECK(N > 0, "pack before forward");
     const int K = (int)e.param("max_num_detections", 100);
+    hipStream_t rs = (e.multi_stream && e.tail_pending) ? e.tail : e.stream;  // results stream
     const char* names[5] = {"det.count", "det.box", "det.score", "det.class", "det.coeff"};
     const int64_t sizes[5] = {(int64_t)N * 4, (int64_t)N * K * 16, (int64_t)N * K * 4, (int64_t)N * K * 4, (int64_t)N * K * 32 * 4};
     int64_t off = 0;
     for (int i = 0; i < 5; ++i) {
         ARG_CHECK(off + sizes[i] <= cap, "record buffer too small");
-        HIP_TRY(hipMemcpyAsync((char*)d_dst + off, e.bufs[names[i]].d, (size_t)sizes[i], hipMemcpyDeviceToDevice, e.stream));
+        HIP_TRY(hipMemcpyAsync((char*)d_dst + off, e.bufs[names[i]].d, (size_t)sizes[i], hipMemcpyDeviceToDevice, rs));
         off += sizes[i];
     }
     if (with_proto) {
         RawBuf& p = e.bufs["proto"];
         const int64_t pb = (int64_t)N * p.shape[1] * p.shape[2] * p.shape[3] * 4;
         ARG_CHECK(off + pb <= cap, "record buffer too small (proto)");
-        HIP_TRY(hipMemcpyAsync((char*)d_dst + off, p.d, (size_t)pb, hipMemcpyDeviceToDevice, e.stream));
+        HIP_TRY(hipMemcpyAsync((char*)d_dst + off, p.d, (size_t)pb, hipMemcpyDeviceToDevice, rs));
         off += pb;
     }
+    if (rs == e.tail && e.tail) HIP_TRY(hipEventRecord(e.tail_done, e.tail));  // the copies read proto / det.*: extend the WAR fence
     *bytes = off;
     return ISEGMI_OK;
 }

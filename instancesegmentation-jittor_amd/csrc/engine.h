@@ -42,6 +42,9 @@ struct Engine {
     hipStream_t stream = nullptr;          // main stream (all results are complete on it when a forward returns)
     hipStream_t side[3] = {nullptr, nullptr, nullptr};  // side streams for independent branches
     hipStream_t cur = nullptr;             // stream the next launch goes to
+    hipStream_t tail = nullptr;            // Yolact Detect + postprocess: latency-bound tail, overlapped with the NEXT forward's backbone
+    hipEvent_t tail_done = nullptr;        // recorded after the last tail launch; the next forward's head/proto writers wait on it
+    bool tail_pending = false;
     bool multi_stream = true;
     bool fp16 = false;                     // fp16 storage + f16 MFMA convs (BASELINE configs[4]); set before loading weights
     std::vector<hipEvent_t> ev_pool;
