@@ -72,3 +72,32 @@ def test_yolact_550_bit_exact(ffi, sd):
     assert np.array_equal(cls, rc) and np.array_equal(sc, rs) and np.array_equal(boxes, rb) and np.array_equal(masks, rm)
     assert masks.sum() > 0
     net.close()
+
+
+def test_back_to_back_forwards_are_independent(ffi, sd):
+    """Cross-step overlap (tail stream): forwards queued without a host sync must not disturb each other.
+    A, B alternate five times with no sync in between; the final results must equal a clean run of the last batch."""
+    from isegmi.yolact import Yolact
+    size = 200
+    net = Yolact(sd, max_batch=2, input_size=size)
+    xa, xb = _images(11, 2, size), _images(12, 2, size)
+    clean = {}
+    for name, x in (("a", xa), ("b", xb)):
+        net.upload(x); net.forward_device(2); net.postprocess_device(150, 170); net.sync()
+        clean[name] = {k: net.fetch(k, 2) for k in ("det.count", "det.score", "det.prior", "det.box", "det.masks", "det.box_int")}
+    da = ffi.DeviceBuffer.from_numpy(xa); db = ffi.DeviceBuffer.from_numpy(xb)
+    import ctypes as C
+    for i in range(5):
+        for name, d in (("a", da), ("b", db)):
+            ffi.check(ffi.lib().isegmi_yolact_forward(net._h, d.ptr, 2))
+            net.postprocess_device(150, 170)
+    net.sync()
+    for k, v in clean["b"].items():
+        got = net.fetch(k, 2)
+        if k == "det.masks":
+            cnt = clean["b"]["det.count"]
+            assert all(np.array_equal(got[i, : cnt[i]], v[i, : cnt[i]]) for i in range(2))
+        else:
+            assert np.array_equal(got, v), k
+    assert not np.array_equal(clean["a"]["det.score"], clean["b"]["det.score"])
+    net.close()
