@@ -128,7 +128,7 @@ void eng_mark(Engine& e, const char* name) {
     StageTime s;
     s.name = name;
     if (hipEventCreate(&s.ev) != hipSuccess) return;
-    (void)hipEventRecord(s.ev, e.stream);
+    (void)hipEventRecord(s.ev, e.cur ? e.cur : e.stream);
     e.marks.push_back(s);
 }
 
@@ -456,7 +456,7 @@ extern "C" int isegmi_engine_sync(isegmi_engine* h) {
 extern "C" int isegmi_engine_stream(isegmi_engine* h, void** stream) {
     ARG_CHECK(h && stream, "null");
     // the stream on which the last forward's RESULTS complete (Yolact: the tail stream)
-    *stream = (void*)((h->e.kind == 1 && h->e.multi_stream && h->e.tail_pending) ? h->e.tail : h->e.stream);
+    *stream = (void*)((h->e.multi_stream && h->e.tail_pending) ? h->e.tail : h->e.stream);
     return ISEGMI_OK;
 }
 

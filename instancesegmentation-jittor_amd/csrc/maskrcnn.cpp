@@ -152,6 +152,9 @@ int maskrcnn_forward(Engine& e, const float* d_images, const int32_t* h_image_hw
                                   ge, l, L, post_nms, cand_boxes, cand_scores, cand_cnt, st));
         return ISEGMI_OK;
     };
+    // WAR: the previous forward's RoI heads (tail stream) still gather from P2..P5 and read proposals / det buffers;
+    // everything up to here (backbone, top-down chain) was free to run underneath them.
+    if (e.multi_stream && e.tail_pending) HIP_TRY(hipStreamWaitEvent(e.stream, e.tail_done, 0));
     for (int l = 0; l < 4; ++l) {
         TRY(eng_conv(e, "backbone.fpn.fpn_layer" + std::to_string(l + 1), last[l], 1, 1, 0, nullptr, "P" + std::to_string(l + 2), &P[l]));
         TRY(rpn_level(l));
@@ -180,6 +183,17 @@ int maskrcnn_forward(Engine& e, const float* d_images, const int32_t* h_image_hw
     TRY(topk_launch(cand_scores, (int64_t)L * post_nms, N, L * post_nms, R, cand_total, 1, fin_vals, fin_idx, fin_cnt, st));
     TRY(gather_proposals_launch(cand_boxes, fin_vals, fin_idx, fin_cnt, N, L * post_nms, R, props, prop_scores, prop_cnt, st));
     eng_mark(e, "proposals");
+
+    // The RoI heads run on the tail stream: their selection kernels are small latency-bound grids, and the next
+    // forward's backbone (main stream) may start underneath them.  Single-stream mode keeps everything on main.
+    if (e.multi_stream) {
+        hipEvent_t ev;
+        HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(ev, e.stream));
+        HIP_TRY(hipStreamWaitEvent(e.tail, ev, 0));
+        HIP_TRY(hipEventDestroy(ev));
+        e.cur = e.tail;
+    }
 
     // ---- box head
     const float* feats[4] = {P[0].d, P[1].d, P[2].d, P[3].d};
@@ -243,6 +257,8 @@ int maskrcnn_forward(Engine& e, const float* d_images, const int32_t* h_image_hw
     if (dt) TRY(mask_logits_select_f16_launch(up.d, N * cap, 784, 256, (const float*)lw->d, (const float*)lb->d, a.d_out_labels, (float*)p, st));
     else TRY(mask_logits_select_launch(up.d, N * cap, 784, 256, (const float*)lw->d, (const float*)lb->d, a.d_out_labels, (float*)p, st));
     eng_mark(e, "mask_head");
+    if (e.multi_stream) { HIP_TRY(hipEventRecord(e.tail_done, e.tail)); e.tail_pending = true; }
+    e.cur = e.stream;
     e.last_N = N;
     return ISEGMI_OK;
 #undef st
@@ -254,21 +270,24 @@ int maskrcnn_paste(Engine& e, const float* h_ratios_wh, int out_h, int out_w) {
     const int cap = (int)e.param("detections_per_img", 100);
     void *p, *rb, *rt;
     TRY(eng_buf(e, "ws.ratios", (int64_t)N * 8, &rt));
-    e.cur = e.stream;
+    hipStream_t ps = (e.multi_stream && e.tail_pending) ? e.tail : e.stream;  // results stream of the last forward
+    e.cur = ps;
     {
         std::vector<float> now(h_ratios_wh, h_ratios_wh + 2 * N);
         if (now != e.last_ratios || e.last_ratios_ptr != (const void*)rt) {
-            HIP_TRY(hipMemcpyAsync(rt, h_ratios_wh, (size_t)N * 8, hipMemcpyHostToDevice, e.stream));
-            HIP_TRY(hipStreamSynchronize(e.stream));
+            HIP_TRY(hipMemcpyAsync(rt, h_ratios_wh, (size_t)N * 8, hipMemcpyHostToDevice, ps));
+            HIP_TRY(hipStreamSynchronize(ps));
             e.last_ratios = now;
             e.last_ratios_ptr = rt;
         }
     }
     TRY(eng_buf(e, "det.box_resized", (int64_t)N * cap * 16, &rb, 0, {N, cap, 4}));
-    TRY(scale_boxes_launch((const float*)e.bufs["det.box"].d, (const float*)rt, N, cap, (float*)rb, e.stream));
+    TRY(scale_boxes_launch((const float*)e.bufs["det.box"].d, (const float*)rt, N, cap, (float*)rb, ps));
     TRY(eng_buf(e, "det.masks", (int64_t)N * cap * out_h * out_w, &p, 2, {N, cap, out_h, out_w}));
     TRY(paste_masks_launch((const float*)e.bufs["det.mask28"].d, (const float*)rb, (const int*)e.bufs["det.count"].d, N, cap, 28, out_h,
-                           out_w, e.param("mask_threshold", 0.5f), (uint8_t*)p, e.stream));
+                           out_w, e.param("mask_threshold", 0.5f), (uint8_t*)p, ps));
+    if (ps == e.tail) HIP_TRY(hipEventRecord(e.tail_done, e.tail));
+    e.cur = e.stream;
     eng_mark(e, "paste");
     return ISEGMI_OK;
 }
@@ -304,14 +323,16 @@ extern "C" int isegmi_maskrcnn_pack_records(isegmi_engine* h, void* d_dst, int64
     const int N = e.last_N;
     ARG_CHECK(N > 0, "pack before forward");
     const int K = (int)e.param("detections_per_img", 100);
+    hipStream_t rs = (e.multi_stream && e.tail_pending) ? e.tail : e.stream;  // results stream
     const char* names[5] = {"det.count", "det.box", "det.score", "det.label", "det.mask28"};
     const int64_t sizes[5] = {(int64_t)N * 4, (int64_t)N * K * 16, (int64_t)N * K * 4, (int64_t)N * K * 4, (int64_t)N * K * 784 * 4};
     int64_t off = 0;
     for (int i = 0; i < 5; ++i) {
         ARG_CHECK(off + sizes[i] <= cap, "record buffer too small");
-        HIP_TRY(hipMemcpyAsync((char*)d_dst + off, e.bufs[names[i]].d, (size_t)sizes[i], hipMemcpyDeviceToDevice, e.stream));
+        HIP_TRY(hipMemcpyAsync((char*)d_dst + off, e.bufs[names[i]].d, (size_t)sizes[i], hipMemcpyDeviceToDevice, rs));
         off += sizes[i];
     }
+    if (rs == e.tail) HIP_TRY(hipEventRecord(e.tail_done, e.tail));
     *bytes = off;
     return ISEGMI_OK;
 }

@@ -144,3 +144,32 @@ def test_maskrcnn_fp16_path_close_to_fp16_oracle(ffi, sd):
     model.paste_device(x.shape[1], x.shape[2]); model.sync()
     assert model.fetch("det.masks", 1).any()
     model.close()
+
+
+def test_maskrcnn_back_to_back_forwards(ffi, sd):
+    """Tail-stream overlap: A, B alternate without host syncs; the last results must equal a clean run of B."""
+    from isegmi.maskrcnn import MaskRCNN, prepare_images
+    rng = np.random.default_rng(31)
+    xa, hwa = prepare_images([rng.uniform(0, 255, (200, 230, 3)).astype(np.float32)])
+    xb, hwb = prepare_images([rng.uniform(0, 255, (196, 236, 3)).astype(np.float32)])
+    assert xa.shape == xb.shape
+    model = MaskRCNN(sd, xa.shape[1], xa.shape[2], max_batch=1)
+    names = ("det.count", "det.score", "det.label", "det.box", "det.mask28", "proposals", "det.masks")
+    model.upload(xb, hwb); model.forward_device(1); model.paste_device(xa.shape[1], xa.shape[2]); model.sync()
+    clean = {k: model.fetch(k, 1) for k in names}
+    da = ffi.DeviceBuffer.from_numpy(xa); db = ffi.DeviceBuffer.from_numpy(xb)
+    import ctypes as C
+    for i in range(4):
+        for d, hw in ((da, hwa), (db, hwb)):
+            ffi.check(ffi.lib().isegmi_maskrcnn_forward(model._h, d.ptr, np.ascontiguousarray(hw, np.int32).ctypes.data_as(C.c_void_p), 1))
+            model._hw = hw
+            model.paste_device(xa.shape[1], xa.shape[2])
+    model.sync()
+    n = int(clean["det.count"][0])
+    for k in names:
+        got = model.fetch(k, 1)
+        if k in ("det.masks",):
+            assert np.array_equal(got[0, :n], clean[k][0, :n])
+        else:
+            assert np.array_equal(got, clean[k]), k
+    model.close()
