@@ -246,6 +246,136 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Small-M / latency-bound variant: block tile 32x32, four waves, each wave ONE 16x16 tile on
+// v_mfma_f32_16x16x4_f32 (lane (i, q) supplies k = 4s + q; the instruction is the same ordered fmaf chain, 4 k deep).
+// A wave's accumulator chain advances 4 k per 40 cycles instead of 2 k per 64, so the K-order latency floor that
+// bounds tiny layers (res5, P5-P7 heads, everything at bs=1) drops ~2.5x, and a layer yields 4x more blocks than
+// with 64x64 tiles.  Same packed weights, same LDS image (36-float rows, [k0 k2 k4 k6 | k1 k3 k5 k7] groups), same
+// buffer-op loads/epilogue as the main kernel; 18.4 KB LDS -> 8 blocks/CU.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void conv_mfma16_kernel(const ConvK p) {
+    constexpr int BM = 32, BN = 32;
+    constexpr int STAGE = (BM + BN) * LDS_ROW;
+    __shared__ __attribute__((aligned(16))) float smem16[2 * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int nt = logical % p.ntiles, mt = logical / p.ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    // loader: thread covers row tid>>3 (32 rows) and 4 consecutive k (g8 = tid&7) of the 32-chunk
+    const int lrow = tid >> 3, g8 = tid & 7;
+    int hi0, wi0, nb;
+    {
+        const int m = m0 + lrow;
+        if (m < p.M) {
+            const int hw = p.Ho * p.Wo;
+            const int n = m / hw, rem = m - n * hw;
+            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+            hi0 = ho * p.stride - p.pad; wi0 = wo * p.stride - p.pad; nb = n * p.H;
+        } else { hi0 = -(1 << 28); wi0 = 0; nb = 0; }
+    }
+    const float* wsrc = p.w + (int64_t)(n0 + lrow) * p.wrow + g8 * 4;
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    u32x4 ra, rb;
+    int kr = 0, ks = 0, kc = 0;
+    auto load_chunk = [&](int chunk) {
+        const int hi = hi0 + kr, wi = wi0 + ks;
+        const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+        const unsigned off = ((unsigned)((nb + hi) * p.W + wi) * (unsigned)p.Cin + (unsigned)(kc * 32 + g8 * 4)) * 4u;
+        ra = __builtin_amdgcn_raw_buffer_load_b128(rs_in, ok ? off : OOB, 0, 0);
+        rb = *(const u32x4*)(wsrc + chunk * 32);
+        if (++kc == p.cin_chunks) { kc = 0; if (++ks == p.S) { ks = 0; ++kr; } }
+    };
+    // element e = 4*(g8&1) + j of 8-group g8>>1 lives at position 4*(e&1) + (e>>1): (x0,x2) and (x1,x3) pairs
+    const int grp = g8 >> 1, half = g8 & 1;
+    auto store_chunk = [&](int stage) {
+        float* As = smem16 + stage * STAGE;
+        float* Bs = As + BM * LDS_ROW;
+        float* d = As + lrow * LDS_ROW + grp * 8 + 2 * half;
+        *(u32x2*)d = u32x2{ra.x, ra.z};
+        *(u32x2*)(d + 4) = u32x2{ra.y, ra.w};
+        *(u32x4*)(Bs + lrow * LDS_ROW + g8 * 4) = rb;  // weights are pre-permuted: straight copy
+    };
+
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int li = lane & 15, lq = lane >> 4;
+    // k = 4s + lq: s even -> e = lq, s odd -> e = 4 + lq  => position 4*(lq&1) + (lq>>1) (+2 for odd s)
+    const int kpos = 4 * (lq & 1) + (lq >> 1);
+    const int a_off = (wm * 16 + li) * LDS_ROW + kpos;
+    const int b_off = BM * LDS_ROW + (wn * 16 + li) * LDS_ROW + kpos;
+    auto compute = [&](int stage) {
+        const float* sb = smem16 + stage * STAGE;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float a0 = sb[a_off + g * 8], a1 = sb[a_off + g * 8 + 2];
+            const float b0 = sb[b_off + g * 8], b1 = sb[b_off + g * 8 + 2];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc, 0, 0, 0);
+        }
+    };
+
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    int cur = 0;
+    for (int t = 0; t + 1 < p.nchunks; ++t) {
+        load_chunk(t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(cur);
+        __builtin_amdgcn_sched_barrier(0);
+        store_chunk(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    compute(cur);
+
+    // epilogue: D col (cout) = lane&15, row (pixel) = (lane>>4)*4 + e
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, p.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? p.res : p.out), 0, p.res ? p.res_bytes : 0u, 0x00020000);
+    const int co = n0 + wn * 16 + li;
+    const bool cok = co < p.Cout;
+    const float sc = (cok && p.scale) ? p.scale[co] : 1.0f;
+    const float sh = (cok && p.shift) ? p.shift[co] : 0.0f;
+    unsigned ooff[4];
+    float rv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int m = m0 + wm * 16 + lq * 4 + e;
+        const bool ok = cok && m < p.M;
+        unsigned off;
+        if (p.contiguous) off = ((unsigned)m * (unsigned)p.out_pix_stride + (unsigned)co) * 4u;
+        else {
+            const int ni = m / p.out_div, pi = m - ni * p.out_div;
+            off = (unsigned)(((int64_t)ni * p.out_img_stride + (int64_t)pi * p.out_pix_stride + co) * 4);
+        }
+        ooff[e] = ok ? off : OOB;
+        rv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_res, ok ? ((unsigned)m * (unsigned)p.Cout + (unsigned)co) * 4u : OOB, 0, 0));
+    }
+    float yv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float y = fmaf(acc[e], sc, sh);
+        y = y + rv[e];
+        yv[e] = p.act == 1 ? (y > 0.0f ? y : 0.0f) : y;
+    }
+    if (p.act == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) yv[e] = dm_tanh(yv[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yv[e]), rs_out, ooff[e], 0, 0);
+}
+
 static inline int perm8(int e) { return 4 * (e & 1) + (e >> 1); }
 static bool is_stem(const isegmi_conv_desc* d) { return d->Cin == 4 && d->R == 7 && d->S == 7; }
 static int cout_pad(const isegmi_conv_desc* d) { return cdiv(d->Cout, 128) * 128; }
@@ -258,7 +388,7 @@ static int check_desc(const isegmi_conv_desc* d) {
     ARG_CHECK(is_stem(d) || (d->Cin > 0 && d->Cin % 32 == 0), "Cin must be a multiple of 32 (or the Cin=4 7x7 stem)");
     ARG_CHECK(d->H + 2 * d->pad >= d->R && d->W + 2 * d->pad >= d->S, "kernel larger than padded input");
     ARG_CHECK(d->act >= 0 && d->act <= 2, "act");
-    ARG_CHECK(d->tile >= 0 && d->tile <= 3, "tile");
+    ARG_CHECK(d->tile >= 0 && d->tile <= 4, "tile");
     return ISEGMI_OK;
 }
 
@@ -318,6 +448,21 @@ int conv2d_launch(const isegmi_conv_desc* d, const float* in, const float* w, co
         // 36.9 KB LDS) matches 128x128 at full occupancy (124 TF/s) and wins everywhere else through finer
         // wave quantisation, so it is the default; 128-wide tiles stay selectable for experiments.
         tile = 3;
+        // ... except (measured per layer at bs=8 and bs=1, profiles/r01_conv_tile3_vs_tile4.txt) where the 32x32 block
+        // on 16x16x4 MFMA wins: grids of fewer than ~160 64x64 tiles (latency-bound: 4x the blocks and a ~2.5x shorter
+        // K-chain per wave), and narrow outputs whose padding to 64 wastes half the MFMA work (Cout <= 32 at any size,
+        // Cout % 64 in 1..32 such as the 96-wide coefficient head while the grid is small).
+        const int64_t t64 = (int64_t)cdiv(k.M, 64) * cdiv(d->Cout, 64);
+        const int rem64 = d->Cout % 64;
+        if (!is_stem(d) && (t64 < 160 || d->Cout <= 32 || (rem64 > 0 && rem64 <= 32 && t64 < 400))) tile = 4;
+    }
+    if (tile == 4 && is_stem(d)) tile = 3;  // the 16x16x4 variant has no stem path
+    if (tile == 4) {
+        k.mtiles = cdiv(k.M, 32);
+        k.ntiles = cdiv(d->Cout, 32);
+        hipLaunchKernelGGL(conv_mfma16_kernel, dim3((unsigned)(k.mtiles * k.ntiles)), dim3(256), 0, st, k);
+        HIP_TRY(hipGetLastError());
+        return ISEGMI_OK;
     }
     switch (tile) {
         case 1: return launch<128, 128, 2, 2>(d, k, st);

@@ -24,5 +24,5 @@ rows = [r.split("\t") for r in buf.value.decode().strip().split("\n")]
 rows.sort(key=lambda r: -float(r[2]))
 tot = sum(float(r[2]) for r in rows) / R
 print("total conv ms/step %.3f" % tot)
-for r in rows[:60]:
+for r in rows:
     print("%-95s %8.2f GF %8.3f ms %7.2f TF/s" % (r[0], float(r[1]) / R, float(r[2]) / R, float(r[3])))
