@@ -1,6 +1,6 @@
 """AddressSanitizer + UBSan pass over the CPU oracle (sanitizers are CPU-only on this pool).
 usage: python tools/oracle_asan.py   (builds /tmp/liboracle_asan.so, re-runs itself under LD_PRELOAD=libasan)"""
-import os, subprocess, sys
+import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if os.environ.get("ORA_ASAN_CHILD") != "1":
     so = "/tmp/liboracle_asan.so"
