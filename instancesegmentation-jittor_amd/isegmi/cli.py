@@ -1,0 +1,136 @@
+"""Command-line front ends shaped like the reference's (README.md:243-249 and README.md:344-347):
+
+  python -m isegmi.cli eval --trained_model=weights.npz --score_threshold=0.15 --top_k=15 --image=in.png[:out.png]
+  python -m isegmi.cli eval --trained_model=weights.npz --images=in_dir:out_dir [--output_coco_json=dets.json]
+  python -m isegmi.cli test_net --config-file cfg.yaml [--images dir] [--output results.json]
+
+`--trained_model` / `MODEL.WEIGHT` take the .npz written by tools/import_pth.py; the literal value `random` uses the
+seeded synthetic weights (there is no network to fetch the reference's .pth files).  Images are read with PIL.
+test_net shards the image list over ranks when launched with torch.distributed.run and all-gathers the detection
+records with RCCL before rank 0 writes the COCO json.
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+
+def _load_image_bgr(path):
+    from PIL import Image
+    return np.asarray(Image.open(path).convert("RGB"))[:, :, ::-1].copy()
+
+
+def _save_image_bgr(path, img):
+    from PIL import Image
+    Image.fromarray(np.ascontiguousarray(img[:, :, ::-1])).save(path)
+
+
+def _weights(spec, kind, depth=50):
+    from .weights import maskrcnn_state_dict, yolact_state_dict
+    if spec in ("", "random", None):
+        return yolact_state_dict(1234) if kind == "yolact" else maskrcnn_state_dict(1234, depth)
+    if not spec.endswith(".npz"):
+        raise SystemExit("%s: convert upstream .pth/.pkl with tools/import_pth.py first" % spec)
+    return dict(np.load(spec))
+
+
+def _overlay(img, masks, boxes, classes):
+    from .predictor import COCODemo
+    colors = COCODemo.compute_colors_for_labels(np.asarray(classes) + 1)
+    out = img.copy()
+    for k in range(len(classes)):
+        m = masks[k].astype(bool)
+        out[m] = (0.5 * out[m] + 0.5 * colors[k].astype(np.float32)).astype(np.uint8)
+        x1, y1, x2, y2 = (int(v) for v in boxes[k])
+        x2, y2 = min(x2, out.shape[1] - 1), min(y2, out.shape[0] - 1)
+        out[y1:y2 + 1, [x1, x2]] = colors[k]
+        out[[y1, y2], x1:x2 + 1] = colors[k]
+    return out
+
+
+def cmd_eval(a):
+    """Yolact eval.py: evalimage / evalimages (+ Detections.dump when --output_coco_json is given)."""
+    from .coco import dump, yolact_results
+    from .transforms import yolact_transform
+    from .yolact import Yolact, postprocess
+    net = Yolact(_weights(a.trained_model, "yolact"), max_batch=1)
+    jobs = []
+    if a.image:
+        src, _, dst = a.image.partition(":")
+        jobs.append((src, dst or None))
+    if a.images:
+        src, _, dst = a.images.partition(":")
+        os.makedirs(dst, exist_ok=True)
+        for f in sorted(os.listdir(src)):
+            jobs.append((os.path.join(src, f), os.path.join(dst, os.path.splitext(f)[0] + ".png")))
+    results = []
+    for i, (src, dst) in enumerate(jobs):
+        frame = _load_image_bgr(src)
+        h, w = frame.shape[:2]
+        preds = net(yolact_transform(frame, net.size))
+        classes, scores, boxes, masks = postprocess(preds, w, h, score_threshold=a.score_threshold)
+        classes, scores, boxes, masks = classes[:a.top_k], scores[:a.top_k], boxes[:a.top_k], masks[:a.top_k]
+        print("%s: %d detections" % (src, len(scores)))
+        if dst:
+            _save_image_bgr(dst, _overlay(frame, masks, boxes, classes))
+        results += yolact_results(i, classes, scores, boxes, masks)
+    if a.output_coco_json:
+        dump(results, a.output_coco_json)
+    net.close()
+    return results
+
+
+def cmd_test_net(a):
+    """tools/test_net.py: build the model from the yaml, run inference() over the images, write COCO-format json."""
+    from .config import cfg, to_maskrcnn_config
+    from .dist import shard_batch
+    from .predictor import COCODemo, inference
+    c = cfg.clone()
+    if a.config_file:
+        c.merge_from_file(a.config_file)
+    c.merge_from_list(a.opts)
+    mc = to_maskrcnn_config(c)
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    files = sorted(os.path.join(a.images, f) for f in os.listdir(a.images)) if a.images else []
+    lo, hi = shard_batch(len(files), rank, world)
+    demo = COCODemo(mc, min_image_size=mc.MIN_SIZE_TEST, confidence_threshold=0.0, state_dict=_weights(c.MODEL.WEIGHT, "maskrcnn", mc.depth),
+                    max_image_size=mc.MAX_SIZE_TEST, device=int(os.environ.get("LOCAL_RANK", "0")))
+    local = inference(demo, [_load_image_bgr(f) for f in files[lo:hi]], image_ids=list(range(lo, hi)))
+    demo.close()
+    if world > 1:  # result lists are ragged python objects: gather them with the process group the launcher set up
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        parts = [None] * world
+        dist.all_gather_object(parts, local)
+        local = [r for p in parts for r in p]
+        dist.destroy_process_group()
+    if rank == 0:
+        with open(a.output, "w") as f:
+            json.dump(local, f)
+        print("wrote %d results for %d images to %s" % (len(local), len(files), a.output))
+    return local
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="isegmi.cli")
+    sub = ap.add_subparsers(dest="cmd", required=True)
+    e = sub.add_parser("eval", help="Yolact eval.py-style image evaluation")
+    e.add_argument("--trained_model", default="random")
+    e.add_argument("--score_threshold", type=float, default=0.0)
+    e.add_argument("--top_k", type=int, default=5)
+    e.add_argument("--image", default=None, help="in.png[:out.png]")
+    e.add_argument("--images", default=None, help="in_dir:out_dir")
+    e.add_argument("--output_coco_json", default=None)
+    t = sub.add_parser("test_net", help="detectron tools/test_net.py-style evaluation -> COCO json")
+    t.add_argument("--config-file", dest="config_file", default="")
+    t.add_argument("--images", default=None, help="directory of images (the COCO dataset catalog is out of scope)")
+    t.add_argument("--output", default="results.json")
+    t.add_argument("opts", nargs=argparse.REMAINDER, default=[])
+    a = ap.parse_args(argv)
+    return cmd_eval(a) if a.cmd == "eval" else cmd_test_net(a)
+
+
+if __name__ == "__main__":
+    main()

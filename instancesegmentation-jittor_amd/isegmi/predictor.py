@@ -18,9 +18,17 @@ class COCODemo:
     CATEGORIES = ("__background",) + COCO_CLASSES
 
     def __init__(self, cfg=None, min_image_size=800, confidence_threshold=0.5, state_dict=None, max_image_size=1333, device=0):
-        if state_dict is None:
-            raise ValueError("COCODemo needs a state_dict (cfg.MODEL.WEIGHT cannot be downloaded here)")
+        if cfg is not None and not isinstance(cfg, MaskRCNNConfig):   # the yacs-shaped node of isegmi.config (README.md:313-324)
+            from .config import to_maskrcnn_config
+            if state_dict is None and getattr(cfg.MODEL, "WEIGHT", ""):
+                w = cfg.MODEL.WEIGHT
+                from .weights import maskrcnn_state_dict
+                state_dict = maskrcnn_state_dict(1234, 101 if "101" in cfg.MODEL.BACKBONE.CONV_BODY else 50) if w == "random" else dict(np.load(w))
+            cfg = to_maskrcnn_config(cfg)
         self.cfg = cfg or MaskRCNNConfig()
+        if state_dict is None:
+            raise ValueError("COCODemo needs weights: pass state_dict=... or set cfg.MODEL.WEIGHT to an .npz (or 'random'); "
+                             "the reference's download URLs (README.md:266) cannot be fetched here")
         self.min_image_size, self.max_image_size = min_image_size, max_image_size
         self.confidence_threshold = confidence_threshold
         self.state_dict, self.device = state_dict, device

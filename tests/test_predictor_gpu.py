@@ -59,3 +59,22 @@ def test_yolact_eval_style_output(ffi):
     if res:
         assert np.array_equal(rle_decode(res[0]["segmentation"]), masks[0])
     net.close()
+
+
+def test_cli_eval_and_test_net(ffi, tmp_path):
+    """`eval` (README.md:243-249) and `test_net` (README.md:344-347) front ends on a folder of synthetic PNGs."""
+    from PIL import Image
+    from isegmi import cli
+    rng = np.random.default_rng(3)
+    src = tmp_path / "in"; dst = tmp_path / "out"; src.mkdir()
+    for i in range(2):
+        Image.fromarray(rng.integers(0, 256, (90 + 10 * i, 120, 3)).astype(np.uint8)).save(src / ("im%d.png" % i))
+    res = cli.main(["eval", "--trained_model=random", "--score_threshold=0.15", "--top_k=15", "--images=%s:%s" % (src, dst),
+                    "--output_coco_json=%s" % (tmp_path / "y.json")])
+    assert len(list(dst.iterdir())) == 2 and json.load(open(tmp_path / "y.json")) == res
+    assert all(set(r) >= {"image_id", "category_id", "bbox", "score", "segmentation"} for r in res)
+    cfgp = tmp_path / "c.yaml"
+    cfgp.write_text('MODEL:\n  WEIGHT: "random"\n  ROI_HEADS:\n    DETECTIONS_PER_IMG: 20\nINPUT:\n  MIN_SIZE_TEST: 160\n  MAX_SIZE_TEST: 256\n')
+    out = cli.main(["test_net", "--config-file", str(cfgp), "--images", str(src), "--output", str(tmp_path / "m.json")])
+    back = json.load(open(tmp_path / "m.json"))
+    assert len(back) == len(out) and {r["image_id"] for r in back} <= {0, 1} and all(len([r for r in back if r["image_id"] == i]) <= 20 for i in (0, 1))
