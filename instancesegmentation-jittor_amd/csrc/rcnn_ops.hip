@@ -537,15 +537,20 @@ __global__ __launch_bounds__(256) void paste_masks_kernel(const float* __restric
     const int y_0 = y1 > 0 ? y1 : 0, y_1 = (y2 + 1) < im_h ? (y2 + 1) : im_h;
     const float* m = masks + ((int64_t)n * K + d) * M * M;
     uint8_t* o = out + ((int64_t)n * K + d) * im_h * im_w;
+    // The plane was zeroed by the memset node ahead of this launch: only the rows the box touches are visited, and a
+    // word is stored only if one of its 4 pixels lies inside the box (paste cost ~ box area, not image area).
     const int64_t total = (int64_t)im_h * im_w;
-    for (int64_t q = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; q < total; q += (int64_t)gridDim.x * 256 * 4) {
+    const int64_t q_begin = ((int64_t)y_0 * im_w) & ~3ll, q_end = (int64_t)y_1 * im_w < total ? (int64_t)y_1 * im_w : total;
+    for (int64_t q = q_begin + ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; q < q_end; q += (int64_t)gridDim.x * 256 * 4) {
         uint32_t word = 0;
+        bool any = false;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int64_t f = q + e;
             if (f >= total) break;
             const int y = (int)(f / im_w), x = (int)(f - (int64_t)y * im_w);
             if (y < y_0 || y >= y_1 || x < x_0 || x >= x_1) continue;
+            any = true;
             int sy0, sy1, sx0, sx1; float ly0, ly1, lx0, lx1;
             dm_bil_coef(y - y1, P, h, sy0, sy1, ly0, ly1);
             dm_bil_coef(x - x1, P, w, sx0, sx1, lx0, lx1);
@@ -555,6 +560,7 @@ __global__ __launch_bounds__(256) void paste_masks_kernel(const float* __restric
             float v = ly0 * top; v = fmaf(ly1, bot, v);
             if (v > thr) word |= (1u << (8 * e));
         }
+        if (!any) continue;
         if (q + 3 < total) *(uint32_t*)(o + q) = word;
         else for (int e = 0; e < 4 && q + e < total; ++e) o[q + e] = (uint8_t)((word >> (8 * e)) & 0xff);
     }
