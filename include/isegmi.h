@@ -127,6 +127,15 @@ typedef struct isegmi_yolact_detect_args {
     int32_t* d_out_classes;  /* [N][max_det] 0..ncls-2 */
     float* d_out_coeffs;     /* [N][max_det][mask_dim] */
     int32_t* d_out_prior;    /* [N][max_det] */
+    /* optional fused-head layout (all zero = the three contiguous buffers above): the prediction head was run as ONE
+     * convolution whose per-pixel output row holds [A x 4 loc | A x ncls conf | A x mask_dim mask]; then d_conf, d_loc
+     * and d_mask all point at that buffer [N][P/A][pix_stride] and prior p = pix*A + a reads from row pix.
+     * mask_tanh: the mask block holds pre-activation values; tanh is applied to the <= max_det gathered rows. */
+    int32_t A;
+    int32_t mask_tanh;
+    int64_t pix_stride;
+    int32_t off_loc, off_conf, off_mask;
+    int32_t reserved;
 } isegmi_yolact_detect_args;
 int isegmi_op_yolact_detect(const isegmi_yolact_detect_args* a, void* stream);
 

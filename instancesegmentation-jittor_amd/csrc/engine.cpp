@@ -238,15 +238,29 @@ int yolact_forward(Engine& e, const float* d_images, int N) {
         auto it = e.tensors.find("priors");
         if (it == e.tensors.end() || it->second.bytes != (int64_t)Ptot * 16) { set_error("priors tensor missing or wrong size"); return ISEGMI_ERR_STATE; }
     }
-    void *loc, *conf, *mask;
-    TRY(eng_buf(e, "loc", (int64_t)N * Ptot * 4 * 4, &loc, 0, {N, Ptot, 4}));
-    TRY(eng_buf(e, "conf", (int64_t)N * Ptot * ncls * 4, &conf, 0, {N, Ptot, ncls}));
-    TRY(eng_buf(e, "mask", (int64_t)N * Ptot * md * 4, &mask, 0, {N, Ptot, md}));
+    // The three prediction convs (bbox 12, conf 243, mask 96) run as ONE 351-wide convolution when the host supplied
+    // the fused layer: 6 instead of 1+4+2 64-wide column tiles per pixel tile, 5 launches instead of 15.  Its output
+    // row per pixel is [A x 4 loc | A x 81 conf | A x 32 mask(pre-tanh)]; Detect reads it in place (HeadLayout).
+    const bool fused = e.convs.count("prediction_layers.0.head_cat") != 0;
+    const int CH = A * (4 + ncls + md);
+    void *loc = nullptr, *conf = nullptr, *mask = nullptr, *headcat = nullptr;
+    if (fused) {
+        TRY(eng_buf(e, "headcat", (int64_t)N * (Ptot / A) * CH * 4, &headcat, 0, {N, Ptot / A, CH}));
+    } else {
+        TRY(eng_buf(e, "loc", (int64_t)N * Ptot * 4 * 4, &loc, 0, {N, Ptot, 4}));
+        TRY(eng_buf(e, "conf", (int64_t)N * Ptot * ncls * 4, &conf, 0, {N, Ptot, ncls}));
+        TRY(eng_buf(e, "mask", (int64_t)N * Ptot * md * 4, &mask, 0, {N, Ptot, md}));
+    }
     auto head_level = [&](int l) -> int {
         Tensor uf;
         const std::string ln = "head.up" + std::to_string(l);
         TRY(eng_conv(e, "prediction_layers.0.upfeature.0", P[l], 1, 1, 1, nullptr, ln, &uf));
         const int hw = uf.H * uf.W;
+        if (fused) {
+            TRY(eng_conv_into(e, "prediction_layers.0.head_cat", uf, 1, 1, 0, (float*)headcat + (int64_t)(off[l] / A) * CH, hw,
+                              (int64_t)(Ptot / A) * CH, CH));
+            return ISEGMI_OK;
+        }
         TRY(eng_conv_into(e, "prediction_layers.0.bbox_layer", uf, 1, 1, 0, (float*)loc + (int64_t)off[l] * 4, hw, (int64_t)Ptot * 4, A * 4));
         TRY(eng_conv_into(e, "prediction_layers.0.conf_layer", uf, 1, 1, 0, (float*)conf + (int64_t)off[l] * ncls, hw, (int64_t)Ptot * ncls, A * ncls));
         TRY(eng_conv_into(e, "prediction_layers.0.mask_layer", uf, 1, 1, 2, (float*)mask + (int64_t)off[l] * md, hw, (int64_t)Ptot * md, A * md));
@@ -286,7 +300,12 @@ int yolact_forward(Engine& e, const float* d_images, int N) {
     a.N = N; a.P = Ptot; a.ncls = ncls; a.mask_dim = md; a.top_k = top_k; a.max_det = max_det;
     a.conf_thresh = e.param("nms_conf_thresh", 0.05f);
     a.nms_thresh = e.param("nms_thresh", 0.5f);
-    a.d_conf = (const float*)conf; a.d_loc = (const float*)loc; a.d_mask = (const float*)mask;
+    if (fused) {
+        a.d_conf = a.d_loc = a.d_mask = (const float*)headcat;
+        a.A = A; a.pix_stride = CH; a.off_loc = 0; a.off_conf = A * 4; a.off_mask = A * 4 + A * ncls; a.mask_tanh = 1;
+    } else {
+        a.d_conf = (const float*)conf; a.d_loc = (const float*)loc; a.d_mask = (const float*)mask;
+    }
     a.d_priors = (const float*)e.tensors["priors"].d;
     void* p;
     TRY(eng_buf(e, "ws.scoresT", (int64_t)N * nc * Ptot * 4, &p)); a.d_ws_scoresT = (float*)p;

@@ -18,15 +18,34 @@ namespace isegmi {
 
 constexpr int SM_ROWS = 128;
 
+// Addressing of the head outputs: separate contiguous buffers (pix_stride == 0) or the fused per-pixel row layout.
+struct HeadLayout {
+    int A;
+    int64_t pix_stride;
+    int off_loc, off_conf, off_mask, mask_tanh;
+};
+__device__ __forceinline__ const float* head_ptr(const float* base, const HeadLayout& L, int n, int P, int p, int width, int off) {
+    if (L.pix_stride == 0) return base + ((int64_t)n * P + p) * width;
+    const int pix = p / L.A, a = p - pix * L.A;
+    return base + ((int64_t)n * (P / L.A) + pix) * L.pix_stride + off + a * width;
+}
+
 __global__ __launch_bounds__(SM_ROWS) void yolact_softmax_decode_kernel(
     const float* __restrict__ conf, const float* __restrict__ loc, const float* __restrict__ priors, int P, int C,
-    float conf_thresh, float* __restrict__ scoresT, float* __restrict__ boxes, int* __restrict__ keep_count) {
+    float conf_thresh, const HeadLayout L, float* __restrict__ scoresT, float* __restrict__ boxes, int* __restrict__ keep_count) {
     extern __shared__ float sm[];  // [SM_ROWS][C]
     const int n = blockIdx.y;
     const int p0 = blockIdx.x * SM_ROWS;
     const int rows = (P - p0) < SM_ROWS ? (P - p0) : SM_ROWS;
-    const float* src = conf + ((int64_t)n * P + p0) * C;
-    for (int i = threadIdx.x; i < rows * C; i += SM_ROWS) sm[i] = src[i];
+    if (L.pix_stride == 0) {
+        const float* src = conf + ((int64_t)n * P + p0) * C;
+        for (int i = threadIdx.x; i < rows * C; i += SM_ROWS) sm[i] = src[i];
+    } else {
+        for (int i = threadIdx.x; i < rows * C; i += SM_ROWS) {
+            const int r = i / C, c = i - r * C;
+            sm[i] = head_ptr(conf, L, n, P, p0 + r, C, L.off_conf)[c];
+        }
+    }
     __syncthreads();
     const int t = threadIdx.x;
     const int p = p0 + t;
@@ -41,7 +60,8 @@ __global__ __launch_bounds__(SM_ROWS) void yolact_softmax_decode_kernel(
         for (int c = 0; c < C; ++c) { const float pr = dm_div(r[c], s); r[c] = pr; if (c >= 1) fg = pr > fg ? pr : fg; }
         kept = fg > conf_thresh;
         // decode
-        const float4 l = *(const float4*)(loc + ((int64_t)n * P + p) * 4);
+        const float* lp = head_ptr(loc, L, n, P, p, 4, L.off_loc);
+        const float4 l = make_float4(lp[0], lp[1], lp[2], lp[3]);
         const float4 q = *(const float4*)(priors + (int64_t)p * 4);
         float tx = l.x * 0.1f; tx = tx * q.z;
         float ty = l.y * 0.1f; ty = ty * q.w;
@@ -101,6 +121,7 @@ __global__ __launch_bounds__(256) void yolact_fast_nms_kernel(const float* __res
 __global__ void yolact_gather_kernel(const float* __restrict__ boxes, const float* __restrict__ mask, const int* __restrict__ tk_idx,
                                      const float* __restrict__ fin_vals, const int* __restrict__ fin_idx,
                                      const int* __restrict__ fin_cnt, int P, int nc, int top_k, int mask_dim, int max_det,
+                                     const HeadLayout L,
                                      int* __restrict__ out_count, float* __restrict__ out_boxes, float* __restrict__ out_scores,
                                      int* __restrict__ out_classes, float* __restrict__ out_coeffs, int* __restrict__ out_prior) {
     const int n = blockIdx.x;
@@ -116,7 +137,8 @@ __global__ void yolact_gather_kernel(const float* __restrict__ boxes, const floa
             out_scores[o] = fin_vals[o];
             out_classes[o] = c;
             out_prior[o] = prior;
-            for (int k = 0; k < mask_dim; ++k) out_coeffs[o * mask_dim + k] = mask[((int64_t)n * P + prior) * mask_dim + k];
+            const float* mp = head_ptr(mask, L, n, P, prior, mask_dim, L.off_mask);
+            for (int k = 0; k < mask_dim; ++k) out_coeffs[o * mask_dim + k] = L.mask_tanh ? dm_tanh(mp[k]) : mp[k];
         } else {
             *(float4*)(out_boxes + o * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
             out_scores[o] = 0.0f;
@@ -264,8 +286,12 @@ int yolact_detect_launch(const isegmi_yolact_detect_args* a, hipStream_t st) {
     int* keep_count = a->d_ws_counts;
     int* kept2 = a->d_ws_counts + a->N;
     const size_t lds = (size_t)SM_ROWS * a->ncls * sizeof(float);
+    HeadLayout L;
+    L.A = a->A > 0 ? a->A : 1; L.pix_stride = a->pix_stride; L.off_loc = a->off_loc; L.off_conf = a->off_conf; L.off_mask = a->off_mask;
+    L.mask_tanh = a->mask_tanh;
+    ARG_CHECK(a->pix_stride == 0 || (a->A > 0 && a->P % a->A == 0), "fused head layout needs A > 0 and P % A == 0");
     hipLaunchKernelGGL(yolact_softmax_decode_kernel, dim3(cdiv(a->P, SM_ROWS), a->N), dim3(SM_ROWS), lds, st, a->d_conf, a->d_loc,
-                       a->d_priors, a->P, a->ncls, a->conf_thresh, a->d_ws_scoresT, a->d_ws_boxes, keep_count);
+                       a->d_priors, a->P, a->ncls, a->conf_thresh, L, a->d_ws_scoresT, a->d_ws_boxes, keep_count);
     HIP_TRY(hipGetLastError());
     int rc = topk_launch(a->d_ws_scoresT, a->P, a->N * nc, a->P, a->top_k, keep_count, nc, a->d_ws_tk_vals, a->d_ws_tk_idx,
                          a->d_ws_tk_cnt, st);
@@ -277,7 +303,7 @@ int yolact_detect_launch(const isegmi_yolact_detect_args* a, hipStream_t st) {
                      a->d_ws_fin_idx, a->d_ws_fin_cnt, st);
     if (rc) return rc;
     hipLaunchKernelGGL(yolact_gather_kernel, dim3(a->N), dim3(128), 0, st, a->d_ws_boxes, a->d_mask, a->d_ws_tk_idx, a->d_ws_fin_vals,
-                       a->d_ws_fin_idx, a->d_ws_fin_cnt, a->P, nc, a->top_k, a->mask_dim, a->max_det, a->d_out_count,
+                       a->d_ws_fin_idx, a->d_ws_fin_cnt, a->P, nc, a->top_k, a->mask_dim, a->max_det, L, a->d_out_count,
                        a->d_out_boxes, a->d_out_scores, a->d_out_classes, a->d_out_coeffs, a->d_out_prior);
     HIP_TRY(hipGetLastError());
     return ISEGMI_OK;

@@ -201,7 +201,9 @@ class YolactDetectArgs(C.Structure):
                [(n, C.c_void_p) for n in (
                    "d_conf", "d_loc", "d_mask", "d_priors", "d_ws_scoresT", "d_ws_boxes", "d_ws_counts", "d_ws_tk_vals",
                    "d_ws_tk_idx", "d_ws_tk_cnt", "d_ws_cand", "d_ws_fin_vals", "d_ws_fin_idx", "d_ws_fin_cnt",
-                   "d_out_count", "d_out_boxes", "d_out_scores", "d_out_classes", "d_out_coeffs", "d_out_prior")]
+                   "d_out_count", "d_out_boxes", "d_out_scores", "d_out_classes", "d_out_coeffs", "d_out_prior")] + \
+               [("A", C.c_int32), ("mask_tanh", C.c_int32), ("pix_stride", C.c_int64), ("off_loc", C.c_int32), ("off_conf", C.c_int32),
+                ("off_mask", C.c_int32), ("reserved", C.c_int32)]
 
 
 def yolact_detect(conf_logits, loc, mask, priors, conf_thresh=0.05, nms_thresh=0.5, top_k=200, max_det=100):
@@ -221,7 +223,7 @@ def yolact_detect(conf_logits, loc, mask, priors, conf_thresh=0.05, nms_thresh=0
         d_out_boxes=DeviceBuffer((N, max_det, 4)), d_out_scores=DeviceBuffer((N, max_det)),
         d_out_classes=DeviceBuffer((N, max_det), np.int32), d_out_coeffs=DeviceBuffer((N, max_det, md)),
         d_out_prior=DeviceBuffer((N, max_det), np.int32))
-    a = YolactDetectArgs(N, P, ncls, md, top_k, max_det, conf_thresh, nms_thresh, *[bufs[n].ptr for n, _ in YolactDetectArgs._fields_[8:]])
+    a = YolactDetectArgs(N, P, ncls, md, top_k, max_det, conf_thresh, nms_thresh, *[bufs[n].ptr for n, _ in YolactDetectArgs._fields_[8:28]])
     check(lib().isegmi_op_yolact_detect(C.byref(a), None))
     cnt = bufs["d_out_count"].numpy()
     out = []

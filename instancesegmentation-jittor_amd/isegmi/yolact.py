@@ -69,10 +69,11 @@ class Yolact:
 
     KIND = 1
 
-    def __init__(self, state_dict, cfg=YolactConfig(), max_batch=8, device=0, input_size=None):
+    def __init__(self, state_dict, cfg=YolactConfig(), max_batch=8, device=0, input_size=None, fuse_heads=True):
         self.cfg = cfg
         self.size = int(input_size or cfg.max_size)
         self.max_batch = max_batch
+        self.fuse_heads = bool(fuse_heads)
         L = _ffi.lib()
         _ffi.set_device(device)
         self._h = C.c_void_p()
@@ -110,6 +111,11 @@ class Yolact:
                  ["prediction_layers.0." + n for n in ("upfeature.0", "bbox_layer", "conf_layer", "mask_layer")]
         for nm in biased:
             self._set_conv(nm, sd[nm + ".weight"], None, sd[nm + ".bias"])
+        # fused prediction head: [A*4 loc | A*81 conf | A*32 mask] as one 351-wide conv (tanh moves to the gather)
+        if self.fuse_heads:
+            names = ["prediction_layers.0." + n for n in ("bbox_layer", "conf_layer", "mask_layer")]
+            self._set_conv("prediction_layers.0.head_cat", np.concatenate([sd[n + ".weight"] for n in names], 0), None,
+                           np.concatenate([sd[n + ".bias"] for n in names]))
         pri = [make_priors(s, s, sc_, self.cfg.max_size, self.cfg.pred_aspect_ratios)
                for s, sc_ in zip(_level_sizes(self.size), self.cfg.pred_scales)]
         self.priors = np.concatenate(pri, 0)

@@ -23,10 +23,19 @@ def sd():
 def _compare(net, ref, x, size, n):
     out = net(x)
     refd = ref.forward(x)
-    for name in ("C3", "P3", "P5", "P7", "proto", "loc", "conf", "mask"):
+    for name in ("C3", "P3", "P5", "P7", "proto"):
         eng_name = {"C3": "backbone.layers.1.3.out"}.get(name, name)
         got = net.fetch(eng_name, n)
         assert np.array_equal(got.reshape(ref.feats[name].shape), ref.feats[name]), name
+    if net.fuse_heads:  # one 351-wide conv: per pixel [3x4 loc | 3x81 conf | 3x32 mask pre-tanh]
+        from oracle import ora
+        hc = net.fetch("headcat", n)
+        heads = {"loc": hc[..., :12].reshape(n, -1, 4), "conf": hc[..., 12:255].reshape(n, -1, 81),
+                 "mask": ora.map_f32(np.ascontiguousarray(hc[..., 255:]), 2).reshape(n, -1, 32)}
+    else:
+        heads = {k: net.fetch(k, n) for k in ("loc", "conf", "mask")}
+    for name in ("loc", "conf", "mask"):
+        assert np.array_equal(heads[name].reshape(ref.feats[name].shape), ref.feats[name]), name
     total = 0
     for i in range(n):
         r = refd[i]
@@ -57,6 +66,16 @@ def test_yolact_small_batch2_bit_exact(ffi, sd):
     for i in range(2):
         for k in ("prior", "score", "box"):
             assert np.array_equal(out[i]["detection"][k], out2[i]["detection"][k])
+    net.close()
+
+
+def test_yolact_unfused_heads_bit_exact(ffi, sd):
+    """The three separate prediction convs (the layout upstream uses) stay available and agree with the oracle too."""
+    from isegmi.yolact import Yolact
+    net = Yolact(sd, max_batch=1, input_size=200, fuse_heads=False)
+    ref = YolactRef(sd, max_size=550)
+    _, _, total = _compare(net, ref, _images(5, 1, 200), 200, 1)
+    assert total > 0
     net.close()
 
 
