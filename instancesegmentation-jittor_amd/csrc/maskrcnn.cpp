@@ -166,9 +166,20 @@ int maskrcnn_forward(Engine& e, const float* d_images, const int32_t* h_image_hw
         else TRY(maxpool_launch(P[3].d, N, P[3].H, P[3].W, P[3].C, 1, 2, 0, P[4].d, st));
         TRY(rpn_level(4));
     }
-    TRY(eng_join(e, 0));
-    TRY(eng_join(e, 1));
-    TRY(eng_join(e, 2));
+    // From here on everything runs on the TAIL stream: it (not the main stream) joins the side streams, so the main
+    // stream is free the moment its last RPN convolution is queued and the next forward's backbone starts underneath
+    // the remaining per-level selection kernels, proposal merge and RoI heads (all latency-bound or small grids).
+    if (e.multi_stream) {
+        hipStream_t srcs[4] = {e.stream, e.side[0], e.side[1], e.side[2]};
+        for (int i = 0; i < 4; ++i) {
+            hipEvent_t ev;
+            HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(ev, srcs[i]));
+            HIP_TRY(hipStreamWaitEvent(e.tail, ev, 0));
+            HIP_TRY(hipEventDestroy(ev));
+        }
+        e.cur = e.tail;
+    }
     eng_mark(e, "fpn_out+rpn");
     TRY(sum_counts_launch(cand_cnt, N, L, cand_total, st));
     float *fin_vals, *props, *prop_scores;
@@ -183,17 +194,6 @@ int maskrcnn_forward(Engine& e, const float* d_images, const int32_t* h_image_hw
     TRY(topk_launch(cand_scores, (int64_t)L * post_nms, N, L * post_nms, R, cand_total, 1, fin_vals, fin_idx, fin_cnt, st));
     TRY(gather_proposals_launch(cand_boxes, fin_vals, fin_idx, fin_cnt, N, L * post_nms, R, props, prop_scores, prop_cnt, st));
     eng_mark(e, "proposals");
-
-    // The RoI heads run on the tail stream: their selection kernels are small latency-bound grids, and the next
-    // forward's backbone (main stream) may start underneath them.  Single-stream mode keeps everything on main.
-    if (e.multi_stream) {
-        hipEvent_t ev;
-        HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        HIP_TRY(hipEventRecord(ev, e.stream));
-        HIP_TRY(hipStreamWaitEvent(e.tail, ev, 0));
-        HIP_TRY(hipEventDestroy(ev));
-        e.cur = e.tail;
-    }
 
     // ---- box head
     const float* feats[4] = {P[0].d, P[1].d, P[2].d, P[3].d};
