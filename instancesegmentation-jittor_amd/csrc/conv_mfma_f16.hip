@@ -2,12 +2,11 @@
 // fp32 accumulate.  BASELINE.json configs[4] ("Mask R-CNN R101-FPN ... with fp16 MFMA conv"); SURVEY 8a M2-M11
 // "num. type f32 (f16 cfg5)".
 //
-// Same structure as conv_mfma.hip (one accumulator chain per output, K walked as (r, s, cin), branch-free buffer
-// loads with hardware zero fill for padding, register-staged double-buffered LDS, fused scale/shift/residual/ReLU
-// epilogue) with the byte geometry kept identical: a K-chunk is 64 halfs = 128 B per row, LDS rows are 144 B.
-// The f16 MFMA consumes 8 consecutive k per lane half (lane (r,h) holds k = 8h..8h+7 of a 16-deep step), so the
-// NHWC channel run is used as stored -- no permutation.  Numerics: products are exact in fp32, the 16-term sum
-// inside one MFMA is not an ordered fmaf chain, so parity with the oracle is TOLERANCE-based here (tests state it).
+// One accumulator per output, K walked as (r, s, cin) in 64-half chunks, padding by the buffer range check, fused
+// scale/shift/residual/ReLU epilogue in fp32.  The f16 MFMA consumes 8 consecutive k per lane half (lane (r,h) holds
+// k = 8h..8h+7 of a 16-deep step), so the NHWC channel run is used as stored.  Numerics: products are exact in fp32, the
+// 16-term sum inside one MFMA is not an ordered fmaf chain, so parity with the oracle is TOLERANCE-based here (tests
+// state it).
 #include "../../include/isegmi.h"
 #include "common.h"
 #include "detmath.h"
@@ -18,6 +17,7 @@ typedef _Float16 half_t;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16h __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4h __attribute__((ext_vector_type(4)));
+typedef float f32x4h __attribute__((ext_vector_type(4)));
 
 struct ConvKH {
     const half_t* in;
@@ -29,88 +29,95 @@ struct ConvKH {
     int N, H, W, Cin, Cout, R, S, stride, pad, Ho, Wo, M;
     int nchunks, cin_chunks;
     int64_t wrow;  // halfs per packed cout row
-    unsigned in_bytes, out_bytes, res_bytes;
-    int act, out_div, contiguous, out_f32;
+    unsigned in_bytes, out_bytes, res_bytes, w_bytes;
+    int act, out_div, contiguous, out_f32, vec_epi;
     int64_t out_img_stride, out_pix_stride;
     int mtiles, ntiles;
 };
 
-constexpr int ROWB = 144;  // LDS row bytes: 128 data + 16 pad (conflict-free b128 reads and writes)
+// ---------------------------------------------------------------------------------------------------------------------
+// The A (pixels x 64 halfs) and B (couts x 64 halfs) chunk images are filled by
+// `buffer_load_dwordx4 ... lds` (no VGPR round trip, no ds_write): one wave-instruction moves 8 rows x 128 B = 1 KiB that
+// lands lane-linear in LDS, so rows are unpadded and the bank swizzle is applied on the SOURCE side: LDS slot
+// (row, cs) holds the row's 16-B column c = cs ^ ((row >> 1) & 7); readers fetch column c of row r at slot
+// c ^ ((r >> 1) & 7), which is conflict-free for ds_read_b128's 16-lane groups.  Padding / M tail / Cout tail come
+// from the buffer range check (offset 0x80000000 -> zeros written to LDS).  NSTAGE-deep ring, ONE barrier per chunk:
+//     s_waitcnt vmcnt((NSTAGE-2)*pieces) ; s_barrier ; issue chunk t+NSTAGE-1 ; MFMAs on chunk t
+// (past the last chunk the issue slot sends all-OOB pieces so the counted wait stays uniform).
+// Epilogue: each wave transposes its fp32 strip through LDS and stores / loads the residual 16 B per lane.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256, 2) void conv_mfma_f16_kernel(const ConvKH p) {
-    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-    constexpr int APASS = BM / 64, BPASS = BN / 64;
-    constexpr int STAGEB = (BM + BN) * ROWB;
-    extern __shared__ __attribute__((aligned(16))) char smemh[];
+template <int BM, int BN, int WM, int WN, int NSTAGE, int OCC>
+__global__ __launch_bounds__(WM * WN * 64, OCC) void conv_f16_glds_kernel(const ConvKH p) {
+    constexpr int NW = WM * WN;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int PPA = BM / 8 / NW, PPB = BN / 8 / NW;
+    constexpr int STAGEB = (BM + BN) * 128;
+    static_assert(PPA >= 1 && PPB >= 1 && TM >= 1 && TN >= 1, "tile/wave split");
+    extern __shared__ __attribute__((aligned(1024))) char smemg[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
 
     const int nwg = gridDim.x, bid = blockIdx.x;
-    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int q8 = nwg >> 3, r8g = nwg & 7, xcd = bid & 7;
+    const int logical = (xcd < r8g ? xcd * (q8 + 1) : r8g * (q8 + 1) + (xcd - r8g) * q8) + (bid >> 3);
     const int nt = logical % p.ntiles, mt = logical / p.ntiles;
     const int m0 = mt * BM, n0 = nt * BN;
 
-    const int lrow = tid >> 2, g = tid & 3;  // 4 lanes per row, 32 B (16 halfs) each
-    int hi0[APASS], wi0[APASS], nb[APASS];
+    const int r8 = lane >> 3, cs = lane & 7;
+    int hi0[PPA], wi0[PPA], abase[PPA];
 #pragma unroll
-    for (int j = 0; j < APASS; ++j) {
-        const int m = m0 + lrow + 64 * j;
+    for (int j = 0; j < PPA; ++j) {
+        const int row = (wave + j * NW) * 8 + r8;
+        const int c = cs ^ ((row >> 1) & 7);
+        const int m = m0 + row;
         if (m < p.M) {
             const int hw = p.Ho * p.Wo;
             const int n = m / hw, rem = m - n * hw;
             const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
             hi0[j] = ho * p.stride - p.pad;
             wi0[j] = wo * p.stride - p.pad;
-            nb[j] = n * p.H;
+            abase[j] = (((n * p.H + hi0[j]) * p.W + wi0[j]) * p.Cin) * 2 + c * 16;
         } else {
             hi0[j] = -(1 << 28);
             wi0[j] = 0;
-            nb[j] = 0;
+            abase[j] = 0;
         }
     }
-    const half_t* wsrc = p.w + (int64_t)(n0 + lrow) * p.wrow + g * 16;
+    unsigned bbase[PPB];
+#pragma unroll
+    for (int j = 0; j < PPB; ++j) {
+        const int row = (wave + j * NW) * 8 + r8;
+        const int c = cs ^ ((row >> 1) & 7);
+        bbase[j] = (unsigned)(n0 + row) * (unsigned)(p.wrow * 2) + (unsigned)(c * 16);
+    }
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
-    u32x4h ra[APASS][2], rb[BPASS][2];
-    int kr = 0, ks = 0, kc = 0;
+    int kr = 0, ks = 0, kc = 0, issued = 0, delta = 0;
 
-    auto load_chunk = [&](int chunk) {
-#pragma unroll
-        for (int j = 0; j < APASS; ++j) {
-            const int hi = hi0[j] + kr, wi = wi0[j] + ks;
+    // one 1-KiB piece (i < PPA: A rows, else B rows) of the chunk being issued; `dead` = OOB once past the last chunk
+    auto piece = [&](int i, int stage, unsigned dead) {
+        char* sA = smemg + stage * STAGEB;
+        if (i < PPA) {
+            const int hi = hi0[i] + kr, wi = wi0[i] + ks;
             const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-            const unsigned off = ((unsigned)((nb[j] + hi) * p.W + wi) * (unsigned)p.Cin + (unsigned)(kc * 64 + g * 16)) * 2u;
-            ra[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, ok ? off : OOB, 0, 0);
-            ra[j][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, ok ? off + 16u : OOB, 0, 0);
+            const unsigned off = (ok ? (unsigned)(abase[i] + delta) : OOB) | dead;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(sA + (wave + i * NW) * 1024), 16, off, 0, 0, 0);
+        } else {
+            const int j = i - PPA;
+            const unsigned off = (bbase[j] + (unsigned)issued * 128u) | dead;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(sA + BM * 128 + (wave + j * NW) * 1024), 16, off, 0, 0, 0);
         }
-#pragma unroll
-        for (int j = 0; j < BPASS; ++j) {
-            const half_t* src = wsrc + (int64_t)(64 * j) * p.wrow + chunk * 64;
-            rb[j][0] = *(const u32x4h*)src;
-            rb[j][1] = *(const u32x4h*)(src + 8);
-        }
+    };
+    auto advance = [&]() {
+        ++issued;
         if (++kc == p.cin_chunks) { kc = 0; if (++ks == p.S) { ks = 0; ++kr; } }
+        delta = ((kr * p.W + ks) * p.Cin + kc * 64) * 2;
     };
-    auto store_chunk = [&](int stage) {
-        char* As = smemh + stage * STAGEB;
-        char* Bs = As + BM * ROWB;
-#pragma unroll
-        for (int j = 0; j < APASS; ++j) {
-            char* d = As + (lrow + 64 * j) * ROWB + g * 32;
-            *(u32x4h*)d = ra[j][0];
-            *(u32x4h*)(d + 16) = ra[j][1];
-        }
-#pragma unroll
-        for (int j = 0; j < BPASS; ++j) {
-            char* d = Bs + (lrow + 64 * j) * ROWB + g * 32;
-            *(u32x4h*)d = rb[j][0];
-            *(u32x4h*)(d + 16) = rb[j][1];
-        }
-    };
+    auto deadmask = [&]() -> unsigned { return (unsigned)((p.nchunks - 1 - issued) >> 31) & OOB; };
 
     f32x16h acc[TM][TN];
 #pragma unroll
@@ -121,57 +128,124 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f16_kernel(const ConvKH p) {
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.0f;
 
     const int lr = lane & 31, lh = lane >> 5;
-    const int a_off = (wm * TM * 32 + lr) * ROWB + lh * 16;
-    const int b_off = BM * ROWB + (wn * TN * 32 + lr) * ROWB + lh * 16;
+    const int swz = lr * 128 + ((lh ^ ((lr >> 1) & 7)) << 4);  // k-step s adds ^ (s << 5)
+    const int a_off = wm * TM * 32 * 128;
+    const int b_off = BM * 128 + wn * TN * 32 * 128;
+    constexpr int PP = PPA + PPB;
+    constexpr int ISSUE_STEPS = 4;  // the next chunk's pieces are spread over this chunk's four MFMA steps
 
-    auto compute = [&](int stage) {
-        const char* sb = smemh + stage * STAGEB;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {  // four 16-deep MFMA steps per 64-half chunk
-            f16x8 fa[TM], fb[TN];
+    for (int s = 0; s < NSTAGE - 1; ++s) {
+        const unsigned dead = deadmask();
 #pragma unroll
-            for (int a = 0; a < TM; ++a) fa[a] = *(const f16x8*)(sb + a_off + a * 32 * ROWB + s * 32);
+        for (int i = 0; i < PP; ++i) piece(i, s, dead);
+        advance();
+    }
+    int rd = 0, wr = NSTAGE - 1;
+    for (int t = 0; t < p.nchunks; ++t) {
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NSTAGE - 2) * PP) : "memory");
+        const unsigned dead = deadmask();
+        const char* sb = smemg + rd * STAGEB;
+        f16x8 fa[2][TM], fb[2][TN];
 #pragma unroll
-            for (int b = 0; b < TN; ++b) fb[b] = *(const f16x8*)(sb + b_off + b * 32 * ROWB + s * 32);
+        for (int a = 0; a < TM; ++a) fa[0][a] = *(const f16x8*)(sb + a_off + a * 4096 + swz);
+#pragma unroll
+        for (int b = 0; b < TN; ++b) fb[0][b] = *(const f16x8*)(sb + b_off + b * 4096 + swz);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {  // four 16-deep MFMA steps per chunk; fragments of step s+1 and the next chunk's pieces issue under step s
+            if (s < 3) {
+                const int so = swz ^ ((s + 1) << 5);
+#pragma unroll
+                for (int a = 0; a < TM; ++a) fa[(s + 1) & 1][a] = *(const f16x8*)(sb + a_off + a * 4096 + so);
+#pragma unroll
+                for (int b = 0; b < TN; ++b) fb[(s + 1) & 1][b] = *(const f16x8*)(sb + b_off + b * 4096 + so);
+            }
+#pragma unroll
+            for (int i = 0; i < PP; ++i)
+                if (i * ISSUE_STEPS / PP == s) piece(i, wr, dead);
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
-                for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+                for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s & 1][a], fb[s & 1][b], acc[a][b], 0, 0, 0);
         }
-    };
-
-    load_chunk(0);
-    store_chunk(0);
-    __syncthreads();
-    int cur = 0;
-    for (int t = 0; t + 1 < p.nchunks; ++t) {
-        load_chunk(t + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(cur);
-        __builtin_amdgcn_sched_barrier(0);
-        store_chunk(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
+        advance();
+        rd = rd + 1 == NSTAGE ? 0 : rd + 1;
+        wr = wr + 1 == NSTAGE ? 0 : wr + 1;
     }
-    compute(cur);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // trailing all-OOB pieces have landed; LDS is free
 
     // ---- epilogue (fp32 math): y = fmaf(acc, scale, shift) + residual -> act -> fp16 (or fp32) NHWC store
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? (const void*)p.res : (const void*)p.out), 0, p.res ? p.res_bytes : 0u, 0x00020000);
     const unsigned esz = p.out_f32 ? 4u : 2u;
+    if (p.vec_epi) {
+        constexpr int PITCH = TN * 32 + 4;
+        constexpr int LPR = TN * 4, RPP = 64 / LPR, NPASS = 32 / RPP;
+        float* ew = (float*)smemg + wave * 32 * PITCH;
+        const int er = lane / LPR, ec = (lane % LPR) * 8;
+        const int co8 = n0 + wn * TN * 32 + ec;
+        const bool cok8 = co8 < p.Cout;
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const int co = n0 + (wn * TN + b) * 32 + lr;
+                const bool cok = co < p.Cout;
+                const float sc = (cok && p.scale) ? p.scale[co] : 1.0f;
+                const float sh = (cok && p.shift) ? p.shift[co] : 0.0f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) ew[((e & 3) + 8 * (e >> 2) + 4 * lh) * PITCH + b * 32 + lr] = fmaf(acc[a][b][e], sc, sh);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                const int rr = ps * RPP + er;
+                const int m = m0 + (wm * TM + a) * 32 + rr;
+                const bool ok = m < p.M && cok8;
+                const f32x4h v0 = *(const f32x4h*)(ew + rr * PITCH + ec);
+                const f32x4h v1 = *(const f32x4h*)(ew + rr * PITCH + ec + 4);
+                const unsigned roff = ok ? ((unsigned)m * (unsigned)p.Cout + (unsigned)co8) * 2u : OOB;
+                const u32x4h rraw = __builtin_amdgcn_raw_buffer_load_b128(rs_res, roff, 0, 0);
+                const f16x8 rh = __builtin_bit_cast(f16x8, rraw);
+                unsigned ooff;
+                if (p.contiguous) ooff = ((unsigned)m * (unsigned)p.out_pix_stride + (unsigned)co8) * esz;
+                else {
+                    const int ni = m / p.out_div, pi = m - ni * p.out_div;
+                    ooff = (unsigned)(((int64_t)ni * p.out_img_stride + (int64_t)pi * p.out_pix_stride + co8) * esz);
+                }
+                if (!ok) ooff = OOB;
+                float y[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float t = (i < 4 ? v0[i] : v1[i - 4]) + (float)rh[i];
+                    y[i] = p.act == 1 ? (t > 0.0f ? t : 0.0f) : t;
+                }
+                if (p.out_f32) {
+                    u32x4h o0, o1;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { o0[i] = __builtin_bit_cast(unsigned, y[i]); o1[i] = __builtin_bit_cast(unsigned, y[i + 4]); }
+                    __builtin_amdgcn_raw_buffer_store_b128(o0, rs_out, ooff, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(o1, rs_out, ok ? ooff + 16u : OOB, 0, 0);
+                } else {
+                    f16x8 o;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) o[i] = (half_t)y[i];
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4h, o), rs_out, ooff, 0, 0);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        return;
+    }
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
         unsigned rowoff[16], resoff[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int m = m0 + (wm * TM + a) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-            rowoff[e] = m < p.M ? (unsigned)m * (unsigned)p.out_pix_stride * esz : OOB;
             resoff[e] = m < p.M ? (unsigned)m * (unsigned)p.Cout * 2u : OOB;
-        }
-        if (!p.contiguous) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + (wm * TM + a) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            if (p.contiguous) rowoff[e] = m < p.M ? (unsigned)m * (unsigned)p.out_pix_stride * esz : OOB;
+            else {
                 const int ni = m / p.out_div, pi = m - ni * p.out_div;
                 rowoff[e] = m < p.M ? (unsigned)(((int64_t)ni * p.out_img_stride + (int64_t)pi * p.out_pix_stride) * esz) : OOB;
             }
@@ -183,16 +257,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f16_kernel(const ConvKH p) {
             const float sc = (cok && p.scale) ? p.scale[co] : 1.0f;
             const float sh = (cok && p.shift) ? p.shift[co] : 0.0f;
             const unsigned cooff = cok ? (unsigned)co : OOB;
-            float rv[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const unsigned short hb = __builtin_amdgcn_raw_buffer_load_b16(rs_res, (resoff[e] | cooff) >= OOB ? OOB : resoff[e] + cooff * 2u, 0, 0);
-                rv[e] = (float)__builtin_bit_cast(half_t, hb);
-            }
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
                 float y = fmaf(acc[a][b][e], sc, sh);
-                y = y + rv[e];
+                y = y + (float)__builtin_bit_cast(half_t, hb);
                 y = p.act == 1 ? (y > 0.0f ? y : 0.0f) : y;
                 const unsigned off = (rowoff[e] | cooff) >= OOB ? OOB : rowoff[e] + cooff * esz;
                 if (p.out_f32) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), rs_out, off, 0, 0);
@@ -203,19 +272,22 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f16_kernel(const ConvKH p) {
     }
 }
 
-static int cout_pad_h(int Cout) { return cdiv(Cout, 128) * 128; }
-
-template <int BM, int BN, int WM, int WN>
-static int launch_h(ConvKH& k, hipStream_t st) {
+template <int BM, int BN, int WM, int WN, int NSTAGE, int OCC>
+static int launch_g(ConvKH& k, hipStream_t st) {
     k.mtiles = cdiv(k.M, BM);
     k.ntiles = cdiv(k.Cout, BN);
-    const size_t lds = 2 * (size_t)(BM + BN) * ROWB;
+    constexpr int NW = WM * WN, TN = BN / WN / 32;
+    size_t lds = (size_t)NSTAGE * (BM + BN) * 128;
+    const size_t epi = (size_t)NW * 32 * (TN * 32 + 4) * 4;
+    if (epi > lds) lds = epi;
     static bool attr = false;
-    if (!attr) { HIP_TRY(hipFuncSetAttribute((const void*)conv_mfma_f16_kernel<BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
-    hipLaunchKernelGGL((conv_mfma_f16_kernel<BM, BN, WM, WN>), dim3((unsigned)(k.mtiles * k.ntiles)), dim3(256), lds, st, k);
+    if (!attr) { HIP_TRY(hipFuncSetAttribute((const void*)conv_f16_glds_kernel<BM, BN, WM, WN, NSTAGE, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+    hipLaunchKernelGGL((conv_f16_glds_kernel<BM, BN, WM, WN, NSTAGE, OCC>), dim3((unsigned)(k.mtiles * k.ntiles)), dim3(NW * 64), lds, st, k);
     HIP_TRY(hipGetLastError());
     return ISEGMI_OK;
 }
+
+static int cout_pad_h(int Cout) { return cdiv(Cout, 128) * 128; }
 
 // fp16 conv: in/w/res are fp16; out is fp16, or fp32 when out_f32 (predictor heads feeding fp32 selection kernels)
 int conv2d_f16_launch(const isegmi_conv_desc* d, const void* in, const void* w, const float* scale, const float* shift, const void* res,
@@ -247,10 +319,34 @@ int conv2d_f16_launch(const isegmi_conv_desc* d, const void* in, const void* w, 
     ARG_CHECK(out_extent < (1ll << 31), "conv output span must be < 2 GiB");
     k.out_bytes = (unsigned)out_extent;
     k.res_bytes = (unsigned)((int64_t)k.M * d->Cout * 2);
+    k.w_bytes = (unsigned)((int64_t)cout_pad_h(d->Cout) * k.wrow * 2);
+    const int64_t align_mask = out_f32 ? 3 : 7;
+    k.vec_epi = (d->Cout % 8 == 0 && (k.out_pix_stride & align_mask) == 0 && (k.out_img_stride & align_mask) == 0 && ((uintptr_t)out & 15) == 0 &&
+                 (res == nullptr || ((uintptr_t)res & 15) == 0)) ? 1 : 0;
     int tile = d->tile;
-    if (tile == 0) tile = ((int64_t)cdiv(k.M, 128) * cdiv(d->Cout, 128) >= 512 && d->Cout > 64) ? 1 : 3;
-    if (tile == 1) return launch_h<128, 128, 2, 2>(k, st);
-    return launch_h<64, 64, 2, 2>(k, st);
+    if (tile == 0) {
+        // measured on MI355X (tools/conv_f16_bench.py, profiles/r01_conv_f16_tiles.txt): big tiles win when they fill the 256 CUs
+        // evenly; 64-row tiles otherwise (a 64x64 tile cannot exceed ~1/2 of the MFMA rate: 32 FLOP per L2 byte)
+        auto fill = [](int64_t nb) { return (double)nb / (double)(cdiv((int)nb, 256) * 256); };
+        const int64_t nb1 = (int64_t)cdiv(k.M, 256) * cdiv(d->Cout, 256), nb2 = (int64_t)cdiv(k.M, 256) * cdiv(d->Cout, 128);
+        if (d->Cout <= 64) tile = 4;
+        else if (k.nchunks <= 4) tile = (k.M >= 262144 && d->Cout >= 256) ? 1 : 5;
+        else if (d->Cout >= 192 && nb1 >= 100 && fill(nb1) >= 0.7) tile = 1;
+        else if (nb2 >= 100 && fill(nb2) >= 0.7) tile = 2;
+        else tile = 5;
+    }
+    switch (tile) {
+        case 1: return launch_g<256, 256, 2, 4, 2, 1>(k, st);  // 8 waves, wave tile 128x64
+        case 2: return launch_g<256, 128, 4, 2, 3, 1>(k, st);  // 8 waves, wave tile 64x64, 3-deep ring
+        case 3: return launch_g<128, 128, 2, 2, 2, 2>(k, st);
+        case 4: return launch_g<64, 64, 2, 2, 3, 3>(k, st);
+        case 5: return launch_g<64, 128, 1, 4, 2, 3>(k, st);
+        case 6: return launch_g<64, 256, 1, 4, 2, 2>(k, st);
+        case 7: return launch_g<128, 256, 2, 4, 3, 1>(k, st);
+        case 8: return launch_g<128, 64, 2, 2, 3, 2>(k, st);
+        default: break;
+    }
+    ARG_CHECK(false, "unknown fp16 conv tile");
 }
 
 }  // namespace isegmi

@@ -5,29 +5,25 @@ import numpy as np
 from isegmi import _ffi
 _ffi.set_device(0)
 rng = np.random.default_rng(0)
-shapes = [(2, 200, 336, 256, 256, 3, 1, 1), (2, 100, 168, 256, 256, 3, 1, 1), (2, 200, 336, 64, 256, 1, 1, 0), (2, 50, 84, 1024, 256, 1, 1, 0),
-          (200, 14, 14, 256, 256, 3, 1, 1), (2000, 7, 7, 256, 1024, 7, 1, 0), (8, 200, 336, 256, 256, 3, 1, 1)]
+shapes = [(8, 200, 336, 256, 256, 3, 1, 1), (8, 100, 168, 256, 256, 3, 1, 1), (8, 200, 336, 64, 256, 1, 1, 0), (8, 200, 336, 256, 64, 1, 1, 0),
+          (8, 200, 336, 64, 64, 3, 1, 1), (8, 100, 168, 128, 512, 1, 1, 0), (8, 100, 168, 128, 128, 3, 1, 1),
+          (8, 50, 84, 1024, 256, 1, 1, 0), (8, 50, 84, 256, 256, 3, 1, 1), (8, 50, 84, 256, 1024, 1, 1, 0), (8, 25, 42, 512, 512, 3, 1, 1),
+          (8, 25, 42, 512, 2048, 1, 1, 0), (800, 14, 14, 256, 256, 3, 1, 1), (8000, 7, 7, 256, 1024, 7, 1, 0)]
+TILES = [int(t) for t in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0, 1, 2, 3, 4, 5, 6, 7, 8]
+WITH_RES = len(sys.argv) > 2 and sys.argv[2] == "res"
 for (N, H, W, Cin, Cout, R, st, pad) in shapes:
     x = rng.standard_normal((N, H, W, Cin)).astype(np.float16)
     w = (rng.standard_normal((Cout, R, R, Cin)) * 0.05).astype(np.float32)
     ho, wo = (H + 2 * pad - R) // st + 1, (W + 2 * pad - R) // st + 1
     fl = 2.0 * N * ho * wo * Cout * R * R * Cin
     line = "N%d %dx%d Cin%d Cout%d %dx%d/%d  %.1f GF:" % (N, H, W, Cin, Cout, R, R, st, fl / 1e9)
-    for tile in (1, 3):
+    for tile in TILES:
         d = _ffi.make_conv_desc(N, H, W, Cin, Cout, R, R, st, pad, 1, tile)
-        dx = _ffi.DeviceBuffer.from_numpy(x); dw = _ffi.DeviceBuffer.from_numpy(_ffi.pack_conv_weights_f16(d, w)); do = _ffi.DeviceBuffer((N, ho, wo, Cout), np.float16)
-        run = lambda: _ffi.check(_ffi.lib().isegmi_op_conv2d_f16(C.byref(d), dx.ptr, dw.ptr, None, None, None, do.ptr, 0, None))
+        dx = _ffi.DeviceBuffer.from_numpy(x); dw = _ffi.DeviceBuffer.from_numpy(_ffi.pack_conv_weights_f16(d, w)); do = _ffi.DeviceBuffer((N, ho, wo, Cout), np.float16); dr = _ffi.DeviceBuffer((N, ho, wo, Cout), np.float16)
+        run = lambda: _ffi.check(_ffi.lib().isegmi_op_conv2d_f16(C.byref(d), dx.ptr, dw.ptr, None, None, dr.ptr if WITH_RES else None, do.ptr, 0, None))
         for _ in range(3): run()
         _ffi.sync(); t0 = time.perf_counter()
         for _ in range(20): run()
         _ffi.sync(); dt = (time.perf_counter() - t0) / 20
-        line += "  f16 tile%d %.3f ms %.0f TF/s" % (tile, dt * 1e3, fl / dt / 1e12)
-    x32 = x.astype(np.float32)
-    d = _ffi.make_conv_desc(N, H, W, Cin, Cout, R, R, st, pad, 1, 0)
-    dx = _ffi.DeviceBuffer.from_numpy(x32); dw = _ffi.DeviceBuffer.from_numpy(_ffi.pack_conv_weights(d, w)); do = _ffi.DeviceBuffer((N, ho, wo, Cout))
-    run = lambda: _ffi.op_conv2d(d, dx, dw, None, None, None, do)
-    for _ in range(3): run()
-    _ffi.sync(); t0 = time.perf_counter()
-    for _ in range(10): run()
-    _ffi.sync(); dt = (time.perf_counter() - t0) / 10
-    print(line + "  | f32 %.3f ms %.0f TF/s" % (dt * 1e3, fl / dt / 1e12), flush=True)
+        line += "  t%d %.3f ms %.0f" % (tile, dt * 1e3, fl / dt / 1e12)
+    print(line, flush=True)
