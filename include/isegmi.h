@@ -68,13 +68,17 @@ int isegmi_op_conv2d(const isegmi_conv_desc* d, const float* d_in, const float* 
                      float* d_out, void* stream);
 
 /* fp16 variant (BASELINE configs[4]: "fp16 MFMA conv"): fp16 storage, v_mfma_f32_32x32x16_f16, fp32 accumulate
- * and epilogue.  Cin % 64 == 0; act none/relu; d_in / d_wpacked / d_residual are fp16, d_out fp16 or (out_f32)
+ * and epilogue.  Cin % 64 == 0 (or the stem, below); act none/relu; d_in / d_wpacked / d_residual are fp16, d_out fp16 or (out_f32)
  * fp32.  The 16-term sum inside one MFMA is not an ordered chain: parity with the oracle is tolerance-based. */
 int isegmi_conv_packed_halfs(const isegmi_conv_desc* d, int64_t* n);
 int isegmi_pack_conv_weights_f16(const isegmi_conv_desc* d, const float* h_w_krsc, uint16_t* h_packed);
 int isegmi_op_conv2d_f16(const isegmi_conv_desc* d, const void* d_in, const void* d_wpacked,
                          const float* d_scale, const float* d_shift, const void* d_residual, void* d_out,
                          int out_f32, void* stream);
+/* fp16 stem (M2 `StemWithFixedBatchNorm` conv1 under configs[4]): desc Cin=4 R=S=7 stride=2 pad=3 with H, W the image
+ * size; d_in of isegmi_op_conv2d_f16 is then the haloed fp16 image [N][H+6][(W+7)&~1][4] this op writes from the fp32
+ * NHWC C=3 batch (3 zero pixels on every side, zero 4th channel); weights are given as [Cout][7][7][4]. */
+int isegmi_op_pad_c3_to_f16_halo(const float* d_in_nhwc3, int N, int H, int W, void* d_out, void* stream);
 
 /* max_pool2d(k,s,p), -inf padding (M2/Y2 stem; k=1,s=2 = LastLevelMaxPool M3) */
 int isegmi_op_maxpool(const float* d_in, int N, int H, int W, int C, int k, int s, int p,

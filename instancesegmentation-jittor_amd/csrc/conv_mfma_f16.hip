@@ -47,7 +47,7 @@ struct ConvKH {
 // Epilogue: each wave transposes its fp32 strip through LDS and stores / loads the residual 16 B per lane.
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-template <int BM, int BN, int WM, int WN, int NSTAGE, int OCC>
+template <int BM, int BN, int WM, int WN, int NSTAGE, int OCC, bool STEM>
 __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_f16_glds_kernel(const ConvKH p) {
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -77,9 +77,15 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_f16_glds_kernel(const 
             const int hw = p.Ho * p.Wo;
             const int n = m / hw, rem = m - n * hw;
             const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-            hi0[j] = ho * p.stride - p.pad;
-            wi0[j] = wo * p.stride - p.pad;
-            abase[j] = (((n * p.H + hi0[j]) * p.W + wi0[j]) * p.Cin) * 2 + c * 16;
+            if (STEM) {  // haloed 4-channel image: chunk j = filter rows 2j, 2j+1; a row's 8 px x 4 ch = 64 B (see conv2d_f16_launch)
+                hi0[j] = 0;
+                wi0[j] = 0;
+                abase[j] = ((n * p.H + 2 * ho + (c >> 2)) * p.W + 2 * wo + 2 * (c & 3)) * 8;
+            } else {
+                hi0[j] = ho * p.stride - p.pad;
+                wi0[j] = wo * p.stride - p.pad;
+                abase[j] = (((n * p.H + hi0[j]) * p.W + wi0[j]) * p.Cin) * 2 + c * 16;
+            }
         } else {
             hi0[j] = -(1 << 28);
             wi0[j] = 0;
@@ -103,7 +109,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_f16_glds_kernel(const 
         char* sA = smemg + stage * STAGEB;
         if (i < PPA) {
             const int hi = hi0[i] + kr, wi = wi0[i] + ks;
-            const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            const bool ok = STEM ? hi0[i] == 0 : ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W);
             const unsigned off = (ok ? (unsigned)(abase[i] + delta) : OOB) | dead;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(sA + (wave + i * NW) * 1024), 16, off, 0, 0, 0);
         } else {
@@ -114,6 +120,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_f16_glds_kernel(const 
     };
     auto advance = [&]() {
         ++issued;
+        if (STEM) { delta = issued * 2 * p.W * 8; return; }
         if (++kc == p.cin_chunks) { kc = 0; if (++ks == p.S) { ks = 0; ++kr; } }
         delta = ((kr * p.W + ks) * p.Cin + kc * 64) * 2;
     };
@@ -272,7 +279,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_f16_glds_kernel(const 
     }
 }
 
-template <int BM, int BN, int WM, int WN, int NSTAGE, int OCC>
+template <int BM, int BN, int WM, int WN, int NSTAGE, int OCC, bool STEM = false>
 static int launch_g(ConvKH& k, hipStream_t st) {
     k.mtiles = cdiv(k.M, BM);
     k.ntiles = cdiv(k.Cout, BN);
@@ -281,19 +288,22 @@ static int launch_g(ConvKH& k, hipStream_t st) {
     const size_t epi = (size_t)NW * 32 * (TN * 32 + 4) * 4;
     if (epi > lds) lds = epi;
     static bool attr = false;
-    if (!attr) { HIP_TRY(hipFuncSetAttribute((const void*)conv_f16_glds_kernel<BM, BN, WM, WN, NSTAGE, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
-    hipLaunchKernelGGL((conv_f16_glds_kernel<BM, BN, WM, WN, NSTAGE, OCC>), dim3((unsigned)(k.mtiles * k.ntiles)), dim3(NW * 64), lds, st, k);
+    if (!attr) { HIP_TRY(hipFuncSetAttribute((const void*)conv_f16_glds_kernel<BM, BN, WM, WN, NSTAGE, OCC, STEM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+    hipLaunchKernelGGL((conv_f16_glds_kernel<BM, BN, WM, WN, NSTAGE, OCC, STEM>), dim3((unsigned)(k.mtiles * k.ntiles)), dim3(NW * 64), lds, st, k);
     HIP_TRY(hipGetLastError());
     return ISEGMI_OK;
 }
 
 static int cout_pad_h(int Cout) { return cdiv(Cout, 128) * 128; }
+static bool is_stem_h(const isegmi_conv_desc* d) { return d->Cin == 4 && d->R == 7 && d->S == 7; }
 
 // fp16 conv: in/w/res are fp16; out is fp16, or fp32 when out_f32 (predictor heads feeding fp32 selection kernels)
 int conv2d_f16_launch(const isegmi_conv_desc* d, const void* in, const void* w, const float* scale, const float* shift, const void* res,
                       void* out, int out_f32, hipStream_t st) {
     ARG_CHECK(d && in && w && out, "null");
-    ARG_CHECK(d->Cin > 0 && d->Cin % 64 == 0, "fp16 conv needs Cin % 64 == 0");
+    const bool stem = is_stem_h(d);
+    ARG_CHECK(stem || (d->Cin > 0 && d->Cin % 64 == 0), "fp16 conv needs Cin % 64 == 0 (or the 7x7/2 Cin=4 stem)");
+    ARG_CHECK(!stem || (d->stride == 2 && d->pad == 3 && res == nullptr), "fp16 stem is 7x7 stride 2 pad 3, no residual");
     ARG_CHECK(d->act == 0 || d->act == 1, "fp16 conv supports act none/relu");
     ConvKH k;
     k.in = (const half_t*)in; k.w = (const half_t*)w; k.scale = scale; k.shift = shift; k.res = (const half_t*)res; k.out = out;
@@ -303,10 +313,14 @@ int conv2d_f16_launch(const isegmi_conv_desc* d, const void* in, const void* w, 
     const int64_t M64 = (int64_t)d->N * k.Ho * k.Wo;
     ARG_CHECK(M64 < (1ll << 31) - 256, "too many output pixels");
     k.M = (int)M64;
-    k.cin_chunks = d->Cin / 64;
-    k.nchunks = d->R * d->S * k.cin_chunks;
+    k.cin_chunks = stem ? 1 : d->Cin / 64;
+    k.nchunks = stem ? 4 : d->R * d->S * k.cin_chunks;
     k.wrow = (int64_t)k.nchunks * 64;
-    const int64_t in_bytes = (int64_t)d->N * d->H * d->W * d->Cin * 2;
+    // stem: `in` is the haloed image [N][H+6][(W+7)&~1][4] written by pad_c3_to_f16_halo (3 zero pixels on every side), so a
+    // filter row's taps wi0..wi0+7 of an output pixel are one aligned 64-B run and need no bounds test; K is laid out as
+    // 8 rows x 8 taps x 4 channels = 256 with zero weights at tap 7 / row 7 / channel 3 (4 chunks of two filter rows).
+    if (stem) { k.H = d->H + 6; k.W = (d->W + 7) & ~1; }
+    const int64_t in_bytes = stem ? (int64_t)d->N * k.H * k.W * 8 : (int64_t)d->N * d->H * d->W * d->Cin * 2;
     ARG_CHECK(in_bytes < (1ll << 31), "conv input must be < 2 GiB");
     k.in_bytes = (unsigned)in_bytes;
     k.act = d->act; k.out_f32 = out_f32;
@@ -324,6 +338,10 @@ int conv2d_f16_launch(const isegmi_conv_desc* d, const void* in, const void* w, 
     k.vec_epi = (d->Cout % 8 == 0 && (k.out_pix_stride & align_mask) == 0 && (k.out_img_stride & align_mask) == 0 && ((uintptr_t)out & 15) == 0 &&
                  (res == nullptr || ((uintptr_t)res & 15) == 0)) ? 1 : 0;
     int tile = d->tile;
+    if (stem) {
+        if (tile == 8) return launch_g<128, 64, 2, 2, 3, 2, true>(k, st);
+        return launch_g<64, 64, 2, 2, 3, 3, true>(k, st);
+    }
     if (tile == 0) {
         // measured on MI355X (tools/conv_f16_bench.py, profiles/r01_conv_f16_tiles.txt): big tiles win when they fill the 256 CUs
         // evenly; 64-row tiles otherwise (a 64x64 tile cannot exceed ~1/2 of the MFMA rate: 32 FLOP per L2 byte)
@@ -354,14 +372,26 @@ int conv2d_f16_launch(const isegmi_conv_desc* d, const void* in, const void* w, 
 using namespace isegmi;
 
 extern "C" int isegmi_conv_packed_halfs(const isegmi_conv_desc* d, int64_t* n) {
-    ARG_CHECK(d && n && d->Cin % 64 == 0 && d->Cin > 0, "fp16 pack needs Cin % 64 == 0");
-    *n = (int64_t)cout_pad_h(d->Cout) * d->R * d->S * d->Cin;
+    ARG_CHECK(d && n && d->Cin > 0 && (d->Cin % 64 == 0 || is_stem_h(d)), "fp16 pack needs Cin % 64 == 0 (or the stem)");
+    *n = is_stem_h(d) ? (int64_t)cout_pad_h(d->Cout) * 256 : (int64_t)cout_pad_h(d->Cout) * d->R * d->S * d->Cin;
     return ISEGMI_OK;
 }
 
 // host: natural fp32 [Cout][R][S][Cin] -> fp16 [Cout padded to 128][R*S*Cin] (round to nearest even)
 extern "C" int isegmi_pack_conv_weights_f16(const isegmi_conv_desc* d, const float* w, uint16_t* packed) {
-    ARG_CHECK(d && w && packed && d->Cin % 64 == 0 && d->Cin > 0, "fp16 pack needs Cin % 64 == 0");
+    ARG_CHECK(d && w && packed && d->Cin > 0 && (d->Cin % 64 == 0 || is_stem_h(d)), "fp16 pack needs Cin % 64 == 0 (or the stem)");
+    if (is_stem_h(d)) {  // [Cout][7][7][4] -> [Cout padded][8 rows][8 taps][4 ch], zero at row 7 / tap 7
+        const int64_t total = (int64_t)cout_pad_h(d->Cout) * 256;
+        for (int64_t i = 0; i < total; ++i) packed[i] = 0;
+        for (int co = 0; co < d->Cout; ++co)
+            for (int r = 0; r < 7; ++r)
+                for (int t = 0; t < 7; ++t)
+                    for (int c = 0; c < 4; ++c) {
+                        const half_t h = (half_t)w[(((int64_t)co * 7 + r) * 7 + t) * 4 + c];
+                        packed[(int64_t)co * 256 + r * 32 + t * 4 + c] = __builtin_bit_cast(uint16_t, h);
+                    }
+        return ISEGMI_OK;
+    }
     const int64_t K = (int64_t)d->R * d->S * d->Cin;
     const int64_t total = (int64_t)cout_pad_h(d->Cout) * K;
     for (int64_t i = 0; i < total; ++i) packed[i] = 0;

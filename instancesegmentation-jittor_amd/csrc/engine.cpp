@@ -96,6 +96,21 @@ int eng_conv(Engine& e, const std::string& layer, const Tensor& in, int stride, 
     return timed_conv(e, layer, &d, in.d, L, residual ? residual->d : nullptr, out->d, out_f32);
 }
 
+// fp16 stem: `halo` is the [N][H+6][(W+7)&~1][4] fp16 image of pad_c3_to_f16_halo; H, W the image size
+int eng_conv_stem_f16(Engine& e, const std::string& layer, const Tensor& halo, int H, int W, const std::string& out_name, Tensor* out) {
+    const ConvLayer* L;
+    int rc = find_conv(e, layer, &L);
+    if (rc) return rc;
+    if (!L->f16 || L->Cin != 4 || L->R != 7 || L->S != 7 || halo.dt != 1) { set_error("conv " + layer + ": not an fp16 stem"); return ISEGMI_ERR_STATE; }
+    const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+    rc = eng_act(e, out_name, halo.N, Ho, Wo, L->Cout, out, 1);
+    if (rc) return rc;
+    isegmi_conv_desc d;
+    memset(&d, 0, sizeof(d));
+    d.N = halo.N; d.H = H; d.W = W; d.Cin = 4; d.Cout = L->Cout; d.R = 7; d.S = 7; d.stride = 2; d.pad = 3; d.act = 1;
+    return timed_conv(e, layer, &d, halo.d, L, nullptr, out->d, false);
+}
+
 static int next_event(Engine& e, hipEvent_t* ev) {
     if (e.ev_pool.empty()) {
         e.ev_pool.resize(128);
@@ -413,7 +428,7 @@ extern "C" int isegmi_engine_set_conv(isegmi_engine* h, const char* name, int Co
     isegmi_conv_desc d;
     memset(&d, 0, sizeof(d));
     d.N = 1; d.H = R; d.W = S; d.Cin = Cin; d.Cout = Cout; d.R = R; d.S = S; d.stride = 1; d.pad = 0;
-    const bool f16 = h->e.fp16 && Cin % 64 == 0;  // the Cin=4 stem stays on the fp32 kernel
+    const bool f16 = h->e.fp16 && (Cin % 64 == 0 || (Cin == 4 && R == 7 && S == 7));
     ConvLayer& L = h->e.convs[name];
     if (L.d_w) { (void)hipFree(L.d_w); L.d_w = nullptr; }
     if (L.d_scale) { (void)hipFree(L.d_scale); L.d_scale = nullptr; }

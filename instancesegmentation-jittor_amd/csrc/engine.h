@@ -84,6 +84,7 @@ int eng_act(Engine& e, const std::string& name, int N, int H, int W, int C, Tens
 int eng_conv(Engine& e, const std::string& layer, const Tensor& in, int stride, int pad, int act, const Tensor* residual,
              const std::string& out_name, Tensor* out, bool out_f32 = false);
 // conv writing into a caller-provided strided destination (heads -> concatenated buffers, deconv parities)
+int eng_conv_stem_f16(Engine& e, const std::string& layer, const Tensor& halo, int H, int W, const std::string& out_name, Tensor* out);
 int eng_conv_into(Engine& e, const std::string& layer, const Tensor& in, int stride, int pad, int act, void* dst, int out_div,
                   int64_t out_img_stride, int64_t out_pix_stride, bool out_f32 = false);
 void eng_mark(Engine& e, const char* name);
@@ -108,6 +109,7 @@ int conv2d_launch(const isegmi_conv_desc* d, const float* in, const float* w, co
                   const float* res, float* out, hipStream_t st);
 int conv2d_f16_launch(const isegmi_conv_desc* d, const void* in, const void* w, const float* scale, const float* shift, const void* res,
                       void* out, int out_f32, hipStream_t st);
+int pad_c3_to_f16_halo_launch(const float* in, int N, int H, int W, void* out, hipStream_t st);
 int maxpool_to_f16_launch(const void* in, int in_f16, int N, int H, int W, int C, int k, int s, int p, void* out, hipStream_t st);
 int nearest2x_add_f16_launch(const void* coarse, int N, int Hc, int Wc, int C, const void* lat, int H, int W, void* out, hipStream_t st);
 int roi_align_f16_launch(const void* const* feats, const int* Hs, const int* Ws, const float* scales, int nlevels, const float* rois,

@@ -163,6 +163,28 @@ static inline unsigned gridf(int64_t total) {
     return (unsigned)b;
 }
 
+// fp32 NHWC C=3 image -> fp16 [N][H+6][(W+7)&~1][4] with a 3-pixel zero halo (and zero 4th channel): the fp16 stem's input
+__global__ void pad_c3_to_f16_halo_kernel(const float* __restrict__ in, int N, int H, int W, int Hp, int Wp, half_t* __restrict__ out) {
+    const int64_t total = (int64_t)N * Hp * Wp;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % Wp) - 3;
+        const int64_t t = i / Wp;
+        const int y = (int)(t % Hp) - 3, n = (int)(t / Hp);
+        h4 v = {(half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f};
+        if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
+            const float* s = in + (((int64_t)n * H + y) * W + x) * 3;
+            v[0] = (half_t)s[0]; v[1] = (half_t)s[1]; v[2] = (half_t)s[2];
+        }
+        *(h4*)(out + i * 4) = v;
+    }
+}
+int pad_c3_to_f16_halo_launch(const float* in, int N, int H, int W, void* out, hipStream_t st) {
+    const int Hp = H + 6, Wp = (W + 7) & ~1;
+    hipLaunchKernelGGL(pad_c3_to_f16_halo_kernel, dim3(gridf((int64_t)N * Hp * Wp)), dim3(256), 0, st, in, N, H, W, Hp, Wp, (half_t*)out);
+    HIP_TRY(hipGetLastError());
+    return ISEGMI_OK;
+}
+
 int maxpool_to_f16_launch(const void* in, int in_f16, int N, int H, int W, int C, int k, int s, int p, void* out, hipStream_t st) {
     ARG_CHECK(C % 4 == 0, "C % 4");
     const int Ho = (H + 2 * p - k) / s + 1, Wo = (W + 2 * p - k) / s + 1;
@@ -202,3 +224,7 @@ int mask_logits_select_f16_launch(const void* feat, int R, int HW, int C, const 
 }
 
 }  // namespace isegmi
+extern "C" int isegmi_op_pad_c3_to_f16_halo(const float* d_in_nhwc3, int N, int H, int W, void* d_out, void* stream) {
+    ARG_CHECK(d_in_nhwc3 && d_out && N > 0 && H > 0 && W > 0, "args");
+    return isegmi::pad_c3_to_f16_halo_launch(d_in_nhwc3, N, H, W, d_out, (hipStream_t)stream);
+}

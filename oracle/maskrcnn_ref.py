@@ -52,8 +52,8 @@ def grid_anchors(gh, gw, stride, cell):
 class MaskRCNNRef:
     def __init__(self, sd, depth=50, pre_nms=1000, post_nms=1000, fpn_post=1000, det_per_img=100, nms_ge=0, fp16=False):
         self.sd, self.depth = sd, depth
-        # fp16=True emulates the product's fp16-storage path (BASELINE configs[4]): conv weights and every stored
-        # activation after the stem are rounded to fp16, all arithmetic stays fp32 (ordered fmaf chain).
+        # fp16=True emulates the product's fp16-storage path (BASELINE configs[4]): conv weights, the input image and every
+        # stored activation are rounded to fp16, all arithmetic stays fp32 (ordered fmaf chain).
         self.fp16 = fp16
         self.pre_nms, self.post_nms, self.fpn_post, self.dpi, self.ge = pre_nms, post_nms, fpn_post, det_per_img, nms_ge
         self.feats = {}
@@ -77,7 +77,7 @@ class MaskRCNNRef:
         w1 = _krsc(sd["backbone.body.stem.conv1.weight"])
         w1 = np.concatenate([w1, np.zeros(w1.shape[:3] + (1,), np.float32)], -1)
         sc, sh = _frozen_bn(sd, "backbone.body.stem.bn1")
-        x = self._h(ora.maxpool(ora.conv2d(x4, w1, 2, 3, sc, sh, None, 1), 3, 2, 1))  # fp32 stem, fp16 trunk
+        x = ora.maxpool(self._h(ora.conv2d(self._h(x4), self._h(w1), 2, 3, sc, sh, None, 1)), 3, 2, 1)  # fp16 mode: image, weights, stem output rounded
         Cs = []
         for li, nb in enumerate((3, 4, 23 if self.depth == 101 else 6, 3), 1):
             for b in range(nb):

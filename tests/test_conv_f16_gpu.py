@@ -33,3 +33,27 @@ def test_conv_f16_close_to_oracle(ffi, case, tile):
             d = np.abs(got.astype(np.float32) - ref16.astype(np.float32))
             assert np.all(d <= np.abs(ref16.astype(np.float32)) * 2.0 ** -10 + 1e-3)
             assert np.mean(got == ref16) >= 0.99
+
+
+@pytest.mark.parametrize("tile", [0, 8])
+@pytest.mark.parametrize("shape", [(2, 50, 70), (1, 37, 45), (1, 64, 33)])
+def test_stem_f16_close_to_oracle(ffi, shape, tile):
+    """fp16 stem: haloed fp16 image (exact) + 7x7/2 conv on the 8x8x4 zero-extended filter; same tolerance as above."""
+    N, H, W = shape
+    rng = np.random.default_rng(H * 1000 + W)
+    x = rng.uniform(-120.0, 130.0, (N, H, W, 3)).astype(np.float32)
+    w = (rng.standard_normal((64, 7, 7, 4)) * (2.0 / 147.0) ** 0.5).astype(np.float16).astype(np.float32)
+    w[..., 3] = 0.0
+    sc = rng.uniform(0.5, 1.5, 64).astype(np.float32); sh = (rng.standard_normal(64) * 0.1).astype(np.float32)
+    got, halo = ffi.stem_f16(x, w, sc, sh, tile)
+    x16 = x.astype(np.float16)
+    assert halo.shape == (N, H + 6, (W + 7) & ~1, 4)
+    assert np.array_equal(halo[:, 3:3 + H, 3:3 + W, :3], x16)
+    mask = np.ones(halo.shape, bool); mask[:, 3:3 + H, 3:3 + W, :3] = False
+    assert not halo[mask].any()
+    x4 = np.concatenate([x16.astype(np.float32), np.zeros((N, H, W, 1), np.float32)], -1)
+    ref16 = ora.conv2d(x4, w, 2, 3, sc, sh, None, 1).astype(np.float16)
+    assert got.shape == ref16.shape
+    d = np.abs(got.astype(np.float32) - ref16.astype(np.float32))
+    assert np.all(d <= np.abs(ref16.astype(np.float32)) * 2.0 ** -10 + 1e-3)
+    assert np.mean(got == ref16) >= 0.99
