@@ -197,7 +197,7 @@ int yolact_forward(Engine& e, const float* d_images, int N) {
         TRY(maxpool_launch(s.d, N, s.H, s.W, s.C, 3, 2, 1, x.d, e.cur));
     }
     eng_mark(e, "stem");
-    const int blocks[4] = {3, 4, 6, 3};
+    const int blocks[4] = {3, 4, (int)e.param("resnet_depth", 50) == 101 ? 23 : 6, 3};
     Tensor outs[4];
     for (int li = 0; li < 4; ++li) {
         for (int b = 0; b < blocks[li]; ++b) {

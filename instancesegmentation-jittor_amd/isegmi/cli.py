@@ -30,7 +30,7 @@ def _save_image_bgr(path, img):
 def _weights(spec, kind, depth=50):
     from .weights import maskrcnn_state_dict, yolact_state_dict
     if spec in ("", "random", None):
-        return yolact_state_dict(1234) if kind == "yolact" else maskrcnn_state_dict(1234, depth)
+        return yolact_state_dict(1234, depth) if kind == "yolact" else maskrcnn_state_dict(1234, depth)
     if not spec.endswith(".npz"):
         raise SystemExit("%s: convert upstream .pth/.pkl with tools/import_pth.py first" % spec)
     return dict(np.load(spec))
@@ -54,8 +54,10 @@ def cmd_eval(a):
     """Yolact eval.py: evalimage / evalimages (+ Detections.dump when --output_coco_json is given)."""
     from .coco import dump, yolact_results
     from .transforms import yolact_transform
-    from .yolact import Yolact, postprocess
-    net = Yolact(_weights(a.trained_model, "yolact"), max_batch=1)
+    from .yolact import Yolact, YolactConfig, postprocess
+    # upstream eval.py --config: yolact_resnet50_config (default here), yolact_base_config (R101), yolact_im700_config
+    cfg = {"yolact_resnet50_config": YolactConfig(), "yolact_base_config": YolactConfig.base(), "yolact_im700_config": YolactConfig.im700()}[a.config]
+    net = Yolact(_weights(a.trained_model, "yolact", cfg.depth), cfg, max_batch=1)
     jobs = []
     if a.image:
         src, _, dst = a.image.partition(":")
@@ -118,6 +120,7 @@ def main(argv=None):
     sub = ap.add_subparsers(dest="cmd", required=True)
     e = sub.add_parser("eval", help="Yolact eval.py-style image evaluation")
     e.add_argument("--trained_model", default="random")
+    e.add_argument("--config", default="yolact_resnet50_config", choices=["yolact_resnet50_config", "yolact_base_config", "yolact_im700_config"])
     e.add_argument("--score_threshold", type=float, default=0.0)
     e.add_argument("--top_k", type=int, default=5)
     e.add_argument("--image", default=None, help="in.png[:out.png]")

@@ -53,10 +53,11 @@ YOLACT_MASK_GAIN = 0.04
 YOLACT_PROTO_GAIN = 0.06
 
 
-def yolact_state_dict(seed=1234):
+def yolact_state_dict(seed=1234, depth=50):
+    """dbolya/yolact state-dict names; depth 50 = yolact_resnet50, 101 = yolact_base / yolact_im700."""
     rng = np.random.default_rng(seed)
     sd = {}
-    resnet_state_dict(rng, sd, "backbone.")
+    resnet_state_dict(rng, sd, "backbone.", blocks=(3, 4, 23 if depth == 101 else 6, 3))
     for i, cin in enumerate((2048, 1024, 512)):
         _conv_bias(rng, sd, "fpn.lat_layers.%d" % i, 256, cin, 1)
     for i in range(3):

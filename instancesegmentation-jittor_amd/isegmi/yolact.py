@@ -31,6 +31,17 @@ class YolactConfig:
     nms_thresh: float = 0.5
     nms_top_k: int = 200
     max_num_detections: int = 100
+    depth: int = 50  # 50 = yolact_resnet50_config, 101 = yolact_base_config / yolact_im700_config
+
+    @staticmethod
+    def base():
+        """yolact_base_config: ResNet101-FPN at 550."""
+        return YolactConfig(depth=101)
+
+    @staticmethod
+    def im700():
+        """yolact_im700_config: ResNet101-FPN at 700, pred_scales = int(s / 550 * 700)."""
+        return YolactConfig(max_size=700, pred_scales=tuple(int(s / 550 * 700) for s in (24, 48, 96, 192, 384)), depth=101)
 
 
 def make_priors(conv_h, conv_w, scale, max_size, ars):
@@ -78,6 +89,7 @@ class Yolact:
         _ffi.set_device(device)
         self._h = C.c_void_p()
         _ffi.check(L.isegmi_engine_create(self.KIND, max_batch, self.size, self.size, C.byref(self._h)))
+        self.set_param("resnet_depth", float(cfg.depth))
         self._load(state_dict)
         for k in ("nms_conf_thresh", "nms_thresh", "nms_top_k", "max_num_detections"):
             self.set_param(k, float(getattr(cfg, k)))
@@ -97,7 +109,7 @@ class Yolact:
     def _load(self, sd):
         sc, sh = fold_batchnorm(sd, "backbone.bn1")
         self._set_conv("backbone.conv1", sd["backbone.conv1.weight"], sc, sh, pad_cin_to=4)
-        for li, nb in enumerate((3, 4, 6, 3)):
+        for li, nb in enumerate((3, 4, 23 if self.cfg.depth == 101 else 6, 3)):
             for b in range(nb):
                 nm = "backbone.layers.%d.%d" % (li, b)
                 for i in (1, 2, 3):

@@ -41,9 +41,11 @@ def make_priors(conv_h, conv_w, scale, max_size, ars=(1.0, 0.5, 2.0)):
 
 
 class YolactRef:
-    def __init__(self, sd, max_size=550):
+    def __init__(self, sd, max_size=550, scales=(24, 48, 96, 192, 384), depth=50):
         self.sd = sd
         self.max_size = max_size
+        self.scales = tuple(scales)
+        self.depth = depth
         self.feats = {}
 
     def _conv_bn(self, x, name, bn, stride, pad, act, residual=None):
@@ -63,7 +65,7 @@ class YolactRef:
         x = ora.conv2d(x4, w1, 2, 3, sc, sh, None, 1)
         x = ora.maxpool(x, 3, 2, 1)
         outs = []
-        for li, nb in enumerate((3, 4, 6, 3)):
+        for li, nb in enumerate((3, 4, 23 if self.depth == 101 else 6, 3)):
             for b in range(nb):
                 nm = "backbone.layers.%d.%d" % (li, b)
                 st = 2 if (b == 0 and li > 0) else 1
@@ -93,7 +95,7 @@ class YolactRef:
         t = self._conv_b(t, "proto_net.8", 1, 1, 1)
         proto = self._conv_b(t, "proto_net.10", 1, 0, 1)
         locs, confs, masks, priors = [], [], [], []
-        scales = (24, 48, 96, 192, 384)
+        scales = self.scales
         for l, p in enumerate(P):
             u = self._conv_b(p, "prediction_layers.0.upfeature.0", 1, 1, 1)
             locs.append(self._conv_b(u, "prediction_layers.0.bbox_layer", 1, 1, 0).reshape(N, -1, 4))

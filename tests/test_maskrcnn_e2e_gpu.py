@@ -173,3 +173,24 @@ def test_maskrcnn_back_to_back_forwards(ffi, sd):
         else:
             assert np.array_equal(got, clean[k]), k
     model.close()
+
+
+def test_maskrcnn_smooth_images_bit_exact(ffi, sd):
+    """Second input suite: smooth low-frequency fields -> clustered proposals, NMS with heavy overlap."""
+    from conftest import smooth_field
+    from isegmi.maskrcnn import MaskRCNN, prepare_images
+    x, hw = prepare_images([smooth_field(41, 224, 288), smooth_field(42, 200, 300)])
+    model = MaskRCNN(sd, x.shape[1], x.shape[2], max_batch=2)
+    out = model(x, hw)
+    ref = MaskRCNNRef(sd)
+    rd = ref.forward(x, hw)
+    pc = model.fetch("proposal_count", 2); pr = model.fetch("proposals", 2)
+    for n in range(2):
+        r = rd[n]
+        assert pc[n] == len(r["proposals"]) and np.array_equal(pr[n, : pc[n]], r["proposals"])
+        bl = out[n]
+        assert len(bl) == len(r["score"])
+        assert np.array_equal(bl.get_field("labels"), r["label"].astype(np.int64))
+        assert np.array_equal(bl.get_field("scores"), r["score"]) and np.array_equal(bl.bbox, r["box"])
+        assert np.array_equal(bl.get_field("mask")[:, 0], r["mask28"])
+    model.close()

@@ -120,3 +120,36 @@ def test_back_to_back_forwards_are_independent(ffi, sd):
             assert np.array_equal(got, v), k
     assert not np.array_equal(clean["a"]["det.score"], clean["b"]["det.score"])
     net.close()
+
+
+def test_yolact_base_and_im700_configs_bit_exact(ffi):
+    """yolact_base (ResNet101-FPN) and yolact_im700 (R101, 700 px, scales int(s/550*700)).
+    Small input for the R101/700-config pair (oracle time), then the full 700x700 image."""
+    from isegmi.weights import yolact_state_dict
+    from isegmi.yolact import Yolact, YolactConfig, postprocess
+    sd101 = yolact_state_dict(1234, depth=101)
+    cfg = YolactConfig.im700()
+    assert cfg.pred_scales == (30, 61, 122, 244, 488) and cfg.max_size == 700 and cfg.depth == 101
+    net = Yolact(sd101, cfg, max_batch=1, input_size=200)
+    ref = YolactRef(sd101, max_size=700, scales=cfg.pred_scales, depth=101)
+    _compare(net, ref, _images(3, 1, 200), 200, 1)
+    net.close()
+    net = Yolact(sd101, cfg, max_batch=1)
+    assert net.size == 700 and net.priors.shape == (30963, 4)
+    x = _images(4, 1, 700)
+    out, refd, total = _compare(net, ref, x, 700, 1)
+    cls, sc, boxes, masks = postprocess(out, 640, 480)
+    rc, rs, rb, rm = YolactRef.postprocess(refd[0], 640, 480)
+    assert np.array_equal(cls, rc) and np.array_equal(sc, rs) and np.array_equal(boxes, rb) and np.array_equal(masks, rm)
+    net.close()
+
+
+def test_yolact_smooth_images_bit_exact(ffi, sd):
+    """Second input suite: smooth low-frequency fields -> clustered boxes, heavy fast-NMS suppression."""
+    from conftest import smooth_field
+    from isegmi.yolact import Yolact, fast_base_transform
+    size = 200
+    x = fast_base_transform(np.stack([smooth_field(31 + i, size, size) for i in range(2)]))
+    net = Yolact(sd, max_batch=2, input_size=size)
+    _compare(net, YolactRef(sd, max_size=550), x, size, 2)
+    net.close()
