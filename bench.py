@@ -205,6 +205,19 @@ def main():
             lat.append((time.perf_counter() - ts) * 1e3)
         lat = sorted(lat[3:])
         out["bs1"] = {"p50_ms_per_image": round(lat[len(lat) // 2], 3), "img_per_s": round(1e3 / lat[len(lat) // 2], 2)}
+        # same pass with the forward replayed as one hipGraph (latency mode: removes the per-launch gaps)
+        net.set_param("graph", 1.0)
+        lat = []
+        for i in range(14):
+            net.sync()
+            ts = time.perf_counter()
+            net.forward_device(1)
+            net.postprocess_device(size, size)
+            net.sync()
+            lat.append((time.perf_counter() - ts) * 1e3)
+        lat = sorted(lat[4:])
+        out["bs1_hipgraph"] = {"p50_ms_per_image": round(lat[len(lat) // 2], 3), "img_per_s": round(1e3 / lat[len(lat) // 2], 2)}
+        net.set_param("graph", 0.0)
         net.set_param("timing", 1.0)
         net.forward_device(a.batch); net.postprocess_device(size, size); net.sync()
         out["stage_ms_bs%d" % a.batch] = {k: round(v, 3) for k, v in net.timings()}
@@ -344,6 +357,15 @@ def main_maskrcnn(a):
                 lat.append((time.perf_counter() - ts) * 1e3)
             lat = sorted(lat[2:])
             out["bs1"] = {"p50_ms_per_image": round(lat[len(lat) // 2], 3), "img_per_s": round(1e3 / lat[len(lat) // 2], 2)}
+            model.set_param("graph", 1.0)  # the forward replayed as one hipGraph (latency mode)
+            lat = []
+            for i in range(11):
+                model.sync(); ts = time.perf_counter()
+                model.forward_device(1); model.paste_device(800, 1333); model.sync()
+                lat.append((time.perf_counter() - ts) * 1e3)
+            lat = sorted(lat[4:])
+            out["bs1_hipgraph"] = {"p50_ms_per_image": round(lat[len(lat) // 2], 3), "img_per_s": round(1e3 / lat[len(lat) // 2], 2)}
+            model.set_param("graph", 0.0)
             model.upload(x, hw)
             model.set_param("timing", 1.0)
             step(); model.sync()

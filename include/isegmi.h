@@ -212,6 +212,10 @@ typedef struct isegmi_engine isegmi_engine;
 int isegmi_engine_create(int model_kind, int max_batch, int H, int W, isegmi_engine** out);
 int isegmi_engine_destroy(isegmi_engine* e);
 int isegmi_engine_set_param(isegmi_engine* e, const char* name, float value);
+/* "graph" param != 0: a forward (yolact / maskrcnn) runs eagerly once, is captured into a hipGraph on the next call with the
+ * same (batch, input pointer) and replayed afterwards (latency mode: ends joined on the main stream; any set_param /
+ * set_conv / set_tensor drops the captured graphs).  Counters for tests and diagnostics: */
+int isegmi_engine_graph_stats(isegmi_engine* h, int64_t* captures, int64_t* replays, int64_t* failures);
 /* h_w_krsc: natural [Cout][R][S][Cin]; h_scale / h_shift [Cout] or NULL */
 int isegmi_engine_set_conv(isegmi_engine* e, const char* name, int Cout, int R, int S, int Cin,
                            const float* h_w_krsc, const float* h_scale, const float* h_shift);

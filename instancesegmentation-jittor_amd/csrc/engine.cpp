@@ -13,6 +13,7 @@ namespace isegmi {
 int eng_buf(Engine& e, const std::string& name, int64_t bytes, void** out, int dtype, std::vector<int64_t> shape) {
     RawBuf& b = e.bufs[name];
     if (b.bytes < bytes) {
+        if (e.capturing) { set_error("buffer " + name + " would be (re)allocated during graph capture"); return ISEGMI_ERR_STATE; }
         if (b.d) HIP_TRY(hipFree(b.d));
         b.d = nullptr;
         HIP_TRY(hipMalloc(&b.d, (size_t)(bytes > 0 ? bytes : 16)));
@@ -111,7 +112,7 @@ int eng_conv_stem_f16(Engine& e, const std::string& layer, const Tensor& halo, i
     return timed_conv(e, layer, &d, halo.d, L, nullptr, out->d, false);
 }
 
-static int next_event(Engine& e, hipEvent_t* ev) {
+int eng_next_event(Engine& e, hipEvent_t* ev) {
     if (e.ev_pool.empty()) {
         e.ev_pool.resize(128);
         for (auto& x : e.ev_pool) HIP_TRY(hipEventCreateWithFlags(&x, hipEventDisableTiming));
@@ -122,7 +123,7 @@ static int next_event(Engine& e, hipEvent_t* ev) {
 int eng_fork(Engine& e, int k) {
     if (!e.multi_stream) return ISEGMI_OK;
     hipEvent_t ev;
-    int rc = next_event(e, &ev);
+    int rc = eng_next_event(e, &ev);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(ev, e.stream));
     HIP_TRY(hipStreamWaitEvent(e.side[k], ev, 0));
@@ -131,10 +132,72 @@ int eng_fork(Engine& e, int k) {
 int eng_join(Engine& e, int k) {
     if (!e.multi_stream) return ISEGMI_OK;
     hipEvent_t ev;
-    int rc = next_event(e, &ev);
+    int rc = eng_next_event(e, &ev);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(ev, e.side[k]));
     HIP_TRY(hipStreamWaitEvent(e.stream, ev, 0));
+    return ISEGMI_OK;
+}
+
+// End of a forward's tail section.  Eager: leave the tail stream running (the next forward overlaps with it) and record
+// the WAR fence.  Under graph capture: join the tail back into the main stream so the capture ends on one stream.
+int eng_tail_end(Engine& e) {
+    if (!e.multi_stream) return ISEGMI_OK;
+    if (e.capturing) {
+        hipEvent_t ev;
+        int rc = eng_next_event(e, &ev);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(ev, e.tail));
+        HIP_TRY(hipStreamWaitEvent(e.stream, ev, 0));
+        return ISEGMI_OK;
+    }
+    HIP_TRY(hipEventRecord(e.tail_done, e.tail));
+    e.tail_pending = true;
+    return ISEGMI_OK;
+}
+
+void eng_graph_reset(Engine& e) {
+    for (auto& kv : e.graphs) (void)hipGraphExecDestroy(kv.second);
+    e.graphs.clear();
+    e.graph_warm.clear();
+}
+
+// Run `body` (a forward's enqueue code) eagerly, or -- with the "graph" param set -- capture it on the second call with the
+// same key and replay the instantiated graph from then on.  The first call stays eager so that every buffer exists.
+int eng_graph_run(Engine& e, const std::string& key, const std::function<int()>& body) {
+    const bool want = e.param("graph", 0.0f) != 0.0f && e.multi_stream && !e.timing && !e.conv_timing;
+    if (!want) return body();
+    auto it = e.graphs.find(key);
+    if (it == e.graphs.end()) {
+        int& warm = e.graph_warm[key];
+        if (warm == 0) { warm = 1; return body(); }
+        if (warm < 0) return body();  // capture failed before: stay eager
+        if (e.tail_pending) { HIP_TRY(hipStreamWaitEvent(e.stream, e.tail_done, 0)); e.tail_pending = false; }
+        HIP_TRY(hipStreamBeginCapture(e.stream, hipStreamCaptureModeRelaxed));
+        e.capturing = true;
+        const int rc = body();
+        e.capturing = false;
+        hipGraph_t g = nullptr;
+        const hipError_t er = hipStreamEndCapture(e.stream, &g);
+        if (rc != ISEGMI_OK || er != hipSuccess || g == nullptr) {
+            if (g) (void)hipGraphDestroy(g);
+            (void)hipGetLastError();
+            warm = -1;
+            ++e.graph_failures;
+            for (int k = 0; k < 3; ++k) (void)hipStreamSynchronize(e.side[k]);
+            (void)hipStreamSynchronize(e.tail);
+            return body();
+        }
+        hipGraphExec_t exec = nullptr;
+        const hipError_t ei = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (ei != hipSuccess) { (void)hipGetLastError(); warm = -1; ++e.graph_failures; return body(); }
+        it = e.graphs.emplace(key, exec).first;
+        ++e.graph_captures;
+    }
+    if (e.tail_pending) { HIP_TRY(hipStreamWaitEvent(e.stream, e.tail_done, 0)); e.tail_pending = false; }
+    HIP_TRY(hipGraphLaunch(it->second, e.stream));
+    ++e.graph_replays;
     return ISEGMI_OK;
 }
 
@@ -283,7 +346,7 @@ int yolact_forward(Engine& e, const float* d_images, int N) {
     };
     // WAR: the previous forward's Detect / postprocess (tail stream) still reads loc/conf/mask/proto and the det.*
     // buffers; everything before this point touched only backbone/FPN buffers and was free to overlap with it.
-    if (e.multi_stream && e.tail_pending) HIP_TRY(hipStreamWaitEvent(e.stream, e.tail_done, 0));
+    if (e.multi_stream && e.tail_pending && !e.capturing) HIP_TRY(hipStreamWaitEvent(e.stream, e.tail_done, 0));
     // protonet (side 0) || heads on P3 (main) || heads on P4,P6 (side 1) || heads on P5,P7 (side 2)
     Tensor proto;
     TRY(eng_fork(e, 0));
@@ -344,15 +407,14 @@ int yolact_forward(Engine& e, const float* d_images, int N) {
     hipStream_t ds = e.stream;
     if (e.multi_stream) {
         hipEvent_t ev;
-        TRY(next_event(e, &ev));
+        TRY(eng_next_event(e, &ev));
         HIP_TRY(hipEventRecord(ev, e.stream));
         HIP_TRY(hipStreamWaitEvent(e.tail, ev, 0));
         ds = e.tail;
     }
     TRY(yolact_detect_launch(&a, ds));
-    if (e.multi_stream) { HIP_TRY(hipEventRecord(e.tail_done, e.tail)); e.tail_pending = true; }
+    TRY(eng_tail_end(e));
     eng_mark(e, "detect");
-    e.last_N = N;
     return ISEGMI_OK;
 }
 
@@ -363,13 +425,14 @@ int yolact_postprocess(Engine& e, int h, int w) {
     RawBuf& proto = e.bufs["proto"];
     const int PH = (int)proto.shape[1], PW = (int)proto.shape[2], md = (int)proto.shape[3];
     void *lo, *masks, *ib;
+    hipStream_t rs = (e.multi_stream && e.tail_pending) ? e.tail : e.stream;  // results stream of the last forward
     TRY(eng_buf(e, "ws.lo", (int64_t)N * K * PH * PW * 4, &lo));
     TRY(eng_buf(e, "det.masks", (int64_t)N * K * h * w, &masks, 2, {N, K, h, w}));
     TRY(eng_buf(e, "det.box_int", (int64_t)N * K * 4 * 8, &ib, 3, {N, K, 4}));
     TRY(yolact_masks_launch((const float*)proto.d, (const float*)e.bufs["det.coeff"].d, (const float*)e.bufs["det.box"].d,
                             (const int*)e.bufs["det.count"].d, N, PH, PW, md, K, h, w, (float*)lo, (uint8_t*)masks, (int64_t*)ib,
-                            e.multi_stream ? e.tail : e.stream));
-    if (e.multi_stream) { HIP_TRY(hipEventRecord(e.tail_done, e.tail)); e.tail_pending = true; }
+                            rs));
+    if (rs == e.tail) HIP_TRY(hipEventRecord(e.tail_done, e.tail));
     eng_mark(e, "masks");
     return ISEGMI_OK;
 }
@@ -400,6 +463,7 @@ extern "C" int isegmi_engine_destroy(isegmi_engine* h) {
     if (!h) return ISEGMI_OK;
     Engine& e = h->e;
     (void)hipStreamSynchronize(e.stream);
+    eng_graph_reset(e);
     if (e.tail) { (void)hipStreamSynchronize(e.tail); (void)hipStreamDestroy(e.tail); }
     if (e.tail_done) (void)hipEventDestroy(e.tail_done);
     for (auto& kv : e.convs) { (void)hipFree(kv.second.d_w); if (kv.second.d_scale) (void)hipFree(kv.second.d_scale); if (kv.second.d_shift) (void)hipFree(kv.second.d_shift); }
@@ -414,11 +478,20 @@ extern "C" int isegmi_engine_destroy(isegmi_engine* h) {
 
 extern "C" int isegmi_engine_set_param(isegmi_engine* h, const char* name, float value) {
     ARG_CHECK(h && name, "null");
+    if (std::string(name) != "graph") eng_graph_reset(h->e);  // kernel arguments are baked into captured graphs
     h->e.params[name] = value;
     if (std::string(name) == "timing") h->e.timing = value != 0.0f;
     if (std::string(name) == "conv_timing") h->e.conv_timing = value != 0.0f;
     if (std::string(name) == "multi_stream") h->e.multi_stream = value != 0.0f;
     if (std::string(name) == "fp16") h->e.fp16 = value != 0.0f;
+    return ISEGMI_OK;
+}
+
+extern "C" int isegmi_engine_graph_stats(isegmi_engine* h, int64_t* captures, int64_t* replays, int64_t* failures) {
+    ARG_CHECK(h, "null");
+    if (captures) *captures = h->e.graph_captures;
+    if (replays) *replays = h->e.graph_replays;
+    if (failures) *failures = h->e.graph_failures;
     return ISEGMI_OK;
 }
 
@@ -429,6 +502,7 @@ extern "C" int isegmi_engine_set_conv(isegmi_engine* h, const char* name, int Co
     memset(&d, 0, sizeof(d));
     d.N = 1; d.H = R; d.W = S; d.Cin = Cin; d.Cout = Cout; d.R = R; d.S = S; d.stride = 1; d.pad = 0;
     const bool f16 = h->e.fp16 && (Cin % 64 == 0 || (Cin == 4 && R == 7 && S == 7));
+    eng_graph_reset(h->e);
     ConvLayer& L = h->e.convs[name];
     if (L.d_w) { (void)hipFree(L.d_w); L.d_w = nullptr; }
     if (L.d_scale) { (void)hipFree(L.d_scale); L.d_scale = nullptr; }
@@ -456,6 +530,7 @@ extern "C" int isegmi_engine_set_conv(isegmi_engine* h, const char* name, int Co
 
 extern "C" int isegmi_engine_set_tensor(isegmi_engine* h, const char* name, const void* h_data, int64_t bytes) {
     ARG_CHECK(h && name && h_data && bytes > 0, "args");
+    eng_graph_reset(h->e);
     RawBuf& b = h->e.tensors[name];
     if (b.d) { (void)hipFree(b.d); b.d = nullptr; }
     HIP_TRY(hipMalloc(&b.d, (size_t)bytes));
@@ -468,7 +543,12 @@ extern "C" int isegmi_yolact_forward(isegmi_engine* h, const float* d_images_nhw
     ARG_CHECK(h && d_images_nhwc3, "null");
     ARG_CHECK(h->e.kind == 1, "engine is not a yolact engine");
     ARG_CHECK(N > 0 && N <= h->e.max_batch, "batch size");
-    return yolact_forward(h->e, d_images_nhwc3, N);
+    Engine& e = h->e;
+    char key[96];
+    snprintf(key, sizeof(key), "yolact:%d:%p", N, (const void*)d_images_nhwc3);
+    const int rc = eng_graph_run(e, key, [&]() { return yolact_forward(e, d_images_nhwc3, N); });
+    if (rc == ISEGMI_OK) e.last_N = N;
+    return rc;
 }
 
 extern "C" int isegmi_yolact_postprocess(isegmi_engine* h, int out_h, int out_w) {

@@ -1,5 +1,6 @@
 // engine.h -- model engine: packed-weight registry, named activation buffers, per-model forward graphs.
 #pragma once
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -46,6 +47,13 @@ struct Engine {
     hipEvent_t tail_done = nullptr;        // recorded after the last tail launch; the next forward's head/proto writers wait on it
     bool tail_pending = false;
     bool multi_stream = true;
+    // hipGraph replay of a forward ("graph" param): the ~130-150 launches of one forward are captured once per
+    // (entry, batch, input pointer) and replayed with one hipGraphLaunch -- removes the per-launch gaps that bound bs=1
+    // latency.  A replay ends joined on the main stream (no cross-step tail overlap), so it is a latency mode.
+    bool capturing = false;
+    std::map<std::string, hipGraphExec_t> graphs;
+    std::map<std::string, int> graph_warm;
+    int64_t graph_captures = 0, graph_replays = 0, graph_failures = 0;
     bool fp16 = false;                     // fp16 storage + f16 MFMA convs (BASELINE configs[4]); set before loading weights
     std::vector<hipEvent_t> ev_pool;
     size_t ev_next = 0;
@@ -84,6 +92,9 @@ int eng_act(Engine& e, const std::string& name, int N, int H, int W, int C, Tens
 int eng_conv(Engine& e, const std::string& layer, const Tensor& in, int stride, int pad, int act, const Tensor* residual,
              const std::string& out_name, Tensor* out, bool out_f32 = false);
 // conv writing into a caller-provided strided destination (heads -> concatenated buffers, deconv parities)
+int eng_graph_run(Engine& e, const std::string& key, const std::function<int()>& body);
+void eng_graph_reset(Engine& e);
+int eng_tail_end(Engine& e);
 int eng_conv_stem_f16(Engine& e, const std::string& layer, const Tensor& halo, int H, int W, const std::string& out_name, Tensor* out);
 int eng_conv_into(Engine& e, const std::string& layer, const Tensor& in, int stride, int pad, int act, void* dst, int out_div,
                   int64_t out_img_stride, int64_t out_pix_stride, bool out_f32 = false);
@@ -101,7 +112,8 @@ struct SideScope {
 
 int yolact_forward(Engine& e, const float* d_images, int N);
 int yolact_postprocess(Engine& e, int h, int w);
-int maskrcnn_forward(Engine& e, const float* d_images, const int32_t* h_image_hw, int N);
+int maskrcnn_forward(Engine& e, const float* d_images, int N);
+int eng_next_event(Engine& e, hipEvent_t* ev);
 int maskrcnn_paste(Engine& e, const float* h_ratios_wh, int out_h, int out_w);
 
 // kernels implemented in other translation units

@@ -44,7 +44,22 @@ static int need_tensor(Engine& e, const std::string& name, int64_t bytes, const 
     return ISEGMI_OK;
 }
 
-int maskrcnn_forward(Engine& e, const float* d_images, const int32_t* h_image_hw, int N) {
+// image_hw is caller memory: copy synchronously, but only when it changed (steady-state batches skip it).  Kept out of
+// maskrcnn_forward so that the forward's enqueue code is capturable into a hipGraph.
+int maskrcnn_set_image_hw(Engine& e, const int32_t* h_image_hw, int N) {
+    void* p;
+    TRY(eng_buf(e, "image_hw", (int64_t)N * 8, &p, 1, {N, 2}));
+    std::vector<int32_t> now(h_image_hw, h_image_hw + 2 * N);
+    if (now != e.last_hw || e.last_hw_ptr != (const void*)p) {
+        HIP_TRY(hipMemcpyAsync(p, h_image_hw, (size_t)N * 8, hipMemcpyHostToDevice, e.stream));
+        HIP_TRY(hipStreamSynchronize(e.stream));
+        e.last_hw = now;
+        e.last_hw_ptr = p;
+    }
+    return ISEGMI_OK;
+}
+
+int maskrcnn_forward(Engine& e, const float* d_images, int N) {
     const int H = e.H, W = e.W;
     if (H % 32 || W % 32) { set_error("Mask R-CNN input must be padded to a multiple of 32"); return ISEGMI_ERR_ARG; }
     e.cur = e.stream;
@@ -53,16 +68,6 @@ int maskrcnn_forward(Engine& e, const float* d_images, const int32_t* h_image_hw
     void* p;
     TRY(eng_buf(e, "image_hw", (int64_t)N * 8, &p, 1, {N, 2}));
     int* d_hw = (int*)p;
-    {
-        // image_hw is caller memory: copy synchronously, but only when it changed (steady-state batches skip it)
-        std::vector<int32_t> now(h_image_hw, h_image_hw + 2 * N);
-        if (now != e.last_hw || e.last_hw_ptr != (const void*)d_hw) {
-            HIP_TRY(hipMemcpyAsync(d_hw, h_image_hw, (size_t)N * 8, hipMemcpyHostToDevice, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            e.last_hw = now;
-            e.last_hw_ptr = d_hw;
-        }
-    }
 
     const int dt = e.fp16 ? 1 : 0;  // storage type of everything after the stem
     Tensor x4, s, x;
@@ -160,7 +165,7 @@ int maskrcnn_forward(Engine& e, const float* d_images, const int32_t* h_image_hw
     };
     // WAR: the previous forward's RoI heads (tail stream) still gather from P2..P5 and read proposals / det buffers;
     // everything up to here (backbone, top-down chain) was free to run underneath them.
-    if (e.multi_stream && e.tail_pending) HIP_TRY(hipStreamWaitEvent(e.stream, e.tail_done, 0));
+    if (e.multi_stream && e.tail_pending && !e.capturing) HIP_TRY(hipStreamWaitEvent(e.stream, e.tail_done, 0));
     for (int l = 0; l < 4; ++l) {
         TRY(eng_conv(e, "backbone.fpn.fpn_layer" + std::to_string(l + 1), last[l], 1, 1, 0, nullptr, "P" + std::to_string(l + 2), &P[l]));
         TRY(rpn_level(l));
@@ -179,10 +184,9 @@ int maskrcnn_forward(Engine& e, const float* d_images, const int32_t* h_image_hw
         hipStream_t srcs[4] = {e.stream, e.side[0], e.side[1], e.side[2]};
         for (int i = 0; i < 4; ++i) {
             hipEvent_t ev;
-            HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            TRY(eng_next_event(e, &ev));
             HIP_TRY(hipEventRecord(ev, srcs[i]));
             HIP_TRY(hipStreamWaitEvent(e.tail, ev, 0));
-            HIP_TRY(hipEventDestroy(ev));
         }
         e.cur = e.tail;
     }
@@ -263,9 +267,8 @@ int maskrcnn_forward(Engine& e, const float* d_images, const int32_t* h_image_hw
     if (dt) TRY(mask_logits_select_f16_launch(up.d, N * cap, 784, 256, (const float*)lw->d, (const float*)lb->d, a.d_out_labels, (float*)p, st));
     else TRY(mask_logits_select_launch(up.d, N * cap, 784, 256, (const float*)lw->d, (const float*)lb->d, a.d_out_labels, (float*)p, st));
     eng_mark(e, "mask_head");
-    if (e.multi_stream) { HIP_TRY(hipEventRecord(e.tail_done, e.tail)); e.tail_pending = true; }
+    TRY(eng_tail_end(e));
     e.cur = e.stream;
-    e.last_N = N;
     return ISEGMI_OK;
 #undef st
 }
@@ -309,7 +312,14 @@ extern "C" int isegmi_maskrcnn_forward(isegmi_engine* h, const float* d_images, 
     for (int i = 0; i < N; ++i)
         ARG_CHECK(h_image_hw[2 * i] > 0 && h_image_hw[2 * i] <= h->e.H && h_image_hw[2 * i + 1] > 0 && h_image_hw[2 * i + 1] <= h->e.W,
                   "image_hw must fit inside the padded input");
-    return maskrcnn_forward(h->e, d_images, h_image_hw, N);
+    Engine& e = h->e;
+    TRY(maskrcnn_set_image_hw(e, h_image_hw, N));
+    char key[96];
+    snprintf(key, sizeof(key), "maskrcnn:%d:%p", N, (const void*)d_images);
+    const int rc = eng_graph_run(e, key, [&]() { return maskrcnn_forward(e, d_images, N); });
+    e.cur = e.stream;
+    if (rc == ISEGMI_OK) e.last_N = N;
+    return rc;
 }
 
 // h_ratios_wh [N][2] = (out_w / w_i, out_h / h_i) as float, computed by the host like BoxList.resize

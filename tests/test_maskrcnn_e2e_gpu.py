@@ -194,3 +194,34 @@ def test_maskrcnn_smooth_images_bit_exact(ffi, sd):
         assert np.array_equal(bl.get_field("scores"), r["score"]) and np.array_equal(bl.bbox, r["box"])
         assert np.array_equal(bl.get_field("mask")[:, 0], r["mask28"])
     model.close()
+
+
+def test_maskrcnn_hipgraph_replay_matches_eager(ffi, sd):
+    """hipGraph replay of the Mask R-CNN forward (eager warm-up, capture, replay) against the eager multi-stream path,
+    with changing image content and changing image_hw between replays (image_hw lives in device memory)."""
+    from isegmi.maskrcnn import MaskRCNN, prepare_images
+    rng = np.random.default_rng(9)
+    xa, hwa = prepare_images([rng.uniform(0, 255, (224, 300, 3)).astype(np.float32)])
+    xb, hwb = prepare_images([rng.uniform(0, 255, (200, 310, 3)).astype(np.float32)])
+    assert xa.shape == xb.shape
+    model = MaskRCNN(sd, xa.shape[1], xa.shape[2], max_batch=1)
+    keys = ("proposal_count", "proposals", "det.count", "det.box", "det.score", "det.label", "det.mask28")
+    def run(x, hw):
+        model.upload(x, hw); model.forward_device(1); model.paste_device(224, 320); model.sync()
+        d = {k: model.fetch(k, 1) for k in keys}
+        d["det.masks"] = model.fetch("det.masks", 1)
+        return d
+    ea, eb = run(xa, hwa), run(xb, hwb)
+    model.set_param("graph", 1.0)
+    for rep in range(3):
+        for x, hw, want in ((xa, hwa, ea), (xb, hwb, eb)):
+            got = run(x, hw)
+            n = int(want["det.count"][0])
+            assert np.array_equal(got["det.count"], want["det.count"]) and np.array_equal(got["proposal_count"], want["proposal_count"])
+            for k in ("det.box", "det.score", "det.label", "det.mask28", "det.masks"):
+                assert np.array_equal(got[k][0, :n], want[k][0, :n]), (rep, k)
+    import ctypes as C
+    cap, rep_, fail = C.c_int64(), C.c_int64(), C.c_int64()
+    ffi.check(ffi.lib().isegmi_engine_graph_stats(model._h, C.byref(cap), C.byref(rep_), C.byref(fail)))
+    assert cap.value == 1 and rep_.value >= 4 and fail.value == 0
+    model.close()

@@ -153,3 +153,38 @@ def test_yolact_smooth_images_bit_exact(ffi, sd):
     net = Yolact(sd, max_batch=2, input_size=size)
     _compare(net, YolactRef(sd, max_size=550), x, size, 2)
     net.close()
+
+
+def test_yolact_hipgraph_replay_matches_eager(ffi, sd):
+    """"graph" param: the forward is captured into a hipGraph on its second call and replayed afterwards; results must
+    equal the eager multi-stream path bit for bit, also after the input buffer's CONTENT changes (same pointer) and
+    after a parameter change (which must drop the captured graph)."""
+    from isegmi.yolact import Yolact
+    size = 200
+    net = Yolact(sd, max_batch=2, input_size=size)
+    keys = ("det.count", "det.score", "det.prior", "det.box", "det.class", "det.masks")
+    def run(x):
+        net.upload(x); net.forward_device(2); net.postprocess_device(150, 170); net.sync()
+        return {k: net.fetch(k, 2) for k in keys}
+    xa, xb = _images(21, 2, size), _images(22, 2, size)
+    ea, eb = run(xa), run(xb)
+    net.set_param("graph", 1.0)
+    for rep in range(3):  # eager warm-up, capture, replay
+        for name, x, want in (("a", xa, ea), ("b", xb, eb)):
+            got = run(x)
+            for k in keys:
+                if k == "det.masks":
+                    assert all(np.array_equal(got[k][i, : want["det.count"][i]], want[k][i, : want["det.count"][i]]) for i in range(2))
+                else:
+                    assert np.array_equal(got[k], want[k]), (rep, name, k)
+    import ctypes as C
+    cap, rep_, fail = C.c_int64(), C.c_int64(), C.c_int64()
+    ffi.check(ffi.lib().isegmi_engine_graph_stats(net._h, C.byref(cap), C.byref(rep_), C.byref(fail)))
+    assert cap.value == 1 and rep_.value >= 4 and fail.value == 0
+    net.set_param("nms_conf_thresh", 0.12)
+    g3 = run(xa)
+    net.set_param("graph", 0.0)
+    e3 = run(xa)
+    assert np.array_equal(g3["det.count"], e3["det.count"]) and np.array_equal(g3["det.score"], e3["det.score"])
+    assert not np.array_equal(e3["det.score"], ea["det.score"])
+    net.close()
