@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8, help="images the CPU oracle is timed on")
     ap.add_argument("--no-latency", action="store_true", help="skip the extra bs=1 latency pass")
+    ap.add_argument("--single-stream", action="store_true", help="profiling aid: run the timed region on one stream too, so that "
+                    "rocprofv3 per-kernel durations are not inflated by overlapping launches (throughput drops ~20 %%)")
     return ap.parse_args()
 
 
@@ -82,6 +84,8 @@ def main():
         raise SystemExit("no HIP device visible: bench.py measures the HIP path only (no CPU fallback)")
     sd = yolact_state_dict(1234)
     net = Yolact(sd, max_batch=a.batch, device=local_rank)
+    if a.single_stream:
+        net.set_param("multi_stream", 0.0)
     size = net.size
     rng = np.random.default_rng(20261003 + rank)
     imgs = fast_base_transform(rng.uniform(0, 255, (a.batch, size, size, 3)).astype(np.float32))
@@ -149,7 +153,7 @@ def main():
     full_sync()
     _ffi.check(_ffi.lib().isegmi_engine_conv_stats(net._h, C.byref(f), C.byref(m), C.byref(l)))
     net.set_param("conv_timing", 0.0)
-    net.set_param("multi_stream", 1.0)
+    net.set_param("multi_stream", 0.0 if a.single_stream else 1.0)
     conv_flops, conv_ms, conv_launches = f.value, m.value, l.value
 
     counts = net.fetch("det.count", a.batch)
@@ -183,8 +187,8 @@ def main():
                 "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                "traffic": pmc_traffic("r01_pmc_yolact_bs8.json"),
-                "traffic_note": "HBM bytes per conv launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (profiles/r01_pmc_yolact_bs8.json; FETCH x2 gfx950 correction); not collected live",
+                "traffic": pmc_traffic("r01_pmc_yolact.json"),
+                "traffic_note": "HBM bytes per conv launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (profiles/r01_pmc_yolact.json; FETCH x2 gfx950 correction); not collected live",
                 "algorithmic_gflop_per_step": round(conv_flops / max(a.steps, 1) / 1e9, 2),
                 "conv_ms_per_step": round(conv_ms / max(a.steps, 1), 3),
                 "launches_per_step": conv_launches // max(a.steps, 1),
@@ -278,6 +282,8 @@ def main_maskrcnn(a):
     imgs = [rng.uniform(0, 255, (800, 1333, 3)).astype(np.float32) for _ in range(a.batch)]
     x, hw = prepare_images(imgs)
     model = MaskRCNN(sd, x.shape[1], x.shape[2], cfg=MaskRCNNConfig(depth=a.depth), max_batch=a.batch, device=local_rank, fp16=a.fp16)
+    if a.single_stream:
+        model.set_param("multi_stream", 0.0)
     tag = "R%d-FPN" % a.depth
     prec = "fp16 storage / f16 MFMA, fp32 accumulate" if a.fp16 else "fp32"
     peak = 2500.0 if a.fp16 else PEAK_F32_MFMA_TFLOPS  # dense f16 MFMA peak (MI355X_MICROARCH.md) vs f32 MFMA peak
@@ -330,7 +336,7 @@ def main_maskrcnn(a):
     model.sync(); _ffi.sync()
     _ffi.check(_ffi.lib().isegmi_engine_conv_stats(model._h, C.byref(f), C.byref(m), C.byref(l)))
     model.set_param("conv_timing", 0.0)
-    model.set_param("multi_stream", 1.0)
+    model.set_param("multi_stream", 0.0 if a.single_stream else 1.0)
     if rank == 0:
         achieved = f.value / (m.value * 1e-3) / 1e12 if m.value > 0 else 0.0
         cnt = model.fetch("det.count", a.batch); pc = model.fetch("proposal_count", a.batch)
@@ -343,8 +349,8 @@ def main_maskrcnn(a):
                           "proposals_per_image": [int(c) for c in pc], "detections_per_image": [int(c) for c in cnt]},
                "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel (all conv launches of a step)",
                             "pass": "K single-stream steps right after the timed region, HIP events around every conv launch", "achieved": round(achieved, 2),
-                            "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None if (a.fp16 or a.depth != 50) else pmc_traffic("r01_pmc_maskrcnn.json"),
-                            "traffic_note": "HBM bytes per conv launch from separate rocprofv3 --pmc passes (profiles/r01_pmc_maskrcnn.json; FETCH x2 gfx950 correction); not collected live",
+                            "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": pmc_traffic("r01_pmc_r101f16.json") if (a.fp16 and a.depth == 101 and a.batch == 8) else None if (a.fp16 or a.depth != 50 or a.batch != 2) else pmc_traffic("r01_pmc_maskrcnn.json"),
+                            "traffic_note": "HBM bytes per conv launch from separate rocprofv3 --pmc passes of this command (tools/profile_round.sh -> profiles/r01_pmc_maskrcnn.json / r01_pmc_r101f16.json; FETCH x2 gfx950 correction); not collected live; null for configurations without a committed PMC pass",
                             "algorithmic_gflop_per_step": round(f.value / a.steps / 1e9, 2), "conv_ms_per_step": round(m.value / a.steps, 3),
                             "launches_per_step": l.value // a.steps, "avg_launch_us": round(m.value * 1e3 / max(l.value, 1), 2)},
                "p50_ms_per_image": round(elapsed / a.steps * 1e3 / a.batch, 3)}
