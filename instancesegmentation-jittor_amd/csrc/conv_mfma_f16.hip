@@ -51,7 +51,10 @@ template <int BM, int BN, int WM, int WN, int NSTAGE, int OCC, bool STEM>
 __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_f16_glds_kernel(const ConvKH p) {
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int PPA = BM / 8 / NW, PPB = BN / 8 / NW;
+    constexpr int PA = BM / 8, PB = BN / 8;                          // 1-KiB pieces per chunk
+    constexpr int PPA = (PA + NW - 1) / NW, PPB = (PB + NW - 1) / NW;  // rounds per wave (the last one may be partial)
+    constexpr bool UNEVEN = (PA % NW != 0) || (PB % NW != 0);
+    static_assert(!UNEVEN || NSTAGE == 2, "a partial piece round changes a wave's vmcnt count: only with the vmcnt(0) ring");
     constexpr int STAGEB = (BM + BN) * 128;
     static_assert(PPA >= 1 && PPB >= 1 && TM >= 1 && TN >= 1, "tile/wave split");
     extern __shared__ __attribute__((aligned(1024))) char smemg[];
@@ -108,12 +111,14 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_f16_glds_kernel(const 
     auto piece = [&](int i, int stage, unsigned dead) {
         char* sA = smemg + stage * STAGEB;
         if (i < PPA) {
+            if (PA % NW != 0 && wave + i * NW >= PA) return;  // wave-uniform: this wave has no piece in the partial round
             const int hi = hi0[i] + kr, wi = wi0[i] + ks;
             const bool ok = STEM ? hi0[i] == 0 : ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W);
             const unsigned off = (ok ? (unsigned)(abase[i] + delta) : OOB) | dead;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(sA + (wave + i * NW) * 1024), 16, off, 0, 0, 0);
         } else {
             const int j = i - PPA;
+            if (PB % NW != 0 && wave + j * NW >= PB) return;
             const unsigned off = (bbase[j] + (unsigned)issued * 128u) | dead;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(sA + BM * 128 + (wave + j * NW) * 1024), 16, off, 0, 0, 0);
         }
@@ -349,7 +354,8 @@ int conv2d_f16_launch(const isegmi_conv_desc* d, const void* in, const void* w, 
         // Tiles that share a CU (occ > 1) are assumed packed onto as few CUs as the dispatcher may choose.
         static const struct { int id, bm, bn, occ; double eff; } T[] = {
             {1, 256, 256, 1, 1.0}, {2, 256, 128, 1, 0.95}, {3, 128, 128, 2, 0.85}, {4, 64, 64, 3, 0.6}, {5, 64, 128, 3, 0.75},
-            {6, 64, 256, 2, 0.75}, {7, 128, 256, 1, 0.95}, {8, 128, 64, 2, 0.6}, {9, 192, 256, 1, 1.0}, {10, 192, 128, 2, 1.0}};
+            {6, 64, 256, 2, 0.75}, {7, 128, 256, 1, 0.95}, {8, 128, 64, 2, 0.6}, {9, 192, 256, 1, 1.0}, {10, 192, 128, 2, 1.0},
+            {11, 160, 256, 1, 0.88}};
         double best = 0.0;
         for (const auto& t : T) {
             const int64_t blocks = (int64_t)cdiv(k.M, t.bm) * cdiv(d->Cout, t.bn);
@@ -370,6 +376,7 @@ int conv2d_f16_launch(const isegmi_conv_desc* d, const void* in, const void* w, 
         case 8: return launch_g<128, 64, 2, 2, 3, 2>(k, st);
         case 9: return launch_g<192, 256, 2, 4, 2, 1>(k, st);   // wave tile 96x64
         case 10: return launch_g<192, 128, 2, 2, 2, 2>(k, st);
+        case 11: return launch_g<160, 256, 1, 8, 2, 1>(k, st);  // wave tile 160x32; 20 A pieces over 8 waves (partial round)
         default: break;
     }
     ARG_CHECK(false, "unknown fp16 conv tile");

@@ -14,7 +14,7 @@ CASES = [(2, 19, 23, 64, 48, 3, 1, 1), (1, 35, 35, 64, 64, 1, 1, 0), (2, 35, 33,
 
 
 @pytest.mark.parametrize("case", CASES)
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
 def test_conv_f16_close_to_oracle(ffi, case, tile):
     N, H, W, Cin, Cout, R, stride, pad = case
     rng = np.random.default_rng(abs(hash(case)) % (2 ** 32))
