@@ -688,7 +688,7 @@ ORA_API int ora_yolact_detect(const float* conf, const float* boxes, const float
     float* cs = (float*)malloc(sizeof(float) * (size_t)nk);
     float* ts = (float*)malloc(sizeof(float) * (size_t)tk);
     int32_t* ti = (int32_t*)malloc(sizeof(int32_t) * (size_t)tk);
-    float* fs = (float*)malloc(sizeof(float) * (size_t)nc * tk);
+    float* fs = (float*)calloc((size_t)nc * tk > 0 ? (size_t)nc * tk : 1, sizeof(float));
     int32_t* fp = (int32_t*)malloc(sizeof(int32_t) * (size_t)nc * tk);
     int32_t* fc = (int32_t*)malloc(sizeof(int32_t) * (size_t)nc * tk);
     int tot = 0;
