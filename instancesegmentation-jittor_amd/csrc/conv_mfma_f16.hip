@@ -153,13 +153,17 @@ __device__ __forceinline__ void conv_f16_epilogue(const ConvKH& p, f32x16h (&acc
     }
 }
 
-template <int BM, int BN, int WM, int WN, int NSTAGE, int OCC, bool STEM>
-__global__ __launch_bounds__(WM * WN * 64, OCC) void conv_f16_glds_kernel(const ConvKH p) {
+// LW > 0: LW extra LOADER waves issue every LDS-DMA piece and the NW MFMA waves issue none (an LDS-DMA instruction stalls its
+// wave for 100-180 cycles while the fill path is busy -- time the MFMA waves then spend on matrix work); LW == 0: every wave
+// loads its share between its MFMAs.
+template <int BM, int BN, int WM, int WN, int NSTAGE, int OCC, bool STEM, int LW>
+__global__ __launch_bounds__((WM * WN + LW) * 64, OCC) void conv_f16_glds_kernel(const ConvKH p) {
     constexpr int NW = WM * WN;
+    constexpr int NL = LW > 0 ? LW : NW;  // waves that issue loads
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int PA = BM / 8, PB = BN / 8;                          // 1-KiB pieces per chunk
-    constexpr int PPA = (PA + NW - 1) / NW, PPB = (PB + NW - 1) / NW;  // rounds per wave (the last one may be partial)
-    constexpr bool UNEVEN = (PA % NW != 0) || (PB % NW != 0);
+    constexpr int PPA = (PA + NL - 1) / NL, PPB = (PB + NL - 1) / NL;  // rounds per loading wave (the last one may be partial)
+    constexpr bool UNEVEN = (PA % NL != 0) || (PB % NL != 0);
     static_assert(!UNEVEN || NSTAGE == 2, "a partial piece round changes a wave's vmcnt count: only with the vmcnt(0) ring");
     constexpr int STAGEB = (BM + BN) * 128;
     static_assert(PPA >= 1 && PPB >= 1 && TM >= 1 && TN >= 1, "tile/wave split");
@@ -168,6 +172,8 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_f16_glds_kernel(const 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
+    const int lw = LW > 0 ? wave - NW : wave;           // index among the loading waves
+    const bool loads = LW == 0 || wave >= NW;
 
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int q8 = nwg >> 3, r8g = nwg & 7, xcd = bid & 7;
@@ -179,7 +185,8 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_f16_glds_kernel(const 
     int hi0[PPA], wi0[PPA], abase[PPA];
 #pragma unroll
     for (int j = 0; j < PPA; ++j) {
-        const int row = (wave + j * NW) * 8 + r8;
+        if (!loads) break;
+        const int row = (lw + j * NL) * 8 + r8;
         const int c = cs ^ ((row >> 1) & 7);
         const int m = m0 + row;
         if (m < p.M) {
@@ -204,7 +211,8 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_f16_glds_kernel(const 
     unsigned bbase[PPB];
 #pragma unroll
     for (int j = 0; j < PPB; ++j) {
-        const int row = (wave + j * NW) * 8 + r8;
+        if (!loads) break;
+        const int row = (lw + j * NL) * 8 + r8;
         const int c = cs ^ ((row >> 1) & 7);
         bbase[j] = (unsigned)(n0 + row) * (unsigned)(p.wrow * 2) + (unsigned)(c * 16);
     }
@@ -217,16 +225,16 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_f16_glds_kernel(const 
     auto piece = [&](int i, int stage, unsigned dead) {
         char* sA = smemg + stage * STAGEB;
         if (i < PPA) {
-            if (PA % NW != 0 && wave + i * NW >= PA) return;  // wave-uniform: this wave has no piece in the partial round
+            if (PA % NL != 0 && lw + i * NL >= PA) return;  // wave-uniform: this wave has no piece in the partial round
             const int hi = hi0[i] + kr, wi = wi0[i] + ks;
             const bool ok = STEM ? hi0[i] == 0 : ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W);
             const unsigned off = (ok ? (unsigned)(abase[i] + delta) : OOB) | dead;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(sA + (wave + i * NW) * 1024), 16, off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(sA + (lw + i * NL) * 1024), 16, off, 0, 0, 0);
         } else {
             const int j = i - PPA;
-            if (PB % NW != 0 && wave + j * NW >= PB) return;
+            if (PB % NL != 0 && lw + j * NL >= PB) return;
             const unsigned off = (bbase[j] + (unsigned)issued * 128u) | dead;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(sA + BM * 128 + (wave + j * NW) * 1024), 16, off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(sA + BM * 128 + (lw + j * NL) * 1024), 16, off, 0, 0, 0);
         }
     };
     auto advance = [&]() {
@@ -252,17 +260,32 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_f16_glds_kernel(const 
     constexpr int PP = PPA + PPB;
     constexpr int ISSUE_STEPS = 4;  // the next chunk's pieces are spread over this chunk's four MFMA steps
 
+    if (loads) {
 #pragma unroll
-    for (int s = 0; s < NSTAGE - 1; ++s) {
-        const unsigned dead = deadmask();
+        for (int s = 0; s < NSTAGE - 1; ++s) {
+            const unsigned dead = deadmask();
 #pragma unroll
-        for (int i = 0; i < PP; ++i) piece(i, s, dead);
-        advance();
+            for (int i = 0; i < PP; ++i) piece(i, s, dead);
+            advance();
+        }
     }
     int rd = 0, wr = NSTAGE - 1;
+    if (LW > 0 && wave >= NW) {  // loader wave: same barrier sequence as the MFMA waves, no matrix work
+        for (int t = 0; t < p.nchunks; ++t) {
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NSTAGE - 2) * PP) : "memory");
+            const unsigned dead = deadmask();
+#pragma unroll
+            for (int i = 0; i < PP; ++i) piece(i, wr, dead);
+            advance();
+            wr = wr + 1 == NSTAGE ? 0 : wr + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        return;
+    }
     for (int t = 0; t < p.nchunks; ++t) {
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NSTAGE - 2) * PP) : "memory");
-        const unsigned dead = deadmask();
+        if (LW == 0) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NSTAGE - 2) * PP) : "memory");
+        else asm volatile("s_barrier" ::: "memory");
+        const unsigned dead = LW == 0 ? deadmask() : 0u;
         const char* sb = smemg + rd * STAGEB;
         f16x8 fa[2][TM], fb[2][TN];
 #pragma unroll
@@ -280,13 +303,13 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_f16_glds_kernel(const 
             }
 #pragma unroll
             for (int i = 0; i < PP; ++i)
-                if (i * ISSUE_STEPS / PP == s) piece(i, wr, dead);
+                if (LW == 0 && i * ISSUE_STEPS / PP == s) piece(i, wr, dead);
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
                 for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s & 1][a], fb[s & 1][b], acc[a][b], 0, 0, 0);
         }
-        advance();
+        if (LW == 0) advance();
         rd = rd + 1 == NSTAGE ? 0 : rd + 1;
         wr = wr + 1 == NSTAGE ? 0 : wr + 1;
     }
@@ -305,20 +328,23 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_f16_glds_kernel(const 
 // Step u = (r, kc, s), s fastest: A strips are double-buffered per (r, kc) group and filled a third per step, B chunks
 // double-buffered per step; every step starts with `s_waitcnt vmcnt(0); s_barrier`.  K is walked as (r, kc, s) instead of
 // (r, s, kc): fp32 accumulation order differs from the generic kernel within the stated fp16 tolerance.
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_f16_strip_kernel(const ConvKH p) {
+template <int BM, int BN, int WM, int WN, int LW>
+__global__ __launch_bounds__((WM * WN + LW) * 64, 1) void conv3x3_f16_strip_kernel(const ConvKH p) {
     constexpr int NW = WM * WN;
+    constexpr int NL = LW > 0 ? LW : NW;            // waves that issue loads (LW > 0: dedicated loader waves, see above)
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int SR_CAP = BM + 64;                 // strip rows: BM + 2 per image-row segment (<= 32 segments)
     constexpr int SP = SR_CAP / 8, PB = BN / 8;     // 1-KiB pieces: strip, B chunk
     constexpr int SP3 = (SP + 2) / 3;               // strip pieces issued per step (a third of the strip)
-    constexpr int RA = (SP3 + NW - 1) / NW, RB = (PB + NW - 1) / NW;  // piece rounds per wave and step
+    constexpr int RA = (SP3 + NL - 1) / NL, RB = (PB + NL - 1) / NL;  // piece rounds per loading wave and step
     constexpr int ABYTES = SR_CAP * 128, BBYTES = BN * 128;
     extern __shared__ __attribute__((aligned(1024))) char smemg[];  // [A strip 0][A strip 1][B 0][B 1]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
+    const int lw = LW > 0 ? wave - NW : wave;
+    const bool loads = LW == 0 || wave >= NW;
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int q8 = nwg >> 3, r8g = nwg & 7, xcd = bid & 7;
     const int logical = (xcd < r8g ? xcd * (q8 + 1) : r8g * (q8 + 1) + (xcd - r8g) * q8) + (bid >> 3);
@@ -339,7 +365,8 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_f16_strip_kernel(cons
     for (int t = 0; t < 3; ++t)
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
-            const int sp = t * SP3 + wave + j * NW;
+            if (!loads) break;
+            const int sp = t * SP3 + lw + j * NL;
             const int q = sp * 8 + r8;
             const int c = cs ^ ((q >> 1) & 7);
             // strip row q -> segment g, position pos inside [left | pixels | right]
@@ -356,7 +383,8 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_f16_strip_kernel(cons
     unsigned bbase[RB];
 #pragma unroll
     for (int j = 0; j < RB; ++j) {
-        const int row = (wave + j * NW) * 8 + r8;
+        if (!loads) break;
+        const int row = (lw + j * NL) * 8 + r8;
         const int c = cs ^ ((row >> 1) & 7);
         bbase[j] = (unsigned)(n0 + row) * (unsigned)(p.wrow * 2) + (unsigned)(c * 16);
     }
@@ -373,7 +401,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_f16_strip_kernel(cons
         char* dst = smemg + ab * ABYTES;
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
-            const int spl = wave + j * NW;               // piece inside the third
+            const int spl = lw + j * NL;                 // piece inside the third
             const int sp = t * SP3 + spl;
             if (spl >= SP3 || sp >= SP || sp * 8 >= SR) continue;  // wave-uniform
             const bool ok = (unsigned)(a_hi0[t][j] + r) < (unsigned)H;
@@ -390,9 +418,9 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_f16_strip_kernel(cons
         char* dst = smemg + 2 * ABYTES + bb * BBYTES;
 #pragma unroll
         for (int j = 0; j < RB; ++j) {
-            if (PB % NW != 0 && wave + j * NW >= PB) continue;
+            if (PB % NL != 0 && lw + j * NL >= PB) continue;
             const unsigned off = bbase[j] + koff;  // (a named operand: hipcc 7.2 silently drops the host stub of the kernel otherwise)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(dst + (wave + j * NW) * 1024), 16, off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(dst + (lw + j * NL) * 1024), 16, off, 0, 0, 0);
         }
     };
 
@@ -421,14 +449,28 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_f16_strip_kernel(cons
     const int b_off = 2 * ABYTES + wn * TN * 32 * 128;
 
     // prologue: whole strip of group 0, B of step 0
-    issue_strip(0, 0, 0); issue_strip(1, 0, 0); issue_strip(2, 0, 0);
-    issue_b(0, 0);
+    if (loads) {
+        issue_strip(0, 0, 0); issue_strip(1, 0, 0); issue_strip(2, 0, 0);
+        issue_b(0, 0);
+    }
     int u = 0;
+    if (LW > 0 && wave >= NW) {  // loader wave: the MFMA waves' barrier sequence, loads only
+        for (int gi = 0; gi < ngroups; ++gi)
+#pragma unroll
+            for (int s = 0; s < 3; ++s, ++u) {
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                issue_b(u + 1, (u + 1) & 1);
+                issue_strip(s, gi + 1, (gi + 1) & 1);
+            }
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        return;
+    }
     for (int gi = 0; gi < ngroups; ++gi) {
         const char* sa = smemg + (gi & 1) * ABYTES;
 #pragma unroll
         for (int s = 0; s < 3; ++s, ++u) {
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            if (LW == 0) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_barrier" ::: "memory");
             const char* sb = smemg + b_off + (u & 1) * BBYTES;
             f16x8 fa[2][TM], fb[2][TN];
 #pragma unroll
@@ -443,8 +485,8 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_f16_strip_kernel(cons
 #pragma unroll
                     for (int b = 0; b < TN; ++b) fb[(ks + 1) & 1][b] = *(const f16x8*)(sb + b * 4096 + (swzb ^ ((ks + 1) << 5)));
                 }
-                if (ks == 0) issue_b(u + 1, (u + 1) & 1);
-                if (ks == 1) issue_strip(s, gi + 1, (gi + 1) & 1);
+                if (LW == 0 && ks == 0) issue_b(u + 1, (u + 1) & 1);
+                if (LW == 0 && ks == 1) issue_strip(s, gi + 1, (gi + 1) & 1);
 #pragma unroll
                 for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -456,7 +498,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_f16_strip_kernel(cons
     conv_f16_epilogue<TM, TN>(p, acc, smemg, wave, lane, wm, wn, m0, n0);
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int LW = 0>
 static int launch_strip(ConvKH& k, hipStream_t st) {
     k.mtiles = cdiv(k.M, BM);
     k.ntiles = cdiv(k.Cout, BN);
@@ -465,13 +507,13 @@ static int launch_strip(ConvKH& k, hipStream_t st) {
     const size_t epi = (size_t)NW * 32 * (TN * 32 + 4) * 4;
     if (epi > lds) lds = epi;
     static bool attr = false;
-    if (!attr) { HIP_TRY(hipFuncSetAttribute((const void*)conv3x3_f16_strip_kernel<BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
-    hipLaunchKernelGGL((conv3x3_f16_strip_kernel<BM, BN, WM, WN>), dim3((unsigned)(k.mtiles * k.ntiles)), dim3(NW * 64), lds, st, k);
+    if (!attr) { HIP_TRY(hipFuncSetAttribute((const void*)conv3x3_f16_strip_kernel<BM, BN, WM, WN, LW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+    hipLaunchKernelGGL((conv3x3_f16_strip_kernel<BM, BN, WM, WN, LW>), dim3((unsigned)(k.mtiles * k.ntiles)), dim3((NW + LW) * 64), lds, st, k);
     HIP_TRY(hipGetLastError());
     return ISEGMI_OK;
 }
 
-template <int BM, int BN, int WM, int WN, int NSTAGE, int OCC, bool STEM = false>
+template <int BM, int BN, int WM, int WN, int NSTAGE, int OCC, bool STEM = false, int LW = 0>
 static int launch_g(ConvKH& k, hipStream_t st) {
     k.mtiles = cdiv(k.M, BM);
     k.ntiles = cdiv(k.Cout, BN);
@@ -480,8 +522,8 @@ static int launch_g(ConvKH& k, hipStream_t st) {
     const size_t epi = (size_t)NW * 32 * (TN * 32 + 4) * 4;
     if (epi > lds) lds = epi;
     static bool attr = false;
-    if (!attr) { HIP_TRY(hipFuncSetAttribute((const void*)conv_f16_glds_kernel<BM, BN, WM, WN, NSTAGE, OCC, STEM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
-    hipLaunchKernelGGL((conv_f16_glds_kernel<BM, BN, WM, WN, NSTAGE, OCC, STEM>), dim3((unsigned)(k.mtiles * k.ntiles)), dim3(NW * 64), lds, st, k);
+    if (!attr) { HIP_TRY(hipFuncSetAttribute((const void*)conv_f16_glds_kernel<BM, BN, WM, WN, NSTAGE, OCC, STEM, LW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+    hipLaunchKernelGGL((conv_f16_glds_kernel<BM, BN, WM, WN, NSTAGE, OCC, STEM, LW>), dim3((unsigned)(k.mtiles * k.ntiles)), dim3((NW + LW) * 64), lds, st, k);
     HIP_TRY(hipGetLastError());
     return ISEGMI_OK;
 }
@@ -547,8 +589,10 @@ int conv2d_f16_launch(const isegmi_conv_desc* d, const void* in, const void* w, 
             {1, 256, 256, 1, 1.0}, {2, 256, 128, 1, 0.95}, {3, 128, 128, 2, 0.85}, {4, 64, 64, 3, 0.6}, {5, 64, 128, 3, 0.75},
             {6, 64, 256, 2, 0.75}, {7, 128, 256, 1, 0.95}, {8, 128, 64, 2, 0.6}, {9, 192, 256, 1, 1.0}, {10, 192, 128, 2, 1.0},
             {11, 160, 256, 1, 0.88},
-            // row-strip variants (3x3 / stride 1 / pad 1 only): ~2.7x fewer A bytes through the CU's fill path
-            {22, 192, 256, 1, 1.10}, {23, 256, 128, 1, 1.03}, {24, 160, 256, 1, 0.93}};
+            // + 4 dedicated loader waves (the MFMA waves issue no LDS-DMA)
+            {12, 192, 256, 1, 1.11}, {13, 256, 256, 1, 1.08}, {14, 256, 128, 1, 0.97}, {16, 160, 256, 1, 0.975},
+            // row-strip variants (3x3 / stride 1 / pad 1 only: ~2.7x fewer A bytes through the CU's fill path) + 4 loader waves
+            {26, 192, 256, 1, 1.18}, {27, 256, 128, 1, 1.03}, {28, 160, 256, 1, 1.0}};
         const bool strip_ok = d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1;
         double best = 0.0;
         for (const auto& t : T) {
@@ -560,15 +604,19 @@ int conv2d_f16_launch(const isegmi_conv_desc* d, const void* in, const void* w, 
             if (tile == 0 || c < best) { best = c; tile = t.id; }
         }
     }
-    if (tile >= 21 && tile <= 24) {
+    if (tile >= 21 && tile <= 28) {
         ARG_CHECK(d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1, "strip tiles are for 3x3 / stride 1 / pad 1");
-        const int bm = tile == 21 ? 256 : tile == 22 ? 192 : tile == 23 ? 256 : 160;
+        const int bm = (tile == 21 || tile == 23 || tile == 25 || tile == 27) ? 256 : (tile == 22 || tile == 26) ? 192 : 160;
         ARG_CHECK((bm - 1) / d->W + 2 <= 32, "strip tile: too many image-row segments (W too small)");
         switch (tile) {
             case 21: return launch_strip<256, 256, 2, 4>(k, st);
             case 22: return launch_strip<192, 256, 2, 4>(k, st);
             case 23: return launch_strip<256, 128, 4, 2>(k, st);
-            default: return launch_strip<160, 256, 1, 8>(k, st);
+            case 24: return launch_strip<160, 256, 1, 8>(k, st);
+            case 25: return launch_strip<256, 256, 2, 4, 4>(k, st);  // + 4 loader waves
+            case 26: return launch_strip<192, 256, 2, 4, 4>(k, st);
+            case 27: return launch_strip<256, 128, 4, 2, 4>(k, st);
+            default: return launch_strip<160, 256, 1, 8, 4>(k, st);
         }
     }
     switch (tile) {
@@ -583,9 +631,13 @@ int conv2d_f16_launch(const isegmi_conv_desc* d, const void* in, const void* w, 
         case 9: return launch_g<192, 256, 2, 4, 2, 1>(k, st);   // wave tile 96x64
         case 10: return launch_g<192, 128, 2, 2, 2, 2>(k, st);
         case 11: return launch_g<160, 256, 1, 8, 2, 1>(k, st);
-        case 12: return launch_g<256, 128, 4, 2, 2, 1>(k, st);  // experiment: t2 with a 2-deep ring
-        case 13: return launch_g<128, 128, 2, 2, 4, 1>(k, st);  // experiment: 128x128, 4-deep ring, 1 block/CU
-        case 14: return launch_g<128, 128, 4, 2, 4, 1>(k, st);  // experiment: 128x128, 8 waves (wave tile 32x64), 4-deep ring  // wave tile 160x32; 20 A pieces over 8 waves (partial round)
+        case 12: return launch_g<192, 256, 2, 4, 2, 1, false, 4>(k, st);  // 8 MFMA waves + 4 loader waves
+        case 13: return launch_g<256, 256, 2, 4, 2, 1, false, 4>(k, st);
+        case 14: return launch_g<256, 128, 4, 2, 3, 1, false, 4>(k, st);
+        case 15: return launch_g<192, 256, 2, 4, 2, 1, false, 8>(k, st);
+        case 16: return launch_g<160, 256, 1, 8, 2, 1, false, 4>(k, st);
+        case 17: return launch_g<192, 128, 2, 2, 2, 2, false, 2>(k, st);
+        case 18: return launch_g<128, 128, 2, 2, 2, 2, false, 2>(k, st);  // wave tile 160x32; 20 A pieces over 8 waves (partial round)
         default: break;
     }
     ARG_CHECK(false, "unknown fp16 conv tile");
