@@ -168,6 +168,10 @@ int isegmi_op_roi_align(const float* const* d_feats, const int32_t* Hs, const in
                         const float* scales, int nlevels, const float* d_rois, const int32_t* d_counts,
                         int N, int K, int C, int PH, int PW, int sampling, int k_min, int fixed_level,
                         float* d_out, int32_t* d_out_level, void* stream);
+/* fp16-storage LevelMapper + RoIAlign (configs[4]): d_feats / d_out are fp16, arithmetic is the fp32 op's. */
+int isegmi_op_roi_align_f16(const void* const* d_feats, const int32_t* Hs, const int32_t* Ws,
+                            const float* scales, int nlevels, const float* d_rois, const int32_t* d_counts,
+                            int N, int K, int C, int PH, int PW, int sampling, int k_min, void* d_out, void* stream);
 /* PostProcessor.filter_results (A.5): softmax, per-class decode(10,10,5,5)+clip, score filter, NMS,
  * kth-value cut to det_per_img.  Output order: class ascending, NMS order inside a class. */
 typedef struct isegmi_box_post_args {

@@ -131,6 +131,70 @@ __global__ __launch_bounds__(256) void roi_align_f16_kernel(const RoiLevelsH lv,
     }
 }
 
+// One 256-thread block per RoI, 8 channels (16 B) per lane: C/8 lanes cover a bin, the block walks the PH*PW bins 256/(C/8) at
+// a time, and the per-RoI arithmetic (level, scale, bin size) is done once per thread instead of once per output element.
+// Per-channel arithmetic and its order are those of roi_align_f16_kernel (same bits out).
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void roi_align_f16_c8_kernel(const RoiLevelsH lv, const float* __restrict__ rois, const int* __restrict__ counts,
+                                                                int K, int C, int PH, int PW, int g, int k_min, int k_max, half_t* __restrict__ out) {
+    const int c8n = C >> 3, bpp = 256 / c8n;         // lanes per bin, bins per pass
+    const int c8 = threadIdx.x % c8n, slot = threadIdx.x / c8n;
+    const int n = blockIdx.x / K, k = blockIdx.x - n * K;
+    const int nb = PH * PW;
+    half_t* o = out + ((int64_t)blockIdx.x * nb) * C + c8 * 8;
+    if (k >= counts[n]) {
+        const h8 z = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+        for (int b = slot; b < nb; b += bpp) *(h8*)(o + (int64_t)b * C) = z;
+        return;
+    }
+    const float4 bx = *(const float4*)(rois + ((int64_t)n * K + k) * 4);
+    const int li = level_of_h(bx, k_min, k_max) - k_min;
+    const int H = lv.H[li], W = lv.W[li];
+    const float sc = lv.scale[li];
+    const half_t* f = lv.feat[li] + (int64_t)n * H * W * C + c8 * 8;
+    const float sw = bx.x * sc, sh = bx.y * sc, ew = bx.z * sc, eh = bx.w * sc;
+    float rw = ew - sw, rh = eh - sh;
+    rw = rw > 1.0f ? rw : 1.0f;
+    rh = rh > 1.0f ? rh : 1.0f;
+    const float bh = dm_div(rh, (float)PH), bw = dm_div(rw, (float)PW);
+    const float cnt = (float)(g * g);
+    for (int b = slot; b < nb; b += bpp) {
+        const int ph = b / PW, pw = b - ph * PW;
+        float acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = 0.0f;
+        for (int iy = 0; iy < g; ++iy) {
+            float y = sh + (float)ph * bh + dm_div(((float)iy + 0.5f) * bh, (float)g);
+            for (int ix = 0; ix < g; ++ix) {
+                float x = sw + (float)pw * bw + dm_div(((float)ix + 0.5f) * bw, (float)g);
+                float yy = y;
+                if (yy < -1.0f || yy > (float)H || x < -1.0f || x > (float)W) continue;  // sample contributes +0
+                if (yy <= 0.0f) yy = 0.0f;
+                if (x <= 0.0f) x = 0.0f;
+                int yl = (int)yy, xl = (int)x, yh, xh;
+                if (yl >= H - 1) { yh = yl = H - 1; yy = (float)yl; } else yh = yl + 1;
+                if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else xh = xl + 1;
+                const float ly = yy - (float)yl, lx = x - (float)xl, hy = 1.0f - ly, hx = 1.0f - lx;
+                const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+                const h8 v1 = *(const h8*)(f + ((int64_t)yl * W + xl) * C), v2 = *(const h8*)(f + ((int64_t)yl * W + xh) * C);
+                const h8 v3 = *(const h8*)(f + ((int64_t)yh * W + xl) * C), v4 = *(const h8*)(f + ((int64_t)yh * W + xh) * C);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float v = w1 * (float)v1[i];
+                    v = v + w2 * (float)v2[i];
+                    v = v + w3 * (float)v3[i];
+                    v = v + w4 * (float)v4[i];
+                    acc[i] = acc[i] + v;
+                }
+            }
+        }
+        h8 r;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r[i] = (half_t)dm_div(acc[i], cnt);
+        *(h8*)(o + (int64_t)b * C) = r;
+    }
+}
+
 __global__ __launch_bounds__(256) void mask_logits_select_f16_kernel(const half_t* __restrict__ feat, int HW, int C, const float* __restrict__ w,
                                                                       const float* __restrict__ b, const int* __restrict__ labels,
                                                                       float* __restrict__ out) {
@@ -209,8 +273,14 @@ int roi_align_f16_launch(const void* const* feats, const int* Hs, const int* Ws,
         const int s = i < nlevels ? i : nlevels - 1;
         lv.feat[i] = (const half_t*)feats[s]; lv.H[i] = Hs[s]; lv.W[i] = Ws[s]; lv.scale[i] = scales[s];
     }
-    hipLaunchKernelGGL(roi_align_f16_kernel, dim3(gridf((int64_t)N * K * PH * PW * (C / 4))), dim3(256), 0, st, lv, rois, counts, N, K, C, PH, PW,
-                       g, k_min, k_min + nlevels - 1, (half_t*)out);
+    if (C % 8 == 0 && 256 % (C / 8) == 0 && (int64_t)N * K < (1ll << 31)) {
+        if (N * K > 0)
+            hipLaunchKernelGGL(roi_align_f16_c8_kernel, dim3((unsigned)(N * K)), dim3(256), 0, st, lv, rois, counts, K, C, PH, PW, g, k_min,
+                               k_min + nlevels - 1, (half_t*)out);
+    } else {
+        hipLaunchKernelGGL(roi_align_f16_kernel, dim3(gridf((int64_t)N * K * PH * PW * (C / 4))), dim3(256), 0, st, lv, rois, counts, N, K, C, PH, PW,
+                           g, k_min, k_min + nlevels - 1, (half_t*)out);
+    }
     HIP_TRY(hipGetLastError());
     return ISEGMI_OK;
 }
@@ -227,4 +297,11 @@ int mask_logits_select_f16_launch(const void* feat, int R, int HW, int C, const 
 extern "C" int isegmi_op_pad_c3_to_f16_halo(const float* d_in_nhwc3, int N, int H, int W, void* d_out, void* stream) {
     ARG_CHECK(d_in_nhwc3 && d_out && N > 0 && H > 0 && W > 0, "args");
     return isegmi::pad_c3_to_f16_halo_launch(d_in_nhwc3, N, H, W, d_out, (hipStream_t)stream);
+}
+extern "C" int isegmi_op_roi_align_f16(const void* const* d_feats, const int32_t* Hs, const int32_t* Ws, const float* scales, int nlevels,
+                                       const float* d_rois, const int32_t* d_counts, int N, int K, int C, int PH, int PW, int sampling, int k_min,
+                                       void* d_out, void* stream) {
+    ARG_CHECK(d_feats && Hs && Ws && scales && d_rois && d_counts && d_out && N > 0 && K > 0 && PH > 0 && PW > 0 && sampling > 0, "args");
+    return isegmi::roi_align_f16_launch(d_feats, Hs, Ws, scales, nlevels, d_rois, d_counts, N, K, C, PH, PW, sampling, k_min, d_out,
+                                        (hipStream_t)stream);
 }

@@ -274,6 +274,20 @@ def roi_align(feats, scales, rois, counts, PH, PW, sampling=2, k_min=2, fixed_le
     return do.numpy(), dl.numpy()
 
 
+def roi_align_f16(feats, scales, rois, counts, PH, PW, sampling=2, k_min=2):
+    """fp16-storage RoIAlign: feats list of [N,H,W,C] (cast to fp16) -> out [N*K,PH,PW,C] fp16."""
+    fb = [DeviceBuffer.from_numpy(np.ascontiguousarray(f, np.float16)) for f in feats]
+    N, K = rois.shape[:2]
+    Cc = feats[0].shape[3]
+    ptrs = (C.c_void_p * len(fb))(*[b.ptr.value for b in fb])
+    Hs = (C.c_int32 * len(fb))(*[f.shape[1] for f in feats]); Ws = (C.c_int32 * len(fb))(*[f.shape[2] for f in feats])
+    sc = (C.c_float * len(fb))(*scales)
+    dr = DeviceBuffer.from_numpy(np.ascontiguousarray(rois, np.float32)); dcnt = DeviceBuffer.from_numpy(np.ascontiguousarray(counts, np.int32))
+    do = DeviceBuffer((N * K, PH, PW, Cc), np.float16)
+    check(lib().isegmi_op_roi_align_f16(ptrs, Hs, Ws, sc, len(fb), dr.ptr, dcnt.ptr, N, K, Cc, PH, PW, sampling, k_min, do.ptr, None))
+    return do.numpy()
+
+
 class BoxPostArgs(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("N", "R", "ncls", "det_per_img", "cap", "nms_ge")] + \
                [("score_thresh", C.c_float), ("nms_thresh", C.c_float), ("logits_stride", C.c_int64), ("regr_stride", C.c_int64)] + \

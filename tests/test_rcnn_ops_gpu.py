@@ -73,6 +73,33 @@ def test_roi_align_matches_oracle(ffi):
     assert np.allclose(o, 3.5, rtol=0, atol=2e-6)  # bilinear weights sum to 1 only up to rounding
 
 
+@pytest.mark.parametrize("Cc", [256, 64, 36])  # 256 / 64: 8-channel-per-lane kernel; 36: generic 4-channel kernel
+def test_roi_align_f16_matches_oracle_on_fp16_features(ffi, Cc):
+    """fp16-storage RoIAlign: same fp32 arithmetic on fp16-rounded features, result rounded to fp16 -> exact match."""
+    rng = np.random.default_rng(12)
+    N, K = 2, 60
+    shapes = [(50, 84), (25, 42), (13, 21), (7, 11)]
+    feats = [rng.standard_normal((N, h, w, Cc)).astype(np.float16) for h, w in shapes]
+    scales = [0.25, 0.125, 0.0625, 0.03125]
+    rois = np.stack([_boxes(rng, K, 336, 200, False) for _ in range(N)])
+    rois[0, 0] = [-50, -40, -10, -5]
+    rois[0, 1] = [10, 10, 10.2, 10.1]
+    counts = np.array([K, 41], np.int32)
+    for PH in (7, 14):
+        out = ffi.roi_align_f16(feats, scales, rois, counts, PH, PH).reshape(N, K, PH, PH, Cc)
+        for n in range(N):
+            k = counts[n]
+            ref_lv = ora.level_map(rois[n, :k])
+            for L in range(2, 6):
+                idx = np.nonzero(ref_lv == L)[0]
+                if len(idx) == 0:
+                    continue
+                r5 = np.concatenate([np.full((len(idx), 1), n, np.float32), rois[n, idx]], 1)
+                ref = ora.roi_align(feats[L - 2].astype(np.float32), r5, scales[L - 2], PH, PH, 2).astype(np.float16)
+                assert np.array_equal(out[n, idx], ref), (PH, n, L)
+            assert not out[n, k:].any()
+
+
 def test_rpn_level_matches_oracle(ffi):
     from isegmi.maskrcnn import generate_anchors, grid_anchors
     rng = np.random.default_rng(5)
