@@ -55,8 +55,21 @@ def parse():
     return ap.parse_args()
 
 
+_JSON_FD = None
+
+
+def emit(line):
+    """The ONE JSON line goes to the process's original stdout; fd 1 itself points at stderr for the whole run, so
+    that library banners (RCCL version banner, gloo's connection message ...) cannot precede or follow it."""
+    os.write(_JSON_FD if _JSON_FD is not None else 1, (line + "\n").encode())
+
+
 def main():
+    global _JSON_FD
     a = parse()
+    sys.stdout.flush()
+    _JSON_FD = os.dup(1)
+    os.dup2(2, 1)
     if a.model == "maskrcnn":
         return main_maskrcnn(a)
     a.batch = a.batch or 8
@@ -98,11 +111,6 @@ def main():
         if rank == 0:
             uid = torch.frombuffer(bytearray(RcclGather.unique_id()), dtype=torch.uint8).clone()
         dist.broadcast(uid, 0)
-        # RCCL prints a version banner on stdout at communicator creation; keep stdout to the ONE JSON line
-        # (printed at init or at the first collective: stdout stays redirected until warm-up is done)
-        sys.stdout.flush()
-        saved_stdout = os.dup(1)
-        os.dup2(2, 1)
         gather = RcclGather(rank, world, bytes(uid.numpy().tobytes()), record_bytes(a.batch))
 
     def step():
@@ -120,9 +128,6 @@ def main():
     for _ in range(max(a.warmup, 1 if gather is not None else 0)):
         step()
     full_sync()
-    if gather is not None:
-        os.dup2(saved_stdout, 1)
-        os.close(saved_stdout)
     import ctypes as C
     f, m, l = C.c_double(), C.c_double(), C.c_int64()
 
@@ -254,7 +259,7 @@ def main():
         out["parity_vs_oracle_on_bench_batch"] = bool(ok)
 
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
     if gather is not None:
         gather.close()
     net.close()
@@ -296,7 +301,6 @@ def main_maskrcnn(a):
         if rank == 0:
             uid = torch.frombuffer(bytearray(RcclGather.unique_id()), dtype=torch.uint8).clone()
         dist.broadcast(uid, 0)
-        sys.stdout.flush(); saved_stdout = os.dup(1); os.dup2(2, 1)
         gather = RcclGather(rank, world, bytes(uid.numpy().tobytes()), maskrcnn_record_bytes(a.batch))
 
     def step():
@@ -309,7 +313,7 @@ def main_maskrcnn(a):
         step()
     model.sync(); _ffi.sync()
     if gather is not None:
-        gather.wait(); os.dup2(saved_stdout, 1); os.close(saved_stdout)
+        gather.wait()
     f, m, l = C.c_double(), C.c_double(), C.c_int64()
     if dist is not None:
         dist.barrier()
@@ -397,7 +401,7 @@ def main_maskrcnn(a):
                                    "sample": "%d passes over 1 image of the bench batch, oracle/ C+numpy restatement (AVX2 FMA + OpenMP, %d threads), %.1f s" % (done, ncpu, tcpu)}
             got = model.fetch("det.box", 1)[0]
             out["parity_vs_oracle_on_bench_batch"] = bool(np.array_equal(got[: len(d[0]["box"])], d[0]["box"]))
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
     model.close()
     if dist is not None:
         dist.barrier(); dist.destroy_process_group()
