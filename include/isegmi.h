@@ -99,7 +99,7 @@ int isegmi_op_map_f32(const float* d_x, float* d_y, int64_t n, int fn, void* str
 
 /* ---- selection: torch.topk / sort stand-in (M6, M9, Y6) ----
  * rows independent problems; row r = d_keys + r*row_stride, n elements; output sorted by
- * (score desc, index asc); k <= 1024.  k_eff = min(k, n, d_limit[r / rows_per_limit]) when
+ * (score desc, index asc); k <= 8192.  k_eff = min(k, n, d_limit[r / rows_per_limit]) when
  * d_limit != NULL.  d_vals/d_idx are [rows][k]; d_cnt [rows] (optional) receives k_eff. */
 int isegmi_op_topk(const float* d_keys, int64_t row_stride, int rows, int n, int k,
                    const int32_t* d_limit, int rows_per_limit, float* d_vals, int32_t* d_idx,
@@ -156,7 +156,7 @@ int isegmi_op_yolact_masks(const float* d_proto, const float* d_coeffs, const fl
                            void* stream);
 
 /* ---- Mask R-CNN RoI ops (M6 M7 M9 M10 M11 M12; App. A.4-A.8; all reached from README.md:331) ---- */
-/* greedy NMS (A.6): `problems` independent sets of n <= 1024 boxes; visiting order (score desc, index
+/* greedy NMS (A.6): `problems` independent sets of n <= 6144 boxes; visiting order (score desc, index
  * asc); IoU with legacy +1 areas when plus_one; suppress on iou > thr (ge: >=).  d_keep [problems][n]
  * receives ORIGINAL indices in score order, d_cnt [problems] the count (<= max_keep when max_keep > 0). */
 int isegmi_op_nms(const float* d_boxes, const float* d_scores, int problems, int n, float thr,

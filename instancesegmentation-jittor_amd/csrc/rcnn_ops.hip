@@ -106,14 +106,18 @@ __device__ __forceinline__ bool iou_exceeds(const float4 a, const float4 b, floa
 // Writes kept positions (indices into sb) to kept[] in visiting order; returns the count (<= max_keep).
 // Chunk of 64: (1) 4 waves test the chunk against the kept list; (2) wave 0 resolves the chunk with one
 // ballot per surviving box.
-constexpr int NMS_CAP = 1024;
-struct NmsShared {
-    float4 sb[NMS_CAP];
-    unsigned short kept[NMS_CAP];
+constexpr int NMS_CAP = 1024;      // per-level FPN problems, per-class box NMS
+constexpr int NMS_CAP_BIG = 6144;  // single-map RPN (PRE_NMS_TOP_N_TEST 6000) and the n = 4819 unit case: 96 KB of boxes in LDS
+template <int CAP>
+struct NmsSharedT {
+    float4 sb[CAP];
+    unsigned short kept[CAP];
     unsigned long long supp[16];
     int kc;
 };
-__device__ int nms_block(NmsShared& S, int n, float thr, float one, int ge, int max_keep, const unsigned char* pre_dead) {
+typedef NmsSharedT<NMS_CAP> NmsShared;
+template <int CAP>
+__device__ int nms_block(NmsSharedT<CAP>& S, int n, float thr, float one, int ge, int max_keep, const unsigned char* pre_dead) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nw = blockDim.x >> 6;
     const IouThr T = make_iou_thr(thr, ge);
@@ -198,6 +202,30 @@ __global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ boxe
     if (threadIdx.x == 0) cnt[pb] = kc;
 }
 
+// Same op for 1024 < n <= NMS_CAP_BIG: the sort keys and the sorted boxes share one LDS region (the original indices are
+// parked in `order` in between), 1024 threads.
+__global__ __launch_bounds__(1024) void nms_big_kernel(const float* __restrict__ boxes, const float* __restrict__ scores, int n, float thr,
+                                                       int plus_one, int ge, int max_keep, int* __restrict__ keep, int* __restrict__ cnt) {
+    __shared__ NmsSharedT<NMS_CAP_BIG> S;
+    __shared__ unsigned short order[NMS_CAP_BIG];
+    unsigned long long* keys = (unsigned long long*)S.sb;  // 8192 keys = 64 KB <= 96 KB of sb
+    const int pb = blockIdx.x;
+    const float* b = boxes + (int64_t)pb * n * 4;
+    const float* sc = scores + (int64_t)pb * n;
+    const int np2 = next_pow2(n);
+    for (int i = threadIdx.x; i < np2; i += blockDim.x)
+        keys[i] = i < n ? (((unsigned long long)f2ord_(sc[i]) << 32) | (unsigned long long)(0xffffffffu - (unsigned)i)) : 0ull;
+    __syncthreads();
+    sort_desc_1024(keys, np2);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) order[i] = (unsigned short)(0xffffffffu - (unsigned)(keys[i] & 0xffffffffull));
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) S.sb[i] = *(const float4*)(b + (int64_t)order[i] * 4);
+    __syncthreads();
+    const int kc = nms_block(S, n, thr, plus_one ? 1.0f : 0.0f, ge, max_keep, nullptr);
+    for (int i = threadIdx.x; i < kc; i += blockDim.x) keep[(int64_t)pb * n + i] = (int)order[S.kept[i]];
+    if (threadIdx.x == 0) cnt[pb] = kc;
+}
+
 // ------------------------------------------------------------------ RPN
 // head [N][HW][CH] with CH = A*5: channel a = objectness logit of anchor a, channel A + a*4 + c = delta c.
 __global__ void rpn_sigmoid_kernel(const float* __restrict__ head, int64_t total, int A, int CH, float* __restrict__ prob) {
@@ -210,6 +238,7 @@ __global__ void rpn_sigmoid_kernel(const float* __restrict__ head, int64_t total
 
 // grid (N); one (image, level) per block.  tk_vals/tk_idx [N][pre_nms] sorted; tk_cnt [N].
 // out_boxes [N][L][post_cap][4], out_scores [N][L][post_cap] (-1 beyond count), out_cnt [N][L].
+template <int CAP>
 __global__ __launch_bounds__(1024) void rpn_decode_nms_kernel(const float* __restrict__ head, const float* __restrict__ anchors,
                                                               const float* __restrict__ tk_vals, const int* __restrict__ tk_idx,
                                                               const int* __restrict__ tk_cnt, const int* __restrict__ image_hw,
@@ -217,8 +246,8 @@ __global__ __launch_bounds__(1024) void rpn_decode_nms_kernel(const float* __res
                                                               float min_size, int ge, int level, int L, int post_cap,
                                                               float* __restrict__ out_boxes, float* __restrict__ out_scores,
                                                               int* __restrict__ out_cnt) {
-    __shared__ NmsShared S;
-    __shared__ unsigned char dead[NMS_CAP];
+    __shared__ NmsSharedT<CAP> S;
+    __shared__ unsigned char dead[CAP];
     const int n = blockIdx.x;
     const int cnt = tk_cnt[n];
     const float im_h = (float)image_hw[2 * n], im_w = (float)image_hw[2 * n + 1];
@@ -591,10 +620,11 @@ int scale_boxes_launch(const float* boxes, const float* ratios, int N, int K, fl
 
 int nms_launch(const float* boxes, const float* scores, int problems, int n, float thr, int plus_one, int ge, int max_keep, int* keep,
                int* cnt, hipStream_t st) {
-    ARG_CHECK(n > 0 && n <= NMS_CAP, "nms n must be in 1..1024");
+    ARG_CHECK(n > 0 && n <= NMS_CAP_BIG, "nms n must be in 1..6144");
     ARG_CHECK(thr > 0.0f, "nms threshold must be > 0");
     if (problems == 0) return ISEGMI_OK;
-    hipLaunchKernelGGL(nms_kernel, dim3(problems), dim3(256), 0, st, boxes, scores, n, thr, plus_one, ge, max_keep, keep, cnt);
+    if (n <= NMS_CAP) hipLaunchKernelGGL(nms_kernel, dim3(problems), dim3(256), 0, st, boxes, scores, n, thr, plus_one, ge, max_keep, keep, cnt);
+    else hipLaunchKernelGGL(nms_big_kernel, dim3(problems), dim3(1024), 0, st, boxes, scores, n, thr, plus_one, ge, max_keep, keep, cnt);
     HIP_TRY(hipGetLastError());
     return ISEGMI_OK;
 }
@@ -608,10 +638,14 @@ int rpn_sigmoid_launch(const float* head, int64_t total, int A, int CH, float* p
 int rpn_decode_nms_launch(const float* head, const float* anchors, const float* tk_vals, const int* tk_idx, const int* tk_cnt,
                           const int* image_hw, int N, int HWA, int A, int CH, int pre_nms, int post_nms, float thr, float min_size,
                           int ge, int level, int L, int post_cap, float* out_boxes, float* out_scores, int* out_cnt, hipStream_t st) {
-    ARG_CHECK(pre_nms <= NMS_CAP && post_nms <= post_cap, "rpn sizes");
+    ARG_CHECK(pre_nms <= NMS_CAP_BIG && post_nms <= post_cap, "rpn sizes (pre_nms <= 6144)");
     ARG_CHECK(thr > 0.0f, "nms threshold must be > 0");
-    hipLaunchKernelGGL(rpn_decode_nms_kernel, dim3(N), dim3(1024), 0, st, head, anchors, tk_vals, tk_idx, tk_cnt, image_hw, HWA, A, CH,
-                       pre_nms, post_nms, thr, min_size, ge, level, L, post_cap, out_boxes, out_scores, out_cnt);
+    if (pre_nms <= NMS_CAP)
+        hipLaunchKernelGGL(rpn_decode_nms_kernel<NMS_CAP>, dim3(N), dim3(1024), 0, st, head, anchors, tk_vals, tk_idx, tk_cnt, image_hw, HWA, A,
+                           CH, pre_nms, post_nms, thr, min_size, ge, level, L, post_cap, out_boxes, out_scores, out_cnt);
+    else
+        hipLaunchKernelGGL(rpn_decode_nms_kernel<NMS_CAP_BIG>, dim3(N), dim3(1024), 0, st, head, anchors, tk_vals, tk_idx, tk_cnt, image_hw, HWA,
+                           A, CH, pre_nms, post_nms, thr, min_size, ge, level, L, post_cap, out_boxes, out_scores, out_cnt);
     HIP_TRY(hipGetLastError());
     return ISEGMI_OK;
 }

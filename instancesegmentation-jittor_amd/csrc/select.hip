@@ -165,7 +165,7 @@ __global__ __launch_bounds__(NT) void topk_kernel(const TopkArgs a) {
 
 int topk_launch(const float* keys, int64_t row_stride, int rows, int n, int k, const int* limit, int rows_per_limit,
                 float* out_vals, int* out_idx, int* out_cnt, hipStream_t st) {
-    ARG_CHECK(rows >= 0 && n >= 0 && k > 0 && k <= 1024, "topk sizes (k <= 1024)");
+    ARG_CHECK(rows >= 0 && n >= 0 && k > 0 && k <= 8192, "topk sizes (k <= 8192)");
     if (rows == 0) return ISEGMI_OK;
     TopkArgs a{keys, row_stride, n, k, limit, rows_per_limit > 0 ? rows_per_limit : 1, out_vals, out_idx, out_cnt};
     if (k <= 128) {
@@ -174,9 +174,11 @@ int topk_launch(const float* keys, int64_t row_stride, int rows, int n, int k, c
     } else if (k <= 256) {
         if (n > 65536) hipLaunchKernelGGL((topk_kernel<1024, 256>), dim3(rows), dim3(1024), 0, st, a);
         else hipLaunchKernelGGL((topk_kernel<256, 256>), dim3(rows), dim3(256), 0, st, a);
-    } else {
+    } else if (k <= 1024) {
         if (n > 16384) hipLaunchKernelGGL((topk_kernel<1024, 1024>), dim3(rows), dim3(1024), 0, st, a);
         else hipLaunchKernelGGL((topk_kernel<256, 1024>), dim3(rows), dim3(256), 0, st, a);
+    } else {  // single-map RPN: PRE_NMS_TOP_N_TEST up to 6000 (64 KB of sort keys in LDS)
+        hipLaunchKernelGGL((topk_kernel<1024, 8192>), dim3(rows), dim3(1024), 0, st, a);
     }
     HIP_TRY(hipGetLastError());
     return ISEGMI_OK;

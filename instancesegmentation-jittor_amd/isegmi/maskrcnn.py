@@ -63,6 +63,22 @@ def generate_anchors(stride, size, aspect_ratios):
     return np.vstack(out).astype(np.float32)
 
 
+def generate_anchors_multi(stride, sizes, aspect_ratios):
+    """Single-feature-map form (R-50-C4: stride 16, sizes 32..512): ratio enumeration outside, ALL scales inside, i.e.
+    anchor index = ratio * len(sizes) + size (maskrcnn-benchmark generate_anchors with several sizes)."""
+    anchor = np.array([1, 1, stride, stride], np.float64) - 1
+    w, h, xc, yc = _whctrs(anchor)
+    ratios = np.asarray(aspect_ratios, np.float64)
+    ws = np.round(np.sqrt(w * h / ratios)); hs = np.round(ws * ratios)
+    ra = _mkanchors(ws, hs, xc, yc)
+    scales = np.asarray(sizes, np.float64) / stride
+    out = []
+    for i in range(ra.shape[0]):
+        w, h, xc, yc = _whctrs(ra[i])
+        out.append(_mkanchors(w * scales, h * scales, xc, yc))
+    return np.vstack(out).astype(np.float32)
+
+
 def grid_anchors(grid_h, grid_w, stride, base):
     sx = np.arange(0, grid_w * stride, stride, dtype=np.float32)
     sy = np.arange(0, grid_h * stride, stride, dtype=np.float32)

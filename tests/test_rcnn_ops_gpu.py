@@ -16,11 +16,11 @@ def _boxes(rng, n, W=1333, H=800, clustered=True):
     return np.clip(b, 0, [W - 1, H - 1, W - 1, H - 1]).astype(np.float32)
 
 
-@pytest.mark.parametrize("n", [3, 64, 200, 1000])
+@pytest.mark.parametrize("n", [3, 64, 200, 1000, 1025, 4819, 6000])  # SURVEY 8d unit sizes; > 1024 takes the 6144-box LDS kernel
 @pytest.mark.parametrize("plus_one,ge", [(1, 0), (1, 1), (0, 0)])
 def test_nms_matches_oracle(ffi, n, plus_one, ge):
     rng = np.random.default_rng(n + plus_one * 10 + ge)
-    P = 4
+    P = 4 if n <= 1024 else 2
     boxes = np.stack([_boxes(rng, n) for _ in range(P)])
     scores = rng.uniform(0, 1, (P, n)).astype(np.float32)
     scores[:, ::7] = scores[:, :1]  # ties
@@ -115,6 +115,26 @@ def test_rpn_level_matches_oracle(ffi):
                                    float(hw[n, 1]), float(hw[n, 0]))
             assert np.array_equal(got[n][1], rs) and np.array_equal(got[n][0], rb), (pre, n)
             assert len(rs) > 10
+
+
+def test_rpn_single_map_6000_matches_oracle(ffi):
+    """R-50-C4 style RPN: one stride-16 map, 15 anchors per location (5 sizes x 3 ratios), PRE_NMS_TOP_N_TEST 6000 ->
+    NMS 0.7 -> 1000 (README.md:267-269).  Exercises the k <= 8192 top-k and the 6144-box NMS kernels."""
+    from isegmi.maskrcnn import generate_anchors_multi, grid_anchors
+    rng = np.random.default_rng(15)
+    N, H, W, A = 2, 40, 60, 15
+    head = np.concatenate([rng.normal(-2, 2, (N, H, W, A)), rng.normal(0, 0.3, (N, H, W, 4 * A))], -1).astype(np.float32)
+    head[1, :6, :6, :A] = 0.75  # ties in the top-k
+    anchors = grid_anchors(H, W, 16, generate_anchors_multi(16, (32, 64, 128, 256, 512), (0.5, 1.0, 2.0)))
+    assert anchors.shape == (H * W * A, 4)
+    hw = np.array([[640, 960], [600, 900]], np.int32)
+    for pre, post in ((6000, 1000), (3000, 300)):
+        got = ffi.rpn_level(head, anchors, hw, A, pre, post)
+        for n in range(N):
+            rb, rs = ora.rpn_level(head[n, ..., :A].reshape(-1), head[n, ..., A:].reshape(-1, 4), anchors, pre, post, 0.7, 0.0,
+                                   float(hw[n, 1]), float(hw[n, 0]))
+            assert np.array_equal(got[n][1], rs) and np.array_equal(got[n][0], rb), (pre, n)
+            assert len(rs) > 100
 
 
 def test_box_postprocess_matches_oracle(ffi):

@@ -7,7 +7,8 @@ from oracle import ora
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("rows,n,k", [(3, 1000, 100), (2, 19248, 200), (1, 201600, 1000), (5, 50, 100), (2, 4096, 1000), (1, 70000, 128)])
+@pytest.mark.parametrize("rows,n,k", [(3, 1000, 100), (2, 19248, 200), (1, 201600, 1000), (5, 50, 100), (2, 4096, 1000), (1, 70000, 128), (2, 63000, 6000), (1, 9000, 8192),
+                                      (2, 5000, 4819)])
 def test_topk_matches_oracle(ffi, rows, n, k):
     rng = np.random.default_rng(rows * 1000 + n + k)
     keys = rng.uniform(0, 1, (rows, n)).astype(np.float32)

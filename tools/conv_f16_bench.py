@@ -9,9 +9,12 @@ shapes = [(8, 200, 336, 256, 256, 3, 1, 1), (8, 100, 168, 256, 256, 3, 1, 1), (8
           (8, 200, 336, 64, 64, 3, 1, 1), (8, 100, 168, 128, 512, 1, 1, 0), (8, 100, 168, 128, 128, 3, 1, 1),
           (8, 50, 84, 1024, 256, 1, 1, 0), (8, 50, 84, 256, 256, 3, 1, 1), (8, 50, 84, 256, 1024, 1, 1, 0), (8, 25, 42, 512, 512, 3, 1, 1),
           (8, 25, 42, 512, 2048, 1, 1, 0), (800, 14, 14, 256, 256, 3, 1, 1), (8000, 7, 7, 256, 1024, 7, 1, 0)]
-TILES = [int(t) for t in sys.argv[1].split(",")] if len(sys.argv) > 1 else [9, 12, 15, 11, 16, 10, 17, 3, 18, 22, 26, 27, 28]
+TILES = [int(t) for t in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0, 1, 2, 3, 4, 5, 9, 10, 11, 12, 13, 14, 16, 26, 27, 28]
 WITH_RES = len(sys.argv) > 2 and sys.argv[2] == "res"
-for (N, H, W, Cin, Cout, R, st, pad) in shapes:
+ONLY = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else None
+for si, (N, H, W, Cin, Cout, R, st, pad) in enumerate(shapes):
+    if ONLY is not None and si not in ONLY:
+        continue
     x = rng.standard_normal((N, H, W, Cin)).astype(np.float16)
     w = (rng.standard_normal((Cout, R, R, Cin)) * 0.05).astype(np.float32)
     ho, wo = (H + 2 * pad - R) // st + 1, (W + 2 * pad - R) // st + 1
