@@ -163,11 +163,15 @@ int isegmi_op_nms(const float* d_boxes, const float* d_scores, int problems, int
                   int plus_one, int ge, int max_keep, int32_t* d_keep, int32_t* d_cnt, void* stream);
 /* LevelMapper + RoIAlign (A.7, legacy aligned=False).  d_feats: host array of nlevels device pointers
  * (NHWC, level k_min first); rois [N][K][4] image coords; counts [N]; out [N*K][PH][PW][C] (rows past
- * count zero-filled).  fixed_level >= 0 bypasses the LevelMapper.  d_out_level [N][K] optional. */
+ * count zero-filled).  fixed_level >= 0 bypasses the LevelMapper.  d_out_level [N][K] optional.
+ * sampling > 0: fixed sampling x sampling grid per bin; sampling <= 0: adaptive ceil(roi / pooled) (ROIAlign's
+ * sampling_ratio = 0, used by the R-50-C4 config of README.md:263-273). */
 int isegmi_op_roi_align(const float* const* d_feats, const int32_t* Hs, const int32_t* Ws,
                         const float* scales, int nlevels, const float* d_rois, const int32_t* d_counts,
                         int N, int K, int C, int PH, int PW, int sampling, int k_min, int fixed_level,
                         float* d_out, int32_t* d_out_level, void* stream);
+/* nn.AvgPool2d over the whole window of every RoI (FastRCNNPredictor of the C4 box head): x [R][HW][C] -> out [R][C] */
+int isegmi_op_avgpool_full(const float* d_x, int64_t R, int HW, int C, float* d_out, void* stream);
 /* fp16-storage LevelMapper + RoIAlign (configs[4]): d_feats / d_out are fp16, arithmetic is the fp32 op's. */
 int isegmi_op_roi_align_f16(const void* const* d_feats, const int32_t* Hs, const int32_t* Ws,
                             const float* scales, int nlevels, const float* d_rois, const int32_t* d_counts,

@@ -29,6 +29,8 @@ int mask_logits_select_launch(const float* feat, int R, int HW, int C, const flo
 int paste_masks_launch(const float* masks, const float* boxes, const int* counts, int N, int K, int M, int im_h, int im_w, float thr,
                        uint8_t* out, hipStream_t st);
 int scale_boxes_launch(const float* boxes, const float* ratios, int N, int K, float* out, hipStream_t st);
+int topk_launch(const float* keys, int64_t row_stride, int rows, int n, int k, const int* limit, int rows_per_limit, float* out_vals,
+                int* out_idx, int* out_cnt, hipStream_t st);
 
 #define TRY(x)               \
     do {                     \
@@ -59,7 +61,10 @@ int maskrcnn_set_image_hw(Engine& e, const int32_t* h_image_hw, int N) {
     return ISEGMI_OK;
 }
 
+static int maskrcnn_c4_forward(Engine& e, const float* d_images, int N);
+
 int maskrcnn_forward(Engine& e, const float* d_images, int N) {
+    if (e.param("arch_c4", 0.0f) != 0.0f) return maskrcnn_c4_forward(e, d_images, N);
     const int H = e.H, W = e.W;
     if (H % 32 || W % 32) { set_error("Mask R-CNN input must be padded to a multiple of 32"); return ISEGMI_ERR_ARG; }
     e.cur = e.stream;
@@ -273,6 +278,161 @@ int maskrcnn_forward(Engine& e, const float* d_images, int N) {
 #undef st
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// e2e_mask_rcnn_R_50_C4_1x (the config README.md:263-273 prints): ResNet-50 conv1..conv4 -> one stride-16 map (1024 ch) ->
+// RPNHead (3x3 1024->1024, 15 anchors: 5 sizes x 3 ratios, ratio-major) -> top PRE_NMS_TOP_N_TEST (6000) -> decode / clip /
+// NMS 0.7 -> POST_NMS_TOP_N_TEST (1000), no cross-level merge -> ROIAlign 14x14, 1/16, sampling_ratio 0 (adaptive) ->
+// ResNet conv5 head (3 bottlenecks, the first with stride 2) -> 7x7x2048 -> AvgPool 7 -> FastRCNNPredictor (81 | 324) ->
+// box post-processing as in the FPN model -> the SAME extractor on the detections (SHARE_BOX_FEATURE_EXTRACTOR) ->
+// MaskRCNNC4Predictor: ConvTranspose 2x2/2 2048->256 + ReLU -> 1x1 -> 81 -> sigmoid, class-selected: 14x14 masks.
+// fp32 only; single stream (the RoI heads are ~1.5 TFLOP per image here and dominate).
+static int res5_head(Engine& e, const std::string& prefix, const std::string& tag, const Tensor& in, Tensor* out) {
+    Tensor x = in;
+    for (int b = 0; b < 3; ++b) {
+        const std::string nm = prefix + "." + std::to_string(b);
+        const std::string bt = tag + "." + std::to_string(b);
+        const int sd = b == 0 ? 2 : 1;
+        Tensor idt = x, t1, t2, y;
+        if (b == 0) TRY(eng_conv(e, nm + ".downsample.0", x, sd, 0, 0, nullptr, bt + ".ds", &idt));
+        TRY(eng_conv(e, nm + ".conv1", x, sd, 0, 1, nullptr, bt + ".t1", &t1));  // STRIDE_IN_1X1
+        TRY(eng_conv(e, nm + ".conv2", t1, 1, 1, 1, nullptr, bt + ".t2", &t2));
+        TRY(eng_conv(e, nm + ".conv3", t2, 1, 0, 1, &idt, bt + ".out", &y));
+        x = y;
+    }
+    *out = x;
+    return ISEGMI_OK;
+}
+
+static int maskrcnn_c4_forward(Engine& e, const float* d_images, int N) {
+    const int H = e.H, W = e.W;
+    if (H % 16 || W % 16) { set_error("Mask R-CNN C4 input must be padded to a multiple of 16"); return ISEGMI_ERR_ARG; }
+    if (e.fp16) { set_error("the C4 configuration is fp32 only"); return ISEGMI_ERR_STATE; }
+    if (e.multi_stream && e.tail_pending && !e.capturing) HIP_TRY(hipStreamWaitEvent(e.stream, e.tail_done, 0));
+    e.cur = e.stream;
+    hipStream_t st = e.stream;
+    eng_mark(e, "start");
+    void* p;
+    TRY(eng_buf(e, "image_hw", (int64_t)N * 8, &p, 1, {N, 2}));
+    int* d_hw = (int*)p;
+    Tensor x4, s, x;
+    TRY(eng_act(e, "input4", N, H, W, 4, &x4));
+    TRY(pad_c3_c4_launch(d_images, (int64_t)N * H * W, x4.d, st));
+    TRY(eng_conv(e, "backbone.body.stem.conv1", x4, 2, 3, 1, nullptr, "stem", &s));
+    {
+        const int Ho = (s.H + 2 - 3) / 2 + 1, Wo = (s.W + 2 - 3) / 2 + 1;
+        TRY(eng_act(e, "pool", N, Ho, Wo, s.C, &x));
+        TRY(maxpool_launch(s.d, N, s.H, s.W, s.C, 3, 2, 1, x.d, st));
+    }
+    const int blocks[3] = {3, 4, 6};
+    for (int li = 0; li < 3; ++li)
+        for (int b = 0; b < blocks[li]; ++b) {
+            const std::string nm = "backbone.body.layer" + std::to_string(li + 1) + "." + std::to_string(b);
+            const int sd = (b == 0 && li > 0) ? 2 : 1;
+            Tensor idt = x, t1, t2, y;
+            if (b == 0) TRY(eng_conv(e, nm + ".downsample.0", x, sd, 0, 0, nullptr, nm + ".ds", &idt));
+            TRY(eng_conv(e, nm + ".conv1", x, sd, 0, 1, nullptr, nm + ".t1", &t1));
+            TRY(eng_conv(e, nm + ".conv2", t1, 1, 1, 1, nullptr, nm + ".t2", &t2));
+            TRY(eng_conv(e, nm + ".conv3", t2, 1, 0, 1, &idt, nm + ".out", &y));
+            x = y;
+        }
+    Tensor C4 = x;  // [N, H/16, W/16, 1024]
+    {   // expose under a stable name for tests
+        Tensor alias;
+        TRY(eng_act(e, "C4", N, C4.H, C4.W, C4.C, &alias));
+        HIP_TRY(hipMemcpyAsync(alias.d, C4.d, (size_t)C4.numel() * 4, hipMemcpyDeviceToDevice, st));
+        C4 = alias;
+    }
+    eng_mark(e, "backbone");
+
+    // ---- RPN on the single map
+    const int A = 15, CH = 75;
+    const int pre_nms = (int)e.param("rpn_pre_nms_top_n", 6000), post_nms = (int)e.param("rpn_post_nms_top_n", 1000);
+    const float rpn_thr = e.param("rpn_nms_thresh", 0.7f), rpn_min = e.param("rpn_min_size", 0.0f);
+    const int ge = (int)e.param("nms_ge", 0);
+    if (pre_nms > 6144 || post_nms > 1024) { set_error("C4 RPN: pre_nms <= 6144, post_nms <= 1024"); return ISEGMI_ERR_ARG; }
+    Tensor t, head;
+    TRY(eng_conv(e, "rpn.head.conv", C4, 1, 1, 1, nullptr, "rpn.t", &t));
+    TRY(eng_conv(e, "rpn.head.cls_bbox", t, 1, 0, 0, nullptr, "rpn.head", &head));
+    if (head.C != CH) { set_error("C4 rpn.head.cls_bbox must have 15 + 60 outputs"); return ISEGMI_ERR_STATE; }
+    const int HWA = head.H * head.W * A;
+    const RawBuf* anc;
+    TRY(need_tensor(e, "anchors.0", (int64_t)HWA * 16, &anc));
+    const int R = post_nms;
+    float *prob, *tkv, *props, *prop_scores;
+    int *tki, *tkc, *prop_cnt;
+    TRY(eng_buf(e, "rpn.prob", (int64_t)N * HWA * 4, &p)); prob = (float*)p;
+    TRY(eng_buf(e, "rpn.tk_vals", (int64_t)N * pre_nms * 4, &p)); tkv = (float*)p;
+    TRY(eng_buf(e, "rpn.tk_idx", (int64_t)N * pre_nms * 4, &p, 1)); tki = (int*)p;
+    TRY(eng_buf(e, "rpn.tk_cnt", (int64_t)N * 4, &p, 1)); tkc = (int*)p;
+    TRY(eng_buf(e, "proposals", (int64_t)N * R * 16, &p, 0, {N, R, 4})); props = (float*)p;
+    TRY(eng_buf(e, "proposal_scores", (int64_t)N * R * 4, &p, 0, {N, R})); prop_scores = (float*)p;
+    TRY(eng_buf(e, "proposal_count", (int64_t)N * 4, &p, 1, {N})); prop_cnt = (int*)p;
+    TRY(rpn_sigmoid_launch(head.d, (int64_t)N * HWA, A, CH, prob, st));
+    TRY(topk_launch(prob, HWA, N, HWA, pre_nms, nullptr, 1, tkv, tki, tkc, st));
+    // one level: the NMS output (score order) IS the proposal list (select_over_all_levels only runs for > 1 level)
+    TRY(rpn_decode_nms_launch(head.d, (const float*)anc->d, tkv, tki, tkc, d_hw, N, HWA, A, CH, pre_nms, post_nms, rpn_thr, rpn_min, ge, 0, 1,
+                              R, props, prop_scores, prop_cnt, st));
+    eng_mark(e, "rpn");
+
+    // ---- box head: ROIAlign 14x14 (adaptive sampling) -> conv5 head -> avgpool -> predictors
+    const float* feats[1] = {C4.d};
+    const int Hs[1] = {C4.H}, Ws[1] = {C4.W};
+    const float scales[1] = {0.0625f};
+    Tensor roi, f5, cb;
+    TRY(eng_act(e, "box.roi_feat", N * R, 14, 14, C4.C, &roi));
+    TRY(roi_align_launch(feats, Hs, Ws, scales, 1, props, prop_cnt, N, R, C4.C, 14, 14, 0, 4, 0, roi.d, nullptr, st));
+    TRY(res5_head(e, "roi_heads.box.feature_extractor.head.layer4", "box.res5", roi, &f5));
+    Tensor pooled;
+    TRY(eng_act(e, "box.pooled", N * R, 1, 1, f5.C, &pooled));
+    TRY(avgpool_full_launch(f5.d, (int64_t)N * R, f5.H * f5.W, f5.C, pooled.d, st));
+    TRY(eng_conv(e, "roi_heads.box.predictor.cls_bbox", pooled, 1, 0, 0, nullptr, "box.cls_bbox", &cb));
+    const int ncls = 81, cap = (int)e.param("detections_per_img", 100), dpi = cap;
+    if (cb.C != ncls * 5) { set_error("cls_bbox layer must have 81+324 outputs"); return ISEGMI_ERR_STATE; }
+    isegmi_box_post_args a;
+    memset(&a, 0, sizeof(a));
+    a.N = N; a.R = R; a.ncls = ncls; a.det_per_img = dpi; a.cap = cap; a.nms_ge = ge;
+    a.score_thresh = e.param("roi_score_thresh", 0.05f);
+    a.nms_thresh = e.param("roi_nms_thresh", 0.5f);
+    a.logits_stride = cb.C; a.regr_stride = cb.C;
+    a.d_logits = cb.d; a.d_regr = cb.d + ncls; a.d_props = props; a.d_prop_cnt = prop_cnt; a.d_image_hw = d_hw;
+    TRY(eng_buf(e, "box.prob", (int64_t)N * R * ncls * 4, &p, 0, {N, R, ncls})); a.d_ws_prob = (float*)p;
+    TRY(eng_buf(e, "box.cand_scores", (int64_t)N * (ncls - 1) * R * 4, &p)); a.d_ws_cand_scores = (float*)p;
+    TRY(eng_buf(e, "box.cand_boxes", (int64_t)N * (ncls - 1) * R * 16, &p)); a.d_ws_cand_boxes = (float*)p;
+    TRY(eng_buf(e, "box.kept_total", (int64_t)N * 4, &p, 1, {N})); a.d_ws_kept_total = (int*)p;
+    TRY(eng_buf(e, "box.top_vals", (int64_t)N * dpi * 4, &p)); a.d_ws_top_vals = (float*)p;
+    TRY(eng_buf(e, "box.top_idx", (int64_t)N * dpi * 4, &p, 1)); a.d_ws_top_idx = (int*)p;
+    TRY(eng_buf(e, "det.count", (int64_t)N * 4, &p, 1, {N})); a.d_out_count = (int*)p;
+    TRY(eng_buf(e, "det.box", (int64_t)N * cap * 16, &p, 0, {N, cap, 4})); a.d_out_boxes = (float*)p;
+    TRY(eng_buf(e, "det.score", (int64_t)N * cap * 4, &p, 0, {N, cap})); a.d_out_scores = (float*)p;
+    TRY(eng_buf(e, "det.label", (int64_t)N * cap * 4, &p, 1, {N, cap})); a.d_out_labels = (int*)p;
+    TRY(box_postprocess_launch(&a, st));
+    eng_mark(e, "box_head");
+
+    // ---- mask head: the shared extractor on the detections, then MaskRCNNC4Predictor
+    Tensor mroi, m5, up;
+    TRY(eng_act(e, "mask.roi_feat", N * cap, 14, 14, C4.C, &mroi));
+    TRY(roi_align_launch(feats, Hs, Ws, scales, 1, a.d_out_boxes, a.d_out_count, N, cap, C4.C, 14, 14, 0, 4, 0, mroi.d, nullptr, st));
+    TRY(res5_head(e, "roi_heads.box.feature_extractor.head.layer4", "mask.res5", mroi, &m5));
+    TRY(eng_act(e, "mask.deconv", N * cap, 14, 14, 256, &up));
+    {
+        Tensor rows;  // view: (roi, i) as "images" of 1 x 7 pixels
+        rows.d = m5.d; rows.N = N * cap * 7; rows.H = 1; rows.W = 7; rows.C = m5.C; rows.dt = 0;
+        for (int ab = 0; ab < 4; ++ab) {
+            const int aa = ab >> 1, bb = ab & 1;
+            TRY(eng_conv_into(e, "roi_heads.mask.predictor.conv5_mask." + std::to_string(ab), rows, 1, 0, 1,
+                              (char*)up.d + (int64_t)(aa * 14 + bb) * 256 * 4, 7, (int64_t)2 * 14 * 256, 2 * 256));
+        }
+    }
+    const RawBuf *lw, *lb;
+    TRY(need_tensor(e, "mask_logits.w", (int64_t)ncls * 256 * 4, &lw));
+    TRY(need_tensor(e, "mask_logits.b", (int64_t)ncls * 4, &lb));
+    TRY(eng_buf(e, "det.mask14", (int64_t)N * cap * 196 * 4, &p, 0, {N, cap, 14, 14}));
+    TRY(mask_logits_select_launch(up.d, N * cap, 196, 256, (const float*)lw->d, (const float*)lb->d, a.d_out_labels, (float*)p, st));
+    eng_mark(e, "mask_head");
+    e.cur = e.stream;
+    return ISEGMI_OK;
+}
+
 int maskrcnn_paste(Engine& e, const float* h_ratios_wh, int out_h, int out_w) {
     const int N = e.last_N;
     if (N <= 0) { set_error("paste before forward"); return ISEGMI_ERR_STATE; }
@@ -293,8 +453,9 @@ int maskrcnn_paste(Engine& e, const float* h_ratios_wh, int out_h, int out_w) {
     TRY(eng_buf(e, "det.box_resized", (int64_t)N * cap * 16, &rb, 0, {N, cap, 4}));
     TRY(scale_boxes_launch((const float*)e.bufs["det.box"].d, (const float*)rt, N, cap, (float*)rb, ps));
     TRY(eng_buf(e, "det.masks", (int64_t)N * cap * out_h * out_w, &p, 2, {N, cap, out_h, out_w}));
-    TRY(paste_masks_launch((const float*)e.bufs["det.mask28"].d, (const float*)rb, (const int*)e.bufs["det.count"].d, N, cap, 28, out_h,
-                           out_w, e.param("mask_threshold", 0.5f), (uint8_t*)p, ps));
+    const bool c4 = e.param("arch_c4", 0.0f) != 0.0f;  // MaskRCNNC4Predictor emits 14x14 masks
+    TRY(paste_masks_launch((const float*)e.bufs[c4 ? "det.mask14" : "det.mask28"].d, (const float*)rb, (const int*)e.bufs["det.count"].d, N,
+                           cap, c4 ? 14 : 28, out_h, out_w, e.param("mask_threshold", 0.5f), (uint8_t*)p, ps));
     if (ps == e.tail) HIP_TRY(hipEventRecord(e.tail_done, e.tail));
     e.cur = e.stream;
     eng_mark(e, "paste");

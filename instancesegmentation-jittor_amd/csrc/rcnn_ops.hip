@@ -364,18 +364,38 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiLevels lv, cons
             rw = rw > 1.0f ? rw : 1.0f;
             rh = rh > 1.0f ? rh : 1.0f;
             const float bh = dm_div(rh, (float)PH), bw = dm_div(rw, (float)PW);
-            for (int iy = 0; iy < g; ++iy) {
-                const float y = sh + (float)ph * bh + dm_div(((float)iy + 0.5f) * bh, (float)g);
-                for (int ix = 0; ix < g; ++ix) {
-                    const float x = sw + (float)pw * bw + dm_div(((float)ix + 0.5f) * bw, (float)g);
+            // g > 0: fixed sampling grid; g <= 0: adaptive ceil(roi / pooled) (ROIAlign's sampling_ratio = 0, the C4 config)
+            const int gh = g > 0 ? g : (int)ceilf(bh), gw = g > 0 ? g : (int)ceilf(bw);
+            for (int iy = 0; iy < gh; ++iy) {
+                const float y = sh + (float)ph * bh + dm_div(((float)iy + 0.5f) * bh, (float)gh);
+                for (int ix = 0; ix < gw; ++ix) {
+                    const float x = sw + (float)pw * bw + dm_div(((float)ix + 0.5f) * bw, (float)gw);
                     const float4 v = roi_bilinear4(f, H, W, C, y, x);
                     o.x = o.x + v.x; o.y = o.y + v.y; o.z = o.z + v.z; o.w = o.w + v.w;
                 }
             }
-            const float cnt = (float)(g * g);
+            const float cnt = (float)(gh * gw);
             o.x = dm_div(o.x, cnt); o.y = dm_div(o.y, cnt); o.z = dm_div(o.z, cnt); o.w = dm_div(o.w, cnt);
         }
         *(float4*)(out + i * 4) = o;
+    }
+}
+
+// AvgPool2d over the whole HW window of every RoI (C4 FastRCNNPredictor): x [R][HW][C] -> out [R][C]; sequential fp32 sum, one division
+__global__ void avgpool_full_kernel(const float* __restrict__ x, int64_t R, int HW, int C, float* __restrict__ out) {
+    const int c4n = C >> 2;
+    const int64_t total = R * c4n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / c4n;
+        const int c4 = (int)(i - r * c4n);
+        const float* p = x + (r * HW) * C + c4 * 4;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < HW; ++q) {
+            const float4 v = *(const float4*)(p + (int64_t)q * C);
+            a.x = a.x + v.x; a.y = a.y + v.y; a.z = a.z + v.z; a.w = a.w + v.w;
+        }
+        const float n = (float)HW;
+        *(float4*)(out + r * C + c4 * 4) = make_float4(dm_div(a.x, n), dm_div(a.y, n), dm_div(a.z, n), dm_div(a.w, n));
     }
 }
 
@@ -680,6 +700,14 @@ int roi_align_launch(const float* const* feats, const int* Hs, const int* Ws, co
     return ISEGMI_OK;
 }
 
+int avgpool_full_launch(const float* x, int64_t R, int HW, int C, float* out, hipStream_t st) {
+    ARG_CHECK(C % 4 == 0 && HW > 0, "avgpool: C % 4, HW");
+    if (R == 0) return ISEGMI_OK;
+    hipLaunchKernelGGL(avgpool_full_kernel, dim3(grid_for(R * (C / 4))), dim3(256), 0, st, x, R, HW, C, out);
+    HIP_TRY(hipGetLastError());
+    return ISEGMI_OK;
+}
+
 int softmax_rows_launch(const float* x, int64_t rows, int C, int64_t in_stride, float* y, hipStream_t st) {
     hipLaunchKernelGGL(softmax_rows_kernel, dim3(grid_for(rows, 64)), dim3(64), 0, st, x, rows, C, in_stride, y);
     HIP_TRY(hipGetLastError());
@@ -744,6 +772,11 @@ extern "C" int isegmi_op_roi_align(const float* const* d_feats, const int32_t* H
                                    int k_min, int fixed_level, float* d_out, int32_t* d_out_level, void* stream) {
     return roi_align_launch(d_feats, Hs, Ws, scales, nlevels, d_rois, d_counts, N, K, C, PH, PW, sampling, k_min, fixed_level, d_out,
                             d_out_level, (hipStream_t)stream);
+}
+
+extern "C" int isegmi_op_avgpool_full(const float* d_x, int64_t R, int HW, int C, float* d_out, void* stream) {
+    ARG_CHECK(d_x && d_out && R >= 0, "args");
+    return avgpool_full_launch(d_x, R, HW, C, d_out, (hipStream_t)stream);
 }
 
 extern "C" int isegmi_op_box_postprocess(const isegmi_box_post_args* a, void* stream) {

@@ -274,6 +274,15 @@ def roi_align(feats, scales, rois, counts, PH, PW, sampling=2, k_min=2, fixed_le
     return do.numpy(), dl.numpy()
 
 
+def avgpool_full(x):
+    """[R,H,W,C] fp32 -> [R,C]: AvgPool2d over the whole window."""
+    x = np.ascontiguousarray(x, np.float32)
+    R_, H, W, Cc = x.shape
+    dx = DeviceBuffer.from_numpy(x); do = DeviceBuffer((R_, Cc))
+    check(lib().isegmi_op_avgpool_full(dx.ptr, C.c_int64(R_), H * W, Cc, do.ptr, None))
+    return do.numpy()
+
+
 def roi_align_f16(feats, scales, rois, counts, PH, PW, sampling=2, k_min=2):
     """fp16-storage RoIAlign: feats list of [N,H,W,C] (cast to fp16) -> out [N*K,PH,PW,C] fp16."""
     fb = [DeviceBuffer.from_numpy(np.ascontiguousarray(f, np.float16)) for f in feats]

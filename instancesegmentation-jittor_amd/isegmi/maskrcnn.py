@@ -35,6 +35,18 @@ class MaskRCNNConfig:
     ROI_NMS: float = 0.5
     DETECTIONS_PER_IMG: int = 100
     NMS_GE: int = 0  # SURVEY App. A.6 switch: 0 suppress on iou > thr (CUDA kernel), 1 on >= (CPU loop)
+    CONV_BODY: str = "R-50-FPN"  # "R-50-FPN" / "R-101-FPN" (depth) or "R-50-C4" (the yaml README.md:263-273 prints)
+
+    @staticmethod
+    def c4():
+        """e2e_mask_rcnn_R_50_C4_1x: one stride-16 map, 15 anchors, PRE/POST_NMS_TOP_N_TEST 6000/1000 (README.md:267-269),
+        ROIAlign 14x14 with sampling_ratio 0, conv5 head shared by box and mask branches, MaskRCNNC4Predictor (14x14 masks)."""
+        return MaskRCNNConfig(CONV_BODY="R-50-C4", SIZE_DIVISIBILITY=16, ANCHOR_STRIDE=(16,), RPN_PRE_NMS_TOP_N_TEST=6000,
+                              RPN_POST_NMS_TOP_N_TEST=1000)
+
+    @property
+    def is_c4(self):
+        return self.CONV_BODY.endswith("-C4")
 
 
 # ---------------------------------------------------------------------------------------- anchors (A.3)
@@ -156,8 +168,10 @@ class MaskRCNN:
     KIND = 2
 
     def __init__(self, state_dict, H, W, cfg=MaskRCNNConfig(), max_batch=2, device=0, fp16=False):
-        assert H % 32 == 0 and W % 32 == 0
+        assert H % cfg.SIZE_DIVISIBILITY == 0 and W % cfg.SIZE_DIVISIBILITY == 0
+        assert not (cfg.is_c4 and fp16), "the C4 configuration is fp32 only"
         self.cfg, self.H, self.W, self.max_batch = cfg, H, W, max_batch
+        self.mask_buf = "det.mask14" if cfg.is_c4 else "det.mask28"
         _ffi.lib()
         _ffi.set_device(device)
         self._h = C.c_void_p()
@@ -165,7 +179,11 @@ class MaskRCNN:
         self.fp16 = bool(fp16)
         if self.fp16:  # fp16 storage + f16 MFMA convs (BASELINE configs[4]); must precede weight loading
             self.set_param("fp16", 1.0)
-        self._load(state_dict)
+        if cfg.is_c4:
+            self.set_param("arch_c4", 1.0)
+            self._load_c4(state_dict)
+        else:
+            self._load(state_dict)
         for k, v in (("resnet_depth", cfg.depth), ("rpn_pre_nms_top_n", cfg.RPN_PRE_NMS_TOP_N_TEST),
                      ("rpn_post_nms_top_n", cfg.RPN_POST_NMS_TOP_N_TEST), ("rpn_fpn_post_nms_top_n", cfg.RPN_FPN_POST_NMS_TOP_N_TEST),
                      ("rpn_nms_thresh", cfg.RPN_NMS_THRESH), ("rpn_min_size", cfg.RPN_MIN_SIZE), ("roi_score_thresh", cfg.ROI_SCORE_THRESH),
@@ -236,6 +254,45 @@ class MaskRCNN:
             self.anchors.append(a)
             self._set_tensor("anchors.%d" % l, a)
 
+    def _load_bottlenecks(self, sd, src_prefix, dst_prefix, nblocks):
+        for b in range(nblocks):
+            src, dst = "%s.%d" % (src_prefix, b), "%s.%d" % (dst_prefix, b)
+            for i in (1, 2, 3):
+                self._set_conv_krsc("%s.conv%d" % (dst, i), to_krsc(sd["%s.conv%d.weight" % (src, i)]),
+                                    *fold_frozen_batchnorm(sd, "%s.bn%d" % (src, i)))
+            if b == 0:
+                self._set_conv_krsc(dst + ".downsample.0", to_krsc(sd[src + ".downsample.0.weight"]),
+                                    *fold_frozen_batchnorm(sd, src + ".downsample.1"))
+
+    def _load_c4(self, sd):
+        """R-50-C4 state dict (maskrcnn-benchmark names): backbone.body.{stem,layer1..3}, rpn.head.* (1024 ch, 15 anchors),
+        roi_heads.box.feature_extractor.head.layer4.* (conv5 head, shared with the mask branch), roi_heads.box.predictor
+        cls_score / bbox_pred on 2048, roi_heads.mask.predictor conv5_mask (2048 -> 256) / mask_fcn_logits."""
+        cfg = self.cfg
+        w = to_krsc(sd["backbone.body.stem.conv1.weight"])
+        w = np.concatenate([w, np.zeros(w.shape[:3] + (1,), np.float32)], -1)
+        self._set_conv_krsc("backbone.body.stem.conv1", w, *fold_frozen_batchnorm(sd, "backbone.body.stem.bn1"))
+        for li, nb in enumerate((3, 4, 6), 1):
+            self._load_bottlenecks(sd, "backbone.body.layer%d" % li, "backbone.body.layer%d" % li, nb)
+        head = "roi_heads.box.feature_extractor.head.layer4"
+        self._load_bottlenecks(sd, head, head, 3)
+        self._set_conv_krsc("rpn.head.conv", to_krsc(sd["rpn.head.conv.weight"]), None, sd["rpn.head.conv.bias"])
+        wcb = np.concatenate([to_krsc(sd["rpn.head.cls_logits.weight"]), to_krsc(sd["rpn.head.bbox_pred.weight"])], 0)
+        bcb = np.concatenate([sd["rpn.head.cls_logits.bias"], sd["rpn.head.bbox_pred.bias"]])
+        self._set_conv_krsc("rpn.head.cls_bbox", wcb, None, bcb)
+        wp = np.concatenate([sd["roi_heads.box.predictor.cls_score.weight"], sd["roi_heads.box.predictor.bbox_pred.weight"]], 0)
+        bp = np.concatenate([sd["roi_heads.box.predictor.cls_score.bias"], sd["roi_heads.box.predictor.bbox_pred.bias"]])
+        self._set_conv_krsc("roi_heads.box.predictor.cls_bbox", wp.reshape(405, 1, 1, 2048), None, bp)
+        wd = sd["roi_heads.mask.predictor.conv5_mask.weight"]  # [Cin 2048][Cout 256][2][2]
+        for ab in range(4):
+            wab = np.ascontiguousarray(wd[:, :, ab >> 1, ab & 1].T).reshape(256, 1, 1, wd.shape[0])
+            self._set_conv_krsc("roi_heads.mask.predictor.conv5_mask.%d" % ab, wab, None, sd["roi_heads.mask.predictor.conv5_mask.bias"])
+        self._set_tensor("mask_logits.w", sd["roi_heads.mask.predictor.mask_fcn_logits.weight"].reshape(81, 256).astype(np.float32))
+        self._set_tensor("mask_logits.b", sd["roi_heads.mask.predictor.mask_fcn_logits.bias"].astype(np.float32))
+        a = grid_anchors(self.H // 16, self.W // 16, 16, generate_anchors_multi(16, cfg.ANCHOR_SIZES, cfg.ASPECT_RATIOS))
+        self.anchors = [a]
+        self._set_tensor("anchors.0", a)
+
     # -- execution -----------------------------------------------------------------------------
     def upload(self, batch_nhwc3, image_hw):
         x = np.ascontiguousarray(batch_nhwc3, np.float32)
@@ -265,12 +322,13 @@ class MaskRCNN:
     timings = None
 
     def __call__(self, batch_nhwc3, image_hw):
-        """-> list of BoxList (one per image, in network-input coordinates) with scores, labels, mask [n,1,28,28]."""
+        """-> list of BoxList (one per image, in network-input coordinates) with scores, labels, mask [n,1,28,28]
+        (14x14 for the C4 predictor)."""
         n = self.upload(batch_nhwc3, image_hw)
         self.forward_device(n)
         self.sync()
         cnt = self.fetch("det.count", n)
-        box, score, label, m28 = (self.fetch(k, n) for k in ("det.box", "det.score", "det.label", "det.mask28"))
+        box, score, label, m28 = (self.fetch(k, n) for k in ("det.box", "det.score", "det.label", self.mask_buf))
         out = []
         for i in range(n):
             c = int(cnt[i])

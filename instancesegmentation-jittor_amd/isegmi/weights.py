@@ -141,3 +141,49 @@ def maskrcnn_state_dict(seed=1234, depth=50):
     sd["roi_heads.mask.predictor.conv5_mask.bias"] = (rng.standard_normal(256) * 0.01).astype(np.float32)
     _conv_bias(rng, sd, "roi_heads.mask.predictor.mask_fcn_logits", 81, 256, 1, gain=MRCNN_MASK_LOGIT_GAIN)
     return sd
+
+
+# Recorded calibration of the R-50-C4 heads on the seeded uniform(0,255) image (same intent as above: about a thousand
+# proposals out of the 6000 pre-NMS candidates and about a hundred detections above 0.05).
+C4_RPN_CLS_GAIN = 0.0012
+C4_RPN_BBOX_GAIN = 0.0001
+C4_CLS_GAIN = 0.0011
+C4_BG_BIAS = 3.6
+C4_BBOX_GAIN = 0.0002
+C4_MASK_LOGIT_GAIN = 0.0005
+
+
+def maskrcnn_c4_state_dict(seed=1234):
+    """maskrcnn-benchmark e2e_mask_rcnn_R_50_C4_1x state-dict names: backbone.body.{stem,layer1..3}; rpn.head on 1024 channels with
+    15 anchors; roi_heads.box.feature_extractor.head.layer4 (conv5 head, shared with the mask branch); FastRCNNPredictor on 2048;
+    MaskRCNNC4Predictor (ConvTranspose 2048 -> 256, 1x1 -> 81)."""
+    rng = np.random.default_rng(seed)
+    sd = {}
+    tmp = {}
+    resnet_state_dict(rng, tmp, "", blocks=(3, 4, 6, 3))
+    for k, v in tmp.items():
+        if k.startswith("conv1.") or k.startswith("bn1."):
+            sd["backbone.body.stem." + k] = v
+            continue
+        parts = k.split(".")
+        li = int(parts[1]) + 1
+        rest = ".".join(parts[2:])
+        if li <= 3:
+            sd["backbone.body.layer%d.%s" % (li, rest)] = v
+        else:
+            sd["roi_heads.box.feature_extractor.head.layer4." + rest] = v
+            sd["roi_heads.mask.feature_extractor.head.layer4." + rest] = v  # SHARE_BOX_FEATURE_EXTRACTOR: the same module
+    _conv_bias(rng, sd, "rpn.head.conv", 1024, 1024, 3)
+    _conv_bias(rng, sd, "rpn.head.cls_logits", 15, 1024, 1, gain=C4_RPN_CLS_GAIN)
+    _conv_bias(rng, sd, "rpn.head.bbox_pred", 60, 1024, 1, gain=C4_RPN_BBOX_GAIN)
+
+    def fc(name, cout, cin, gain=1.0):
+        sd[name + ".weight"] = (rng.standard_normal((cout, cin)) * gain * np.sqrt(2.0 / cin)).astype(np.float32)
+        sd[name + ".bias"] = (rng.standard_normal(cout) * 0.01).astype(np.float32)
+    fc("roi_heads.box.predictor.cls_score", 81, 2048, C4_CLS_GAIN)
+    fc("roi_heads.box.predictor.bbox_pred", 324, 2048, C4_BBOX_GAIN)
+    sd["roi_heads.box.predictor.cls_score.bias"][0] += C4_BG_BIAS
+    sd["roi_heads.mask.predictor.conv5_mask.weight"] = (rng.standard_normal((2048, 256, 2, 2)) * np.sqrt(2.0 / 2048)).astype(np.float32)
+    sd["roi_heads.mask.predictor.conv5_mask.bias"] = (rng.standard_normal(256) * 0.01).astype(np.float32)
+    _conv_bias(rng, sd, "roi_heads.mask.predictor.mask_fcn_logits", 81, 256, 1, gain=C4_MASK_LOGIT_GAIN)
+    return sd

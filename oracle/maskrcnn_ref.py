@@ -40,6 +40,11 @@ def cell_anchors(stride, size, ratios=(0.5, 1.0, 2.0)):
     return np.asarray(out, np.float64).astype(np.float32)
 
 
+def cell_anchors_multi(stride, sizes, ratios=(0.5, 1.0, 2.0)):
+    """Single-map form: for each ratio (outer) every size (inner) -> 15 anchors at stride 16 for the C4 config."""
+    return np.concatenate([np.stack([cell_anchors(stride, s, (r,))[0] for s in sizes]) for r in ratios], 0).astype(np.float32)
+
+
 def grid_anchors(gh, gw, stride, cell):
     out = np.empty((gh, gw, cell.shape[0], 4), np.float32)
     for y in range(gh):
@@ -159,6 +164,71 @@ class MaskRCNNRef:
                                              sd["roi_heads.mask.predictor.mask_fcn_logits.bias"], dl).reshape(D, 28, 28)
             dets.append(dict(box=db, score=ds, label=dl, mask28=m28, proposals=pr, proposal_scores=pscores[n]))
         self.feats = dict(C2=Cs[0], C5=Cs[3], P2=P[0], P3=P[1], P4=P[2], P5=P[3], P6=P[4])
+        return dets
+
+    # ---- e2e_mask_rcnn_R_50_C4_1x (README.md:263-273): one stride-16 map, conv5 head shared by box and mask branches
+    def _res5(self, x):
+        sd = self.sd
+        for b in range(3):
+            nm = "roi_heads.box.feature_extractor.head.layer4.%d" % b
+            st = 2 if b == 0 else 1
+            idt = self._cbn(x, nm + ".downsample.0", nm + ".downsample.1", st, 0, 0) if b == 0 else x
+            t = self._cbn(x, nm + ".conv1", nm + ".bn1", st, 0, 1)
+            t = self._cbn(t, nm + ".conv2", nm + ".bn2", 1, 1, 1)
+            x = self._cbn(t, nm + ".conv3", nm + ".bn3", 1, 0, 1, residual=idt)
+        return x
+
+    def forward_c4(self, images_nhwc3, image_hw, pre_nms=6000, post_nms=1000):
+        """App. A restated for the C4 config: anchors 5 sizes x 3 ratios (ratio-major) at stride 16; top pre_nms -> decode /
+        clip / NMS 0.7 -> post_nms, no cross-level merge; ROIAlign 14x14 scale 1/16 sampling_ratio 0; conv5 head (first
+        block stride 2) -> AvgPool 7 -> cls_score | bbox_pred; same box post-processing; the shared extractor on the
+        detections -> ConvTranspose 2x2/2 2048->256 + ReLU -> 1x1 -> class-selected sigmoid: 14x14 masks."""
+        assert not self.fp16
+        sd = self.sd
+        x = np.asarray(images_nhwc3, np.float32)
+        N = x.shape[0]
+        x4 = np.concatenate([x, np.zeros(x.shape[:3] + (1,), np.float32)], -1)
+        w1 = _krsc(sd["backbone.body.stem.conv1.weight"])
+        w1 = np.concatenate([w1, np.zeros(w1.shape[:3] + (1,), np.float32)], -1)
+        sc, sh = _frozen_bn(sd, "backbone.body.stem.bn1")
+        x = ora.maxpool(ora.conv2d(x4, w1, 2, 3, sc, sh, None, 1), 3, 2, 1)
+        for li, nb in enumerate((3, 4, 6), 1):
+            for b in range(nb):
+                nm = "backbone.body.layer%d.%d" % (li, b)
+                st = 2 if (b == 0 and li > 1) else 1
+                idt = self._cbn(x, nm + ".downsample.0", nm + ".downsample.1", st, 0, 0) if b == 0 else x
+                t = self._cbn(x, nm + ".conv1", nm + ".bn1", st, 0, 1)
+                t = self._cbn(t, nm + ".conv2", nm + ".bn2", 1, 1, 1)
+                x = self._cbn(t, nm + ".conv3", nm + ".bn3", 1, 0, 1, residual=idt)
+        C4 = x
+        t = self._cb(C4, "rpn.head.conv", 1, 1, 1)
+        logits = self._cb(t, "rpn.head.cls_logits", 1, 0, 0, keep_f32=True)   # [N,H,W,15]
+        deltas = self._cb(t, "rpn.head.bbox_pred", 1, 0, 0, keep_f32=True)    # [N,H,W,60]
+        anc = grid_anchors(C4.shape[1], C4.shape[2], 16, cell_anchors_multi(16, (32, 64, 128, 256, 512)))
+        dets = []
+        for n in range(N):
+            pr, ps = ora.rpn_level(logits[n].reshape(-1), deltas[n].reshape(-1, 4), anc, pre_nms, post_nms, 0.7, 0.0,
+                                   float(image_hw[n][1]), float(image_hw[n][0]), self.ge)
+            R = pr.shape[0]
+            rois = np.concatenate([np.full((R, 1), n, np.float32), pr], 1)
+            f5 = self._res5(ora.roi_align(C4, rois, 1.0 / 16, 14, 14, 0))
+            pooled = ora.avgpool_full(f5).reshape(R, 1, 1, -1)
+            cls = ora.conv2d(pooled, sd["roi_heads.box.predictor.cls_score.weight"].reshape(81, 1, 1, -1), 1, 0, None,
+                             sd["roi_heads.box.predictor.cls_score.bias"], None, 0).reshape(R, 81)
+            reg = ora.conv2d(pooled, sd["roi_heads.box.predictor.bbox_pred.weight"].reshape(324, 1, 1, -1), 1, 0, None,
+                             sd["roi_heads.box.predictor.bbox_pred.bias"], None, 0).reshape(R, 324)
+            db, ds, dl = ora.box_postprocess(cls, reg, pr, float(image_hw[n][1]), float(image_hw[n][0]), 0.05, 0.5, self.dpi, self.ge, self.dpi)
+            D = db.shape[0]
+            m14 = np.zeros((D, 14, 14), np.float32)
+            if D:
+                mr = np.concatenate([np.full((D, 1), n, np.float32), db], 1)
+                m5 = self._res5(ora.roi_align(C4, mr, 1.0 / 16, 14, 14, 0))
+                up = ora.deconv2x2(m5, sd["roi_heads.mask.predictor.conv5_mask.weight"].astype(np.float32),
+                                   sd["roi_heads.mask.predictor.conv5_mask.bias"], 1)
+                m14 = ora.mask_logits_select(up.reshape(D, 196, 256), sd["roi_heads.mask.predictor.mask_fcn_logits.weight"].reshape(81, 256),
+                                             sd["roi_heads.mask.predictor.mask_fcn_logits.bias"], dl).reshape(D, 14, 14)
+            dets.append(dict(box=db, score=ds, label=dl, mask28=m14, proposals=pr, proposal_scores=ps, cls=cls))
+        self.feats = dict(C4=C4)
         return dets
 
     @staticmethod

@@ -177,6 +177,15 @@ def roi_align(feat, rois, spatial_scale, PH, PW, g=2):
     return out
 
 
+def avgpool_full(x):
+    """[R,H,W,C] -> [R,C]: AvgPool2d over the whole H x W window (C4 FastRCNNPredictor)."""
+    x = _f(x)
+    R_, H, W_, Cc = x.shape
+    out = np.empty((R_, Cc), np.float32)
+    lib().ora_avgpool_full(_p(x), I(R_), I(H * W_), I(Cc), _p(out))
+    return out
+
+
 def box_postprocess(logits, regr, props, im_w, im_h, score_thr=0.05, nms_thr=0.5, det_per_img=100,
                     nms_ge=0, cap=128):
     logits = _f(logits); regr = _f(regr); props = _f(props)

@@ -505,16 +505,20 @@ ORA_API void ora_roi_align(const float* feat, int N, int H, int W, int C, const 
         rw = rw > 1.0f ? rw : 1.0f;
         rh = rh > 1.0f ? rh : 1.0f;
         const float bh = rh / (float)PH, bw = rw / (float)PW;
-        const float count = (float)(g * g);
+        /* sampling_ratio > 0: fixed g x g grid; <= 0: adaptive ceil(roi_size / pooled_size) (the ROIAlign default used by
+         * the R-50-C4 config, whose yaml does not set POOLER_SAMPLING_RATIO) */
+        const int gh = g > 0 ? g : (int)ceilf(rh / (float)PH);
+        const int gw = g > 0 ? g : (int)ceilf(rw / (float)PW);
+        const float count = (float)(gh * gw);
         for (int ph = 0; ph < PH; ++ph)
             for (int pw = 0; pw < PW; ++pw) {
                 float* o = out + (((size_t)r * PH + ph) * PW + pw) * C;
                 for (int c = 0; c < C; ++c) {
                     float acc = 0.0f;
-                    for (int iy = 0; iy < g; ++iy) {
-                        const float y = sh + (float)ph * bh + ((float)iy + 0.5f) * bh / (float)g;
-                        for (int ix = 0; ix < g; ++ix) {
-                            const float x = sw + (float)pw * bw + ((float)ix + 0.5f) * bw / (float)g;
+                    for (int iy = 0; iy < gh; ++iy) {
+                        const float y = sh + (float)ph * bh + ((float)iy + 0.5f) * bh / (float)gh;
+                        for (int ix = 0; ix < gw; ++ix) {
+                            const float x = sw + (float)pw * bw + ((float)ix + 0.5f) * bw / (float)gw;
                             acc = acc + roi_bilinear(f, H, W, C, c, y, x);
                         }
                     }
@@ -522,6 +526,18 @@ ORA_API void ora_roi_align(const float* feat, int N, int H, int W, int C, const 
                 }
             }
     }
+}
+
+/* nn.AvgPool2d(k) on an R x k x k x C NHWC tensor with k == H == W (FastRCNNPredictor of the C4 head): sequential fp32
+ * sum over (h, w), one division.  out [R][C]. */
+ORA_API void ora_avgpool_full(const float* x, int R, int HW, int C, float* out) {
+#pragma omp parallel for
+    for (int r = 0; r < R; ++r)
+        for (int c = 0; c < C; ++c) {
+            float acc = 0.0f;
+            for (int i = 0; i < HW; ++i) acc = acc + x[((size_t)r * HW + i) * C + c];
+            out[(size_t)r * C + c] = acc / (float)HW;
+        }
 }
 
 /* ------------------------------------------- Mask R-CNN: box post-process -- */

@@ -225,3 +225,59 @@ def test_maskrcnn_hipgraph_replay_matches_eager(ffi, sd):
     ffi.check(ffi.lib().isegmi_engine_graph_stats(model._h, C.byref(cap), C.byref(rep_), C.byref(fail)))
     assert cap.value == 1 and rep_.value >= 4 and fail.value == 0
     model.close()
+
+
+def test_maskrcnn_c4_bit_exact(ffi):
+    """e2e_mask_rcnn_R_50_C4_1x (the yaml README.md:263-273 prints): single stride-16 map, 15 anchors, PRE_NMS_TOP_N_TEST 6000,
+    ROIAlign with adaptive sampling, conv5 head shared by the box and mask branches, 14x14 masks, Masker paste."""
+    import dataclasses
+    from isegmi.maskrcnn import MaskRCNN, MaskRCNNConfig, prepare_images
+    from isegmi.weights import maskrcnn_c4_state_dict
+    sd = maskrcnn_c4_state_dict(1234)
+    rng = np.random.default_rng(20261003)
+    imgs = [rng.uniform(0, 255, (250, 340, 3)).astype(np.float32), rng.uniform(0, 255, (256, 300, 3)).astype(np.float32)]
+    x, hw = prepare_images(imgs, 16)
+    assert x.shape == (2, 256, 352, 3)
+    cfg = dataclasses.replace(MaskRCNNConfig.c4(), RPN_POST_NMS_TOP_N_TEST=300)  # 300 proposals keep the CPU oracle's conv5 head affordable
+    assert cfg.RPN_PRE_NMS_TOP_N_TEST == 6000 and cfg.is_c4
+    model = MaskRCNN(sd, x.shape[1], x.shape[2], cfg=cfg, max_batch=2)
+    out = model(x, hw)
+    ref = MaskRCNNRef(sd)
+    rd = ref.forward_c4(x, hw, pre_nms=6000, post_nms=300)
+    assert np.array_equal(model.fetch("C4", 2), ref.feats["C4"])
+    pc = model.fetch("proposal_count", 2); pr = model.fetch("proposals", 2); ps = model.fetch("proposal_scores", 2)
+    total = 0
+    for n in range(2):
+        r = rd[n]
+        assert pc[n] == len(r["proposals"]) == 300
+        assert np.array_equal(ps[n, : pc[n]], r["proposal_scores"]) and np.array_equal(pr[n, : pc[n]], r["proposals"])
+        bl = out[n]
+        assert len(bl) == len(r["score"])
+        assert np.array_equal(bl.get_field("labels"), r["label"].astype(np.int64))
+        assert np.array_equal(bl.get_field("scores"), r["score"]) and np.array_equal(bl.bbox, r["box"])
+        assert bl.get_field("mask").shape[1:] == (1, 14, 14) and np.array_equal(bl.get_field("mask")[:, 0], r["mask28"])
+        total += len(bl)
+    assert total > 20
+    model.paste_device(256, 352); model.sync()
+    masks = model.fetch("det.masks", 2)
+    for n in range(2):
+        rm, _ = MaskRCNNRef.paste(rd[n], 256, 352)
+        assert np.array_equal(masks[n, : len(rm)], rm) and rm.any()
+    model.close()
+
+
+def test_maskrcnn_c4_default_1000_proposals(ffi):
+    """The config's own sizes (6000 -> 1000 proposals) on one small image."""
+    from isegmi.maskrcnn import MaskRCNN, MaskRCNNConfig, prepare_images
+    from isegmi.weights import maskrcnn_c4_state_dict
+    sd = maskrcnn_c4_state_dict(7)
+    rng = np.random.default_rng(3)
+    x, hw = prepare_images([rng.uniform(0, 255, (240, 320, 3)).astype(np.float32)], 16)
+    model = MaskRCNN(sd, x.shape[1], x.shape[2], cfg=MaskRCNNConfig.c4(), max_batch=1)
+    (bl,) = model(x, hw)
+    r = MaskRCNNRef(sd).forward_c4(x, hw)[0]
+    pc = model.fetch("proposal_count", 1)
+    assert pc[0] == len(r["proposals"]) and np.array_equal(model.fetch("proposals", 1)[0, : pc[0]], r["proposals"])
+    assert len(bl) == len(r["score"]) and np.array_equal(bl.get_field("scores"), r["score"]) and np.array_equal(bl.bbox, r["box"])
+    assert np.array_equal(bl.get_field("mask")[:, 0], r["mask28"])
+    model.close()

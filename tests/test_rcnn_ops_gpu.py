@@ -73,6 +73,29 @@ def test_roi_align_matches_oracle(ffi):
     assert np.allclose(o, 3.5, rtol=0, atol=2e-6)  # bilinear weights sum to 1 only up to rounding
 
 
+def test_roi_align_adaptive_sampling_and_avgpool_match_oracle(ffi):
+    """sampling_ratio = 0 (adaptive ceil(roi/pooled) grid; the R-50-C4 pooler) on one stride-16 map, and the C4 head's
+    whole-window average pool."""
+    rng = np.random.default_rng(21)
+    N, K, Cc = 2, 80, 32
+    feat = rng.standard_normal((N, 50, 84, Cc)).astype(np.float32)
+    rois = np.stack([_boxes(rng, K, 1344, 800, False) for _ in range(N)])
+    rois[0, 0] = [0, 0, 1343, 799]          # 6 x 4 samples per bin at 14 x 14
+    rois[0, 1] = [100, 100, 103, 102]       # tiny -> 1 x 1
+    counts = np.array([K, 33], np.int32)
+    for PH in (14, 7):
+        out, _ = ffi.roi_align([feat], [1.0 / 16], rois, counts, PH, PH, sampling=0, fixed_level=0)
+        out = out.reshape(N, K, PH, PH, Cc)
+        for n in range(N):
+            k = counts[n]
+            r5 = np.concatenate([np.full((k, 1), n, np.float32), rois[n, :k]], 1)
+            ref = ora.roi_align(feat, r5, 1.0 / 16, PH, PH, 0)
+            assert np.array_equal(out[n, :k], ref), (PH, n)
+            assert not out[n, k:].any()
+    x = rng.standard_normal((37, 7, 7, 64)).astype(np.float32)
+    assert np.array_equal(ffi.avgpool_full(x), ora.avgpool_full(x))
+
+
 @pytest.mark.parametrize("Cc", [256, 64, 36])  # 256 / 64: 8-channel-per-lane kernel; 36: generic 4-channel kernel
 def test_roi_align_f16_matches_oracle_on_fp16_features(ffi, Cc):
     """fp16-storage RoIAlign: same fp32 arithmetic on fp16-rounded features, result rounded to fp16 -> exact match."""
