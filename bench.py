@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--model", default="yolact", choices=["yolact", "maskrcnn"])
     ap.add_argument("--depth", type=int, default=50, choices=[50, 101], help="maskrcnn: ResNet depth")
     ap.add_argument("--fp16", action="store_true", help="maskrcnn: fp16 storage + f16 MFMA convs (BASELINE configs[4])")
+    ap.add_argument("--c4", action="store_true", help="maskrcnn: the R-50-C4 config (README.md:263-273) instead of R-50/101-FPN")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8, help="images the CPU oracle is timed on")
     ap.add_argument("--no-latency", action="store_true", help="skip the extra bs=1 latency pass")
@@ -282,14 +283,19 @@ def main_maskrcnn(a):
     from isegmi.weights import maskrcnn_state_dict
     if _ffi.device_count() < 1:
         raise SystemExit("no HIP device visible: bench.py measures the HIP path only (no CPU fallback)")
-    sd = maskrcnn_state_dict(1234, depth=a.depth)
+    if a.c4:
+        from isegmi.weights import maskrcnn_c4_state_dict
+        assert not a.fp16 and a.depth == 50, "--c4 is R-50, fp32"
+        sd, mcfg = maskrcnn_c4_state_dict(1234), MaskRCNNConfig.c4()
+    else:
+        sd, mcfg = maskrcnn_state_dict(1234, depth=a.depth), MaskRCNNConfig(depth=a.depth)
     rng = np.random.default_rng(20261003 + rank)
     imgs = [rng.uniform(0, 255, (800, 1333, 3)).astype(np.float32) for _ in range(a.batch)]
-    x, hw = prepare_images(imgs)
-    model = MaskRCNN(sd, x.shape[1], x.shape[2], cfg=MaskRCNNConfig(depth=a.depth), max_batch=a.batch, device=local_rank, fp16=a.fp16)
+    x, hw = prepare_images(imgs, mcfg.SIZE_DIVISIBILITY)
+    model = MaskRCNN(sd, x.shape[1], x.shape[2], cfg=mcfg, max_batch=a.batch, device=local_rank, fp16=a.fp16)
     if a.single_stream:
         model.set_param("multi_stream", 0.0)
-    tag = "R%d-FPN" % a.depth
+    tag = "R50-C4" if a.c4 else "R%d-FPN" % a.depth
     prec = "fp16 storage / f16 MFMA, fp32 accumulate" if a.fp16 else "fp32"
     peak = 2500.0 if a.fp16 else PEAK_F32_MFMA_TFLOPS  # dense f16 MFMA peak (MI355X_MICROARCH.md) vs f32 MFMA peak
     model.upload(x, hw)
@@ -348,7 +354,7 @@ def main_maskrcnn(a):
                "value": round(a.batch * world * a.steps / elapsed, 3), "unit": "img/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f16" if a.fp16 else "f32", "data": "synthetic",
-               "config": {"workload": "Mask R-CNN %s 1333x800 (padded 800x1344) bs=%d/GPU random weights, %s: backbone+FPN+RPN+RoIAlign+box head+NMS+mask head+paste (BASELINE configs[%d])" % (tag, a.batch, prec, 4 if a.fp16 else 2),
+               "config": {"workload": ("Mask R-CNN %s 1333x800 (padded 800x1344) bs=%d/GPU random weights, %s: conv1-4 + single-map RPN (6000 -> 1000) + RoIAlign + conv5 head + NMS + shared-extractor mask branch + paste (the README.md:263-273 config; not a BASELINE config)" % (tag, a.batch, prec)) if a.c4 else "Mask R-CNN %s 1333x800 (padded 800x1344) bs=%d/GPU random weights, %s: backbone+FPN+RPN+RoIAlign+box head+NMS+mask head+paste (BASELINE configs[%d])" % (tag, a.batch, prec, 4 if a.fp16 else 2),
                           "global_batch": a.batch * world, "parallelism": "batch-sharded x%d" % world,
                           "proposals_per_image": [int(c) for c in pc], "detections_per_image": [int(c) for c in cnt]},
                "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel (all conv launches of a step)",
@@ -381,7 +387,7 @@ def main_maskrcnn(a):
             step(); model.sync()
             out["stage_ms_bs%d" % a.batch] = {k: round(v, 3) for k, v in model.timings()}
             model.set_param("timing", 0.0)
-        if world == 1 and not a.no_cpu_baseline and not a.fp16 and a.depth == 50:
+        if world == 1 and not a.no_cpu_baseline and not a.fp16 and a.depth == 50 and not a.c4:
             from oracle.maskrcnn_ref import MaskRCNNRef
             ncpu = min(len(os.sched_getaffinity(0)), 16)
             os.environ["OMP_NUM_THREADS"] = str(ncpu)

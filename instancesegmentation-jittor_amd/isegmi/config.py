@@ -87,14 +87,26 @@ cfg = _defaults()
 def to_maskrcnn_config(c):
     """Map the yaml-keyed node onto the frozen dataclass the engine consumes; rejects what the path does not build."""
     body = c.MODEL.BACKBONE.CONV_BODY
-    if body not in ("R-50-FPN", "R-101-FPN"):
-        raise ValueError("only the FPN bodies R-50-FPN / R-101-FPN are built (got %r; C4 configs are SURVEY 8f rank 4)" % body)
-    for k in ("PRE_NMS_TOP_N_TEST", "POST_NMS_TOP_N_TEST", "FPN_POST_NMS_TOP_N_TEST"):
-        if int(c.MODEL.RPN[k]) > 1024:
-            raise ValueError("MODEL.RPN.%s=%d: the HIP selection kernels hold at most 1024 boxes per level" % (k, c.MODEL.RPN[k]))
     r = c.MODEL.RPN
     h = c.MODEL.ROI_HEADS
-    return MaskRCNNConfig(depth=101 if "101" in body else 50, MIN_SIZE_TEST=int(c.INPUT.MIN_SIZE_TEST), MAX_SIZE_TEST=int(c.INPUT.MAX_SIZE_TEST),
+    if body == "R-50-C4":
+        # the yaml the reference prints (README.md:263-273): everything it does not set comes from maskrcnn-benchmark's
+        # defaults.py -- one stride-16 map, no FPN merge, SIZE_DIVISIBILITY 0 (the engine pads to 16), 14x14 masks
+        if int(r.PRE_NMS_TOP_N_TEST) > 6144 or int(r.POST_NMS_TOP_N_TEST) > 1024:
+            raise ValueError("MODEL.RPN.PRE/POST_NMS_TOP_N_TEST: the single-map HIP selection kernels hold 6144 / 1024 boxes")
+        return MaskRCNNConfig(CONV_BODY=body, MIN_SIZE_TEST=int(c.INPUT.MIN_SIZE_TEST), MAX_SIZE_TEST=int(c.INPUT.MAX_SIZE_TEST),
+                              SIZE_DIVISIBILITY=16, ANCHOR_SIZES=tuple(r.ANCHOR_SIZES), ANCHOR_STRIDE=(16,),
+                              ASPECT_RATIOS=tuple(float(x) for x in r.ASPECT_RATIOS), RPN_PRE_NMS_TOP_N_TEST=int(r.PRE_NMS_TOP_N_TEST),
+                              RPN_POST_NMS_TOP_N_TEST=int(r.POST_NMS_TOP_N_TEST), RPN_NMS_THRESH=float(r.NMS_THRESH),
+                              RPN_MIN_SIZE=float(r.MIN_SIZE), ROI_SCORE_THRESH=float(h.SCORE_THRESH), ROI_NMS=float(h.NMS),
+                              DETECTIONS_PER_IMG=int(h.DETECTIONS_PER_IMG))
+    if body not in ("R-50-FPN", "R-101-FPN"):
+        raise ValueError("built bodies: R-50-FPN, R-101-FPN, R-50-C4 (got %r)" % body)
+    for k in ("PRE_NMS_TOP_N_TEST", "POST_NMS_TOP_N_TEST", "FPN_POST_NMS_TOP_N_TEST"):
+        if int(c.MODEL.RPN[k]) > 1024:
+            raise ValueError("MODEL.RPN.%s=%d: the per-level FPN selection kernels hold at most 1024 boxes" % (k, c.MODEL.RPN[k]))
+    return MaskRCNNConfig(depth=101 if "101" in body else 50, CONV_BODY=body, MIN_SIZE_TEST=int(c.INPUT.MIN_SIZE_TEST),
+                          MAX_SIZE_TEST=int(c.INPUT.MAX_SIZE_TEST),
                           SIZE_DIVISIBILITY=int(c.DATALOADER.SIZE_DIVISIBILITY), ANCHOR_SIZES=tuple(r.ANCHOR_SIZES),
                           ANCHOR_STRIDE=tuple(r.ANCHOR_STRIDE), ASPECT_RATIOS=tuple(float(x) for x in r.ASPECT_RATIOS),
                           RPN_PRE_NMS_TOP_N_TEST=int(r.PRE_NMS_TOP_N_TEST), RPN_POST_NMS_TOP_N_TEST=int(r.POST_NMS_TOP_N_TEST),

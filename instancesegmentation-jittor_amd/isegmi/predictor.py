@@ -22,8 +22,10 @@ class COCODemo:
             from .config import to_maskrcnn_config
             if state_dict is None and getattr(cfg.MODEL, "WEIGHT", ""):
                 w = cfg.MODEL.WEIGHT
-                from .weights import maskrcnn_state_dict
-                state_dict = maskrcnn_state_dict(1234, 101 if "101" in cfg.MODEL.BACKBONE.CONV_BODY else 50) if w == "random" else dict(np.load(w))
+                from .weights import maskrcnn_c4_state_dict, maskrcnn_state_dict
+                body = cfg.MODEL.BACKBONE.CONV_BODY
+                rnd = (lambda: maskrcnn_c4_state_dict(1234)) if body.endswith("-C4") else (lambda: maskrcnn_state_dict(1234, 101 if "101" in body else 50))
+                state_dict = rnd() if w == "random" else dict(np.load(w))
             cfg = to_maskrcnn_config(cfg)
         self.cfg = cfg or MaskRCNNConfig()
         if state_dict is None:
@@ -44,7 +46,7 @@ class COCODemo:
         """-> BoxList in ORIGINAL image coordinates with scores, labels and mask [n,1,H,W] uint8 (Masker output)."""
         h, w = original_image.shape[:2]
         resized = maskrcnn_resize(original_image, self.min_image_size, self.max_image_size)
-        x, hw = prepare_images([resized])
+        x, hw = prepare_images([resized], self.cfg.SIZE_DIVISIBILITY)
         model = self._model(x.shape[1], x.shape[2])
         (pred,) = model(x, hw)
         model.paste_device(h, w, [(w, h)])

@@ -16,13 +16,24 @@ def test_cfg_merge_and_mapping():
     m = to_maskrcnn_config(c)
     assert m.depth == 101 and m.DETECTIONS_PER_IMG == 50 and m.RPN_PRE_NMS_TOP_N_TEST == 1000 and m.ANCHOR_STRIDE == (4, 8, 16, 32, 64)
     assert cfg.MODEL.BACKBONE.CONV_BODY == "R-50-FPN"        # the global default is untouched by the clone
-    c.MODEL.RPN.PRE_NMS_TOP_N_TEST = 6000                    # the README's C4 sample value
+    c.MODEL.RPN.PRE_NMS_TOP_N_TEST = 6000                    # fine for the C4 body, too many for a per-level FPN selection
     with pytest.raises(ValueError, match="1024"):
         to_maskrcnn_config(c)
     c.MODEL.RPN.PRE_NMS_TOP_N_TEST = 1000
-    c.MODEL.BACKBONE.CONV_BODY = "R-50-C4"
-    with pytest.raises(ValueError, match="FPN"):
+    c.MODEL.BACKBONE.CONV_BODY = "R-152-FPN"
+    with pytest.raises(ValueError, match="built bodies"):
         to_maskrcnn_config(c)
+
+
+def test_c4_yaml_of_the_readme_maps_to_the_c4_engine_config():
+    """README.md:263-284 prints e2e_mask_rcnn_R_50_C4_1x.yaml; its keys (incl. the training ones) load and map."""
+    from isegmi.config import cfg, to_maskrcnn_config
+    c = cfg.clone()
+    c.merge_from_file(os.path.join(ROOT, "configs", "e2e_mask_rcnn_R_50_C4_1x.yaml"))
+    assert c.MODEL.ROI_MASK_HEAD.SHARE_BOX_FEATURE_EXTRACTOR is True and c.SOLVER.STEPS == (120000, 160000)
+    m = to_maskrcnn_config(c)
+    assert m.is_c4 and m.RPN_PRE_NMS_TOP_N_TEST == 6000 and m.RPN_POST_NMS_TOP_N_TEST == 1000 and m.ANCHOR_STRIDE == (16,)
+    assert m.SIZE_DIVISIBILITY == 16 and m.ANCHOR_SIZES == (32, 64, 128, 256, 512)
 
 
 def test_cli_parses_reference_flags():

@@ -41,6 +41,23 @@ def test_cocodemo_run_and_inference(ffi, tmp_path):
     demo.close()
 
 
+def test_cocodemo_with_the_c4_yaml_of_the_readme(ffi):
+    """README.md:313-331 with the yaml README.md:263-284 prints (R-50-C4): cfg.merge_from_file -> COCODemo -> run_on_opencv_image."""
+    import os
+    from isegmi.config import cfg
+    from isegmi.predictor import COCODemo
+    c = cfg.clone()
+    c.merge_from_file(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs", "e2e_mask_rcnn_R_50_C4_1x.yaml"))
+    c.MODEL.WEIGHT = "random"
+    demo = COCODemo(c, min_image_size=160, confidence_threshold=0.06, max_image_size=256)
+    assert demo.cfg.is_c4
+    image = np.random.default_rng(8).integers(0, 256, (120, 180, 3)).astype(np.uint8)
+    pred = demo.compute_prediction(image)
+    assert pred.size == (180, 120) and pred.get_field("mask").shape[1:] == (1, 120, 180)
+    out = demo.run_on_opencv_image(image)
+    assert out.shape == image.shape and out.dtype == np.uint8
+
+
 def test_yolact_eval_style_output(ffi):
     from isegmi.coco import rle_decode, yolact_results
     from isegmi.transforms import yolact_transform
