@@ -307,7 +307,7 @@ def main_maskrcnn(a):
         if rank == 0:
             uid = torch.frombuffer(bytearray(RcclGather.unique_id()), dtype=torch.uint8).clone()
         dist.broadcast(uid, 0)
-        gather = RcclGather(rank, world, bytes(uid.numpy().tobytes()), maskrcnn_record_bytes(a.batch))
+        gather = RcclGather(rank, world, bytes(uid.numpy().tobytes()), maskrcnn_record_bytes(a.batch, M=14 if a.c4 else 28))
 
     def step():
         model.forward_device(a.batch)

@@ -491,7 +491,7 @@ extern "C" int isegmi_maskrcnn_paste(isegmi_engine* h, const float* h_ratios_wh,
 }
 
 // One contiguous record block of the last Mask R-CNN forward for the all-gather:
-//   [count i32 x N][box f32 x N*K*4][score f32 x N*K][label i32 x N*K][mask28 f32 x N*K*784]
+//   [count i32 x N][box f32 x N*K*4][score f32 x N*K][label i32 x N*K][mask f32 x N*K*M*M]   (M = 28; 14 for the C4 predictor)
 // (the 28x28 masks travel; the consumer pastes them).  D2D copies on the engine stream.
 extern "C" int isegmi_maskrcnn_pack_records(isegmi_engine* h, void* d_dst, int64_t cap, int64_t* bytes) {
     ARG_CHECK(h && d_dst && bytes, "null");
@@ -501,8 +501,10 @@ extern "C" int isegmi_maskrcnn_pack_records(isegmi_engine* h, void* d_dst, int64
     ARG_CHECK(N > 0, "pack before forward");
     const int K = (int)e.param("detections_per_img", 100);
     hipStream_t rs = (e.multi_stream && e.tail_pending) ? e.tail : e.stream;  // results stream
-    const char* names[5] = {"det.count", "det.box", "det.score", "det.label", "det.mask28"};
-    const int64_t sizes[5] = {(int64_t)N * 4, (int64_t)N * K * 16, (int64_t)N * K * 4, (int64_t)N * K * 4, (int64_t)N * K * 784 * 4};
+    const bool c4 = e.param("arch_c4", 0.0f) != 0.0f;  // MaskRCNNC4Predictor: 14x14 masks
+    const int64_t msz = c4 ? 196 : 784;
+    const char* names[5] = {"det.count", "det.box", "det.score", "det.label", c4 ? "det.mask14" : "det.mask28"};
+    const int64_t sizes[5] = {(int64_t)N * 4, (int64_t)N * K * 16, (int64_t)N * K * 4, (int64_t)N * K * 4, (int64_t)N * K * msz * 4};
     int64_t off = 0;
     for (int i = 0; i < 5; ++i) {
         ARG_CHECK(off + sizes[i] <= cap, "record buffer too small");

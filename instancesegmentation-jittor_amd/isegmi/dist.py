@@ -57,8 +57,9 @@ def unpack_records(buf, n, K=K_DEFAULT, md=MD, proto_hw=None):
     return out
 
 
-def maskrcnn_record_bytes(n, K=K_DEFAULT):
-    return n * 4 + n * K * 16 + n * K * 4 + n * K * 4 + n * K * 784 * 4
+def maskrcnn_record_bytes(n, K=K_DEFAULT, M=28):
+    """M = RoI mask resolution: 28 (FPN mask head), 14 (MaskRCNNC4Predictor)."""
+    return n * 4 + n * K * 16 + n * K * 4 + n * K * 4 + n * K * M * M * 4
 
 
 def pack_maskrcnn_records(count, box, score, label, mask28):
@@ -67,10 +68,10 @@ def pack_maskrcnn_records(count, box, score, label, mask28):
     return np.concatenate([p.view(np.uint8).ravel() for p in parts])
 
 
-def unpack_maskrcnn_records(buf, n, K=K_DEFAULT):
+def unpack_maskrcnn_records(buf, n, K=K_DEFAULT, M=28):
     buf = np.ascontiguousarray(buf, np.uint8)
     sizes = [(n * 4, np.int32, (n,)), (n * K * 16, np.float32, (n, K, 4)), (n * K * 4, np.float32, (n, K)), (n * K * 4, np.int32, (n, K)),
-             (n * K * 784 * 4, np.float32, (n, K, 28, 28))]
+             (n * K * M * M * 4, np.float32, (n, K, M, M))]
     out, off = [], 0
     for nb, dt, shp in sizes:
         out.append(buf[off:off + nb].view(dt).reshape(shp)); off += nb

@@ -50,3 +50,25 @@ def test_rccl_world1_maskrcnn_records(ffi):
     rec = unpack_maskrcnn_records(got, 1)
     assert rec["count"][0] > 0 and np.array_equal(rec["mask28"], model.fetch("det.mask28", 1))
     g.close(); model.close()
+
+
+def test_rccl_world1_maskrcnn_c4_records(ffi):
+    """The C4 predictor's 14x14 masks travel in the same record layout (M = 14)."""
+    import dataclasses
+    from isegmi.dist import RcclGather, maskrcnn_record_bytes, pack_maskrcnn_records, unpack_maskrcnn_records
+    from isegmi.maskrcnn import MaskRCNN, MaskRCNNConfig, prepare_images
+    from isegmi.weights import maskrcnn_c4_state_dict
+    rng = np.random.default_rng(20261003)
+    x, hw = prepare_images([rng.uniform(0, 255, (250, 340, 3)).astype(np.float32)], 16)
+    cfg = dataclasses.replace(MaskRCNNConfig.c4(), RPN_POST_NMS_TOP_N_TEST=300)
+    model = MaskRCNN(maskrcnn_c4_state_dict(1234), x.shape[1], x.shape[2], cfg=cfg, max_batch=1)
+    model(x, hw)
+    g = RcclGather(0, 1, RcclGather.unique_id(), maskrcnn_record_bytes(1, M=14))
+    g.gather_from(model)
+    got = g.fetch()[0]
+    host = pack_maskrcnn_records(model.fetch("det.count", 1), model.fetch("det.box", 1), model.fetch("det.score", 1),
+                                 model.fetch("det.label", 1), model.fetch("det.mask14", 1))
+    assert np.array_equal(got, host)
+    rec = unpack_maskrcnn_records(got, 1, M=14)
+    assert rec["count"][0] > 0 and np.array_equal(rec["mask28"], model.fetch("det.mask14", 1))
+    g.close(); model.close()
