@@ -596,7 +596,7 @@ int conv2d_f16_launch(const isegmi_conv_desc* d, const void* in, const void* w, 
         const bool strip_ok = d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1;
         double best = 0.0;
         for (const auto& t : T) {
-            if (t.id >= 21 && !(strip_ok && (t.bm - 1) / d->W + 2 <= 32)) continue;
+            if (t.id >= 26 && !(strip_ok && (t.bm - 1) / d->W + 2 <= 32)) continue;
             const int64_t blocks = (int64_t)cdiv(k.M, t.bm) * cdiv(d->Cout, t.bn);
             int64_t per_cu = (blocks + 255) / 256;
             if (t.occ > 1 && blocks <= 256 * t.occ) per_cu = blocks < t.occ ? blocks : t.occ;
@@ -604,16 +604,11 @@ int conv2d_f16_launch(const isegmi_conv_desc* d, const void* in, const void* w, 
             if (tile == 0 || c < best) { best = c; tile = t.id; }
         }
     }
-    if (tile >= 21 && tile <= 28) {
+    if (tile >= 26 && tile <= 28) {
         ARG_CHECK(d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1, "strip tiles are for 3x3 / stride 1 / pad 1");
-        const int bm = (tile == 21 || tile == 23 || tile == 25 || tile == 27) ? 256 : (tile == 22 || tile == 26) ? 192 : 160;
+        const int bm = tile == 26 ? 192 : tile == 27 ? 256 : 160;
         ARG_CHECK((bm - 1) / d->W + 2 <= 32, "strip tile: too many image-row segments (W too small)");
-        switch (tile) {
-            case 21: return launch_strip<256, 256, 2, 4>(k, st);
-            case 22: return launch_strip<192, 256, 2, 4>(k, st);
-            case 23: return launch_strip<256, 128, 4, 2>(k, st);
-            case 24: return launch_strip<160, 256, 1, 8>(k, st);
-            case 25: return launch_strip<256, 256, 2, 4, 4>(k, st);  // + 4 loader waves
+        switch (tile) {  // row strips + 4 loader waves
             case 26: return launch_strip<192, 256, 2, 4, 4>(k, st);
             case 27: return launch_strip<256, 128, 4, 2, 4>(k, st);
             default: return launch_strip<160, 256, 1, 8, 4>(k, st);
@@ -634,10 +629,7 @@ int conv2d_f16_launch(const isegmi_conv_desc* d, const void* in, const void* w, 
         case 12: return launch_g<192, 256, 2, 4, 2, 1, false, 4>(k, st);  // 8 MFMA waves + 4 loader waves
         case 13: return launch_g<256, 256, 2, 4, 2, 1, false, 4>(k, st);
         case 14: return launch_g<256, 128, 4, 2, 3, 1, false, 4>(k, st);
-        case 15: return launch_g<192, 256, 2, 4, 2, 1, false, 8>(k, st);
-        case 16: return launch_g<160, 256, 1, 8, 2, 1, false, 4>(k, st);
-        case 17: return launch_g<192, 128, 2, 2, 2, 2, false, 2>(k, st);
-        case 18: return launch_g<128, 128, 2, 2, 2, 2, false, 2>(k, st);  // wave tile 160x32; 20 A pieces over 8 waves (partial round)
+        case 16: return launch_g<160, 256, 1, 8, 2, 1, false, 4>(k, st);  // wave tile 160x32; 20 A pieces over 8 waves (partial round)
         default: break;
     }
     ARG_CHECK(false, "unknown fp16 conv tile");

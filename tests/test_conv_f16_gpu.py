@@ -15,12 +15,12 @@ CASES = [(2, 19, 23, 64, 48, 3, 1, 1), (3, 14, 14, 128, 96, 3, 1, 1), (1, 30, 30
 
 
 @pytest.mark.parametrize("case", CASES)
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 21, 22, 23, 24, 25, 26, 27, 28])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 26, 27, 28])
 def test_conv_f16_close_to_oracle(ffi, case, tile):
     N, H, W, Cin, Cout, R, stride, pad = case
-    if tile >= 21 and not (R == 3 and stride == 1 and pad == 1):
+    if tile >= 26 and not (R == 3 and stride == 1 and pad == 1):
         pytest.skip("row-strip tiles are 3x3 / stride 1 / pad 1 only")
-    if tile >= 21 and W < 9:
+    if tile >= 26 and W < 9:
         pytest.skip("row-strip tiles need <= 32 image-row segments per tile (the auto rule falls back to the generic kernel)")
     rng = np.random.default_rng(abs(hash(case)) % (2 ** 32))
     x = rng.standard_normal((N, H, W, Cin)).astype(np.float16)
