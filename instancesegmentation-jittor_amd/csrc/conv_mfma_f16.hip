@@ -590,7 +590,7 @@ int conv2d_f16_launch(const isegmi_conv_desc* d, const void* in, const void* w, 
             {6, 64, 256, 2, 0.75}, {7, 128, 256, 1, 0.95}, {8, 128, 64, 2, 0.6}, {9, 192, 256, 1, 1.0}, {10, 192, 128, 2, 1.0},
             {11, 160, 256, 1, 0.88},
             // + 4 dedicated loader waves (the MFMA waves issue no LDS-DMA)
-            {12, 192, 256, 1, 1.11}, {13, 256, 256, 1, 1.08}, {14, 256, 128, 1, 0.97}, {16, 160, 256, 1, 0.975}, {17, 192, 256, 1, 1.14},
+            {12, 192, 256, 1, 1.11}, {13, 256, 256, 1, 1.08}, {14, 256, 128, 1, 0.97}, {16, 160, 256, 1, 0.975}, {17, 192, 256, 1, 1.14}, {19, 128, 256, 1, 1.0}, {20, 192, 128, 2, 1.04},
             // row-strip variants (3x3 / stride 1 / pad 1 only: ~2.7x fewer A bytes through the CU's fill path) + 4 loader waves
             {26, 192, 256, 1, 1.18}, {27, 256, 128, 1, 1.03}, {28, 160, 256, 1, 1.0}, {29, 192, 256, 1, 1.21}};
         const bool strip_ok = d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1;
@@ -631,7 +631,9 @@ int conv2d_f16_launch(const isegmi_conv_desc* d, const void* in, const void* w, 
         case 13: return launch_g<256, 256, 2, 4, 2, 1, false, 4>(k, st);
         case 14: return launch_g<256, 128, 4, 2, 3, 1, false, 4>(k, st);
         case 16: return launch_g<160, 256, 1, 8, 2, 1, false, 4>(k, st);
-        case 17: return launch_g<192, 256, 3, 4, 2, 1, false, 4>(k, st);  // 12 MFMA waves (64x64 each) + 4 loader waves  // wave tile 160x32; 20 A pieces over 8 waves (partial round)
+        case 17: return launch_g<192, 256, 3, 4, 2, 1, false, 4>(k, st);  // 12 MFMA waves (64x64 each) + 4 loader waves
+        case 19: return launch_g<128, 256, 2, 4, 3, 1, false, 4>(k, st);  // 128x256, 3-deep ring, 8 MFMA + 4 loader waves
+        case 20: return launch_g<192, 128, 3, 2, 2, 2, false, 2>(k, st);  // 6 MFMA + 2 loader waves, 2 blocks/CU  // wave tile 160x32; 20 A pieces over 8 waves (partial round)
         default: break;
     }
     ARG_CHECK(false, "unknown fp16 conv tile");

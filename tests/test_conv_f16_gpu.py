@@ -15,7 +15,7 @@ CASES = [(2, 19, 23, 64, 48, 3, 1, 1), (3, 14, 14, 128, 96, 3, 1, 1), (1, 30, 30
 
 
 @pytest.mark.parametrize("case", CASES)
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 17, 26, 27, 28, 29])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 17, 19, 20, 26, 27, 28, 29])
 def test_conv_f16_close_to_oracle(ffi, case, tile):
     N, H, W, Cin, Cout, R, stride, pad = case
     if tile >= 26 and not (R == 3 and stride == 1 and pad == 1):
