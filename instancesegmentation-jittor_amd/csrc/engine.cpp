@@ -249,15 +249,24 @@ int yolact_forward(Engine& e, const float* d_images, int N) {
     const int H = e.H, W = e.W;
     e.cur = e.stream;
     eng_mark(e, "start");
+    const int dt = e.fp16 ? 1 : 0;  // fp16 storage + f16 MFMA convolutions (optional mode; heads / prototypes / Detect stay fp32)
+    if (dt && e.convs.count("prediction_layers.0.head_cat") == 0) { set_error("fp16 Yolact needs the fused prediction head"); return ISEGMI_ERR_STATE; }
     Tensor x4;
-    TRY(eng_act(e, "input4", N, H, W, 4, &x4));
-    TRY(pad_c3_c4_launch(d_images, (int64_t)N * H * W, x4.d, e.cur));
     Tensor s, x;
-    TRY(eng_conv(e, "backbone.conv1", x4, 2, 3, 1, nullptr, "stem", &s));
+    if (dt) {
+        TRY(eng_act(e, "input4h", N, H + 6, (W + 7) & ~1, 4, &x4, 1));
+        TRY(pad_c3_to_f16_halo_launch(d_images, N, H, W, x4.d, e.cur));
+        TRY(eng_conv_stem_f16(e, "backbone.conv1", x4, H, W, "stem", &s));
+    } else {
+        TRY(eng_act(e, "input4", N, H, W, 4, &x4));
+        TRY(pad_c3_c4_launch(d_images, (int64_t)N * H * W, x4.d, e.cur));
+        TRY(eng_conv(e, "backbone.conv1", x4, 2, 3, 1, nullptr, "stem", &s));
+    }
     {
         const int Ho = (s.H + 2 - 3) / 2 + 1, Wo = (s.W + 2 - 3) / 2 + 1;
-        TRY(eng_act(e, "pool", N, Ho, Wo, s.C, &x));
-        TRY(maxpool_launch(s.d, N, s.H, s.W, s.C, 3, 2, 1, x.d, e.cur));
+        TRY(eng_act(e, "pool", N, Ho, Wo, s.C, &x, dt));
+        if (dt) TRY(maxpool_to_f16_launch(s.d, 1, N, s.H, s.W, s.C, 3, 2, 1, x.d, e.cur));
+        else TRY(maxpool_launch(s.d, N, s.H, s.W, s.C, 3, 2, 1, x.d, e.cur));
     }
     eng_mark(e, "stem");
     const int blocks[4] = {3, 4, (int)e.param("resnet_depth", 50) == 101 ? 23 : 6, 3};
@@ -291,10 +300,12 @@ int yolact_forward(Engine& e, const float* d_images, int N) {
     TRY(eng_conv(e, "fpn.lat_layers.0", C5, 1, 0, 0, nullptr, "fpn.lat5", &l5));
     TRY(eng_join(e, 0));
     TRY(eng_join(e, 1));
-    TRY(eng_act(e, "fpn.x4", N, l4.H, l4.W, l4.C, &x4f));
-    TRY(resize_bilinear_launch(l5.d, N, l5.H, l5.W, l5.C, l4.H, l4.W, l4.d, 0, x4f.d, e.cur));
-    TRY(eng_act(e, "fpn.x3", N, l3.H, l3.W, l3.C, &x3f));
-    TRY(resize_bilinear_launch(x4f.d, N, x4f.H, x4f.W, x4f.C, l3.H, l3.W, l3.d, 0, x3f.d, e.cur));
+    TRY(eng_act(e, "fpn.x4", N, l4.H, l4.W, l4.C, &x4f, dt));
+    if (dt) TRY(resize_bilinear_f16_launch(l5.d, N, l5.H, l5.W, l5.C, l4.H, l4.W, l4.d, 0, x4f.d, e.cur));
+    else TRY(resize_bilinear_launch(l5.d, N, l5.H, l5.W, l5.C, l4.H, l4.W, l4.d, 0, x4f.d, e.cur));
+    TRY(eng_act(e, "fpn.x3", N, l3.H, l3.W, l3.C, &x3f, dt));
+    if (dt) TRY(resize_bilinear_f16_launch(x4f.d, N, x4f.H, x4f.W, x4f.C, l3.H, l3.W, l3.d, 0, x3f.d, e.cur));
+    else TRY(resize_bilinear_launch(x4f.d, N, x4f.H, x4f.W, x4f.C, l3.H, l3.W, l3.d, 0, x3f.d, e.cur));
     TRY(eng_fork(e, 0));
     TRY(eng_fork(e, 1));
     {
@@ -336,7 +347,7 @@ int yolact_forward(Engine& e, const float* d_images, int N) {
         const int hw = uf.H * uf.W;
         if (fused) {
             TRY(eng_conv_into(e, "prediction_layers.0.head_cat", uf, 1, 1, 0, (float*)headcat + (int64_t)(off[l] / A) * CH, hw,
-                              (int64_t)(Ptot / A) * CH, CH));
+                              (int64_t)(Ptot / A) * CH, CH, /*out_f32=*/true));
             return ISEGMI_OK;
         }
         TRY(eng_conv_into(e, "prediction_layers.0.bbox_layer", uf, 1, 1, 0, (float*)loc + (int64_t)off[l] * 4, hw, (int64_t)Ptot * 4, A * 4));
@@ -358,10 +369,11 @@ int yolact_forward(Engine& e, const float* d_images, int N) {
         TRY(eng_conv(e, "proto_net.0", P[0], 1, 1, 1, nullptr, "proto.t0", &t));
         TRY(eng_conv(e, "proto_net.2", t, 1, 1, 1, nullptr, "proto.t1", &u));
         TRY(eng_conv(e, "proto_net.4", u, 1, 1, 1, nullptr, "proto.t2", &t));
-        TRY(eng_act(e, "proto.up", N, t.H * 2, t.W * 2, t.C, &u));
-        TRY(resize_bilinear_launch(t.d, N, t.H, t.W, t.C, t.H * 2, t.W * 2, nullptr, 1, u.d, e.cur));
+        TRY(eng_act(e, "proto.up", N, t.H * 2, t.W * 2, t.C, &u, dt));
+        if (dt) TRY(resize_bilinear_f16_launch(t.d, N, t.H, t.W, t.C, t.H * 2, t.W * 2, nullptr, 1, u.d, e.cur));
+        else TRY(resize_bilinear_launch(t.d, N, t.H, t.W, t.C, t.H * 2, t.W * 2, nullptr, 1, u.d, e.cur));
         TRY(eng_conv(e, "proto_net.8", u, 1, 1, 1, nullptr, "proto.t3", &t));
-        TRY(eng_conv(e, "proto_net.10", t, 1, 0, 1, nullptr, "proto", &proto));
+        TRY(eng_conv(e, "proto_net.10", t, 1, 0, 1, nullptr, "proto", &proto, /*out_f32=*/true));
     }
     { SideScope sc(e, 1); TRY(head_level(1)); TRY(head_level(3)); }
     { SideScope sc(e, 2); TRY(head_level(2)); TRY(head_level(4)); }

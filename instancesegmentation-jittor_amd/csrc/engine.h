@@ -123,6 +123,7 @@ int conv2d_f16_launch(const isegmi_conv_desc* d, const void* in, const void* w, 
                       void* out, int out_f32, hipStream_t st);
 int pad_c3_to_f16_halo_launch(const float* in, int N, int H, int W, void* out, hipStream_t st);
 int avgpool_full_launch(const float* x, int64_t R, int HW, int C, float* out, hipStream_t st);
+int resize_bilinear_f16_launch(const void* in, int N, int H, int W, int C, int Ho, int Wo, const void* add, int relu, void* out, hipStream_t st);
 int maxpool_to_f16_launch(const void* in, int in_f16, int N, int H, int W, int C, int k, int s, int p, void* out, hipStream_t st);
 int nearest2x_add_f16_launch(const void* coarse, int N, int Hc, int Wc, int C, const void* lat, int H, int W, void* out, hipStream_t st);
 int roi_align_f16_launch(const void* const* feats, const int* Hs, const int* Ws, const float* scales, int nlevels, const float* rois,

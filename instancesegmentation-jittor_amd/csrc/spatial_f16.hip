@@ -249,12 +249,61 @@ int pad_c3_to_f16_halo_launch(const float* in, int N, int H, int W, void* out, h
     return ISEGMI_OK;
 }
 
+// F.interpolate(bilinear, align_corners=False) on fp16 storage (+ optional add, + optional ReLU): Yolact's FPN top-down and
+// the protonet 2x upsample under fp16.  Arithmetic = resize_bilinear_kernel's (fp32, same order).
+__device__ __forceinline__ float bil1_h(float lx0, float lx1, float ly0, float ly1, float v00, float v01, float v10, float v11) {
+    float top = lx0 * v00; top = fmaf(lx1, v01, top);
+    float bot = lx0 * v10; bot = fmaf(lx1, v11, bot);
+    float v = ly0 * top; v = fmaf(ly1, bot, v);
+    return v;
+}
+__global__ void resize_bilinear_f16_kernel(const half_t* __restrict__ in, int N, int H, int W, int C, int Ho, int Wo,
+                                           const half_t* __restrict__ add, int relu, half_t* __restrict__ out) {
+    const int c4n = C >> 2;
+    const int64_t total = (int64_t)N * Ho * Wo * c4n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n);
+        int64_t t = i / c4n;
+        const int x = (int)(t % Wo); t /= Wo;
+        const int y = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
+        dm_bil_coef(y, H, Ho, y0, y1, ly0, ly1);
+        dm_bil_coef(x, W, Wo, x0, x1, lx0, lx1);
+        const half_t* b = in + (int64_t)n * H * W * C + c4 * 4;
+        const float4 v00 = ld4(b + ((int64_t)y0 * W + x0) * C), v01 = ld4(b + ((int64_t)y0 * W + x1) * C);
+        const float4 v10 = ld4(b + ((int64_t)y1 * W + x0) * C), v11 = ld4(b + ((int64_t)y1 * W + x1) * C);
+        float4 o;
+        o.x = bil1_h(lx0, lx1, ly0, ly1, v00.x, v01.x, v10.x, v11.x);
+        o.y = bil1_h(lx0, lx1, ly0, ly1, v00.y, v01.y, v10.y, v11.y);
+        o.z = bil1_h(lx0, lx1, ly0, ly1, v00.z, v01.z, v10.z, v11.z);
+        o.w = bil1_h(lx0, lx1, ly0, ly1, v00.w, v01.w, v10.w, v11.w);
+        const int64_t oo = (((int64_t)n * Ho + y) * Wo + x) * C + c4 * 4;
+        if (add) {
+            const float4 a = ld4(add + oo);
+            o.x = o.x + a.x; o.y = o.y + a.y; o.z = o.z + a.z; o.w = o.w + a.w;
+        }
+        if (relu) {
+            o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f;
+            o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
+        }
+        st4(out + oo, o);
+    }
+}
+
 int maxpool_to_f16_launch(const void* in, int in_f16, int N, int H, int W, int C, int k, int s, int p, void* out, hipStream_t st) {
     ARG_CHECK(C % 4 == 0, "C % 4");
     const int Ho = (H + 2 * p - k) / s + 1, Wo = (W + 2 * p - k) / s + 1;
     const unsigned g = gridf((int64_t)N * Ho * Wo * (C / 4));
     if (in_f16) hipLaunchKernelGGL(maxpool_to_f16_kernel<half_t>, dim3(g), dim3(256), 0, st, (const half_t*)in, N, H, W, C, k, s, p, Ho, Wo, (half_t*)out);
     else hipLaunchKernelGGL(maxpool_to_f16_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)in, N, H, W, C, k, s, p, Ho, Wo, (half_t*)out);
+    HIP_TRY(hipGetLastError());
+    return ISEGMI_OK;
+}
+int resize_bilinear_f16_launch(const void* in, int N, int H, int W, int C, int Ho, int Wo, const void* add, int relu, void* out, hipStream_t st) {
+    ARG_CHECK(C % 4 == 0, "C % 4");
+    hipLaunchKernelGGL(resize_bilinear_f16_kernel, dim3(gridf((int64_t)N * Ho * Wo * (C / 4))), dim3(256), 0, st, (const half_t*)in, N, H, W, C, Ho,
+                       Wo, (const half_t*)add, relu, (half_t*)out);
     HIP_TRY(hipGetLastError());
     return ISEGMI_OK;
 }

@@ -80,7 +80,11 @@ class Yolact:
 
     KIND = 1
 
-    def __init__(self, state_dict, cfg=YolactConfig(), max_batch=8, device=0, input_size=None, fuse_heads=True):
+    def __init__(self, state_dict, cfg=YolactConfig(), max_batch=8, device=0, input_size=None, fuse_heads=True, fp16=False):
+        """fp16=True: optional fp16-storage / f16-MFMA mode (backbone, FPN, protonet and head convolutions; the fused head
+        outputs, the prototypes and Detect / mask assembly stay fp32).  Not bit-exact: tolerance parity vs YolactRef(fp16=True)."""
+        assert not fp16 or fuse_heads, "fp16 Yolact uses the fused prediction head"
+        self.fp16 = bool(fp16)
         self.cfg = cfg
         self.size = int(input_size or cfg.max_size)
         self.max_batch = max_batch
@@ -90,6 +94,8 @@ class Yolact:
         self._h = C.c_void_p()
         _ffi.check(L.isegmi_engine_create(self.KIND, max_batch, self.size, self.size, C.byref(self._h)))
         self.set_param("resnet_depth", float(cfg.depth))
+        if self.fp16:  # must precede weight loading (weights are packed as fp16)
+            self.set_param("fp16", 1.0)
         self._load(state_dict)
         for k in ("nms_conf_thresh", "nms_thresh", "nms_top_k", "max_num_detections"):
             self.set_param(k, float(getattr(cfg, k)))

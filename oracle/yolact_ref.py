@@ -41,19 +41,26 @@ def make_priors(conv_h, conv_w, scale, max_size, ars=(1.0, 0.5, 2.0)):
 
 
 class YolactRef:
-    def __init__(self, sd, max_size=550, scales=(24, 48, 96, 192, 384), depth=50):
+    def __init__(self, sd, max_size=550, scales=(24, 48, 96, 192, 384), depth=50, fp16=False):
+        # fp16=True emulates the product's optional fp16-storage mode: image, conv weights and every stored activation are rounded
+        # to fp16 (the fused head outputs and the prototypes stay fp32), arithmetic stays the fp32 ordered chain.
+        self.fp16 = fp16
         self.sd = sd
         self.max_size = max_size
         self.scales = tuple(scales)
         self.depth = depth
         self.feats = {}
 
+    def _h(self, x):
+        return x.astype(np.float16).astype(np.float32) if self.fp16 else x
+
     def _conv_bn(self, x, name, bn, stride, pad, act, residual=None):
         sc, sh = _fold_bn(self.sd, bn)
-        return ora.conv2d(x, _krsc(self.sd[name + ".weight"]), stride, pad, sc, sh, residual, act)
+        return self._h(ora.conv2d(x, self._h(_krsc(self.sd[name + ".weight"])), stride, pad, sc, sh, residual, act))
 
-    def _conv_b(self, x, name, stride, pad, act, **kw):
-        return ora.conv2d(x, _krsc(self.sd[name + ".weight"]), stride, pad, None, self.sd[name + ".bias"], None, act, **kw)
+    def _conv_b(self, x, name, stride, pad, act, keep_f32=False, **kw):
+        y = ora.conv2d(x, self._h(_krsc(self.sd[name + ".weight"])), stride, pad, None, self.sd[name + ".bias"], None, act, **kw)
+        return y if keep_f32 else self._h(y)
 
     def forward(self, images_nhwc3):
         x = np.asarray(images_nhwc3, np.float32)
@@ -62,7 +69,7 @@ class YolactRef:
         w1 = _krsc(self.sd["backbone.conv1.weight"])
         w1 = np.concatenate([w1, np.zeros(w1.shape[:3] + (1,), np.float32)], -1)
         sc, sh = _fold_bn(self.sd, "backbone.bn1")
-        x = ora.conv2d(x4, w1, 2, 3, sc, sh, None, 1)
+        x = self._h(ora.conv2d(self._h(x4), self._h(w1), 2, 3, sc, sh, None, 1))
         x = ora.maxpool(x, 3, 2, 1)
         outs = []
         for li, nb in enumerate((3, 4, 23 if self.depth == 101 else 6, 3)):
@@ -80,8 +87,8 @@ class YolactRef:
         l5 = self._conv_b(C5, "fpn.lat_layers.0", 1, 0, 0)
         l4 = self._conv_b(C4, "fpn.lat_layers.1", 1, 0, 0)
         l3 = self._conv_b(C3, "fpn.lat_layers.2", 1, 0, 0)
-        x4f = ora.resize_bilinear(l5, l4.shape[1], l4.shape[2], add=l4)
-        x3f = ora.resize_bilinear(x4f, l3.shape[1], l3.shape[2], add=l3)
+        x4f = self._h(ora.resize_bilinear(l5, l4.shape[1], l4.shape[2], add=l4))
+        x3f = self._h(ora.resize_bilinear(x4f, l3.shape[1], l3.shape[2], add=l3))
         P5 = self._conv_b(l5, "fpn.pred_layers.0", 1, 1, 1)
         P4 = self._conv_b(x4f, "fpn.pred_layers.1", 1, 1, 1)
         P3 = self._conv_b(x3f, "fpn.pred_layers.2", 1, 1, 1)
@@ -91,16 +98,16 @@ class YolactRef:
         t = self._conv_b(P3, "proto_net.0", 1, 1, 1)
         t = self._conv_b(t, "proto_net.2", 1, 1, 1)
         t = self._conv_b(t, "proto_net.4", 1, 1, 1)
-        t = ora.resize_bilinear(t, t.shape[1] * 2, t.shape[2] * 2, relu=1)
+        t = self._h(ora.resize_bilinear(t, t.shape[1] * 2, t.shape[2] * 2, relu=1))
         t = self._conv_b(t, "proto_net.8", 1, 1, 1)
-        proto = self._conv_b(t, "proto_net.10", 1, 0, 1)
+        proto = self._conv_b(t, "proto_net.10", 1, 0, 1, keep_f32=True)
         locs, confs, masks, priors = [], [], [], []
         scales = self.scales
         for l, p in enumerate(P):
             u = self._conv_b(p, "prediction_layers.0.upfeature.0", 1, 1, 1)
-            locs.append(self._conv_b(u, "prediction_layers.0.bbox_layer", 1, 1, 0).reshape(N, -1, 4))
-            confs.append(self._conv_b(u, "prediction_layers.0.conf_layer", 1, 1, 0).reshape(N, -1, 81))
-            masks.append(self._conv_b(u, "prediction_layers.0.mask_layer", 1, 1, 2).reshape(N, -1, 32))
+            locs.append(self._conv_b(u, "prediction_layers.0.bbox_layer", 1, 1, 0, keep_f32=True).reshape(N, -1, 4))
+            confs.append(self._conv_b(u, "prediction_layers.0.conf_layer", 1, 1, 0, keep_f32=True).reshape(N, -1, 81))
+            masks.append(self._conv_b(u, "prediction_layers.0.mask_layer", 1, 1, 2, keep_f32=True).reshape(N, -1, 32))
             priors.append(make_priors(p.shape[1], p.shape[2], scales[l], self.max_size))
         loc = np.concatenate(locs, 1); conf = np.concatenate(confs, 1); mask = np.concatenate(masks, 1)
         priors = np.concatenate(priors, 0)

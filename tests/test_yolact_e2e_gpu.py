@@ -188,3 +188,53 @@ def test_yolact_hipgraph_replay_matches_eager(ffi, sd):
     assert np.array_equal(g3["det.count"], e3["det.count"]) and np.array_equal(g3["det.score"], e3["det.score"])
     assert not np.array_equal(e3["det.score"], ea["det.score"])
     net.close()
+
+
+def _iou_norm(a, b):
+    ax1, ay1, ax2, ay2 = [a[:, i][:, None] for i in range(4)]
+    bx1, by1, bx2, by2 = [b[:, i][None, :] for i in range(4)]
+    iw = np.clip(np.minimum(ax2, bx2) - np.maximum(ax1, bx1), 0, None); ih = np.clip(np.minimum(ay2, by2) - np.maximum(ay1, by1), 0, None)
+    inter = iw * ih
+    return inter / ((ax2 - ax1) * (ay2 - ay1) + (bx2 - bx1) * (by2 - by1) - inter + 1e-12)
+
+
+def test_yolact_fp16_mode_close_to_fp16_oracle(ffi, sd):
+    """Optional fp16-storage / f16-MFMA mode of the Yolact engine.  TOLERANCE (stated): the 16-term sum inside one f16 MFMA is
+    unordered, so features are compared at 5e-3 of the tensor's max magnitude against an oracle that rounds the same tensors to
+    fp16; detections are matched by IoU because near-tied scores may swap: >= 90 % of the oracle's detections must have a
+    same-class partner with IoU >= 0.9 and |score diff| <= 0.01; masks of matched pairs must agree on >= 99 % of the pixels."""
+    from isegmi.yolact import Yolact, postprocess
+    size = 200
+    net = Yolact(sd, max_batch=2, input_size=size, fp16=True)
+    ref = YolactRef(sd, max_size=550, fp16=True)
+    x = _images(20261003, 2, size)
+    out = net(x)
+    refd = ref.forward(x)
+    for name in ("P3", "P5", "P7"):
+        g = net.fetch(name, 2)
+        assert g.dtype == np.float16
+        r = ref.feats[name]
+        assert np.abs(g.astype(np.float32).reshape(r.shape) - r).max() <= 5e-3 * np.abs(r).max(), name
+    g = net.fetch("proto", 2); r = ref.feats["proto"]
+    assert g.dtype == np.float32 and np.abs(g.reshape(r.shape) - r).max() <= 5e-3 * np.abs(r).max()
+    hc = net.fetch("headcat", 2)
+    assert hc.dtype == np.float32
+    assert np.abs(hc[..., 12:255].reshape(ref.feats["conf"].shape) - ref.feats["conf"]).max() <= 5e-3 * np.abs(ref.feats["conf"]).max()
+    total = 0
+    for i in range(2):
+        r, d = refd[i], out[i]["detection"]
+        assert d is not None and abs(len(d["score"]) - len(r["score"])) <= 5
+        iou = _iou_norm(r["box"], d["box"])
+        same = r["cls"][:, None] == d["class"][None, :]
+        close = np.abs(r["score"][:, None] - d["score"][None, :]) <= 0.01
+        ok = (iou >= 0.9) & same & close
+        matched = np.any(ok, axis=1)
+        assert matched.mean() >= 0.9, matched.mean()
+        total += len(r["score"])
+        cls, sc, boxes, masks = postprocess(out, 231, 187, batch_idx=i, score_threshold=0.0)
+        rc, rs, rb, rm = YolactRef.postprocess(r, 231, 187, 0.0)
+        j = np.argmax(np.where(ok, iou, -1), axis=1)
+        agree = (masks[j[matched]] == rm[matched]).mean()
+        assert agree >= 0.99, agree
+    assert total > 20
+    net.close()
