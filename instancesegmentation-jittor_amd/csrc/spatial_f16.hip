@@ -42,6 +42,36 @@ __global__ void maxpool_to_f16_kernel(const TI* __restrict__ in, int N, int H, i
     }
 }
 
+// fp16 -> fp16 max-pool with 8 channels (16 B) per lane (the stem pool reads 9 taps per output: half the load instructions)
+typedef _Float16 h8p __attribute__((ext_vector_type(8)));
+__global__ void maxpool_f16_c8_kernel(const half_t* __restrict__ in, int N, int H, int W, int C, int k, int s, int p, int Ho, int Wo,
+                                      half_t* __restrict__ out) {
+    const int c8n = C >> 3;
+    const int64_t total = (int64_t)N * Ho * Wo * c8n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % c8n);
+        int64_t t = i / c8n;
+        const int wo = (int)(t % Wo); t /= Wo;
+        const int ho = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        h8p m;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m[j] = (half_t)(-INFINITY);
+        for (int r = 0; r < k; ++r) {
+            const int hi = ho * s + r - p;
+            if ((unsigned)hi >= (unsigned)H) continue;
+            for (int q = 0; q < k; ++q) {
+                const int wi = wo * s + q - p;
+                if ((unsigned)wi >= (unsigned)W) continue;
+                const h8p v = *(const h8p*)(in + (((int64_t)n * H + hi) * W + wi) * C + c8 * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) m[j] = v[j] > m[j] ? v[j] : m[j];  // exact: a max of fp16 values is one of them
+            }
+        }
+        *(h8p*)(out + (((int64_t)n * Ho + ho) * Wo + wo) * C + c8 * 8) = m;
+    }
+}
+
 __global__ void nearest2x_add_f16_kernel(const half_t* __restrict__ coarse, int N, int Hc, int Wc, int C, const half_t* __restrict__ lat,
                                          int H, int W, half_t* __restrict__ out) {
     const int c4n = C >> 2;
@@ -295,7 +325,10 @@ int maxpool_to_f16_launch(const void* in, int in_f16, int N, int H, int W, int C
     ARG_CHECK(C % 4 == 0, "C % 4");
     const int Ho = (H + 2 * p - k) / s + 1, Wo = (W + 2 * p - k) / s + 1;
     const unsigned g = gridf((int64_t)N * Ho * Wo * (C / 4));
-    if (in_f16) hipLaunchKernelGGL(maxpool_to_f16_kernel<half_t>, dim3(g), dim3(256), 0, st, (const half_t*)in, N, H, W, C, k, s, p, Ho, Wo, (half_t*)out);
+    if (in_f16 && C % 8 == 0)
+        hipLaunchKernelGGL(maxpool_f16_c8_kernel, dim3(gridf((int64_t)N * Ho * Wo * (C / 8))), dim3(256), 0, st, (const half_t*)in, N, H, W, C, k, s, p, Ho,
+                           Wo, (half_t*)out);
+    else if (in_f16) hipLaunchKernelGGL(maxpool_to_f16_kernel<half_t>, dim3(g), dim3(256), 0, st, (const half_t*)in, N, H, W, C, k, s, p, Ho, Wo, (half_t*)out);
     else hipLaunchKernelGGL(maxpool_to_f16_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)in, N, H, W, C, k, s, p, Ho, Wo, (half_t*)out);
     HIP_TRY(hipGetLastError());
     return ISEGMI_OK;
