@@ -35,7 +35,7 @@ struct ConvK {
     int N, H, W, Cin, Cout, R, S, stride, pad, Ho, Wo, M;
     int nchunks, cin_chunks;
     int64_t wrow;
-    unsigned in_bytes, out_bytes, res_bytes;
+    unsigned in_bytes, out_bytes, res_bytes, w_bytes;
     int act, out_div, contiguous;
     int64_t out_img_stride, out_pix_stride;
     int mtiles, ntiles;
@@ -255,6 +255,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK p) {
 // buffer-op loads/epilogue as the main kernel; 18.4 KB LDS -> 8 blocks/CU.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Loads run RING chunks ahead in registers (one 16-B A load and one 16-B B load per thread and chunk): these layers run at
+// 1-2 blocks per CU with only 8 short MFMAs per chunk, so a single chunk of prefetch left every chunk waiting ~0.7 us for
+// its own loads (53 us per K=2304 layer at bs=1); chunks past the end load zeros through the buffer range check.
+template <int RING>
 __global__ __launch_bounds__(256) void conv_mfma16_kernel(const ConvK p) {
     constexpr int BM = 32, BN = 32;
     constexpr int STAGE = (BM + BN) * LDS_ROW;
@@ -281,30 +285,32 @@ __global__ __launch_bounds__(256) void conv_mfma16_kernel(const ConvK p) {
             hi0 = ho * p.stride - p.pad; wi0 = wo * p.stride - p.pad; nb = n * p.H;
         } else { hi0 = -(1 << 28); wi0 = 0; nb = 0; }
     }
-    const float* wsrc = p.w + (int64_t)(n0 + lrow) * p.wrow + g8 * 4;
+    const unsigned wbase = ((unsigned)(n0 + lrow) * (unsigned)p.wrow + (unsigned)(g8 * 4)) * 4u;
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-    u32x4 ra, rb;
+    u32x4 ra[RING], rb[RING];
     int kr = 0, ks = 0, kc = 0;
-    auto load_chunk = [&](int chunk) {
+    auto load_chunk = [&](int slot, int chunk) {
+        const unsigned dead = (unsigned)((p.nchunks - 1 - chunk) >> 31) & OOB;
         const int hi = hi0 + kr, wi = wi0 + ks;
         const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
         const unsigned off = ((unsigned)((nb + hi) * p.W + wi) * (unsigned)p.Cin + (unsigned)(kc * 32 + g8 * 4)) * 4u;
-        ra = __builtin_amdgcn_raw_buffer_load_b128(rs_in, ok ? off : OOB, 0, 0);
-        rb = *(const u32x4*)(wsrc + chunk * 32);
+        ra[slot] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (ok ? off : OOB) | dead, 0, 0);
+        rb[slot] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (wbase + (unsigned)chunk * 128u) | dead, 0, 0);
         if (++kc == p.cin_chunks) { kc = 0; if (++ks == p.S) { ks = 0; ++kr; } }
     };
     // element e = 4*(g8&1) + j of 8-group g8>>1 lives at position 4*(e&1) + (e>>1): (x0,x2) and (x1,x3) pairs
     const int grp = g8 >> 1, half = g8 & 1;
-    auto store_chunk = [&](int stage) {
+    auto store_chunk = [&](int slot, int stage) {
         float* As = smem16 + stage * STAGE;
         float* Bs = As + BM * LDS_ROW;
         float* d = As + lrow * LDS_ROW + grp * 8 + 2 * half;
-        *(u32x2*)d = u32x2{ra.x, ra.z};
-        *(u32x2*)(d + 4) = u32x2{ra.y, ra.w};
-        *(u32x4*)(Bs + lrow * LDS_ROW + g8 * 4) = rb;  // weights are pre-permuted: straight copy
+        *(u32x2*)d = u32x2{ra[slot].x, ra[slot].z};
+        *(u32x2*)(d + 4) = u32x2{ra[slot].y, ra[slot].w};
+        *(u32x4*)(Bs + lrow * LDS_ROW + g8 * 4) = rb[slot];  // weights are pre-permuted: straight copy
     };
 
     f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -313,31 +319,44 @@ __global__ __launch_bounds__(256) void conv_mfma16_kernel(const ConvK p) {
     const int kpos = 4 * (lq & 1) + (lq >> 1);
     const int a_off = (wm * 16 + li) * LDS_ROW + kpos;
     const int b_off = BM * LDS_ROW + (wn * 16 + li) * LDS_ROW + kpos;
-    auto compute = [&](int stage) {
+    // all sixteen fragment reads of a chunk are issued BEFORE its eight dependent MFMAs: one LDS latency per chunk instead
+    // of four (read -> wait -> 2 MFMAs -> read ... cost ~0.5 us per chunk where a layer is one short block per CU)
+    float fa[8], fb[8];
+    auto read_frags = [&](int stage) {
         const float* sb = smem16 + stage * STAGE;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float a0 = sb[a_off + g * 8], a1 = sb[a_off + g * 8 + 2];
-            const float b0 = sb[b_off + g * 8], b1 = sb[b_off + g * 8 + 2];
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc, 0, 0, 0);
+            fa[2 * g] = sb[a_off + g * 8]; fa[2 * g + 1] = sb[a_off + g * 8 + 2];
+            fb[2 * g] = sb[b_off + g * 8]; fb[2 * g + 1] = sb[b_off + g * 8 + 2];
         }
     };
+    auto mma = [&]() {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[s], fb[s], acc, 0, 0, 0);
+    };
 
-    load_chunk(0);
-    store_chunk(0);
+#pragma unroll
+    for (int i = 0; i < RING; ++i) load_chunk(i, i);
+    store_chunk(0, 0);
     __syncthreads();
     int cur = 0;
-    for (int t = 0; t + 1 < p.nchunks; ++t) {
-        load_chunk(t + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(cur);
-        __builtin_amdgcn_sched_barrier(0);
-        store_chunk(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
+    // chunk c waits in register slot c % RING; iteration t refills the slot chunk t just left, computes chunk t from LDS
+    // and moves chunk t+1 (issued RING-1 iterations ago) to the other LDS stage
+    for (int t0 = 0; t0 < p.nchunks; t0 += RING) {
+#pragma unroll
+        for (int j = 0; j < RING; ++j) {
+            const int t = t0 + j;
+            if (t >= p.nchunks) break;  // uniform
+            load_chunk(j, t + RING);
+            __builtin_amdgcn_sched_barrier(0);
+            read_frags(cur);
+            mma();
+            __builtin_amdgcn_sched_barrier(0);
+            store_chunk((j + 1) % RING, cur ^ 1);  // chunk t+1 was loaded RING-1 iterations ago
+            __syncthreads();
+            cur ^= 1;
+        }
     }
-    compute(cur);
 
     // epilogue: D col (cout) = lane&15, row (pixel) = (lane>>4)*4 + e
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, p.out_bytes, 0x00020000);
@@ -430,6 +449,7 @@ int conv2d_launch(const isegmi_conv_desc* d, const float* in, const float* w, co
     const int64_t in_bytes = (int64_t)d->N * d->H * d->W * d->Cin * 4;
     ARG_CHECK(in_bytes < (1ll << 31), "conv input must be < 2 GiB (32-bit buffer offsets)");
     k.in_bytes = (unsigned)in_bytes;
+    k.w_bytes = (unsigned)((int64_t)cout_pad(d) * k.wrow * 4);
     k.act = d->act;
     k.out_div = d->out_div > 0 ? d->out_div : k.Ho * k.Wo;
     k.out_pix_stride = d->out_pix_stride > 0 ? d->out_pix_stride : d->Cout;
@@ -460,7 +480,7 @@ int conv2d_launch(const isegmi_conv_desc* d, const float* in, const float* w, co
     if (tile == 4) {
         k.mtiles = cdiv(k.M, 32);
         k.ntiles = cdiv(d->Cout, 32);
-        hipLaunchKernelGGL(conv_mfma16_kernel, dim3((unsigned)(k.mtiles * k.ntiles)), dim3(256), 0, st, k);
+        hipLaunchKernelGGL(conv_mfma16_kernel<4>, dim3((unsigned)(k.mtiles * k.ntiles)), dim3(256), 0, st, k);
         HIP_TRY(hipGetLastError());
         return ISEGMI_OK;
     }
