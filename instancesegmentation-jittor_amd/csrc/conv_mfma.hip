@@ -468,13 +468,12 @@ int conv2d_launch(const isegmi_conv_desc* d, const float* in, const float* w, co
         // 36.9 KB LDS) matches 128x128 at full occupancy (124 TF/s) and wins everywhere else through finer
         // wave quantisation, so it is the default; 128-wide tiles stay selectable for experiments.
         tile = 3;
-        // ... except (measured per layer at bs=8 and bs=1, profiles/r01_conv_tile3_vs_tile4.txt) where the 32x32 block
-        // on 16x16x4 MFMA wins: grids of fewer than ~160 64x64 tiles (latency-bound: 4x the blocks and a ~2.5x shorter
-        // K-chain per wave), and narrow outputs whose padding to 64 wastes half the MFMA work (Cout <= 32 at any size,
-        // Cout % 64 in 1..32 such as the 96-wide coefficient head while the grid is small).
+        // ... except (measured per layer at bs = 1, 2, 8 on both models, profiles/r01_conv_tile3_vs_tile4_v2.txt) where the 32x32 block
+        // on 16x16x4 MFMA wins: grids of fewer than ~130 64x64 tiles (latency-bound: 4x the blocks and a 2x shorter K-chain per
+        // wave; 0.62-0.83 of the 64x64 time there, 1.04-1.8x above), and outputs of at most 32 channels at any size (padding
+        // them to a 64-wide tile wastes half the MFMA work: 0.75-0.9).
         const int64_t t64 = (int64_t)cdiv(k.M, 64) * cdiv(d->Cout, 64);
-        const int rem64 = d->Cout % 64;
-        if (!is_stem(d) && (t64 < 160 || d->Cout <= 32 || (rem64 > 0 && rem64 <= 32 && t64 < 400))) tile = 4;
+        if (!is_stem(d) && (t64 < 130 || d->Cout <= 32)) tile = 4;
     }
     if (tile == 4 && is_stem(d)) tile = 3;  // the 16x16x4 variant has no stem path
     if (tile == 4) {
