@@ -251,9 +251,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK p) {
 // v_mfma_f32_16x16x4_f32 (lane (i, q) supplies k = 4s + q; the instruction is the same ordered fmaf chain, 4 k deep).
 // A wave's accumulator chain advances 4 k per 40 cycles instead of 2 k per 64, so the K-order latency floor that
 // bounds tiny layers (res5, P5-P7 heads, everything at bs=1) drops ~2.5x, and a layer yields 4x more blocks than
-// with 64x64 tiles.  Same packed weights, same LDS image (36-float rows, [k0 k2 k4 k6 | k1 k3 k5 k7] groups), same
-// buffer-op loads/epilogue as the main kernel; 18.4 KB LDS -> 8 blocks/CU.
+// with 64x64 tiles.  Same packed weights and buffer-op loads/epilogue as the main kernel; the LDS image differs: rows
+// hold the 32 k of a chunk in NATURAL order at a 34-float pitch, so the 32 lanes of a ds_read_b32 group (16 rows x 2
+// k-quads) land on 32 different banks (bank = 2*row + k mod 32).  The main kernel's 36-float permuted image made these
+// reads 4-way conflicted (512 LDS cycles per chunk and block, the largest single term of a chunk at 1-2 blocks per CU).
+// 17.4 KB LDS -> 8 blocks/CU.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int LDS_ROW16 = 34;
 
 // Loads run RING chunks ahead in registers (one 16-B A load and one 16-B B load per thread and chunk): these layers run at
 // 1-2 blocks per CU with only 8 short MFMAs per chunk, so a single chunk of prefetch left every chunk waiting ~0.7 us for
@@ -261,7 +265,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int RING>
 __global__ __launch_bounds__(256) void conv_mfma16_kernel(const ConvK p) {
     constexpr int BM = 32, BN = 32;
-    constexpr int STAGE = (BM + BN) * LDS_ROW;
+    constexpr int STAGE = (BM + BN) * LDS_ROW16;
     __shared__ __attribute__((aligned(16))) float smem16[2 * STAGE];
 
     const int tid = threadIdx.x;
@@ -302,33 +306,30 @@ __global__ __launch_bounds__(256) void conv_mfma16_kernel(const ConvK p) {
         rb[slot] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (wbase + (unsigned)chunk * 128u) | dead, 0, 0);
         if (++kc == p.cin_chunks) { kc = 0; if (++ks == p.S) { ks = 0; ++kr; } }
     };
-    // element e = 4*(g8&1) + j of 8-group g8>>1 lives at position 4*(e&1) + (e>>1): (x0,x2) and (x1,x3) pairs
+    // A arrives in natural k order (two 8-byte stores: rows are only 8-byte aligned at this pitch); the packed weight row
+    // holds [k0 k2 k4 k6 | k1 k3 k5 k7] per 8-group, so thread (grp, half) owns k = 8*grp + 2j + half
     const int grp = g8 >> 1, half = g8 & 1;
     auto store_chunk = [&](int slot, int stage) {
         float* As = smem16 + stage * STAGE;
-        float* Bs = As + BM * LDS_ROW;
-        float* d = As + lrow * LDS_ROW + grp * 8 + 2 * half;
-        *(u32x2*)d = u32x2{ra[slot].x, ra[slot].z};
-        *(u32x2*)(d + 4) = u32x2{ra[slot].y, ra[slot].w};
-        *(u32x4*)(Bs + lrow * LDS_ROW + g8 * 4) = rb[slot];  // weights are pre-permuted: straight copy
+        float* Bs = As + BM * LDS_ROW16;
+        float* d = As + lrow * LDS_ROW16 + g8 * 4;
+        *(u32x2*)d = u32x2{ra[slot].x, ra[slot].y};
+        *(u32x2*)(d + 2) = u32x2{ra[slot].z, ra[slot].w};
+        unsigned* b = (unsigned*)(Bs + lrow * LDS_ROW16 + grp * 8 + half);
+        b[0] = rb[slot].x; b[2] = rb[slot].y; b[4] = rb[slot].z; b[6] = rb[slot].w;
     };
 
     f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
     const int li = lane & 15, lq = lane >> 4;
-    // k = 4s + lq: s even -> e = lq, s odd -> e = 4 + lq  => position 4*(lq&1) + (lq>>1) (+2 for odd s)
-    const int kpos = 4 * (lq & 1) + (lq >> 1);
-    const int a_off = (wm * 16 + li) * LDS_ROW + kpos;
-    const int b_off = BM * LDS_ROW + (wn * 16 + li) * LDS_ROW + kpos;
+    const int a_off = (wm * 16 + li) * LDS_ROW16 + lq;  // step s reads k = 4s + lq
+    const int b_off = BM * LDS_ROW16 + (wn * 16 + li) * LDS_ROW16 + lq;
     // all sixteen fragment reads of a chunk are issued BEFORE its eight dependent MFMAs: one LDS latency per chunk instead
     // of four (read -> wait -> 2 MFMAs -> read ... cost ~0.5 us per chunk where a layer is one short block per CU)
     float fa[8], fb[8];
     auto read_frags = [&](int stage) {
         const float* sb = smem16 + stage * STAGE;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            fa[2 * g] = sb[a_off + g * 8]; fa[2 * g + 1] = sb[a_off + g * 8 + 2];
-            fb[2 * g] = sb[b_off + g * 8]; fb[2 * g + 1] = sb[b_off + g * 8 + 2];
-        }
+        for (int s = 0; s < 8; ++s) { fa[s] = sb[a_off + s * 4]; fb[s] = sb[b_off + s * 4]; }
     };
     auto mma = [&]() {
 #pragma unroll
@@ -468,12 +469,17 @@ int conv2d_launch(const isegmi_conv_desc* d, const float* in, const float* w, co
         // 36.9 KB LDS) matches 128x128 at full occupancy (124 TF/s) and wins everywhere else through finer
         // wave quantisation, so it is the default; 128-wide tiles stay selectable for experiments.
         tile = 3;
-        // ... except (measured per layer at bs = 1, 2, 8 on both models, profiles/r01_conv_tile3_vs_tile4_v2.txt) where the 32x32 block
-        // on 16x16x4 MFMA wins: grids of fewer than ~130 64x64 tiles (latency-bound: 4x the blocks and a 2x shorter K-chain per
-        // wave; 0.62-0.83 of the 64x64 time there, 1.04-1.8x above), and outputs of at most 32 channels at any size (padding
-        // them to a 64-wide tile wastes half the MFMA work: 0.75-0.9).
+        // ... except where the 32x32 block on 16x16x4 MFMA wins (measured per layer at bs = 1, 2, 8 on both models,
+        // profiles/r01_conv_tile3_vs_tile4_v3.txt).  Both kernels are latency-bound on these grids and their times fit
+        //   64x64:  26 + 34 * ceil(t64 / 256)   (whole rounds of one block per CU; 4 blocks/CU only hide part of a round)
+        //   32x32:  29 + 10.5 * (t64 / 64)      (4x the blocks, 8 per CU, fractional rounds)
+        // in units of K/2304 x 1 us, t64 = number of 64x64 tiles: the 32x32 block takes every grid of up to one round, and
+        // above that the tail end of each 64x64 round (257-395, 513-602, 769-809 tiles) until the 64x64 tile's halved
+        // L2 traffic and MFMA issue rate win for good.  Outputs of at most 32 channels always go to the 32-wide block
+        // (padding them to 64 wastes half the MFMA work: 0.67-0.91 of the 64x64 time at any size).
         const int64_t t64 = (int64_t)cdiv(k.M, 64) * cdiv(d->Cout, 64);
-        if (!is_stem(d) && (t64 < 130 || d->Cout <= 32)) tile = 4;
+        const bool small_wins = 384 + 21 * t64 < 4352 * ((t64 + 255) / 256);
+        if (!is_stem(d) && (small_wins || d->Cout <= 32)) tile = 4;
     }
     if (tile == 4 && is_stem(d)) tile = 3;  // the 16x16x4 variant has no stem path
     if (tile == 4) {
