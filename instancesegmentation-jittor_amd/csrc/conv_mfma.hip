@@ -17,6 +17,7 @@
 // consecutive k the LDS image is stored as [k0 k2 k4 k6 | k1 k3 k5 k7] so that one ds_read_b128
 // per lane half feeds 4 MFMAs in natural k order (weights are pre-permuted at pack time,
 // activations by register renaming at LDS-write time).
+#include <type_traits>
 #include "../../include/isegmi.h"
 #include "common.h"
 #include "detmath.h"
@@ -39,6 +40,7 @@ struct ConvK {
     int act, out_div, contiguous;
     int64_t out_img_stride, out_pix_stride;
     int mtiles, ntiles;
+    int mfast;  // tile order within an XCD: 1 = M fastest (weights larger than the input), 0 = Cout fastest
 };
 
 constexpr int LDS_ROW = 36;
@@ -61,7 +63,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK p) {
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
     const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int nt = logical % p.ntiles, mt = logical / p.ntiles;
+    // an XCD's consecutive tiles walk the operand that is SMALLER in bytes, so its L2 holds all of that one and only an
+    // eighth of the larger (weights on small-M layers: res5 / P5-P7 heads / everything at bs=1 were re-streaming the whole
+    // filter bank from HBM into every XCD)
+    const int nt = p.mfast ? logical / p.mtiles : logical % p.ntiles;
+    const int mt = p.mfast ? logical % p.mtiles : logical / p.ntiles;
     const int m0 = mt * BM, n0 = nt * BN;
 
     // ---- loader state: thread covers row (tid>>2)+64*j, 8-group g = tid&3 of the 32-chunk
@@ -257,105 +263,187 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK p) {
 // reads 4-way conflicted (512 LDS cycles per chunk and block, the largest single term of a chunk at 1-2 blocks per CU).
 // 17.4 KB LDS -> 8 blocks/CU.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int LDS_ROW16 = 34;
 
 // Loads run RING chunks ahead in registers (one 16-B A load and one 16-B B load per thread and chunk): these layers run at
 // 1-2 blocks per CU with only 8 short MFMAs per chunk, so a single chunk of prefetch left every chunk waiting ~0.7 us for
 // its own loads (53 us per K=2304 layer at bs=1); chunks past the end load zeros through the buffer range check.
-template <int RING>
-__global__ __launch_bounds__(256) void conv_mfma16_kernel(const ConvK p) {
+//
+// LW = true adds four LOADER waves (512 threads): at one block per CU a wave's chunk is bound by its own instruction stream
+// (timing-only builds: ~290 cycles of address arithmetic + loop control, ~110 of LDS traffic, ~60 of barrier on top of the
+// 256-cycle dependent MFMA chain, nothing of it overlapped because there is no second wave on the SIMD), so the global
+// loads, their address arithmetic and the LDS stores move to a partner wave on the same SIMD and the MFMA wave is left
+// with 8 ds_read2 + 8 MFMA + 1 barrier per chunk.
+template <int RING, bool LW>
+__global__ __launch_bounds__(LW ? 512 : 256) void conv_mfma16_kernel(const ConvK p) {
     constexpr int BM = 32, BN = 32;
-    constexpr int STAGE = (BM + BN) * LDS_ROW16;
-    __shared__ __attribute__((aligned(16))) float smem16[2 * STAGE];
+    constexpr int ROW = 34;  // floats; pitch = 2 mod 32: bank = 2*row + k for the fragment reads
+    constexpr int STAGE = (BM + BN) * ROW;
+    constexpr int NST = LW ? 3 : 2;  // LDS stages (LW: chunk t computed while t+1 is read into registers and t+2 written)
+    __shared__ __attribute__((aligned(16))) float smem16[NST * STAGE];
 
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x & 255;
+    const bool loader = LW && __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) != 0;  // wave-uniform, and known to be
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
     const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int nt = logical % p.ntiles, mt = logical / p.ntiles;
+    // an XCD's consecutive tiles walk the operand that is SMALLER in bytes, so its L2 holds all of that one and only an
+    // eighth of the larger
+    const int nt = p.mfast ? logical / p.mtiles : logical % p.ntiles;
+    const int mt = p.mfast ? logical % p.mtiles : logical / p.ntiles;
     const int m0 = mt * BM, n0 = nt * BN;
 
     // loader: thread covers row tid>>3 (32 rows) and 4 consecutive k (g8 = tid&7) of the 32-chunk
     const int lrow = tid >> 3, g8 = tid & 7;
-    int hi0, wi0, nb;
+    int hi0, wi0;
+    unsigned abase;  // byte offset of (n, hi0, wi0, 4*g8); wraps for padding taps, which the range test below rejects
     {
         const int m = m0 + lrow;
         if (m < p.M) {
             const int hw = p.Ho * p.Wo;
             const int n = m / hw, rem = m - n * hw;
             const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-            hi0 = ho * p.stride - p.pad; wi0 = wo * p.stride - p.pad; nb = n * p.H;
-        } else { hi0 = -(1 << 28); wi0 = 0; nb = 0; }
+            hi0 = ho * p.stride - p.pad; wi0 = wo * p.stride - p.pad;
+            abase = ((unsigned)((n * p.H + hi0) * p.W + wi0) * (unsigned)p.Cin + (unsigned)(g8 * 4)) * 4u;
+        } else { hi0 = -(1 << 28); wi0 = 0; abase = 0; }
     }
     const unsigned wbase = ((unsigned)(n0 + lrow) * (unsigned)p.wrow + (unsigned)(g8 * 4)) * 4u;
-    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    // The ring's loads are issued and awaited through inline asm: with the builtin loads the compiler's own s_waitcnt
+    // placement loses count across the unrolled loop's back edge (vmcnt(1), (0) at the head of every RING-th iteration: the
+    // whole ring drained there and a full memory latency, ~850 cycles, showed up at the block's barrier every RING chunks).
+    // Loads return in order, so "the chunk RING-1 behind the newest has landed" is exactly vmcnt(2 * (RING - 1)); chunks
+    // past the end still issue (out of range, zeros) and keep that count exact.
+    auto make_rsrc = [](const void* ptr, unsigned bytes) {
+        const unsigned long long a = (unsigned long long)ptr;
+        return u32x4{(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a),
+                     (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu)),
+                     (unsigned)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000u};
+    };
+    const u32x4 rs_in = make_rsrc(p.in, p.in_bytes), rs_w = make_rsrc(p.w, p.w_bytes);
     u32x4 ra[RING], rb[RING];
-    int kr = 0, ks = 0, kc = 0;
-    auto load_chunk = [&](int slot, int chunk) {
+    int kr = 0, ks = 0, kc = 0, chunk = 0;  // position of the next chunk to load (they are loaded strictly in order)
+    auto load_chunk = [&](int slot) {
         const unsigned dead = (unsigned)((p.nchunks - 1 - chunk) >> 31) & OOB;
-        const int hi = hi0 + kr, wi = wi0 + ks;
-        const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-        const unsigned off = ((unsigned)((nb + hi) * p.W + wi) * (unsigned)p.Cin + (unsigned)(kc * 32 + g8 * 4)) * 4u;
-        ra[slot] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (ok ? off : OOB) | dead, 0, 0);
-        rb[slot] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (wbase + (unsigned)chunk * 128u) | dead, 0, 0);
-        if (++kc == p.cin_chunks) { kc = 0; if (++ks == p.S) { ks = 0; ++kr; } }
+        const bool ok = (unsigned)(hi0 + kr) < (unsigned)p.H && (unsigned)(wi0 + ks) < (unsigned)p.W;
+        const unsigned tap = (unsigned)((kr * p.W + ks) * p.Cin + kc * 32) * 4u;  // scalar
+        const unsigned offa = (ok ? abase + tap : OOB) | dead, offb = (wbase + (unsigned)chunk * 128u) | dead;
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(ra[slot]) : "v"(offa), "s"(rs_in) : "memory");
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(rb[slot]) : "v"(offb), "s"(rs_w) : "memory");
+        // branch-free tap counters: the pipelined iteration below must stay one basic block for its issue-order directives
+        const int wc = (kc + 1 == p.cin_chunks) ? 1 : 0;
+        kc = wc ? 0 : kc + 1;
+        const int ws = (wc && ks + 1 == p.S) ? 1 : 0;
+        ks = ws ? 0 : ks + wc;
+        kr += ws;
+        ++chunk;
     };
     // A arrives in natural k order (two 8-byte stores: rows are only 8-byte aligned at this pitch); the packed weight row
     // holds [k0 k2 k4 k6 | k1 k3 k5 k7] per 8-group, so thread (grp, half) owns k = 8*grp + 2j + half
     const int grp = g8 >> 1, half = g8 & 1;
-    auto store_chunk = [&](int slot, int stage) {
+    auto store_chunk = [&](int slot, int stage, auto pending) {  // pending = loads issued after this slot's
+        asm volatile("s_waitcnt vmcnt(%2)" : "+v"(ra[slot]), "+v"(rb[slot]) : "n"(decltype(pending)::value) : "memory");
         float* As = smem16 + stage * STAGE;
-        float* Bs = As + BM * LDS_ROW16;
-        float* d = As + lrow * LDS_ROW16 + g8 * 4;
+        float* Bs = As + BM * ROW;
+        float* d = As + lrow * ROW + g8 * 4;
         *(u32x2*)d = u32x2{ra[slot].x, ra[slot].y};
         *(u32x2*)(d + 2) = u32x2{ra[slot].z, ra[slot].w};
-        unsigned* b = (unsigned*)(Bs + lrow * LDS_ROW16 + grp * 8 + half);
+        unsigned* b = (unsigned*)(Bs + lrow * ROW + grp * 8 + half);
         b[0] = rb[slot].x; b[2] = rb[slot].y; b[4] = rb[slot].z; b[6] = rb[slot].w;
     };
 
     f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
     const int li = lane & 15, lq = lane >> 4;
-    const int a_off = (wm * 16 + li) * LDS_ROW16 + lq;  // step s reads k = 4s + lq
-    const int b_off = BM * LDS_ROW16 + (wn * 16 + li) * LDS_ROW16 + lq;
-    // all sixteen fragment reads of a chunk are issued BEFORE its eight dependent MFMAs: one LDS latency per chunk instead
-    // of four (read -> wait -> 2 MFMAs -> read ... cost ~0.5 us per chunk where a layer is one short block per CU)
-    float fa[8], fb[8];
-    auto read_frags = [&](int stage) {
+    const int a_off = (wm * 16 + li) * ROW + lq;  // MFMA step s reads k = 4s + lq
+    const int b_off = BM * ROW + (wn * 16 + li) * ROW + lq;
+    float fa[LW ? 2 : 1][8], fb[LW ? 2 : 1][8];
+    auto read_frags = [&](int set, int stage) {
         const float* sb = smem16 + stage * STAGE;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) { fa[s] = sb[a_off + s * 4]; fb[s] = sb[b_off + s * 4]; }
+        for (int s = 0; s < 8; ++s) { fa[set][s] = sb[a_off + s * 4]; fb[set][s] = sb[b_off + s * 4]; }
     };
-    auto mma = [&]() {
+    auto mma = [&](int set) {
 #pragma unroll
-        for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[s], fb[s], acc, 0, 0, 0);
+        for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[set][s], fb[set][s], acc, 0, 0, 0);
     };
+    typedef std::integral_constant<int, 2 * (RING - 1)> Steady;
+    static_assert(RING % 2 == 0 && RING >= 4, "fragment sets alternate with the unrolled slot index");
 
+    if (!LW) {
+        // Plain variant (17.4 KB LDS, 8 blocks/CU -- the one for grids of several blocks per CU, where the other blocks hide
+        // a chunk's latencies): chunk c waits in register slot c % RING; iteration t refills the slot chunk t left, issues all
+        // sixteen fragment reads of chunk t BEFORE its eight dependent MFMAs (one LDS latency per chunk instead of four) and
+        // moves chunk t+1 to the other LDS stage.
 #pragma unroll
-    for (int i = 0; i < RING; ++i) load_chunk(i, i);
-    store_chunk(0, 0);
-    __syncthreads();
-    int cur = 0;
-    // chunk c waits in register slot c % RING; iteration t refills the slot chunk t just left, computes chunk t from LDS
-    // and moves chunk t+1 (issued RING-1 iterations ago) to the other LDS stage
-    for (int t0 = 0; t0 < p.nchunks; t0 += RING) {
+        for (int i = 0; i < RING; ++i) load_chunk(i);
+        store_chunk(0, 0, Steady());
+        __syncthreads();
+        int cur = 0;
+        for (int t0 = 0; t0 < p.nchunks; t0 += RING) {
 #pragma unroll
-        for (int j = 0; j < RING; ++j) {
-            const int t = t0 + j;
-            if (t >= p.nchunks) break;  // uniform
-            load_chunk(j, t + RING);
-            __builtin_amdgcn_sched_barrier(0);
-            read_frags(cur);
-            mma();
-            __builtin_amdgcn_sched_barrier(0);
-            store_chunk((j + 1) % RING, cur ^ 1);  // chunk t+1 was loaded RING-1 iterations ago
-            __syncthreads();
-            cur ^= 1;
+            for (int j = 0; j < RING; ++j) {
+                if (t0 + j >= p.nchunks) break;  // uniform
+                load_chunk(j);
+                __builtin_amdgcn_sched_barrier(0);
+                read_frags(0, cur);
+                mma(0);
+                __builtin_amdgcn_sched_barrier(0);
+                store_chunk((j + 1) % RING, cur ^ 1, Steady());
+                __syncthreads();
+                cur ^= 1;
+            }
+        }
+        // the past-the-end loads still in flight target ring registers the epilogue is about to reuse
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        // Loader-wave variant, software-pipelined over three LDS stages (the K order of every accumulator is untouched):
+        // in iteration t the MFMA waves issue the fragment reads of chunk t+1 into the other register set and run the eight
+        // dependent MFMAs of chunk t under them, while the loader waves move chunk t+2 from its register slot to the third
+        // LDS stage and refill that slot with chunk t+2+RING.  One barrier per chunk, same count in both roles; the stage
+        // written at t was last read by the fragment reads issued at t-2, consumed before the barrier of t-1.
+        if (loader) {
+#pragma unroll
+            for (int i = 0; i < RING; ++i) load_chunk(i);
+            store_chunk(0, 0, Steady());
+            store_chunk(1, 1, std::integral_constant<int, 2 * (RING - 2)>());
+            load_chunk(0);
+            load_chunk(1);
+        }
+        __syncthreads();
+        if (loader) {
+            int st2 = 2;
+            for (int t0 = 0; t0 < p.nchunks; t0 += RING) {
+#pragma unroll
+                for (int j = 0; j < RING; ++j) {
+                    if (t0 + j >= p.nchunks) break;  // uniform
+                    store_chunk((j + 2) % RING, st2, Steady());
+                    load_chunk((j + 2) % RING);
+                    __syncthreads();
+                    st2 = st2 == NST - 1 ? 0 : st2 + 1;
+                }
+            }
+            return;  // the epilogue is not theirs
+        }
+        read_frags(0, 0);
+        int st1 = 1;
+        for (int t0 = 0; t0 < p.nchunks; t0 += 2) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (t0 + j >= p.nchunks) break;  // uniform
+                read_frags((j + 1) & 1, st1);
+                mma(j & 1);
+                // issue order: one fragment read in the shadow of each dependent MFMA (32 cycles apart)
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+                }
+                __syncthreads();
+                st1 = st1 == NST - 1 ? 0 : st1 + 1;
+            }
         }
     }
 
@@ -408,7 +496,7 @@ static int check_desc(const isegmi_conv_desc* d) {
     ARG_CHECK(is_stem(d) || (d->Cin > 0 && d->Cin % 32 == 0), "Cin must be a multiple of 32 (or the Cin=4 7x7 stem)");
     ARG_CHECK(d->H + 2 * d->pad >= d->R && d->W + 2 * d->pad >= d->S, "kernel larger than padded input");
     ARG_CHECK(d->act >= 0 && d->act <= 2, "act");
-    ARG_CHECK(d->tile >= 0 && d->tile <= 4, "tile");
+    ARG_CHECK(d->tile >= 0 && d->tile <= 5, "tile");
     return ISEGMI_OK;
 }
 
@@ -451,6 +539,7 @@ int conv2d_launch(const isegmi_conv_desc* d, const float* in, const float* w, co
     ARG_CHECK(in_bytes < (1ll << 31), "conv input must be < 2 GiB (32-bit buffer offsets)");
     k.in_bytes = (unsigned)in_bytes;
     k.w_bytes = (unsigned)((int64_t)cout_pad(d) * k.wrow * 4);
+    k.mfast = (int64_t)k.w_bytes > in_bytes ? 1 : 0;
     k.act = d->act;
     k.out_div = d->out_div > 0 ? d->out_div : k.Ho * k.Wo;
     k.out_pix_stride = d->out_pix_stride > 0 ? d->out_pix_stride : d->Cout;
@@ -470,22 +559,29 @@ int conv2d_launch(const isegmi_conv_desc* d, const float* in, const float* w, co
         // wave quantisation, so it is the default; 128-wide tiles stay selectable for experiments.
         tile = 3;
         // ... except where the 32x32 block on 16x16x4 MFMA wins (measured per layer at bs = 1, 2, 8 on both models,
-        // profiles/r01_conv_tile3_vs_tile4_v3.txt).  Both kernels are latency-bound on these grids and their times fit
-        //   64x64:  26 + 34 * ceil(t64 / 256)   (whole rounds of one block per CU; 4 blocks/CU only hide part of a round)
-        //   32x32:  29 + 10.5 * (t64 / 64)      (4x the blocks, 8 per CU, fractional rounds)
-        // in units of K/2304 x 1 us, t64 = number of 64x64 tiles: the 32x32 block takes every grid of up to one round, and
-        // above that the tail end of each 64x64 round (257-395, 513-602, 769-809 tiles) until the 64x64 tile's halved
-        // L2 traffic and MFMA issue rate win for good.  Outputs of at most 32 channels always go to the 32-wide block
+        // profiles/r01_conv_tile3_vs_tile45_v4.txt).  All three kernels are latency-bound on these grids and their times fit,
+        // in units of K/2304 x 1 us with t64 = number of 64x64 tiles, r3 = ceil(t64 / 256), r4 = ceil(t64 / 64):
+        //   tile 3, 64x64:                 26 + 34   * r3   (whole rounds of one block per CU; 4 blocks/CU hide part of a round)
+        //   tile 4, 32x32:                 18 + 11.5 * r4   (4x the blocks, rounds a third as long)
+        //   tile 5, 32x32 + loader waves:  12 + 13.5 * r4   (shortest chunk, but 8-wave blocks pack the CU worse)
+        // so tile 5 takes grids of up to 128 tiles, tile 4 the rest of the first round up to 192 tiles and the head of the second
+        // and third 64x64 rounds (257-384, and 513-576 where K >= 1024 leaves the fixed costs behind); a full first round
+        // (193-256) and everything larger stay on the 64x64 tile.  Outputs of at most 32 channels never use the 64-wide tile
         // (padding them to 64 wastes half the MFMA work: 0.67-0.91 of the 64x64 time at any size).
         const int64_t t64 = (int64_t)cdiv(k.M, 64) * cdiv(d->Cout, 64);
-        const bool small_wins = 384 + 21 * t64 < 4352 * ((t64 + 255) / 256);
-        if (!is_stem(d) && (small_wins || d->Cout <= 32)) tile = 4;
+        const int64_t r3 = (t64 + 255) / 256, r4 = (t64 + 63) / 64;
+        if (!is_stem(d)) {
+            if (r4 < 3) tile = 5;
+            else if (d->Cout <= 32 || (23 * r4 < 16 + 68 * r3 && (r3 < 3 || k.nchunks >= 32))) tile = 4;
+        }
     }
-    if (tile == 4 && is_stem(d)) tile = 3;  // the 16x16x4 variant has no stem path
-    if (tile == 4) {
+    if (tile >= 4 && is_stem(d)) tile = 3;  // the 16x16x4 variants have no stem path
+    if (tile >= 4) {
         k.mtiles = cdiv(k.M, 32);
         k.ntiles = cdiv(d->Cout, 32);
-        hipLaunchKernelGGL(conv_mfma16_kernel<4>, dim3((unsigned)(k.mtiles * k.ntiles)), dim3(256), 0, st, k);
+        const dim3 g16((unsigned)(k.mtiles * k.ntiles));
+        if (tile == 5) hipLaunchKernelGGL((conv_mfma16_kernel<8, true>), g16, dim3(512), 0, st, k);
+        else hipLaunchKernelGGL((conv_mfma16_kernel<4, false>), g16, dim3(256), 0, st, k);
         HIP_TRY(hipGetLastError());
         return ISEGMI_OK;
     }
