@@ -562,17 +562,17 @@ int conv2d_launch(const isegmi_conv_desc* d, const float* in, const float* w, co
         // profiles/r01_conv_tile3_vs_tile45_v4.txt).  All three kernels are latency-bound on these grids and their times fit,
         // in units of K/2304 x 1 us with t64 = number of 64x64 tiles, r3 = ceil(t64 / 256), r4 = ceil(t64 / 64):
         //   tile 3, 64x64:                 26 + 34   * r3   (whole rounds of one block per CU; 4 blocks/CU hide part of a round)
-        //   tile 4, 32x32:                 18 + 11.5 * r4   (4x the blocks, rounds a third as long)
+        //   tile 4, 32x32:                 18 + 10.6 * r4   (4x the blocks, rounds a third as long)
         //   tile 5, 32x32 + loader waves:  12 + 13.5 * r4   (shortest chunk, but 8-wave blocks pack the CU worse)
-        // so tile 5 takes grids of up to 128 tiles, tile 4 the rest of the first round up to 192 tiles and the head of the second
-        // and third 64x64 rounds (257-384, and 513-576 where K >= 1024 leaves the fixed costs behind); a full first round
-        // (193-256) and everything larger stay on the 64x64 tile.  Outputs of at most 32 channels never use the 64-wide tile
-        // (padding them to 64 wastes half the MFMA work: 0.67-0.91 of the 64x64 time at any size).
+        // so tile 5 takes grids of up to 128 tiles and tile 4 the rest of the first three 64x64 rounds wherever its finer
+        // rounds come out ahead (129-256, 257-448, and 513-640 where K >= 1024 leaves the fixed costs behind); full 64x64
+        // rounds (449-512: fc6/fc7 at two images) and everything larger stay on the 64x64 tile.  Outputs of at most 32
+        // channels never use the 64-wide tile (padding them to 64 wastes half the MFMA work: 0.67-0.91 of the 64x64 time).
         const int64_t t64 = (int64_t)cdiv(k.M, 64) * cdiv(d->Cout, 64);
         const int64_t r3 = (t64 + 255) / 256, r4 = (t64 + 63) / 64;
         if (!is_stem(d)) {
             if (r4 < 3) tile = 5;
-            else if (d->Cout <= 32 || (23 * r4 < 16 + 68 * r3 && (r3 < 3 || k.nchunks >= 32))) tile = 4;
+            else if (d->Cout <= 32 || (106 * r4 <= 80 + 340 * r3 && (r3 < 3 || (r3 == 3 && k.nchunks >= 32)))) tile = 4;
         }
     }
     if (tile >= 4 && is_stem(d)) tile = 3;  // the 16x16x4 variants have no stem path
