@@ -168,11 +168,14 @@ int topk_launch(const float* keys, int64_t row_stride, int rows, int n, int k, c
     ARG_CHECK(rows >= 0 && n >= 0 && k > 0 && k <= 8192, "topk sizes (k <= 8192)");
     if (rows == 0) return ISEGMI_OK;
     TopkArgs a{keys, row_stride, n, k, limit, rows_per_limit > 0 ? rows_per_limit : 1, out_vals, out_idx, out_cnt};
+    // wide blocks when the rows alone cannot fill the chip (bs=1 Detect: 80 class rows of 19 248 priors, then ONE row of 16 000
+    // candidates): a row's five passes over its keys are latency-bound per thread, so 1024 threads cut them ~3x
+    const bool wide = n > 65536 || (n > 8192 && rows < 256);
     if (k <= 128) {
-        if (n > 65536) hipLaunchKernelGGL((topk_kernel<1024, 128>), dim3(rows), dim3(1024), 0, st, a);
+        if (wide) hipLaunchKernelGGL((topk_kernel<1024, 128>), dim3(rows), dim3(1024), 0, st, a);
         else hipLaunchKernelGGL((topk_kernel<256, 128>), dim3(rows), dim3(256), 0, st, a);
     } else if (k <= 256) {
-        if (n > 65536) hipLaunchKernelGGL((topk_kernel<1024, 256>), dim3(rows), dim3(1024), 0, st, a);
+        if (wide) hipLaunchKernelGGL((topk_kernel<1024, 256>), dim3(rows), dim3(1024), 0, st, a);
         else hipLaunchKernelGGL((topk_kernel<256, 256>), dim3(rows), dim3(256), 0, st, a);
     } else if (k <= 1024) {
         if (n > 16384) hipLaunchKernelGGL((topk_kernel<1024, 1024>), dim3(rows), dim3(1024), 0, st, a);
