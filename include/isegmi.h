@@ -210,7 +210,9 @@ int isegmi_op_rpn_level(const float* d_head, const float* d_anchors, const int32
                         int HW, int A, int pre_nms, int post_nms, float nms_thr, float min_size,
                         int nms_ge, float* d_ws_prob, float* d_ws_tk_vals, int32_t* d_ws_tk_idx,
                         int32_t* d_ws_tk_cnt, float* d_out_boxes, float* d_out_scores,
-                        int32_t* d_out_cnt, void* stream);
+                        int32_t* d_out_cnt, void* d_ws_nms /* optional: N * 131072 bytes, the suppression
+                        matrix of the chip-wide NMS used when pre_nms <= 1024; NULL = single-block NMS */,
+                        void* stream);
 
 /* ---- model engine ----
  * Replaces the model object the reference builds inside COCODemo(cfg, ...) (README.md:320-324)

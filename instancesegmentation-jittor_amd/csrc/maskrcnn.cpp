@@ -16,7 +16,8 @@ int nms_launch(const float*, const float*, int, int, float, int, int, int, int*,
 int rpn_sigmoid_launch(const float* head, int64_t total, int A, int CH, float* prob, hipStream_t st);
 int rpn_decode_nms_launch(const float* head, const float* anchors, const float* tk_vals, const int* tk_idx, const int* tk_cnt,
                           const int* image_hw, int N, int HWA, int A, int CH, int pre_nms, int post_nms, float thr, float min_size,
-                          int ge, int level, int L, int post_cap, float* out_boxes, float* out_scores, int* out_cnt, hipStream_t st);
+                          int ge, int level, int L, int post_cap, float* out_boxes, float* out_scores, int* out_cnt, void* nms_ws,
+                          hipStream_t st);
 int sum_counts_launch(const int* cnt, int N, int L, int* total, hipStream_t st);
 int gather_proposals_launch(const float* cand_boxes, const float* fin_vals, const int* fin_idx, const int* fin_cnt, int N,
                             int cand_per_img, int K, float* props, float* prop_scores, int* prop_cnt, hipStream_t st);
@@ -159,13 +160,15 @@ int maskrcnn_forward(Engine& e, const float* d_images, int N) {
         TRY(eng_buf(e, "rpn.tk_vals" + ls, (int64_t)N * pre_nms * 4, &q)); tkv = (float*)q;
         TRY(eng_buf(e, "rpn.tk_idx" + ls, (int64_t)N * pre_nms * 4, &q, 1)); tki = (int*)q;
         TRY(eng_buf(e, "rpn.tk_cnt" + ls, (int64_t)N * 4, &q, 1)); tkc = (int*)q;
+        void* nms_ws = nullptr;  // suppression matrix of the chip-wide NMS (one per level: the levels run concurrently)
+        if (pre_nms <= 1024) TRY(eng_buf(e, "rpn.nms_ws" + ls, (int64_t)N * 131072, &nms_ws, 1));
         const int sk = l % 3;
         TRY(eng_fork(e, sk));
         SideScope sc(e, sk);
         TRY(rpn_sigmoid_launch(head.d, (int64_t)N * HWA, A, CH, prob, st));
         TRY(topk_launch(prob, HWA, N, HWA, pre_nms, nullptr, 1, tkv, tki, tkc, st));
         TRY(rpn_decode_nms_launch(head.d, (const float*)anc->d, tkv, tki, tkc, d_hw, N, HWA, A, CH, pre_nms, post_nms, rpn_thr, rpn_min,
-                                  ge, l, L, post_nms, cand_boxes, cand_scores, cand_cnt, st));
+                                  ge, l, L, post_nms, cand_boxes, cand_scores, cand_cnt, nms_ws, st));
         return ISEGMI_OK;
     };
     // WAR: the previous forward's RoI heads (tail stream) still gather from P2..P5 and read proposals / det buffers;
@@ -370,8 +373,10 @@ static int maskrcnn_c4_forward(Engine& e, const float* d_images, int N) {
     TRY(rpn_sigmoid_launch(head.d, (int64_t)N * HWA, A, CH, prob, st));
     TRY(topk_launch(prob, HWA, N, HWA, pre_nms, nullptr, 1, tkv, tki, tkc, st));
     // one level: the NMS output (score order) IS the proposal list (select_over_all_levels only runs for > 1 level)
+    void* nms_ws = nullptr;
+    if (pre_nms <= 1024) TRY(eng_buf(e, "rpn.nms_ws", (int64_t)N * 131072, &nms_ws, 1));
     TRY(rpn_decode_nms_launch(head.d, (const float*)anc->d, tkv, tki, tkc, d_hw, N, HWA, A, CH, pre_nms, post_nms, rpn_thr, rpn_min, ge, 0, 1,
-                              R, props, prop_scores, prop_cnt, st));
+                              R, props, prop_scores, prop_cnt, nms_ws, st));
     eng_mark(e, "rpn");
 
     // ---- box head: ROIAlign 14x14 (adaptive sampling) -> conv5 head -> avgpool -> predictors

@@ -278,6 +278,147 @@ __global__ __launch_bounds__(1024) void rpn_decode_nms_kernel(const float* __res
     if (threadIdx.x == 0) out_cnt[n * L + level] = kc;
 }
 
+// ---- the same per-level RPN NMS split over the chip (pre_nms <= NMS_CAP and a matrix workspace from the caller).
+// The single-block kernel above is bound by ONE CU's VALU rate (~n^2/2 exact IoU tests, 256 us per level at n = 1000).  Here
+//   rpn_nms_matrix_kernel  (136 waves per image): wave (r, w), r <= w, owns rows 64r..64r+63 x columns 64w..64w+63 of the
+//       suppression matrix: bit j of M[i][w] set iff j > i and IoU(i, j) exceeds thr (lane = row, 64 broadcast column boxes);
+//   rpn_nms_scan_kernel    (one block per image): copies the matrix into LDS and runs the greedy scan on bits alone -- a
+//       chunk of 64 is resolved from its diagonal words by a 64-step scalar chain (readlane / bitcmp / andn2), then lane
+//       (w, q) ORs the kept rows' word w into the `removed` words with 16 unconditional LDS reads.
+// Same predicate, same visiting order => the kept list is identical to nms_block's.  ws: [N][NMS_CAP][NMS_CAP/64] u64.
+__device__ __forceinline__ float4 rpn_candidate_box(const float* __restrict__ head, const float* __restrict__ anchors,
+                                                    const int* __restrict__ tk_idx, int n, int j, int pre_nms, int HWA, int A, int CH,
+                                                    float im_w, float im_h) {
+    const int idx = tk_idx[(int64_t)n * pre_nms + j];
+    const int pix = idx / A, a = idx - pix * A;
+    const float* hp = head + ((int64_t)n * (HWA / A) + pix) * CH + A + a * 4;
+    const float4 d = make_float4(hp[0], hp[1], hp[2], hp[3]);
+    const float4 an = *(const float4*)(anchors + (int64_t)idx * 4);
+    return clip_box(decode_box(an, d, 1.f, 1.f, 1.f, 1.f), im_w, im_h);
+}
+
+__global__ __launch_bounds__(256) void rpn_nms_matrix_kernel(const float* __restrict__ head, const float* __restrict__ anchors,
+                                                             const int* __restrict__ tk_idx, const int* __restrict__ tk_cnt,
+                                                             const int* __restrict__ image_hw, int HWA, int A, int CH, int pre_nms,
+                                                             float thr, int ge, unsigned long long* __restrict__ ws) {
+    constexpr int W = NMS_CAP / 64;
+    __shared__ float4 cols[4][64];
+    const int n = blockIdx.y;
+    const int cnt = tk_cnt[n];
+    const int nwords = (cnt + 63) >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pair = blockIdx.x * 4 + wave;  // wave-uniform
+    int w = 0;
+    while ((w + 1) * (w + 2) / 2 <= pair) ++w;
+    const int r = pair - w * (w + 1) / 2;
+    if (w >= nwords) return;  // whole wave; no block-level barrier below
+    const float im_h = (float)image_hw[2 * n], im_w = (float)image_hw[2 * n + 1];
+    const IouThr T = make_iou_thr(thr, ge);
+    const int i = (r << 6) + lane, jc = (w << 6) + lane;
+    const float4 mine = rpn_candidate_box(head, anchors, tk_idx, n, i < cnt ? i : 0, pre_nms, HWA, A, CH, im_w, im_h);
+    cols[wave][lane] = rpn_candidate_box(head, anchors, tk_idx, n, jc < cnt ? jc : 0, pre_nms, HWA, A, CH, im_w, im_h);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's own LDS writes have landed
+    unsigned long long m = 0ull;
+#pragma unroll 8
+    for (int b = 0; b < 64; ++b) {
+        const int j = (w << 6) + b;
+        const bool sup = j > i && j < cnt && iou_exceeds(mine, cols[wave][b], 1.0f, T);
+        m |= sup ? (1ull << b) : 0ull;
+    }
+    if (i < cnt) ws[((int64_t)n * NMS_CAP + i) * W + w] = m;
+}
+
+__global__ __launch_bounds__(1024) void rpn_nms_scan_kernel(const float* __restrict__ head, const float* __restrict__ anchors,
+                                                            const float* __restrict__ tk_vals, const int* __restrict__ tk_idx,
+                                                            const int* __restrict__ tk_cnt, const int* __restrict__ image_hw,
+                                                            int HWA, int A, int CH, int pre_nms, int post_nms, float min_size,
+                                                            int level, int L, int post_cap, const unsigned long long* __restrict__ ws,
+                                                            float* __restrict__ out_boxes, float* __restrict__ out_scores,
+                                                            int* __restrict__ out_cnt) {
+    constexpr int W = NMS_CAP / 64;
+    extern __shared__ unsigned long long M[];  // [NMS_CAP][W]
+    __shared__ float4 sb[NMS_CAP];
+    __shared__ unsigned short kept[NMS_CAP];
+    __shared__ unsigned char dead[NMS_CAP];
+    __shared__ int kc_sh;
+    const int n = blockIdx.x;
+    const int cnt = tk_cnt[n];
+    const int nwords = (cnt + 63) >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float im_h = (float)image_hw[2 * n], im_w = (float)image_hw[2 * n + 1];
+    {   // matrix rows [0, cnt) -> LDS, 16 bytes per thread and step (rows past cnt and words left of the diagonal are stale
+        // workspace; the scan never selects them)
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4* src = (const u32x4*)(ws + (int64_t)n * NMS_CAP * W);
+        u32x4* dst = (u32x4*)M;
+        const int n16 = cnt * W / 2;
+        for (int q = tid; q < n16; q += 1024) dst[q] = src[q];
+    }
+    for (int j = tid; j < cnt; j += 1024) {
+        const float4 b = rpn_candidate_box(head, anchors, tk_idx, n, j, pre_nms, HWA, A, CH, im_w, im_h);
+        sb[j] = b;
+        const float ws_ = b.z - b.x + 1.0f, hs = b.w - b.y + 1.0f;
+        dead[j] = (ws_ >= min_size && hs >= min_size) ? 0 : 1;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        unsigned long long rem = 0ull;  // lane w < nwords: removed / not-a-candidate bits of word w
+        for (int w = 0; w < nwords; ++w) {
+            const int i = (w << 6) + lane;
+            const unsigned long long m = __ballot(i >= cnt || dead[i < cnt ? i : 0]);
+            if (lane == w) rem = m;
+        }
+        const unsigned long long lt_mask = (1ull << lane) - 1ull;
+        const int pw = lane & 15, pq = lane >> 4;
+        int kc = 0;
+        for (int c = 0; c < nwords; ++c) {
+            if (kc >= post_nms) break;
+            const int i = (c << 6) + lane;
+            const unsigned long long d = i < cnt ? M[i * W + c] : 0ull;
+            const int dlo = (int)(unsigned)d, dhi = (int)(unsigned)(d >> 32);
+            const unsigned long long rc = __shfl(rem, c, 64);
+            unsigned long long alive = ~(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(rc >> 32)) << 32) |
+                                         (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)rc));
+#pragma unroll
+            for (int b = 0; b < 64; ++b) {  // box b survives => it strikes its later chunk-mates; survivors are the kept ones
+                const unsigned long long db = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(dhi, b) << 32) |
+                                              (unsigned long long)(unsigned)__builtin_amdgcn_readlane(dlo, b);
+                alive &= ((alive >> b) & 1ull) ? ~db : ~0ull;
+            }
+            unsigned long long keepm = alive;
+            while (kc + __popcll(keepm) > post_nms) keepm &= ~(1ull << (63 - __builtin_clzll(keepm)));  // uniform; last chunk only
+            if ((keepm >> lane) & 1ull) kept[kc + __popcll(keepm & lt_mask)] = (unsigned short)i;
+            unsigned long long acc = 0ull;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int b = pq * 16 + u;
+                const unsigned long long v = M[((c << 6) + b) * W + pw];
+                acc |= ((keepm >> b) & 1ull) ? v : 0ull;
+            }
+            acc |= __shfl_xor(acc, 16, 64);
+            acc |= __shfl_xor(acc, 32, 64);
+            if (lane < 16 && lane > c) rem |= acc;
+            kc += __popcll(keepm);
+        }
+        if (lane == 0) kc_sh = kc;
+    }
+    __syncthreads();
+    const int kc = kc_sh;
+    const int64_t ob = ((int64_t)n * L + level) * post_cap;
+    for (int i = tid; i < post_cap; i += 1024) {
+        if (i < kc) {
+            const int src = kept[i];
+            *(float4*)(out_boxes + (ob + i) * 4) = sb[src];
+            out_scores[ob + i] = tk_vals[(int64_t)n * pre_nms + src];
+        } else {
+            *(float4*)(out_boxes + (ob + i) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            out_scores[ob + i] = -1.0f;
+        }
+    }
+    if (tid == 0) out_cnt[n * L + level] = kc;
+}
+
 __global__ void sum_counts_kernel(const int* __restrict__ cnt, int L, int* __restrict__ total) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= (int)gridDim.x * (int)blockDim.x) return;
@@ -657,10 +798,25 @@ int rpn_sigmoid_launch(const float* head, int64_t total, int A, int CH, float* p
 
 int rpn_decode_nms_launch(const float* head, const float* anchors, const float* tk_vals, const int* tk_idx, const int* tk_cnt,
                           const int* image_hw, int N, int HWA, int A, int CH, int pre_nms, int post_nms, float thr, float min_size,
-                          int ge, int level, int L, int post_cap, float* out_boxes, float* out_scores, int* out_cnt, hipStream_t st) {
+                          int ge, int level, int L, int post_cap, float* out_boxes, float* out_scores, int* out_cnt, void* nms_ws,
+                          hipStream_t st) {
     ARG_CHECK(pre_nms <= NMS_CAP_BIG && post_nms <= post_cap, "rpn sizes (pre_nms <= 6144)");
     ARG_CHECK(thr > 0.0f, "nms threshold must be > 0");
-    if (pre_nms <= NMS_CAP)
+    if (pre_nms <= NMS_CAP && nms_ws != nullptr && post_nms > 0) {
+        constexpr int W = NMS_CAP / 64;
+        constexpr int matrix_bytes = NMS_CAP * W * 8;  // 128 KB next to 19 KB of static LDS
+        static bool attr = false;
+        if (!attr) {
+            HIP_TRY(hipFuncSetAttribute((const void*)rpn_nms_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, matrix_bytes));
+            attr = true;
+        }
+        const int pairs = W * (W + 1) / 2;
+        hipLaunchKernelGGL(rpn_nms_matrix_kernel, dim3(cdiv(pairs, 4), N), dim3(256), 0, st, head, anchors, tk_idx, tk_cnt, image_hw, HWA, A,
+                           CH, pre_nms, thr, ge, (unsigned long long*)nms_ws);
+        hipLaunchKernelGGL(rpn_nms_scan_kernel, dim3(N), dim3(1024), matrix_bytes, st, head, anchors, tk_vals, tk_idx, tk_cnt, image_hw, HWA,
+                           A, CH, pre_nms, post_nms, min_size, level, L, post_cap, (const unsigned long long*)nms_ws, out_boxes, out_scores,
+                           out_cnt);
+    } else if (pre_nms <= NMS_CAP)
         hipLaunchKernelGGL(rpn_decode_nms_kernel<NMS_CAP>, dim3(N), dim3(1024), 0, st, head, anchors, tk_vals, tk_idx, tk_cnt, image_hw, HWA, A,
                            CH, pre_nms, post_nms, thr, min_size, ge, level, L, post_cap, out_boxes, out_scores, out_cnt);
     else
@@ -795,11 +951,12 @@ extern "C" int isegmi_op_paste_masks(const float* d_masks, const float* d_boxes,
 }
 
 // One RPN level for N images (parity-test entry; the engine calls the same launchers):
-// head [N][HW][A*5] -> boxes/scores [N][post_nms] (+count).  Workspaces: prob [N][HWA], tk_* [N][pre_nms].
+// head [N][HW][A*5] -> boxes/scores [N][post_nms] (+count).  Workspaces: prob [N][HWA], tk_* [N][pre_nms]; d_ws_nms: optional
+// N * 128 KiB for the chip-wide NMS (pre_nms <= 1024), NULL = single-block NMS.
 extern "C" int isegmi_op_rpn_level(const float* d_head, const float* d_anchors, const int32_t* d_image_hw, int N, int HW, int A,
                                    int pre_nms, int post_nms, float nms_thr, float min_size, int nms_ge, float* d_ws_prob,
                                    float* d_ws_tk_vals, int32_t* d_ws_tk_idx, int32_t* d_ws_tk_cnt, float* d_out_boxes,
-                                   float* d_out_scores, int32_t* d_out_cnt, void* stream) {
+                                   float* d_out_scores, int32_t* d_out_cnt, void* d_ws_nms, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int HWA = HW * A, CH = A * 5;
     int rc = rpn_sigmoid_launch(d_head, (int64_t)N * HWA, A, CH, d_ws_prob, st);
@@ -809,5 +966,5 @@ extern "C" int isegmi_op_rpn_level(const float* d_head, const float* d_anchors, 
     if (rc) return rc;
     (void)k;
     return rpn_decode_nms_launch(d_head, d_anchors, d_ws_tk_vals, d_ws_tk_idx, d_ws_tk_cnt, d_image_hw, N, HWA, A, CH, pre_nms, post_nms,
-                                 nms_thr, min_size, nms_ge, 0, 1, post_nms, d_out_boxes, d_out_scores, d_out_cnt, st);
+                                 nms_thr, min_size, nms_ge, 0, 1, post_nms, d_out_boxes, d_out_scores, d_out_cnt, d_ws_nms, st);
 }

@@ -344,8 +344,9 @@ def paste_masks(masks, boxes, counts, im_h, im_w, thr=0.5):
     return do.numpy()
 
 
-def rpn_level(head, anchors, image_hw, A, pre_nms, post_nms, nms_thr=0.7, min_size=0.0, nms_ge=0):
-    """head [N,H,W,A*5] fused (A logits, A*4 deltas) -> list of (boxes, scores)."""
+def rpn_level(head, anchors, image_hw, A, pre_nms, post_nms, nms_thr=0.7, min_size=0.0, nms_ge=0, chip_wide=True):
+    """head [N,H,W,A*5] fused (A logits, A*4 deltas) -> list of (boxes, scores).  chip_wide: hand the op its optional
+    suppression-matrix workspace (two-kernel NMS, pre_nms <= 1024); False = single-block NMS."""
     head = np.ascontiguousarray(head, np.float32)
     N, H, W, CH = head.shape
     HW = H * W
@@ -353,8 +354,9 @@ def rpn_level(head, anchors, image_hw, A, pre_nms, post_nms, nms_thr=0.7, min_si
     dhw = DeviceBuffer.from_numpy(np.ascontiguousarray(image_hw, np.int32))
     wp = DeviceBuffer((N, HW * A)); tv = DeviceBuffer((N, pre_nms)); ti = DeviceBuffer((N, pre_nms), np.int32); tc = DeviceBuffer((N,), np.int32)
     ob = DeviceBuffer((N, post_nms, 4)); os_ = DeviceBuffer((N, post_nms)); oc = DeviceBuffer((N,), np.int32)
+    wn = DeviceBuffer((N, 131072), np.uint8) if chip_wide and pre_nms <= 1024 else None
     check(lib().isegmi_op_rpn_level(dh.ptr, da.ptr, dhw.ptr, N, HW, A, pre_nms, post_nms, C.c_float(nms_thr), C.c_float(min_size), nms_ge,
-                                    wp.ptr, tv.ptr, ti.ptr, tc.ptr, ob.ptr, os_.ptr, oc.ptr, None))
+                                    wp.ptr, tv.ptr, ti.ptr, tc.ptr, ob.ptr, os_.ptr, oc.ptr, wn.ptr if wn is not None else None, None))
     c = oc.numpy(); B = ob.numpy(); S = os_.numpy()
     return [(B[i, : c[i]], S[i, : c[i]]) for i in range(N)]
 

@@ -123,20 +123,24 @@ def test_roi_align_f16_matches_oracle_on_fp16_features(ffi, Cc):
             assert not out[n, k:].any()
 
 
-def test_rpn_level_matches_oracle(ffi):
+@pytest.mark.parametrize("chip_wide", [True, False])
+def test_rpn_level_matches_oracle(ffi, chip_wide):
+    """chip_wide: the two-kernel NMS (suppression matrix over many CUs + bit scan) against the single-block one; both must
+    reproduce the oracle's greedy NMS exactly, including min-size removals, the post_nms cut and ragged counts."""
     from isegmi.maskrcnn import generate_anchors, grid_anchors
     rng = np.random.default_rng(5)
     N, H, W, A = 2, 40, 56, 3
     head = np.concatenate([rng.normal(-2, 2, (N, H, W, A)), rng.normal(0, 0.3, (N, H, W, 4 * A))], -1).astype(np.float32)
     head[0, :4, :4, :A] = 1.25  # ties in the top-k
+    head[1, 10:30, 10:50, A:] *= 0.02  # a region of near-identical boxes: long suppression chains inside 64-box chunks
     anchors = grid_anchors(H, W, 8, generate_anchors(8, 64, (0.5, 1.0, 2.0)))
     hw = np.array([[300, 440], [320, 448]], np.int32)
-    for pre, post in ((1000, 1000), (300, 50)):
-        got = ffi.rpn_level(head, anchors, hw, A, pre, post)
+    for pre, post, min_size in ((1000, 1000, 0.0), (300, 50, 0.0), (1000, 37, 0.0), (1024, 1000, 40.0), (70, 70, 0.0)):
+        got = ffi.rpn_level(head, anchors, hw, A, pre, post, min_size=min_size, chip_wide=chip_wide)
         for n in range(N):
-            rb, rs = ora.rpn_level(head[n, ..., :A].reshape(-1), head[n, ..., A:].reshape(-1, 4), anchors, pre, post, 0.7, 0.0,
+            rb, rs = ora.rpn_level(head[n, ..., :A].reshape(-1), head[n, ..., A:].reshape(-1, 4), anchors, pre, post, 0.7, min_size,
                                    float(hw[n, 1]), float(hw[n, 0]))
-            assert np.array_equal(got[n][1], rs) and np.array_equal(got[n][0], rb), (pre, n)
+            assert np.array_equal(got[n][1], rs) and np.array_equal(got[n][0], rb), (pre, post, min_size, n)
             assert len(rs) > 10
 
 
