@@ -188,7 +188,7 @@ def main():
                        "detections_per_image_rank0": [int(c) for c in counts]},
             "roofline": {
                 "bound": "mfma",
-                "kernel": ("conv_f16_glds / conv3x3_f16_strip kernels (all %d conv launches of a step, v_mfma_f32_32x32x16_f16)" if a.fp16 else "conv_mfma_kernel (all %d conv launches of a step, v_mfma_f32_32x32x2_f32)") % (conv_launches // max(a.steps, 1)),
+                "kernel": ("conv_f16_glds / conv3x3_f16_strip kernels (all %d conv launches of a step, v_mfma_f32_32x32x16_f16)" if a.fp16 else "conv_mfma_kernel + conv_mfma16_kernel (all %d conv launches of a step; v_mfma_f32_32x32x2_f32 on 64x64 tiles, v_mfma_f32_16x16x4_f32 on the 32x32 blocks of small grids)") % (conv_launches // max(a.steps, 1)),
                 "pass": "K single-stream steps right after the timed region, HIP events around every conv launch",
                 "achieved": round(achieved, 2),
                 "peak": ypeak,
@@ -359,7 +359,7 @@ def main_maskrcnn(a):
                "config": {"workload": ("Mask R-CNN %s 1333x800 (padded 800x1344) bs=%d/GPU random weights, %s: conv1-4 + single-map RPN (6000 -> 1000) + RoIAlign + conv5 head + NMS + shared-extractor mask branch + paste (the README.md:263-273 config; not a BASELINE config)" % (tag, a.batch, prec)) if a.c4 else "Mask R-CNN %s 1333x800 (padded 800x1344) bs=%d/GPU random weights, %s: backbone+FPN+RPN+RoIAlign+box head+NMS+mask head+paste (BASELINE configs[%d])" % (tag, a.batch, prec, 4 if a.fp16 else 2),
                           "global_batch": a.batch * world, "parallelism": "batch-sharded x%d" % world,
                           "proposals_per_image": [int(c) for c in pc], "detections_per_image": [int(c) for c in cnt]},
-               "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel (all conv launches of a step)",
+               "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel + conv_mfma16_kernel (all conv launches of a step)",
                             "pass": "K single-stream steps right after the timed region, HIP events around every conv launch", "achieved": round(achieved, 2),
                             "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": pmc_traffic("r01_pmc_r101f16.json") if (a.fp16 and a.depth == 101 and a.batch == 8) else None if (a.fp16 or a.depth != 50 or a.batch != 2) else pmc_traffic("r01_pmc_maskrcnn.json"),
                             "traffic_note": "HBM bytes per conv launch from separate rocprofv3 --pmc passes of this command (tools/profile_round.sh -> profiles/r01_pmc_maskrcnn.json / r01_pmc_r101f16.json; FETCH x2 gfx950 correction); not collected live; null for configurations without a committed PMC pass",
