@@ -88,6 +88,12 @@ int isegmi_op_maxpool(const float* d_in, int N, int H, int W, int C, int k, int 
 /* bilinear align_corners=False to (Ho,Wo), optional +add, optional relu (Y3, Y4) */
 int isegmi_op_resize_bilinear(const float* d_in, int N, int H, int W, int C, int Ho, int Wo,
                               const float* d_add, int relu, float* d_out, void* stream);
+/* modulated deformable im2col: the sampling stage of the DCNv2 3x3 convolutions of the YOLACT++ backbones
+ * (the YOLACT++ rows of README.md:216-221).  d_offset_mask [N][Ho][Wo][3*R*S] is the raw conv_offset_mask
+ * output (channel 2k = dy_k, 2k+1 = dx_k, 2*R*S+k = mask logit); d_out [N][Ho][Wo][R*S][C] feeds a 1x1
+ * convolution over R*S*C channels with the layer's KRSC weights.  C % 4 == 0. */
+int isegmi_op_deform_im2col(const float* d_x, int N, int H, int W, int C, const float* d_offset_mask,
+                            int R, int S, int stride, int pad, int dil, float* d_out, void* stream);
 /* out = lateral + nearest2x(coarse) (M3) */
 int isegmi_op_upsample_nearest2x_add(const float* d_coarse, int N, int Hc, int Wc, int C,
                                      const float* d_lateral, int H, int W, float* d_out,

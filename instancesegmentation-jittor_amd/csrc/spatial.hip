@@ -134,6 +134,58 @@ int resize_bilinear_launch(const float* in, int N, int H, int W, int C, int Ho, 
     HIP_TRY(hipGetLastError());
     return ISEGMI_OK;
 }
+// Modulated deformable im2col (DCNv2 sampling stage of the YOLACT++ backbones; oracle: ora_deform_im2col, same rounding
+// sequence).  One thread per (output pixel, tap, 4-channel vector): the three offset/mask values of a (pixel, tap) are
+// broadcast reads, the four corner vectors 16-byte gathers, the store a coalesced 16 bytes.  HBM-bound: writes K*C*4 B per
+// output pixel, reads <= 4 corner vectors per tap (mostly L2 hits: neighbouring taps and pixels share corners).
+__global__ __launch_bounds__(256) void deform_im2col_kernel(const float* __restrict__ x, int N, int H, int W, int C,
+                                                            const float* __restrict__ om, int R, int S, int stride, int pad, int dil,
+                                                            int Ho, int Wo, float* __restrict__ out) {
+    const int K = R * S, C4 = C >> 2;
+    const int64_t total = (int64_t)N * Ho * Wo * K * C4;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(t % C4);
+        int64_t r = t / C4;
+        const int k = (int)(r % K);
+        const int64_t pix = r / K;
+        const int wo = (int)(pix % Wo);
+        const int64_t q = pix / Wo;
+        const int ho = (int)(q % Ho), n = (int)(q / Ho);
+        const float* o = om + pix * 3 * K;
+        const int i = k / S, j = k - i * S;
+        const float h = (float)(ho * stride - pad + i * dil) + o[2 * k];
+        const float w = (float)(wo * stride - pad + j * dil) + o[2 * k + 1];
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (h > -1.0f && w > -1.0f && h < (float)H && w < (float)W) {
+            const float m = dm_sigmoid(o[2 * K + k]);
+            const float hf = floorf(h), wf = floorf(w);
+            const int hl = (int)hf, wl = (int)wf, hh_ = hl + 1, wh_ = wl + 1;
+            const float lh = h - hf, lw = w - wf, hh = 1.0f - lh, hw = 1.0f - lw;
+            const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4* base = (const float4*)(x + (int64_t)n * H * W * C) + c4;
+            const float4 v1 = (hl >= 0 && wl >= 0) ? base[((int64_t)hl * W + wl) * C4] : z;
+            const float4 v2 = (hl >= 0 && wh_ <= W - 1) ? base[((int64_t)hl * W + wh_) * C4] : z;
+            const float4 v3 = (hh_ <= H - 1 && wl >= 0) ? base[((int64_t)hh_ * W + wl) * C4] : z;
+            const float4 v4 = (hh_ <= H - 1 && wh_ <= W - 1) ? base[((int64_t)hh_ * W + wh_) * C4] : z;
+            v.x = (((w1 * v1.x + w2 * v2.x) + w3 * v3.x) + w4 * v4.x) * m;
+            v.y = (((w1 * v1.y + w2 * v2.y) + w3 * v3.y) + w4 * v4.y) * m;
+            v.z = (((w1 * v1.z + w2 * v2.z) + w3 * v3.z) + w4 * v4.z) * m;
+            v.w = (((w1 * v1.w + w2 * v2.w) + w3 * v3.w) + w4 * v4.w) * m;
+        }
+        ((float4*)out)[t] = v;
+    }
+}
+int deform_im2col_launch(const float* x, int N, int H, int W, int C, const float* om, int R, int S, int stride, int pad, int dil,
+                         float* out, hipStream_t st) {
+    ARG_CHECK(C % 4 == 0 && R > 0 && S > 0 && stride > 0 && dil > 0 && pad >= 0, "deform_im2col geometry (C % 4 == 0)");
+    const int Ho = (H + 2 * pad - dil * (R - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (S - 1) - 1) / stride + 1;
+    ARG_CHECK(Ho > 0 && Wo > 0, "deform_im2col output size");
+    hipLaunchKernelGGL(deform_im2col_kernel, dim3(grid_for((int64_t)N * Ho * Wo * R * S * (C / 4))), dim3(256), 0, st, x, N, H, W, C, om, R,
+                       S, stride, pad, dil, Ho, Wo, out);
+    HIP_TRY(hipGetLastError());
+    return ISEGMI_OK;
+}
 int nearest2x_add_launch(const float* coarse, int N, int Hc, int Wc, int C, const float* lat, int H, int W, float* out,
                          hipStream_t st) {
     ARG_CHECK(C % 4 == 0, "C % 4");
@@ -159,6 +211,11 @@ extern "C" int isegmi_op_maxpool(const float* d_in, int N, int H, int W, int C, 
 extern "C" int isegmi_op_resize_bilinear(const float* d_in, int N, int H, int W, int C, int Ho, int Wo,
                                          const float* d_add, int relu, float* d_out, void* stream) {
     return resize_bilinear_launch(d_in, N, H, W, C, Ho, Wo, d_add, relu, d_out, (hipStream_t)stream);
+}
+extern "C" int isegmi_op_deform_im2col(const float* d_x, int N, int H, int W, int C, const float* d_offset_mask, int R, int S,
+                                       int stride, int pad, int dil, float* d_out, void* stream) {
+    ARG_CHECK(d_x && d_offset_mask && d_out, "null device pointer");
+    return deform_im2col_launch(d_x, N, H, W, C, d_offset_mask, R, S, stride, pad, dil, d_out, (hipStream_t)stream);
 }
 extern "C" int isegmi_op_upsample_nearest2x_add(const float* d_coarse, int N, int Hc, int Wc, int C,
                                                 const float* d_lateral, int H, int W, float* d_out, void* stream) {

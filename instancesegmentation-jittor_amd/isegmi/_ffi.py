@@ -167,6 +167,17 @@ def resize_bilinear(x, Ho, Wo, add=None, relu=0):
     return do.numpy()
 
 
+def deform_im2col(x, om, R=3, S=3, stride=1, pad=1, dil=1):
+    """x [N,H,W,C], om [N,Ho,Wo,3*R*S] raw conv_offset_mask output -> DCNv2 columns [N,Ho,Wo,R*S*C]."""
+    x = np.ascontiguousarray(x, np.float32); om = np.ascontiguousarray(om, np.float32)
+    N, H, W, Cc = x.shape
+    Ho = (H + 2 * pad - dil * (R - 1) - 1) // stride + 1; Wo = (W + 2 * pad - dil * (S - 1) - 1) // stride + 1
+    assert om.shape == (N, Ho, Wo, 3 * R * S), om.shape
+    dx = DeviceBuffer.from_numpy(x); dm = DeviceBuffer.from_numpy(om); do = DeviceBuffer((N, Ho, Wo, R * S * Cc))
+    check(lib().isegmi_op_deform_im2col(dx.ptr, N, H, W, Cc, dm.ptr, R, S, stride, pad, dil, do.ptr, None))
+    return do.numpy()
+
+
 def upsample_nearest2x_add(coarse, lateral):
     coarse = np.ascontiguousarray(coarse, np.float32); lateral = np.ascontiguousarray(lateral, np.float32)
     N, Hc, Wc, Cc = coarse.shape

@@ -108,6 +108,17 @@ def resize_bilinear(x, Ho, Wo, add=None, relu=0):
     return out
 
 
+def deform_im2col(x, om, R=3, S=3, stride=1, pad=1, dil=1):
+    """x [N,H,W,C], om [N,Ho,Wo,3*R*S] (dy/dx interleaved, then mask logits) -> columns [N,Ho,Wo,R*S*C]."""
+    x = _f(x); om = _f(om)
+    N, H, W_, Cc = x.shape
+    Ho = (H + 2 * pad - dil * (R - 1) - 1) // stride + 1; Wo = (W_ + 2 * pad - dil * (S - 1) - 1) // stride + 1
+    assert om.shape == (N, Ho, Wo, 3 * R * S), (om.shape, (N, Ho, Wo, 3 * R * S))
+    out = np.empty((N, Ho, Wo, R * S * Cc), np.float32)
+    lib().ora_deform_im2col(_p(x), I(N), I(H), I(W_), I(Cc), _p(om), I(R), I(S), I(stride), I(pad), I(dil), _p(out))
+    return out
+
+
 def upsample_nearest2x_add(coarse, lateral):
     coarse = _f(coarse); lateral = _f(lateral)
     N, Hc, Wc, Cc = coarse.shape

@@ -275,6 +275,56 @@ static inline void bil_coef(int dst, int in_sz, int out_sz, int* i0, int* i1, fl
     *l1 = src - (float)a;
     *l0 = 1.0f - *l1;
 }
+/* Modulated deformable im2col -- the sampling stage of DCNv2, the deformable 3x3 convolutions of the YOLACT++ backbones
+ * (README.md:216-221 lists the YOLACT++ models; dbolya/yolact's DCNv2 lineage [UPSTREAM-RECALL], PARITY UNPINNED).
+ *   x   [N][H][W][C]
+ *   om  [N][Ho][Wo][3K], K = R*S taps, the raw output of the block's conv_offset_mask: channel 2k = dy_k, 2k+1 = dx_k,
+ *       2K+k = mask logit (DCNv2: offset = cat(o1, o2), mask = sigmoid(o3))
+ *   out [N][Ho][Wo][K][C]: tap k = (i, j) sampled at (ho*stride - pad + i*dil + dy_k, wo*stride - pad + j*dil + dx_k) by the
+ *       DCNv2 bilinear rule (zero outside the open range (-1, H) x (-1, W); corners outside the image contribute 0), times
+ *       sigmoid(mask logit).  The deformable conv itself is then a 1x1 convolution over K*C channels with the block's KRSC
+ *       weights (the same k-ordered chain as a plain 3x3 convolution over (r, s, cin)).
+ * Rounding sequence: h = (float)(integer tap row) + dy; lh = h - floor(h); hh = 1 - lh; w1..w4 products; value =
+ * ((w1*v1 + w2*v2) + w3*v3) + w4*v4, each operation individually rounded; result * sigmoid(m). */
+ORA_API void ora_deform_im2col(const float* x, int N, int H, int W, int C, const float* om, int R, int S, int stride, int pad,
+                               int dil, float* out) {
+    const int K = R * S;
+    const int Ho = (H + 2 * pad - dil * (R - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (S - 1) - 1) / stride + 1;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int n = 0; n < N; ++n)
+        for (int ho = 0; ho < Ho; ++ho)
+            for (int wo = 0; wo < Wo; ++wo) {
+                const float* o = om + (((int64_t)n * Ho + ho) * Wo + wo) * 3 * K;
+                float* dst = out + (((int64_t)n * Ho + ho) * Wo + wo) * K * C;
+                for (int k = 0; k < K; ++k) {
+                    const int i = k / S, j = k - i * S;
+                    const float h = (float)(ho * stride - pad + i * dil) + o[2 * k];
+                    const float w = (float)(wo * stride - pad + j * dil) + o[2 * k + 1];
+                    const float m = ora_sigmoidf(o[2 * K + k]);
+                    float* d = dst + (int64_t)k * C;
+                    if (!(h > -1.0f && w > -1.0f && h < (float)H && w < (float)W)) {
+                        for (int c = 0; c < C; ++c) d[c] = 0.0f;
+                        continue;
+                    }
+                    const float hf = floorf(h), wf = floorf(w);
+                    const int hl = (int)hf, wl = (int)wf, hh_ = hl + 1, wh_ = wl + 1;
+                    const float lh = h - hf, lw = w - wf, hh = 1.0f - lh, hw = 1.0f - lw;
+                    const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+                    const float* p1 = (hl >= 0 && wl >= 0) ? x + (((int64_t)n * H + hl) * W + wl) * C : NULL;
+                    const float* p2 = (hl >= 0 && wh_ <= W - 1) ? x + (((int64_t)n * H + hl) * W + wh_) * C : NULL;
+                    const float* p3 = (hh_ <= H - 1 && wl >= 0) ? x + (((int64_t)n * H + hh_) * W + wl) * C : NULL;
+                    const float* p4 = (hh_ <= H - 1 && wh_ <= W - 1) ? x + (((int64_t)n * H + hh_) * W + wh_) * C : NULL;
+                    for (int c = 0; c < C; ++c) {
+                        const float v1 = p1 ? p1[c] : 0.0f, v2 = p2 ? p2[c] : 0.0f, v3 = p3 ? p3[c] : 0.0f, v4 = p4 ? p4[c] : 0.0f;
+                        float v = w1 * v1 + w2 * v2;
+                        v = v + w3 * v3;
+                        v = v + w4 * v4;
+                        d[c] = v * m;
+                    }
+                }
+            }
+}
+
 ORA_API void ora_resize_bilinear(const float* in, int N, int H, int W, int C, int Ho, int Wo,
                                  const float* add, int relu, float* out) {
 #pragma omp parallel for collapse(2)

@@ -65,6 +65,49 @@ def test_pool_resize_deconv_vs_torch():
     assert np.max(np.abs(ora.deconv2x2(a, wd, b, 1) - ref)) < 1e-5
 
 
+def test_deform_im2col_known_answers():
+    """DCNv2 sampling stage (YOLACT++ backbones): zero offsets + saturated mask == plain zero-padded im2col, exactly; a
+    half-pixel shift averages neighbours; an independent float64 restatement agrees on random offsets incl. out-of-range."""
+    rng = np.random.default_rng(3)
+    N, H, W, C = 2, 7, 9, 8
+    x = rng.standard_normal((N, H, W, C)).astype(np.float32)
+    for stride in (1, 2):
+        Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+        om = np.zeros((N, Ho, Wo, 27), np.float32); om[..., 18:] = 30.0
+        col = ora.deform_im2col(x, om, 3, 3, stride, 1, 1).reshape(N, Ho, Wo, 9, C)
+        xp = np.pad(x, ((0, 0), (1, 1), (1, 1), (0, 0)))
+        for i in range(3):
+            for j in range(3):
+                ref = xp[:, i:i + (Ho - 1) * stride + 1:stride, j:j + (Wo - 1) * stride + 1:stride]
+                assert np.array_equal(col[:, :, :, i * 3 + j], ref), (stride, i, j)
+    om = np.zeros((N, H, W, 27), np.float32); om[..., 18:] = 30.0
+    om[..., 9] = 0.5  # centre tap (k = 4): dx = +0.5 (channel 2k+1)
+    col = ora.deform_im2col(x, om).reshape(N, H, W, 9, C)
+    ref = 0.5 * x[:, :, :-1] + 0.5 * x[:, :, 1:]
+    assert np.array_equal(col[:, :, :-1, 4], ref)
+    assert np.array_equal(col[:, :, -1, 4], 0.5 * x[:, :, -1])  # right neighbour outside the image contributes 0
+    # random offsets / masks against float64
+    om = rng.normal(0, 2.5, (N, H, W, 27)).astype(np.float32)
+    col = ora.deform_im2col(x, om).reshape(N, H, W, 9, C)
+    ref = np.zeros((N, H, W, 9, C))
+    for n in range(N):
+        for ho in range(H):
+            for wo in range(W):
+                for k in range(9):
+                    h = ho - 1 + k // 3 + float(om[n, ho, wo, 2 * k]); w = wo - 1 + k % 3 + float(om[n, ho, wo, 2 * k + 1])
+                    if not (h > -1 and w > -1 and h < H and w < W):
+                        continue
+                    hl, wl = int(np.floor(h)), int(np.floor(w))
+                    lh, lw = h - hl, w - wl
+                    v = np.zeros(C)
+                    for (yy, xx, ww) in ((hl, wl, (1 - lh) * (1 - lw)), (hl, wl + 1, (1 - lh) * lw), (hl + 1, wl, lh * (1 - lw)), (hl + 1, wl + 1, lh * lw)):
+                        if 0 <= yy < H and 0 <= xx < W:
+                            v += ww * x[n, yy, xx].astype(np.float64)
+                    ref[n, ho, wo, k] = v / (1.0 + np.exp(-float(om[n, ho, wo, 18 + k])))
+    assert np.allclose(col, ref, rtol=1e-5, atol=1e-6)
+    assert (ref == 0).reshape(-1, C).all(1).sum() > 20  # the out-of-range branch was exercised
+
+
 def test_topk_total_order():
     s = np.array([0.5, 0.9, 0.5, 0.1, 0.9, 0.5], np.float32)
     v, i = ora.topk(s, 4)

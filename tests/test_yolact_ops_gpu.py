@@ -33,6 +33,25 @@ def test_topk_all_equal_and_negative(ffi):
     assert np.array_equal(vals[1], -np.arange(200, dtype=np.float32))
 
 
+@pytest.mark.parametrize("stride", [1, 2])
+def test_deform_im2col_matches_oracle(ffi, stride):
+    """DCNv2 sampling stage of the YOLACT++ backbones: bit-exact columns for random offsets (in range, out of range, exactly on
+    the -1 / H borders, integer positions) and mask logits."""
+    rng = np.random.default_rng(40 + stride)
+    N, H, W, C = 2, 23, 31, 64
+    x = rng.standard_normal((N, H, W, C)).astype(np.float32)
+    Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+    om = rng.normal(0, 3.0, (N, Ho, Wo, 27)).astype(np.float32)
+    om[0, :4, :, :18] = np.round(om[0, :4, :, :18])      # integer sample positions
+    om[1, 0, :, 0] = -float(0 * stride - 1 + 0) - 1.0     # tap 0 lands exactly on h = -1 (excluded)
+    om[1, -1, :, 12] = float(H) - float((Ho - 1) * stride - 1 + 2)  # tap 6 lands exactly on h = H (excluded)
+    got = ffi.deform_im2col(x, om, 3, 3, stride, 1, 1)
+    ref = ora.deform_im2col(x, om, 3, 3, stride, 1, 1)
+    assert got.shape == ref.shape == (N, Ho, Wo, 9 * C)
+    assert np.array_equal(got, ref)
+    assert (ref.reshape(-1, C) == 0).all(1).sum() > 50
+
+
 def _yolact_inputs(rng, N, P, ncls=81, md=32, hot=0.02):
     conf = rng.standard_normal((N, P, ncls)).astype(np.float32)
     conf[..., 0] += 4.0  # background dominates, as in a real detector
