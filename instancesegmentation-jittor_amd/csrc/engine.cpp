@@ -282,7 +282,18 @@ int yolact_forward(Engine& e, const float* d_images, int N) {
                 TRY(eng_conv(e, nm + ".downsample.0", x, st, 0, 0, nullptr, nm + ".ds", &idt));
             }
             TRY(eng_conv(e, nm + ".conv1", x, 1, 0, 1, nullptr, nm + ".t1", &t1));
-            TRY(eng_conv(e, nm + ".conv2", t1, st, 1, 1, nullptr, nm + ".t2", &t2));
+            if (e.convs.count(nm + ".conv2.conv_offset_mask")) {
+                // DCNv2 3x3 (YOLACT++ backbones): offsets + mask logits from a plain 3x3 -> the nine taps sampled into columns ->
+                // the deformable conv proper as a 1x1 over 9*C channels (weights handed over in KRSC order, bias folded into BN)
+                if (dt) { set_error("the DCNv2 backbones run in fp32 only"); return ISEGMI_ERR_STATE; }
+                Tensor om, col;
+                TRY(eng_conv(e, nm + ".conv2.conv_offset_mask", t1, st, 1, 0, nullptr, nm + ".om", &om));
+                TRY(eng_act(e, nm + ".col", N, om.H, om.W, 9 * t1.C, &col));
+                TRY(deform_im2col_launch((const float*)t1.d, N, t1.H, t1.W, t1.C, (const float*)om.d, 3, 3, st, 1, 1, (float*)col.d, e.cur));
+                TRY(eng_conv(e, nm + ".conv2", col, 1, 0, 1, nullptr, nm + ".t2", &t2));
+            } else {
+                TRY(eng_conv(e, nm + ".conv2", t1, st, 1, 1, nullptr, nm + ".t2", &t2));
+            }
             if (b == 0) TRY(eng_join(e, 0));
             TRY(eng_conv(e, nm + ".conv3", t2, 1, 0, 1, &idt, nm + ".out", &y));
             x = y;
@@ -320,7 +331,7 @@ int yolact_forward(Engine& e, const float* d_images, int N) {
     TRY(eng_join(e, 1));
     eng_mark(e, "fpn");
     // shared prediction head geometry
-    const int A = 3, ncls = 81, md = 32;
+    const int A = (int)e.param("num_priors", 3), ncls = 81, md = 32;  // 9 for YOLACT++ (3 scales x 3 aspect ratios per cell)
     int Ptot = 0, off[5];
     for (int l = 0; l < 5; ++l) { off[l] = Ptot; Ptot += P[l].H * P[l].W * A; }
     {

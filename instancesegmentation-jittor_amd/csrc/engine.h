@@ -135,6 +135,8 @@ int resize_bilinear_launch(const float* in, int N, int H, int W, int C, int Ho, 
                            hipStream_t st);
 int nearest2x_add_launch(const float* coarse, int N, int Hc, int Wc, int C, const float* lat, int H, int W, float* out,
                          hipStream_t st);
+int deform_im2col_launch(const float* x, int N, int H, int W, int C, const float* om, int R, int S, int stride, int pad, int dil,
+                         float* out, hipStream_t st);
 int pad_c3_c4_launch(const float* in, int64_t npix, float* out, hipStream_t st);
 int topk_launch(const float* keys, int64_t row_stride, int rows, int n, int k, const int* limit, int rows_per_limit,
                 float* out_vals, int* out_idx, int* out_cnt, hipStream_t st);

@@ -53,11 +53,35 @@ YOLACT_MASK_GAIN = 0.04
 YOLACT_PROTO_GAIN = 0.06
 
 
-def yolact_state_dict(seed=1234, depth=50):
-    """dbolya/yolact state-dict names; depth 50 = yolact_resnet50, 101 = yolact_base / yolact_im700."""
+def dcn_blocks(depth, dcn_layers, dcn_interval):
+    """(layer, block) pairs whose 3x3 is a DCNv2 (dbolya/yolact ResNetBackbone._make_layer: the first block of a layer when
+    dcn_layers >= blocks, block i > 0 when i + dcn_layers >= blocks and i % dcn_interval == 0)."""
+    out = set()
+    for li, nb in enumerate((3, 4, 23 if depth == 101 else 6, 3)):
+        dl = dcn_layers[li]
+        for b in range(nb):
+            if (b == 0 and dl >= nb) or (b > 0 and b + dl >= nb and b % dcn_interval == 0):
+                out.add((li, b))
+    return out
+
+
+YOLACT_DCN_OFFSET_STD = 0.6   # synthetic conv_offset_mask outputs: offsets of about +-1 pixel, mask logits around 0
+
+
+def yolact_state_dict(seed=1234, depth=50, num_priors=3, dcn_layers=(0, 0, 0, 0), dcn_interval=1, maskiou=False):
+    """dbolya/yolact state-dict names; depth 50 = yolact_resnet50, 101 = yolact_base / yolact_im700.
+    YOLACT++ (yolact_plus_*): num_priors=9, DCNv2 3x3s per dcn_layers / dcn_interval (conv2.weight/.bias and
+    conv2.conv_offset_mask.weight/.bias), maskiou=True adds maskiou_net.{0,2,4,6,8,10}."""
     rng = np.random.default_rng(seed)
     sd = {}
     resnet_state_dict(rng, sd, "backbone.", blocks=(3, 4, 23 if depth == 101 else 6, 3))
+    for li, b in sorted(dcn_blocks(depth, dcn_layers, dcn_interval)):
+        nm = "backbone.layers.%d.%d.conv2" % (li, b)
+        planes = 64 << li
+        sd[nm + ".bias"] = (rng.standard_normal(planes) * 0.05).astype(np.float32)
+        # conv1 outputs (post BN+ReLU) are O(1): a 3x3 x planes fan-in with this std gives offsets / logits of about OFFSET_STD
+        sd[nm + ".conv_offset_mask.weight"] = (rng.standard_normal((27, planes, 3, 3)) * (YOLACT_DCN_OFFSET_STD / np.sqrt(9.0 * planes))).astype(np.float32)
+        sd[nm + ".conv_offset_mask.bias"] = (rng.standard_normal(27) * 0.1).astype(np.float32)
     for i, cin in enumerate((2048, 1024, 512)):
         _conv_bias(rng, sd, "fpn.lat_layers.%d" % i, 256, cin, 1)
     for i in range(3):
@@ -68,11 +92,18 @@ def yolact_state_dict(seed=1234, depth=50):
         _conv_bias(rng, sd, "proto_net.%d" % i, 256, 256, 3)
     _conv_bias(rng, sd, "proto_net.10", 32, 256, 1, gain=YOLACT_PROTO_GAIN)
     _conv_bias(rng, sd, "prediction_layers.0.upfeature.0", 256, 256, 3)
-    _conv_bias(rng, sd, "prediction_layers.0.bbox_layer", 12, 256, 3, gain=YOLACT_LOC_GAIN)
-    _conv_bias(rng, sd, "prediction_layers.0.conf_layer", 243, 256, 3, gain=YOLACT_CONF_GAIN)
-    _conv_bias(rng, sd, "prediction_layers.0.mask_layer", 96, 256, 3, gain=YOLACT_MASK_GAIN)
-    b = sd["prediction_layers.0.conf_layer.bias"].reshape(3, 81)
+    A = num_priors
+    _conv_bias(rng, sd, "prediction_layers.0.bbox_layer", A * 4, 256, 3, gain=YOLACT_LOC_GAIN)
+    _conv_bias(rng, sd, "prediction_layers.0.conf_layer", A * 81, 256, 3, gain=YOLACT_CONF_GAIN)
+    _conv_bias(rng, sd, "prediction_layers.0.mask_layer", A * 32, 256, 3, gain=YOLACT_MASK_GAIN)
+    b = sd["prediction_layers.0.conf_layer.bias"].reshape(A, 81)
     b[:, 0] += YOLACT_BG_BIAS
+    if maskiou:  # FastMaskIoUNet: 1 -> 8 -> 16 -> 32 -> 64 -> 128 (3x3 stride 2, no padding, ReLU) -> 80 (1x1, ReLU) -> global max
+        cin = 1
+        for i, cout in enumerate((8, 16, 32, 64, 128)):
+            _conv_bias(rng, sd, "maskiou_net.%d" % (2 * i), cout, cin, 3, bias_std=0.05)
+            cin = cout
+        _conv_bias(rng, sd, "maskiou_net.10", 80, 128, 1, bias_std=0.05)
     return sd
 
 

@@ -13,7 +13,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import _ffi
-from .weights import fold_batchnorm, to_krsc
+from .weights import dcn_blocks, fold_batchnorm, to_krsc
 
 MEANS = (103.94, 116.78, 123.68)  # BGR
 STD = (57.38, 57.12, 58.40)
@@ -32,6 +32,33 @@ class YolactConfig:
     nms_top_k: int = 200
     max_num_detections: int = 100
     depth: int = 50  # 50 = yolact_resnet50_config, 101 = yolact_base_config / yolact_im700_config
+    # YOLACT++ (yolact_plus_*_config, the YOLACT++ rows of README.md:216-221): three scales per level x three aspect ratios,
+    # rectangular anchors, DCNv2 3x3s in the backbone, fast mask re-scoring
+    scales_per_level: int = 1          # 3: scale * 2**(j/3), j = 0..2
+    use_square_anchors: bool = True
+    dcn_layers: tuple = (0, 0, 0, 0)
+    dcn_interval: int = 1
+    use_maskiou: bool = False
+
+    @property
+    def num_priors(self):
+        return self.scales_per_level * len(self.pred_aspect_ratios)
+
+    def level_scales(self, level):
+        s = self.pred_scales[level]
+        return tuple(s * 2 ** (j / 3.0) for j in range(self.scales_per_level))
+
+    @staticmethod
+    def plus_base():
+        """yolact_plus_base_config: ResNet101-FPN with a DCNv2 every third block of layers 2-4 (resnet101_dcn_inter3_backbone)."""
+        return YolactConfig(depth=101, scales_per_level=3, use_square_anchors=False, dcn_layers=(0, 4, 23, 3), dcn_interval=3,
+                            use_maskiou=True)
+
+    @staticmethod
+    def plus_resnet50():
+        """yolact_plus_resnet50_config: ResNet50-FPN with DCNv2 in every block of layers 2-4 (resnet50_dcnv2_backbone)."""
+        return YolactConfig(depth=50, scales_per_level=3, use_square_anchors=False, dcn_layers=(0, 4, 6, 3), dcn_interval=1,
+                            use_maskiou=True)
 
     @staticmethod
     def base():
@@ -44,16 +71,22 @@ class YolactConfig:
         return YolactConfig(max_size=700, pred_scales=tuple(int(s / 550 * 700) for s in (24, 48, 96, 192, 384)), depth=101)
 
 
-def make_priors(conv_h, conv_w, scale, max_size, ars):
-    out = np.empty((conv_h, conv_w, len(ars), 4), np.float64)
+def make_priors(conv_h, conv_w, scales, max_size, ars, square=True):
+    """PredictionModule.make_priors with use_pixel_scales, preapply_sqrt=False: per cell, scale-major / ratio-minor."""
+    scales = tuple(scales) if isinstance(scales, (tuple, list)) else (scales,)
+    out = np.empty((conv_h, conv_w, len(scales) * len(ars), 4), np.float64)
     xs = (np.arange(conv_w) + 0.5) / conv_w
     ys = (np.arange(conv_h) + 0.5) / conv_h
     out[..., 0] = xs[None, :, None]
     out[..., 1] = ys[:, None, None]
-    for a, ar in enumerate(ars):
-        w = scale * math.sqrt(ar) / max_size
-        out[..., a, 2] = w
-        out[..., a, 3] = w  # use_square_anchors
+    a = 0
+    for scale in scales:
+        for ar in ars:
+            r = math.sqrt(ar)
+            w = scale * r / max_size
+            out[..., a, 2] = w
+            out[..., a, 3] = w if square else scale / r / max_size
+            a += 1
     return out.reshape(-1, 4).astype(np.float32)
 
 
@@ -94,6 +127,8 @@ class Yolact:
         self._h = C.c_void_p()
         _ffi.check(L.isegmi_engine_create(self.KIND, max_batch, self.size, self.size, C.byref(self._h)))
         self.set_param("resnet_depth", float(cfg.depth))
+        self.set_param("num_priors", float(cfg.num_priors))
+        assert not (fp16 and any(cfg.dcn_layers)), "the DCNv2 backbones run in fp32 only"
         if self.fp16:  # must precede weight loading (weights are packed as fp16)
             self.set_param("fp16", 1.0)
         self._load(state_dict)
@@ -113,6 +148,7 @@ class Yolact:
         _ffi.check(_ffi.lib().isegmi_engine_set_conv(self._h, name.encode(), cout, r, s, cin, fp(w), fp(sc), fp(sh)))
 
     def _load(self, sd):
+        dcn = dcn_blocks(self.cfg.depth, self.cfg.dcn_layers, self.cfg.dcn_interval)
         sc, sh = fold_batchnorm(sd, "backbone.bn1")
         self._set_conv("backbone.conv1", sd["backbone.conv1.weight"], sc, sh, pad_cin_to=4)
         for li, nb in enumerate((3, 4, 23 if self.cfg.depth == 101 else 6, 3)):
@@ -120,7 +156,16 @@ class Yolact:
                 nm = "backbone.layers.%d.%d" % (li, b)
                 for i in (1, 2, 3):
                     sc, sh = fold_batchnorm(sd, "%s.bn%d" % (nm, i))
-                    self._set_conv("%s.conv%d" % (nm, i), sd["%s.conv%d.weight" % (nm, i)], sc, sh)
+                    w = sd["%s.conv%d.weight" % (nm, i)]
+                    if i == 2 and (li, b) in dcn:
+                        # DCNv2: the engine samples the 9 taps into columns (isegmi_op_deform_im2col) and runs the 3x3 as a 1x1 over
+                        # 9*Cin channels in KRSC order -- the same k-ordered chain; the DCN bias folds into the BN shift
+                        k = to_krsc(w)
+                        w = k.reshape(k.shape[0], 1, 1, -1).transpose(0, 3, 1, 2)
+                        sh = (sh + sd[nm + ".conv2.bias"].astype(np.float32) * sc).astype(np.float32)
+                        self._set_conv(nm + ".conv2.conv_offset_mask", sd[nm + ".conv2.conv_offset_mask.weight"], None,
+                                       sd[nm + ".conv2.conv_offset_mask.bias"])
+                    self._set_conv("%s.conv%d" % (nm, i), w, sc, sh)
                 if b == 0:
                     sc, sh = fold_batchnorm(sd, nm + ".downsample.1")
                     self._set_conv(nm + ".downsample.0", sd[nm + ".downsample.0.weight"], sc, sh)
@@ -134,8 +179,8 @@ class Yolact:
             names = ["prediction_layers.0." + n for n in ("bbox_layer", "conf_layer", "mask_layer")]
             self._set_conv("prediction_layers.0.head_cat", np.concatenate([sd[n + ".weight"] for n in names], 0), None,
                            np.concatenate([sd[n + ".bias"] for n in names]))
-        pri = [make_priors(s, s, sc_, self.cfg.max_size, self.cfg.pred_aspect_ratios)
-               for s, sc_ in zip(_level_sizes(self.size), self.cfg.pred_scales)]
+        pri = [make_priors(s, s, self.cfg.level_scales(l), self.cfg.max_size, self.cfg.pred_aspect_ratios, self.cfg.use_square_anchors)
+               for l, s in enumerate(_level_sizes(self.size))]
         self.priors = np.concatenate(pri, 0)
         _ffi.check(_ffi.lib().isegmi_engine_set_tensor(self._h, b"priors", self.priors.ctypes.data_as(C.c_void_p),
                                                        C.c_int64(self.priors.nbytes)))

@@ -25,23 +25,30 @@ def _fold_bn(sd, prefix, eps=np.float32(1e-5)):
     return scale, shift
 
 
-def make_priors(conv_h, conv_w, scale, max_size, ars=(1.0, 0.5, 2.0)):
-    """A.9 make_priors with use_pixel_scales, preapply_sqrt=False, use_square_anchors=True."""
+def make_priors(conv_h, conv_w, scale, max_size, ars=(1.0, 0.5, 2.0), square=True):
+    """A.9 make_priors with use_pixel_scales, preapply_sqrt=False; scale: one number (use_square_anchors configs) or the
+    level's list of scales (YOLACT++: three per level, rectangular anchors), scale-major / ratio-minor per cell."""
+    scales = tuple(scale) if isinstance(scale, (tuple, list)) else (scale,)
     out = []
     for j in range(conv_h):
         for i in range(conv_w):
             x = (i + 0.5) / conv_w
             y = (j + 0.5) / conv_h
-            for ar in ars:
-                ar = math.sqrt(ar)
-                w = scale * ar / max_size
-                h = w
-                out += [x, y, w, h]
+            for sc in scales:
+                for ar in ars:
+                    ar = math.sqrt(ar)
+                    w = sc * ar / max_size
+                    h = w if square else sc / ar / max_size
+                    out += [x, y, w, h]
     return np.asarray(out, np.float64).astype(np.float32).reshape(-1, 4)
 
 
 class YolactRef:
-    def __init__(self, sd, max_size=550, scales=(24, 48, 96, 192, 384), depth=50, fp16=False):
+    def __init__(self, sd, max_size=550, scales=(24, 48, 96, 192, 384), depth=50, fp16=False, scales_per_level=1, square=True):
+        # YOLACT++: scales_per_level=3, square=False; DCNv2 blocks and the mask-IoU net are recognised by their state-dict
+        # entries (<block>.conv2.conv_offset_mask.weight, maskiou_net.0.weight)
+        self.scales_per_level = scales_per_level
+        self.square = square
         # fp16=True emulates the product's optional fp16-storage mode: image, conv weights and every stored activation are rounded
         # to fp16 (the fused head outputs and the prototypes stay fp32), arithmetic stays the fp32 ordered chain.
         self.fp16 = fp16
@@ -80,7 +87,17 @@ class YolactRef:
                 if b == 0:
                     idt = self._conv_bn(x, nm + ".downsample.0", nm + ".downsample.1", st, 0, 0)
                 t = self._conv_bn(x, nm + ".conv1", nm + ".bn1", 1, 0, 1)
-                t = self._conv_bn(t, nm + ".conv2", nm + ".bn2", st, 1, 1)
+                if nm + ".conv2.conv_offset_mask.weight" in self.sd:
+                    # DCNv2 (modulated deformable 3x3): offsets / mask logits from a plain 3x3 on the same input, the nine taps
+                    # sampled bilinearly (ora_deform_im2col), then the weights applied in (r, s, cin) order; bias, then BN + ReLU
+                    om = self._conv_b(t, nm + ".conv2.conv_offset_mask", st, 1, 0, keep_f32=True)
+                    col = ora.deform_im2col(t, om, 3, 3, st, 1, 1)
+                    w = _krsc(self.sd[nm + ".conv2.weight"])
+                    sc, sh = _fold_bn(self.sd, nm + ".bn2")
+                    sh = (sh + self.sd[nm + ".conv2.bias"].astype(np.float32) * sc).astype(np.float32)
+                    t = ora.conv2d(col, w.reshape(w.shape[0], 1, 1, -1), 1, 0, sc, sh, None, 1)
+                else:
+                    t = self._conv_bn(t, nm + ".conv2", nm + ".bn2", st, 1, 1)
                 x = self._conv_bn(t, nm + ".conv3", nm + ".bn3", 1, 0, 1, residual=idt)
             outs.append(x)
         C3, C4, C5 = outs[1], outs[2], outs[3]
@@ -108,7 +125,8 @@ class YolactRef:
             locs.append(self._conv_b(u, "prediction_layers.0.bbox_layer", 1, 1, 0, keep_f32=True).reshape(N, -1, 4))
             confs.append(self._conv_b(u, "prediction_layers.0.conf_layer", 1, 1, 0, keep_f32=True).reshape(N, -1, 81))
             masks.append(self._conv_b(u, "prediction_layers.0.mask_layer", 1, 1, 2, keep_f32=True).reshape(N, -1, 32))
-            priors.append(make_priors(p.shape[1], p.shape[2], scales[l], self.max_size))
+            lv = tuple(scales[l] * 2 ** (j / 3.0) for j in range(self.scales_per_level))
+            priors.append(make_priors(p.shape[1], p.shape[2], lv if self.scales_per_level > 1 else scales[l], self.max_size, square=self.square))
         loc = np.concatenate(locs, 1); conf = np.concatenate(confs, 1); mask = np.concatenate(masks, 1)
         priors = np.concatenate(priors, 0)
         self.feats = dict(C3=C3, C4=C4, C5=C5, P3=P3, P4=P4, P5=P5, P6=P6, P7=P7, proto=proto, loc=loc, conf=conf,

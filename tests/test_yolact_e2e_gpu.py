@@ -27,11 +27,12 @@ def _compare(net, ref, x, size, n):
         eng_name = {"C3": "backbone.layers.1.3.out"}.get(name, name)
         got = net.fetch(eng_name, n)
         assert np.array_equal(got.reshape(ref.feats[name].shape), ref.feats[name]), name
-    if net.fuse_heads:  # one 351-wide conv: per pixel [3x4 loc | 3x81 conf | 3x32 mask pre-tanh]
+    if net.fuse_heads:  # one (A*117)-wide conv: per pixel [Ax4 loc | Ax81 conf | Ax32 mask pre-tanh], A = 3 (9 for YOLACT++)
         from oracle import ora
         hc = net.fetch("headcat", n)
-        heads = {"loc": hc[..., :12].reshape(n, -1, 4), "conf": hc[..., 12:255].reshape(n, -1, 81),
-                 "mask": ora.map_f32(np.ascontiguousarray(hc[..., 255:]), 2).reshape(n, -1, 32)}
+        A = net.cfg.num_priors
+        heads = {"loc": hc[..., :4 * A].reshape(n, -1, 4), "conf": hc[..., 4 * A:85 * A].reshape(n, -1, 81),
+                 "mask": ora.map_f32(np.ascontiguousarray(hc[..., 85 * A:]), 2).reshape(n, -1, 32)}
     else:
         heads = {k: net.fetch(k, n) for k in ("loc", "conf", "mask")}
     for name in ("loc", "conf", "mask"):
@@ -142,6 +143,31 @@ def test_yolact_base_and_im700_configs_bit_exact(ffi):
     rc, rs, rb, rm = YolactRef.postprocess(refd[0], 640, 480)
     assert np.array_equal(cls, rc) and np.array_equal(sc, rs) and np.array_equal(boxes, rb) and np.array_equal(masks, rm)
     net.close()
+
+
+def test_yolact_plus_dcn_backbones_bit_exact(ffi):
+    """SURVEY 8f rank 4, the YOLACT++ rows of README.md:216-221: DCNv2 3x3s in the backbone (every block of layers 2-4 on
+    ResNet50, every third on ResNet101), nine rectangular anchors per cell (three scales x three ratios)."""
+    from isegmi.weights import dcn_blocks, yolact_state_dict
+    from isegmi.yolact import Yolact, YolactConfig, postprocess
+    assert sorted(dcn_blocks(101, (0, 4, 23, 3), 3)) == [(1, 0), (1, 3)] + [(2, b) for b in range(0, 23, 3)] + [(3, 0)]
+    assert len(dcn_blocks(50, (0, 4, 6, 3), 1)) == 13
+    for cfg, size in ((YolactConfig.plus_resnet50(), 200), (YolactConfig.plus_base(), 136)):
+        sd = yolact_state_dict(77, depth=cfg.depth, num_priors=9, dcn_layers=cfg.dcn_layers, dcn_interval=cfg.dcn_interval)
+        net = Yolact(sd, cfg, max_batch=2, input_size=size)
+        assert net.priors.shape[1] == 4 and net.priors.shape[0] % 9 == 0
+        ref = YolactRef(sd, max_size=550, depth=cfg.depth, scales_per_level=3, square=False)
+        x = _images(5 + size, 2, size)
+        out, refd, total = _compare(net, ref, x, size, 2)
+        assert np.array_equal(net.priors, ref.feats["priors"])
+        assert total > 0
+        # one deformable block in detail: offsets / mask logits, sampled columns
+        om = net.fetch("backbone.layers.1.0.om", 2)
+        assert om.shape[-1] == 27 and float(np.abs(om[..., :18]).mean()) > 0.05  # the synthetic offsets are not all ~0
+        cls, sc, boxes, masks = postprocess(out, size, size)
+        rc, rs, rb, rm = YolactRef.postprocess(refd[0], size, size)
+        assert np.array_equal(cls, rc) and np.array_equal(sc, rs) and np.array_equal(boxes, rb) and np.array_equal(masks, rm)
+        net.close()
 
 
 def test_yolact_smooth_images_bit_exact(ffi, sd):
