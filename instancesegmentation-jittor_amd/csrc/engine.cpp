@@ -455,6 +455,28 @@ int yolact_postprocess(Engine& e, int h, int w) {
     TRY(yolact_masks_launch((const float*)proto.d, (const float*)e.bufs["det.coeff"].d, (const float*)e.bufs["det.box"].d,
                             (const int*)e.bufs["det.count"].d, N, PH, PW, md, K, h, w, (float*)lo, (uint8_t*)masks, (int64_t*)ib,
                             rs));
+    if (e.convs.count("maskiou_net.2")) {
+        // YOLACT++ fast mask re-scoring on the proto-resolution masks just written to ws.lo: first layer (1 input channel) and
+        // the global-max / class pick as small dedicated kernels, the rest on the MFMA conv kernels over all N*K slots
+        auto w0 = e.tensors.find("maskiou.w0"), b0 = e.tensors.find("maskiou.b0");
+        if (w0 == e.tensors.end() || b0 == e.tensors.end()) { set_error("maskiou_net.0 weights missing"); return ISEGMI_ERR_STATE; }
+        hipStream_t saved = e.cur;
+        e.cur = rs;
+        Tensor t, u;
+        TRY(eng_act(e, "maskiou.t0", N * K, (PH - 3) / 2 + 1, (PW - 3) / 2 + 1, 32, &t));
+        TRY(maskiou_conv1_launch((const float*)lo, N * K, PH, PW, (const float*)w0->second.d, (const float*)b0->second.d, t.d, rs));
+        for (int i = 2; i <= 8; i += 2) {
+            if (t.H < 3 || t.W < 3) { e.cur = saved; set_error("input too small for the mask-IoU net (five stride-2 3x3 convs)"); return ISEGMI_ERR_ARG; }
+            TRY(eng_conv(e, "maskiou_net." + std::to_string(i), t, 2, 0, 1, nullptr, "maskiou.t" + std::to_string(i), &u));
+            t = u;
+        }
+        TRY(eng_conv(e, "maskiou_net.10", t, 1, 0, 1, nullptr, "maskiou.cls", &u));
+        void* ms;
+        TRY(eng_buf(e, "det.mask_score", (int64_t)N * K * 4, &ms, 0, {N, K}));
+        TRY(maskiou_rescore_launch(u.d, N, K, u.H * u.W, u.C, (const int*)e.bufs["det.class"].d, (const float*)e.bufs["det.score"].d,
+                                   (const int*)e.bufs["det.count"].d, (float*)ms, rs));
+        e.cur = saved;
+    }
     if (rs == e.tail) HIP_TRY(hipEventRecord(e.tail_done, e.tail));
     eng_mark(e, "masks");
     return ISEGMI_OK;

@@ -135,6 +135,9 @@ int resize_bilinear_launch(const float* in, int N, int H, int W, int C, int Ho, 
                            hipStream_t st);
 int nearest2x_add_launch(const float* coarse, int N, int Hc, int Wc, int C, const float* lat, int H, int W, float* out,
                          hipStream_t st);
+int maskiou_conv1_launch(const float* lo, int NK, int PH, int PW, const float* w, const float* b, float* out, hipStream_t st);
+int maskiou_rescore_launch(const float* feat, int N, int K, int HW, int C, const int* cls, const float* score, const int* count,
+                           float* out, hipStream_t st);
 int deform_im2col_launch(const float* x, int N, int H, int W, int C, const float* om, int R, int S, int stride, int pad, int dil,
                          float* out, hipStream_t st);
 int pad_c3_c4_launch(const float* in, int64_t npix, float* out, hipStream_t st);

@@ -309,6 +309,78 @@ int yolact_detect_launch(const isegmi_yolact_detect_args* a, hipStream_t st) {
     return ISEGMI_OK;
 }
 
+// ---- YOLACT++ fast mask re-scoring (FastMaskIoUNet) ends: the first layer (one input channel: the cropped proto-resolution
+// mask) and the final global-max + class pick; the four 3x3 layers and the 1x1 in between run on the MFMA conv kernels.
+// lo [NK][PH][PW]; w [8][9] (KRSC with C = 1), b [8]; out [NK][Ho][Wo][32], channels 8..31 zero (the next conv's Cin is padded
+// to 32 with zero weights: exact, the extra products are +-0).  k-ordered fmaf chain over the nine taps, + bias, ReLU.
+__global__ __launch_bounds__(256) void maskiou_conv1_kernel(const float* __restrict__ lo, int64_t total, int PH, int PW, int Ho, int Wo,
+                                                            const float* __restrict__ w, const float* __restrict__ b,
+                                                            float* __restrict__ out) {
+    __shared__ float sw[72], sb[8];
+    if (threadIdx.x < 72) sw[threadIdx.x] = w[threadIdx.x];
+    if (threadIdx.x < 8) sb[threadIdx.x] = b[threadIdx.x];
+    __syncthreads();
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int wo = (int)(t % Wo);
+        const int64_t q = t / Wo;
+        const int ho = (int)(q % Ho);
+        const int64_t img = q / Ho;
+        const float* src = lo + (img * PH + 2 * ho) * PW + 2 * wo;
+        float x[9];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) x[r * 3 + c] = src[r * PW + c];
+        float y[8];
+#pragma unroll
+        for (int co = 0; co < 8; ++co) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc = fmaf(x[k], sw[co * 9 + k], acc);
+            const float v = fmaf(acc, 1.0f, sb[co]) + 0.0f;
+            y[co] = v > 0.0f ? v : 0.0f;
+        }
+        float4* d = (float4*)(out + t * 32);
+        d[0] = make_float4(y[0], y[1], y[2], y[3]);
+        d[1] = make_float4(y[4], y[5], y[6], y[7]);
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 2; k < 8; ++k) d[k] = z;
+    }
+}
+// feat [N*K][HW][C] (post-ReLU class maps); mask_score[n][d] = score * max over HW of feat[.][.][class] for d < count[n], else 0
+__global__ void maskiou_rescore_kernel(const float* __restrict__ feat, int HW, int C, const int* __restrict__ cls,
+                                       const float* __restrict__ score, const int* __restrict__ count, int K,
+                                       float* __restrict__ out) {
+    const int n = blockIdx.x;
+    for (int d = threadIdx.x; d < K; d += blockDim.x) {
+        float r = 0.0f;
+        if (d < count[n]) {
+            const float* f = feat + ((int64_t)n * K + d) * HW * C + cls[n * K + d];
+            float m = f[0];
+            for (int p = 1; p < HW; ++p) { const float v = f[(int64_t)p * C]; m = v > m ? v : m; }
+            r = score[n * K + d] * m;
+        }
+        out[n * K + d] = r;
+    }
+}
+int maskiou_conv1_launch(const float* lo, int NK, int PH, int PW, const float* w, const float* b, float* out, hipStream_t st) {
+    ARG_CHECK(PH >= 3 && PW >= 3, "mask-IoU net input smaller than 3x3");
+    const int Ho = (PH - 3) / 2 + 1, Wo = (PW - 3) / 2 + 1;
+    const int64_t total = (int64_t)NK * Ho * Wo;
+    int64_t blocks = cdiv64(total, 256);
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(maskiou_conv1_kernel, dim3((unsigned)blocks), dim3(256), 0, st, lo, total, PH, PW, Ho, Wo, w, b, out);
+    HIP_TRY(hipGetLastError());
+    return ISEGMI_OK;
+}
+int maskiou_rescore_launch(const float* feat, int N, int K, int HW, int C, const int* cls, const float* score, const int* count,
+                           float* out, hipStream_t st) {
+    hipLaunchKernelGGL(maskiou_rescore_kernel, dim3(N), dim3(128), 0, st, feat, HW, C, cls, score, count, K, out);
+    HIP_TRY(hipGetLastError());
+    return ISEGMI_OK;
+}
+
 int yolact_masks_launch(const float* proto, const float* coeffs, const float* boxes, const int* count, int N, int PH, int PW,
                         int mask_dim, int K, int h, int w, float* ws_lo, uint8_t* out_masks, int64_t* out_boxes, hipStream_t st) {
     ARG_CHECK(mask_dim == MD, "mask_dim must be 32");

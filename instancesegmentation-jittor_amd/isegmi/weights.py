@@ -104,6 +104,7 @@ def yolact_state_dict(seed=1234, depth=50, num_priors=3, dcn_layers=(0, 0, 0, 0)
             _conv_bias(rng, sd, "maskiou_net.%d" % (2 * i), cout, cin, 3, bias_std=0.05)
             cin = cout
         _conv_bias(rng, sd, "maskiou_net.10", 80, 128, 1, bias_std=0.05)
+        sd["maskiou_net.10.bias"] += np.float32(0.25)  # most class maps clear the final ReLU: non-degenerate IoU predictions
     return sd
 
 

@@ -179,6 +179,21 @@ class Yolact:
             names = ["prediction_layers.0." + n for n in ("bbox_layer", "conf_layer", "mask_layer")]
             self._set_conv("prediction_layers.0.head_cat", np.concatenate([sd[n + ".weight"] for n in names], 0), None,
                            np.concatenate([sd[n + ".bias"] for n in names]))
+        self.has_maskiou = bool(self.cfg.use_maskiou and "maskiou_net.0.weight" in sd)  # a checkpoint without the net: box scores only
+        if self.has_maskiou:
+            # FastMaskIoUNet: layer 0 (one input channel) goes over as plain tensors for its dedicated kernel; layers 2..8 and the
+            # 1x1 run on the MFMA conv kernels with channels padded to 32 by ZERO weights / biases (exact: the extra terms are +-0)
+            w0 = to_krsc(sd["maskiou_net.0.weight"]).reshape(8, 9)
+            for nm, arr in (("maskiou.w0", w0), ("maskiou.b0", sd["maskiou_net.0.bias"])):
+                a = np.ascontiguousarray(arr, np.float32)
+                _ffi.check(_ffi.lib().isegmi_engine_set_tensor(self._h, nm.encode(), a.ctypes.data_as(C.c_void_p), C.c_int64(a.nbytes)))
+            for i in (2, 4, 6, 8, 10):
+                w = np.asarray(sd["maskiou_net.%d.weight" % i], np.float32); bias = np.asarray(sd["maskiou_net.%d.bias" % i], np.float32)
+                cout, cin = w.shape[:2]
+                cin_p = max(32, cin); cout_p = max(32, cout) if i != 10 else cout
+                wp = np.zeros((cout_p, cin_p) + w.shape[2:], np.float32); wp[:cout, :cin] = w
+                bp = np.zeros(cout_p, np.float32); bp[:cout] = bias
+                self._set_conv("maskiou_net.%d" % i, wp, None, bp)
         pri = [make_priors(s, s, self.cfg.level_scales(l), self.cfg.max_size, self.cfg.pred_aspect_ratios, self.cfg.use_square_anchors)
                for l, s in enumerate(_level_sizes(self.size))]
         self.priors = np.concatenate(pri, 0)
@@ -271,7 +286,11 @@ def postprocess(det_output, w, h, batch_idx=0, score_threshold=0.0):
         net._pp_key = key
         net._pp_masks = net.fetch("det.masks")
         net._pp_boxes = net.fetch("det.box_int")
+        net._pp_mask_scores = net.fetch("det.mask_score") if net.has_maskiou else None
     d = dets["detection"]
     keep = d["score"] > np.float32(score_threshold)
     c = len(d["score"])
-    return d["class"][keep], d["score"][keep], net._pp_boxes[i, :c][keep], net._pp_masks[i, :c][keep]
+    scores = d["score"][keep]
+    if net.has_maskiou:  # upstream (rescore_mask, not rescore_bbox): scores = [box scores, box scores * mask IoU]
+        scores = [scores, net._pp_mask_scores[i, :c][keep]]
+    return d["class"][keep], scores, net._pp_boxes[i, :c][keep], net._pp_masks[i, :c][keep]

@@ -243,6 +243,16 @@ def yolact_detect(conf, boxes, mask, conf_thresh=0.05, nms_thr=0.5, top_k=200, m
     return dict(box=ob[:c].copy(), score=os_[:c].copy(), cls=oc[:c].copy(), mask=om[:c].copy(), prior=op[:c].copy())
 
 
+def yolact_proto_masks(proto, coeffs, boxes):
+    """crop(sigmoid(proto @ coeffs)) at prototype resolution: [n, PH, PW] (the mask-IoU net's input)."""
+    proto = _f(proto); coeffs = _f(coeffs); boxes = _f(boxes)
+    PH, PW, K = proto.shape
+    n = coeffs.shape[0]
+    lo = np.empty((max(n, 1), PH, PW), np.float32)
+    lib().ora_yolact_proto_masks(_p(proto), I(PH), I(PW), I(K), _p(coeffs), _p(boxes), I(n), _p(lo))
+    return lo[:n]
+
+
 def yolact_masks(proto, coeffs, boxes, h, w):
     proto = _f(proto); coeffs = _f(coeffs); boxes = _f(boxes)
     PH, PW, K = proto.shape

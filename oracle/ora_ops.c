@@ -843,4 +843,29 @@ ORA_API void ora_yolact_masks(const float* proto, int PH, int PW, int K, const f
     }
 }
 
+/* The proto-resolution stage of ora_yolact_masks on its own: lo[d] = crop(sigmoid(proto @ coeffs[d])), [n][PH][PW].
+ * YOLACT++'s fast mask re-scoring net (FastMaskIoUNet) takes these as its input (output_utils.postprocess: maskiou_net(masks)
+ * before the upsampling) [UPSTREAM-RECALL, PARITY UNPINNED]. */
+ORA_API void ora_yolact_proto_masks(const float* proto, int PH, int PW, int K, const float* coeffs, const float* boxes, int n,
+                                    float* lo_out) {
+#pragma omp parallel for
+    for (int d = 0; d < n; ++d) {
+        float* lo = lo_out + (size_t)d * PH * PW;
+        const float* cf = coeffs + (size_t)d * K;
+        const float* b = boxes + 4 * (size_t)d;
+        float x1, x2, y1, y2;
+        sanitize(b[0], b[2], PW, 1.0f, &x1, &x2);
+        sanitize(b[1], b[3], PH, 1.0f, &y1, &y2);
+        for (int y = 0; y < PH; ++y)
+            for (int x = 0; x < PW; ++x) {
+                const float* p = proto + ((size_t)y * PW + x) * K;
+                float acc = 0.0f;
+                for (int k = 0; k < K; ++k) acc = fmaf(p[k], cf[k], acc);
+                const float v = ora_sigmoidf(acc);
+                const int inside = ((float)x >= x1) && ((float)x < x2) && ((float)y >= y1) && ((float)y < y2);
+                lo[(size_t)y * PW + x] = inside ? v : 0.0f;
+            }
+    }
+}
+
 ORA_API int ora_version(void) { return 1; }

@@ -139,6 +139,22 @@ class YolactRef:
             dets.append(d)
         return dets
 
+    def mask_scores(self, det, score_threshold=0.0):
+        """YOLACT++ fast mask re-scoring (use_maskiou, rescore_mask, not rescore_bbox): FastMaskIoUNet on the cropped proto-
+        resolution masks -- five 3x3 stride-2 unpadded convs + ReLU, a 1x1 to the 80 classes + ReLU, global max pool --, the
+        detection's own class picked, times the box score.  Returns the mask scores of the kept detections."""
+        keep = det["score"] > np.float32(score_threshold)
+        box, coeff, cls, score = det["box"][keep], det["mask"][keep], det["cls"][keep], det["score"][keep]
+        n = len(score)
+        if n == 0:
+            return np.zeros((0,), np.float32)
+        x = ora.yolact_proto_masks(det["proto"], coeff, box)[..., None]
+        for i in (0, 2, 4, 6, 8):
+            x = self._conv_b(x, "maskiou_net.%d" % i, 2, 0, 1, keep_f32=True)
+        x = self._conv_b(x, "maskiou_net.10", 1, 0, 1, keep_f32=True)
+        p = x.reshape(n, -1, x.shape[-1]).max(1)
+        return (score * p[np.arange(n), cls]).astype(np.float32)
+
     @staticmethod
     def postprocess(det, w, h, score_threshold=0.0):
         keep = det["score"] > np.float32(score_threshold)

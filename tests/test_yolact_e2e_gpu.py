@@ -170,6 +170,33 @@ def test_yolact_plus_dcn_backbones_bit_exact(ffi):
         net.close()
 
 
+def test_yolact_plus_mask_rescoring_bit_exact(ffi):
+    """YOLACT++ fast mask re-scoring (use_maskiou / rescore_mask): postprocess returns scores = [box scores, box scores x
+    mask IoU], the mask IoU from FastMaskIoUNet on the cropped proto-resolution masks.  256 px is the smallest input whose
+    64x64 prototypes survive the net's five unpadded stride-2 3x3 convs."""
+    from isegmi.weights import yolact_state_dict
+    from isegmi.yolact import Yolact, YolactConfig, postprocess
+    cfg = YolactConfig.plus_resnet50()
+    size = 256
+    sd = yolact_state_dict(77, depth=50, num_priors=9, dcn_layers=cfg.dcn_layers, dcn_interval=cfg.dcn_interval, maskiou=True)
+    net = Yolact(sd, cfg, max_batch=2, input_size=size)
+    ref = YolactRef(sd, max_size=550, depth=50, scales_per_level=3, square=False)
+    x = _images(91, 2, size)
+    out, refd, total = _compare(net, ref, x, size, 2)
+    assert total > 0
+    for i in range(2):
+        for thr in (0.0, 0.3):
+            cls, sc, boxes, masks = postprocess(out, size, size, batch_idx=i, score_threshold=thr)
+            rc, rs, rb, rm = YolactRef.postprocess(refd[i], size, size, thr)
+            assert isinstance(sc, list) and len(sc) == 2
+            assert np.array_equal(cls, rc) and np.array_equal(sc[0], rs) and np.array_equal(boxes, rb) and np.array_equal(masks, rm)
+            rms = ref.mask_scores(refd[i], thr)
+            assert np.array_equal(sc[1], rms), (i, thr)
+            if len(rms):
+                assert (rms >= 0).all() and float(rms.max()) > 0.0  # the synthetic net gives non-trivial IoU predictions
+    net.close()
+
+
 def test_yolact_smooth_images_bit_exact(ffi, sd):
     """Second input suite: smooth low-frequency fields -> clustered boxes, heavy fast-NMS suppression."""
     from conftest import smooth_field
