@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--depth", type=int, default=50, choices=[50, 101], help="maskrcnn: ResNet depth")
     ap.add_argument("--fp16", action="store_true", help="fp16 storage + f16 MFMA convs: maskrcnn = BASELINE configs[4]; yolact = optional mode (the headline configs[1] is fp32: default)")
     ap.add_argument("--c4", action="store_true", help="maskrcnn: the R-50-C4 config (README.md:263-273) instead of R-50/101-FPN")
+    ap.add_argument("--yolact-config", default="resnet50", choices=["resnet50", "base", "im700", "plus_resnet50", "plus_base"],
+                    help="yolact: which upstream config (the headline configs[1] is resnet50: default); plus_* = YOLACT++ (DCNv2 backbone, 9 anchors, mask re-scoring)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8, help="images the CPU oracle is timed on")
     ap.add_argument("--no-latency", action="store_true", help="skip the extra bs=1 latency pass")
@@ -96,8 +98,13 @@ def main():
 
     if _ffi.device_count() < 1:
         raise SystemExit("no HIP device visible: bench.py measures the HIP path only (no CPU fallback)")
-    sd = yolact_state_dict(1234)
-    net = Yolact(sd, max_batch=a.batch, device=local_rank, fp16=a.fp16)
+    from isegmi.yolact import YolactConfig
+    ycfg = {"resnet50": YolactConfig(), "base": YolactConfig.base(), "im700": YolactConfig.im700(),
+            "plus_resnet50": YolactConfig.plus_resnet50(), "plus_base": YolactConfig.plus_base()}[a.yolact_config]
+    yname = {"resnet50": "Yolact R50-FPN", "base": "Yolact R101-FPN (yolact_base)", "im700": "Yolact R101-FPN 700 (yolact_im700)",
+             "plus_resnet50": "YOLACT++ R50-FPN (DCNv2, 9 anchors, mask re-scoring)", "plus_base": "YOLACT++ R101-FPN (DCNv2 every 3rd block, 9 anchors, mask re-scoring)"}[a.yolact_config]
+    sd = yolact_state_dict(1234, ycfg.depth, ycfg.num_priors, ycfg.dcn_layers, ycfg.dcn_interval, ycfg.use_maskiou)
+    net = Yolact(sd, ycfg, max_batch=a.batch, device=local_rank, fp16=a.fp16)
     ypeak = 2500.0 if a.fp16 else PEAK_F32_MFMA_TFLOPS
     if a.single_stream:
         net.set_param("multi_stream", 0.0)
@@ -171,7 +178,7 @@ def main():
     if rank == 0:
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         out = {
-            "metric": "images/sec (Yolact R50-FPN 550x550, bs=%d per GPU, %s)" % (a.batch, "fp16 storage / f16 MFMA, fp32 accumulate (optional mode, not configs[1])" if a.fp16 else "fp32"),
+            "metric": "images/sec (%s %dx%d, bs=%d per GPU, %s)" % (yname, size, size, a.batch, "fp16 storage / f16 MFMA, fp32 accumulate (optional mode, not configs[1])" if a.fp16 else "fp32"),
             "value": round(value, 2),
             "unit": "img/s",
             "n_gpus": world,
@@ -183,7 +190,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f16" if a.fp16 else "f32",
             "data": "synthetic",
-            "config": {"workload": "Yolact R50-FPN 550x550 bs=%d/GPU random weights: backbone+FPN+protonet+heads+Detect(fast-NMS)+550x550 mask assembly (BASELINE configs[1])" % a.batch,
+            "config": {"workload": "%s %dx%d bs=%d/GPU random weights: backbone+FPN+protonet+heads+Detect(fast-NMS)+%dx%d mask assembly%s" % (
+                           yname, size, size, a.batch, size, size, " (BASELINE configs[1])" if a.yolact_config == "resnet50" else " (variant, not configs[1])"),
                        "global_batch": a.batch * world, "parallelism": "batch-sharded x%d, RCCL all-gather of detections" % world,
                        "detections_per_image_rank0": [int(c) for c in counts]},
             "roofline": {
@@ -239,7 +247,8 @@ def main():
         from oracle.yolact_ref import YolactRef
         ncpu = min(len(os.sched_getaffinity(0)), 16)  # the GPU box's CPU share for one GPU
         os.environ["OMP_NUM_THREADS"] = str(ncpu)
-        ref = YolactRef(sd)
+        ref = YolactRef(sd, max_size=ycfg.max_size, scales=ycfg.pred_scales, depth=ycfg.depth, scales_per_level=ycfg.scales_per_level,
+                        square=ycfg.use_square_anchors)
         k = max(1, min(a.cpu_sample, a.batch))
         tc = time.perf_counter()
         done = 0

@@ -105,8 +105,9 @@ def maskrcnn_results(image_id, boxes_xyxy, scores, labels, masks=None):
     return out
 
 
-def yolact_results(image_id, classes, scores, boxes_xyxy_int, masks=None):
-    """Yolact eval.py Detections.add_bbox/add_mask: bbox [x1,y1,w,h] rounded to 0.1, class 0..79 -> COCO id."""
+def yolact_results(image_id, classes, scores, boxes_xyxy_int, masks=None, mask_scores=None):
+    """Yolact eval.py Detections.add_bbox/add_mask: bbox [x1,y1,w,h] rounded to 0.1, class 0..79 -> COCO id.
+    mask_scores (YOLACT++ re-scoring): upstream writes the mask entry with the re-scored value; kept here as "mask_score"."""
     out = []
     b = np.asarray(boxes_xyxy_int).reshape(-1, 4)
     for k in range(b.shape[0]):
@@ -115,6 +116,8 @@ def yolact_results(image_id, classes, scores, boxes_xyxy_int, masks=None):
         d = {"image_id": int(image_id), "category_id": COCO_CATEGORY_IDS[int(classes[k])], "bbox": bbox, "score": float(scores[k])}
         if masks is not None:
             d["segmentation"] = rle_encode(masks[k])
+        if mask_scores is not None:
+            d["mask_score"] = float(mask_scores[k])
         out.append(d)
     return out
 
