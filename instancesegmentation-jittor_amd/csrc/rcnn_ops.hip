@@ -278,6 +278,87 @@ __global__ __launch_bounds__(1024) void rpn_decode_nms_kernel(const float* __res
     if (threadIdx.x == 0) out_cnt[n * L + level] = kc;
 }
 
+// Greedy NMS scan over a finished suppression matrix (ONE wave; M in LDS, NMS_CAP/64 words per row: bit j of M[i][w] set iff
+// box 64w+j comes after box i and IoU(i, j) exceeds the threshold).  A chunk of 64 is resolved from its diagonal words by a
+// 64-step scalar chain (readlane / bitcmp / andn2: no IoU, no memory), then lane (w, q) ORs the kept rows' word w into the
+// `removed` words with 16 unconditional LDS reads.  dead[i] != 0 removes box i beforehand; at most max_keep boxes are kept.
+// Returns the kept count (uniform); kept[] holds the kept positions in visiting order.
+__device__ __forceinline__ int nms_bit_scan(const unsigned long long* M, int cnt, int max_keep, const unsigned char* dead, unsigned short* kept) {
+    constexpr int W = NMS_CAP / 64;
+    const int lane = threadIdx.x & 63;
+    const int nwords = (cnt + 63) >> 6;
+    const int post_nms = max_keep;
+    int kc_out;
+    {
+        unsigned long long rem = 0ull;  // lane w < nwords: removed / not-a-candidate bits of word w
+        for (int w = 0; w < nwords; ++w) {
+            const int i = (w << 6) + lane;
+            const unsigned long long m = __ballot(i >= cnt || (dead != nullptr && dead[i < cnt ? i : 0]));
+            if (lane == w) rem = m;
+        }
+        const unsigned long long lt_mask = (1ull << lane) - 1ull;
+        const int pw = lane & 15, pq = lane >> 4;
+        int kc = 0;
+        for (int c = 0; c < nwords; ++c) {
+            if (kc >= post_nms) break;
+            const int i = (c << 6) + lane;
+            const unsigned long long d = i < cnt ? M[i * W + c] : 0ull;
+            const int dlo = (int)(unsigned)d, dhi = (int)(unsigned)(d >> 32);
+            const unsigned long long rc = __shfl(rem, c, 64);
+            unsigned long long alive = ~(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(rc >> 32)) << 32) |
+                                         (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)rc));
+#pragma unroll
+            for (int b = 0; b < 64; ++b) {  // box b survives => it strikes its later chunk-mates; survivors are the kept ones
+                const unsigned long long db = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(dhi, b) << 32) |
+                                              (unsigned long long)(unsigned)__builtin_amdgcn_readlane(dlo, b);
+                alive &= ((alive >> b) & 1ull) ? ~db : ~0ull;
+            }
+            unsigned long long keepm = alive;
+            while (kc + __popcll(keepm) > post_nms) keepm &= ~(1ull << (63 - __builtin_clzll(keepm)));  // uniform; last chunk only
+            if ((keepm >> lane) & 1ull) kept[kc + __popcll(keepm & lt_mask)] = (unsigned short)i;
+            unsigned long long acc = 0ull;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int b = pq * 16 + u;
+                const unsigned long long v = M[((c << 6) + b) * W + pw];
+                acc |= ((keepm >> b) & 1ull) ? v : 0ull;
+            }
+            acc |= __shfl_xor(acc, 16, 64);
+            acc |= __shfl_xor(acc, 32, 64);
+            if (lane < 16 && lane > c) rem |= acc;
+            kc += __popcll(keepm);
+        }
+        kc_out = kc;
+    }
+    return kc_out;
+}
+
+// The suppression matrix of n <= NMS_CAP boxes built by ONE block (all its waves): wave-task (r, w), r <= w, owns rows
+// 64r..64r+63 (lane = row) x the 64 broadcast column boxes of word w.  For problems that have a block to themselves anyway
+// (a crowded class in the per-class box NMS: 600 candidates took 250 us in nms_block's chunk-against-kept-list form).
+__device__ void nms_matrix_block(const float4* sb, int n, float thr, float one, int ge, unsigned long long* M) {
+    constexpr int W = NMS_CAP / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const IouThr T = make_iou_thr(thr, ge);
+    const int nwords = (n + 63) >> 6;
+    const int npairs = nwords * (nwords + 1) / 2;
+    for (int pair = wave; pair < npairs; pair += nw) {
+        int w = 0;
+        while ((w + 1) * (w + 2) / 2 <= pair) ++w;
+        const int r = pair - w * (w + 1) / 2;
+        const int i = (r << 6) + lane;
+        const float4 mine = sb[i < n ? i : 0];
+        unsigned long long m = 0ull;
+#pragma unroll 8
+        for (int b = 0; b < 64; ++b) {
+            const int j = (w << 6) + b;
+            const bool sup = j > i && j < n && iou_exceeds(mine, sb[j < n ? j : 0], one, T);
+            m |= sup ? (1ull << b) : 0ull;
+        }
+        if (i < n) M[i * W + w] = m;
+    }
+}
+
 // ---- the same per-level RPN NMS split over the chip (pre_nms <= NMS_CAP and a matrix workspace from the caller).
 // The single-block kernel above is bound by ONE CU's VALU rate (~n^2/2 exact IoU tests, 256 us per level at n = 1000).  Here
 //   rpn_nms_matrix_kernel  (136 waves per image): wave (r, w), r <= w, owns rows 64r..64r+63 x columns 64w..64w+63 of the
@@ -344,7 +425,6 @@ __global__ __launch_bounds__(1024) void rpn_nms_scan_kernel(const float* __restr
     __shared__ int kc_sh;
     const int n = blockIdx.x;
     const int cnt = tk_cnt[n];
-    const int nwords = (cnt + 63) >> 6;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float im_h = (float)image_hw[2 * n], im_w = (float)image_hw[2 * n + 1];
     {   // matrix rows [0, cnt) -> LDS, 16 bytes per thread and step (rows past cnt and words left of the diagonal are stale
@@ -363,44 +443,7 @@ __global__ __launch_bounds__(1024) void rpn_nms_scan_kernel(const float* __restr
     }
     __syncthreads();
     if (wave == 0) {
-        unsigned long long rem = 0ull;  // lane w < nwords: removed / not-a-candidate bits of word w
-        for (int w = 0; w < nwords; ++w) {
-            const int i = (w << 6) + lane;
-            const unsigned long long m = __ballot(i >= cnt || dead[i < cnt ? i : 0]);
-            if (lane == w) rem = m;
-        }
-        const unsigned long long lt_mask = (1ull << lane) - 1ull;
-        const int pw = lane & 15, pq = lane >> 4;
-        int kc = 0;
-        for (int c = 0; c < nwords; ++c) {
-            if (kc >= post_nms) break;
-            const int i = (c << 6) + lane;
-            const unsigned long long d = i < cnt ? M[i * W + c] : 0ull;
-            const int dlo = (int)(unsigned)d, dhi = (int)(unsigned)(d >> 32);
-            const unsigned long long rc = __shfl(rem, c, 64);
-            unsigned long long alive = ~(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(rc >> 32)) << 32) |
-                                         (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)rc));
-#pragma unroll
-            for (int b = 0; b < 64; ++b) {  // box b survives => it strikes its later chunk-mates; survivors are the kept ones
-                const unsigned long long db = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(dhi, b) << 32) |
-                                              (unsigned long long)(unsigned)__builtin_amdgcn_readlane(dlo, b);
-                alive &= ((alive >> b) & 1ull) ? ~db : ~0ull;
-            }
-            unsigned long long keepm = alive;
-            while (kc + __popcll(keepm) > post_nms) keepm &= ~(1ull << (63 - __builtin_clzll(keepm)));  // uniform; last chunk only
-            if ((keepm >> lane) & 1ull) kept[kc + __popcll(keepm & lt_mask)] = (unsigned short)i;
-            unsigned long long acc = 0ull;
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int b = pq * 16 + u;
-                const unsigned long long v = M[((c << 6) + b) * W + pw];
-                acc |= ((keepm >> b) & 1ull) ? v : 0ull;
-            }
-            acc |= __shfl_xor(acc, 16, 64);
-            acc |= __shfl_xor(acc, 32, 64);
-            if (lane < 16 && lane > c) rem |= acc;
-            kc += __popcll(keepm);
-        }
+        const int kc = nms_bit_scan(M, cnt, post_nms, dead, kept);
         if (lane == 0) kc_sh = kc;
     }
     __syncthreads();
@@ -555,7 +598,10 @@ __global__ void softmax_rows_kernel(const float* __restrict__ x, int64_t rows, i
 
 // grid (ncls-1, N).  prob [N][R][ncls]; regr [N][R][regr_stride] (class j deltas at 4j..4j+3); props [N][R][4];
 // prop_cnt [N].  cand_scores/cand_boxes [N][ncls-1][R] in NMS (score) order, -1 beyond the kept count.
-__global__ __launch_bounds__(256) void box_cls_nms_kernel(const float* __restrict__ prob, const float* __restrict__ regr,
+// 16 waves: a crowded class's suppression matrix is ~60 dependent instructions per IoU test, and a wave alone on its SIMD
+// issues one every ~6 cycles (11 us per 64x64 matrix block); four waves per SIMD fill the issue slots.
+constexpr int BOX_NMS_THREADS = 1024;
+__global__ __launch_bounds__(BOX_NMS_THREADS) void box_cls_nms_kernel(const float* __restrict__ prob, const float* __restrict__ regr,
                                                            int64_t regr_stride, const float* __restrict__ props,
                                                            const int* __restrict__ prop_cnt, const int* __restrict__ image_hw, int R,
                                                            int ncls, float score_thr, float nms_thr, int ge,
@@ -563,12 +609,13 @@ __global__ __launch_bounds__(256) void box_cls_nms_kernel(const float* __restric
                                                            int* __restrict__ kept_total) {
     __shared__ NmsShared S;
     __shared__ unsigned long long keys[NMS_CAP];
-    __shared__ int wcnt[4];
+    constexpr int NT = BOX_NMS_THREADS, NW = NT / 64;
+    __shared__ int wcnt[NW];
     const int j = blockIdx.x + 1, n = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Rn = prop_cnt[n];
-    // ordered compaction of candidates (proposal order): wave w owns a contiguous quarter
-    const int seg = ((Rn + 3) / 4 + 63) & ~63;
+    // ordered compaction of candidates (proposal order): wave w owns a contiguous share
+    const int seg = ((Rn + NW - 1) / NW + 63) & ~63;
     const int s0 = wave * seg, s1 = (s0 + seg) < Rn ? (s0 + seg) : Rn;
     int c = 0;
     for (int i = s0 + lane; (i - lane) < s1; i += 64) {
@@ -579,7 +626,8 @@ __global__ __launch_bounds__(256) void box_cls_nms_kernel(const float* __restric
     __syncthreads();
     int base = 0;
     for (int w = 0; w < wave; ++w) base += wcnt[w];
-    const int m = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    int m = 0;
+    for (int w = 0; w < NW; ++w) m += wcnt[w];
     int run = base;
     for (int i = s0 + lane; (i - lane) < s1; i += 64) {
         float p = 0.0f;
@@ -592,11 +640,11 @@ __global__ __launch_bounds__(256) void box_cls_nms_kernel(const float* __restric
         run += __popcll(bm);
     }
     const int np2 = next_pow2(m > 1 ? m : 2);
-    for (int i = m + tid; i < np2; i += 256) keys[i] = 0ull;
+    for (int i = m + tid; i < np2; i += NT) keys[i] = 0ull;
     __syncthreads();
     sort_desc_1024(keys, np2);
     const float im_h = (float)image_hw[2 * n], im_w = (float)image_hw[2 * n + 1];
-    for (int q = tid; q < m; q += 256) {
+    for (int q = tid; q < m; q += NT) {
         const int i = (int)(0xffffffffu - (unsigned)(keys[q] & 0xffffffffull));
         const float4 pr = *(const float4*)(props + ((int64_t)n * R + i) * 4);
         const float* dp = regr + ((int64_t)n * R + i) * regr_stride + 4 * j;
@@ -604,9 +652,22 @@ __global__ __launch_bounds__(256) void box_cls_nms_kernel(const float* __restric
         S.sb[q] = clip_box(decode_box(pr, d, 10.f, 10.f, 5.f, 5.f), im_w, im_h);
     }
     __syncthreads();
-    const int kc = nms_block(S, m, nms_thr, 1.0f, ge, 0, nullptr);
+    int kc;
+    if (m > 128) {  // crowded class: bitmask NMS (identical kept list), the matrix in this block's dynamic LDS
+        extern __shared__ unsigned long long nms_matrix[];
+        nms_matrix_block(S.sb, m, nms_thr, 1.0f, ge, nms_matrix);
+        __syncthreads();
+        if (wave == 0) {
+            const int k = nms_bit_scan(nms_matrix, m, m, nullptr, S.kept);
+            if (lane == 0) S.kc = k;
+        }
+        __syncthreads();
+        kc = S.kc;
+    } else {
+        kc = nms_block(S, m, nms_thr, 1.0f, ge, 0, nullptr);
+    }
     const int64_t ob = ((int64_t)n * (ncls - 1) + (j - 1)) * R;
-    for (int q = tid; q < R; q += 256) {
+    for (int q = tid; q < R; q += NT) {
         if (q < kc) {
             const int src = S.kept[q];
             cand_scores[ob + q] = ord2f_((unsigned)(keys[src] >> 32));
@@ -882,7 +943,13 @@ int box_postprocess_launch(const isegmi_box_post_args* a, hipStream_t st) {
     int rc = softmax_rows_launch(a->d_logits, (int64_t)a->N * a->R, a->ncls, a->logits_stride, a->d_ws_prob, st);
     if (rc) return rc;
     HIP_TRY(hipMemsetAsync(a->d_ws_kept_total, 0, sizeof(int) * (size_t)a->N, st));
-    hipLaunchKernelGGL(box_cls_nms_kernel, dim3(nc, a->N), dim3(256), 0, st, a->d_ws_prob, a->d_regr, a->regr_stride, a->d_props,
+    constexpr int matrix_bytes = NMS_CAP * (NMS_CAP / 64) * 8;  // 128 KB next to 26 KB of static LDS: one block per CU
+    static bool attr = false;
+    if (!attr) {
+        HIP_TRY(hipFuncSetAttribute((const void*)box_cls_nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, matrix_bytes));
+        attr = true;
+    }
+    hipLaunchKernelGGL(box_cls_nms_kernel, dim3(nc, a->N), dim3(BOX_NMS_THREADS), matrix_bytes, st, a->d_ws_prob, a->d_regr, a->regr_stride, a->d_props,
                        a->d_prop_cnt, a->d_image_hw, a->R, a->ncls, a->score_thresh, a->nms_thresh, a->nms_ge, a->d_ws_cand_scores,
                        a->d_ws_cand_boxes, a->d_ws_kept_total);
     HIP_TRY(hipGetLastError());

@@ -180,6 +180,15 @@ def test_box_postprocess_matches_oracle(ffi):
         rb, rs, rl = ora.box_postprocess(logits[n, :k], regr[n, :k], props[n, :k], float(hw[n, 1]), float(hw[n, 0]), cap=100)
         assert len(rs) == 100
         assert np.array_equal(got[n][2], rl) and np.array_equal(got[n][1], rs) and np.array_equal(got[n][0], rb)
+    # crowded classes (several hundred candidates each: the in-block bitmask NMS) on tightly clustered, near-identical proposals
+    props3 = props.copy()
+    props3[:, 200:] = props3[:, :800] + rng.normal(0, 1.5, (N, 800, 4)).astype(np.float32)
+    logits3 = logits.copy(); logits3[..., [7, 31]] += 1.5
+    got = ffi.box_postprocess(logits3, regr * 0.05, props3, cnt, hw)
+    for n in range(N):
+        k = cnt[n]
+        rb, rs, rl = ora.box_postprocess(logits3[n, :k], regr[n, :k] * 0.05, props3[n, :k], float(hw[n, 1]), float(hw[n, 0]), cap=100)
+        assert np.array_equal(got[n][2], rl) and np.array_equal(got[n][1], rs) and np.array_equal(got[n][0], rb)
     # fewer than det_per_img survivors: everything kept, order preserved
     logits2 = logits.copy(); logits2[..., 0] += 6.0
     got = ffi.box_postprocess(logits2, regr, props, cnt, hw)
