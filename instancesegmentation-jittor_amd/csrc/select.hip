@@ -200,7 +200,7 @@ int topk_launch(const float* keys, int64_t row_stride, int rows, int n, int k, c
         if (wide) hipLaunchKernelGGL((topk_kernel<1024, 256>), dim3(rows), dim3(1024), 0, st, a);
         else hipLaunchKernelGGL((topk_kernel<256, 256>), dim3(rows), dim3(256), 0, st, a);
     } else if (k <= 1024) {
-        if (n > 16384) hipLaunchKernelGGL((topk_kernel<1024, 1024>), dim3(rows), dim3(1024), 0, st, a);
+        if (n > 16384 || rows < 64) hipLaunchKernelGGL((topk_kernel<1024, 1024>), dim3(rows), dim3(1024), 0, st, a);  // few rows: the 1024-key sort wants the threads
         else hipLaunchKernelGGL((topk_kernel<256, 1024>), dim3(rows), dim3(256), 0, st, a);
     } else {  // single-map RPN: PRE_NMS_TOP_N_TEST up to 6000 (64 KB of sort keys in LDS)
         hipLaunchKernelGGL((topk_kernel<1024, 8192>), dim3(rows), dim3(1024), 0, st, a);
