@@ -931,6 +931,8 @@ int softmax_rows_launch(const float* x, int64_t rows, int C, int64_t in_stride, 
     return ISEGMI_OK;
 }
 
+int topk_segmented_launch(const float* keys, int64_t row_stride, int rows, int nseg, int seg_len, int seg_take, int k, const int* limit,
+                          int rows_per_limit, float* out_vals, int* out_idx, int* out_cnt, hipStream_t st);
 int topk_launch(const float* keys, int64_t row_stride, int rows, int n, int k, const int* limit, int rows_per_limit,
                 float* out_vals, int* out_idx, int* out_cnt, hipStream_t st);
 
@@ -953,8 +955,13 @@ int box_postprocess_launch(const isegmi_box_post_args* a, hipStream_t st) {
                        a->d_prop_cnt, a->d_image_hw, a->R, a->ncls, a->score_thresh, a->nms_thresh, a->nms_ge, a->d_ws_cand_scores,
                        a->d_ws_cand_boxes, a->d_ws_kept_total);
     HIP_TRY(hipGetLastError());
-    rc = topk_launch(a->d_ws_cand_scores, (int64_t)nc * a->R, a->N, nc * a->R, a->det_per_img, a->d_ws_kept_total, 1, a->d_ws_top_vals,
-                     a->d_ws_top_idx, nullptr, st);
+    // the per-class lists are sorted: nothing past a class's first det_per_img entries can make the image's top det_per_img
+    if (a->det_per_img <= 128 && a->det_per_img <= a->R)
+        rc = topk_segmented_launch(a->d_ws_cand_scores, (int64_t)nc * a->R, a->N, nc, a->R, a->det_per_img, a->det_per_img, a->d_ws_kept_total, 1,
+                                   a->d_ws_top_vals, a->d_ws_top_idx, nullptr, st);
+    else
+        rc = topk_launch(a->d_ws_cand_scores, (int64_t)nc * a->R, a->N, nc * a->R, a->det_per_img, a->d_ws_kept_total, 1, a->d_ws_top_vals,
+                         a->d_ws_top_idx, nullptr, st);
     if (rc) return rc;
     hipLaunchKernelGGL(finalize_dets_kernel, dim3(a->N), dim3(1024), 0, st, a->d_ws_cand_scores, a->d_ws_cand_boxes, a->d_ws_kept_total,
                        a->d_ws_top_vals, nc, a->R, a->det_per_img, a->cap, a->d_out_count, a->d_out_boxes, a->d_out_scores,

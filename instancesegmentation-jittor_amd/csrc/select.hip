@@ -36,9 +36,14 @@ struct TopkArgs {
     float* out_vals;        // [rows][k]
     int* out_idx;           // [rows][k]
     int* out_cnt;           // [rows] (optional)
+    int seg_len, seg_take;  // SEG kernels: the row is nseg segments of seg_len keys, of which only the first seg_take count
 };
 
-template <int NT, int KCAP>
+// SEG: the logical row is the concatenation of the first seg_take keys of every seg_len-long segment (element e lives at
+// (e / seg_take) * seg_len + e % seg_take); reported indices are positions in the FULL row, and since the mapping is
+// monotonic the (score desc, index asc) order is the full row's.  For rows made of per-class lists that are already sorted
+// (the final top-100 over 80 x 1000 per-class NMS outputs: nothing past a class's first 100 entries can make the top 100).
+template <int NT, int KCAP, bool SEG = false>
 __global__ __launch_bounds__(NT) void topk_kernel(const TopkArgs a) {
     constexpr int NW = NT / 64;
     constexpr int BINS = 4096;
@@ -53,6 +58,7 @@ __global__ __launch_bounds__(NT) void topk_kernel(const TopkArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* keys = a.keys + (int64_t)row * a.row_stride;
     const int n = a.n;
+    auto phys = [&](int e) { return SEG ? (e / a.seg_take) * a.seg_len + (e % a.seg_take) : e; };
     int k_eff = a.k < n ? a.k : n;
     if (a.limit) {
         const int l = a.limit[row / a.rows_per_limit];
@@ -76,7 +82,7 @@ __global__ __launch_bounds__(NT) void topk_kernel(const TopkArgs a) {
         for (int i0 = tid; i0 < n; i0 += NT * UNR) {
             float kv[UNR];
 #pragma unroll
-            for (int q = 0; q < UNR; ++q) { const int i = i0 + q * NT; kv[q] = i < n ? keys[i] : 0.0f; }
+            for (int q = 0; q < UNR; ++q) { const int i = i0 + q * NT; kv[q] = i < n ? keys[phys(i)] : 0.0f; }
 #pragma unroll
             for (int q = 0; q < UNR; ++q) {
                 const unsigned u = f2ord(kv[q]);
@@ -123,7 +129,7 @@ __global__ __launch_bounds__(NT) void topk_kernel(const TopkArgs a) {
     for (int i0 = s0 + lane; (i0 - lane) < s1; i0 += 64 * UNR) {
         float kv[UNR];
 #pragma unroll
-        for (int q = 0; q < UNR; ++q) { const int i = i0 + q * 64; kv[q] = i < s1 ? keys[i] : 0.0f; }
+        for (int q = 0; q < UNR; ++q) { const int i = i0 + q * 64; kv[q] = i < s1 ? keys[phys(i)] : 0.0f; }
 #pragma unroll
         for (int q = 0; q < UNR; ++q) {
             const bool in = i0 + q * 64 < s1;
@@ -142,7 +148,7 @@ __global__ __launch_bounds__(NT) void topk_kernel(const TopkArgs a) {
     for (int i0 = s0 + lane; (i0 - lane) < s1; i0 += 64 * UNR) {
         float kv[UNR];
 #pragma unroll
-        for (int q = 0; q < UNR; ++q) { const int i = i0 + q * 64; kv[q] = i < s1 ? keys[i] : 0.0f; }
+        for (int q = 0; q < UNR; ++q) { const int i = i0 + q * 64; kv[q] = i < s1 ? keys[phys(i)] : 0.0f; }
 #pragma unroll
         for (int q = 0; q < UNR; ++q) {  // index order is kept: q walks the wave's segment 64 elements at a time
             const int i = i0 + q * 64;
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(NT) void topk_kernel(const TopkArgs a) {
             const unsigned long long bsel = __ballot(sel);
             if (sel) {
                 const unsigned pos = run_sel + (unsigned)__popcll(bsel & lt_mask);
-                if (pos < (unsigned)KCAP) sbuf[pos] = ((unsigned long long)u << 32) | (unsigned long long)(0xffffffffu - (unsigned)i);
+                if (pos < (unsigned)KCAP) sbuf[pos] = ((unsigned long long)u << 32) | (unsigned long long)(0xffffffffu - (unsigned)phys(i));
             }
             run_sel += (unsigned)__popcll(bsel);
             run_eq += (unsigned)__popcll(beq);
@@ -189,7 +195,7 @@ int topk_launch(const float* keys, int64_t row_stride, int rows, int n, int k, c
                 float* out_vals, int* out_idx, int* out_cnt, hipStream_t st) {
     ARG_CHECK(rows >= 0 && n >= 0 && k > 0 && k <= 8192, "topk sizes (k <= 8192)");
     if (rows == 0) return ISEGMI_OK;
-    TopkArgs a{keys, row_stride, n, k, limit, rows_per_limit > 0 ? rows_per_limit : 1, out_vals, out_idx, out_cnt};
+    TopkArgs a{keys, row_stride, n, k, limit, rows_per_limit > 0 ? rows_per_limit : 1, out_vals, out_idx, out_cnt, 0, 0};
     // wide blocks when the rows alone cannot fill the chip (bs=1 Detect: 80 class rows of 19 248 priors, then ONE row of 16 000
     // candidates): a row's five passes over its keys are latency-bound per thread, so 1024 threads cut them ~3x
     const bool wide = n > 65536 || (n > 8192 && rows < 256);
@@ -205,6 +211,17 @@ int topk_launch(const float* keys, int64_t row_stride, int rows, int n, int k, c
     } else {  // single-map RPN: PRE_NMS_TOP_N_TEST up to 6000 (64 KB of sort keys in LDS)
         hipLaunchKernelGGL((topk_kernel<1024, 8192>), dim3(rows), dim3(1024), 0, st, a);
     }
+    HIP_TRY(hipGetLastError());
+    return ISEGMI_OK;
+}
+
+// top-k over the first seg_take keys of each of nseg segments of seg_len keys per row (k <= 128); indices refer to the full row
+int topk_segmented_launch(const float* keys, int64_t row_stride, int rows, int nseg, int seg_len, int seg_take, int k, const int* limit,
+                          int rows_per_limit, float* out_vals, int* out_idx, int* out_cnt, hipStream_t st) {
+    ARG_CHECK(rows >= 0 && nseg > 0 && seg_len > 0 && seg_take > 0 && seg_take <= seg_len && k > 0 && k <= 128, "segmented topk sizes (k <= 128)");
+    if (rows == 0) return ISEGMI_OK;
+    TopkArgs a{keys, row_stride, nseg * seg_take, k, limit, rows_per_limit > 0 ? rows_per_limit : 1, out_vals, out_idx, out_cnt, seg_len, seg_take};
+    hipLaunchKernelGGL((topk_kernel<1024, 128, true>), dim3(rows), dim3(1024), 0, st, a);
     HIP_TRY(hipGetLastError());
     return ISEGMI_OK;
 }
