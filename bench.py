@@ -202,7 +202,7 @@ def main():
                 "peak": ypeak,
                 "unit": "TFLOP/s",
                 "frac": round(achieved / ypeak, 4),
-                "traffic": None if a.fp16 else pmc_traffic("r01_pmc_yolact.json"),
+                "traffic": None if (a.fp16 or a.yolact_config != "resnet50") else pmc_traffic("r01_pmc_yolact.json"),  # null: no committed PMC pass for this variant
                 "traffic_note": "HBM bytes per conv launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (profiles/r01_pmc_yolact.json; FETCH x2 gfx950 correction); not collected live",
                 "algorithmic_gflop_per_step": round(conv_flops / max(a.steps, 1) / 1e9, 2),
                 "conv_ms_per_step": round(conv_ms / max(a.steps, 1), 3),
