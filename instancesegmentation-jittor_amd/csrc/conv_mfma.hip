@@ -273,9 +273,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // 256-cycle dependent MFMA chain, nothing of it overlapped because there is no second wave on the SIMD), so the global
 // loads, their address arithmetic and the LDS stores move to a partner wave on the same SIMD and the MFMA wave is left
 // with 8 ds_read2 + 8 MFMA + 1 barrier per chunk.
-template <int RING, bool LW>
+// WN = 16x16 tiles per wave along Cout (block 32 x 32*WN): with WN = 2 a wave runs two independent accumulator chains off one
+// A fragment -- 0.75 instead of 1 LDS fragment read per MFMA, 3 instead of 4 global loads per 16 MFMAs, and the MFMA pipe sees
+// two chains per wave -- for the mid-size grids where the 32x32 block is steady-state LDS/issue-bound.
+template <int RING, bool LW, int WN = 1>
 __global__ __launch_bounds__(LW ? 512 : 256) void conv_mfma16_kernel(const ConvK p) {
-    constexpr int BM = 32, BN = 32;
+    static_assert(WN == 1 || !LW, "the loader-wave variant runs one tile per wave");
+    constexpr int BM = 32, BN = 32 * WN;
     constexpr int ROW = 34;  // floats; pitch = 2 mod 32: bank = 2*row + k for the fragment reads
     constexpr int STAGE = (BM + BN) * ROW;
     constexpr int NST = LW ? 3 : 2;  // LDS stages (LW: chunk t computed while t+1 is read into registers and t+2 written)
@@ -324,15 +328,19 @@ __global__ __launch_bounds__(LW ? 512 : 256) void conv_mfma16_kernel(const ConvK
                      (unsigned)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000u};
     };
     const u32x4 rs_in = make_rsrc(p.in, p.in_bytes), rs_w = make_rsrc(p.w, p.w_bytes);
-    u32x4 ra[RING], rb[RING];
+    u32x4 ra[RING], rb[RING][WN];
     int kr = 0, ks = 0, kc = 0, chunk = 0;  // position of the next chunk to load (they are loaded strictly in order)
     auto load_chunk = [&](int slot) {
         const unsigned dead = (unsigned)((p.nchunks - 1 - chunk) >> 31) & OOB;
         const bool ok = (unsigned)(hi0 + kr) < (unsigned)p.H && (unsigned)(wi0 + ks) < (unsigned)p.W;
         const unsigned tap = (unsigned)((kr * p.W + ks) * p.Cin + kc * 32) * 4u;  // scalar
-        const unsigned offa = (ok ? abase + tap : OOB) | dead, offb = (wbase + (unsigned)chunk * 128u) | dead;
+        const unsigned offa = (ok ? abase + tap : OOB) | dead;
         asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(ra[slot]) : "v"(offa), "s"(rs_in) : "memory");
-        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(rb[slot]) : "v"(offb), "s"(rs_w) : "memory");
+#pragma unroll
+        for (int t = 0; t < WN; ++t) {  // weight rows lrow and lrow + 32
+            const unsigned offb = (wbase + (unsigned)t * 32u * (unsigned)p.wrow * 4u + (unsigned)chunk * 128u) | dead;
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(rb[slot][t]) : "v"(offb), "s"(rs_w) : "memory");
+        }
         // branch-free tap counters: the pipelined iteration below must stay one basic block for its issue-order directives
         const int wc = (kc + 1 == p.cin_chunks) ? 1 : 0;
         kc = wc ? 0 : kc + 1;
@@ -345,31 +353,44 @@ __global__ __launch_bounds__(LW ? 512 : 256) void conv_mfma16_kernel(const ConvK
     // holds [k0 k2 k4 k6 | k1 k3 k5 k7] per 8-group, so thread (grp, half) owns k = 8*grp + 2j + half
     const int grp = g8 >> 1, half = g8 & 1;
     auto store_chunk = [&](int slot, int stage, auto pending) {  // pending = loads issued after this slot's
-        asm volatile("s_waitcnt vmcnt(%2)" : "+v"(ra[slot]), "+v"(rb[slot]) : "n"(decltype(pending)::value) : "memory");
+        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ra[slot]) : "n"(decltype(pending)::value) : "memory");
+#pragma unroll
+        for (int t = 0; t < WN; ++t) asm volatile("" : "+v"(rb[slot][t]) :: "memory");
         float* As = smem16 + stage * STAGE;
         float* Bs = As + BM * ROW;
         float* d = As + lrow * ROW + g8 * 4;
         *(u32x2*)d = u32x2{ra[slot].x, ra[slot].y};
         *(u32x2*)(d + 2) = u32x2{ra[slot].z, ra[slot].w};
-        unsigned* b = (unsigned*)(Bs + lrow * ROW + grp * 8 + half);
-        b[0] = rb[slot].x; b[2] = rb[slot].y; b[4] = rb[slot].z; b[6] = rb[slot].w;
+#pragma unroll
+        for (int t = 0; t < WN; ++t) {
+            unsigned* b = (unsigned*)(Bs + (lrow + 32 * t) * ROW + grp * 8 + half);
+            b[0] = rb[slot][t].x; b[2] = rb[slot][t].y; b[4] = rb[slot][t].z; b[6] = rb[slot][t].w;
+        }
     };
 
-    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    f32x4 acc[WN];
+#pragma unroll
+    for (int t = 0; t < WN; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     const int li = lane & 15, lq = lane >> 4;
     const int a_off = (wm * 16 + li) * ROW + lq;  // MFMA step s reads k = 4s + lq
-    const int b_off = BM * ROW + (wn * 16 + li) * ROW + lq;
-    float fa[LW ? 2 : 1][8], fb[LW ? 2 : 1][8];
+    const int b_off = BM * ROW + (wn * 16 * WN + li) * ROW + lq;
+    float fa[LW ? 2 : 1][8], fb[LW ? 2 : 1][WN][8];
     auto read_frags = [&](int set, int stage) {
         const float* sb = smem16 + stage * STAGE;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) { fa[set][s] = sb[a_off + s * 4]; fb[set][s] = sb[b_off + s * 4]; }
+        for (int s = 0; s < 8; ++s) {
+            fa[set][s] = sb[a_off + s * 4];
+#pragma unroll
+            for (int t = 0; t < WN; ++t) fb[set][t][s] = sb[b_off + t * 16 * ROW + s * 4];
+        }
     };
     auto mma = [&](int set) {
 #pragma unroll
-        for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[set][s], fb[set][s], acc, 0, 0, 0);
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int t = 0; t < WN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[set][s], fb[set][t][s], acc[t], 0, 0, 0);
     };
-    typedef std::integral_constant<int, 2 * (RING - 1)> Steady;
+    typedef std::integral_constant<int, (1 + WN) * (RING - 1)> Steady;
     static_assert(RING % 2 == 0 && RING >= 4, "fragment sets alternate with the unrolled slot index");
 
     if (!LW) {
@@ -408,7 +429,7 @@ __global__ __launch_bounds__(LW ? 512 : 256) void conv_mfma16_kernel(const ConvK
 #pragma unroll
             for (int i = 0; i < RING; ++i) load_chunk(i);
             store_chunk(0, 0, Steady());
-            store_chunk(1, 1, std::integral_constant<int, 2 * (RING - 2)>());
+            store_chunk(1, 1, std::integral_constant<int, (1 + WN) * (RING - 2)>());
             load_chunk(0);
             load_chunk(1);
         }
@@ -450,38 +471,41 @@ __global__ __launch_bounds__(LW ? 512 : 256) void conv_mfma16_kernel(const ConvK
     // epilogue: D col (cout) = lane&15, row (pixel) = (lane>>4)*4 + e
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, p.out_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? p.res : p.out), 0, p.res ? p.res_bytes : 0u, 0x00020000);
-    const int co = n0 + wn * 16 + li;
-    const bool cok = co < p.Cout;
-    const float sc = (cok && p.scale) ? p.scale[co] : 1.0f;
-    const float sh = (cok && p.shift) ? p.shift[co] : 0.0f;
-    unsigned ooff[4];
-    float rv[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int m = m0 + wm * 16 + lq * 4 + e;
-        const bool ok = cok && m < p.M;
-        unsigned off;
-        if (p.contiguous) off = ((unsigned)m * (unsigned)p.out_pix_stride + (unsigned)co) * 4u;
-        else {
-            const int ni = m / p.out_div, pi = m - ni * p.out_div;
-            off = (unsigned)(((int64_t)ni * p.out_img_stride + (int64_t)pi * p.out_pix_stride + co) * 4);
+    for (int t = 0; t < WN; ++t) {
+        const int co = n0 + (wn * WN + t) * 16 + li;
+        const bool cok = co < p.Cout;
+        const float sc = (cok && p.scale) ? p.scale[co] : 1.0f;
+        const float sh = (cok && p.shift) ? p.shift[co] : 0.0f;
+        unsigned ooff[4];
+        float rv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int m = m0 + wm * 16 + lq * 4 + e;
+            const bool ok = cok && m < p.M;
+            unsigned off;
+            if (p.contiguous) off = ((unsigned)m * (unsigned)p.out_pix_stride + (unsigned)co) * 4u;
+            else {
+                const int ni = m / p.out_div, pi = m - ni * p.out_div;
+                off = (unsigned)(((int64_t)ni * p.out_img_stride + (int64_t)pi * p.out_pix_stride + co) * 4);
+            }
+            ooff[e] = ok ? off : OOB;
+            rv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_res, ok ? ((unsigned)m * (unsigned)p.Cout + (unsigned)co) * 4u : OOB, 0, 0));
         }
-        ooff[e] = ok ? off : OOB;
-        rv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_res, ok ? ((unsigned)m * (unsigned)p.Cout + (unsigned)co) * 4u : OOB, 0, 0));
-    }
-    float yv[4];
+        float yv[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        float y = fmaf(acc[e], sc, sh);
-        y = y + rv[e];
-        yv[e] = p.act == 1 ? (y > 0.0f ? y : 0.0f) : y;
-    }
-    if (p.act == 2) {
+        for (int e = 0; e < 4; ++e) {
+            float y = fmaf(acc[t][e], sc, sh);
+            y = y + rv[e];
+            yv[e] = p.act == 1 ? (y > 0.0f ? y : 0.0f) : y;
+        }
+        if (p.act == 2) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) yv[e] = dm_tanh(yv[e]);
-    }
+            for (int e = 0; e < 4; ++e) yv[e] = dm_tanh(yv[e]);
+        }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yv[e]), rs_out, ooff[e], 0, 0);
+        for (int e = 0; e < 4; ++e) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yv[e]), rs_out, ooff[e], 0, 0);
+    }
 }
 
 static inline int perm8(int e) { return 4 * (e & 1) + (e >> 1); }
@@ -496,7 +520,7 @@ static int check_desc(const isegmi_conv_desc* d) {
     ARG_CHECK(is_stem(d) || (d->Cin > 0 && d->Cin % 32 == 0), "Cin must be a multiple of 32 (or the Cin=4 7x7 stem)");
     ARG_CHECK(d->H + 2 * d->pad >= d->R && d->W + 2 * d->pad >= d->S, "kernel larger than padded input");
     ARG_CHECK(d->act >= 0 && d->act <= 2, "act");
-    ARG_CHECK(d->tile >= 0 && d->tile <= 5, "tile");
+    ARG_CHECK(d->tile >= 0 && d->tile <= 6, "tile");
     return ISEGMI_OK;
 }
 
@@ -573,14 +597,23 @@ int conv2d_launch(const isegmi_conv_desc* d, const float* in, const float* w, co
         if (!is_stem(d)) {
             if (r4 < 3) tile = 5;
             else if (d->Cout <= 32 || (106 * r4 <= 80 + 340 * r3 && (r3 < 3 || (r3 == 3 && k.nchunks >= 32)))) tile = 4;
+            // ... and the 32x64 block (tile 6: two 16x16 tiles per wave, 18 + 20 * ceil(t64 / 128) in the same units, within
+            // 1-3 % of the 64x64 tile even on the largest layers) takes the grids that sit just past a whole number of 64x64
+            // rounds, where the 64x64 tile pays a full extra round and the 32x32 block's rounds are too many: measured windows
+            // (profiles/r01_conv_tile3_vs_tile46_v5.txt), each 0.89-0.97 of the better of the other two.
+            const int nck = k.nchunks;
+            if (d->Cout > 32 && ((t64 > 320 && t64 <= 384 && nck >= 32) || (t64 > 512 && t64 <= 640 && nck >= 32) ||
+                                 (t64 > 1024 && t64 <= 1280 && nck >= 16) || (t64 > 2048 && t64 <= 2432 && nck >= 72)))
+                tile = 6;
         }
     }
     if (tile >= 4 && is_stem(d)) tile = 3;  // the 16x16x4 variants have no stem path
     if (tile >= 4) {
         k.mtiles = cdiv(k.M, 32);
-        k.ntiles = cdiv(d->Cout, 32);
+        k.ntiles = cdiv(d->Cout, tile == 6 ? 64 : 32);
         const dim3 g16((unsigned)(k.mtiles * k.ntiles));
         if (tile == 5) hipLaunchKernelGGL((conv_mfma16_kernel<8, true>), g16, dim3(512), 0, st, k);
+        else if (tile == 6) hipLaunchKernelGGL((conv_mfma16_kernel<4, false, 2>), g16, dim3(256), 0, st, k);
         else hipLaunchKernelGGL((conv_mfma16_kernel<4, false>), g16, dim3(256), 0, st, k);
         HIP_TRY(hipGetLastError());
         return ISEGMI_OK;
