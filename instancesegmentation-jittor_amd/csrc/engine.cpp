@@ -245,9 +245,23 @@ static void collect_times(Engine& e) {
         if (_rc) return _rc; \
     } while (0)
 
+// Redirects everything the rest of a forward launches (main stream, side streams, current stream) to the heads stream group.
+struct HeadsScope {
+    Engine& e;
+    hipStream_t s, sd[3];
+    bool on = false;
+    explicit HeadsScope(Engine& e_) : e(e_), s(e_.stream) { for (int k = 0; k < 3; ++k) sd[k] = e.side[k]; }
+    void enter() { on = true; e.stream = e.heads; for (int k = 0; k < 3; ++k) e.side[k] = e.hside[k]; e.cur = e.heads; }
+    ~HeadsScope() { if (on) { e.stream = s; for (int k = 0; k < 3; ++k) e.side[k] = sd[k]; e.cur = s; } }
+};
+
 int yolact_forward(Engine& e, const float* d_images, int N) {
     const int H = e.H, W = e.W;
     e.cur = e.stream;
+    // cross-step pipelining of the heads phase (eager multi-stream throughput mode only)
+    const bool pipe = e.multi_stream && !e.capturing && !e.timing && !e.conv_timing && e.heads != nullptr &&
+                      e.param("graph", 0.0f) == 0.0f && e.param("pipeline_heads", 1.0f) != 0.0f;
+    HeadsScope hscope(e);
     eng_mark(e, "start");
     const int dt = e.fp16 ? 1 : 0;  // fp16 storage + f16 MFMA convolutions (optional mode; heads / prototypes / Detect stay fp32)
     if (dt && e.convs.count("prediction_layers.0.head_cat") == 0) { set_error("fp16 Yolact needs the fused prediction head"); return ISEGMI_ERR_STATE; }
@@ -295,6 +309,9 @@ int yolact_forward(Engine& e, const float* d_images, int N) {
                 TRY(eng_conv(e, nm + ".conv2", t1, st, 1, 1, nullptr, nm + ".t2", &t2));
             }
             if (b == 0) TRY(eng_join(e, 0));
+            // C3 (then C4, C5) is about to be overwritten: the previous step's lateral convs, running on the heads streams, must
+            // have read them (they are the first thing of that phase, so this wait practically never blocks)
+            if (li == 1 && b == blocks[1] - 1 && e.lat_pending) HIP_TRY(hipStreamWaitEvent(e.stream, e.lat_done, 0));
             TRY(eng_conv(e, nm + ".conv3", t2, 1, 0, 1, &idt, nm + ".out", &y));
             x = y;
         }
@@ -302,6 +319,16 @@ int yolact_forward(Engine& e, const float* d_images, int N) {
         eng_mark(e, li == 0 ? "layer1" : li == 1 ? "layer2" : li == 2 ? "layer3" : "layer4");
     }
     const Tensor C3 = outs[1], C4 = outs[2], C5 = outs[3];
+    if (pipe) {  // hand the rest of this forward to the heads stream group; the caller's next forward starts its backbone at once
+        hipEvent_t ev;
+        TRY(eng_next_event(e, &ev));
+        HIP_TRY(hipEventRecord(ev, e.stream));
+        HIP_TRY(hipStreamWaitEvent(e.heads, ev, 0));
+        hscope.enter();
+    } else if (e.heads_pending) {  // mode switch without a sync in between: an earlier pipelined heads phase writes the same buffers
+        HIP_TRY(hipStreamWaitEvent(e.stream, e.heads_done, 0));
+        e.heads_pending = false;
+    }
     // FPN: the three laterals are independent; so are the three prediction convs
     Tensor l5, l4, l3, x4f, x3f, P[5];
     TRY(eng_fork(e, 0));
@@ -311,6 +338,7 @@ int yolact_forward(Engine& e, const float* d_images, int N) {
     TRY(eng_conv(e, "fpn.lat_layers.0", C5, 1, 0, 0, nullptr, "fpn.lat5", &l5));
     TRY(eng_join(e, 0));
     TRY(eng_join(e, 1));
+    if (pipe) { HIP_TRY(hipEventRecord(e.lat_done, e.stream)); e.lat_pending = true; }
     TRY(eng_act(e, "fpn.x4", N, l4.H, l4.W, l4.C, &x4f, dt));
     if (dt) TRY(resize_bilinear_f16_launch(l5.d, N, l5.H, l5.W, l5.C, l4.H, l4.W, l4.d, 0, x4f.d, e.cur));
     else TRY(resize_bilinear_launch(l5.d, N, l5.H, l5.W, l5.C, l4.H, l4.W, l4.d, 0, x4f.d, e.cur));
@@ -436,6 +464,7 @@ int yolact_forward(Engine& e, const float* d_images, int N) {
         ds = e.tail;
     }
     TRY(yolact_detect_launch(&a, ds));
+    if (pipe) { HIP_TRY(hipEventRecord(e.heads_done, e.stream)); e.heads_pending = true; }
     TRY(eng_tail_end(e));
     eng_mark(e, "detect");
     return ISEGMI_OK;
@@ -498,6 +527,10 @@ extern "C" int isegmi_engine_create(int model_kind, int max_batch, int H, int W,
     if (er != hipSuccess) { set_error(std::string("hipStreamCreate: ") + hipGetErrorString(er)); delete h; return ISEGMI_ERR_HIP; }
     if (er == hipSuccess) er = hipStreamCreateWithFlags(&h->e.tail, hipStreamNonBlocking);
     if (er == hipSuccess) er = hipEventCreateWithFlags(&h->e.tail_done, hipEventDisableTiming);
+    if (er == hipSuccess) er = hipStreamCreateWithFlags(&h->e.heads, hipStreamNonBlocking);
+    for (int i = 0; i < 3 && er == hipSuccess; ++i) er = hipStreamCreateWithFlags(&h->e.hside[i], hipStreamNonBlocking);
+    if (er == hipSuccess) er = hipEventCreateWithFlags(&h->e.lat_done, hipEventDisableTiming);
+    if (er == hipSuccess) er = hipEventCreateWithFlags(&h->e.heads_done, hipEventDisableTiming);
     if (er != hipSuccess) { set_error(std::string("tail stream: ") + hipGetErrorString(er)); delete h; return ISEGMI_ERR_HIP; }
     h->e.cur = h->e.stream;
     *out = h;
@@ -509,8 +542,13 @@ extern "C" int isegmi_engine_destroy(isegmi_engine* h) {
     Engine& e = h->e;
     (void)hipStreamSynchronize(e.stream);
     eng_graph_reset(e);
+    if (e.heads) { (void)hipStreamSynchronize(e.heads); }
     if (e.tail) { (void)hipStreamSynchronize(e.tail); (void)hipStreamDestroy(e.tail); }
     if (e.tail_done) (void)hipEventDestroy(e.tail_done);
+    for (int i = 0; i < 3; ++i) if (e.hside[i]) (void)hipStreamDestroy(e.hside[i]);
+    if (e.heads) (void)hipStreamDestroy(e.heads);
+    if (e.lat_done) (void)hipEventDestroy(e.lat_done);
+    if (e.heads_done) (void)hipEventDestroy(e.heads_done);
     for (auto& kv : e.convs) { (void)hipFree(kv.second.d_w); if (kv.second.d_scale) (void)hipFree(kv.second.d_scale); if (kv.second.d_shift) (void)hipFree(kv.second.d_shift); }
     for (auto& kv : e.tensors) (void)hipFree(kv.second.d);
     for (auto& kv : e.bufs) (void)hipFree(kv.second.d);
@@ -606,8 +644,11 @@ extern "C" int isegmi_yolact_postprocess(isegmi_engine* h, int out_h, int out_w)
 extern "C" int isegmi_engine_sync(isegmi_engine* h) {
     ARG_CHECK(h, "null");
     HIP_TRY(hipStreamSynchronize(h->e.stream));
+    if (h->e.heads) HIP_TRY(hipStreamSynchronize(h->e.heads));
     if (h->e.tail) HIP_TRY(hipStreamSynchronize(h->e.tail));
     h->e.tail_pending = false;
+    h->e.lat_pending = false;
+    h->e.heads_pending = false;
     collect_times(h->e);
     return ISEGMI_OK;
 }

@@ -46,6 +46,15 @@ struct Engine {
     hipStream_t tail = nullptr;            // Yolact Detect + postprocess: latency-bound tail, overlapped with the NEXT forward's backbone
     hipEvent_t tail_done = nullptr;        // recorded after the last tail launch; the next forward's head/proto writers wait on it
     bool tail_pending = false;
+    // Yolact cross-step pipelining: FPN + protonet + prediction heads of step i run on their own stream group while step i+1's
+    // backbone already runs on the main stream (the backbone chain of mid-size layers leaves CUs idle that the heads' large
+    // layers fill).  lat_done fences the only backbone buffers the heads phase reads (C3-C5, by the lateral convs).
+    hipStream_t heads = nullptr;
+    hipStream_t hside[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t lat_done = nullptr;
+    bool lat_pending = false;
+    hipEvent_t heads_done = nullptr;       // end of the last pipelined heads phase (a non-pipelined forward's heads phase waits on it)
+    bool heads_pending = false;
     bool multi_stream = true;
     // hipGraph replay of a forward ("graph" param): the ~130-150 launches of one forward are captured once per
     // (entry, batch, input pointer) and replayed with one hipGraphLaunch -- removes the per-launch gaps that bound bs=1

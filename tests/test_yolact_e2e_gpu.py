@@ -208,6 +208,37 @@ def test_yolact_smooth_images_bit_exact(ffi, sd):
     net.close()
 
 
+def test_yolact_pipelined_heads_back_to_back(ffi, sd):
+    """Cross-step pipelining ("pipeline_heads", default on): FPN + protonet + heads of forward i run on their own streams while
+    forward i+1's backbone is already running.  Several forwards enqueued back to back without a sync, on CHANGING inputs,
+    must leave exactly the results of the last input computed alone (fences: C3-C5 vs the lateral convs, head buffers vs the
+    previous Detect / postprocess), and switching the mode off without a sync in between must be safe too."""
+    from isegmi.yolact import Yolact
+    size = 200
+    keys = ("det.count", "det.score", "det.prior", "det.box", "det.class", "det.masks", "proto")
+    xs = [_images(300 + i, 2, size) for i in range(4)]
+    net = Yolact(sd, max_batch=2, input_size=size)
+    net.set_param("pipeline_heads", 0.0)
+    net.upload(xs[3]); net.forward_device(2); net.postprocess_device(size, size); net.sync()
+    want = {k: net.fetch(k, 2) for k in keys}
+    assert int(want["det.count"].sum()) > 0
+    net.set_param("pipeline_heads", 1.0)
+    for rep in range(2):
+        for x in xs:
+            net.upload(x); net.forward_device(2); net.postprocess_device(size, size)
+        net.sync()
+        for k in keys:
+            assert np.array_equal(net.fetch(k, 2), want[k]), (rep, k)
+    # pipelined forwards on other inputs, then WITHOUT a sync a non-pipelined one on the reference input
+    for x in xs[:3]:
+        net.upload(x); net.forward_device(2); net.postprocess_device(size, size)
+    net.set_param("pipeline_heads", 0.0)
+    net.upload(xs[3]); net.forward_device(2); net.postprocess_device(size, size); net.sync()
+    for k in keys:
+        assert np.array_equal(net.fetch(k, 2), want[k]), ("switch", k)
+    net.close()
+
+
 def test_yolact_hipgraph_replay_matches_eager(ffi, sd):
     """"graph" param: the forward is captured into a hipGraph on its second call and replayed afterwards; results must
     equal the eager multi-stream path bit for bit, also after the input buffer's CONTENT changes (same pointer) and
