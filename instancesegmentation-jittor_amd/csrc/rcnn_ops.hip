@@ -584,15 +584,40 @@ __global__ void avgpool_full_kernel(const float* __restrict__ x, int64_t R, int 
 }
 
 // ------------------------------------------------------------------ box head post-processing
-__global__ void softmax_rows_kernel(const float* __restrict__ x, int64_t rows, int C, int64_t in_stride, float* __restrict__ y) {
-    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
-        const float* a = x + r * in_stride;
-        float* o = y + r * C;
-        float m = a[0];
-        for (int c = 1; c < C; ++c) m = a[c] > m ? a[c] : m;
-        float s = 0.0f;
-        for (int c = 0; c < C; ++c) { const float e = dm_exp(a[c] - m); o[c] = e; s = s + e; }
-        for (int c = 0; c < C; ++c) o[c] = dm_div(o[c], s);
+// One wave per row (C <= 320): the exponentials and the final divisions run across the lanes; the max is order-free; the SUM
+// keeps the oracle's sequential order (s = ((e0 + e1) + e2) + ...), every lane adding the row's exponentials from LDS in
+// class order.  (One thread per row left 2000-row problems on 32 waves: 60 us.)
+constexpr int SOFTMAX_MAXC = 320;
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, int64_t rows, int C, int64_t in_stride,
+                                                           float* __restrict__ y) {
+    __shared__ float ex[4][SOFTMAX_MAXC];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+    if (r >= rows) return;  // whole wave; no block barrier below
+    const float* a = x + r * in_stride;
+    float* o = y + r * C;
+    float v[SOFTMAX_MAXC / 64];
+    float m = -3.0e38f;
+#pragma unroll
+    for (int q = 0; q < SOFTMAX_MAXC / 64; ++q) {
+        const int c = lane + 64 * q;
+        v[q] = c < C ? a[c] : -3.0e38f;
+        m = v[q] > m ? v[q] : m;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const float t = __shfl_xor(m, off, 64); m = t > m ? t : m; }
+#pragma unroll
+    for (int q = 0; q < SOFTMAX_MAXC / 64; ++q) {
+        const int c = lane + 64 * q;
+        if (c < C) { v[q] = dm_exp(v[q] - m); ex[wave][c] = v[q]; }
+    }
+    __builtin_amdgcn_wave_barrier();
+    float sum = 0.0f;
+    for (int c = 0; c < C; ++c) sum = sum + ex[wave][c];
+#pragma unroll
+    for (int q = 0; q < SOFTMAX_MAXC / 64; ++q) {
+        const int c = lane + 64 * q;
+        if (c < C) o[c] = dm_div(v[q], sum);
     }
 }
 
@@ -926,7 +951,8 @@ int avgpool_full_launch(const float* x, int64_t R, int HW, int C, float* out, hi
 }
 
 int softmax_rows_launch(const float* x, int64_t rows, int C, int64_t in_stride, float* y, hipStream_t st) {
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3(grid_for(rows, 64)), dim3(64), 0, st, x, rows, C, in_stride, y);
+    ARG_CHECK(C >= 1 && C <= SOFTMAX_MAXC, "softmax width (<= 320 classes)");
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, rows, C, in_stride, y);
     HIP_TRY(hipGetLastError());
     return ISEGMI_OK;
 }
