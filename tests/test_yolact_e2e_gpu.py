@@ -124,17 +124,14 @@ def test_back_to_back_forwards_are_independent(ffi, sd):
 
 
 def test_yolact_base_and_im700_configs_bit_exact(ffi):
-    """yolact_base (ResNet101-FPN) and yolact_im700 (R101, 700 px, scales int(s/550*700)).
-    Small input for the R101/700-config pair (oracle time), then the full 700x700 image."""
+    """yolact_base (ResNet101-FPN) and yolact_im700 (R101, 700 px, scales int(s/550*700)) on the full 700x700
+    image (the ResNet101 backbone at a small input is covered by the YOLACT++ and Mask R-CNN R101 tests)."""
     from isegmi.weights import yolact_state_dict
     from isegmi.yolact import Yolact, YolactConfig, postprocess
     sd101 = yolact_state_dict(1234, depth=101)
     cfg = YolactConfig.im700()
     assert cfg.pred_scales == (30, 61, 122, 244, 488) and cfg.max_size == 700 and cfg.depth == 101
-    net = Yolact(sd101, cfg, max_batch=1, input_size=200)
     ref = YolactRef(sd101, max_size=700, scales=cfg.pred_scales, depth=101)
-    _compare(net, ref, _images(3, 1, 200), 200, 1)
-    net.close()
     net = Yolact(sd101, cfg, max_batch=1)
     assert net.size == 700 and net.priors.shape == (30963, 4)
     x = _images(4, 1, 700)
@@ -154,15 +151,16 @@ def test_yolact_plus_dcn_backbones_bit_exact(ffi):
     assert len(dcn_blocks(50, (0, 4, 6, 3), 1)) == 13
     for cfg, size in ((YolactConfig.plus_resnet50(), 200), (YolactConfig.plus_base(), 136)):
         sd = yolact_state_dict(77, depth=cfg.depth, num_priors=9, dcn_layers=cfg.dcn_layers, dcn_interval=cfg.dcn_interval)
-        net = Yolact(sd, cfg, max_batch=2, input_size=size)
+        nb = 2 if cfg.depth == 50 else 1  # (oracle time: the ResNet101 pass runs one image)
+        net = Yolact(sd, cfg, max_batch=nb, input_size=size)
         assert net.priors.shape[1] == 4 and net.priors.shape[0] % 9 == 0
         ref = YolactRef(sd, max_size=550, depth=cfg.depth, scales_per_level=3, square=False)
-        x = _images(5 + size, 2, size)
-        out, refd, total = _compare(net, ref, x, size, 2)
+        x = _images(5 + size, nb, size)
+        out, refd, total = _compare(net, ref, x, size, nb)
         assert np.array_equal(net.priors, ref.feats["priors"])
         assert total > 0
         # one deformable block in detail: offsets / mask logits, sampled columns
-        om = net.fetch("backbone.layers.1.0.om", 2)
+        om = net.fetch("backbone.layers.1.0.om", nb)
         assert om.shape[-1] == 27 and float(np.abs(om[..., :18]).mean()) > 0.05  # the synthetic offsets are not all ~0
         cls, sc, boxes, masks = postprocess(out, size, size)
         rc, rs, rb, rm = YolactRef.postprocess(refd[0], size, size)
