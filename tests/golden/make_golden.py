@@ -4,7 +4,7 @@ PROVENANCE: the reference (Jittor/InstanceSegmentation-jittor) holds no runnable
 golden vectors for this path (SURVEY.md sections 0, 4, 8c), so these vectors come from THIS repo's CPU
 oracle (oracle/ora_ops.c, SURVEY App. A revision 2026-10-03) plus hand-derived known-answer
 cases.  They certify HIP == CPU restatement, not == Jittor ("parity unpinned").
-Run:  python tests/golden/make_golden.py
+Run:  python tests/golden/make_golden.py [name ...]   (no names = all fixtures)
 """
 import os
 import sys
@@ -58,7 +58,15 @@ def main():
     m28 = rng.uniform(0, 1, (5, 28, 28)).astype(np.float32)
     pb = np.array([[10.2, 20.7, 80.1, 90.9], [-12.5, -3.0, 30.0, 44.4], [100, 50, 159.5, 119.2], [40, 40, 40.3, 40.2], [0, 0, 159, 119]], np.float32)
     g["paste"] = dict(masks=m28, boxes=pb, out=np.packbits(ora.paste_masks(m28, pb, 120, 160)))
+    # DCNv2 sampling stage (YOLACT++ backbones): own generator so that the fixtures above stay byte-stable
+    r2 = np.random.default_rng(20261004)
+    xd = r2.standard_normal((1, 9, 11, 8)).astype(np.float32)
+    omd = r2.normal(0, 2.0, (1, 5, 6, 27)).astype(np.float32); omd[0, 0, :, :18] = np.round(omd[0, 0, :, :18])
+    g["deform"] = dict(x=xd, om=omd, col=ora.deform_im2col(xd, omd, 3, 3, 2, 1, 1))
+    only = sys.argv[1:]
     for k, v in g.items():
+        if only and k not in only:
+            continue
         np.savez_compressed(os.path.join(HERE, k + ".npz"), **v)
         print(k, {a: getattr(b, "shape", None) for a, b in v.items()})
 

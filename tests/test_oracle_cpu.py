@@ -182,7 +182,7 @@ def test_box_postprocess_kth_value_cut():
     assert np.array_equal(s, s2[s2 >= thr])
 
 
-@pytest.mark.parametrize("name", ["conv", "conv1x1s2", "detmath", "nms", "roi_align", "yolact", "paste"])
+@pytest.mark.parametrize("name", ["conv", "conv1x1s2", "detmath", "nms", "roi_align", "yolact", "paste", "deform"])
 def test_oracle_reproduces_golden(name):
     g = gold(name)
     if name == "conv":
@@ -209,3 +209,5 @@ def test_oracle_reproduces_golden(name):
         assert np.array_equal(np.packbits(mm), g["masks"]) and np.array_equal(ib, g["int_boxes"])
     elif name == "paste":
         assert np.array_equal(np.packbits(ora.paste_masks(g["masks"], g["boxes"], 120, 160)), g["out"])
+    elif name == "deform":
+        assert np.array_equal(ora.deform_im2col(g["x"], g["om"], 3, 3, 2, 1, 1), g["col"])
