@@ -1,0 +1,82 @@
+"""Randomised HIP-vs-oracle parity sweep over the kernels with the most intricate control flow (dev tool, GPU):
+16x16x4 / 32x64 conv tiles on random shapes, chip-wide and single-block RPN NMS, per-class box NMS with crowded classes,
+top-k at random sizes.  Prints one line per family; exits non-zero on the first mismatch."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path[:0] = [ROOT, os.path.join(ROOT, "instancesegmentation-jittor_amd")]
+import numpy as np
+from isegmi import _ffi as ffi
+from isegmi.maskrcnn import generate_anchors, grid_anchors
+from oracle import ora
+
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+rng = np.random.default_rng(seed)
+
+def fail(msg):
+    print("MISMATCH", msg); sys.exit(1)
+
+# ---- conv, forced tiles
+for it in range(rounds):
+    N = int(rng.integers(1, 3)); H = int(rng.integers(3, 40)); W = int(rng.integers(3, 40))
+    Cin = 32 * int(rng.integers(1, 5)); Cout = int(rng.choice([5, 16, 31, 32, 33, 64, 65, 96, 130, 200]))
+    R = int(rng.choice([1, 3])); stride = int(rng.choice([1, 2])); pad = R // 2 if rng.uniform() < 0.8 else 0
+    if H + 2 * pad < R or W + 2 * pad < R: continue
+    x = rng.standard_normal((N, H, W, Cin)).astype(np.float32); w = (rng.standard_normal((Cout, R, R, Cin)) * 0.1).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, Cout).astype(np.float32); sh = rng.standard_normal(Cout).astype(np.float32)
+    Ho = (H + 2 * pad - R) // stride + 1; Wo = (W + 2 * pad - R) // stride + 1
+    res = rng.standard_normal((N, Ho, Wo, Cout)).astype(np.float32) if rng.uniform() < 0.5 else None
+    act = int(rng.integers(0, 3))
+    ref = ora.conv2d(x, w, stride, pad, sc, sh, res, act)
+    for tile in (0, 3, 4, 5, 6):
+        got = ffi.conv2d(x, w, stride, pad, sc, sh, res, act, tile)
+        if not np.array_equal(got, ref): fail(("conv", it, tile, x.shape, w.shape, stride, pad, act))
+print("conv ok", rounds)
+
+# ---- RPN level: chip-wide vs single-block vs oracle
+for it in range(rounds):
+    N = int(rng.integers(1, 3)); H = int(rng.integers(6, 44)); W = int(rng.integers(6, 60)); A = 3
+    head = np.concatenate([rng.normal(-2, 2, (N, H, W, A)), rng.normal(0, rng.choice([0.02, 0.3, 1.0]), (N, H, W, 4 * A))], -1).astype(np.float32)
+    if rng.uniform() < 0.5: head[0, : H // 2, : W // 2, :A] = 1.0
+    anchors = grid_anchors(H, W, 8, generate_anchors(8, int(rng.choice([32, 64, 128])), (0.5, 1.0, 2.0)))
+    hw = np.array([[H * 8 - int(rng.integers(0, 8)), W * 8 - int(rng.integers(0, 8))] for _ in range(N)], np.int32)
+    pre = int(rng.choice([17, 64, 65, 128, 300, 640, 1000, 1024])); post = int(rng.integers(1, pre + 1))
+    ms = float(rng.choice([0.0, 0.0, 16.0, 40.0]))
+    for cw in (True, False):
+        got = ffi.rpn_level(head, anchors, hw, A, pre, post, min_size=ms, chip_wide=cw)
+        for n in range(N):
+            rb, rs = ora.rpn_level(head[n, ..., :A].reshape(-1), head[n, ..., A:].reshape(-1, 4), anchors, pre, post, 0.7, ms, float(hw[n, 1]), float(hw[n, 0]))
+            if not (np.array_equal(got[n][1], rs) and np.array_equal(got[n][0], rb)): fail(("rpn", it, cw, H, W, pre, post, ms, n))
+print("rpn ok", rounds)
+
+# ---- box post-processing with crowded classes
+def boxes(n, Wd=1333, Hd=800):
+    c = rng.uniform(0, 1, (n, 2)) * [Wd, Hd]
+    c[n // 2:] = c[: n - n // 2] + rng.normal(0, rng.choice([1.0, 6.0, 30.0]), (n - n // 2, 2))
+    wh = np.exp(rng.uniform(np.log(16), np.log(512), (n, 2)))
+    return np.clip(np.concatenate([c - wh / 2, c + wh / 2], 1), 0, [Wd - 1, Hd - 1, Wd - 1, Hd - 1]).astype(np.float32)
+for it in range(max(rounds // 3, 4)):
+    N, R, ncls = 2, int(rng.choice([200, 700, 1000])), 81
+    logits = rng.normal(0, 1.0, (N, R, ncls)).astype(np.float32); logits[..., 0] += float(rng.choice([1.0, 2.0, 4.0]))
+    hot = rng.choice(np.arange(1, ncls), 3, replace=False); logits[..., hot] += float(rng.choice([1.5, 2.5, 4.0]))
+    regr = (rng.normal(0, float(rng.choice([0.02, 0.5])), (N, R, 4 * ncls))).astype(np.float32)
+    props = np.stack([boxes(R) for _ in range(N)])
+    cnt = np.array([R, int(rng.integers(1, R + 1))], np.int32)
+    hw = np.array([[800, 1333], [750, 1200]], np.int32)
+    got = ffi.box_postprocess(logits, regr, props, cnt, hw)
+    for n in range(N):
+        k = cnt[n]
+        rb, rs, rl = ora.box_postprocess(logits[n, :k], regr[n, :k], props[n, :k], float(hw[n, 1]), float(hw[n, 0]), cap=100)
+        if not (np.array_equal(got[n][2], rl) and np.array_equal(got[n][1], rs) and np.array_equal(got[n][0], rb)): fail(("boxpost", it, R, n))
+print("box_postprocess ok", max(rounds // 3, 4))
+
+# ---- top-k
+for it in range(rounds):
+    rows = int(rng.choice([1, 2, 5, 80, 300])); n = int(rng.choice([50, 777, 4096, 9000, 19248, 70000])); k = int(rng.choice([1, 100, 128, 200, 256, 1000, 1024]))
+    if rows * n > 6_000_000: rows = 2
+    keys = rng.uniform(0, 1, (rows, n)).astype(np.float32)
+    if rng.uniform() < 0.5: keys = np.round(keys * 50) / 50  # heavy ties
+    vals, idx, cnt = ffi.topk(keys, k)
+    for r in range(min(rows, 6)):
+        s, i = ora.topk(keys[r], k)
+        if not (cnt[r] == len(s) and np.array_equal(idx[r, : cnt[r]], i) and np.array_equal(vals[r, : cnt[r]], s)): fail(("topk", it, rows, n, k, r))
+print("topk ok", rounds)
