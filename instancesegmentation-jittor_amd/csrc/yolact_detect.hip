@@ -121,29 +121,35 @@ __device__ __forceinline__ float jaccard(const float4 a, const float4 b) {
 }
 
 // grid (ncls_fg, N); block 256. topk_idx/vals: [N][nc][top_k]; cnt: [N][nc].
-__global__ __launch_bounds__(256) void yolact_fast_nms_kernel(const float* __restrict__ boxes, const float* __restrict__ tk_vals,
-                                                               const int* __restrict__ tk_idx, const int* __restrict__ tk_cnt,
-                                                               int P, int nc, int top_k, float thr,
-                                                               float* __restrict__ cand, int* __restrict__ kept_count) {
+// Four threads per box (tid = part * 256 + j): "no earlier box of the class overlaps box j by more than thr" is an AND over the
+// earlier boxes, so each part tests every fourth one and the verdicts are combined in LDS -- a 4x shorter dependent chain than
+// one thread walking up to 199 IEEE divisions (31 -> ~15 us on one image's 80 class blocks).
+__global__ __launch_bounds__(1024) void yolact_fast_nms_kernel(const float* __restrict__ boxes, const float* __restrict__ tk_vals,
+                                                                const int* __restrict__ tk_idx, const int* __restrict__ tk_cnt,
+                                                                int P, int nc, int top_k, float thr,
+                                                                float* __restrict__ cand, int* __restrict__ kept_count) {
     __shared__ float4 sb[256];
+    __shared__ unsigned char okp[4][256];
     const int c = blockIdx.x, n = blockIdx.y;
     const int base = (n * nc + c) * top_k;
     const int cnt = tk_cnt[n * nc + c];
-    const int j = threadIdx.x;
-    if (j < cnt) sb[j] = *(const float4*)(boxes + ((int64_t)n * P + tk_idx[base + j]) * 4);
+    const int j = threadIdx.x & 255, part = threadIdx.x >> 8;
+    if (part == 0 && j < cnt) sb[j] = *(const float4*)(boxes + ((int64_t)n * P + tk_idx[base + j]) * 4);
     __syncthreads();
-    bool keep = false;
+    bool ok = true;
     if (j < cnt) {
-        keep = true;
         const float4 bj = sb[j];
-        for (int i = 0; i < j; ++i) {
+        for (int i = part; i < j; i += 4) {
             const float o = jaccard(sb[i], bj);
-            if (!(o <= thr)) { keep = false; break; }
+            if (!(o <= thr)) { ok = false; break; }
         }
     }
-    if (j < top_k) cand[base + j] = keep ? tk_vals[base + j] : -1.0f;
+    okp[part][j] = ok ? 1 : 0;
+    __syncthreads();
+    const bool keep = part == 0 && j < cnt && okp[0][j] && okp[1][j] && okp[2][j] && okp[3][j];
+    if (part == 0 && j < top_k) cand[base + j] = keep ? tk_vals[base + j] : -1.0f;
     const int k = __syncthreads_count(keep ? 1 : 0);
-    if (j == 0 && k) atomicAdd(&kept_count[n], k);
+    if (threadIdx.x == 0 && k) atomicAdd(&kept_count[n], k);
 }
 
 // grid (N); block 128: one thread per output slot.
@@ -330,7 +336,7 @@ int yolact_detect_launch(const isegmi_yolact_detect_args* a, hipStream_t st) {
     int rc = topk_launch(a->d_ws_scoresT, a->P, a->N * nc, a->P, a->top_k, keep_count, nc, a->d_ws_tk_vals, a->d_ws_tk_idx,
                          a->d_ws_tk_cnt, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(yolact_fast_nms_kernel, dim3(nc, a->N), dim3(256), 0, st, a->d_ws_boxes, a->d_ws_tk_vals, a->d_ws_tk_idx,
+    hipLaunchKernelGGL(yolact_fast_nms_kernel, dim3(nc, a->N), dim3(1024), 0, st, a->d_ws_boxes, a->d_ws_tk_vals, a->d_ws_tk_idx,
                        a->d_ws_tk_cnt, a->P, nc, a->top_k, a->nms_thresh, a->d_ws_cand, kept2);
     HIP_TRY(hipGetLastError());
     rc = topk_launch(a->d_ws_cand, (int64_t)nc * a->top_k, a->N, nc * a->top_k, a->max_det, kept2, 1, a->d_ws_fin_vals,
