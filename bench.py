@@ -370,7 +370,7 @@ def main_maskrcnn(a):
                           "proposals_per_image": [int(c) for c in pc], "detections_per_image": [int(c) for c in cnt]},
                "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel + conv_mfma16_kernel (all conv launches of a step)",
                             "pass": "K single-stream steps right after the timed region, HIP events around every conv launch", "achieved": round(achieved, 2),
-                            "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": pmc_traffic("r01_pmc_r101f16.json") if (a.fp16 and a.depth == 101 and a.batch == 8) else None if (a.fp16 or a.depth != 50 or a.batch != 2) else pmc_traffic("r01_pmc_maskrcnn.json"),
+                            "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": pmc_traffic("r01_pmc_r101f16.json") if (a.fp16 and a.depth == 101 and a.batch == 8 and not a.c4) else None if (a.fp16 or a.c4 or a.depth != 50 or a.batch != 2) else pmc_traffic("r01_pmc_maskrcnn.json"),
                             "traffic_note": "HBM bytes per conv launch from separate rocprofv3 --pmc passes of this command (tools/profile_round.sh -> profiles/r01_pmc_maskrcnn.json / r01_pmc_r101f16.json; FETCH x2 gfx950 correction); not collected live; null for configurations without a committed PMC pass",
                             "algorithmic_gflop_per_step": round(f.value / a.steps / 1e9, 2), "conv_ms_per_step": round(m.value / a.steps, 3),
                             "launches_per_step": l.value // a.steps, "avg_launch_us": round(m.value * 1e3 / max(l.value, 1), 2)},
