@@ -24,6 +24,38 @@ def test_yolact_priors_match_oracle_and_count():
     assert tot == 19248
 
 
+def test_yolact_plus_config_priors_dcn_blocks_and_weights():
+    """YOLACT++ host logic: nine rectangular anchors per cell in scale-major / ratio-minor order (57 744 priors at 550 px), the
+    upstream _make_layer rule for which bottlenecks carry a DCNv2 3x3, and the synthetic state dict's upstream names / shapes."""
+    from isegmi.weights import dcn_blocks, yolact_state_dict
+    from isegmi.yolact import YolactConfig, _level_sizes, make_priors
+    from oracle.yolact_ref import make_priors as ref_priors
+    cfg = YolactConfig.plus_base()
+    assert cfg.num_priors == 9 and not cfg.use_square_anchors and cfg.use_maskiou and cfg.depth == 101
+    tot = 0
+    for l, s in enumerate(_level_sizes(550)):
+        sc = cfg.level_scales(l)
+        assert len(sc) == 3 and sc[0] == cfg.pred_scales[l] and abs(sc[2] / sc[0] - 2 ** (2 / 3.0)) < 1e-12
+        a = make_priors(s, s, sc, cfg.max_size, cfg.pred_aspect_ratios, square=False)
+        b = ref_priors(s, s, sc, cfg.max_size, square=False)
+        assert np.array_equal(a, b)
+        tot += len(a)
+    assert tot == 57744
+    first = make_priors(2, 2, (24.0, 30.0), 550, (1.0, 0.5, 2.0), square=False)[:6]
+    assert np.allclose(first[:, 2] / first[:, 3], [1.0, 0.5, 2.0, 1.0, 0.5, 2.0])  # w/h = aspect ratio, ratios inside scales
+    assert np.allclose(first[[0, 3], 2] * 550, [24.0, 30.0])
+    # resnet101_dcn_inter3_backbone: first block of layers 2-4 and every third after it; resnet50_dcnv2_backbone: all of layers 2-4
+    assert sorted(dcn_blocks(101, (0, 4, 23, 3), 3)) == [(1, 0), (1, 3)] + [(2, b) for b in range(0, 23, 3)] + [(3, 0)]
+    assert sorted(dcn_blocks(50, (0, 4, 6, 3), 1)) == [(1, b) for b in range(4)] + [(2, b) for b in range(6)] + [(3, b) for b in range(3)]
+    assert dcn_blocks(50, (0, 0, 0, 0), 1) == set()
+    c50 = YolactConfig.plus_resnet50()
+    sd = yolact_state_dict(5, c50.depth, c50.num_priors, c50.dcn_layers, c50.dcn_interval, True)
+    assert sd["backbone.layers.1.0.conv2.conv_offset_mask.weight"].shape == (27, 128, 3, 3)
+    assert sd["backbone.layers.3.2.conv2.bias"].shape == (512,) and "backbone.layers.0.0.conv2.bias" not in sd
+    assert sd["prediction_layers.0.conf_layer.weight"].shape == (9 * 81, 256, 3, 3)
+    assert [sd["maskiou_net.%d.weight" % i].shape[:2] for i in (0, 2, 4, 6, 8, 10)] == [(8, 1), (16, 8), (32, 16), (64, 32), (128, 64), (80, 128)]
+
+
 def test_maskrcnn_anchors_and_shapes():
     from isegmi.maskrcnn import generate_anchors, grid_anchors, level_shapes
     from oracle.maskrcnn_ref import cell_anchors, grid_anchors as ref_grid
