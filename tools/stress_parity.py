@@ -1,6 +1,7 @@
 """Randomised HIP-vs-oracle parity sweep over the kernels with the most intricate control flow (dev tool, GPU):
 16x16x4 / 32x64 conv tiles on random shapes, chip-wide and single-block RPN NMS, per-class box NMS with crowded classes,
-top-k at random sizes.  Prints one line per family; exits non-zero on the first mismatch."""
+top-k at random sizes, Yolact Detect (softmax / decode / fast-NMS / final top-k) and mask assembly, DCNv2 sampling.
+Prints one line per family; exits non-zero on the first mismatch."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path[:0] = [ROOT, os.path.join(ROOT, "instancesegmentation-jittor_amd")]
 import numpy as np
@@ -80,3 +81,52 @@ for it in range(rounds):
         s, i = ora.topk(keys[r], k)
         if not (cnt[r] == len(s) and np.array_equal(idx[r, : cnt[r]], i) and np.array_equal(vals[r, : cnt[r]], s)): fail(("topk", it, rows, n, k, r))
 print("topk ok", rounds)
+
+# ---- Yolact Detect + masks
+for it in range(max(rounds // 3, 4)):
+    N = int(rng.integers(1, 4)); P = int(rng.choice([300, 1200, 4800, 19248])); ncls = 81
+    conf = rng.standard_normal((N, P, ncls)).astype(np.float32); conf[..., 0] += float(rng.choice([2.0, 4.0, 6.0]))
+    hotm = rng.uniform(0, 1, (N, P)) < float(rng.choice([0.0, 0.01, 0.05, 0.3]))
+    cls = rng.integers(1, ncls, (N, P)) if rng.uniform() < 0.7 else np.full((N, P), 7)
+    for n in range(N):
+        idx = np.nonzero(hotm[n])[0]
+        conf[n, idx, cls[n, idx]] += float(rng.choice([5.0, 8.0]))
+    c = rng.uniform(0.05, 0.95, (P, 2)); wh = rng.uniform(0.02, 0.5, (P, 2))
+    if rng.uniform() < 0.5: c[P // 2:] = c[: P - P // 2] + rng.normal(0, 0.01, (P - P // 2, 2))
+    priors = np.concatenate([c, wh], 1).astype(np.float32)
+    loc = (rng.standard_normal((N, P, 4)) * float(rng.choice([0.1, 0.5]))).astype(np.float32)
+    mask = np.tanh(rng.standard_normal((N, P, 32))).astype(np.float32)
+    got, bx = ffi.yolact_detect(conf, loc, mask, priors)
+    for n in range(N):
+        rbx = ora.yolact_decode(loc[n], priors)
+        ref = ora.yolact_detect(ora.softmax(conf[n]), rbx, mask[n])
+        if not np.array_equal(bx[n], rbx): fail(("yolact boxes", it, n))
+        for key in ("prior", "cls", "score", "box", "mask"):
+            if not np.array_equal(got[n][key], ref[key]): fail(("yolact detect", it, N, P, n, key))
+print("yolact detect ok", max(rounds // 3, 4))
+for it in range(max(rounds // 6, 2)):
+    N, K = int(rng.integers(1, 3)), 100; PH = int(rng.choice([24, 69, 138])); h = int(rng.integers(20, 300)); w = int(rng.integers(20, 300))
+    proto = np.maximum(rng.standard_normal((N, PH, PH, 32)), 0).astype(np.float32)
+    coeffs = np.tanh(rng.standard_normal((N, K, 32))).astype(np.float32)
+    cc = rng.uniform(-0.1, 1.1, (N, K, 2)); ss = rng.uniform(0.01, 0.8, (N, K, 2))
+    boxes_ = np.concatenate([cc - ss / 2, cc + ss / 2], -1).astype(np.float32)
+    counts = rng.integers(0, K + 1, N).astype(np.int32)
+    masks, ib = ffi.yolact_masks(proto, coeffs, boxes_, counts, h, w)
+    for n in range(N):
+        k = int(counts[n])
+        if k == 0: continue
+        rm, rb = ora.yolact_masks(proto[n], coeffs[n, :k], boxes_[n, :k], h, w)
+        if not (np.array_equal(masks[n, :k], rm) and np.array_equal(ib[n, :k], rb)): fail(("yolact masks", it, n, PH, h, w))
+print("yolact masks ok", max(rounds // 6, 2))
+
+# ---- DCNv2 sampling
+for it in range(max(rounds // 3, 4)):
+    N = int(rng.integers(1, 3)); H = int(rng.integers(3, 30)); W = int(rng.integers(3, 30)); C = 4 * int(rng.integers(1, 20))
+    stride = int(rng.choice([1, 2])); dil = int(rng.choice([1, 1, 2])); pad = dil
+    Ho = (H + 2 * pad - dil * 2 - 1) // stride + 1; Wo = (W + 2 * pad - dil * 2 - 1) // stride + 1
+    if Ho < 1 or Wo < 1: continue
+    x = rng.standard_normal((N, H, W, C)).astype(np.float32)
+    om = rng.normal(0, float(rng.choice([0.3, 2.0, 8.0])), (N, Ho, Wo, 27)).astype(np.float32)
+    if rng.uniform() < 0.5: om[..., :18] = np.round(om[..., :18] * 2) / 2
+    if not np.array_equal(ffi.deform_im2col(x, om, 3, 3, stride, pad, dil), ora.deform_im2col(x, om, 3, 3, stride, pad, dil)): fail(("deform", it, x.shape, stride, dil))
+print("deform_im2col ok", max(rounds // 3, 4))
