@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--depth", type=int, default=50, choices=[50, 101], help="maskrcnn: ResNet depth")
     ap.add_argument("--fp16", action="store_true", help="fp16 storage + f16 MFMA convs: maskrcnn = BASELINE configs[4]; yolact = optional mode (the headline configs[1] is fp32: default)")
     ap.add_argument("--c4", action="store_true", help="maskrcnn: the R-50-C4 config (README.md:263-273) instead of R-50/101-FPN")
-    ap.add_argument("--yolact-config", default="resnet50", choices=["resnet50", "base", "im700", "plus_resnet50", "plus_base"],
+    ap.add_argument("--yolact-config", default="resnet50", choices=["resnet50", "base", "im700", "plus_resnet50", "plus_base", "darknet53"],
                     help="yolact: which upstream config (the headline configs[1] is resnet50: default); plus_* = YOLACT++ (DCNv2 backbone, 9 anchors, mask re-scoring)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8, help="images the CPU oracle is timed on")
@@ -100,17 +100,23 @@ def main():
         raise SystemExit("no HIP device visible: bench.py measures the HIP path only (no CPU fallback)")
     from isegmi.yolact import YolactConfig
     ycfg = {"resnet50": YolactConfig(), "base": YolactConfig.base(), "im700": YolactConfig.im700(),
-            "plus_resnet50": YolactConfig.plus_resnet50(), "plus_base": YolactConfig.plus_base()}[a.yolact_config]
+            "plus_resnet50": YolactConfig.plus_resnet50(), "plus_base": YolactConfig.plus_base(), "darknet53": YolactConfig.darknet53()}[a.yolact_config]
     yname = {"resnet50": "Yolact R50-FPN", "base": "Yolact R101-FPN (yolact_base)", "im700": "Yolact R101-FPN 700 (yolact_im700)",
-             "plus_resnet50": "YOLACT++ R50-FPN (DCNv2, 9 anchors, mask re-scoring)", "plus_base": "YOLACT++ R101-FPN (DCNv2 every 3rd block, 9 anchors, mask re-scoring)"}[a.yolact_config]
-    sd = yolact_state_dict(1234, ycfg.depth, ycfg.num_priors, ycfg.dcn_layers, ycfg.dcn_interval, ycfg.use_maskiou)
+             "plus_resnet50": "YOLACT++ R50-FPN (DCNv2, 9 anchors, mask re-scoring)", "plus_base": "YOLACT++ R101-FPN (DCNv2 every 3rd block, 9 anchors, mask re-scoring)",
+             "darknet53": "Yolact Darknet53-FPN (yolact_darknet53)"}[a.yolact_config]
+    sd = yolact_state_dict(1234, ycfg.depth, ycfg.num_priors, ycfg.dcn_layers, ycfg.dcn_interval, ycfg.use_maskiou, ycfg.backbone)
     net = Yolact(sd, ycfg, max_batch=a.batch, device=local_rank, fp16=a.fp16)
     ypeak = 2500.0 if a.fp16 else PEAK_F32_MFMA_TFLOPS
     if a.single_stream:
         net.set_param("multi_stream", 0.0)
     size = net.size
     rng = np.random.default_rng(20261003 + rank)
-    imgs = fast_base_transform(rng.uniform(0, 255, (a.batch, size, size, 3)).astype(np.float32))
+    raw = rng.uniform(0, 255, (a.batch, size, size, 3)).astype(np.float32)
+    if ycfg.backbone == "darknet53":
+        from isegmi.yolact import darknet_base_transform
+        imgs = darknet_base_transform(raw)
+    else:
+        imgs = fast_base_transform(raw)
     net.upload(imgs)
 
     gather = None

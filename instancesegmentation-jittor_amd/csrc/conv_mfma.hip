@@ -237,8 +237,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 float y = fmaf(acc[a][b][e], sc, sh);
+                if (p.act == 4) {  // DarkNet block: LeakyReLU(0.1) FIRST, then the shortcut
+                    y = y > 0.0f ? y : y * 0.1f;
+                    yv[e] = y + rv[e];
+                    continue;
+                }
                 y = y + rv[e];            // rv is +0 without a residual: y + 0 == y for every y we can produce
-                yv[e] = p.act == 1 ? (y > 0.0f ? y : 0.0f) : y;
+                yv[e] = p.act == 1 ? (y > 0.0f ? y : 0.0f) : (p.act == 3 ? (y > 0.0f ? y : y * 0.1f) : y);
             }
             if (p.act == 2) {  // uniform; tanh only on the Yolact coefficient head
 #pragma unroll
@@ -496,8 +501,13 @@ __global__ __launch_bounds__(LW ? 512 : 256) void conv_mfma16_kernel(const ConvK
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float y = fmaf(acc[t][e], sc, sh);
+            if (p.act == 4) {  // DarkNet block: LeakyReLU(0.1) first, then the shortcut
+                y = y > 0.0f ? y : y * 0.1f;
+                yv[e] = y + rv[e];
+                continue;
+            }
             y = y + rv[e];
-            yv[e] = p.act == 1 ? (y > 0.0f ? y : 0.0f) : y;
+            yv[e] = p.act == 1 ? (y > 0.0f ? y : 0.0f) : (p.act == 3 ? (y > 0.0f ? y : y * 0.1f) : y);
         }
         if (p.act == 2) {
 #pragma unroll
@@ -519,7 +529,7 @@ static int check_desc(const isegmi_conv_desc* d) {
               "non-positive conv geometry");
     ARG_CHECK(is_stem(d) || (d->Cin > 0 && d->Cin % 32 == 0), "Cin must be a multiple of 32 (or the Cin=4 7x7 stem)");
     ARG_CHECK(d->H + 2 * d->pad >= d->R && d->W + 2 * d->pad >= d->S, "kernel larger than padded input");
-    ARG_CHECK(d->act >= 0 && d->act <= 2, "act");
+    ARG_CHECK(d->act >= 0 && d->act <= 4, "act");
     ARG_CHECK(d->tile >= 0 && d->tile <= 6, "tile");
     return ISEGMI_OK;
 }

@@ -267,6 +267,35 @@ int yolact_forward(Engine& e, const float* d_images, int N) {
     if (dt && e.convs.count("prediction_layers.0.head_cat") == 0) { set_error("fp16 Yolact needs the fused prediction head"); return ISEGMI_ERR_STATE; }
     Tensor x4;
     Tensor s, x;
+    Tensor outs[5];
+    const bool darknet = e.param("darknet", 0.0f) != 0.0f;  // yolact_darknet53_config: DarkNetBackbone([1, 2, 8, 8, 4]), selected layers 2-4
+    if (darknet) {
+        if (dt) { set_error("the Darknet53 backbone runs in fp32 only"); return ISEGMI_ERR_STATE; }
+        // _preconv: 3x3 on the 3-channel image, via a zero-padded 32-channel copy; every conv is Conv + BN + LeakyReLU(0.1), a
+        // block is 1x1 (C -> C/2) then 3x3 (C/2 -> C) with the shortcut added AFTER the activation (act 4)
+        TRY(eng_act(e, "input32", N, H, W, 32, &x4));
+        TRY(pad_c3_c32_launch(d_images, (int64_t)N * H * W, x4.d, e.cur));
+        TRY(eng_conv(e, "backbone._preconv.0", x4, 1, 1, 3, nullptr, "stem", &x));
+        eng_mark(e, "stem");
+        const int nblk[5] = {1, 2, 8, 8, 4};
+        for (int li = 0; li < 5; ++li) {
+            const std::string ln = "backbone.layers." + std::to_string(li);
+            // C3 (layer 2's output, then C4, C5) is about to be overwritten: the previous step's lateral convs must have read them
+            if (li == 2 && e.lat_pending) HIP_TRY(hipStreamWaitEvent(e.stream, e.lat_done, 0));
+            Tensor y;
+            TRY(eng_conv(e, ln + ".0.0", x, 2, 1, 3, nullptr, ln + ".down", &y));
+            x = y;
+            for (int b = 1; b <= nblk[li]; ++b) {
+                const std::string nm = ln + "." + std::to_string(b);
+                Tensor t1;
+                TRY(eng_conv(e, nm + ".conv1", x, 1, 0, 3, nullptr, nm + ".t1", &t1));
+                TRY(eng_conv(e, nm + ".conv2", t1, 1, 1, 4, &x, nm + ".out", &y));
+                x = y;
+            }
+            outs[li] = x;
+            if (li >= 1) eng_mark(e, li == 1 ? "layer1" : li == 2 ? "layer2" : li == 3 ? "layer3" : "layer4");
+        }
+    } else {
     if (dt) {
         TRY(eng_act(e, "input4h", N, H + 6, (W + 7) & ~1, 4, &x4, 1));
         TRY(pad_c3_to_f16_halo_launch(d_images, N, H, W, x4.d, e.cur));
@@ -284,7 +313,6 @@ int yolact_forward(Engine& e, const float* d_images, int N) {
     }
     eng_mark(e, "stem");
     const int blocks[4] = {3, 4, (int)e.param("resnet_depth", 50) == 101 ? 23 : 6, 3};
-    Tensor outs[4];
     for (int li = 0; li < 4; ++li) {
         for (int b = 0; b < blocks[li]; ++b) {
             const std::string nm = "backbone.layers." + std::to_string(li) + "." + std::to_string(b);
@@ -318,7 +346,8 @@ int yolact_forward(Engine& e, const float* d_images, int N) {
         outs[li] = x;
         eng_mark(e, li == 0 ? "layer1" : li == 1 ? "layer2" : li == 2 ? "layer3" : "layer4");
     }
-    const Tensor C3 = outs[1], C4 = outs[2], C5 = outs[3];
+    }
+    const Tensor C3 = outs[darknet ? 2 : 1], C4 = outs[darknet ? 3 : 2], C5 = outs[darknet ? 4 : 3];
     if (pipe) {  // hand the rest of this forward to the heads stream group; the caller's next forward starts its backbone at once
         hipEvent_t ev;
         TRY(eng_next_event(e, &ev));

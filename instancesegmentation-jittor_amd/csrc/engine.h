@@ -150,6 +150,7 @@ int maskiou_rescore_launch(const float* feat, int N, int K, int HW, int C, const
 int deform_im2col_launch(const float* x, int N, int H, int W, int C, const float* om, int R, int S, int stride, int pad, int dil,
                          float* out, hipStream_t st);
 int pad_c3_c4_launch(const float* in, int64_t npix, float* out, hipStream_t st);
+int pad_c3_c32_launch(const float* in, int64_t npix, float* out, hipStream_t st);
 int topk_launch(const float* keys, int64_t row_stride, int rows, int n, int k, const int* limit, int rows_per_limit,
                 float* out_vals, int* out_idx, int* out_cnt, hipStream_t st);
 int yolact_detect_launch(const isegmi_yolact_detect_args* a, hipStream_t st);

@@ -194,6 +194,21 @@ int nearest2x_add_launch(const float* coarse, int N, int Hc, int Wc, int C, cons
     HIP_TRY(hipGetLastError());
     return ISEGMI_OK;
 }
+// NHWC C=3 -> C=32 (channels 3..31 zero): the input of a 3-channel 3x3 first layer (Darknet53's _preconv) that runs on the
+// ordinary Cin % 32 == 0 conv kernels with zero weights on the padding channels.  One thread per 16 output bytes.
+__global__ void pad_c3_c32_kernel(const float* __restrict__ in, int64_t npix, float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix * 8; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = i >> 3;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((i & 7) == 0) { const float* s = in + pix * 3; v = make_float4(s[0], s[1], s[2], 0.0f); }
+        ((float4*)out)[i] = v;
+    }
+}
+int pad_c3_c32_launch(const float* in, int64_t npix, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(pad_c3_c32_kernel, dim3(grid_for(npix * 8)), dim3(256), 0, st, in, npix, out);
+    HIP_TRY(hipGetLastError());
+    return ISEGMI_OK;
+}
 int pad_c3_c4_launch(const float* in, int64_t npix, float* out, hipStream_t st) {
     hipLaunchKernelGGL(pad_c3_c4_kernel, dim3(grid_for(npix)), dim3(256), 0, st, in, npix, out);
     HIP_TRY(hipGetLastError());

@@ -31,7 +31,7 @@ def _weights(spec, kind, depth=50, ycfg=None):
     from .weights import maskrcnn_state_dict, yolact_state_dict
     if spec in ("", "random", None):
         if kind == "yolact" and ycfg is not None:
-            return yolact_state_dict(1234, ycfg.depth, ycfg.num_priors, ycfg.dcn_layers, ycfg.dcn_interval, ycfg.use_maskiou)
+            return yolact_state_dict(1234, ycfg.depth, ycfg.num_priors, ycfg.dcn_layers, ycfg.dcn_interval, ycfg.use_maskiou, ycfg.backbone)
         return yolact_state_dict(1234, depth) if kind == "yolact" else maskrcnn_state_dict(1234, depth)
     if not spec.endswith(".npz"):
         raise SystemExit("%s: convert upstream .pth/.pkl with tools/import_pth.py first" % spec)
@@ -60,7 +60,8 @@ def cmd_eval(a):
     # upstream eval.py --config: yolact_resnet50_config (default here), yolact_base_config (R101), yolact_im700_config, and the
     # YOLACT++ pair yolact_plus_resnet50_config / yolact_plus_base_config (DCNv2 backbones, 9 anchors, mask re-scoring)
     cfg = {"yolact_resnet50_config": YolactConfig(), "yolact_base_config": YolactConfig.base(), "yolact_im700_config": YolactConfig.im700(),
-           "yolact_plus_resnet50_config": YolactConfig.plus_resnet50(), "yolact_plus_base_config": YolactConfig.plus_base()}[a.config]
+           "yolact_plus_resnet50_config": YolactConfig.plus_resnet50(), "yolact_plus_base_config": YolactConfig.plus_base(),
+           "yolact_darknet53_config": YolactConfig.darknet53()}[a.config]
     net = Yolact(_weights(a.trained_model, "yolact", cfg.depth, cfg), cfg, max_batch=1)
     jobs = []
     if a.image:
@@ -75,7 +76,7 @@ def cmd_eval(a):
     for i, (src, dst) in enumerate(jobs):
         frame = _load_image_bgr(src)
         h, w = frame.shape[:2]
-        preds = net(yolact_transform(frame, net.size))
+        preds = net(yolact_transform(frame, net.size, darknet=cfg.backbone == "darknet53"))
         classes, scores, boxes, masks = postprocess(preds, w, h, score_threshold=a.score_threshold)
         mask_scores = None
         if isinstance(scores, list):  # YOLACT++ re-scoring: [box scores, mask scores] (upstream prep_display takes scores[0])
@@ -127,7 +128,7 @@ def main(argv=None):
     sub = ap.add_subparsers(dest="cmd", required=True)
     e = sub.add_parser("eval", help="Yolact eval.py-style image evaluation")
     e.add_argument("--trained_model", default="random")
-    e.add_argument("--config", default="yolact_resnet50_config", choices=["yolact_resnet50_config", "yolact_base_config", "yolact_im700_config", "yolact_plus_resnet50_config", "yolact_plus_base_config"])
+    e.add_argument("--config", default="yolact_resnet50_config", choices=["yolact_resnet50_config", "yolact_base_config", "yolact_im700_config", "yolact_plus_resnet50_config", "yolact_plus_base_config", "yolact_darknet53_config"])
     e.add_argument("--score_threshold", type=float, default=0.0)
     e.add_argument("--top_k", type=int, default=5)
     e.add_argument("--image", default=None, help="in.png[:out.png]")

@@ -52,6 +52,8 @@ def bilinear_resize(img, oh, ow):
     return top * ly0[:, None, None] + bot * ly1[:, None, None]
 
 
-def yolact_transform(image_bgr_u8, size=550):
-    from .yolact import fast_base_transform
-    return fast_base_transform(bilinear_resize(np.asarray(image_bgr_u8, np.float32), size, size)[None])
+def yolact_transform(image_bgr_u8, size=550, darknet=False):
+    """FastBaseTransform: resize to size x size, then the backbone's transform (ResNet: mean / std; darknet=True: x / 255), RGB."""
+    from .yolact import darknet_base_transform, fast_base_transform
+    x = bilinear_resize(np.asarray(image_bgr_u8, np.float32), size, size)[None]
+    return darknet_base_transform(x) if darknet else fast_base_transform(x)

@@ -53,6 +53,21 @@ YOLACT_MASK_GAIN = 0.04
 YOLACT_PROTO_GAIN = 0.06
 
 
+def darknet53_state_dict(rng, sd, prefix="backbone."):
+    """dbolya/yolact DarkNetBackbone([1, 2, 8, 8, 4]) names: _preconv.{0,1}; layers.L.0.{0,1} = the stride-2 3x3 + BN that opens
+    a layer; layers.L.B.{conv1,bn1,conv2,bn2} = DarkNetBlock B (1x1 C -> C/2, 3x3 C/2 -> C, shortcut after the activation)."""
+    sd[prefix + "_preconv.0.weight"] = _conv(rng, 32, 3, 3); _bn(rng, sd, prefix + "_preconv.1", 32)
+    cin = 32
+    for li, nb in enumerate((1, 2, 8, 8, 4)):
+        ch = 32 << li
+        nm = prefix + "layers.%d" % li
+        sd[nm + ".0.0.weight"] = _conv(rng, ch * 2, cin, 3); _bn(rng, sd, nm + ".0.1", ch * 2)
+        cin = ch * 2
+        for b in range(1, nb + 1):
+            sd["%s.%d.conv1.weight" % (nm, b)] = _conv(rng, ch, cin, 1); _bn(rng, sd, "%s.%d.bn1" % (nm, b), ch)
+            sd["%s.%d.conv2.weight" % (nm, b)] = _conv(rng, cin, ch, 3); _bn(rng, sd, "%s.%d.bn2" % (nm, b), cin, 0.35)
+
+
 def dcn_blocks(depth, dcn_layers, dcn_interval):
     """(layer, block) pairs whose 3x3 is a DCNv2 (dbolya/yolact ResNetBackbone._make_layer: the first block of a layer when
     dcn_layers >= blocks, block i > 0 when i + dcn_layers >= blocks and i % dcn_interval == 0)."""
@@ -68,13 +83,17 @@ def dcn_blocks(depth, dcn_layers, dcn_interval):
 YOLACT_DCN_OFFSET_STD = 0.6   # synthetic conv_offset_mask outputs: offsets of about +-1 pixel, mask logits around 0
 
 
-def yolact_state_dict(seed=1234, depth=50, num_priors=3, dcn_layers=(0, 0, 0, 0), dcn_interval=1, maskiou=False):
+def yolact_state_dict(seed=1234, depth=50, num_priors=3, dcn_layers=(0, 0, 0, 0), dcn_interval=1, maskiou=False, backbone="resnet"):
     """dbolya/yolact state-dict names; depth 50 = yolact_resnet50, 101 = yolact_base / yolact_im700.
     YOLACT++ (yolact_plus_*): num_priors=9, DCNv2 3x3s per dcn_layers / dcn_interval (conv2.weight/.bias and
     conv2.conv_offset_mask.weight/.bias), maskiou=True adds maskiou_net.{0,2,4,6,8,10}."""
     rng = np.random.default_rng(seed)
     sd = {}
-    resnet_state_dict(rng, sd, "backbone.", blocks=(3, 4, 23 if depth == 101 else 6, 3))
+    if backbone == "darknet53":  # yolact_darknet53_config: C3/C4/C5 have 256/512/1024 channels
+        darknet53_state_dict(rng, sd, "backbone.")
+        dcn_layers = (0, 0, 0, 0)
+    else:
+        resnet_state_dict(rng, sd, "backbone.", blocks=(3, 4, 23 if depth == 101 else 6, 3))
     for li, b in sorted(dcn_blocks(depth, dcn_layers, dcn_interval)):
         nm = "backbone.layers.%d.%d.conv2" % (li, b)
         planes = 64 << li
@@ -82,7 +101,7 @@ def yolact_state_dict(seed=1234, depth=50, num_priors=3, dcn_layers=(0, 0, 0, 0)
         # conv1 outputs (post BN+ReLU) are O(1): a 3x3 x planes fan-in with this std gives offsets / logits of about OFFSET_STD
         sd[nm + ".conv_offset_mask.weight"] = (rng.standard_normal((27, planes, 3, 3)) * (YOLACT_DCN_OFFSET_STD / np.sqrt(9.0 * planes))).astype(np.float32)
         sd[nm + ".conv_offset_mask.bias"] = (rng.standard_normal(27) * 0.1).astype(np.float32)
-    for i, cin in enumerate((2048, 1024, 512)):
+    for i, cin in enumerate((1024, 512, 256) if backbone == "darknet53" else (2048, 1024, 512)):
         _conv_bias(rng, sd, "fpn.lat_layers.%d" % i, 256, cin, 1)
     for i in range(3):
         _conv_bias(rng, sd, "fpn.pred_layers.%d" % i, 256, 256, 3)

@@ -39,6 +39,7 @@ class YolactConfig:
     dcn_layers: tuple = (0, 0, 0, 0)
     dcn_interval: int = 1
     use_maskiou: bool = False
+    backbone: str = "resnet"           # "darknet53": yolact_darknet53_config (DarkNetBackbone([1, 2, 8, 8, 4]), LeakyReLU(0.1))
 
     @property
     def num_priors(self):
@@ -47,6 +48,12 @@ class YolactConfig:
     def level_scales(self, level):
         s = self.pred_scales[level]
         return tuple(s * 2 ** (j / 3.0) for j in range(self.scales_per_level))
+
+    @staticmethod
+    def darknet53():
+        """yolact_darknet53_config: Darknet53-FPN at 550 (same heads / anchors as the ResNet configs; upstream preprocesses with
+        darknet_transform: RGB, x / 255, no mean / std)."""
+        return YolactConfig(backbone="darknet53")
 
     @staticmethod
     def plus_base():
@@ -90,6 +97,12 @@ def make_priors(conv_h, conv_w, scales, max_size, ars, square=True):
     return out.reshape(-1, 4).astype(np.float32)
 
 
+def darknet_base_transform(images_bgr_u8):
+    """FastBaseTransform under darknet_transform (yolact_darknet53_config): x / 255, then BGR -> RGB; no mean / std.  NHWC3 fp32."""
+    x = np.asarray(images_bgr_u8, np.float32) / np.float32(255.0)
+    return np.ascontiguousarray(x[..., ::-1])
+
+
 def fast_base_transform(images_bgr_u8):
     """FastBaseTransform for already-550x550 BGR uint8 images (Y1): (x-mean)/std then BGR->RGB. NHWC3 fp32."""
     x = np.asarray(images_bgr_u8, np.float32)
@@ -128,6 +141,8 @@ class Yolact:
         _ffi.check(L.isegmi_engine_create(self.KIND, max_batch, self.size, self.size, C.byref(self._h)))
         self.set_param("resnet_depth", float(cfg.depth))
         self.set_param("num_priors", float(cfg.num_priors))
+        self.set_param("darknet", 1.0 if cfg.backbone == "darknet53" else 0.0)
+        assert not (fp16 and cfg.backbone == "darknet53"), "the Darknet53 backbone runs in fp32 only"
         assert not (fp16 and any(cfg.dcn_layers)), "the DCNv2 backbones run in fp32 only"
         if self.fp16:  # must precede weight loading (weights are packed as fp16)
             self.set_param("fp16", 1.0)
@@ -149,6 +164,22 @@ class Yolact:
 
     def _load(self, sd):
         dcn = dcn_blocks(self.cfg.depth, self.cfg.dcn_layers, self.cfg.dcn_interval)
+        if self.cfg.backbone == "darknet53":
+            sc, sh = fold_batchnorm(sd, "backbone._preconv.1")
+            self._set_conv("backbone._preconv.0", sd["backbone._preconv.0.weight"], sc, sh, pad_cin_to=32)
+            for li, nb in enumerate((1, 2, 8, 8, 4)):
+                nm = "backbone.layers.%d" % li
+                sc, sh = fold_batchnorm(sd, nm + ".0.1")
+                self._set_conv(nm + ".0.0", sd[nm + ".0.0.weight"], sc, sh)
+                for b in range(1, nb + 1):
+                    for i in (1, 2):
+                        sc, sh = fold_batchnorm(sd, "%s.%d.bn%d" % (nm, b, i))
+                        self._set_conv("%s.%d.conv%d" % (nm, b, i), sd["%s.%d.conv%d.weight" % (nm, b, i)], sc, sh)
+        else:
+            self._load_resnet(sd, dcn)
+        self._load_heads(sd)
+
+    def _load_resnet(self, sd, dcn):
         sc, sh = fold_batchnorm(sd, "backbone.bn1")
         self._set_conv("backbone.conv1", sd["backbone.conv1.weight"], sc, sh, pad_cin_to=4)
         for li, nb in enumerate((3, 4, 23 if self.cfg.depth == 101 else 6, 3)):
@@ -169,6 +200,8 @@ class Yolact:
                 if b == 0:
                     sc, sh = fold_batchnorm(sd, nm + ".downsample.1")
                     self._set_conv(nm + ".downsample.0", sd[nm + ".downsample.0.weight"], sc, sh)
+
+    def _load_heads(self, sd):
         biased = ["fpn.lat_layers.%d" % i for i in range(3)] + ["fpn.pred_layers.%d" % i for i in range(3)] + \
                  ["fpn.downsample_layers.%d" % i for i in range(2)] + ["proto_net.%d" % i for i in (0, 2, 4, 8, 10)] + \
                  ["prediction_layers.0." + n for n in ("upfeature.0", "bbox_layer", "conf_layer", "mask_layer")]

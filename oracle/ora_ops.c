@@ -200,9 +200,16 @@ ORA_API void ora_conv2d(const float* in, int N, int H, int W, int Cin,
                         for (int j = 0; j < 32 && cb + j < Cout; ++j) {
                             const int co = cb + j;
                             float y = fmaf(av[j], scale ? scale[co] : 1.0f, shift ? shift[co] : 0.0f);
+                            if (act == 4) {  /* DarkNet block: LeakyReLU(0.1) first, then the shortcut */
+                                y = y > 0.0f ? y : y * 0.1f;
+                                if (res) y = y + res[co];
+                                o[co] = y;
+                                continue;
+                            }
                             if (res) y = y + res[co];
                             if (act == 1) y = y > 0.0f ? y : 0.0f;
                             else if (act == 2) y = ora_tanhf(y);
+                            else if (act == 3) y = y > 0.0f ? y : y * 0.1f;  /* LeakyReLU(0.1) */
                             o[co] = y;
                         }
                     }

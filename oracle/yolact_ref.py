@@ -69,9 +69,27 @@ class YolactRef:
         y = ora.conv2d(x, self._h(_krsc(self.sd[name + ".weight"])), stride, pad, None, self.sd[name + ".bias"], None, act, **kw)
         return y if keep_f32 else self._h(y)
 
+    def _darknet(self, x):
+        """DarkNetBackbone([1, 2, 8, 8, 4]) of yolact_darknet53_config [UPSTREAM-RECALL]: every conv is Conv(bias=False) + BN +
+        LeakyReLU(0.1) (conv2d act 3); a block is 1x1 (C -> C/2), 3x3 (C/2 -> C) and the shortcut added AFTER the activation
+        (act 4); layers 2, 3, 4 (256 / 512 / 1024 channels at strides 8 / 16 / 32) feed the FPN."""
+        x = self._conv_bn(x, "backbone._preconv.0", "backbone._preconv.1", 1, 1, 3)
+        outs = []
+        for li, nb in enumerate((1, 2, 8, 8, 4)):
+            nm = "backbone.layers.%d" % li
+            x = self._conv_bn(x, nm + ".0.0", nm + ".0.1", 2, 1, 3)
+            for b in range(1, nb + 1):
+                t = self._conv_bn(x, "%s.%d.conv1" % (nm, b), "%s.%d.bn1" % (nm, b), 1, 0, 3)
+                x = self._conv_bn(t, "%s.%d.conv2" % (nm, b), "%s.%d.bn2" % (nm, b), 1, 1, 4, residual=x)
+            outs.append(x)
+        return outs[2], outs[3], outs[4]
+
     def forward(self, images_nhwc3):
         x = np.asarray(images_nhwc3, np.float32)
         N = x.shape[0]
+        if "backbone._preconv.0.weight" in self.sd:
+            C3, C4, C5 = self._darknet(x)
+            return self._heads(N, C3, C4, C5)
         x4 = np.concatenate([x, np.zeros(x.shape[:3] + (1,), np.float32)], -1)
         w1 = _krsc(self.sd["backbone.conv1.weight"])
         w1 = np.concatenate([w1, np.zeros(w1.shape[:3] + (1,), np.float32)], -1)
@@ -100,7 +118,9 @@ class YolactRef:
                     t = self._conv_bn(t, nm + ".conv2", nm + ".bn2", st, 1, 1)
                 x = self._conv_bn(t, nm + ".conv3", nm + ".bn3", 1, 0, 1, residual=idt)
             outs.append(x)
-        C3, C4, C5 = outs[1], outs[2], outs[3]
+        return self._heads(N, outs[1], outs[2], outs[3])
+
+    def _heads(self, N, C3, C4, C5):
         l5 = self._conv_b(C5, "fpn.lat_layers.0", 1, 0, 0)
         l4 = self._conv_b(C4, "fpn.lat_layers.1", 1, 0, 0)
         l3 = self._conv_b(C3, "fpn.lat_layers.2", 1, 0, 0)

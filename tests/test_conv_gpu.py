@@ -35,7 +35,8 @@ def test_conv_bit_exact(ffi, case, tile):
     Ho = (H + 2 * pad - R) // stride + 1
     Wo = (W + 2 * pad - R) // stride + 1
     res = _rand(rng, (N, Ho, Wo, Cout))
-    for act, use_res in [(1, True), (0, False), (2, False)]:
+    # act 3 = LeakyReLU(0.1), act 4 = LeakyReLU(0.1) then + residual (the DarkNet block of yolact_darknet53_config)
+    for act, use_res in [(1, True), (0, False), (2, False), (3, False), (4, True)]:
         ref = ora.conv2d(x, w, stride, pad, sc, sh, res if use_res else None, act)
         got = ffi.conv2d(x, w, stride, pad, sc, sh, res if use_res else None, act, tile)
         assert got.shape == ref.shape

@@ -65,6 +65,16 @@ def test_pool_resize_deconv_vs_torch():
     assert np.max(np.abs(ora.deconv2x2(a, wd, b, 1) - ref)) < 1e-5
 
 
+def test_conv_leaky_activations_known_answers():
+    """act 3 = LeakyReLU(0.1) after the (optional) residual; act 4 = LeakyReLU(0.1) FIRST, then the residual (DarkNetBlock)."""
+    x = np.zeros((1, 1, 2, 32), np.float32); x[0, 0, 0, 0] = 2.0; x[0, 0, 1, 0] = -3.0
+    w = np.zeros((1, 1, 1, 32), np.float32); w[0, 0, 0, 0] = 1.0
+    res = np.full((1, 1, 2, 1), 10.0, np.float32)
+    assert np.array_equal(ora.conv2d(x, w, 1, 0, None, None, None, 3).ravel(), np.float32([2.0, np.float32(-3.0) * np.float32(0.1)]))
+    assert np.array_equal(ora.conv2d(x, w, 1, 0, None, None, res, 4).ravel(), np.float32([12.0, np.float32(-3.0) * np.float32(0.1) + np.float32(10.0)]))
+    assert np.array_equal(ora.conv2d(x, w, 1, 0, None, None, -res, 3).ravel(), np.float32([np.float32(-8.0) * np.float32(0.1), np.float32(-13.0) * np.float32(0.1)]))
+
+
 def test_deform_im2col_known_answers():
     """DCNv2 sampling stage (YOLACT++ backbones): zero offsets + saturated mask == plain zero-padded im2col, exactly; a
     half-pixel shift averages neighbours; an independent float64 restatement agrees on random offsets incl. out-of-range."""

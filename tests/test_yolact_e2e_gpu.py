@@ -142,6 +142,40 @@ def test_yolact_base_and_im700_configs_bit_exact(ffi):
     net.close()
 
 
+def test_yolact_darknet53_bit_exact(ffi):
+    """yolact_darknet53_config (the Darknet53-FPN row of README.md:209-214): DarkNetBackbone([1, 2, 8, 8, 4]) with LeakyReLU(0.1)
+    and the shortcut added after the activation, layers 2-4 into the usual FPN / protonet / heads."""
+    from isegmi.weights import yolact_state_dict
+    from isegmi.yolact import Yolact, YolactConfig, darknet_base_transform, postprocess
+    cfg = YolactConfig.darknet53()
+    sd = yolact_state_dict(31, backbone="darknet53")
+    assert sd["fpn.lat_layers.0.weight"].shape == (256, 1024, 1, 1) and sd["backbone.layers.4.4.conv2.weight"].shape == (1024, 512, 3, 3)
+    size = 200
+    rng = np.random.default_rng(8)
+    x = darknet_base_transform(rng.uniform(0, 255, (2, size, size, 3)).astype(np.float32))
+    assert float(x.max()) <= 1.0 and float(x.min()) >= 0.0
+    net = Yolact(sd, cfg, max_batch=2, input_size=size)
+    ref = YolactRef(sd, max_size=550)
+    out = net(x)
+    refd = ref.forward(x)
+    for name, eng in (("C3", "backbone.layers.2.8.out"), ("P3", "P3"), ("P7", "P7"), ("proto", "proto")):
+        assert np.array_equal(net.fetch(eng, 2).reshape(ref.feats[name].shape), ref.feats[name]), name
+    total = 0
+    for i in range(2):
+        r, d = refd[i], out[i]["detection"]
+        if len(r["score"]) == 0:
+            assert d is None
+            continue
+        for a, b in (("prior", "prior"), ("class", "cls"), ("score", "score"), ("box", "box"), ("mask", "mask")):
+            assert np.array_equal(d[a], r[b]), a
+        total += len(r["score"])
+        cls, sc, boxes, masks = postprocess(out, size, size, batch_idx=i)
+        rc, rs, rb, rm = YolactRef.postprocess(r, size, size)
+        assert np.array_equal(cls, rc) and np.array_equal(sc, rs) and np.array_equal(boxes, rb) and np.array_equal(masks, rm)
+    assert total > 0
+    net.close()
+
+
 def test_yolact_plus_dcn_backbones_bit_exact(ffi):
     """SURVEY 8f rank 4, the YOLACT++ rows of README.md:216-221: DCNv2 3x3s in the backbone (every block of layers 2-4 on
     ResNet50, every third on ResNet101), nine rectangular anchors per cell (three scales x three ratios)."""

@@ -26,7 +26,8 @@ for it in range(rounds):
     sc = rng.uniform(0.5, 1.5, Cout).astype(np.float32); sh = rng.standard_normal(Cout).astype(np.float32)
     Ho = (H + 2 * pad - R) // stride + 1; Wo = (W + 2 * pad - R) // stride + 1
     res = rng.standard_normal((N, Ho, Wo, Cout)).astype(np.float32) if rng.uniform() < 0.5 else None
-    act = int(rng.integers(0, 3))
+    act = int(rng.integers(0, 5))
+    if act == 4 and res is None: act = 3
     ref = ora.conv2d(x, w, stride, pad, sc, sh, res, act)
     for tile in (0, 3, 4, 5, 6):
         got = ffi.conv2d(x, w, stride, pad, sc, sh, res, act, tile)
