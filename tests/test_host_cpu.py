@@ -56,6 +56,29 @@ def test_yolact_plus_config_priors_dcn_blocks_and_weights():
     assert [sd["maskiou_net.%d.weight" % i].shape[:2] for i in (0, 2, 4, 6, 8, 10)] == [(8, 1), (16, 8), (32, 16), (64, 32), (128, 64), (80, 128)]
 
 
+def test_yolact_darknet53_config_weights_and_transform():
+    """yolact_darknet53_config host logic: upstream DarkNetBackbone state-dict names / shapes, the 256/512/1024-channel FPN inputs,
+    darknet_transform (x / 255, BGR -> RGB) and the oracle's backbone on a tiny input (strides 8 / 16 / 32)."""
+    from isegmi.weights import yolact_state_dict
+    from isegmi.yolact import YolactConfig, darknet_base_transform
+    from oracle.yolact_ref import YolactRef
+    cfg = YolactConfig.darknet53()
+    assert cfg.backbone == "darknet53" and cfg.num_priors == 3 and cfg.use_square_anchors
+    sd = yolact_state_dict(3, backbone="darknet53")
+    assert sd["backbone._preconv.0.weight"].shape == (32, 3, 3, 3) and sd["backbone.layers.0.0.0.weight"].shape == (64, 32, 3, 3)
+    assert sd["backbone.layers.2.8.conv1.weight"].shape == (128, 256, 1, 1) and sd["backbone.layers.2.8.conv2.weight"].shape == (256, 128, 3, 3)
+    assert "backbone.layers.2.9.conv1.weight" not in sd and "backbone.conv1.weight" not in sd
+    assert [sd["fpn.lat_layers.%d.weight" % i].shape[1] for i in range(3)] == [1024, 512, 256]
+    n_blocks = sum(1 for k in sd if k.endswith(".conv2.weight") and k.startswith("backbone.layers."))
+    assert n_blocks == 1 + 2 + 8 + 8 + 4
+    img = np.zeros((1, 2, 2, 3), np.float32); img[0, 0, 0] = [255.0, 51.0, 0.0]
+    t = darknet_base_transform(img)
+    assert np.array_equal(t[0, 0, 0], np.float32([0.0, np.float32(51.0) / np.float32(255.0), 1.0]))
+    ref = YolactRef(sd)
+    c3, c4, c5 = ref._darknet(np.random.default_rng(0).uniform(0, 1, (1, 64, 64, 3)).astype(np.float32))
+    assert c3.shape == (1, 8, 8, 256) and c4.shape == (1, 4, 4, 512) and c5.shape == (1, 2, 2, 1024)
+
+
 def test_maskrcnn_anchors_and_shapes():
     from isegmi.maskrcnn import generate_anchors, grid_anchors, level_shapes
     from oracle.maskrcnn_ref import cell_anchors, grid_anchors as ref_grid
