@@ -19,6 +19,8 @@ run maskrcnn_r50_fp16_bs2 --model maskrcnn --fp16 --batch 2
 run maskrcnn_r101_fp16_bs8 --model maskrcnn --depth 101 --fp16 --batch 8
 run maskrcnn_r50_c4_bs2 --model maskrcnn --c4 --steps 10
 run yolact_fp16_bs8 --fp16 --no-cpu-baseline
+run yolact_base_bs8 --yolact-config base --no-cpu-baseline
+run yolact_im700_bs8 --yolact-config im700 --no-cpu-baseline
 run yolact_darknet53_bs8 --yolact-config darknet53 --no-cpu-baseline
 run yolact_plus_resnet50_bs8 --yolact-config plus_resnet50 --no-cpu-baseline
 run yolact_plus_base_bs8 --yolact-config plus_base --no-cpu-baseline
