@@ -37,6 +37,8 @@ int isegmi_device_count(int* n);
 int isegmi_set_device(int device_id);
 int isegmi_malloc(void** d_ptr, int64_t bytes);
 int isegmi_free(void* d_ptr);
+int isegmi_malloc_host(void** h_ptr, int64_t bytes);   /* pinned host memory (source of isegmi_engine_upload_async) */
+int isegmi_free_host(void* h_ptr);
 int isegmi_h2d(void* d_dst, const void* h_src, int64_t bytes);
 int isegmi_d2h(void* h_dst, const void* d_src, int64_t bytes);
 int isegmi_memset(void* d_ptr, int value, int64_t bytes);
@@ -253,6 +255,13 @@ int isegmi_maskrcnn_paste(isegmi_engine* e, const float* h_ratios_wh, int out_h,
 int isegmi_yolact_postprocess(isegmi_engine* e, int out_h, int out_w);
 int isegmi_engine_sync(isegmi_engine* e);
 int isegmi_engine_stream(isegmi_engine* e, void** stream);
+/* asynchronous H2D of an input batch from PINNED host memory on the engine's copy stream: ordered after the previous
+ * forward consumed its input, and the next forward is ordered behind it (stands where the reference's
+ * jt.array(image) host->device transfer sits, README.md:311/331) */
+int isegmi_engine_upload_async(isegmi_engine* e, void* d_dst, const void* h_src_pinned, int64_t bytes);
+/* per-step completion marks on the results stream; step_times returns the intervals between consecutive marks (ms) */
+int isegmi_engine_mark_step(isegmi_engine* e);
+int isegmi_engine_step_times(isegmi_engine* e, float* ms, int cap, int* count);
 /* dtype: 0 f32, 1 i32, 2 u8, 3 i64; shape4 receives up to 4 dims */
 int isegmi_engine_buffer_info(isegmi_engine* e, const char* name, void** d_ptr, int64_t* bytes,
                               int32_t* dtype, int64_t* shape4, int32_t* ndim);
@@ -286,6 +295,13 @@ int isegmi_comm_destroy(isegmi_comm* c);
 int isegmi_comm_allgather(isegmi_comm* c, const void* d_send, void* d_recv, int64_t bytes,
                           void* producer_stream);
 int isegmi_comm_wait(isegmi_comm* c);
+/* Two record slots (0, 1) so that step t+1 packs while step t gathers, without a host sync in between:
+ *   fence_producer(slot, s): work enqueued on stream s afterwards runs after the slot's last all-gather finished (WAR);
+ *   allgather_slot: as isegmi_comm_allgather (= slot 0) through the given slot; wait_slot: host wait for that slot. */
+int isegmi_comm_fence_producer(isegmi_comm* c, int slot, void* producer_stream);
+int isegmi_comm_allgather_slot(isegmi_comm* c, int slot, const void* d_send, void* d_recv, int64_t bytes,
+                               void* producer_stream);
+int isegmi_comm_wait_slot(isegmi_comm* c, int slot);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

@@ -23,6 +23,13 @@ extern "C" int isegmi_malloc(void** p, int64_t bytes) {
     HIP_TRY(hipMalloc(p, (size_t)(bytes > 0 ? bytes : 16)));
     return ISEGMI_OK;
 }
+// pinned (page-locked) host memory: the source of isegmi_engine_upload_async
+extern "C" int isegmi_malloc_host(void** p, int64_t bytes) {
+    ARG_CHECK(p && bytes >= 0, "malloc_host args");
+    HIP_TRY(hipHostMalloc(p, (size_t)(bytes > 0 ? bytes : 16), hipHostMallocDefault));
+    return ISEGMI_OK;
+}
+extern "C" int isegmi_free_host(void* p) { HIP_TRY(hipHostFree(p)); return ISEGMI_OK; }
 extern "C" int isegmi_free(void* p) { HIP_TRY(hipFree(p)); return ISEGMI_OK; }
 extern "C" int isegmi_h2d(void* d, const void* h, int64_t bytes) { HIP_TRY(hipMemcpy(d, h, (size_t)bytes, hipMemcpyHostToDevice)); return ISEGMI_OK; }
 extern "C" int isegmi_d2h(void* h, const void* d, int64_t bytes) { HIP_TRY(hipMemcpy(h, d, (size_t)bytes, hipMemcpyDeviceToHost)); return ISEGMI_OK; }

@@ -56,10 +56,16 @@ static int load_rccl() {
 }  // namespace isegmi
 using namespace isegmi;
 
+// Two record slots: step t gathers out of / into slot t % 2 while the producer already packs step t+1 into the other one.
+// done[s] is recorded behind slot s's all-gather; isegmi_comm_fence_producer makes the producer stream wait on it before it
+// overwrites send[s] / before a new gather overwrites recv[s] (WAR), so no host synchronisation is needed between steps.
+constexpr int COMM_SLOTS = 2;
 struct isegmi_comm {
     ncclComm_tt comm = nullptr;
     hipStream_t stream = nullptr;
-    hipEvent_t ready = nullptr, done = nullptr;
+    hipEvent_t ready = nullptr;
+    hipEvent_t done[COMM_SLOTS] = {nullptr, nullptr};
+    bool used[COMM_SLOTS] = {false, false};
     int rank = 0, world = 1;
 };
 
@@ -85,7 +91,7 @@ extern "C" int isegmi_comm_create(const void* uid128, int rank, int world, isegm
     if (r != 0) { set_error(std::string("ncclCommInitRank -> ") + (R.errstr ? R.errstr(r) : "?")); delete c; return ISEGMI_ERR_RCCL; }
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
+    for (int i = 0; i < COMM_SLOTS; ++i) HIP_TRY(hipEventCreateWithFlags(&c->done[i], hipEventDisableTiming));
     *out = c;
     return ISEGMI_OK;
 }
@@ -95,25 +101,44 @@ extern "C" int isegmi_comm_destroy(isegmi_comm* c) {
     (void)hipStreamSynchronize(c->stream);
     if (c->comm) R.destroy(c->comm);
     (void)hipEventDestroy(c->ready);
-    (void)hipEventDestroy(c->done);
+    for (int i = 0; i < COMM_SLOTS; ++i) (void)hipEventDestroy(c->done[i]);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return ISEGMI_OK;
 }
 
-// All-gather `bytes` bytes from every rank: d_recv holds world*bytes, rank r's block at r*bytes.
+// WAR fence of slot `slot`: everything enqueued on `producer_stream` after this call runs after the slot's last all-gather has
+// finished reading its send block and writing its receive block.  Call it before re-packing records into the slot's send buffer.
+extern "C" int isegmi_comm_fence_producer(isegmi_comm* c, int slot, void* producer_stream) {
+    ARG_CHECK(c && slot >= 0 && slot < COMM_SLOTS, "fence args");
+    if (c->used[slot]) HIP_TRY(hipStreamWaitEvent((hipStream_t)producer_stream, c->done[slot], 0));
+    return ISEGMI_OK;
+}
+
+// All-gather `bytes` bytes from every rank through slot `slot` (0 or 1): d_recv holds world*bytes, rank r's block at r*bytes.
 // Ordered after everything already enqueued on `producer_stream`; runs on the comm's own stream.
-extern "C" int isegmi_comm_allgather(isegmi_comm* c, const void* d_send, void* d_recv, int64_t bytes, void* producer_stream) {
-    ARG_CHECK(c && d_send && d_recv && bytes > 0, "allgather args");
+extern "C" int isegmi_comm_allgather_slot(isegmi_comm* c, int slot, const void* d_send, void* d_recv, int64_t bytes, void* producer_stream) {
+    ARG_CHECK(c && d_send && d_recv && bytes > 0 && slot >= 0 && slot < COMM_SLOTS, "allgather args");
     HIP_TRY(hipEventRecord(c->ready, (hipStream_t)producer_stream));
     HIP_TRY(hipStreamWaitEvent(c->stream, c->ready, 0));
     RCCL_TRY(R.allgather(d_send, d_recv, (size_t)bytes, /*ncclInt8*/ 0, c->comm, c->stream));
-    HIP_TRY(hipEventRecord(c->done, c->stream));
+    HIP_TRY(hipEventRecord(c->done[slot], c->stream));
+    c->used[slot] = true;
+    return ISEGMI_OK;
+}
+
+extern "C" int isegmi_comm_allgather(isegmi_comm* c, const void* d_send, void* d_recv, int64_t bytes, void* producer_stream) {
+    return isegmi_comm_allgather_slot(c, 0, d_send, d_recv, bytes, producer_stream);
+}
+
+extern "C" int isegmi_comm_wait_slot(isegmi_comm* c, int slot) {
+    ARG_CHECK(c && slot >= 0 && slot < COMM_SLOTS, "wait args");
+    if (c->used[slot]) HIP_TRY(hipEventSynchronize(c->done[slot]));
     return ISEGMI_OK;
 }
 
 extern "C" int isegmi_comm_wait(isegmi_comm* c) {
     ARG_CHECK(c, "null");
-    HIP_TRY(hipEventSynchronize(c->done));
+    for (int i = 0; i < COMM_SLOTS; ++i) if (c->used[i]) HIP_TRY(hipEventSynchronize(c->done[i]));
     return ISEGMI_OK;
 }

@@ -156,6 +156,13 @@ int eng_tail_end(Engine& e) {
     return ISEGMI_OK;
 }
 
+int eng_input_consumed(Engine& e) {
+    if (e.capturing || e.in_done == nullptr) return ISEGMI_OK;
+    HIP_TRY(hipEventRecord(e.in_done, e.cur));
+    e.in_pending = true;
+    return ISEGMI_OK;
+}
+
 void eng_graph_reset(Engine& e) {
     for (auto& kv : e.graphs) (void)hipGraphExecDestroy(kv.second);
     e.graphs.clear();
@@ -275,6 +282,7 @@ int yolact_forward(Engine& e, const float* d_images, int N) {
         // block is 1x1 (C -> C/2) then 3x3 (C/2 -> C) with the shortcut added AFTER the activation (act 4)
         TRY(eng_act(e, "input32", N, H, W, 32, &x4));
         TRY(pad_c3_c32_launch(d_images, (int64_t)N * H * W, x4.d, e.cur));
+        TRY(eng_input_consumed(e));
         TRY(eng_conv(e, "backbone._preconv.0", x4, 1, 1, 3, nullptr, "stem", &x));
         eng_mark(e, "stem");
         const int nblk[5] = {1, 2, 8, 8, 4};
@@ -299,10 +307,12 @@ int yolact_forward(Engine& e, const float* d_images, int N) {
     if (dt) {
         TRY(eng_act(e, "input4h", N, H + 6, (W + 7) & ~1, 4, &x4, 1));
         TRY(pad_c3_to_f16_halo_launch(d_images, N, H, W, x4.d, e.cur));
+        TRY(eng_input_consumed(e));
         TRY(eng_conv_stem_f16(e, "backbone.conv1", x4, H, W, "stem", &s));
     } else {
         TRY(eng_act(e, "input4", N, H, W, 4, &x4));
         TRY(pad_c3_c4_launch(d_images, (int64_t)N * H * W, x4.d, e.cur));
+        TRY(eng_input_consumed(e));
         TRY(eng_conv(e, "backbone.conv1", x4, 2, 3, 1, nullptr, "stem", &s));
     }
     {
@@ -560,6 +570,9 @@ extern "C" int isegmi_engine_create(int model_kind, int max_batch, int H, int W,
     for (int i = 0; i < 3 && er == hipSuccess; ++i) er = hipStreamCreateWithFlags(&h->e.hside[i], hipStreamNonBlocking);
     if (er == hipSuccess) er = hipEventCreateWithFlags(&h->e.lat_done, hipEventDisableTiming);
     if (er == hipSuccess) er = hipEventCreateWithFlags(&h->e.heads_done, hipEventDisableTiming);
+    if (er == hipSuccess) er = hipStreamCreateWithFlags(&h->e.copy, hipStreamNonBlocking);
+    if (er == hipSuccess) er = hipEventCreateWithFlags(&h->e.in_done, hipEventDisableTiming);
+    if (er == hipSuccess) er = hipEventCreateWithFlags(&h->e.up_done, hipEventDisableTiming);
     if (er != hipSuccess) { set_error(std::string("tail stream: ") + hipGetErrorString(er)); delete h; return ISEGMI_ERR_HIP; }
     h->e.cur = h->e.stream;
     *out = h;
@@ -578,6 +591,10 @@ extern "C" int isegmi_engine_destroy(isegmi_engine* h) {
     if (e.heads) (void)hipStreamDestroy(e.heads);
     if (e.lat_done) (void)hipEventDestroy(e.lat_done);
     if (e.heads_done) (void)hipEventDestroy(e.heads_done);
+    if (e.copy) { (void)hipStreamSynchronize(e.copy); (void)hipStreamDestroy(e.copy); }
+    if (e.in_done) (void)hipEventDestroy(e.in_done);
+    if (e.up_done) (void)hipEventDestroy(e.up_done);
+    for (auto& ev : e.step_marks) (void)hipEventDestroy(ev);
     for (auto& kv : e.convs) { (void)hipFree(kv.second.d_w); if (kv.second.d_scale) (void)hipFree(kv.second.d_scale); if (kv.second.d_shift) (void)hipFree(kv.second.d_shift); }
     for (auto& kv : e.tensors) (void)hipFree(kv.second.d);
     for (auto& kv : e.bufs) (void)hipFree(kv.second.d);
@@ -679,6 +696,49 @@ extern "C" int isegmi_engine_sync(isegmi_engine* h) {
     h->e.lat_pending = false;
     h->e.heads_pending = false;
     collect_times(h->e);
+    return ISEGMI_OK;
+}
+
+// Asynchronous input upload: `h_src` must be pinned host memory (isegmi_malloc_host) that stays untouched until the forward
+// consuming `d_dst` has been enqueued and the engine synchronised (or a later upload_async to the same d_dst returned and was
+// synchronised).  The copy runs on the engine's copy stream, after the previous forward has consumed ITS input (so one device
+// buffer may be reused every step, two alternate without any wait), and the next forward is ordered behind the copy.
+extern "C" int isegmi_engine_upload_async(isegmi_engine* h, void* d_dst, const void* h_src, int64_t bytes) {
+    ARG_CHECK(h && d_dst && h_src && bytes > 0, "upload args");
+    Engine& e = h->e;
+    if (e.in_pending) { HIP_TRY(hipStreamWaitEvent(e.copy, e.in_done, 0)); e.in_pending = false; }
+    HIP_TRY(hipMemcpyAsync(d_dst, h_src, (size_t)bytes, hipMemcpyHostToDevice, e.copy));
+    HIP_TRY(hipEventRecord(e.up_done, e.copy));
+    HIP_TRY(hipStreamWaitEvent(e.stream, e.up_done, 0));
+    return ISEGMI_OK;
+}
+
+// Records a completion mark for the step just enqueued on the stream its results finish on; isegmi_engine_step_times returns
+// the intervals between consecutive marks (ms) -- per-step latency samples of a pipelined run -- and clears them.
+extern "C" int isegmi_engine_mark_step(isegmi_engine* h) {
+    ARG_CHECK(h, "null");
+    Engine& e = h->e;
+    ARG_CHECK(e.step_marks.size() < 65536, "too many pending step marks");
+    hipEvent_t ev;
+    HIP_TRY(hipEventCreate(&ev));
+    HIP_TRY(hipEventRecord(ev, (e.multi_stream && e.tail_pending) ? e.tail : e.stream));
+    e.step_marks.push_back(ev);
+    return ISEGMI_OK;
+}
+
+extern "C" int isegmi_engine_step_times(isegmi_engine* h, float* ms, int cap, int* count) {
+    ARG_CHECK(h && ms && count && cap >= 0, "step_times args");
+    Engine& e = h->e;
+    int c = 0;
+    if (!e.step_marks.empty()) HIP_TRY(hipEventSynchronize(e.step_marks.back()));
+    for (size_t i = 1; i < e.step_marks.size() && c < cap; ++i) {
+        float t = 0;
+        HIP_TRY(hipEventElapsedTime(&t, e.step_marks[i - 1], e.step_marks[i]));
+        ms[c++] = t;
+    }
+    for (auto& ev : e.step_marks) (void)hipEventDestroy(ev);
+    e.step_marks.clear();
+    *count = c;
     return ISEGMI_OK;
 }
 

@@ -63,6 +63,13 @@ struct Engine {
     std::map<std::string, hipGraphExec_t> graphs;
     std::map<std::string, int> graph_warm;
     int64_t graph_captures = 0, graph_replays = 0, graph_failures = 0;
+    // asynchronous input upload (isegmi_engine_upload_async): pinned host -> device on a copy stream; in_done marks the point
+    // where the last forward has consumed its input buffer (WAR for the next upload), up_done the end of the last upload
+    hipStream_t copy = nullptr;
+    hipEvent_t in_done = nullptr, up_done = nullptr;
+    bool in_pending = false;
+    // per-step completion marks on the results stream (isegmi_engine_mark_step / _step_times): true per-step latency samples
+    std::vector<hipEvent_t> step_marks;
     bool fp16 = false;                     // fp16 storage + f16 MFMA convs (BASELINE configs[4]); set before loading weights
     std::vector<hipEvent_t> ev_pool;
     size_t ev_next = 0;
@@ -104,6 +111,7 @@ int eng_conv(Engine& e, const std::string& layer, const Tensor& in, int stride, 
 int eng_graph_run(Engine& e, const std::string& key, const std::function<int()>& body);
 void eng_graph_reset(Engine& e);
 int eng_tail_end(Engine& e);
+int eng_input_consumed(Engine& e);  // call right after the last kernel that reads the caller's input buffer
 int eng_conv_stem_f16(Engine& e, const std::string& layer, const Tensor& halo, int H, int W, const std::string& out_name, Tensor* out);
 int eng_conv_into(Engine& e, const std::string& layer, const Tensor& in, int stride, int pad, int act, void* dst, int out_div,
                   int64_t out_img_stride, int64_t out_pix_stride, bool out_f32 = false);

@@ -54,6 +54,8 @@ int maskrcnn_set_image_hw(Engine& e, const int32_t* h_image_hw, int N) {
     TRY(eng_buf(e, "image_hw", (int64_t)N * 8, &p, 1, {N, 2}));
     std::vector<int32_t> now(h_image_hw, h_image_hw + 2 * N);
     if (now != e.last_hw || e.last_hw_ptr != (const void*)p) {
+        // the previous forward's RoI heads (tail stream) may still read image_hw
+        if (e.tail_pending && e.tail) HIP_TRY(hipStreamSynchronize(e.tail));
         HIP_TRY(hipMemcpyAsync(p, h_image_hw, (size_t)N * 8, hipMemcpyHostToDevice, e.stream));
         HIP_TRY(hipStreamSynchronize(e.stream));
         e.last_hw = now;
@@ -80,10 +82,12 @@ int maskrcnn_forward(Engine& e, const float* d_images, int N) {
     if (dt) {  // fp16: images are rounded to fp16 into a zero-haloed 4-channel buffer the stem kernel reads without bounds tests
         TRY(eng_act(e, "input4h", N, H + 6, (W + 7) & ~1, 4, &x4, 1));
         TRY(pad_c3_to_f16_halo_launch(d_images, N, H, W, x4.d, st));
+        TRY(eng_input_consumed(e));
         TRY(eng_conv_stem_f16(e, "backbone.body.stem.conv1", x4, H, W, "stem", &s));
     } else {
         TRY(eng_act(e, "input4", N, H, W, 4, &x4));
         TRY(pad_c3_c4_launch(d_images, (int64_t)N * H * W, x4.d, st));
+        TRY(eng_input_consumed(e));
         TRY(eng_conv(e, "backbone.body.stem.conv1", x4, 2, 3, 1, nullptr, "stem", &s));
     }
     {
@@ -320,6 +324,7 @@ static int maskrcnn_c4_forward(Engine& e, const float* d_images, int N) {
     Tensor x4, s, x;
     TRY(eng_act(e, "input4", N, H, W, 4, &x4));
     TRY(pad_c3_c4_launch(d_images, (int64_t)N * H * W, x4.d, st));
+    TRY(eng_input_consumed(e));
     TRY(eng_conv(e, "backbone.body.stem.conv1", x4, 2, 3, 1, nullptr, "stem", &s));
     {
         const int Ho = (s.H + 2 - 3) / 2 + 1, Wo = (s.W + 2 - 3) / 2 + 1;

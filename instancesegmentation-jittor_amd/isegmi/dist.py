@@ -86,15 +86,24 @@ def gather_records(local_record, world, allgather):
 
 
 class RcclGather:
-    """RCCL all-gather of the engine's packed detection records (device side)."""
+    """RCCL all-gather of the engine's packed detection records (device side).
+
+    Two (send, recv) slots alternate between steps: step t packs into / gathers through slot t % 2 while step t-1's
+    all-gather may still be in flight on the comm stream.  Before a slot is re-packed the producer stream waits (on the
+    device, isegmi_comm_fence_producer) for that slot's previous all-gather, so consecutive `gather_from` calls need no
+    host synchronisation in between and ranks never see records of mixed steps.  `fetch()` returns the records of the
+    most recent `gather_from`; `fetch(previous=True)` those of the one before (still intact: the other slot)."""
+
+    SLOTS = 2
 
     def __init__(self, rank, world, uid_bytes, per_rank_bytes):
         self.rank, self.world, self.nbytes = rank, world, int(per_rank_bytes)
         self._c = C.c_void_p()
         uid = C.create_string_buffer(bytes(uid_bytes), 128)
         _ffi.check(_ffi.lib().isegmi_comm_create(uid, rank, world, C.byref(self._c)))
-        self.send = _ffi.DeviceBuffer((self.nbytes,), np.uint8)
-        self.recv = _ffi.DeviceBuffer((self.nbytes * world,), np.uint8)
+        self.sends = [_ffi.DeviceBuffer((self.nbytes,), np.uint8) for _ in range(self.SLOTS)]
+        self.recvs = [_ffi.DeviceBuffer((self.nbytes * world,), np.uint8) for _ in range(self.SLOTS)]
+        self.step = 0
 
     @staticmethod
     def unique_id():
@@ -102,24 +111,40 @@ class RcclGather:
         _ffi.check(_ffi.lib().isegmi_comm_unique_id(b))
         return b.raw
 
+    @property
+    def send(self):  # slot of the most recent gather
+        return self.sends[(self.step - 1) % self.SLOTS]
+
+    @property
+    def recv(self):
+        return self.recvs[(self.step - 1) % self.SLOTS]
+
     def gather_from(self, net, with_proto=False):
-        """Pack the last forward's records on the engine stream, then all-gather on the comm stream (async)."""
+        """Pack the last forward's records on the engine's results stream, then all-gather on the comm stream (async)."""
+        L = _ffi.lib()
+        slot = self.step % self.SLOTS
+        send, recv = self.sends[slot], self.recvs[slot]
+        st = C.c_void_p()
+        _ffi.check(L.isegmi_engine_stream(net._h, C.byref(st)))
+        _ffi.check(L.isegmi_comm_fence_producer(self._c, slot, st))  # WAR: the slot's previous gather has finished
         nb = C.c_int64()
         if getattr(net, "KIND", 1) == 2:
-            _ffi.check(_ffi.lib().isegmi_maskrcnn_pack_records(net._h, self.send.ptr, C.c_int64(self.nbytes), C.byref(nb)))
+            _ffi.check(L.isegmi_maskrcnn_pack_records(net._h, send.ptr, C.c_int64(self.nbytes), C.byref(nb)))
         else:
-            _ffi.check(_ffi.lib().isegmi_yolact_pack_records(net._h, self.send.ptr, C.c_int64(self.nbytes), int(with_proto), C.byref(nb)))
+            _ffi.check(L.isegmi_yolact_pack_records(net._h, send.ptr, C.c_int64(self.nbytes), int(with_proto), C.byref(nb)))
         assert nb.value == self.nbytes, (nb.value, self.nbytes)
-        st = C.c_void_p()
-        _ffi.check(_ffi.lib().isegmi_engine_stream(net._h, C.byref(st)))
-        _ffi.check(_ffi.lib().isegmi_comm_allgather(self._c, self.send.ptr, self.recv.ptr, C.c_int64(self.nbytes), st))
+        _ffi.check(L.isegmi_engine_stream(net._h, C.byref(st)))
+        _ffi.check(L.isegmi_comm_allgather_slot(self._c, slot, send.ptr, recv.ptr, C.c_int64(self.nbytes), st))
+        self.step += 1
 
     def wait(self):
         _ffi.check(_ffi.lib().isegmi_comm_wait(self._c))
 
-    def fetch(self):
-        self.wait()
-        return self.recv.numpy().reshape(self.world, self.nbytes)
+    def fetch(self, previous=False):
+        assert self.step > (1 if previous else 0), "fetch before gather_from"
+        slot = (self.step - (2 if previous else 1)) % self.SLOTS
+        _ffi.check(_ffi.lib().isegmi_comm_wait_slot(self._c, slot))
+        return self.recvs[slot].numpy().reshape(self.world, self.nbytes)
 
     def close(self):
         if self._c:

@@ -150,6 +150,8 @@ class Yolact:
         for k in ("nms_conf_thresh", "nms_thresh", "nms_top_k", "max_num_detections"):
             self.set_param(k, float(getattr(cfg, k)))
         self._d_in = _ffi.DeviceBuffer((max_batch, self.size, self.size, 3))
+        self._forward_id = 0
+        self._pp_key = None
 
     # -- weights -------------------------------------------------------------------------------
     def _set_conv(self, name, w_oihw, scale=None, shift=None, pad_cin_to=None):
@@ -245,6 +247,8 @@ class Yolact:
 
     def forward_device(self, n):
         """Launch forward on the batch already resident in the engine's input buffer (asynchronous)."""
+        self._pp_key = None  # masks / integer boxes cached by postprocess() belong to the previous forward
+        self._forward_id += 1
         _ffi.check(_ffi.lib().isegmi_yolact_forward(self._h, self._d_in.ptr, n))
 
     def postprocess_device(self, h, w):
@@ -285,7 +289,7 @@ class Yolact:
             c = int(cnt[i])
             det = None if c == 0 else dict(box=box[i, :c], mask=coeff[i, :c], score=score[i, :c], proto=proto[i],
                                            prior=prior[i, :c], **{"class": cls[i, :c]})
-            out.append({"detection": det, "net": self, "_index": i})
+            out.append({"detection": det, "net": self, "_index": i, "_forward": self._forward_id})
         return out
 
     def close(self):
@@ -312,7 +316,10 @@ def postprocess(det_output, w, h, batch_idx=0, score_threshold=0.0):
         z = np.zeros((0,), np.int32)
         return z, np.zeros((0,), np.float32), np.zeros((0, 4), np.int64), np.zeros((0, h, w), np.uint8)
     i = dets["_index"]
-    key = (h, w)
+    if dets.get("_forward", net._forward_id) != net._forward_id:
+        raise RuntimeError("postprocess(): these predictions come from an earlier forward of this net; the device buffers "
+                           "(prototypes, coefficients) now hold a later batch")
+    key = (h, w, net._forward_id)
     if getattr(net, "_pp_key", None) != key:
         net.postprocess_device(h, w)
         net.sync()

@@ -72,3 +72,37 @@ def test_rccl_world1_maskrcnn_c4_records(ffi):
     rec = unpack_maskrcnn_records(got, 1, M=14)
     assert rec["count"][0] > 0 and np.array_equal(rec["mask28"], model.fetch("det.mask14", 1))
     g.close(); model.close()
+
+
+def test_rccl_queued_steps_without_host_sync(ffi):
+    """Four forward -> gather_from steps on changing inputs, queued with no host synchronisation in between: the two record
+    slots + the producer fence must keep every step's records intact (the last two are still fetchable: one per slot)."""
+    from isegmi.dist import RcclGather, record_bytes, unpack_records
+    from isegmi.weights import yolact_state_dict
+    from isegmi.yolact import Yolact, fast_base_transform
+    size, n = 200, 2
+    net = Yolact(yolact_state_dict(1234), max_batch=n, input_size=size)
+    rng = np.random.default_rng(9)
+    xs = [fast_base_transform(rng.uniform(0, 255, (n, size, size, 3)).astype(np.float32)) for _ in range(4)]
+    clean = []
+    for x in xs:  # clean, fully synchronised runs
+        net(x)
+        clean.append({k: net.fetch(k, n) for k in ("det.count", "det.score", "det.box", "det.class", "det.coeff")})
+    assert not np.array_equal(clean[2]["det.score"], clean[3]["det.score"])
+    ds = [ffi.DeviceBuffer.from_numpy(x) for x in xs]
+    g = RcclGather(0, 1, RcclGather.unique_id(), record_bytes(n))
+    for rep in range(3):  # 12 queued steps; the last pass ends on inputs 2, 3
+        for d in ds:
+            ffi.check(ffi.lib().isegmi_yolact_forward(net._h, d.ptr, n))
+            g.gather_from(net)
+    last = unpack_records(g.fetch()[0], n)
+    prev = unpack_records(g.fetch(previous=True)[0], n)
+    for rec, ref in ((last, clean[3]), (prev, clean[2])):
+        assert np.array_equal(rec["count"], ref["det.count"])
+        for i in range(n):
+            c = int(ref["det.count"][i])
+            assert np.array_equal(rec["score"][i, :c], ref["det.score"][i, :c])
+            assert np.array_equal(rec["box"][i, :c], ref["det.box"][i, :c])
+            assert np.array_equal(rec["cls"][i, :c], ref["det.class"][i, :c])
+            assert np.array_equal(rec["coeff"][i, :c], ref["det.coeff"][i, :c])
+    g.close(); net.close()

@@ -172,6 +172,32 @@ for r in range(world):
         assert np.array_equal(got[k], full[k][a:b]), (rank, r, k)
     off += b - a
 assert off == GLOBAL
+# Mask R-CNN records (28x28 masks of the FPN head, 14x14 of MaskRCNNC4Predictor), two consecutive steps with different
+# content and no barrier in between: every rank must see each step's records of every other rank, never a mix
+from isegmi.dist import pack_maskrcnn_records, unpack_maskrcnn_records, maskrcnn_record_bytes
+def mrec(lo, hi, M, step):
+    n = hi - lo
+    cnt = np.zeros(n, np.int32); box = np.zeros((n, K, 4), np.float32); sc = np.zeros((n, K), np.float32)
+    lab = np.zeros((n, K), np.int32); mk = np.zeros((n, K, M, M), np.float32)
+    for j, i in enumerate(range(lo, hi)):
+        rng = np.random.default_rng(77 * step + i)
+        c = int(rng.integers(0, K + 1)); cnt[j] = c
+        box[j, :c] = rng.uniform(0, 800, (c, 4)); sc[j, :c] = np.sort(rng.uniform(0, 1, c))[::-1]
+        lab[j, :c] = rng.integers(1, 81, c); mk[j, :c] = rng.uniform(0, 1, (c, M, M))
+    return pack_maskrcnn_records(cnt, box, sc, lab, mk)
+for M in (28, 14):
+    gathered = []
+    for step in range(2):
+        mine = mrec(lo, hi, M, step)
+        assert mine.nbytes == maskrcnn_record_bytes(hi - lo, K, M)
+        gathered.append(gather_records(mine, world, allgather))
+    for step in range(2):
+        full = unpack_maskrcnn_records(mrec(0, GLOBAL, M, step), GLOBAL, K, M)
+        for r in range(world):
+            a, b = shard_batch(GLOBAL, r, world)
+            got = unpack_maskrcnn_records(gathered[step][r], b - a, K, M)
+            for k in got:
+                assert np.array_equal(got[k], full[k][a:b]), (rank, r, k, M, step)
 dist.barrier(); dist.destroy_process_group()
 open(os.path.join(sys.argv[2], "ok_%d" % rank), "w").write("ok")
 '''

@@ -94,6 +94,52 @@ def test_yolact_550_bit_exact(ffi, sd):
     net.close()
 
 
+def test_postprocess_after_second_forward_uses_the_new_batch(ffi, sd):
+    """One net, two different batches, postprocess at the SAME output size after each (the `eval --images` loop): the masks and
+    integer boxes of the second call must belong to the second batch; stale predictions are refused."""
+    from isegmi.yolact import Yolact, postprocess
+    size = 200
+    net = Yolact(sd, max_batch=1, input_size=size)
+    ref = YolactRef(sd, max_size=550)
+    outs = []
+    for seed in (31, 32):
+        x = _images(seed, 1, size)
+        out = net(x)
+        r = ref.forward(x)[0]
+        cls, sc, boxes, masks = postprocess(out, 190, 210)
+        rc, rs, rb, rm = YolactRef.postprocess(r, 190, 210)
+        assert len(rs) > 0
+        assert np.array_equal(cls, rc) and np.array_equal(sc, rs) and np.array_equal(boxes, rb) and np.array_equal(masks, rm), seed
+        outs.append((out, masks))
+    assert outs[0][1].shape != outs[1][1].shape or not np.array_equal(outs[0][1], outs[1][1])
+    with pytest.raises(RuntimeError, match="earlier forward"):
+        postprocess(outs[0][0], 190, 210)
+    net.close()
+
+
+def test_yolact_550_bs8_bit_exact(ffi, sd):
+    """BASELINE configs[1] at its own workload: eight 550x550 images in one batch, every detection field and the
+    550x550 masks of every image against the oracle."""
+    from isegmi.yolact import Yolact, postprocess
+    net = Yolact(sd, max_batch=8)
+    ref = YolactRef(sd)
+    x = _images(20261003, 8, 550)
+    out = net(x)
+    refd = ref.forward(x)
+    total = 0
+    for i in range(8):
+        r, d = refd[i], out[i]["detection"]
+        assert d is not None and len(d["score"]) == len(r["score"])
+        for a, b in (("prior", "prior"), ("class", "cls"), ("score", "score"), ("box", "box"), ("mask", "mask")):
+            assert np.array_equal(d[a], r[b]), (i, a)
+        cls, sc, boxes, masks = postprocess(out, 550, 550, batch_idx=i)
+        rc, rs, rb, rm = YolactRef.postprocess(r, 550, 550)
+        assert np.array_equal(cls, rc) and np.array_equal(sc, rs) and np.array_equal(boxes, rb) and np.array_equal(masks, rm), i
+        total += len(rs)
+    assert total >= 400
+    net.close()
+
+
 def test_back_to_back_forwards_are_independent(ffi, sd):
     """Cross-step overlap (tail stream): forwards queued without a host sync must not disturb each other.
     A, B alternate five times with no sync in between; the final results must equal a clean run of the last batch."""
