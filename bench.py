@@ -1,19 +1,26 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X-native RoI/mask inference hot path.
 
-`python bench.py --gpus N --steps K --warmup W`  (N>1: launched by torch.distributed.run, one rank per GPU).
+`python bench.py --gpus N --steps K --warmup W`
+  N = 1: runs in this process.  N > 1 without a torch.distributed environment: this process only starts N child ranks
+  (`python -m torch.distributed.run --nproc-per-node N bench.py ...`, before any HIP call), relays rank 0's JSON line and
+  exits with the children's code.  N > 1 inside such an environment (RANK/WORLD_SIZE set): one rank per GPU.
 
-A "step" = one pass of the hot path over one batch of synthetic input that is already resident
-in HBM: Yolact R50-FPN 550x550, bs=8 per GPU (BASELINE.json configs[1]): backbone -> FPN ->
-protonet + prediction heads -> Detect (softmax, decode, fast-NMS) -> postprocess (mask assembly
-at 550x550, uint8) [-> RCCL all-gather of detection records when N>1].  `--model maskrcnn`
-switches to Mask R-CNN R50-FPN 1333x800 bs=2 (configs[2]) once that path is built.
+A "step" = one pass of the hot path over one batch of synthetic input that is already resident in HBM.
+Default workload = BASELINE.json configs[1]: Yolact R50-FPN 550x550, bs=8 per GPU: backbone -> FPN -> protonet +
+prediction heads -> Detect (softmax, decode, fast-NMS) -> postprocess (mask assembly at 550x550, uint8)
+[-> RCCL all-gather of detection records when N>1].  At N=1 the default run ALSO measures BASELINE configs[2] /
+north_star's own target (Mask R-CNN R50-FPN 1333x800: bs=2 throughput, bs=1 latency, conv roofline fraction, parity
+against the CPU oracle on the bench batch) and reports it under the "maskrcnn" key of the same JSON line.
+`--model maskrcnn [--depth 101] [--fp16] [--c4]` makes Mask R-CNN the measured workload itself.
 
 Prints ONE JSON line on rank 0 (contract in the task brief) with `roofline` and `cpu_baseline`.
 """
 import argparse
+import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -26,16 +33,19 @@ for p in (ROOT, PKG):
 import numpy as np  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32-input MFMA peak (spec)
-YOLACT_GFLOP_PER_IMAGE = 118.28  # algorithmic conv work per 550x550 image
+PEAK_F16_MFMA_TFLOPS = 2500.0  # dense f16 MFMA peak (spec, no sparsity)
+PROFILE_ROUND = "r02"
 
 
 def pmc_traffic(name):
     """HBM bytes per conv launch from the committed PMC summary (tools/pmc_summary.py), or None."""
-    try:
-        with open(os.path.join(ROOT, "profiles", name)) as f:
-            return json.load(f)["conv_mfma_kernel_all"]["hbm_bytes_per_launch"]
-    except Exception:
-        return None
+    for rnd in (PROFILE_ROUND, "r01"):
+        try:
+            with open(os.path.join(ROOT, "profiles", "%s_%s" % (rnd, name))) as f:
+                return json.load(f)["conv_mfma_kernel_all"]["hbm_bytes_per_launch"], "%s_%s" % (rnd, name)
+        except Exception:
+            continue
+    return None, None
 
 
 def parse():
@@ -53,6 +63,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8, help="images the CPU oracle is timed on")
     ap.add_argument("--no-latency", action="store_true", help="skip the extra bs=1 latency pass")
+    ap.add_argument("--no-maskrcnn", action="store_true", help="default yolact run: skip the extra Mask R-CNN R50-FPN measurement")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the extra timed loop that includes the pinned-host H2D of every batch")
     ap.add_argument("--single-stream", action="store_true", help="profiling aid: run the timed region on one stream too, so that "
                     "rocprofv3 per-kernel durations are not inflated by overlapping launches (throughput drops ~20 %%)")
     return ap.parse_args()
@@ -67,46 +79,178 @@ def emit(line):
     os.write(_JSON_FD if _JSON_FD is not None else 1, (line + "\n").encode())
 
 
-def main():
-    global _JSON_FD
-    a = parse()
+def spawn_ranks(a):
+    """--gpus N > 1 outside a torch.distributed environment: start the N ranks as CHILD processes (nothing in this process has
+    touched HIP), relay rank 0's JSON line, propagate the exit code."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    lines = [ln for ln in r.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        sys.stderr.write("bench.py: the %d-rank run failed (rc %d)\n" % (a.gpus, r.returncode))
+        raise SystemExit(r.returncode or 1)
+    sys.stdout.write(lines[-1] + "\n")
     sys.stdout.flush()
-    _JSON_FD = os.dup(1)
-    os.dup2(2, 1)
-    if a.model == "maskrcnn":
-        return main_maskrcnn(a)
-    a.batch = a.batch or 8
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if a.gpus != world and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    raise SystemExit(0)
 
-    force_dist = os.environ.get("ISEGMI_BENCH_FORCE_DIST") == "1"  # exercise the N>1 code path on a 1-GPU box
-    dist = None
-    if world > 1 or force_dist:
-        # torch.distributed is plumbing only (rendezvous, barrier, max-reduce of the wall time):
-        # CPU/gloo, so torch never touches the GPU.  The data-path collective is RCCL in libisegmi.
+
+def set_omp_threads(n):
+    """The oracle's OpenMP team size (libgomp is loaded with liboracle.so); OMP_NUM_THREADS only acts before that load."""
+    os.environ["OMP_NUM_THREADS"] = str(n)
+    try:
+        C.CDLL("libgomp.so.1").omp_set_num_threads(int(n))
+    except OSError:
+        pass
+
+
+def pct(xs, q):
+    xs = sorted(xs)
+    return xs[min(len(xs) - 1, int(q * len(xs)))] if xs else None
+
+
+class Dist:
+    """torch.distributed is plumbing only (rendezvous, barrier, max-reduce of the wall time): CPU/gloo, so torch never touches
+    the GPU.  The data-path collective is RCCL inside libisegmi."""
+
+    def __init__(self, a):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.force = os.environ.get("ISEGMI_BENCH_FORCE_DIST") == "1"  # exercise the N>1 code path on a 1-GPU box
+        if a.gpus != self.world:
+            sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d\n" % (a.gpus, self.world))
+            raise SystemExit(2)
+        self.pg = None
+        if self.world > 1 or self.force:
+            import torch.distributed as dist
+            dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+            self.pg = dist
+
+    @property
+    def on(self):
+        return self.pg is not None
+
+    def barrier(self):
+        if self.pg is not None:
+            self.pg.barrier()
+
+    def max(self, v):
+        if self.pg is None:
+            return v
         import torch
-        import torch.distributed as dist
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([v], dtype=torch.float64)
+        self.pg.all_reduce(t, op=self.pg.ReduceOp.MAX)
+        return float(t.item())
 
+    def make_gather(self, nbytes):
+        if self.pg is None:
+            return None
+        import torch
+        from isegmi.dist import RcclGather
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if self.rank == 0:
+            uid = torch.frombuffer(bytearray(RcclGather.unique_id()), dtype=torch.uint8).clone()
+        self.pg.broadcast(uid, 0)
+        return RcclGather(self.rank, self.world, bytes(uid.numpy().tobytes()), nbytes)
+
+    def close(self):
+        if self.pg is not None:
+            self.pg.barrier()
+            self.pg.destroy_process_group()
+
+
+def timed_region(net, step, full_sync, dist, steps):
+    """EXACTLY `steps` steps bracketed by barrier + full synchronisation on both sides; MAX over ranks.  Every step leaves a
+    completion mark on the stream its results finish on: the intervals are per-step latency samples of the pipelined run."""
+    dist.barrier()
+    full_sync()
+    net.step_times()  # drop stale marks
+    net.mark_step()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+        net.mark_step()
+    full_sync()
+    dist.barrier()
+    elapsed = dist.max(time.perf_counter() - t0)
+    return elapsed, net.step_times()
+
+
+def roofline_pass(net, step, full_sync, steps, single_stream):
+    """The same K steps again, single-stream, every conv launch bracketed by HIP events on the engine stream (per-launch
+    durations are not meaningful while launches from several streams overlap)."""
     from isegmi import _ffi
-    from isegmi.dist import RcclGather, record_bytes
-    from isegmi.weights import yolact_state_dict
-    from isegmi.yolact import Yolact, fast_base_transform
+    f, m, l = C.c_double(), C.c_double(), C.c_int64()
+    net.set_param("multi_stream", 0.0)
+    net.set_param("conv_timing", 1.0)
+    _ffi.check(_ffi.lib().isegmi_engine_conv_stats(net._h, C.byref(f), C.byref(m), C.byref(l)))  # reset
+    for i in range(steps):
+        step(i)
+    full_sync()
+    _ffi.check(_ffi.lib().isegmi_engine_conv_stats(net._h, C.byref(f), C.byref(m), C.byref(l)))
+    net.set_param("conv_timing", 0.0)
+    net.set_param("multi_stream", 0.0 if single_stream else 1.0)
+    return f.value, m.value, l.value
 
-    if _ffi.device_count() < 1:
-        raise SystemExit("no HIP device visible: bench.py measures the HIP path only (no CPU fallback)")
-    from isegmi.yolact import YolactConfig
+
+def h2d_region(net, pinned, run, full_sync, dist, steps):
+    """The timed region once more with a pinned-host asynchronous H2D of every batch inside the step: the copy of batch i+1 goes
+    to the other input buffer on the copy stream while batch i computes."""
+    net.upload_async(pinned, 0)
+    dist.barrier(); full_sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        if i + 1 < steps:
+            net.upload_async(pinned, (i + 1) & 1)
+        run(i & 1)
+    full_sync(); dist.barrier()
+    return dist.max(time.perf_counter() - t0)
+
+
+def latency_pass(net, run1, iters=13, drop=3):
+    lat = []
+    for i in range(iters):
+        net.sync()
+        ts = time.perf_counter()
+        run1()
+        net.sync()
+        lat.append((time.perf_counter() - ts) * 1e3)
+    lat = sorted(lat[drop:])
+    return {"p50_ms_per_image": round(lat[len(lat) // 2], 3), "img_per_s": round(1e3 / lat[len(lat) // 2], 2)}
+
+
+def roofline_dict(kernel, flops, ms, launches, steps, peak, traffic_file):
+    achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    traffic, src = pmc_traffic(traffic_file) if traffic_file else (None, None)
+    return {"bound": "mfma", "kernel": kernel,
+            "pass": "K single-stream steps right after the timed region, HIP events around every conv launch on the engine stream",
+            "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+            "traffic_note": ("HBM bytes per conv launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (profiles/%s; FETCH x2 gfx950 correction); not collected live" % src) if traffic else "null: no committed PMC pass for this configuration",
+            "algorithmic_gflop_per_step": round(flops / max(steps, 1) / 1e9, 2), "conv_ms_per_step": round(ms / max(steps, 1), 3),
+            "launches_per_step": launches // max(steps, 1), "avg_launch_us": round(ms * 1e3 / max(launches, 1), 2)}
+
+
+# ------------------------------------------------------------------------------------------------------------------ Yolact
+def bench_yolact(a, dist):
+    from isegmi import _ffi
+    from isegmi.dist import record_bytes
+    from isegmi.weights import yolact_state_dict
+    from isegmi.yolact import Yolact, YolactConfig, fast_base_transform
+    a.batch = a.batch or 8
+    rank, world = dist.rank, dist.world
     ycfg = {"resnet50": YolactConfig(), "base": YolactConfig.base(), "im700": YolactConfig.im700(),
             "plus_resnet50": YolactConfig.plus_resnet50(), "plus_base": YolactConfig.plus_base(), "darknet53": YolactConfig.darknet53()}[a.yolact_config]
     yname = {"resnet50": "Yolact R50-FPN", "base": "Yolact R101-FPN (yolact_base)", "im700": "Yolact R101-FPN 700 (yolact_im700)",
              "plus_resnet50": "YOLACT++ R50-FPN (DCNv2, 9 anchors, mask re-scoring)", "plus_base": "YOLACT++ R101-FPN (DCNv2 every 3rd block, 9 anchors, mask re-scoring)",
              "darknet53": "Yolact Darknet53-FPN (yolact_darknet53)"}[a.yolact_config]
     sd = yolact_state_dict(1234, ycfg.depth, ycfg.num_priors, ycfg.dcn_layers, ycfg.dcn_interval, ycfg.use_maskiou, ycfg.backbone)
-    net = Yolact(sd, ycfg, max_batch=a.batch, device=local_rank, fp16=a.fp16)
-    ypeak = 2500.0 if a.fp16 else PEAK_F32_MFMA_TFLOPS
+    net = Yolact(sd, ycfg, max_batch=a.batch, device=dist.local_rank, fp16=a.fp16)
+    ypeak = PEAK_F16_MFMA_TFLOPS if a.fp16 else PEAK_F32_MFMA_TFLOPS
     if a.single_stream:
         net.set_param("multi_stream", 0.0)
     size = net.size
@@ -118,21 +262,16 @@ def main():
     else:
         imgs = fast_base_transform(raw)
     net.upload(imgs)
+    gather = dist.make_gather(record_bytes(a.batch))
 
-    gather = None
-    if world > 1 or force_dist:
-        import torch
-        uid = torch.zeros(128, dtype=torch.uint8)
-        if rank == 0:
-            uid = torch.frombuffer(bytearray(RcclGather.unique_id()), dtype=torch.uint8).clone()
-        dist.broadcast(uid, 0)
-        gather = RcclGather(rank, world, bytes(uid.numpy().tobytes()), record_bytes(a.batch))
-
-    def step():
-        net.forward_device(a.batch)
+    def run(slot=0):
+        net.forward_device(a.batch, slot)
         net.postprocess_device(size, size)
         if gather is not None:
             gather.gather_from(net)
+
+    def step(i):
+        run(0)
 
     def full_sync():
         net.sync()
@@ -141,293 +280,267 @@ def main():
         _ffi.sync()
 
     for _ in range(max(a.warmup, 1 if gather is not None else 0)):
-        step()
+        run()
     full_sync()
-    import ctypes as C
-    f, m, l = C.c_double(), C.c_double(), C.c_int64()
-
-    if dist is not None:
-        dist.barrier()
-    full_sync()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    full_sync()
-    if dist is not None:
-        dist.barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    if dist is not None:
-        import torch
-        te = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
-
-    # roofline pass: the same K steps again, single-stream, every conv launch bracketed by HIP events on the
-    # engine stream (per-launch durations are not meaningful while launches from several streams overlap)
-    net.set_param("multi_stream", 0.0)
-    net.set_param("conv_timing", 1.0)
-    _ffi.check(_ffi.lib().isegmi_engine_conv_stats(net._h, C.byref(f), C.byref(m), C.byref(l)))  # reset
-    for _ in range(a.steps):
-        step()
-    full_sync()
-    _ffi.check(_ffi.lib().isegmi_engine_conv_stats(net._h, C.byref(f), C.byref(m), C.byref(l)))
-    net.set_param("conv_timing", 0.0)
-    net.set_param("multi_stream", 0.0 if a.single_stream else 1.0)
-    conv_flops, conv_ms, conv_launches = f.value, m.value, l.value
-
-    counts = net.fetch("det.count", a.batch)
-    total_images = a.batch * world * a.steps
-    value = total_images / elapsed
-
-    out = None
-    if rank == 0:
-        achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-        out = {
-            "metric": "images/sec (%s %dx%d, bs=%d per GPU, %s)" % (yname, size, size, a.batch, "fp16 storage / f16 MFMA, fp32 accumulate (optional mode, not configs[1])" if a.fp16 else "fp32"),
-            "value": round(value, 2),
-            "unit": "img/s",
-            "n_gpus": world,
-            "steps": a.steps,
-            "warmup": a.warmup,
-            "ms_per_step": round(elapsed / a.steps * 1e3, 3),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f16" if a.fp16 else "f32",
-            "data": "synthetic",
-            "config": {"workload": "%s %dx%d bs=%d/GPU random weights: backbone+FPN+protonet+heads+Detect(fast-NMS)+%dx%d mask assembly%s" % (
-                           yname, size, size, a.batch, size, size, " (BASELINE configs[1])" if a.yolact_config == "resnet50" else " (variant, not configs[1])"),
-                       "global_batch": a.batch * world, "parallelism": "batch-sharded x%d, RCCL all-gather of detections" % world,
-                       "detections_per_image_rank0": [int(c) for c in counts]},
-            "roofline": {
-                "bound": "mfma",
-                "kernel": ("conv_f16_glds / conv3x3_f16_strip kernels (all %d conv launches of a step, v_mfma_f32_32x32x16_f16)" if a.fp16 else "conv_mfma_kernel + conv_mfma16_kernel (all %d conv launches of a step; v_mfma_f32_32x32x2_f32 on 64x64 tiles, v_mfma_f32_16x16x4_f32 on the 32x32 blocks of small grids)") % (conv_launches // max(a.steps, 1)),
-                "pass": "K single-stream steps right after the timed region, HIP events around every conv launch",
-                "achieved": round(achieved, 2),
-                "peak": ypeak,
-                "unit": "TFLOP/s",
-                "frac": round(achieved / ypeak, 4),
-                "traffic": None if (a.fp16 or a.yolact_config != "resnet50") else pmc_traffic("r01_pmc_yolact.json"),  # null: no committed PMC pass for this variant
-                "traffic_note": "HBM bytes per conv launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (profiles/r01_pmc_yolact.json; FETCH x2 gfx950 correction); not collected live",
-                "algorithmic_gflop_per_step": round(conv_flops / max(a.steps, 1) / 1e9, 2),
-                "conv_ms_per_step": round(conv_ms / max(a.steps, 1), 3),
-                "launches_per_step": conv_launches // max(a.steps, 1),
-                "avg_launch_us": round(conv_ms * 1e3 / max(conv_launches, 1), 2),
-            },
-            "p50_ms_per_image": round(elapsed / a.steps * 1e3 / a.batch, 3),
-        }
-
-    # ---- extra: bs=1 latency pass (metric also asks for bs=1 img/s and p50 per-image latency)
-    if rank == 0 and not a.no_latency:
-        lat = []
-        for i in range(13):
-            net.sync()
-            ts = time.perf_counter()
-            net.forward_device(1)
-            net.postprocess_device(size, size)
-            net.sync()
-            lat.append((time.perf_counter() - ts) * 1e3)
-        lat = sorted(lat[3:])
-        out["bs1"] = {"p50_ms_per_image": round(lat[len(lat) // 2], 3), "img_per_s": round(1e3 / lat[len(lat) // 2], 2)}
-        # same pass with the forward replayed as one hipGraph (latency mode: removes the per-launch gaps)
-        net.set_param("graph", 1.0)
-        lat = []
-        for i in range(14):
-            net.sync()
-            ts = time.perf_counter()
-            net.forward_device(1)
-            net.postprocess_device(size, size)
-            net.sync()
-            lat.append((time.perf_counter() - ts) * 1e3)
-        lat = sorted(lat[4:])
-        out["bs1_hipgraph"] = {"p50_ms_per_image": round(lat[len(lat) // 2], 3), "img_per_s": round(1e3 / lat[len(lat) // 2], 2)}
-        net.set_param("graph", 0.0)
+    elapsed, step_ms = timed_region(net, step, full_sync, dist, a.steps)
+    conv_flops, conv_ms, conv_launches = roofline_pass(net, step, full_sync, a.steps, a.single_stream)
+    # what the GPU produced for the bench batch (compared with the oracle below, before anything else runs a forward)
+    gpu = {k: net.fetch(k, a.batch) for k in ("det.count", "det.prior", "det.class", "det.score", "det.box", "det.coeff", "det.masks", "det.box_int")}
+    rccl = None
+    if gather is not None:
+        from isegmi.dist import unpack_records
+        blocks = gather.fetch()
+        rccl = {"rccl_ranks": int(gather.world), "ranks_with_records": int(sum(1 for r in range(world) if unpack_records(blocks[r], a.batch)["count"].any()))}
+    h2d_elapsed = None
+    if not a.no_h2d:
+        pinned = _ffi.PinnedBuffer(imgs.shape)
+        pinned.array[...] = imgs
+        h2d_elapsed = h2d_region(net, pinned, run, full_sync, dist, a.steps)
+        net.upload(imgs)
+        full_sync()
+        pinned.free()
+    counts = gpu["det.count"]
+    value = a.batch * world * a.steps / elapsed
+    if rank != 0:
+        return None, net, gather
+    fp16_note = "fp16 storage / f16 MFMA, fp32 accumulate (optional mode, not configs[1])" if a.fp16 else "fp32"
+    out = {
+        "metric": "images/sec (%s %dx%d, bs=%d per GPU, %s)" % (yname, size, size, a.batch, fp16_note),
+        "value": round(value, 2), "unit": "img/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f16" if a.fp16 else "f32", "data": "synthetic",
+        "config": {"workload": "%s %dx%d bs=%d/GPU random weights: backbone+FPN+protonet+heads+Detect(fast-NMS)+%dx%d mask assembly%s" % (
+                       yname, size, size, a.batch, size, size, " (BASELINE configs[1])" if a.yolact_config == "resnet50" and not a.fp16 else " (variant, not configs[1])"),
+                   "global_batch": a.batch * world, "parallelism": "batch-sharded x%d, RCCL all-gather of detections" % world,
+                   "detections_per_image_rank0": [int(c) for c in counts]},
+        "roofline": roofline_dict(("conv_f16_glds / conv3x3_f16_strip kernels (all conv launches of a step, v_mfma_f32_32x32x16_f16)" if a.fp16 else
+                                   "conv_mfma_kernel + conv_mfma16_kernel (all conv launches of a step; v_mfma_f32_32x32x2_f32 on 64x64 tiles, v_mfma_f32_16x16x4_f32 on the 32x32 / 32x64 blocks of small grids)"),
+                                  conv_flops, conv_ms, conv_launches, a.steps, ypeak, None if (a.fp16 or a.yolact_config != "resnet50") else "pmc_yolact.json"),
+        "step_ms": {"mean": round(elapsed / a.steps * 1e3, 3), "p50": round(pct(step_ms, 0.5), 3), "p90": round(pct(step_ms, 0.9), 3),
+                    "note": "intervals between consecutive per-step completion events on the results stream (pipelined multi-stream run)"},
+        "mean_ms_per_image": round(elapsed / a.steps * 1e3 / a.batch, 3),
+        "p50_ms_per_image": round(pct(step_ms, 0.5) / a.batch, 3),
+    }
+    if h2d_elapsed is not None:
+        out["value_incl_h2d"] = round(a.batch * world * a.steps / h2d_elapsed, 2)
+        out["h2d_note"] = "same K steps with a pinned-host async H2D of every batch (%.1f MB) on a copy stream, double-buffered input; `value` itself has the batch resident in HBM" % (imgs.nbytes / 1e6)
+    if rccl:
+        out.update(rccl)
+    if not a.no_latency:
+        out["bs1"] = latency_pass(net, lambda: (net.forward_device(1), net.postprocess_device(size, size)))
         net.set_param("timing", 1.0)
         net.forward_device(a.batch); net.postprocess_device(size, size); net.sync()
         out["stage_ms_bs%d" % a.batch] = {k: round(v, 3) for k, v in net.timings()}
         net.set_param("timing", 0.0)
 
-    # ---- CPU baseline: the oracle restatement on the host cores (rank 0, N=1 only)
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    # ---- CPU baseline: the oracle restatement on the host cores (rank 0, N=1 only); doubles as the parity check of this batch
+    if world == 1 and not a.no_cpu_baseline:
         from oracle.yolact_ref import YolactRef
         ncpu = min(len(os.sched_getaffinity(0)), 16)  # the GPU box's CPU share for one GPU
-        os.environ["OMP_NUM_THREADS"] = str(ncpu)
+        set_omp_threads(ncpu)
         ref = YolactRef(sd, max_size=ycfg.max_size, scales=ycfg.pred_scales, depth=ycfg.depth, scales_per_level=ycfg.scales_per_level,
                         square=ycfg.use_square_anchors)
         k = max(1, min(a.cpu_sample, a.batch))
         tc = time.perf_counter()
-        done = 0
-        dets = None
+        done, dets, posts = 0, None, None
         while True:  # bounded sample: whole passes over k images until ~10 s of CPU work (cap: 6 passes)
             d_ = ref.forward(imgs[:k])
-            for d in d_:
-                YolactRef.postprocess(d, size, size)
-            dets = dets or d_
+            p_ = [YolactRef.postprocess(d, size, size) for d in d_]
+            dets, posts = dets or d_, posts or p_
             done += k
             tcpu = time.perf_counter() - tc
             if tcpu >= 10.0 or done >= 6 * k:
                 break
         out["cpu_baseline"] = {"value": round(done / tcpu, 4), "unit": "img/s", "cores": ncpu, "kind": "port",
                                "sample": "%d images (passes over %d images of the bench batch), oracle/ C+numpy restatement (AVX2 FMA + OpenMP, %d threads), %.1f s" % (done, k, ncpu, tcpu)}
-        # the oracle run doubles as a parity check of this very batch
-        got = net.fetch("det.prior", a.batch)
-        ok = all(np.array_equal(got[i, : len(dets[i]["prior"])], dets[i]["prior"]) for i in range(k))
+        set_omp_threads(1)
+        tc = time.perf_counter()
+        d1 = ref.forward(imgs[:1])
+        YolactRef.postprocess(d1[0], size, size)
+        t1 = time.perf_counter() - tc
+        set_omp_threads(ncpu)
+        out["cpu_baseline"]["value_1thread"] = round(1.0 / t1, 4)
+        out["cpu_baseline"]["sample_1thread"] = "1 image of the bench batch, 1 thread, %.1f s" % t1
         if not a.fp16:  # the fp16 mode is tolerance-parity (tests), not index-exact
+            ok = True
+            for i in range(k):
+                r, (rc, rs, rb, rm) = dets[i], posts[i]
+                c = len(r["score"])
+                ok &= int(gpu["det.count"][i]) == c
+                ok &= all(np.array_equal(gpu[g][i, :c], r[o]) for g, o in (("det.prior", "prior"), ("det.class", "cls"), ("det.score", "score"),
+                                                                          ("det.box", "box"), ("det.coeff", "mask")))
+                if not ycfg.use_maskiou:
+                    ok &= np.array_equal(gpu["det.box_int"][i, :c], rb) and np.array_equal(gpu["det.masks"][i, :c], rm)
             out["parity_vs_oracle_on_bench_batch"] = bool(ok)
-
-    if rank == 0:
-        emit(json.dumps(out))
-    if gather is not None:
-        gather.close()
-    net.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+            out["parity_note"] = "%d images: detection count, prior index, class, score, box, coefficients, integer boxes and %dx%d masks all bit-equal" % (k, size, size)
+    return out, net, gather
 
 
-def main_maskrcnn(a):
-    """Mask R-CNN R50-FPN 1333x800 (padded 800x1344), bs=2 per GPU: BASELINE configs[2]; step = forward + Masker paste."""
-    import ctypes as C
-    a.batch = a.batch or 2
-    rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+# ------------------------------------------------------------------------------------------------------------ Mask R-CNN
+def bench_maskrcnn(a, dist, summary=False):
+    """Mask R-CNN R50-FPN 1333x800 (padded 800x1344), bs=2 per GPU: BASELINE configs[2]; step = forward + Masker paste.
+    summary=True: the compact record the default (Yolact) run embeds under "maskrcnn"."""
     from isegmi import _ffi
     from isegmi.maskrcnn import MaskRCNN, MaskRCNNConfig, prepare_images
     from isegmi.weights import maskrcnn_state_dict
-    if _ffi.device_count() < 1:
-        raise SystemExit("no HIP device visible: bench.py measures the HIP path only (no CPU fallback)")
-    if a.c4:
+    batch = 2 if summary else (a.batch or 2)
+    depth, fp16, c4 = (50, False, False) if summary else (a.depth, a.fp16, a.c4)
+    rank, world = dist.rank, dist.world
+    if c4:
         from isegmi.weights import maskrcnn_c4_state_dict
-        assert not a.fp16 and a.depth == 50, "--c4 is R-50, fp32"
+        assert not fp16 and depth == 50, "--c4 is R-50, fp32"
         sd, mcfg = maskrcnn_c4_state_dict(1234), MaskRCNNConfig.c4()
     else:
-        sd, mcfg = maskrcnn_state_dict(1234, depth=a.depth), MaskRCNNConfig(depth=a.depth)
+        sd, mcfg = maskrcnn_state_dict(1234, depth=depth), MaskRCNNConfig(depth=depth)
     rng = np.random.default_rng(20261003 + rank)
-    imgs = [rng.uniform(0, 255, (800, 1333, 3)).astype(np.float32) for _ in range(a.batch)]
+    imgs = [rng.uniform(0, 255, (800, 1333, 3)).astype(np.float32) for _ in range(batch)]
     x, hw = prepare_images(imgs, mcfg.SIZE_DIVISIBILITY)
-    model = MaskRCNN(sd, x.shape[1], x.shape[2], cfg=mcfg, max_batch=a.batch, device=local_rank, fp16=a.fp16)
+    model = MaskRCNN(sd, x.shape[1], x.shape[2], cfg=mcfg, max_batch=batch, device=dist.local_rank, fp16=fp16)
     if a.single_stream:
         model.set_param("multi_stream", 0.0)
-    tag = "R50-C4" if a.c4 else "R%d-FPN" % a.depth
-    prec = "fp16 storage / f16 MFMA, fp32 accumulate" if a.fp16 else "fp32"
-    peak = 2500.0 if a.fp16 else PEAK_F32_MFMA_TFLOPS  # dense f16 MFMA peak (MI355X_MICROARCH.md) vs f32 MFMA peak
+    tag = "R50-C4" if c4 else "R%d-FPN" % depth
+    prec = "fp16 storage / f16 MFMA, fp32 accumulate" if fp16 else "fp32"
+    peak = PEAK_F16_MFMA_TFLOPS if fp16 else PEAK_F32_MFMA_TFLOPS
     model.upload(x, hw)
     gather = None
-    if world > 1:
-        import torch
-        from isegmi.dist import RcclGather, maskrcnn_record_bytes
-        uid = torch.zeros(128, dtype=torch.uint8)
-        if rank == 0:
-            uid = torch.frombuffer(bytearray(RcclGather.unique_id()), dtype=torch.uint8).clone()
-        dist.broadcast(uid, 0)
-        gather = RcclGather(rank, world, bytes(uid.numpy().tobytes()), maskrcnn_record_bytes(a.batch, M=14 if a.c4 else 28))
+    if not summary:
+        from isegmi.dist import maskrcnn_record_bytes
+        gather = dist.make_gather(maskrcnn_record_bytes(batch, M=14 if c4 else 28))
 
-    def step():
-        model.forward_device(a.batch)
+    def run(slot=0):
+        model.forward_device(batch, slot)
         model.paste_device(800, 1333)
         if gather is not None:
             gather.gather_from(model)
 
-    for _ in range(max(a.warmup, 1 if gather is not None else 0)):
-        step()
-    model.sync(); _ffi.sync()
+    def step(i):
+        run(0)
+
+    def full_sync():
+        model.sync()
+        if gather is not None:
+            gather.wait()
+        _ffi.sync()
+
+    steps, warmup = a.steps, a.warmup
+    for _ in range(max(warmup, 1 if gather is not None else 0)):
+        run()
+    full_sync()
+    elapsed, step_ms = timed_region(model, step, full_sync, dist, steps)
+    flops, ms, launches = roofline_pass(model, step, full_sync, steps, a.single_stream)
+    names = ("det.count", "det.score", "det.label", "det.box", "det.mask14" if c4 else "det.mask28", "det.masks", "proposal_count", "proposals")
+    gpu = {k: model.fetch(k, batch) for k in names}
+    rccl = None
     if gather is not None:
-        gather.wait()
-    f, m, l = C.c_double(), C.c_double(), C.c_int64()
-    if dist is not None:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    model.sync()
-    if gather is not None:
-        gather.wait()
-    _ffi.sync()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        te = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
-    model.set_param("multi_stream", 0.0)
-    model.set_param("conv_timing", 1.0)
-    _ffi.check(_ffi.lib().isegmi_engine_conv_stats(model._h, C.byref(f), C.byref(m), C.byref(l)))
-    for _ in range(a.steps):
-        step()
-    model.sync(); _ffi.sync()
-    _ffi.check(_ffi.lib().isegmi_engine_conv_stats(model._h, C.byref(f), C.byref(m), C.byref(l)))
-    model.set_param("conv_timing", 0.0)
-    model.set_param("multi_stream", 0.0 if a.single_stream else 1.0)
-    if rank == 0:
-        achieved = f.value / (m.value * 1e-3) / 1e12 if m.value > 0 else 0.0
-        cnt = model.fetch("det.count", a.batch); pc = model.fetch("proposal_count", a.batch)
-        out = {"metric": "images/sec (Mask R-CNN %s 1333x800, bs=%d per GPU, %s)" % (tag, a.batch, prec),
-               "value": round(a.batch * world * a.steps / elapsed, 3), "unit": "img/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-               "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f16" if a.fp16 else "f32", "data": "synthetic",
-               "config": {"workload": ("Mask R-CNN %s 1333x800 (padded 800x1344) bs=%d/GPU random weights, %s: conv1-4 + single-map RPN (6000 -> 1000) + RoIAlign + conv5 head + NMS + shared-extractor mask branch + paste (the README.md:263-273 config; not a BASELINE config)" % (tag, a.batch, prec)) if a.c4 else "Mask R-CNN %s 1333x800 (padded 800x1344) bs=%d/GPU random weights, %s: backbone+FPN+RPN+RoIAlign+box head+NMS+mask head+paste (BASELINE configs[%d])" % (tag, a.batch, prec, 4 if a.fp16 else 2),
-                          "global_batch": a.batch * world, "parallelism": "batch-sharded x%d" % world,
-                          "proposals_per_image": [int(c) for c in pc], "detections_per_image": [int(c) for c in cnt]},
-               "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel + conv_mfma16_kernel (all conv launches of a step)",
-                            "pass": "K single-stream steps right after the timed region, HIP events around every conv launch", "achieved": round(achieved, 2),
-                            "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": pmc_traffic("r01_pmc_r101f16.json") if (a.fp16 and a.depth == 101 and a.batch == 8 and not a.c4) else None if (a.fp16 or a.c4 or a.depth != 50 or a.batch != 2) else pmc_traffic("r01_pmc_maskrcnn.json"),
-                            "traffic_note": "HBM bytes per conv launch from separate rocprofv3 --pmc passes of this command (tools/profile_round.sh -> profiles/r01_pmc_maskrcnn.json / r01_pmc_r101f16.json; FETCH x2 gfx950 correction); not collected live; null for configurations without a committed PMC pass",
-                            "algorithmic_gflop_per_step": round(f.value / a.steps / 1e9, 2), "conv_ms_per_step": round(m.value / a.steps, 3),
-                            "launches_per_step": l.value // a.steps, "avg_launch_us": round(m.value * 1e3 / max(l.value, 1), 2)},
-               "p50_ms_per_image": round(elapsed / a.steps * 1e3 / a.batch, 3)}
-        if not a.no_latency:
-            lat = []
-            model.upload(x[:1], hw[:1])
-            for i in range(9):
-                model.sync(); ts = time.perf_counter()
-                model.forward_device(1); model.paste_device(800, 1333); model.sync()
-                lat.append((time.perf_counter() - ts) * 1e3)
-            lat = sorted(lat[2:])
-            out["bs1"] = {"p50_ms_per_image": round(lat[len(lat) // 2], 3), "img_per_s": round(1e3 / lat[len(lat) // 2], 2)}
-            model.set_param("graph", 1.0)  # the forward replayed as one hipGraph (latency mode)
-            lat = []
-            for i in range(11):
-                model.sync(); ts = time.perf_counter()
-                model.forward_device(1); model.paste_device(800, 1333); model.sync()
-                lat.append((time.perf_counter() - ts) * 1e3)
-            lat = sorted(lat[4:])
-            out["bs1_hipgraph"] = {"p50_ms_per_image": round(lat[len(lat) // 2], 3), "img_per_s": round(1e3 / lat[len(lat) // 2], 2)}
-            model.set_param("graph", 0.0)
-            model.upload(x, hw)
+        from isegmi.dist import unpack_maskrcnn_records
+        blocks = gather.fetch()
+        rccl = {"rccl_ranks": int(gather.world), "ranks_with_records": int(sum(1 for r in range(world) if unpack_maskrcnn_records(blocks[r], batch, M=14 if c4 else 28)["count"].any()))}
+    h2d_elapsed = None
+    if not a.no_h2d:
+        pinned = _ffi.PinnedBuffer(x.shape)
+        pinned.array[...] = x
+        h2d_elapsed = h2d_region(model, pinned, run, full_sync, dist, steps)
+        model.upload(x, hw)
+        full_sync()
+        pinned.free()
+    if rank != 0:
+        return None, model, gather
+    value = batch * world * steps / elapsed
+    traffic_file = "pmc_r101f16.json" if (fp16 and depth == 101 and batch == 8 and not c4) else None if (fp16 or c4 or depth != 50 or batch != 2) else "pmc_maskrcnn.json"
+    roof = roofline_dict("conv_f16_glds / conv3x3_f16_strip kernels (all conv launches of a step)" if fp16 else "conv_mfma_kernel + conv_mfma16_kernel (all conv launches of a step)",
+                         flops, ms, launches, steps, peak, traffic_file)
+    workload = ("Mask R-CNN %s 1333x800 (padded 800x1344) bs=%d/GPU random weights, %s: conv1-4 + single-map RPN (6000 -> 1000) + RoIAlign + conv5 head + NMS + shared-extractor mask branch + paste (the README.md:263-273 config; not a BASELINE config)" % (tag, batch, prec)) if c4 else \
+        "Mask R-CNN %s 1333x800 (padded 800x1344) bs=%d/GPU random weights, %s: backbone+FPN+RPN+RoIAlign+box head+NMS+mask head+paste (BASELINE configs[%d])" % (tag, batch, prec, 4 if fp16 else 2)
+    out = {"metric": "images/sec (Mask R-CNN %s 1333x800, bs=%d per GPU, %s)" % (tag, batch, prec),
+           "value": round(value, 3), "unit": "img/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+           "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f16" if fp16 else "f32", "data": "synthetic",
+           "config": {"workload": workload, "global_batch": batch * world, "parallelism": "batch-sharded x%d, RCCL all-gather of detection records" % world,
+                      "proposals_per_image": [int(c) for c in gpu["proposal_count"]], "detections_per_image": [int(c) for c in gpu["det.count"]]},
+           "roofline": roof,
+           "step_ms": {"mean": round(elapsed / steps * 1e3, 3), "p50": round(pct(step_ms, 0.5), 3), "p90": round(pct(step_ms, 0.9), 3),
+                       "note": "intervals between consecutive per-step completion events on the results stream (pipelined multi-stream run)"},
+           "mean_ms_per_image": round(elapsed / steps * 1e3 / batch, 3), "p50_ms_per_image": round(pct(step_ms, 0.5) / batch, 3)}
+    if h2d_elapsed is not None:
+        out["value_incl_h2d"] = round(batch * world * steps / h2d_elapsed, 3)
+        out["h2d_note"] = "same K steps with a pinned-host async H2D of every batch (%.1f MB) on a copy stream, double-buffered input" % (x.nbytes / 1e6)
+    if rccl:
+        out.update(rccl)
+    if not a.no_latency:
+        model.upload(x[:1], hw[:1])
+        out["bs1"] = latency_pass(model, lambda: (model.forward_device(1), model.paste_device(800, 1333)), iters=11, drop=3)
+        model.upload(x, hw)
+        if not summary:
             model.set_param("timing", 1.0)
-            step(); model.sync()
-            out["stage_ms_bs%d" % a.batch] = {k: round(v, 3) for k, v in model.timings()}
+            run(); model.sync()
+            out["stage_ms_bs%d" % batch] = {k: round(v, 3) for k, v in model.timings()}
             model.set_param("timing", 0.0)
-        if world == 1 and not a.no_cpu_baseline and not a.fp16 and a.depth == 50 and not a.c4:
-            from oracle.maskrcnn_ref import MaskRCNNRef
-            ncpu = min(len(os.sched_getaffinity(0)), 16)
-            os.environ["OMP_NUM_THREADS"] = str(ncpu)
-            ref = MaskRCNNRef(sd)
+    if world == 1 and not a.no_cpu_baseline and not fp16 and depth == 50 and not c4:
+        from oracle.maskrcnn_ref import MaskRCNNRef
+        ncpu = min(len(os.sched_getaffinity(0)), 16)
+        set_omp_threads(ncpu)
+        ref = MaskRCNNRef(sd)
+        tc = time.perf_counter()
+        rd = ref.forward(x, hw)  # the whole bench batch: timing sample AND parity reference
+        pasted = [MaskRCNNRef.paste(r, 800, 1333)[0] for r in rd]
+        tcpu = time.perf_counter() - tc
+        out["cpu_baseline"] = {"value": round(batch / tcpu, 4), "unit": "img/s", "cores": ncpu, "kind": "port",
+                               "sample": "one pass over the %d images of the bench batch, oracle/ C+numpy restatement (AVX2 FMA + OpenMP, %d threads), %.1f s" % (batch, ncpu, tcpu)}
+        if not summary:
+            set_omp_threads(1)
             tc = time.perf_counter()
-            done = 0
-            d = None
-            while True:  # bounded sample: whole images until ~10 s of CPU work (cap 6)
-                d_ = ref.forward(x[:1], hw[:1])
-                MaskRCNNRef.paste(d_[0], 800, 1333)
-                d = d or d_
-                done += 1
-                tcpu = time.perf_counter() - tc
-                if tcpu >= 10.0 or done >= 6:
-                    break
-            out["cpu_baseline"] = {"value": round(done / tcpu, 4), "unit": "img/s", "cores": ncpu, "kind": "port",
-                                   "sample": "%d passes over 1 image of the bench batch, oracle/ C+numpy restatement (AVX2 FMA + OpenMP, %d threads), %.1f s" % (done, ncpu, tcpu)}
-            got = model.fetch("det.box", 1)[0]
-            out["parity_vs_oracle_on_bench_batch"] = bool(np.array_equal(got[: len(d[0]["box"])], d[0]["box"]))
+            r1 = ref.forward(x[:1], hw[:1]); MaskRCNNRef.paste(r1[0], 800, 1333)
+            t1 = time.perf_counter() - tc
+            set_omp_threads(ncpu)
+            out["cpu_baseline"]["value_1thread"] = round(1.0 / t1, 4)
+            out["cpu_baseline"]["sample_1thread"] = "1 image of the bench batch, 1 thread, %.1f s" % t1
+        ok = True
+        for i in range(batch):
+            r = rd[i]
+            c = len(r["score"])
+            ok &= int(gpu["det.count"][i]) == c and int(gpu["proposal_count"][i]) == len(r["proposals"])
+            ok &= np.array_equal(gpu["proposals"][i, : len(r["proposals"])], r["proposals"])
+            ok &= all(np.array_equal(gpu[g][i, :c], r[o]) for g, o in (("det.score", "score"), ("det.label", "label"), ("det.box", "box"), ("det.mask28", "mask28")))
+            ok &= np.array_equal(gpu["det.masks"][i, :c], pasted[i])
+        out["parity_vs_oracle_on_bench_batch"] = bool(ok)
+        out["parity_note"] = "%d images: proposals, detection count, score, label, box, 28x28 masks and the masks pasted at 800x1333 all bit-equal" % batch
+    if summary:
+        keep = {"workload": out["config"]["workload"], "img_per_s": out["value"], "batch": batch, "ms_per_step": out["ms_per_step"], "steps": steps, "warmup": warmup,
+                "step_ms": out["step_ms"], "value_incl_h2d": out.get("value_incl_h2d"), "bs1": out.get("bs1"),
+                "roofline": {k: roof[k] for k in ("achieved", "peak", "unit", "frac", "conv_ms_per_step", "launches_per_step", "algorithmic_gflop_per_step")},
+                "detections_per_image": out["config"]["detections_per_image"], "proposals_per_image": out["config"]["proposals_per_image"],
+                "cpu_baseline": out.get("cpu_baseline"), "parity_vs_oracle_on_bench_batch": out.get("parity_vs_oracle_on_bench_batch"),
+                "north_star_target": "Mask R-CNN R50-FPN 1333x800 bs=1 >= 30 img/s: bs1.img_per_s"}
+        return keep, model, gather
+    return out, model, gather
+
+
+def main():
+    global _JSON_FD
+    a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(a)
+    sys.stdout.flush()
+    _JSON_FD = os.dup(1)
+    os.dup2(2, 1)
+    dist = Dist(a)
+    from isegmi import _ffi
+    if _ffi.device_count() < 1:
+        raise SystemExit("no HIP device visible: bench.py measures the HIP path only (no CPU fallback)")
+    if a.model == "maskrcnn":
+        out, net, gather = bench_maskrcnn(a, dist)
+    else:
+        out, net, gather = bench_yolact(a, dist)
+    if gather is not None:
+        gather.close()
+    net.close()
+    if out is not None and a.model == "yolact" and dist.world == 1 and not dist.on and not a.no_maskrcnn and a.yolact_config == "resnet50" and not a.fp16:
+        m, model, _ = bench_maskrcnn(a, dist, summary=True)
+        out["maskrcnn"] = m
+        model.close()
+    if out is not None:
         emit(json.dumps(out))
-    model.close()
-    if dist is not None:
-        dist.barrier(); dist.destroy_process_group()
+    dist.close()
 
 
 if __name__ == "__main__":

@@ -101,6 +101,31 @@ class DeviceBuffer:
             pass
 
 
+class PinnedBuffer:
+    """Page-locked host memory with a numpy view (`.array`): the source of the engines' asynchronous uploads."""
+
+    def __init__(self, shape, dtype=np.float32):
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        p = C.c_void_p()
+        check(lib().isegmi_malloc_host(C.byref(p), C.c_int64(self.nbytes)))
+        self.ptr = p
+        self.array = np.frombuffer((C.c_char * self.nbytes).from_address(p.value), self.dtype).reshape(self.shape)
+
+    def free(self):
+        if self.ptr is not None and self.ptr.value:
+            self.array = None
+            lib().isegmi_free_host(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 def _ptr(b):
     return None if b is None else b.ptr
 

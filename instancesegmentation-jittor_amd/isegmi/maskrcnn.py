@@ -302,8 +302,8 @@ class MaskRCNN:
         assert self._hw.shape[0] == x.shape[0]
         return x.shape[0]
 
-    def forward_device(self, n):
-        _ffi.check(_ffi.lib().isegmi_maskrcnn_forward(self._h, self._d_in.ptr, self._hw.ctypes.data_as(C.c_void_p), n))
+    def forward_device(self, n, slot=0):
+        _ffi.check(_ffi.lib().isegmi_maskrcnn_forward(self._h, self.input_buffer(slot).ptr, self._hw.ctypes.data_as(C.c_void_p), n))
 
     def paste_device(self, out_h, out_w, orig_sizes_wh=None):
         """Masker paste into (out_h, out_w); orig_sizes_wh [N,2] are the sizes boxes are resized to (default: no resize)."""
@@ -354,3 +354,7 @@ from .yolact import Yolact as _Y  # noqa: E402
 
 MaskRCNN.fetch = _Y.fetch
 MaskRCNN.timings = _Y.timings
+MaskRCNN.input_buffer = _Y.input_buffer
+MaskRCNN.upload_async = _Y.upload_async
+MaskRCNN.mark_step = _Y.mark_step
+MaskRCNN.step_times = _Y.step_times

@@ -245,11 +245,36 @@ class Yolact:
         _ffi.check(_ffi.lib().isegmi_h2d(self._d_in.ptr, x.ctypes.data_as(C.c_void_p), C.c_int64(x.nbytes)))
         return x.shape[0]
 
-    def forward_device(self, n):
+
+    def input_buffer(self, slot=0):
+        """Device input buffer `slot` (0 or 1; the second one is allocated on first use, for double-buffered uploads)."""
+        if slot == 0:
+            return self._d_in
+        if getattr(self, "_d_in2", None) is None:
+            self._d_in2 = _ffi.DeviceBuffer(self._d_in.shape)
+        return self._d_in2
+
+    def upload_async(self, pinned, slot=0):
+        """Asynchronous H2D of a whole batch from a _ffi.PinnedBuffer into input buffer `slot` on the engine's copy stream; the
+        next forward is ordered behind it and it is ordered behind the previous forward's read of its input."""
+        d = self.input_buffer(slot)
+        assert pinned.nbytes <= d.nbytes
+        _ffi.check(_ffi.lib().isegmi_engine_upload_async(self._h, d.ptr, pinned.ptr, C.c_int64(pinned.nbytes)))
+
+    def mark_step(self):
+        _ffi.check(_ffi.lib().isegmi_engine_mark_step(self._h))
+
+    def step_times(self, cap=65536):
+        """Intervals (ms) between consecutive mark_step() completion marks; clears the marks."""
+        ms = (C.c_float * cap)(); cnt = C.c_int()
+        _ffi.check(_ffi.lib().isegmi_engine_step_times(self._h, ms, cap, C.byref(cnt)))
+        return [float(ms[i]) for i in range(cnt.value)]
+
+    def forward_device(self, n, slot=0):
         """Launch forward on the batch already resident in the engine's input buffer (asynchronous)."""
         self._pp_key = None  # masks / integer boxes cached by postprocess() belong to the previous forward
         self._forward_id += 1
-        _ffi.check(_ffi.lib().isegmi_yolact_forward(self._h, self._d_in.ptr, n))
+        _ffi.check(_ffi.lib().isegmi_yolact_forward(self._h, self.input_buffer(slot).ptr, n))
 
     def postprocess_device(self, h, w):
         _ffi.check(_ffi.lib().isegmi_yolact_postprocess(self._h, h, w))
