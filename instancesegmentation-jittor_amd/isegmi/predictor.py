@@ -7,6 +7,8 @@
 compute_prediction / select_top_predictions follow the upstream demo ([UPSTREAM-RECALL], SURVEY 3.1);
 overlay drawing is plain numpy (cv2 is not in the image): mask tint + box outline, no text.
 """
+import collections
+
 import numpy as np
 
 from .coco import COCO_CLASSES
@@ -16,6 +18,8 @@ from .transforms import maskrcnn_resize
 
 class COCODemo:
     CATEGORIES = ("__background",) + COCO_CLASSES
+
+    MAX_ENGINES = 4   # one engine per distinct padded input size (weights + activation buffers each): least recently used is closed
 
     def __init__(self, cfg=None, min_image_size=800, confidence_threshold=0.5, state_dict=None, max_image_size=1333, device=0):
         if cfg is not None and not isinstance(cfg, MaskRCNNConfig):   # the yacs-shaped node of isegmi.config (README.md:313-324)
@@ -34,12 +38,19 @@ class COCODemo:
         self.min_image_size, self.max_image_size = min_image_size, max_image_size
         self.confidence_threshold = confidence_threshold
         self.state_dict, self.device = state_dict, device
-        self._models = {}
+        self._models = collections.OrderedDict()
 
     def _model(self, H, W):
+        """Engine for the padded size (H, W).  Upstream pads a single image to the next multiple of 32 only, and the RPN sees the
+        padded area, so results depend on the exact canvas: one engine per canvas size, at most MAX_ENGINES alive (LRU)."""
         key = (H, W)
-        if key not in self._models:
-            self._models[key] = MaskRCNN(self.state_dict, H, W, cfg=self.cfg, max_batch=1, device=self.device)
+        if key in self._models:
+            self._models.move_to_end(key)
+            return self._models[key]
+        while len(self._models) >= self.MAX_ENGINES:
+            _, old = self._models.popitem(last=False)
+            old.close()
+        self._models[key] = MaskRCNN(self.state_dict, H, W, cfg=self.cfg, max_batch=1, device=self.device)
         return self._models[key]
 
     def compute_prediction(self, original_image):
@@ -92,7 +103,7 @@ class COCODemo:
     def close(self):
         for m in self._models.values():
             m.close()
-        self._models = {}
+        self._models = collections.OrderedDict()
 
 
 def inference(predictor, images, image_ids=None):

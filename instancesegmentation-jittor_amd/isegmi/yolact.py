@@ -220,8 +220,7 @@ class Yolact:
             # 1x1 run on the MFMA conv kernels with channels padded to 32 by ZERO weights / biases (exact: the extra terms are +-0)
             w0 = to_krsc(sd["maskiou_net.0.weight"]).reshape(8, 9)
             for nm, arr in (("maskiou.w0", w0), ("maskiou.b0", sd["maskiou_net.0.bias"])):
-                a = np.ascontiguousarray(arr, np.float32)
-                _ffi.check(_ffi.lib().isegmi_engine_set_tensor(self._h, nm.encode(), a.ctypes.data_as(C.c_void_p), C.c_int64(a.nbytes)))
+                self._set_tensor(nm, np.ascontiguousarray(arr, np.float32))
             for i in (2, 4, 6, 8, 10):
                 w = np.asarray(sd["maskiou_net.%d.weight" % i], np.float32); bias = np.asarray(sd["maskiou_net.%d.bias" % i], np.float32)
                 cout, cin = w.shape[:2]
@@ -232,8 +231,11 @@ class Yolact:
         pri = [make_priors(s, s, self.cfg.level_scales(l), self.cfg.max_size, self.cfg.pred_aspect_ratios, self.cfg.use_square_anchors)
                for l, s in enumerate(_level_sizes(self.size))]
         self.priors = np.concatenate(pri, 0)
-        _ffi.check(_ffi.lib().isegmi_engine_set_tensor(self._h, b"priors", self.priors.ctypes.data_as(C.c_void_p),
-                                                       C.c_int64(self.priors.nbytes)))
+        self._set_tensor("priors", self.priors)
+
+    def _set_tensor(self, name, a):
+        a = np.ascontiguousarray(a)
+        _ffi.check(_ffi.lib().isegmi_engine_set_tensor(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), C.c_int64(a.nbytes)))
 
     def set_param(self, name, value):
         _ffi.check(_ffi.lib().isegmi_engine_set_param(self._h, name.encode(), C.c_float(value)))

@@ -217,3 +217,43 @@ def test_world2_gloo_detection_gather(tmp_path):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists()
+
+
+def test_cocodemo_engine_cache_is_bounded(monkeypatch):
+    """COCODemo keeps one engine per padded canvas size; beyond MAX_ENGINES the least recently used one is closed."""
+    from isegmi import predictor
+
+    class Fake:
+        alive = 0
+
+        def __init__(self, sd, H, W, **kw):
+            self.key = (H, W); Fake.alive += 1
+
+        def close(self):
+            Fake.alive -= 1
+    monkeypatch.setattr(predictor, "MaskRCNN", Fake)
+    demo = predictor.COCODemo(state_dict={"x": 0})
+    sizes = [(800, 1344), (800, 1216), (832, 1344), (800, 1088), (768, 1344), (800, 1344)]
+    for hw in sizes:
+        m = demo._model(*hw)
+        assert m.key == hw and Fake.alive <= predictor.COCODemo.MAX_ENGINES
+    assert Fake.alive == predictor.COCODemo.MAX_ENGINES
+    first = demo._model(800, 1088)
+    assert demo._model(800, 1088) is first          # a hit re-uses the engine and refreshes its age
+    demo.close()
+    assert Fake.alive == 0
+
+
+def test_bench_gpus_n_without_devices_fails_loudly():
+    """`python bench.py --gpus 2` outside a torch.distributed environment starts its own two ranks; with no HIP device they fail,
+    and the parent must exit non-zero without printing a JSON line (never a silent 1-GPU run reported as n_gpus=1)."""
+    pytest.importorskip("torch")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    # and inside a torch.distributed environment a --gpus / WORLD_SIZE mismatch is refused before anything else happens
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=dict(env, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "WORLD_SIZE=2" in r.stderr
