@@ -83,10 +83,8 @@ __device__ __forceinline__ float dm_log2(float x) {
     return fmaf(ln, 1.44269504088896341f, (float)e);
 }
 
-// bilinear source coordinate, align_corners=False (matches oracle bil_coef)
-__device__ __forceinline__ void dm_bil_coef(int dst, int in_sz, int out_sz, int& i0, int& i1, float& l0,
-                                            float& l1) {
-    const float scale = dm_div((float)in_sz, (float)out_sz);
+// bilinear source coordinate, align_corners=False (matches oracle bil_coef); `scale` = dm_div(in_sz, out_sz), hoistable
+__device__ __forceinline__ void dm_bil_coef_s(int dst, int in_sz, float scale, int& i0, int& i1, float& l0, float& l1) {
     float src = scale * ((float)dst + 0.5f) - 0.5f;
     if (src < 0.0f) src = 0.0f;
     int a = (int)src;
@@ -95,6 +93,10 @@ __device__ __forceinline__ void dm_bil_coef(int dst, int in_sz, int out_sz, int&
     i1 = a < in_sz - 1 ? a + 1 : a;
     l1 = src - (float)a;
     l0 = 1.0f - l1;
+}
+__device__ __forceinline__ void dm_bil_coef(int dst, int in_sz, int out_sz, int& i0, int& i1, float& l0,
+                                            float& l1) {
+    dm_bil_coef_s(dst, in_sz, dm_div((float)in_sz, (float)out_sz), i0, i1, l0, l1);
 }
 
 }  // namespace isegmi

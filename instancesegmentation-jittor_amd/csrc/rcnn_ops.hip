@@ -523,33 +523,57 @@ __device__ __forceinline__ float4 roi_bilinear4(const float* f, int H, int W, in
 }
 // rois [N][K][4] image coords; counts [N]; out [N*K][PH][PW][C]; rows beyond count are zero-filled.
 // fixed_level >= 0 forces that level index (unit tests of a single map); else LevelMapper(k_min..k_max).
+// One block per (RoI, slice of its PH*PW*C/4 output vectors): everything that depends on the RoI alone -- level (sqrt, log2,
+// division), scaled corners, bin sizes (two IEEE divisions), sampling grid -- is computed once per thread instead of once per
+// output vector, and all index arithmetic is 32-bit.  The per-sample arithmetic is unchanged (same rounding sequence).
+// GS = 2: the FPN models' fixed 2 x 2 sampling grid with the sample loops unrolled, so that a bin's 16 tap loads are in flight
+// together (with run-time loop bounds every sample waited for its own four taps: four memory round trips per output vector).
+template <int GS>
 __global__ __launch_bounds__(256) void roi_align_kernel(const RoiLevels lv, const float* __restrict__ rois, const int* __restrict__ counts,
                                                          int N, int K, int C, int PH, int PW, int g, int k_min, int k_max,
                                                          int fixed_level, float* __restrict__ out, int* __restrict__ out_level) {
+    const int roi = blockIdx.x;
+    const int n = roi / K, k = roi - n * K;
     const int c4n = C >> 2;
-    const int64_t total = (int64_t)N * K * PH * PW * c4n;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int c4 = (int)(i % c4n);
-        int64_t t = i / c4n;
-        const int pw = (int)(t % PW); t /= PW;
-        const int ph = (int)(t % PH); t /= PH;
-        const int k = (int)(t % K);
-        const int n = (int)(t / K);
+    const int per = PH * PW * c4n;
+    const int chunk = (per + gridDim.y - 1) / gridDim.y;
+    const int start = blockIdx.y * chunk, end = start + chunk < per ? start + chunk : per;
+    float4* o4 = (float4*)out + (int64_t)roi * per;
+    if (k >= counts[n]) {
+        for (int j = start + threadIdx.x; j < end; j += 256) o4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    const float4 b = *(const float4*)(rois + (int64_t)roi * 4);
+    const int li = fixed_level >= 0 ? fixed_level : level_of(b, k_min, k_max) - k_min;
+    if (out_level && threadIdx.x == 0 && blockIdx.y == 0) out_level[roi] = li + k_min;
+    const int H = lv.H[li], W = lv.W[li];
+    const float sc = lv.scale[li];
+    const float* fbase = lv.feat[li] + (int64_t)n * H * W * C;
+    const float sw = b.x * sc, sh = b.y * sc, ew = b.z * sc, eh = b.w * sc;
+    float rw = ew - sw, rh = eh - sh;
+    rw = rw > 1.0f ? rw : 1.0f;
+    rh = rh > 1.0f ? rh : 1.0f;
+    const float bh = dm_div(rh, (float)PH), bw = dm_div(rw, (float)PW);
+    // g > 0: fixed sampling grid; g <= 0: adaptive ceil(roi / pooled) (ROIAlign's sampling_ratio = 0, the C4 config)
+    const int gh = GS > 0 ? GS : (g > 0 ? g : (int)ceilf(bh)), gw = GS > 0 ? GS : (g > 0 ? g : (int)ceilf(bw));
+    const float cnt = (float)(gh * gw);
+    for (int j = start + threadIdx.x; j < end; j += 256) {
+        const int bin = j / c4n, c4 = j - bin * c4n;
+        const int ph = bin / PW, pw = bin - ph * PW;
+        const float* f = fbase + c4 * 4;
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < counts[n]) {
-            const float4 b = *(const float4*)(rois + ((int64_t)n * K + k) * 4);
-            const int li = fixed_level >= 0 ? fixed_level : level_of(b, k_min, k_max) - k_min;
-            if (out_level && c4 == 0 && ph == 0 && pw == 0) out_level[n * K + k] = li + k_min;
-            const int H = lv.H[li], W = lv.W[li];
-            const float sc = lv.scale[li];
-            const float* f = lv.feat[li] + (int64_t)n * H * W * C + c4 * 4;
-            const float sw = b.x * sc, sh = b.y * sc, ew = b.z * sc, eh = b.w * sc;
-            float rw = ew - sw, rh = eh - sh;
-            rw = rw > 1.0f ? rw : 1.0f;
-            rh = rh > 1.0f ? rh : 1.0f;
-            const float bh = dm_div(rh, (float)PH), bw = dm_div(rw, (float)PW);
-            // g > 0: fixed sampling grid; g <= 0: adaptive ceil(roi / pooled) (ROIAlign's sampling_ratio = 0, the C4 config)
-            const int gh = g > 0 ? g : (int)ceilf(bh), gw = g > 0 ? g : (int)ceilf(bw);
+        if (GS > 0) {
+#pragma unroll
+            for (int iy = 0; iy < GS; ++iy) {
+                const float y = sh + (float)ph * bh + dm_div(((float)iy + 0.5f) * bh, (float)GS);
+#pragma unroll
+                for (int ix = 0; ix < GS; ++ix) {
+                    const float x = sw + (float)pw * bw + dm_div(((float)ix + 0.5f) * bw, (float)GS);
+                    const float4 v = roi_bilinear4(f, H, W, C, y, x);
+                    o.x = o.x + v.x; o.y = o.y + v.y; o.z = o.z + v.z; o.w = o.w + v.w;
+                }
+            }
+        } else {
             for (int iy = 0; iy < gh; ++iy) {
                 const float y = sh + (float)ph * bh + dm_div(((float)iy + 0.5f) * bh, (float)gh);
                 for (int ix = 0; ix < gw; ++ix) {
@@ -558,10 +582,9 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiLevels lv, cons
                     o.x = o.x + v.x; o.y = o.y + v.y; o.z = o.z + v.z; o.w = o.w + v.w;
                 }
             }
-            const float cnt = (float)(gh * gw);
-            o.x = dm_div(o.x, cnt); o.y = dm_div(o.y, cnt); o.z = dm_div(o.z, cnt); o.w = dm_div(o.w, cnt);
         }
-        *(float4*)(out + i * 4) = o;
+        o.x = dm_div(o.x, cnt); o.y = dm_div(o.y, cnt); o.z = dm_div(o.z, cnt); o.w = dm_div(o.w, cnt);
+        o4[j] = o;
     }
 }
 
@@ -935,9 +958,19 @@ int roi_align_launch(const float* const* feats, const int* Hs, const int* Ws, co
         const int s = i < nlevels ? i : nlevels - 1;
         lv.feat[i] = feats[s]; lv.H[i] = Hs[s]; lv.W[i] = Ws[s]; lv.scale[i] = scales[s];
     }
-    const int64_t total = (int64_t)N * K * PH * PW * (C / 4);
-    hipLaunchKernelGGL(roi_align_kernel, dim3(grid_for(total)), dim3(256), 0, st, lv, rois, counts, N, K, C, PH, PW, g, k_min,
-                       k_min + nlevels - 1, fixed_level, out, out_level);
+    ARG_CHECK(N > 0 && K > 0 && (int64_t)N * K < (1ll << 31) && (int64_t)PH * PW * (C / 4) < (1ll << 30), "roi_align sizes");
+    // one block per (RoI, slice): enough slices that few-RoI launches (the mask head: N x 100 RoIs of 14 x 14 bins) still fill the chip
+    const int per = PH * PW * (C / 4);
+    int slices = (2048 + N * K - 1) / (N * K);
+    const int max_slices = (per + 255) / 256;
+    if (slices > max_slices) slices = max_slices;
+    if (slices < 1) slices = 1;
+    if (g == 2)
+        hipLaunchKernelGGL(roi_align_kernel<2>, dim3((unsigned)(N * K), (unsigned)slices), dim3(256), 0, st, lv, rois, counts, N, K, C, PH, PW, g, k_min,
+                           k_min + nlevels - 1, fixed_level, out, out_level);
+    else
+        hipLaunchKernelGGL(roi_align_kernel<0>, dim3((unsigned)(N * K), (unsigned)slices), dim3(256), 0, st, lv, rois, counts, N, K, C, PH, PW, g, k_min,
+                           k_min + nlevels - 1, fixed_level, out, out_level);
     HIP_TRY(hipGetLastError());
     return ISEGMI_OK;
 }
