@@ -258,6 +258,189 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// v2 of the 64x64 / 32x32x2 kernel (tiles 7, 8, 9 = RING 2, 3, 4): same tile, same LDS image, same numerics, other schedule.
+//  * Loads run RING chunks ahead in registers, issued by inline asm and awaited by an exact `s_waitcnt vmcnt` (see the ring
+//    notes on conv_mfma16_kernel): with one chunk of prefetch a block whose A operand streams from HBM (Cout <= 128: the
+//    1x1 reductions of res2 / res3, 8 KB per chunk) had at most 32 KB in flight per CU and sat at ~3 TB/s.
+//  * A chunk's registers reach LDS at the START of the iteration that precedes its use (they landed an iteration ago), next to
+//    the first fragment reads; the next loads' address arithmetic follows, and only then the 16 dependent MFMAs with the
+//    fragment reads of step g+1 issued under the MFMAs of step g.  A wave that is alone on its SIMD (grids of 1-3 blocks per
+//    CU) no longer serialises [loads | MFMAs | LDS store | barrier]: everything but the barrier sits under its own MFMAs.
+//  * The residual is requested before the LAST chunk's MFMAs instead of after them (one memory round trip per tile, all of a
+//    K = 64 layer's tile time besides the loads themselves).
+template <int RING, bool EARLY>
+__global__ __launch_bounds__(256, 4) void conv_mfma_v2_kernel(const ConvK p) {
+    constexpr int BM = 64, BN = 64;
+    constexpr int STAGE = (BM + BN) * LDS_ROW;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int nt = p.mfast ? logical / p.mtiles : logical % p.ntiles;
+    const int mt = p.mfast ? logical % p.mtiles : logical / p.ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    // loader: thread covers row tid>>2 of the A and of the B tile, 8 consecutive k (g = tid&3) of the 32-chunk
+    const int lrow = tid >> 2, g = tid & 3;
+    int hi0, wi0;
+    unsigned abase;  // byte offset of (n, hi0, wi0, 8 g); wraps for padding taps, which the range test rejects
+    {
+        const int m = m0 + lrow;
+        if (m < p.M) {
+            const int hw = p.Ho * p.Wo;
+            const int n = m / hw, rem = m - n * hw;
+            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+            hi0 = ho * p.stride - p.pad; wi0 = wo * p.stride - p.pad;
+            abase = ((unsigned)((n * p.H + hi0) * p.W + wi0) * (unsigned)p.Cin + (unsigned)(g * 8)) * 4u;
+        } else { hi0 = -(1 << 28); wi0 = 0; abase = 0; }
+    }
+    const unsigned wbase = ((unsigned)(n0 + lrow) * (unsigned)p.wrow + (unsigned)(g * 8)) * 4u;
+    constexpr unsigned OOB = 0x80000000u;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    auto make_rsrc = [](const void* ptr, unsigned bytes) {
+        const unsigned long long a = (unsigned long long)ptr;
+        return u32x4{(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a),
+                     (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu)),
+                     (unsigned)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000u};
+    };
+    const u32x4 rs_in = make_rsrc(p.in, p.in_bytes), rs_w = make_rsrc(p.w, p.w_bytes);
+    u32x4 ra[RING][2], rb[RING][2];
+    int kr = 0, ks = 0, kc = 0, chunk = 0;  // position of the next chunk to load (strictly in order)
+    auto load_chunk = [&](int slot) {
+        const unsigned dead = (unsigned)((p.nchunks - 1 - chunk) >> 31) & OOB;  // chunks past the end: zeros, exact vmcnt
+        const bool ok = (unsigned)(hi0 + kr) < (unsigned)p.H && (unsigned)(wi0 + ks) < (unsigned)p.W;
+        const unsigned tap = (unsigned)((kr * p.W + ks) * p.Cin + kc * 32) * 4u;  // scalar
+        const unsigned offa = (ok ? abase + tap : OOB) | dead;
+        const unsigned offb = (wbase + (unsigned)chunk * 128u) | dead;
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(ra[slot][0]) : "v"(offa), "s"(rs_in) : "memory");
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:16" : "=v"(ra[slot][1]) : "v"(offa), "s"(rs_in) : "memory");
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(rb[slot][0]) : "v"(offb), "s"(rs_w) : "memory");
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:16" : "=v"(rb[slot][1]) : "v"(offb), "s"(rs_w) : "memory");
+        const int wc = (kc + 1 == p.cin_chunks) ? 1 : 0;
+        kc = wc ? 0 : kc + 1;
+        const int ws = (wc && ks + 1 == p.S) ? 1 : 0;
+        ks = ws ? 0 : ks + wc;
+        kr += ws;
+        ++chunk;
+    };
+    auto store_chunk = [&](int slot, int stage, auto pending) {  // pending = loads issued after this slot's
+        asm volatile("s_waitcnt vmcnt(%4)" : "+v"(ra[slot][0]), "+v"(ra[slot][1]), "+v"(rb[slot][0]), "+v"(rb[slot][1]) : "n"(decltype(pending)::value) : "memory");
+        float* As = smem + stage * STAGE;
+        float* Bs = As + BM * LDS_ROW;
+        float* da = As + lrow * LDS_ROW + g * 8;
+        *(u32x4*)da = u32x4{ra[slot][0].x, ra[slot][0].z, ra[slot][1].x, ra[slot][1].z};
+        *(u32x4*)(da + 4) = u32x4{ra[slot][0].y, ra[slot][0].w, ra[slot][1].y, ra[slot][1].w};
+        float* db = Bs + lrow * LDS_ROW + g * 8;
+        *(u32x4*)db = rb[slot][0];
+        *(u32x4*)(db + 4) = rb[slot][1];
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int a_off = (wm * 32 + lr) * LDS_ROW + lh * 4;
+    const int b_off = BM * LDS_ROW + (wn * 32 + lr) * LDS_ROW + lh * 4;
+    float4 fa[2], fb[2];
+    auto read_frags = [&](int set, int stage, int gg) {
+        const float* sb = smem + stage * STAGE;
+        fa[set] = *(const float4*)(sb + a_off + gg * 8);
+        fb[set] = *(const float4*)(sb + b_off + gg * 8);
+    };
+    auto mma4 = [&](int set) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set].x, fb[set].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set].y, fb[set].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set].z, fb[set].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set].w, fb[set].w, acc, 0, 0, 0);
+    };
+    auto compute = [&](int stage) {  // fragment reads of step g+1 under the MFMAs of step g; set 0 of step 0 is already requested
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) {
+            if (gg < 3) read_frags((gg + 1) & 1, stage, gg + 1);
+            mma4(gg & 1);
+        }
+    };
+    typedef std::integral_constant<int, 4 * (RING - 1)> Steady;   // store right after the refill of the previous slot
+    typedef std::integral_constant<int, 4 * (RING - 2) < 0 ? 0 : 4 * (RING - 2)> Early;  // store BEFORE this iteration's refill
+
+#pragma unroll
+    for (int i = 0; i < RING; ++i) load_chunk(i);
+    store_chunk(0, 0, Steady());
+    __syncthreads();
+    int cur = 0;
+    const int last = p.nchunks - 1;
+    for (int t0 = 0; t0 < last; t0 += RING) {
+#pragma unroll
+        for (int j = 0; j < RING; ++j) {
+            if (t0 + j >= last) break;  // uniform
+            read_frags(0, cur, 0);
+            if (EARLY) store_chunk((j + 1) % RING, cur ^ 1, Early());   // chunk t+1: requested RING-1 iterations ago
+            load_chunk(j);                                               // chunk t+RING into the slot chunk t left
+            __builtin_amdgcn_sched_barrier(0);
+            compute(cur);
+            __builtin_amdgcn_sched_barrier(0);
+            // EARLY = false (layers that stream A from HBM): the wait for chunk t+1 sits BELOW chunk t's MFMAs
+            if (!EARLY) store_chunk((j + 1) % RING, cur ^ 1, Steady());
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+    // last chunk (already in LDS): the residual is requested first, so that it travels under the chunk's MFMAs
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, p.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? p.res : p.out), 0, p.res ? p.res_bytes : 0u, 0x00020000);
+    unsigned rowoff[16];
+    const int co = n0 + wn * 32 + lr;
+    const bool cok = co < p.Cout;
+    const unsigned cooff = cok ? (unsigned)co * 4u : OOB;  // OOB + anything stays out of range (< 2^32)
+    float rv[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const unsigned resoff = m < p.M ? (unsigned)m * (unsigned)p.Cout * 4u : OOB;
+        rv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_res, (resoff | cooff) >= OOB ? OOB : resoff + cooff, 0, 0));
+        if (p.contiguous) rowoff[e] = m < p.M ? (unsigned)m * (unsigned)p.out_pix_stride * 4u : OOB;
+        else {  // strided destination (concatenated head buffers, deconv parities)
+            const int ni = m / p.out_div, pi = m - ni * p.out_div;
+            rowoff[e] = m < p.M ? (unsigned)(((int64_t)ni * p.out_img_stride + (int64_t)pi * p.out_pix_stride) * 4) : OOB;
+        }
+    }
+    const float sc = (cok && p.scale) ? p.scale[co] : 1.0f;
+    const float sh = (cok && p.shift) ? p.shift[co] : 0.0f;
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(0, cur, 0);
+    compute(cur);
+    __builtin_amdgcn_sched_barrier(0);
+    // the past-the-end loads of the ring must have landed before their registers are reused
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < RING; ++i) asm volatile("" :: "v"(ra[i][0]), "v"(ra[i][1]), "v"(rb[i][0]), "v"(rb[i][1]));
+
+    // epilogue: y = fmaf(acc, scale, shift) (+res) -> act -> NHWC store (see conv_mfma_kernel)
+    float yv[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        float y = fmaf(acc[e], sc, sh);
+        if (p.act == 4) {  // DarkNet block: LeakyReLU(0.1) FIRST, then the shortcut
+            y = y > 0.0f ? y : y * 0.1f;
+            yv[e] = y + rv[e];
+            continue;
+        }
+        y = y + rv[e];
+        yv[e] = p.act == 1 ? (y > 0.0f ? y : 0.0f) : (p.act == 3 ? (y > 0.0f ? y : y * 0.1f) : y);
+    }
+    if (p.act == 2) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) yv[e] = dm_tanh(yv[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yv[e]), rs_out, (rowoff[e] | cooff) >= OOB ? OOB : rowoff[e] + cooff, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Small-M / latency-bound variant: block tile 32x32, four waves, each wave ONE 16x16 tile on
 // v_mfma_f32_16x16x4_f32 (lane (i, q) supplies k = 4s + q; the instruction is the same ordered fmaf chain, 4 k deep).
 // A wave's accumulator chain advances 4 k per 40 cycles instead of 2 k per 64, so the K-order latency floor that
@@ -530,7 +713,7 @@ static int check_desc(const isegmi_conv_desc* d) {
     ARG_CHECK(is_stem(d) || (d->Cin > 0 && d->Cin % 32 == 0), "Cin must be a multiple of 32 (or the Cin=4 7x7 stem)");
     ARG_CHECK(d->H + 2 * d->pad >= d->R && d->W + 2 * d->pad >= d->S, "kernel larger than padded input");
     ARG_CHECK(d->act >= 0 && d->act <= 4, "act");
-    ARG_CHECK(d->tile >= 0 && d->tile <= 6, "tile");
+    ARG_CHECK(d->tile >= 0 && d->tile <= 12, "tile");
     return ISEGMI_OK;
 }
 
@@ -588,36 +771,44 @@ int conv2d_launch(const isegmi_conv_desc* d, const float* in, const float* w, co
     ARG_CHECK(res == nullptr || (int64_t)k.M * d->Cout * 4 < (1ll << 31), "residual must be < 2 GiB");
     int tile = d->tile;
     if (tile == 0) {
-        // Measured on MI355X (profiles/r01_conv_tiles_bs8.txt): the 64x64 tile (4 blocks/CU = 4 waves/SIMD,
-        // 36.9 KB LDS) matches 128x128 at full occupancy (124 TF/s) and wins everywhere else through finer
-        // wave quantisation, so it is the default; 128-wide tiles stay selectable for experiments.
-        tile = 3;
-        // ... except where the 32x32 block on 16x16x4 MFMA wins (measured per layer at bs = 1, 2, 8 on both models,
-        // profiles/r01_conv_tile3_vs_tile45_v4.txt).  All three kernels are latency-bound on these grids and their times fit,
-        // in units of K/2304 x 1 us with t64 = number of 64x64 tiles, r3 = ceil(t64 / 256), r4 = ceil(t64 / 64):
-        //   tile 3, 64x64:                 26 + 34   * r3   (whole rounds of one block per CU; 4 blocks/CU hide part of a round)
-        //   tile 4, 32x32:                 18 + 10.6 * r4   (4x the blocks, rounds a third as long)
-        //   tile 5, 32x32 + loader waves:  12 + 13.5 * r4   (shortest chunk, but 8-wave blocks pack the CU worse)
-        // so tile 5 takes grids of up to 128 tiles and tile 4 the rest of the first three 64x64 rounds wherever its finer
-        // rounds come out ahead (129-256, 257-448, and 513-640 where K >= 1024 leaves the fixed costs behind); full 64x64
-        // rounds (449-512: fc6/fc7 at two images) and everything larger stay on the 64x64 tile.  Outputs of at most 32
-        // channels never use the 64-wide tile (padding them to 64 wastes half the MFMA work: 0.67-0.91 of the 64x64 time).
+        // Tile rule, refitted in round 2 on per-layer sweeps of both models at bs 1 / 2 / 8 with every kernel forced in turn
+        // (tools/conv_tile_sweep.py -> profiles/r02_conv_tile_sweep.txt; t64 = number of 64x64 tiles of the layer, nck = K chunks):
+        //   * grids of many 64x64 rounds: the v2 schedule (tile 10, loads two chunks ahead; tile 12, four chunks ahead, from
+        //     K = 2304 on) -- 3-8 % ahead of the round-1 64x64 kernel on every 3x3 / FC layer; the round-1 kernel (tile 3) stays
+        //     for K = 64, where a tile is two chunks and the ring only adds its past-the-end loads;
+        //   * all three 16x16x4 kernels are latency-bound on small grids and fit 26 + 34 r3 (64x64), 18 + 10.6 r4 (tile 4),
+        //     12 + 13.5 r4 (tile 5) us per K = 2304 with r3 = ceil(t64 / 256), r4 = ceil(t64 / 64): tile 5 up to 128 tiles, tile 4
+        //     to 320 tiles, the 32x64 block (tile 6) where a grid sits just past a whole number of 64x64 rounds (321-384, 513-640,
+        //     1025-1100);
+        //   * outputs of at most 32 channels never use a 64-wide tile (padding them to 64 wastes half the MFMA work).
         const int64_t t64 = (int64_t)cdiv(k.M, 64) * cdiv(d->Cout, 64);
-        const int64_t r3 = (t64 + 255) / 256, r4 = (t64 + 63) / 64;
-        if (!is_stem(d)) {
-            if (r4 < 3) tile = 5;
-            else if (d->Cout <= 32 || (106 * r4 <= 80 + 340 * r3 && (r3 < 3 || (r3 == 3 && k.nchunks >= 32)))) tile = 4;
-            // ... and the 32x64 block (tile 6: two 16x16 tiles per wave, 18 + 20 * ceil(t64 / 128) in the same units, within
-            // 1-3 % of the 64x64 tile even on the largest layers) takes the grids that sit just past a whole number of 64x64
-            // rounds, where the 64x64 tile pays a full extra round and the 32x32 block's rounds are too many: measured windows
-            // (profiles/r01_conv_tile3_vs_tile46_v5.txt), each 0.89-0.97 of the better of the other two.
-            const int nck = k.nchunks;
-            if (d->Cout > 32 && ((t64 > 320 && t64 <= 384 && nck >= 32) || (t64 > 512 && t64 <= 640 && nck >= 32) ||
-                                 (t64 > 1024 && t64 <= 1280 && nck >= 16) || (t64 > 2048 && t64 <= 2432 && nck >= 72)))
-                tile = 6;
-        }
+        const int nck = k.nchunks;
+        const int v2 = nck >= 72 ? 12 : 10;
+        if (is_stem(d)) tile = 3;
+        else if (t64 <= 128) tile = 5;
+        else if (d->Cout <= 32 || t64 <= 320) tile = 4;
+        else if (t64 <= 384) tile = nck >= 32 ? 6 : 4;
+        else if (t64 <= 512) tile = v2;
+        else if (t64 <= 640) tile = nck >= 32 ? 6 : 4;
+        else if (t64 <= 1024) tile = v2;
+        else if (t64 <= 1100 && nck >= 8) tile = 6;
+        else tile = nck <= 2 ? 3 : v2;
     }
-    if (tile >= 4 && is_stem(d)) tile = 3;  // the 16x16x4 variants have no stem path
+    if (tile >= 4 && is_stem(d)) tile = 3;  // only the original 64x64 kernel has the stem path
+    if (tile >= 7) {
+        k.mtiles = cdiv(k.M, 64);
+        k.ntiles = cdiv(d->Cout, 64);
+        const size_t lds = 2 * (size_t)(64 + 64) * LDS_ROW * sizeof(float);
+        const dim3 g7((unsigned)(k.mtiles * k.ntiles));
+        if (tile == 7) hipLaunchKernelGGL((conv_mfma_v2_kernel<2, true>), g7, dim3(256), lds, st, k);
+        else if (tile == 8) hipLaunchKernelGGL((conv_mfma_v2_kernel<3, true>), g7, dim3(256), lds, st, k);
+        else if (tile == 9) hipLaunchKernelGGL((conv_mfma_v2_kernel<4, true>), g7, dim3(256), lds, st, k);
+        else if (tile == 10) hipLaunchKernelGGL((conv_mfma_v2_kernel<2, false>), g7, dim3(256), lds, st, k);
+        else if (tile == 11) hipLaunchKernelGGL((conv_mfma_v2_kernel<3, false>), g7, dim3(256), lds, st, k);
+        else hipLaunchKernelGGL((conv_mfma_v2_kernel<4, false>), g7, dim3(256), lds, st, k);
+        HIP_TRY(hipGetLastError());
+        return ISEGMI_OK;
+    }
     if (tile >= 4) {
         k.mtiles = cdiv(k.M, 32);
         k.ntiles = cdiv(d->Cout, tile == 6 ? 64 : 32);

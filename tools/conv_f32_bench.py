@@ -25,7 +25,12 @@ def body(N, H, W):
     return out
 
 
-SETS = {"y8": body(8, 138, 138), "m2": body(2, 200, 336)}
+SETS = {"y8": body(8, 138, 138), "m2": body(2, 200, 336),
+        # the large layers outside the ResNet body: Yolact P3 3x3s / protonet at 138^2 / fused 351-wide head; Mask R-CNN FPN + RPN 3x3s at
+        # P2 / P3, mask-head 3x3 on 200 RoIs, FC6 as a 7x7 valid conv on 2000 RoIs
+        "big": [(8, 69, 69, 256, 256, 3, 1, 1, 0), (8, 138, 138, 256, 256, 3, 1, 1, 0), (8, 69, 69, 256, 351, 3, 1, 1, 0), (8, 35, 35, 256, 351, 3, 1, 1, 0),
+                (2, 200, 336, 256, 256, 3, 1, 1, 0), (2, 100, 168, 256, 256, 3, 1, 1, 0), (200, 14, 14, 256, 256, 3, 1, 1, 0),
+                (2000, 7, 7, 256, 1024, 7, 1, 0, 0), (2, 200, 336, 256, 256, 1, 1, 0, 0), (2, 200, 336, 64, 256, 1, 1, 0, 1)]}
 TILES = [int(t) for t in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0, 3, 4, 6]
 which = sys.argv[2] if len(sys.argv) > 2 else "all"
 ROT = int(sys.argv[3]) if len(sys.argv) > 3 else 3
