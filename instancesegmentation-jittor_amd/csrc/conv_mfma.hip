@@ -775,7 +775,7 @@ int conv2d_launch(const isegmi_conv_desc* d, const float* in, const float* w, co
         // (tools/conv_tile_sweep.py -> profiles/r02_conv_tile_sweep.txt; t64 = number of 64x64 tiles of the layer, nck = K chunks):
         //   * grids of many 64x64 rounds: the v2 schedule (tile 10, loads two chunks ahead; tile 12, four chunks ahead, from
         //     K = 2304 on) -- 3-8 % ahead of the round-1 64x64 kernel on every 3x3 / FC layer; the round-1 kernel (tile 3) stays
-        //     for K = 64, where a tile is two chunks and the ring only adds its past-the-end loads;
+        //     for K <= 512 (the 1x1 reductions / expansions of res2-res3: short tiles whose A operand streams from HBM);
         //   * all three 16x16x4 kernels are latency-bound on small grids and fit 26 + 34 r3 (64x64), 18 + 10.6 r4 (tile 4),
         //     12 + 13.5 r4 (tile 5) us per K = 2304 with r3 = ceil(t64 / 256), r4 = ceil(t64 / 64): tile 5 up to 128 tiles, tile 4
         //     to 320 tiles, the 32x64 block (tile 6) where a grid sits just past a whole number of 64x64 rounds (321-384, 513-640,
@@ -792,7 +792,7 @@ int conv2d_launch(const isegmi_conv_desc* d, const float* in, const float* w, co
         else if (t64 <= 640) tile = nck >= 32 ? 6 : 4;
         else if (t64 <= 1024) tile = v2;
         else if (t64 <= 1100 && nck >= 8) tile = 6;
-        else tile = nck <= 2 ? 3 : v2;
+        else tile = nck <= 16 ? 3 : v2;   // K <= 512: the two schedules tie inside the models, and the ring loses on some boxes when A streams from HBM
     }
     if (tile >= 4 && is_stem(d)) tile = 3;  // only the original 64x64 kernel has the stem path
     if (tile >= 7) {

@@ -25,7 +25,7 @@ def body(N, H, W):
     return out
 
 
-SETS = {"y8": body(8, 138, 138), "m2": body(2, 200, 336),
+SETS = {"y8": body(8, 138, 138), "m2": body(2, 200, 336), "y4": body(4, 138, 138)[:6], "m1": body(1, 200, 336)[:6],
         # the large layers outside the ResNet body: Yolact P3 3x3s / protonet at 138^2 / fused 351-wide head; Mask R-CNN FPN + RPN 3x3s at
         # P2 / P3, mask-head 3x3 on 200 RoIs, FC6 as a 7x7 valid conv on 2000 RoIs
         "big": [(8, 69, 69, 256, 256, 3, 1, 1, 0), (8, 138, 138, 256, 256, 3, 1, 1, 0), (8, 69, 69, 256, 351, 3, 1, 1, 0), (8, 35, 35, 256, 351, 3, 1, 1, 0),
