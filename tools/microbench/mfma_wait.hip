@@ -16,6 +16,12 @@ __global__ __launch_bounds__(256) void chain(float* out, int n) {
     for (int j = 0; j < 8; ++j) { a[j] = 1.0f + j * 1e-3f + threadIdx.x * 1e-7f; b[j] = 1e-6f * (1.0f + j); }
     lds[threadIdx.x] = f32x4{a[0], a[1], a[2], a[3]};
     __syncthreads();
+    float pre = 0.0f;
+    if (V == 30 || V == 31 || V == 32) {  // the wave HAS used vector memory before the loop: one global load, landed and consumed
+        pre = out[(blockIdx.x * blockDim.x + threadIdx.x) & 65535];
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pre) :: "memory");
+        a[0] += pre * 0.0f;
+    }
     f32x16 acc = {};
     f32x4 acc4 = {0, 0, 0, 0};
     f32x4 fr = {0, 0, 0, 0};
@@ -34,7 +40,15 @@ __global__ __launch_bounds__(256) void chain(float* out, int n) {
             if (V == 8 && at) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             if (V == 9 && at) asm volatile("s_setprio 1\n\ts_setprio 0" ::: "memory");
             if (V == 10 && at) asm volatile("v_mov_b32 %0, %0" : "+v"(fr[1]));
-            if (M16) {
+            if (V == 30 && at) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (V == 31 && at) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (V >= 20) {
+                if ((V == 21) && at) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if ((V == 22) && at) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if ((V == 23) && at) asm volatile("s_waitcnt vmcnt(0)");
+                if (M16) acc4 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc4, 0, 0, 0);
+                else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
+            } else if (M16) {
                 if (AG) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc4) : "v"(a[j]), "v"(b[j]));
                 else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc4) : "v"(a[j]), "v"(b[j]));
             } else {
@@ -85,6 +99,16 @@ int main() {
     run<5, true>("A5  + 1 x s_barrier", 1, out);
     run<6, true>("A6  + 2 x (ds_read_b128; s_waitcnt lgkmcnt(0))", 2, out);
     run<3, true>("A3  + 2 x s_nop 0", 2, out);
+    printf("---- builtin MFMAs (hipcc allocates the accumulator; AGPRs here)\n");
+    run<20>("B20 8 dependent builtin MFMAs", 0, out);
+    run<21>("B21 + 2 x s_waitcnt vmcnt(0) with a memory clobber", 2, out);
+    run<23>("B23 + 2 x s_waitcnt vmcnt(0) without a memory clobber", 2, out);
+    run<22>("B22 + 2 x s_waitcnt lgkmcnt(0) with a memory clobber", 2, out);
+    run<32>("B32 builtin MFMAs after one global load before the loop", 0, out);
+    run<30>("B30 = B32 + 2 x s_waitcnt vmcnt(0) inside the loop", 2, out);
+    run<31>("B31 = B32 + 2 x s_waitcnt lgkmcnt(0) inside the loop", 2, out);
+    run<20, false, true>("B20m 8 dependent builtin 16x16x4 MFMAs", 0, out);
+    run<22, false, true>("B22m + 2 x s_waitcnt lgkmcnt(0), 16x16x4", 2, out);
     printf("---- v_mfma_f32_16x16x4_f32, acc in VGPRs / AGPRs\n");
     run<0, false, true>("M0  8 dependent 16x16x4 MFMAs, VGPR", 0, out);
     run<2, false, true>("M2  + 2 x s_waitcnt lgkmcnt(0), VGPR", 2, out);
