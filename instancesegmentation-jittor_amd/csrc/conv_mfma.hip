@@ -307,48 +307,68 @@ __global__ __launch_bounds__(256, 4) void conv_mfma_v2_kernel(const ConvK p) {
                      (unsigned)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000u};
     };
     const u32x4 rs_in = make_rsrc(p.in, p.in_bytes), rs_w = make_rsrc(p.w, p.w_bytes);
+    // Every wave64 VALU instruction in this loop costs 2-3 cycles of the SIMD's matrix pipe with four waves per SIMD and 4-6 with
+    // one (tools/microbench/mfma_switch.hip: independent v_mov / v_add between dependent MFMAs; SALU and un-awaited LDS reads cost
+    // nothing), so the per-chunk vector work is cut to two instructions:
+    //  * the tap's byte offset and the past-the-end switch are scalar (SALU): the A load's voffset is `abase + tap` (one v_add),
+    //    made out-of-range by ONE v_cndmask under a lane mask that is recomputed only when the tap changes (uniform branch);
+    //    past-the-end chunks swap in a zero-length descriptor with scalar selects; the B load's voffset is a loop constant and
+    //    its chunk offset rides in the instruction's scalar offset;
+    //  * the LDS image's k permutation is done by ds_write2_b32 (two data registers, two offsets) instead of moving the loaded
+    //    registers into b128 order (8 v_mov per chunk), and all LDS addresses are per-stage constants with immediate offsets.
+    const u32x4 rs_null = u32x4{rs_in.x, rs_in.y, 0u, rs_in.w};
     u32x4 ra[RING][2], rb[RING][2];
     int kr = 0, ks = 0, kc = 0, chunk = 0;  // position of the next chunk to load (strictly in order)
+    const bool taps = p.R * p.S > 1 || p.pad > 0;  // 1x1 / pad 0: every tap of a row < M is inside the image
+    // lanes whose current tap is inside the image: a per-lane bool, i.e. a lane mask in an SGPR pair
+    bool ok = taps ? ((unsigned)hi0 < (unsigned)p.H && (unsigned)wi0 < (unsigned)p.W) : hi0 >= 0;
+    unsigned tapoff = 0;  // scalar: byte offset of the next chunk's (kr, ks, kc) from (hi0, wi0, 0)
     auto load_chunk = [&](int slot) {
-        const unsigned dead = (unsigned)((p.nchunks - 1 - chunk) >> 31) & OOB;  // chunks past the end: zeros, exact vmcnt
-        const bool ok = (unsigned)(hi0 + kr) < (unsigned)p.H && (unsigned)(wi0 + ks) < (unsigned)p.W;
-        const unsigned tap = (unsigned)((kr * p.W + ks) * p.Cin + kc * 32) * 4u;  // scalar
-        const unsigned offa = (ok ? abase + tap : OOB) | dead;
-        const unsigned offb = (wbase + (unsigned)chunk * 128u) | dead;
-        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(ra[slot][0]) : "v"(offa), "s"(rs_in) : "memory");
-        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:16" : "=v"(ra[slot][1]) : "v"(offa), "s"(rs_in) : "memory");
-        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(rb[slot][0]) : "v"(offb), "s"(rs_w) : "memory");
-        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:16" : "=v"(rb[slot][1]) : "v"(offb), "s"(rs_w) : "memory");
-        const int wc = (kc + 1 == p.cin_chunks) ? 1 : 0;
-        kc = wc ? 0 : kc + 1;
-        const int ws = (wc && ks + 1 == p.S) ? 1 : 0;
-        ks = ws ? 0 : ks + wc;
-        kr += ws;
+        const bool live = chunk < p.nchunks;
+        const u32x4 rsa = live ? rs_in : rs_null, rsb = live ? rs_w : rs_null;  // scalar selects
+        unsigned offa = abase + tapoff;
+        offa = ok ? offa : OOB;  // v_cndmask under the lane mask
+        const unsigned soffb = (unsigned)chunk * 128u;
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(ra[slot][0]) : "v"(offa), "s"(rsa) : "memory");
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:16" : "=v"(ra[slot][1]) : "v"(offa), "s"(rsa) : "memory");
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(rb[slot][0]) : "v"(wbase), "s"(rsb), "s"(soffb) : "memory");
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:16" : "=v"(rb[slot][1]) : "v"(wbase), "s"(rsb), "s"(soffb) : "memory");
         ++chunk;
+        if (++kc == p.cin_chunks) {  // uniform: next tap -- the only place the per-lane validity is recomputed
+            kc = 0;
+            if (++ks == p.S) { ks = 0; ++kr; }
+            if (taps) ok = (unsigned)(hi0 + kr) < (unsigned)p.H && (unsigned)(wi0 + ks) < (unsigned)p.W;
+        }
+        tapoff = (unsigned)((kr * p.W + ks) * p.Cin + kc * 32) * 4u;
     };
+    // LDS addresses (floats): per-thread constants; the stage is a compile-time term wherever the loop is unrolled over it
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const unsigned lds_wr_addr = (unsigned)(uintptr_t)(lds_ptr)(smem + lrow * LDS_ROW + g * 8);  // LDS byte address of this thread's 8 floats, stage 0
     auto store_chunk = [&](int slot, int stage, auto pending) {  // pending = loads issued after this slot's
         asm volatile("s_waitcnt vmcnt(%4)" : "+v"(ra[slot][0]), "+v"(ra[slot][1]), "+v"(rb[slot][0]), "+v"(rb[slot][1]) : "n"(decltype(pending)::value) : "memory");
-        float* As = smem + stage * STAGE;
-        float* Bs = As + BM * LDS_ROW;
-        float* da = As + lrow * LDS_ROW + g * 8;
-        *(u32x4*)da = u32x4{ra[slot][0].x, ra[slot][0].z, ra[slot][1].x, ra[slot][1].z};
-        *(u32x4*)(da + 4) = u32x4{ra[slot][0].y, ra[slot][0].w, ra[slot][1].y, ra[slot][1].w};
-        float* db = Bs + lrow * LDS_ROW + g * 8;
-        *(u32x4*)db = rb[slot][0];
-        *(u32x4*)(db + 4) = rb[slot][1];
+        // [k0 k2 k4 k6 | k1 k3 k5 k7]: four ds_write2_b32, each taking its two dwords from two different loaded registers (written
+        // as plain stores hipcc re-vectorises them into ds_write_b128 behind eight v_mov); B keeps its two ds_write_b128.  The
+        // block's s_barrier below is preceded by an explicit lgkmcnt(0): the compiler does not count asm LDS operations.
+        const unsigned wa = lds_wr_addr + (unsigned)(stage * STAGE * 4);
+        asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" :: "v"(wa), "v"(ra[slot][0].x), "v"(ra[slot][0].z) : "memory");
+        asm volatile("ds_write2_b32 %0, %1, %2 offset0:2 offset1:3" :: "v"(wa), "v"(ra[slot][1].x), "v"(ra[slot][1].z) : "memory");
+        asm volatile("ds_write2_b32 %0, %1, %2 offset0:4 offset1:5" :: "v"(wa), "v"(ra[slot][0].y), "v"(ra[slot][0].w) : "memory");
+        asm volatile("ds_write2_b32 %0, %1, %2 offset0:6 offset1:7" :: "v"(wa), "v"(ra[slot][1].y), "v"(ra[slot][1].w) : "memory");
+        asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(wa), "v"(rb[slot][0]), "n"(BM * LDS_ROW * 4) : "memory");
+        asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(wa), "v"(rb[slot][1]), "n"(BM * LDS_ROW * 4 + 16) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
 
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
     const int lr = lane & 31, lh = lane >> 5;
-    const int a_off = (wm * 32 + lr) * LDS_ROW + lh * 4;
-    const int b_off = BM * LDS_ROW + (wn * 32 + lr) * LDS_ROW + lh * 4;
+    const float* const lds_a = smem + (wm * 32 + lr) * LDS_ROW + lh * 4;
+    const float* const lds_b = smem + BM * LDS_ROW + (wn * 32 + lr) * LDS_ROW + lh * 4;
     float4 fa[2], fb[2];
     auto read_frags = [&](int set, int stage, int gg) {
-        const float* sb = smem + stage * STAGE;
-        fa[set] = *(const float4*)(sb + a_off + gg * 8);
-        fb[set] = *(const float4*)(sb + b_off + gg * 8);
+        fa[set] = *(const float4*)(lds_a + stage * STAGE + gg * 8);
+        fb[set] = *(const float4*)(lds_b + stage * STAGE + gg * 8);
     };
     auto mma4 = [&](int set) {
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set].x, fb[set].x, acc, 0, 0, 0);
@@ -365,17 +385,18 @@ __global__ __launch_bounds__(256, 4) void conv_mfma_v2_kernel(const ConvK p) {
     };
     typedef std::integral_constant<int, 4 * (RING - 1)> Steady;   // store right after the refill of the previous slot
     typedef std::integral_constant<int, 4 * (RING - 2) < 0 ? 0 : 4 * (RING - 2)> Early;  // store BEFORE this iteration's refill
+    static_assert(RING % 2 == 0, "the LDS stage of an unrolled position is its parity");
 
 #pragma unroll
     for (int i = 0; i < RING; ++i) load_chunk(i);
     store_chunk(0, 0, Steady());
     __syncthreads();
-    int cur = 0;
     const int last = p.nchunks - 1;
     for (int t0 = 0; t0 < last; t0 += RING) {
 #pragma unroll
         for (int j = 0; j < RING; ++j) {
             if (t0 + j >= last) break;  // uniform
+            const int cur = j & 1;      // compile-time: t0 is a multiple of the (even) ring depth
             read_frags(0, cur, 0);
             if (EARLY) store_chunk((j + 1) % RING, cur ^ 1, Early());   // chunk t+1: requested RING-1 iterations ago
             load_chunk(j);                                               // chunk t+RING into the slot chunk t left
@@ -385,9 +406,9 @@ __global__ __launch_bounds__(256, 4) void conv_mfma_v2_kernel(const ConvK p) {
             // EARLY = false (layers that stream A from HBM): the wait for chunk t+1 sits BELOW chunk t's MFMAs
             if (!EARLY) store_chunk((j + 1) % RING, cur ^ 1, Steady());
             __syncthreads();
-            cur ^= 1;
         }
     }
+    const int cur = last & 1;
     // last chunk (already in LDS): the residual is requested first, so that it travels under the chunk's MFMAs
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, p.out_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? p.res : p.out), 0, p.res ? p.res_bytes : 0u, 0x00020000);
@@ -516,26 +537,34 @@ __global__ __launch_bounds__(LW ? 512 : 256) void conv_mfma16_kernel(const ConvK
                      (unsigned)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000u};
     };
     const u32x4 rs_in = make_rsrc(p.in, p.in_bytes), rs_w = make_rsrc(p.w, p.w_bytes);
+    const u32x4 rs_null = u32x4{rs_in.x, rs_in.y, 0u, rs_in.w};
     u32x4 ra[RING], rb[RING][WN];
     int kr = 0, ks = 0, kc = 0, chunk = 0;  // position of the next chunk to load (they are loaded strictly in order)
+    // Per-chunk vector work is two instructions (see conv_mfma_v2_kernel: every VALU instruction costs matrix-pipe cycles): voffset
+    // = abase + scalar tap offset, pushed out of range by one v_cndmask under a lane mask that is recomputed only when the tap
+    // changes; past-the-end chunks swap in a zero-length descriptor (scalar selects); B's chunk offset is the scalar offset operand.
+    const bool taps = p.R * p.S > 1 || p.pad > 0;
+    bool ok = taps ? ((unsigned)hi0 < (unsigned)p.H && (unsigned)wi0 < (unsigned)p.W) : hi0 >= 0;
+    unsigned tapoff = 0;
     auto load_chunk = [&](int slot) {
-        const unsigned dead = (unsigned)((p.nchunks - 1 - chunk) >> 31) & OOB;
-        const bool ok = (unsigned)(hi0 + kr) < (unsigned)p.H && (unsigned)(wi0 + ks) < (unsigned)p.W;
-        const unsigned tap = (unsigned)((kr * p.W + ks) * p.Cin + kc * 32) * 4u;  // scalar
-        const unsigned offa = (ok ? abase + tap : OOB) | dead;
-        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(ra[slot]) : "v"(offa), "s"(rs_in) : "memory");
+        const bool live = chunk < p.nchunks;
+        const u32x4 rsa = live ? rs_in : rs_null, rsb = live ? rs_w : rs_null;
+        unsigned offa = abase + tapoff;
+        offa = ok ? offa : OOB;
+        const unsigned soffb = (unsigned)chunk * 128u;
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(ra[slot]) : "v"(offa), "s"(rsa) : "memory");
 #pragma unroll
         for (int t = 0; t < WN; ++t) {  // weight rows lrow and lrow + 32
-            const unsigned offb = (wbase + (unsigned)t * 32u * (unsigned)p.wrow * 4u + (unsigned)chunk * 128u) | dead;
-            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(rb[slot][t]) : "v"(offb), "s"(rs_w) : "memory");
+            const unsigned vb = wbase + (unsigned)t * 32u * (unsigned)p.wrow * 4u;  // loop constant
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(rb[slot][t]) : "v"(vb), "s"(rsb), "s"(soffb) : "memory");
         }
-        // branch-free tap counters: the pipelined iteration below must stay one basic block for its issue-order directives
-        const int wc = (kc + 1 == p.cin_chunks) ? 1 : 0;
-        kc = wc ? 0 : kc + 1;
-        const int ws = (wc && ks + 1 == p.S) ? 1 : 0;
-        ks = ws ? 0 : ks + wc;
-        kr += ws;
         ++chunk;
+        if (++kc == p.cin_chunks) {  // uniform: next tap
+            kc = 0;
+            if (++ks == p.S) { ks = 0; ++kr; }
+            if (taps) ok = (unsigned)(hi0 + kr) < (unsigned)p.H && (unsigned)(wi0 + ks) < (unsigned)p.W;
+        }
+        tapoff = (unsigned)((kr * p.W + ks) * p.Cin + kc * 32) * 4u;
     };
     // A arrives in natural k order (two 8-byte stores: rows are only 8-byte aligned at this pitch); the packed weight row
     // holds [k0 k2 k4 k6 | k1 k3 k5 k7] per 8-group, so thread (grp, half) owns k = 8*grp + 2j + half
@@ -796,15 +825,14 @@ int conv2d_launch(const isegmi_conv_desc* d, const float* in, const float* w, co
     }
     if (tile >= 4 && is_stem(d)) tile = 3;  // only the original 64x64 kernel has the stem path
     if (tile >= 7) {
+        ARG_CHECK(tile != 8 && tile != 11, "tiles 8 / 11 (ring of 3) were dropped: the LDS stage of an unrolled position is its parity");
         k.mtiles = cdiv(k.M, 64);
         k.ntiles = cdiv(d->Cout, 64);
         const size_t lds = 2 * (size_t)(64 + 64) * LDS_ROW * sizeof(float);
         const dim3 g7((unsigned)(k.mtiles * k.ntiles));
         if (tile == 7) hipLaunchKernelGGL((conv_mfma_v2_kernel<2, true>), g7, dim3(256), lds, st, k);
-        else if (tile == 8) hipLaunchKernelGGL((conv_mfma_v2_kernel<3, true>), g7, dim3(256), lds, st, k);
         else if (tile == 9) hipLaunchKernelGGL((conv_mfma_v2_kernel<4, true>), g7, dim3(256), lds, st, k);
         else if (tile == 10) hipLaunchKernelGGL((conv_mfma_v2_kernel<2, false>), g7, dim3(256), lds, st, k);
-        else if (tile == 11) hipLaunchKernelGGL((conv_mfma_v2_kernel<3, false>), g7, dim3(256), lds, st, k);
         else hipLaunchKernelGGL((conv_mfma_v2_kernel<4, false>), g7, dim3(256), lds, st, k);
         HIP_TRY(hipGetLastError());
         return ISEGMI_OK;
