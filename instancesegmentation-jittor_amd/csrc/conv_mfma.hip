@@ -803,25 +803,24 @@ int conv2d_launch(const isegmi_conv_desc* d, const float* in, const float* w, co
         // Tile rule, refitted in round 2 on per-layer sweeps of both models at bs 1 / 2 / 8 with every kernel forced in turn
         // (tools/conv_tile_sweep.py -> profiles/r02_conv_tile_sweep.txt; t64 = number of 64x64 tiles of the layer, nck = K chunks):
         //   * grids of many 64x64 rounds: the v2 schedule (tile 10, loads two chunks ahead; tile 12, four chunks ahead, from
-        //     K = 2304 on) -- 3-8 % ahead of the round-1 64x64 kernel on every 3x3 / FC layer; the round-1 kernel (tile 3) stays
-        //     for K <= 512 (the 1x1 reductions / expansions of res2-res3: short tiles whose A operand streams from HBM);
-        //   * all three 16x16x4 kernels are latency-bound on small grids and fit 26 + 34 r3 (64x64), 18 + 10.6 r4 (tile 4),
-        //     12 + 13.5 r4 (tile 5) us per K = 2304 with r3 = ceil(t64 / 256), r4 = ceil(t64 / 64): tile 5 up to 128 tiles, tile 4
-        //     to 320 tiles, the 32x64 block (tile 6) where a grid sits just past a whole number of 64x64 rounds (321-384, 513-640,
-        //     1025-1100);
+        //     K = 2304 on) -- 3-8 % ahead of the round-1 64x64 kernel on every layer of three or more chunks; the round-1 kernel
+        //     (tile 3) stays for K = 64;
+        //   * the three 16x16x4 kernels take the small grids (second sweep, after the per-chunk vector work was cut to two
+        //     instructions, profiles/r02_conv_tile_sweep_v2.txt): the loader-wave variant (tile 5) up to 176 tiles, the 32x32 block
+        //     (tile 4) to 480 tiles, the 32x64 block (tile 6) for K >= 1024 where a grid sits just past a whole number of 64x64
+        //     rounds (513-640, 1025-1100);
         //   * outputs of at most 32 channels never use a 64-wide tile (padding them to 64 wastes half the MFMA work).
         const int64_t t64 = (int64_t)cdiv(k.M, 64) * cdiv(d->Cout, 64);
         const int nck = k.nchunks;
         const int v2 = nck >= 72 ? 12 : 10;
         if (is_stem(d)) tile = 3;
-        else if (t64 <= 128) tile = 5;
-        else if (d->Cout <= 32 || t64 <= 320) tile = 4;
-        else if (t64 <= 384) tile = nck >= 32 ? 6 : 4;
+        else if (t64 <= 176) tile = 5;
+        else if (d->Cout <= 32 || t64 <= 480) tile = 4;
         else if (t64 <= 512) tile = v2;
         else if (t64 <= 640) tile = nck >= 32 ? 6 : 4;
         else if (t64 <= 1024) tile = v2;
-        else if (t64 <= 1100 && nck >= 8) tile = 6;
-        else tile = nck <= 16 ? 3 : v2;   // K <= 512: the two schedules tie inside the models, and the ring loses on some boxes when A streams from HBM
+        else if (t64 <= 1100) tile = nck >= 32 ? 6 : 4;
+        else tile = nck <= 2 ? 3 : v2;   // K = 64: a tile is two chunks, the ring only adds its past-the-end loads
     }
     if (tile >= 4 && is_stem(d)) tile = 3;  // only the original 64x64 kernel has the stem path
     if (tile >= 7) {
