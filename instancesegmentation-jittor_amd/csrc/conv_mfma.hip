@@ -289,13 +289,17 @@ __global__ __launch_bounds__(256, 4) void conv_mfma_v2_kernel(const ConvK p) {
     unsigned abase;  // byte offset of (n, hi0, wi0, 8 g); wraps for padding taps, which the range test rejects
     {
         const int m = m0 + lrow;
-        if (m < p.M) {
+        if (m >= p.M) { hi0 = -(1 << 28); wi0 = 0; abase = 0; }
+        else if (p.R * p.S == 1 && p.stride == 1 && p.pad == 0) {  // uniform: output pixel m IS input pixel m (no two integer divisions)
+            hi0 = 0; wi0 = 0;
+            abase = ((unsigned)m * (unsigned)p.Cin + (unsigned)(g * 8)) * 4u;
+        } else {
             const int hw = p.Ho * p.Wo;
             const int n = m / hw, rem = m - n * hw;
             const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
             hi0 = ho * p.stride - p.pad; wi0 = wo * p.stride - p.pad;
             abase = ((unsigned)((n * p.H + hi0) * p.W + wi0) * (unsigned)p.Cin + (unsigned)(g * 8)) * 4u;
-        } else { hi0 = -(1 << 28); wi0 = 0; abase = 0; }
+        }
     }
     const unsigned wbase = ((unsigned)(n0 + lrow) * (unsigned)p.wrow + (unsigned)(g * 8)) * 4u;
     constexpr unsigned OOB = 0x80000000u;
@@ -513,13 +517,17 @@ __global__ __launch_bounds__(LW ? 512 : 256) void conv_mfma16_kernel(const ConvK
     unsigned abase;  // byte offset of (n, hi0, wi0, 4*g8); wraps for padding taps, which the range test below rejects
     {
         const int m = m0 + lrow;
-        if (m < p.M) {
+        if (m >= p.M) { hi0 = -(1 << 28); wi0 = 0; abase = 0; }
+        else if (p.R * p.S == 1 && p.stride == 1 && p.pad == 0) {  // uniform: output pixel m IS input pixel m (no two integer divisions)
+            hi0 = 0; wi0 = 0;
+            abase = ((unsigned)m * (unsigned)p.Cin + (unsigned)(g8 * 4)) * 4u;
+        } else {
             const int hw = p.Ho * p.Wo;
             const int n = m / hw, rem = m - n * hw;
             const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
             hi0 = ho * p.stride - p.pad; wi0 = wo * p.stride - p.pad;
             abase = ((unsigned)((n * p.H + hi0) * p.W + wi0) * (unsigned)p.Cin + (unsigned)(g8 * 4)) * 4u;
-        } else { hi0 = -(1 << 28); wi0 = 0; abase = 0; }
+        }
     }
     const unsigned wbase = ((unsigned)(n0 + lrow) * (unsigned)p.wrow + (unsigned)(g8 * 4)) * 4u;
     constexpr unsigned OOB = 0x80000000u;
