@@ -47,6 +47,89 @@ constexpr int LDS_ROW = 36;
 
 
 
+// ---- shared epilogue of the 32x32-tile kernels.  D layout: col (cout) = lane&31, row (pixel) = (e&3) + 8*(e>>2) + 4*(lane>>5).
+// Vector instructions between MFMAs cost matrix-pipe cycles (tools/microbench/mfma_switch.hip), so the common layout -- a
+// dense [M, Cout] destination -- gets its 16 element offsets with ONE add each: row r of the wave's tile is a wave-uniform
+// multiple of the row pitch away from the lane's base, rows past M fall behind a descriptor cut at M rows, and a lane whose
+// column is past Cout starts from the out-of-range base.  Other destinations (concatenated head buffers, deconv parities) keep
+// the general per-row arithmetic.  `row0` = the lane's first pixel row (tile row base + 4*(lane>>5)), `co` = its channel.
+struct Epi {
+    __amdgpu_buffer_rsrc_t rs_out, rs_res;
+    unsigned off[16];   // byte offset of element e in the destination (out of range = dropped)
+    float rv[16];       // residual (+0 without one)
+};
+
+__device__ __forceinline__ void epi_begin(const ConvK& p, int row0, int co, Epi& ep) {
+    constexpr unsigned OOB = 0x80000000u;
+    const bool cok = co < p.Cout;
+    const bool dense = p.contiguous && p.out_pix_stride == p.Cout;  // wave-uniform
+    const unsigned dense_bytes = (unsigned)p.M * (unsigned)p.Cout * 4u;
+    ep.rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, dense ? dense_bytes : p.out_bytes, 0x00020000);
+    ep.rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? p.res : p.out), 0, p.res ? p.res_bytes : 0u, 0x00020000);
+    if (dense) {
+        const unsigned pitch = (unsigned)p.Cout * 4u;
+        const unsigned base = cok ? (unsigned)row0 * pitch + (unsigned)co * 4u : OOB;  // OOB + 27 rows stays out of range
+#pragma unroll
+        for (int e = 0; e < 16; ++e) ep.off[e] = base + (unsigned)((e & 3) + 8 * (e >> 2)) * pitch;
+        if (p.res) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) ep.rv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ep.rs_res, ep.off[e], 0, 0));
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) ep.rv[e] = 0.0f;
+        }
+    } else {
+        const unsigned cooff = cok ? (unsigned)co * 4u : OOB;  // OOB + anything stays out of range (< 2^32)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = row0 + (e & 3) + 8 * (e >> 2);
+            const unsigned resoff = m < p.M ? (unsigned)m * (unsigned)p.Cout * 4u : OOB;
+            ep.rv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ep.rs_res, (resoff | cooff) >= OOB ? OOB : resoff + cooff, 0, 0));
+            unsigned rowoff;
+            if (p.contiguous) rowoff = m < p.M ? (unsigned)m * (unsigned)p.out_pix_stride * 4u : OOB;
+            else {
+                const int ni = m / p.out_div, pi = m - ni * p.out_div;
+                rowoff = m < p.M ? (unsigned)(((int64_t)ni * p.out_img_stride + (int64_t)pi * p.out_pix_stride) * 4) : OOB;
+            }
+            ep.off[e] = (rowoff | cooff) >= OOB ? OOB : rowoff + cooff;
+        }
+    }
+}
+
+// y = fmaf(acc, scale, shift) (+res) -> act -> NHWC store; the activation is a wave-uniform branch around the element loop.
+template <typename Acc>
+__device__ __forceinline__ void epi_finish(const ConvK& p, const Acc& acc, float sc, float sh, const Epi& ep) {
+    float yv[16];
+    if (p.act == 1) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float y = fmaf(acc[e], sc, sh) + ep.rv[e];  // rv is +0 without a residual: y + 0 == y for every y we can produce
+            yv[e] = y > 0.0f ? y : 0.0f;
+        }
+    } else if (p.act == 0) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) yv[e] = fmaf(acc[e], sc, sh) + ep.rv[e];
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            float y = fmaf(acc[e], sc, sh);
+            if (p.act == 4) {  // DarkNet block: LeakyReLU(0.1) FIRST, then the shortcut
+                y = y > 0.0f ? y : y * 0.1f;
+                yv[e] = y + ep.rv[e];
+                continue;
+            }
+            y = y + ep.rv[e];
+            yv[e] = p.act == 3 ? (y > 0.0f ? y : y * 0.1f) : y;
+        }
+        if (p.act == 2) {  // tanh only on the Yolact coefficient head
+#pragma unroll
+            for (int e = 0; e < 16; ++e) yv[e] = dm_tanh(yv[e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yv[e]), ep.rs_out, ep.off[e], 0, 0);
+}
+
 template <int BM, int BN, int WM, int WN, bool STEM>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK p) {
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
@@ -178,6 +261,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK p) {
                 for (int b = 0; b < TN; ++b) {
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].x, fb[b].x, acc[a][b], 0, 0, 0);
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].y, fb[b].y, acc[a][b], 0, 0, 0);
+                    // stem: a chunk is one filter row, 7 taps x 4 channels; k = 28..31 are zero pads in both operands and
+                    // fmaf(0, 0, acc) == acc for every acc a +0 start can reach, so their two MFMAs are left out
+                    if (STEM && gg == 3) continue;
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].z, fb[b].z, acc[a][b], 0, 0, 0);
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].w, fb[b].w, acc[a][b], 0, 0, 0);
                 }
@@ -198,60 +284,19 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK p) {
     }
     compute(cur);
 
-    // ---- epilogue: y = fmaf(acc, scale, shift) (+res) -> act -> NHWC store.
-    // D layout: col (cout) = lane&31, row (pixel) = (e&3) + 8*(e>>2) + 4*(lane>>5).
-    // Branch-free: residual loads and output stores are raw buffer ops whose offset is pushed out of range
-    // for rows >= M / couts >= Cout (hardware returns 0 / drops the store), so all 16 loads of a tile are
-    // in flight together instead of 16 guarded round trips.
-    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, p.out_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? p.res : p.out), 0, p.res ? p.res_bytes : 0u, 0x00020000);
+    // ---- epilogue (epi_begin / epi_finish above): residual loads and output stores are raw buffer ops whose offset is out of
+    // range for rows >= M / couts >= Cout (hardware returns 0 / drops the store), so all 16 loads of a tile are in flight together.
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
-        unsigned rowoff[16], resoff[16];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int m = m0 + (wm * TM + a) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-            rowoff[e] = m < p.M ? (unsigned)m * (unsigned)p.out_pix_stride * 4u : OOB;
-            resoff[e] = m < p.M ? (unsigned)m * (unsigned)p.Cout * 4u : OOB;
-        }
-        if (!p.contiguous) {  // strided destination (concatenated head buffers, deconv parities): uniform branch
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + (wm * TM + a) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                const int ni = m / p.out_div, pi = m - ni * p.out_div;
-                rowoff[e] = m < p.M ? (unsigned)(((int64_t)ni * p.out_img_stride + (int64_t)pi * p.out_pix_stride) * 4) : OOB;
-            }
-        }
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
             const int co = n0 + (wn * TN + b) * 32 + lr;
             const bool cok = co < p.Cout;
             const float sc = (cok && p.scale) ? p.scale[co] : 1.0f;
             const float sh = (cok && p.shift) ? p.shift[co] : 0.0f;
-            const unsigned cooff = cok ? (unsigned)co * 4u : OOB;  // OOB + anything stays out of range (< 2^32)
-            float rv[16];
-#pragma unroll
-            for (int e = 0; e < 16; ++e)
-                rv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_res, (resoff[e] | cooff) >= OOB ? OOB : resoff[e] + cooff, 0, 0));
-            float yv[16];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float y = fmaf(acc[a][b][e], sc, sh);
-                if (p.act == 4) {  // DarkNet block: LeakyReLU(0.1) FIRST, then the shortcut
-                    y = y > 0.0f ? y : y * 0.1f;
-                    yv[e] = y + rv[e];
-                    continue;
-                }
-                y = y + rv[e];            // rv is +0 without a residual: y + 0 == y for every y we can produce
-                yv[e] = p.act == 1 ? (y > 0.0f ? y : 0.0f) : (p.act == 3 ? (y > 0.0f ? y : y * 0.1f) : y);
-            }
-            if (p.act == 2) {  // uniform; tanh only on the Yolact coefficient head
-#pragma unroll
-                for (int e = 0; e < 16; ++e) yv[e] = dm_tanh(yv[e]);
-            }
-#pragma unroll
-            for (int e = 0; e < 16; ++e)
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yv[e]), rs_out, (rowoff[e] | cooff) >= OOB ? OOB : rowoff[e] + cooff, 0, 0);
+            Epi ep;
+            epi_begin(p, m0 + (wm * TM + a) * 32 + 4 * lh, co, ep);
+            epi_finish(p, acc[a][b], sc, sh, ep);
             __builtin_amdgcn_sched_barrier(0);  // one 32x32 tile's loads in flight at a time (register budget)
         }
     }
@@ -414,24 +459,10 @@ __global__ __launch_bounds__(256, 4) void conv_mfma_v2_kernel(const ConvK p) {
     }
     const int cur = last & 1;
     // last chunk (already in LDS): the residual is requested first, so that it travels under the chunk's MFMAs
-    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, p.out_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? p.res : p.out), 0, p.res ? p.res_bytes : 0u, 0x00020000);
-    unsigned rowoff[16];
     const int co = n0 + wn * 32 + lr;
     const bool cok = co < p.Cout;
-    const unsigned cooff = cok ? (unsigned)co * 4u : OOB;  // OOB + anything stays out of range (< 2^32)
-    float rv[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int m = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        const unsigned resoff = m < p.M ? (unsigned)m * (unsigned)p.Cout * 4u : OOB;
-        rv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_res, (resoff | cooff) >= OOB ? OOB : resoff + cooff, 0, 0));
-        if (p.contiguous) rowoff[e] = m < p.M ? (unsigned)m * (unsigned)p.out_pix_stride * 4u : OOB;
-        else {  // strided destination (concatenated head buffers, deconv parities)
-            const int ni = m / p.out_div, pi = m - ni * p.out_div;
-            rowoff[e] = m < p.M ? (unsigned)(((int64_t)ni * p.out_img_stride + (int64_t)pi * p.out_pix_stride) * 4) : OOB;
-        }
-    }
+    Epi ep;
+    epi_begin(p, m0 + wm * 32 + 4 * lh, co, ep);
     const float sc = (cok && p.scale) ? p.scale[co] : 1.0f;
     const float sh = (cok && p.shift) ? p.shift[co] : 0.0f;
     __builtin_amdgcn_sched_barrier(0);
@@ -442,27 +473,7 @@ __global__ __launch_bounds__(256, 4) void conv_mfma_v2_kernel(const ConvK p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int i = 0; i < RING; ++i) asm volatile("" :: "v"(ra[i][0]), "v"(ra[i][1]), "v"(rb[i][0]), "v"(rb[i][1]));
-
-    // epilogue: y = fmaf(acc, scale, shift) (+res) -> act -> NHWC store (see conv_mfma_kernel)
-    float yv[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        float y = fmaf(acc[e], sc, sh);
-        if (p.act == 4) {  // DarkNet block: LeakyReLU(0.1) FIRST, then the shortcut
-            y = y > 0.0f ? y : y * 0.1f;
-            yv[e] = y + rv[e];
-            continue;
-        }
-        y = y + rv[e];
-        yv[e] = p.act == 1 ? (y > 0.0f ? y : 0.0f) : (p.act == 3 ? (y > 0.0f ? y : y * 0.1f) : y);
-    }
-    if (p.act == 2) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) yv[e] = dm_tanh(yv[e]);
-    }
-#pragma unroll
-    for (int e = 0; e < 16; ++e)
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yv[e]), rs_out, (rowoff[e] | cooff) >= OOB ? OOB : rowoff[e] + cooff, 0, 0);
+    epi_finish(p, acc, sc, sh, ep);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -693,9 +704,14 @@ __global__ __launch_bounds__(LW ? 512 : 256) void conv_mfma16_kernel(const ConvK
         }
     }
 
-    // epilogue: D col (cout) = lane&15, row (pixel) = (lane>>4)*4 + e
-    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, p.out_bytes, 0x00020000);
+    // epilogue: D col (cout) = lane&15, row (pixel) = (lane>>4)*4 + e.  Same two layouts as epi_begin: a dense [M, Cout]
+    // destination takes one add per element (descriptor cut at M rows, out-of-range base for a column past Cout).
+    const bool dense = p.contiguous && p.out_pix_stride == p.Cout;  // wave-uniform
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, dense ? (unsigned)p.M * (unsigned)p.Cout * 4u : p.out_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? p.res : p.out), 0, p.res ? p.res_bytes : 0u, 0x00020000);
+    const int row0 = m0 + wm * 16 + lq * 4;
+    const unsigned pitch = (unsigned)p.Cout * 4u;
+    const unsigned rowbase = (unsigned)row0 * pitch;
 #pragma unroll
     for (int t = 0; t < WN; ++t) {
         const int co = n0 + (wn * WN + t) * 16 + li;
@@ -704,34 +720,58 @@ __global__ __launch_bounds__(LW ? 512 : 256) void conv_mfma16_kernel(const ConvK
         const float sh = (cok && p.shift) ? p.shift[co] : 0.0f;
         unsigned ooff[4];
         float rv[4];
+        if (dense) {
+            const unsigned base = cok ? rowbase + (unsigned)co * 4u : OOB;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int m = m0 + wm * 16 + lq * 4 + e;
-            const bool ok = cok && m < p.M;
-            unsigned off;
-            if (p.contiguous) off = ((unsigned)m * (unsigned)p.out_pix_stride + (unsigned)co) * 4u;
-            else {
-                const int ni = m / p.out_div, pi = m - ni * p.out_div;
-                off = (unsigned)(((int64_t)ni * p.out_img_stride + (int64_t)pi * p.out_pix_stride + co) * 4);
+            for (int e = 0; e < 4; ++e) ooff[e] = base + (unsigned)e * pitch;
+            if (p.res) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_res, ooff[e], 0, 0));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rv[e] = 0.0f;
             }
-            ooff[e] = ok ? off : OOB;
-            rv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_res, ok ? ((unsigned)m * (unsigned)p.Cout + (unsigned)co) * 4u : OOB, 0, 0));
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = row0 + e;
+                const bool ok = cok && m < p.M;
+                unsigned off;
+                if (p.contiguous) off = ((unsigned)m * (unsigned)p.out_pix_stride + (unsigned)co) * 4u;
+                else {
+                    const int ni = m / p.out_div, pi = m - ni * p.out_div;
+                    off = (unsigned)(((int64_t)ni * p.out_img_stride + (int64_t)pi * p.out_pix_stride + co) * 4);
+                }
+                ooff[e] = ok ? off : OOB;
+                rv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_res, ok ? ((unsigned)m * (unsigned)p.Cout + (unsigned)co) * 4u : OOB, 0, 0));
+            }
         }
         float yv[4];
+        if (p.act == 1) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float y = fmaf(acc[t][e], sc, sh);
-            if (p.act == 4) {  // DarkNet block: LeakyReLU(0.1) first, then the shortcut
-                y = y > 0.0f ? y : y * 0.1f;
-                yv[e] = y + rv[e];
-                continue;
+            for (int e = 0; e < 4; ++e) {
+                const float y = fmaf(acc[t][e], sc, sh) + rv[e];
+                yv[e] = y > 0.0f ? y : 0.0f;
             }
-            y = y + rv[e];
-            yv[e] = p.act == 1 ? (y > 0.0f ? y : 0.0f) : (p.act == 3 ? (y > 0.0f ? y : y * 0.1f) : y);
-        }
-        if (p.act == 2) {
+        } else if (p.act == 0) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) yv[e] = dm_tanh(yv[e]);
+            for (int e = 0; e < 4; ++e) yv[e] = fmaf(acc[t][e], sc, sh) + rv[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float y = fmaf(acc[t][e], sc, sh);
+                if (p.act == 4) {  // DarkNet block: LeakyReLU(0.1) first, then the shortcut
+                    y = y > 0.0f ? y : y * 0.1f;
+                    yv[e] = y + rv[e];
+                    continue;
+                }
+                y = y + rv[e];
+                yv[e] = p.act == 3 ? (y > 0.0f ? y : y * 0.1f) : y;
+            }
+            if (p.act == 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) yv[e] = dm_tanh(yv[e]);
+            }
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yv[e]), rs_out, ooff[e], 0, 0);
@@ -811,8 +851,7 @@ int conv2d_launch(const isegmi_conv_desc* d, const float* in, const float* w, co
         // Tile rule, refitted in round 2 on per-layer sweeps of both models at bs 1 / 2 / 8 with every kernel forced in turn
         // (tools/conv_tile_sweep.py -> profiles/r02_conv_tile_sweep.txt; t64 = number of 64x64 tiles of the layer, nck = K chunks):
         //   * grids of many 64x64 rounds: the v2 schedule (tile 10, loads two chunks ahead; tile 12, four chunks ahead, from
-        //     K = 2304 on) -- 3-8 % ahead of the round-1 64x64 kernel on every layer of three or more chunks; the round-1 kernel
-        //     (tile 3) stays for K = 64;
+        //     K = 2304 on) -- 3-8 % ahead of the round-1 64x64 kernel on every layer; the round-1 kernel (tile 3) keeps the stem;
         //   * the three 16x16x4 kernels take the small grids (second sweep, after the per-chunk vector work was cut to two
         //     instructions, profiles/r02_conv_tile_sweep_v2.txt): the loader-wave variant (tile 5) up to 176 tiles, the 32x32 block
         //     (tile 4) to 480 tiles, the 32x64 block (tile 6) for K >= 1024 where a grid sits just past a whole number of 64x64
@@ -823,12 +862,13 @@ int conv2d_launch(const isegmi_conv_desc* d, const float* in, const float* w, co
         const int v2 = nck >= 72 ? 12 : 10;
         if (is_stem(d)) tile = 3;
         else if (t64 <= 176) tile = 5;
+        else if (nck <= 2 && d->Cout > 32) tile = v2;  // K = 64: after the one-add epilogue the 64x64 v2 tile leads at every grid size
         else if (d->Cout <= 32 || t64 <= 480) tile = 4;
         else if (t64 <= 512) tile = v2;
         else if (t64 <= 640) tile = nck >= 32 ? 6 : 4;
         else if (t64 <= 1024) tile = v2;
         else if (t64 <= 1100) tile = nck >= 32 ? 6 : 4;
-        else tile = nck <= 2 ? 3 : v2;   // K = 64: a tile is two chunks, the ring only adds its past-the-end loads
+        else tile = v2;
     }
     if (tile >= 4 && is_stem(d)) tile = 3;  // only the original 64x64 kernel has the stem path
     if (tile >= 7) {
