@@ -369,26 +369,31 @@ __global__ __launch_bounds__(256, 4) void conv_mfma_v2_kernel(const ConvK p) {
     u32x4 ra[RING][2], rb[RING][2];
     int kr = 0, ks = 0, kc = 0, chunk = 0;  // position of the next chunk to load (strictly in order)
     const bool taps = p.R * p.S > 1 || p.pad > 0;  // 1x1 / pad 0: every tap of a row < M is inside the image
-    // lanes whose current tap is inside the image: a per-lane bool, i.e. a lane mask in an SGPR pair
-    bool ok = taps ? ((unsigned)hi0 < (unsigned)p.H && (unsigned)wi0 < (unsigned)p.W) : hi0 >= 0;
-    unsigned tapoff = 0;  // scalar: byte offset of the next chunk's (kr, ks, kc) from (hi0, wi0, 0)
+    // round 2, second pass: the two remaining instructions went too -- the lane's voffset (pixel base + tap offset, or the
+    // out-of-range constant for a padding tap / a row past M) is rebuilt only when the tap changes, behind a scalar branch; the
+    // cin chunk inside the tap rides in the scalar offset operand (outside the range check; it never leaves the pixel's Cin floats).
+    const bool ok0 = taps ? ((unsigned)hi0 < (unsigned)p.H && (unsigned)wi0 < (unsigned)p.W) : hi0 >= 0;
+    unsigned avoff = ok0 ? abase : OOB;
+    unsigned soffa = 0;
     auto load_chunk = [&](int slot) {
         const bool live = chunk < p.nchunks;
         const u32x4 rsa = live ? rs_in : rs_null, rsb = live ? rs_w : rs_null;  // scalar selects
-        unsigned offa = abase + tapoff;
-        offa = ok ? offa : OOB;  // v_cndmask under the lane mask
         const unsigned soffb = (unsigned)chunk * 128u;
-        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(ra[slot][0]) : "v"(offa), "s"(rsa) : "memory");
-        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:16" : "=v"(ra[slot][1]) : "v"(offa), "s"(rsa) : "memory");
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(ra[slot][0]) : "v"(avoff), "s"(rsa), "s"(soffa) : "memory");
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:16" : "=v"(ra[slot][1]) : "v"(avoff), "s"(rsa), "s"(soffa) : "memory");
         asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(rb[slot][0]) : "v"(wbase), "s"(rsb), "s"(soffb) : "memory");
         asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:16" : "=v"(rb[slot][1]) : "v"(wbase), "s"(rsb), "s"(soffb) : "memory");
         ++chunk;
-        if (++kc == p.cin_chunks) {  // uniform: next tap -- the only place the per-lane validity is recomputed
+        soffa += 128u;
+        if (++kc == p.cin_chunks) {  // uniform: next tap -- the only place with per-lane work
             kc = 0;
+            soffa = 0;
             if (++ks == p.S) { ks = 0; ++kr; }
-            if (taps) ok = (unsigned)(hi0 + kr) < (unsigned)p.H && (unsigned)(wi0 + ks) < (unsigned)p.W;
+            int tr = __builtin_amdgcn_readfirstlane(kr), ts = __builtin_amdgcn_readfirstlane(ks);
+            asm volatile("" : "+s"(tr), "+s"(ts));  // keeps the tap change behind its branch: speculated, its VALU work would run every chunk
+            const bool okt = taps ? (unsigned)(hi0 + tr) < (unsigned)p.H && (unsigned)(wi0 + ts) < (unsigned)p.W : ok0;
+            avoff = okt ? abase + (unsigned)((tr * p.W + ts) * p.Cin) * 4u : OOB;
         }
-        tapoff = (unsigned)((kr * p.W + ks) * p.Cin + kc * 32) * 4u;
     };
     // LDS addresses (floats): per-thread constants; the stage is a compile-time term wherever the loop is unrolled over it
     typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -559,31 +564,36 @@ __global__ __launch_bounds__(LW ? 512 : 256) void conv_mfma16_kernel(const ConvK
     const u32x4 rs_null = u32x4{rs_in.x, rs_in.y, 0u, rs_in.w};
     u32x4 ra[RING], rb[RING][WN];
     int kr = 0, ks = 0, kc = 0, chunk = 0;  // position of the next chunk to load (they are loaded strictly in order)
-    // Per-chunk vector work is two instructions (see conv_mfma_v2_kernel: every VALU instruction costs matrix-pipe cycles): voffset
-    // = abase + scalar tap offset, pushed out of range by one v_cndmask under a lane mask that is recomputed only when the tap
-    // changes; past-the-end chunks swap in a zero-length descriptor (scalar selects); B's chunk offset is the scalar offset operand.
+    // Per-chunk vector work is ZERO instructions (see conv_mfma_v2_kernel: every VALU instruction costs matrix-pipe cycles): the
+    // lane's voffset = pixel base + tap offset, or the out-of-range constant for a padding tap / a row past M, is rebuilt only
+    // when the tap changes (a scalar branch); the cin chunk inside the tap and B's chunk offset ride in the scalar offset
+    // operand (not part of the range check, and it never leaves the pixel's Cin floats); past-the-end chunks swap in a
+    // zero-length descriptor (scalar selects).
     const bool taps = p.R * p.S > 1 || p.pad > 0;
-    bool ok = taps ? ((unsigned)hi0 < (unsigned)p.H && (unsigned)wi0 < (unsigned)p.W) : hi0 >= 0;
-    unsigned tapoff = 0;
+    const bool ok0 = taps ? ((unsigned)hi0 < (unsigned)p.H && (unsigned)wi0 < (unsigned)p.W) : hi0 >= 0;
+    unsigned avoff = ok0 ? abase : OOB;
+    unsigned soffa = 0;
     auto load_chunk = [&](int slot) {
         const bool live = chunk < p.nchunks;
         const u32x4 rsa = live ? rs_in : rs_null, rsb = live ? rs_w : rs_null;
-        unsigned offa = abase + tapoff;
-        offa = ok ? offa : OOB;
         const unsigned soffb = (unsigned)chunk * 128u;
-        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(ra[slot]) : "v"(offa), "s"(rsa) : "memory");
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(ra[slot]) : "v"(avoff), "s"(rsa), "s"(soffa) : "memory");
 #pragma unroll
         for (int t = 0; t < WN; ++t) {  // weight rows lrow and lrow + 32
             const unsigned vb = wbase + (unsigned)t * 32u * (unsigned)p.wrow * 4u;  // loop constant
             asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(rb[slot][t]) : "v"(vb), "s"(rsb), "s"(soffb) : "memory");
         }
         ++chunk;
+        soffa += 128u;
         if (++kc == p.cin_chunks) {  // uniform: next tap
             kc = 0;
+            soffa = 0;
             if (++ks == p.S) { ks = 0; ++kr; }
-            if (taps) ok = (unsigned)(hi0 + kr) < (unsigned)p.H && (unsigned)(wi0 + ks) < (unsigned)p.W;
+            int tr = __builtin_amdgcn_readfirstlane(kr), ts = __builtin_amdgcn_readfirstlane(ks);
+            asm volatile("" : "+s"(tr), "+s"(ts));  // keeps the tap change behind its branch: speculated, its VALU work would run every chunk
+            const bool okt = taps ? (unsigned)(hi0 + tr) < (unsigned)p.H && (unsigned)(wi0 + ts) < (unsigned)p.W : ok0;
+            avoff = okt ? abase + (unsigned)((tr * p.W + ts) * p.Cin) * 4u : OOB;
         }
-        tapoff = (unsigned)((kr * p.W + ks) * p.Cin + kc * 32) * 4u;
     };
     // A arrives in natural k order (two 8-byte stores: rows are only 8-byte aligned at this pitch); the packed weight row
     // holds [k0 k2 k4 k6 | k1 k3 k5 k7] per 8-group, so thread (grp, half) owns k = 8*grp + 2j + half
@@ -638,11 +648,11 @@ __global__ __launch_bounds__(LW ? 512 : 256) void conv_mfma16_kernel(const ConvK
         for (int i = 0; i < RING; ++i) load_chunk(i);
         store_chunk(0, 0, Steady());
         __syncthreads();
-        int cur = 0;
         for (int t0 = 0; t0 < p.nchunks; t0 += RING) {
 #pragma unroll
             for (int j = 0; j < RING; ++j) {
                 if (t0 + j >= p.nchunks) break;  // uniform
+                const int cur = j & 1;  // compile-time (t0 is a multiple of the even ring depth): LDS addresses are immediates
                 load_chunk(j);
                 __builtin_amdgcn_sched_barrier(0);
                 read_frags(0, cur);
@@ -650,7 +660,6 @@ __global__ __launch_bounds__(LW ? 512 : 256) void conv_mfma16_kernel(const ConvK
                 __builtin_amdgcn_sched_barrier(0);
                 store_chunk((j + 1) % RING, cur ^ 1, Steady());
                 __syncthreads();
-                cur ^= 1;
             }
         }
         // the past-the-end loads still in flight target ring registers the epilogue is about to reuse
