@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform, and known to be (scalar address arithmetic)
     const int wm = wave / WN, wn = wave % WN;
 
     // XCD-aware bijective remap: blocks that share an XCD get consecutive logical tiles
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256, 4) void conv_mfma_v2_kernel(const ConvK p) {
     constexpr int STAGE = (BM + BN) * LDS_ROW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform, and known to be (scalar address arithmetic)
     const int wm = wave >> 1, wn = wave & 1;
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(LW ? 512 : 256) void conv_mfma16_kernel(const ConvK
 
     const int tid = threadIdx.x & 255;
     const bool loader = LW && __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) != 0;  // wave-uniform, and known to be
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform, and known to be (scalar address arithmetic)
     const int wm = wave >> 1, wn = wave & 1;
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;

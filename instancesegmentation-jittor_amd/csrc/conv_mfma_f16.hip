@@ -170,7 +170,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, OCC) void conv_f16_glds_kernel
     extern __shared__ __attribute__((aligned(1024))) char smemg[];
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform, and known to be (scalar address arithmetic)
     const int wm = wave / WN, wn = wave % WN;
     const int lw = LW > 0 ? wave - NW : wave;           // index among the loading waves
     const bool loads = LW == 0 || wave >= NW;
@@ -218,32 +218,62 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, OCC) void conv_f16_glds_kernel
     }
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+    // zero-length twins: every piece of a chunk past the last one is dropped by the range check (zeros land in LDS)
+    const __amdgpu_buffer_rsrc_t rs_in0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
-    int kr = 0, ks = 0, kc = 0, issued = 0, delta = 0;
+    int kr = 0, ks = 0, kc = 0, issued = 0;
+    // A vector instruction issued by ANY wave of a SIMD takes issue slots from that SIMD's MFMAs (tools/microbench/mfma_switch.hip),
+    // and the loader used to spend ~7 of them per A piece and 2 per B piece (93 per chunk and wave on the 192x256 tile).  Now a
+    // piece is its LDS-DMA instruction alone: the lane's voffset (pixel base + tap offset, or the out-of-range constant for a
+    // padding tap / a row past M) is rebuilt only when the tap changes, behind a scalar branch; the cin chunk inside the tap
+    // (stem: the filter-row pair) and B's chunk offset ride in the scalar offset operand, which is outside the range check and
+    // never leaves the pixel's Cin halfs / the weight row; past-the-end chunks take the zero-length descriptors (scalar selects).
+    unsigned avoff[PPA];
+#pragma unroll
+    for (int j = 0; j < PPA; ++j) {
+        if (!loads) break;
+        const bool ok = STEM ? hi0[j] == 0 : ((unsigned)hi0[j] < (unsigned)p.H && (unsigned)wi0[j] < (unsigned)p.W);
+        avoff[j] = ok ? (unsigned)abase[j] : OOB;
+    }
+    unsigned soffa = 0;
 
-    // one 1-KiB piece (i < PPA: A rows, else B rows) of the chunk being issued; `dead` = OOB once past the last chunk
-    auto piece = [&](int i, int stage, unsigned dead) {
+    // one 1-KiB piece (i < PPA: A rows, else B rows) of the chunk being issued; `live` = not past the last chunk
+    auto piece = [&](int i, int stage, bool live) {
         char* sA = smemg + stage * STAGEB;
         if (i < PPA) {
             if (PA % NL != 0 && lw + i * NL >= PA) return;  // wave-uniform: this wave has no piece in the partial round
-            const int hi = hi0[i] + kr, wi = wi0[i] + ks;
-            const bool ok = STEM ? hi0[i] == 0 : ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W);
-            const unsigned off = (ok ? (unsigned)(abase[i] + delta) : OOB) | dead;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(sA + (lw + i * NL) * 1024), 16, off, 0, 0, 0);
+            // (named operands: hipcc 7.2 silently drops the host stub of the kernel when this builtin takes expressions)
+            const __amdgpu_buffer_rsrc_t rs = live ? rs_in : rs_in0;
+            const unsigned voff = avoff[i];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(sA + (lw + i * NL) * 1024), 16, voff, soffa, 0, 0);
         } else {
             const int j = i - PPA;
             if (PB % NL != 0 && lw + j * NL >= PB) return;
-            const unsigned off = (bbase[j] + (unsigned)issued * 128u) | dead;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(sA + BM * 128 + (lw + j * NL) * 1024), 16, off, 0, 0, 0);
+            const __amdgpu_buffer_rsrc_t rs = live ? rs_w : rs_w0;
+            const unsigned voff = bbase[j], soffb = (unsigned)issued * 128u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(sA + BM * 128 + (lw + j * NL) * 1024), 16, voff, soffb, 0, 0);
         }
     };
     auto advance = [&]() {
         ++issued;
-        if (STEM) { delta = issued * 2 * p.W * 8; return; }
-        if (++kc == p.cin_chunks) { kc = 0; if (++ks == p.S) { ks = 0; ++kr; } }
-        delta = ((kr * p.W + ks) * p.Cin + kc * 64) * 2;
+        if (STEM) { soffa = (unsigned)(issued * 2 * p.W * 8); return; }
+        soffa += 128u;
+        if (++kc == p.cin_chunks) {  // uniform: next tap -- the only place with per-lane work
+            kc = 0;
+            soffa = 0;
+            if (++ks == p.S) { ks = 0; ++kr; }
+            int tr = __builtin_amdgcn_readfirstlane(kr), ts = __builtin_amdgcn_readfirstlane(ks);
+            asm volatile("" : "+s"(tr), "+s"(ts));  // keeps the tap change behind its branch: speculated, its VALU work would run every chunk
+            const int delta = ((tr * p.W + ts) * p.Cin) * 2;
+#pragma unroll
+            for (int j = 0; j < PPA; ++j) {
+                const bool ok = (unsigned)(hi0[j] + tr) < (unsigned)p.H && (unsigned)(wi0[j] + ts) < (unsigned)p.W;
+                avoff[j] = ok ? (unsigned)(abase[j] + delta) : OOB;
+            }
+        }
     };
-    auto deadmask = [&]() -> unsigned { return (unsigned)((p.nchunks - 1 - issued) >> 31) & OOB; };
+    auto is_live = [&]() -> bool { return issued < p.nchunks; };  // the chunk about to be issued exists
 
     f32x16h acc[TM][TN];
 #pragma unroll
@@ -263,55 +293,60 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, OCC) void conv_f16_glds_kernel
     if (loads) {
 #pragma unroll
         for (int s = 0; s < NSTAGE - 1; ++s) {
-            const unsigned dead = deadmask();
+            const bool live = is_live();
 #pragma unroll
-            for (int i = 0; i < PP; ++i) piece(i, s, dead);
+            for (int i = 0; i < PP; ++i) piece(i, s, live);
             advance();
         }
     }
-    int rd = 0, wr = NSTAGE - 1;
+    int wr = NSTAGE - 1;
     if (LW > 0 && wave >= NW) {  // loader wave: same barrier sequence as the MFMA waves, no matrix work
         for (int t = 0; t < p.nchunks; ++t) {
             asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NSTAGE - 2) * PP) : "memory");
-            const unsigned dead = deadmask();
+            const bool live = is_live();
 #pragma unroll
-            for (int i = 0; i < PP; ++i) piece(i, wr, dead);
+            for (int i = 0; i < PP; ++i) piece(i, wr, live);
             advance();
             wr = wr + 1 == NSTAGE ? 0 : wr + 1;
         }
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         return;
     }
-    for (int t = 0; t < p.nchunks; ++t) {
-        if (LW == 0) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NSTAGE - 2) * PP) : "memory");
-        else asm volatile("s_barrier" ::: "memory");
-        const unsigned dead = LW == 0 ? deadmask() : 0u;
-        const char* sb = smemg + rd * STAGEB;
-        f16x8 fa[2][TM], fb[2][TN];
+    // the chunk loop is unrolled over the ring so that the stage is a compile-time term: fragment addresses are then a
+    // per-lane base plus an immediate (the per-chunk v_add of the stage offset took MFMA issue slots, see above)
+    for (int t0 = 0; t0 < p.nchunks; t0 += NSTAGE) {
 #pragma unroll
-        for (int a = 0; a < TM; ++a) fa[0][a] = *(const f16x8*)(sb + a_off + a * 4096 + swz);
+        for (int u = 0; u < NSTAGE; ++u) {
+            if (t0 + u >= p.nchunks) break;  // uniform
+            const int rd = u, wr = (u + NSTAGE - 1) % NSTAGE;
+            if (LW == 0) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NSTAGE - 2) * PP) : "memory");
+            else asm volatile("s_barrier" ::: "memory");
+            const bool live = LW == 0 ? is_live() : true;
+            const char* sb = smemg + rd * STAGEB;
+            f16x8 fa[2][TM], fb[2][TN];
 #pragma unroll
-        for (int b = 0; b < TN; ++b) fb[0][b] = *(const f16x8*)(sb + b_off + b * 4096 + swz);
+            for (int a = 0; a < TM; ++a) fa[0][a] = *(const f16x8*)(sb + a_off + a * 4096 + swz);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {  // four 16-deep MFMA steps per chunk; fragments of step s+1 and the next chunk's pieces issue under step s
-            if (s < 3) {
-                const int so = swz ^ ((s + 1) << 5);
+            for (int b = 0; b < TN; ++b) fb[0][b] = *(const f16x8*)(sb + b_off + b * 4096 + swz);
 #pragma unroll
-                for (int a = 0; a < TM; ++a) fa[(s + 1) & 1][a] = *(const f16x8*)(sb + a_off + a * 4096 + so);
+            for (int s = 0; s < 4; ++s) {  // four 16-deep MFMA steps per chunk; fragments of step s+1 and the next chunk's pieces issue under step s
+                if (s < 3) {
+                    const int so = swz ^ ((s + 1) << 5);
 #pragma unroll
-                for (int b = 0; b < TN; ++b) fb[(s + 1) & 1][b] = *(const f16x8*)(sb + b_off + b * 4096 + so);
+                    for (int a = 0; a < TM; ++a) fa[(s + 1) & 1][a] = *(const f16x8*)(sb + a_off + a * 4096 + so);
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) fb[(s + 1) & 1][b] = *(const f16x8*)(sb + b_off + b * 4096 + so);
+                }
+#pragma unroll
+                for (int i = 0; i < PP; ++i)
+                    if (LW == 0 && i * ISSUE_STEPS / PP == s) piece(i, wr, live);
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s & 1][a], fb[s & 1][b], acc[a][b], 0, 0, 0);
             }
-#pragma unroll
-            for (int i = 0; i < PP; ++i)
-                if (LW == 0 && i * ISSUE_STEPS / PP == s) piece(i, wr, dead);
-#pragma unroll
-            for (int a = 0; a < TM; ++a)
-#pragma unroll
-                for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s & 1][a], fb[s & 1][b], acc[a][b], 0, 0, 0);
+            if (LW == 0) advance();
         }
-        if (LW == 0) advance();
-        rd = rd + 1 == NSTAGE ? 0 : rd + 1;
-        wr = wr + 1 == NSTAGE ? 0 : wr + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // trailing all-OOB pieces have landed; LDS is free
 
@@ -341,7 +376,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, 1) void conv3x3_f16_strip_kern
     extern __shared__ __attribute__((aligned(1024))) char smemg[];  // [A strip 0][A strip 1][B 0][B 1]
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform, and known to be (scalar address arithmetic)
     const int wm = wave / WN, wn = wave % WN;
     const int lw = LW > 0 ? wave - NW : wave;
     const bool loads = LW == 0 || wave >= NW;
@@ -393,35 +428,65 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, 1) void conv3x3_f16_strip_kern
     constexpr unsigned OOB = 0x80000000u;
     const int ngroups = 3 * p.cin_chunks, nsteps = 3 * ngroups;
 
-    // a third (t) of the strip of group gi = (r, kc) into A buffer `ab`
-    auto issue_strip = [&](int t, int gi, int ab) {
-        if (gi >= ngroups) return;
-        const int r = gi / p.cin_chunks, kc = gi - r * p.cin_chunks;
-        const int delta = (r * W * p.Cin + kc * 64) * 2;
+    // Loader state, all scalar except the per-piece voffsets (see the generic kernel: a vector instruction of ANY wave takes MFMA
+    // issue slots of its SIMD, and an integer division by a run-time value is vector code even on uniform operands):
+    //  * strips: group being issued (s_r, s_kc); a piece's voffset = its row base + r * W * Cin halfs, or out of range where the
+    //    filter row falls off the image -- rebuilt when r changes (three times per tile), cin chunk in the scalar offset;
+    //  * B: step being issued (b_r, b_kc, b_s), chunk offset in the scalar offset; steps / groups past the end issue nothing
+    //    (every step waits on vmcnt(0), so the count need not stay uniform).
+    unsigned avoff[3][RA];
+    auto strip_row = [&](int r) {
+        const int delta = r * W * p.Cin * 2;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int j = 0; j < RA; ++j) {
+                const bool ok = (unsigned)(a_hi0[t][j] + r) < (unsigned)H;
+                avoff[t][j] = ok ? (unsigned)(a_base[t][j] + delta) : OOB;
+            }
+    };
+    if (loads) strip_row(0);
+    int s_gi = 0, s_r = 0, s_kc = 0;
+    // a third (t) of the strip of the current group into A buffer `ab`
+    auto issue_strip = [&](int t, int ab) {
+        if (s_gi >= ngroups) return;
         char* dst = smemg + ab * ABYTES;
+        const unsigned soff = (unsigned)s_kc * 128u;
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
             const int spl = lw + j * NL;                 // piece inside the third
             const int sp = t * SP3 + spl;
             if (spl >= SP3 || sp >= SP || sp * 8 >= SR) continue;  // wave-uniform
-            const bool ok = (unsigned)(a_hi0[t][j] + r) < (unsigned)H;
-            const unsigned off = ok ? (unsigned)(a_base[t][j] + delta) : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(dst + sp * 1024), 16, off, 0, 0, 0);
+            const unsigned voff = avoff[t][j];  // (a named operand: hipcc 7.2 silently drops the host stub of the kernel otherwise)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(dst + sp * 1024), 16, voff, soff, 0, 0);
         }
     };
-    // the B chunk of step u = (gi, s) into B buffer `bb`: packed weights are (r, s, cin) ordered
-    auto issue_b = [&](int u, int bb) {
-        if (u >= nsteps) return;
-        const int gi = u / 3, s = u - gi * 3;
-        const int r = gi / p.cin_chunks, kc = gi - r * p.cin_chunks;
-        const unsigned koff = (unsigned)(((r * 3 + s) * p.cin_chunks + kc) * 128);
+    auto next_group = [&]() {
+        ++s_gi;
+        if (++s_kc == p.cin_chunks) {  // uniform: next filter row
+            s_kc = 0;
+            ++s_r;
+            int tr = __builtin_amdgcn_readfirstlane(s_r);
+            asm volatile("" : "+s"(tr));  // keeps the row change behind its branch
+            strip_row(tr);
+        }
+    };
+    int b_u = 0, b_r = 0, b_kc = 0, b_s = 0;
+    // the B chunk of the current step (r, kc, s) into B buffer `bb`: packed weights are (r, s, cin) ordered
+    auto issue_b = [&](int bb) {
+        if (b_u >= nsteps) return;
+        const unsigned koff = (unsigned)(((b_r * 3 + b_s) * p.cin_chunks + b_kc) * 128);
         char* dst = smemg + 2 * ABYTES + bb * BBYTES;
 #pragma unroll
         for (int j = 0; j < RB; ++j) {
             if (PB % NL != 0 && lw + j * NL >= PB) continue;
-            const unsigned off = bbase[j] + koff;  // (a named operand: hipcc 7.2 silently drops the host stub of the kernel otherwise)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(dst + (lw + j * NL) * 1024), 16, off, 0, 0, 0);
+            const unsigned voff = bbase[j];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(dst + (lw + j * NL) * 1024), 16, voff, koff, 0, 0);
         }
+    };
+    auto next_b = [&]() {
+        ++b_u;
+        if (++b_s == 3) { b_s = 0; if (++b_kc == p.cin_chunks) { b_kc = 0; ++b_r; } }
     };
 
     f32x16h acc[TM][TN];
@@ -450,48 +515,61 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, 1) void conv3x3_f16_strip_kern
 
     // prologue: whole strip of group 0, B of step 0
     if (loads) {
-        issue_strip(0, 0, 0); issue_strip(1, 0, 0); issue_strip(2, 0, 0);
-        issue_b(0, 0);
+        issue_strip(0, 0); issue_strip(1, 0); issue_strip(2, 0);
+        next_group();
+        issue_b(0);
+        next_b();
     }
-    int u = 0;
     if (LW > 0 && wave >= NW) {  // loader wave: the MFMA waves' barrier sequence, loads only
-        for (int gi = 0; gi < ngroups; ++gi)
+        int u = 0;
+        for (int gi = 0; gi < ngroups; ++gi) {
 #pragma unroll
             for (int s = 0; s < 3; ++s, ++u) {
                 asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-                issue_b(u + 1, (u + 1) & 1);
-                issue_strip(s, gi + 1, (gi + 1) & 1);
+                issue_b((u + 1) & 1);
+                next_b();
+                issue_strip(s, (gi + 1) & 1);
             }
+            next_group();
+        }
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         return;
     }
-    for (int gi = 0; gi < ngroups; ++gi) {
-        const char* sa = smemg + (gi & 1) * ABYTES;
+    // unrolled over two groups so that both LDS stages are compile-time terms (A buffer = gi & 1, B buffer = (gi + s) & 1, because
+    // u = 3 gi + s): fragment addresses are a per-lane base plus an immediate
+    for (int g0 = 0; g0 < ngroups; g0 += 2) {
 #pragma unroll
-        for (int s = 0; s < 3; ++s, ++u) {
-            if (LW == 0) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-            else asm volatile("s_barrier" ::: "memory");
-            const char* sb = smemg + b_off + (u & 1) * BBYTES;
-            f16x8 fa[2][TM], fb[2][TN];
+        for (int gg = 0; gg < 2; ++gg) {
+            if (g0 + gg >= ngroups) break;  // uniform
+            const char* sa = smemg + gg * ABYTES;
 #pragma unroll
-            for (int a = 0; a < TM; ++a) fa[0][a] = *(const f16x8*)(sa + abase_s[a][s]);
+            for (int s = 0; s < 3; ++s) {
+                if (LW == 0) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                else asm volatile("s_barrier" ::: "memory");
+                const int ub = (gg + s) & 1;
+                const char* sb = smemg + b_off + ub * BBYTES;
+                f16x8 fa[2][TM], fb[2][TN];
 #pragma unroll
-            for (int b = 0; b < TN; ++b) fb[0][b] = *(const f16x8*)(sb + b * 4096 + swzb);
+                for (int a = 0; a < TM; ++a) fa[0][a] = *(const f16x8*)(sa + abase_s[a][s]);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                if (ks < 3) {
+                for (int b = 0; b < TN; ++b) fb[0][b] = *(const f16x8*)(sb + b * 4096 + swzb);
 #pragma unroll
-                    for (int a = 0; a < TM; ++a) fa[(ks + 1) & 1][a] = *(const f16x8*)(sa + (abase_s[a][s] ^ ((ks + 1) << 5)));
+                for (int ks = 0; ks < 4; ++ks) {
+                    if (ks < 3) {
 #pragma unroll
-                    for (int b = 0; b < TN; ++b) fb[(ks + 1) & 1][b] = *(const f16x8*)(sb + b * 4096 + (swzb ^ ((ks + 1) << 5)));
+                        for (int a = 0; a < TM; ++a) fa[(ks + 1) & 1][a] = *(const f16x8*)(sa + (abase_s[a][s] ^ ((ks + 1) << 5)));
+#pragma unroll
+                        for (int b = 0; b < TN; ++b) fb[(ks + 1) & 1][b] = *(const f16x8*)(sb + b * 4096 + (swzb ^ ((ks + 1) << 5)));
+                    }
+                    if (LW == 0 && ks == 0) { issue_b(ub ^ 1); next_b(); }
+                    if (LW == 0 && ks == 1) issue_strip(s, gg ^ 1);
+#pragma unroll
+                    for (int a = 0; a < TM; ++a)
+#pragma unroll
+                        for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks & 1][a], fb[ks & 1][b], acc[a][b], 0, 0, 0);
                 }
-                if (LW == 0 && ks == 0) issue_b(u + 1, (u + 1) & 1);
-                if (LW == 0 && ks == 1) issue_strip(s, gi + 1, (gi + 1) & 1);
-#pragma unroll
-                for (int a = 0; a < TM; ++a)
-#pragma unroll
-                    for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks & 1][a], fb[ks & 1][b], acc[a][b], 0, 0, 0);
             }
+            if (LW == 0) next_group();
         }
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");

@@ -10,7 +10,7 @@ funcs = re.split(r'^(_Z\w+):.*$', src, flags=re.M)
 for name, body in zip(funcs[1::2], funcs[2::2]):
     if want not in name:
         continue
-    body = body.split("s_endpgm")[0]
+    body = body.split(".Lfunc_end")[0]
     blocks, cur = [], ["entry", []]
     for l in body.split("\n"):
         t = l.strip()
