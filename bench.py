@@ -314,7 +314,7 @@ def bench_yolact(a, dist):
                    "global_batch": a.batch * world, "parallelism": "batch-sharded x%d, RCCL all-gather of detections" % world,
                    "detections_per_image_rank0": [int(c) for c in counts]},
         "roofline": roofline_dict(("conv_f16_glds / conv3x3_f16_strip kernels (all conv launches of a step, v_mfma_f32_32x32x16_f16)" if a.fp16 else
-                                   "conv_mfma_kernel + conv_mfma16_kernel (all conv launches of a step; v_mfma_f32_32x32x2_f32 on 64x64 tiles, v_mfma_f32_16x16x4_f32 on the 32x32 / 32x64 blocks of small grids)"),
+                                   "conv_mfma_v2_kernel + conv_mfma16_kernel + conv_mfma_kernel (all conv launches of a step; v_mfma_f32_32x32x2_f32 on 64x64 tiles, v_mfma_f32_16x16x4_f32 on the 32x32 / 32x64 blocks of small grids)"),
                                   conv_flops, conv_ms, conv_launches, a.steps, ypeak, None if (a.fp16 or a.yolact_config != "resnet50") else "pmc_yolact.json"),
         "step_ms": {"mean": round(elapsed / a.steps * 1e3, 3), "p50": round(pct(step_ms, 0.5), 3), "p90": round(pct(step_ms, 0.9), 3),
                     "note": "intervals between consecutive per-step completion events on the results stream (pipelined multi-stream run)"},
@@ -447,7 +447,7 @@ def bench_maskrcnn(a, dist, summary=False):
         return None, model, gather
     value = batch * world * steps / elapsed
     traffic_file = "pmc_r101f16.json" if (fp16 and depth == 101 and batch == 8 and not c4) else None if (fp16 or c4 or depth != 50 or batch != 2) else "pmc_maskrcnn.json"
-    roof = roofline_dict("conv_f16_glds / conv3x3_f16_strip kernels (all conv launches of a step)" if fp16 else "conv_mfma_kernel + conv_mfma16_kernel (all conv launches of a step)",
+    roof = roofline_dict("conv_f16_glds / conv3x3_f16_strip kernels (all conv launches of a step)" if fp16 else "conv_mfma_v2_kernel + conv_mfma16_kernel + conv_mfma_kernel (all conv launches of a step)",
                          flops, ms, launches, steps, peak, traffic_file)
     workload = ("Mask R-CNN %s 1333x800 (padded 800x1344) bs=%d/GPU random weights, %s: conv1-4 + single-map RPN (6000 -> 1000) + RoIAlign + conv5 head + NMS + shared-extractor mask branch + paste (the README.md:263-273 config; not a BASELINE config)" % (tag, batch, prec)) if c4 else \
         "Mask R-CNN %s 1333x800 (padded 800x1344) bs=%d/GPU random weights, %s: backbone+FPN+RPN+RoIAlign+box head+NMS+mask head+paste (BASELINE configs[%d])" % (tag, batch, prec, 4 if fp16 else 2)
