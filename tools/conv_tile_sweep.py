@@ -1,14 +1,18 @@
 """Per-layer tile comparison on the GPU (dev tool): runs tools/conv_report.py for every (model, batch) with each forced tile and merges
-the per-layer times:  python tools/conv_tile_sweep.py 3,4,5,6,12 > gpurun_out/sweep.txt
+the per-layer times:  python tools/conv_tile_sweep.py 3,4,5,6,12 [f16] > gpurun_out/sweep.txt
 Columns: t64 (number of 64x64 tiles), Cout, K, ms per tile id, best, source (cry8 = Yolact bs 8, crm2 = Mask R-CNN bs 2 ...), layer."""
 import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tiles = [int(t) for t in (sys.argv[1] if len(sys.argv) > 1 else "3,4,5,6,12").split(",")]
 runs = [("yolact", 1), ("yolact", 8), ("maskrcnn", 1), ("maskrcnn", 2)]
+extra = []
+if len(sys.argv) > 2 and sys.argv[2] == "f16":  # the fp16 family: R101 bs 8 (configs[4]) and R50 bs 2
+    runs = [("maskrcnn", 8), ("maskrcnn", 2)]
+    extra = {8: ["fp16", "101"], 2: ["fp16", "50"]}
 rows = {}
 for model, bs in runs:
     for t in tiles:
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "conv_report.py"), str(bs), str(t), model], capture_output=True, text=True, timeout=600).stdout
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "conv_report.py"), str(bs), str(t), model] + (extra[bs] if extra else []), capture_output=True, text=True, timeout=600).stdout
         for ln in out.splitlines():
             m = re.match(r"(\S+) \[M=(\d+) K=(\d+) Cout=(\d+) (\d)x\d/(\d)\]\s+([\d.]+) GF\s+([\d.]+) ms", ln)
             if not m:
