@@ -505,6 +505,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // WN = 16x16 tiles per wave along Cout (block 32 x 32*WN): with WN = 2 a wave runs two independent accumulator chains off one
 // A fragment -- 0.75 instead of 1 LDS fragment read per MFMA, 3 instead of 4 global loads per 16 MFMAs, and the MFMA pipe sees
 // two chains per wave -- for the mid-size grids where the 32x32 block is steady-state LDS/issue-bound.
+// TIMING-ONLY build switches (results wrong, time only; both 0 in the product): HALF_B makes the 32x64 block read one B fragment instead of
+// two (a third fewer LDS reads), NO_LOADS turns every global load of the 16x16x4 kernels into a zero-length-descriptor load.
+// profiles/r02_experiments.txt has what they showed.
+#ifndef EXPERIMENT_HALF_B
+#define EXPERIMENT_HALF_B 0
+#endif
+#ifndef EXPERIMENT_NO_LOADS
+#define EXPERIMENT_NO_LOADS 0
+#endif
 template <int RING, bool LW, int WN = 1>
 __global__ __launch_bounds__(LW ? 512 : 256) void conv_mfma16_kernel(const ConvK p) {
     static_assert(WN == 1 || !LW, "the loader-wave variant runs one tile per wave");
@@ -574,7 +583,7 @@ __global__ __launch_bounds__(LW ? 512 : 256) void conv_mfma16_kernel(const ConvK
     unsigned avoff = ok0 ? abase : OOB;
     unsigned soffa = 0;
     auto load_chunk = [&](int slot) {
-        const bool live = chunk < p.nchunks;
+        const bool live = chunk < p.nchunks && !EXPERIMENT_NO_LOADS;
         const u32x4 rsa = live ? rs_in : rs_null, rsb = live ? rs_w : rs_null;
         const unsigned soffb = (unsigned)chunk * 128u;
         asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(ra[slot]) : "v"(avoff), "s"(rsa), "s"(soffa) : "memory");
@@ -627,7 +636,7 @@ __global__ __launch_bounds__(LW ? 512 : 256) void conv_mfma16_kernel(const ConvK
         for (int s = 0; s < 8; ++s) {
             fa[set][s] = sb[a_off + s * 4];
 #pragma unroll
-            for (int t = 0; t < WN; ++t) fb[set][t][s] = sb[b_off + t * 16 * ROW + s * 4];
+            for (int t = 0; t < WN; ++t) fb[set][t][s] = sb[b_off + (EXPERIMENT_HALF_B ? 0 : t) * 16 * ROW + s * 4];
         }
     };
     auto mma = [&](int set) {

@@ -28,6 +28,9 @@ def body(N, H, W):
 SETS = {"y8": body(8, 138, 138), "m2": body(2, 200, 336), "y4": body(4, 138, 138)[:6], "m1": body(1, 200, 336)[:6],
         # the large layers outside the ResNet body: Yolact P3 3x3s / protonet at 138^2 / fused 351-wide head; Mask R-CNN FPN + RPN 3x3s at
         # P2 / P3, mask-head 3x3 on 200 RoIs, FC6 as a 7x7 valid conv on 2000 RoIs
+        # res4 / res5 of Yolact at bs 8: grids of one to three 64x64 rounds (the 16x16x4 kernels' territory)
+        "mid": [(8, 35, 35, 256, 256, 3, 1, 1, 0), (8, 35, 35, 1024, 256, 1, 1, 0, 0), (8, 35, 35, 256, 1024, 1, 1, 0, 1), (8, 18, 18, 512, 512, 3, 1, 1, 0),
+                (2, 50, 84, 256, 256, 3, 1, 1, 0), (2, 50, 84, 1024, 256, 1, 1, 0, 0)],
         "big": [(8, 69, 69, 256, 256, 3, 1, 1, 0), (8, 138, 138, 256, 256, 3, 1, 1, 0), (8, 69, 69, 256, 351, 3, 1, 1, 0), (8, 35, 35, 256, 351, 3, 1, 1, 0),
                 (2, 200, 336, 256, 256, 3, 1, 1, 0), (2, 100, 168, 256, 256, 3, 1, 1, 0), (200, 14, 14, 256, 256, 3, 1, 1, 0),
                 (2000, 7, 7, 256, 1024, 7, 1, 0, 0), (2, 200, 336, 256, 256, 1, 1, 0, 0), (2, 200, 336, 64, 256, 1, 1, 0, 1)]}
