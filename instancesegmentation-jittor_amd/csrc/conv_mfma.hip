@@ -514,6 +514,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef EXPERIMENT_NO_LOADS
 #define EXPERIMENT_NO_LOADS 0
 #endif
+#ifndef EXPERIMENT_MODE  // bit 0: no per-chunk barrier, bit 1: no LDS stores (plain 16x16x4 loop)
+#define EXPERIMENT_MODE 0
+#endif
 template <int RING, bool LW, int WN = 1>
 __global__ __launch_bounds__(LW ? 512 : 256) void conv_mfma16_kernel(const ConvK p) {
     static_assert(WN == 1 || !LW, "the loader-wave variant runs one tile per wave");
@@ -667,8 +670,8 @@ __global__ __launch_bounds__(LW ? 512 : 256) void conv_mfma16_kernel(const ConvK
                 read_frags(0, cur);
                 mma(0);
                 __builtin_amdgcn_sched_barrier(0);
-                store_chunk((j + 1) % RING, cur ^ 1, Steady());
-                __syncthreads();
+                if (!(EXPERIMENT_MODE & 2)) store_chunk((j + 1) % RING, cur ^ 1, Steady());
+                if (!(EXPERIMENT_MODE & 1)) __syncthreads();
             }
         }
         // the past-the-end loads still in flight target ring registers the epilogue is about to reuse
