@@ -198,15 +198,15 @@ def roofline_pass(net, step, full_sync, steps, single_stream):
     return f.value, m.value, l.value
 
 
-def h2d_region(net, pinned, run, full_sync, dist, steps):
-    """The timed region once more with a pinned-host asynchronous H2D of every batch inside the step: the copy of batch i+1 goes
+def h2d_region(upload, run, full_sync, dist, steps):
+    """The timed region once more with a pinned-host asynchronous H2D of every batch inside the step: `upload(slot)` sends batch i+1
     to the other input buffer on the copy stream while batch i computes."""
-    net.upload_async(pinned, 0)
+    upload(0)
     dist.barrier(); full_sync()
     t0 = time.perf_counter()
     for i in range(steps):
         if i + 1 < steps:
-            net.upload_async(pinned, (i + 1) & 1)
+            upload((i + 1) & 1)
         run(i & 1)
     full_sync(); dist.barrier()
     return dist.max(time.perf_counter() - t0)
@@ -255,7 +255,8 @@ def bench_yolact(a, dist):
         net.set_param("multi_stream", 0.0)
     size = net.size
     rng = np.random.default_rng(20261003 + rank)
-    raw = rng.uniform(0, 255, (a.batch, size, size, 3)).astype(np.float32)
+    raw_u8 = rng.integers(0, 256, (a.batch, size, size, 3), dtype=np.uint8)  # what cv2.imread hands FastBaseTransform
+    raw = raw_u8.astype(np.float32)
     if ycfg.backbone == "darknet53":
         from isegmi.yolact import darknet_base_transform
         imgs = darknet_base_transform(raw)
@@ -291,14 +292,19 @@ def bench_yolact(a, dist):
         from isegmi.dist import unpack_records
         blocks = gather.fetch()
         rccl = {"rccl_ranks": int(gather.world), "ranks_with_records": int(sum(1 for r in range(world) if unpack_records(blocks[r], a.batch)["count"].any()))}
-    h2d_elapsed = None
+    h2d_elapsed = h2d_u8_elapsed = None
     if not a.no_h2d:
         pinned = _ffi.PinnedBuffer(imgs.shape)
         pinned.array[...] = imgs
-        h2d_elapsed = h2d_region(net, pinned, run, full_sync, dist, a.steps)
+        h2d_elapsed = h2d_region(lambda slot: net.upload_async(pinned, slot), run, full_sync, dist, a.steps)
+        pinned.free()
+        # the same with the device front end: the uint8 images cross PCIe (a quarter of the bytes), FastBaseTransform runs on the engine's stream
+        pin8 = _ffi.PinnedBuffer(raw_u8.shape, np.uint8)
+        pin8.array[...] = raw_u8
+        h2d_u8_elapsed = h2d_region(lambda slot: net.upload_u8_async(pin8, a.batch, size, size, slot), run, full_sync, dist, a.steps)
         net.upload(imgs)
         full_sync()
-        pinned.free()
+        pin8.free()
     counts = gpu["det.count"]
     value = a.batch * world * a.steps / elapsed
     if rank != 0:
@@ -324,6 +330,8 @@ def bench_yolact(a, dist):
     if h2d_elapsed is not None:
         out["value_incl_h2d"] = round(a.batch * world * a.steps / h2d_elapsed, 2)
         out["h2d_note"] = "same K steps with a pinned-host async H2D of every batch (%.1f MB) on a copy stream, double-buffered input; `value` itself has the batch resident in HBM" % (imgs.nbytes / 1e6)
+        out["value_incl_h2d_u8"] = round(a.batch * world * a.steps / h2d_u8_elapsed, 2)
+        out["h2d_u8_note"] = "the same with the device front end: the uint8 images cross PCIe (%.1f MB per batch) and FastBaseTransform runs on the engine's stream (isegmi_engine_preprocess_u8, bit-identical to the host transform)" % (raw_u8.nbytes / 1e6)
     if rccl:
         out.update(rccl)
     if not a.no_latency:
@@ -393,7 +401,8 @@ def bench_maskrcnn(a, dist, summary=False):
     else:
         sd, mcfg = maskrcnn_state_dict(1234, depth=depth), MaskRCNNConfig(depth=depth)
     rng = np.random.default_rng(20261003 + rank)
-    imgs = [rng.uniform(0, 255, (800, 1333, 3)).astype(np.float32) for _ in range(batch)]
+    imgs_u8 = [rng.integers(0, 256, (800, 1333, 3), dtype=np.uint8) for _ in range(batch)]  # what PIL's resize hands build_transform
+    imgs = [im.astype(np.float32) for im in imgs_u8]
     x, hw = prepare_images(imgs, mcfg.SIZE_DIVISIBILITY)
     model = MaskRCNN(sd, x.shape[1], x.shape[2], cfg=mcfg, max_batch=batch, device=dist.local_rank, fp16=fp16)
     if a.single_stream:
@@ -435,11 +444,16 @@ def bench_maskrcnn(a, dist, summary=False):
         from isegmi.dist import unpack_maskrcnn_records
         blocks = gather.fetch()
         rccl = {"rccl_ranks": int(gather.world), "ranks_with_records": int(sum(1 for r in range(world) if unpack_maskrcnn_records(blocks[r], batch, M=14 if c4 else 28)["count"].any()))}
-    h2d_elapsed = None
+    h2d_elapsed = h2d_u8_elapsed = None
     if not a.no_h2d:
         pinned = _ffi.PinnedBuffer(x.shape)
         pinned.array[...] = x
-        h2d_elapsed = h2d_region(model, pinned, run, full_sync, dist, steps)
+        h2d_elapsed = h2d_region(lambda slot: model.upload_async(pinned, slot), run, full_sync, dist, steps)
+        flat = np.concatenate([im.reshape(-1) for im in imgs_u8])
+        pin8 = _ffi.PinnedBuffer(flat.shape, np.uint8)
+        pin8.array[...] = flat
+        h2d_u8_elapsed = h2d_region(lambda slot: model.upload_u8_async(pin8, hw, slot), run, full_sync, dist, steps)
+        pin8.free()
         model.upload(x, hw)
         full_sync()
         pinned.free()
@@ -464,6 +478,8 @@ def bench_maskrcnn(a, dist, summary=False):
     if h2d_elapsed is not None:
         out["value_incl_h2d"] = round(batch * world * steps / h2d_elapsed, 3)
         out["h2d_note"] = "same K steps with a pinned-host async H2D of every batch (%.1f MB) on a copy stream, double-buffered input" % (x.nbytes / 1e6)
+        out["value_incl_h2d_u8"] = round(batch * world * steps / h2d_u8_elapsed, 3)
+        out["h2d_u8_note"] = "the same with the device front end: uint8 images (%.1f MB per batch), mean subtraction and padding on the engine's stream" % (flat.nbytes / 1e6)
     if rccl:
         out.update(rccl)
     if not a.no_latency:
@@ -506,7 +522,7 @@ def bench_maskrcnn(a, dist, summary=False):
         out["parity_note"] = "%d images: proposals, detection count, score, label, box, 28x28 masks and the masks pasted at 800x1333 all bit-equal" % batch
     if summary:
         keep = {"workload": out["config"]["workload"], "img_per_s": out["value"], "batch": batch, "ms_per_step": out["ms_per_step"], "steps": steps, "warmup": warmup,
-                "step_ms": out["step_ms"], "value_incl_h2d": out.get("value_incl_h2d"), "bs1": out.get("bs1"),
+                "step_ms": out["step_ms"], "value_incl_h2d": out.get("value_incl_h2d"), "value_incl_h2d_u8": out.get("value_incl_h2d_u8"), "bs1": out.get("bs1"),
                 "roofline": {k: roof[k] for k in ("achieved", "peak", "unit", "frac", "conv_ms_per_step", "launches_per_step", "algorithmic_gflop_per_step")},
                 "detections_per_image": out["config"]["detections_per_image"], "proposals_per_image": out["config"]["proposals_per_image"],
                 "cpu_baseline": out.get("cpu_baseline"), "parity_vs_oracle_on_bench_batch": out.get("parity_vs_oracle_on_bench_batch"),

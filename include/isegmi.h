@@ -87,6 +87,12 @@ int isegmi_op_conv2d_f16(const isegmi_conv_desc* d, const void* d_in, const void
  * NHWC C=3 batch (3 zero pixels on every side, zero 4th channel); weights are given as [Cout][7][7][4]. */
 int isegmi_op_pad_c3_to_f16_halo(const float* d_in_nhwc3, int N, int H, int W, void* d_out, void* stream);
 
+/* device front end (Y1 FastBaseTransform, README.md:243-249 `--image=...`; M1 build_transform + to_image_list, README.md:320-331): a uint8
+ * [N][Hin][Win][3] batch -> fp32 NHWC3 [N][Hpad][Wpad][3]: bilinear (align_corners = False) to Hout x Wout (identity when the sizes match),
+ * out[.., swap_rb ? 2-c : c] = (v[c] - mean3[c]) / std3[c], zeros in the padding; bit-identical to the numpy transforms of isegmi/transforms.py */
+int isegmi_op_preprocess_u8(const uint8_t* d_in, int N, int Hin, int Win, float* d_out, int Hout, int Wout, int Hpad, int Wpad,
+                            int64_t out_img_stride, const float* mean3, const float* std3, int swap_rb, void* stream);
+
 /* max_pool2d(k,s,p), -inf padding (M2/Y2 stem; k=1,s=2 = LastLevelMaxPool M3) */
 int isegmi_op_maxpool(const float* d_in, int N, int H, int W, int C, int k, int s, int p,
                       float* d_out, void* stream);
@@ -262,6 +268,9 @@ int isegmi_engine_stream(isegmi_engine* e, void** stream);
  * forward consumed its input, and the next forward is ordered behind it (stands where the reference's
  * jt.array(image) host->device transfer sits, README.md:311/331) */
 int isegmi_engine_upload_async(isegmi_engine* e, void* d_dst, const void* h_src_pinned, int64_t bytes);
+/* isegmi_op_preprocess_u8 on the engine's main stream: behind any upload_async of the bytes, in front of the next forward */
+int isegmi_engine_preprocess_u8(isegmi_engine* e, const uint8_t* d_u8, int N, int Hin, int Win, float* d_out, int Hout, int Wout,
+                                int Hpad, int Wpad, int64_t out_img_stride, const float* mean3, const float* std3, int swap_rb);
 /* per-step completion marks on the results stream; step_times returns the intervals between consecutive marks (ms) */
 int isegmi_engine_mark_step(isegmi_engine* e);
 int isegmi_engine_step_times(isegmi_engine* e, float* ms, int cap, int* count);

@@ -713,6 +713,13 @@ extern "C" int isegmi_engine_upload_async(isegmi_engine* h, void* d_dst, const v
     return ISEGMI_OK;
 }
 
+// Device front end on the engine's main stream (behind any upload_async, in front of the next forward): see preprocess_u8_kernel.
+extern "C" int isegmi_engine_preprocess_u8(isegmi_engine* h, const uint8_t* d_u8, int N, int Hin, int Win, float* d_out, int Hout, int Wout,
+                                           int Hpad, int Wpad, int64_t out_img_stride, const float* mean3, const float* std3, int swap_rb) {
+    ARG_CHECK(h, "null");
+    return preprocess_u8_launch(d_u8, N, Hin, Win, d_out, Hout, Wout, Hpad, Wpad, out_img_stride, mean3, std3, swap_rb, h->e.stream);
+}
+
 // Records a completion mark for the step just enqueued on the stream its results finish on; isegmi_engine_step_times returns
 // the intervals between consecutive marks (ms) -- per-step latency samples of a pipelined run -- and clears them.
 extern "C" int isegmi_engine_mark_step(isegmi_engine* h) {

@@ -158,6 +158,8 @@ int maskiou_rescore_launch(const float* feat, int N, int K, int HW, int C, const
 int deform_im2col_launch(const float* x, int N, int H, int W, int C, const float* om, int R, int S, int stride, int pad, int dil,
                          float* out, hipStream_t st);
 int pad_c3_c4_launch(const float* in, int64_t npix, float* out, hipStream_t st);
+int preprocess_u8_launch(const uint8_t* in, int N, int Hin, int Win, float* out, int Hout, int Wout, int Hpad, int Wpad, int64_t out_img_stride,
+                         const float* mean3, const float* std3, int swap_rb, hipStream_t st);
 int pad_c3_c32_launch(const float* in, int64_t npix, float* out, hipStream_t st);
 int topk_launch(const float* keys, int64_t row_stride, int rows, int n, int k, const int* limit, int rows_per_limit,
                 float* out_vals, int* out_idx, int* out_cnt, hipStream_t st);

@@ -104,6 +104,51 @@ __global__ void pad_c3_c4_kernel(const float* __restrict__ in, int64_t npix, flo
     }
 }
 
+// Device front end: a uint8 HxWx3 image batch -> the engines' fp32 NHWC3 input, bit-identical to the host
+// transforms of isegmi/transforms.py + fast_base_transform / prepare_images (numpy fp32 semantics: every multiply and add rounded on
+// its own -- this file is built with -ffp-contract=off -- and an IEEE division):
+//   v = bilinear(in, align_corners = False)   [F.interpolate; identity when the sizes match: the far taps' weight is exactly 0]
+//   out[.., swap ? 2 - c : c] = (v[c] - mean[c]) / std[c]      inside Hout x Wout, 0 in the padding up to Hpad x Wpad (to_image_list)
+// Uploading the bytes instead of the floats cuts the PCIe traffic of a batch by 4.
+struct PreU8 {
+    const uint8_t* in;
+    float* out;
+    int N, Hin, Win, Hout, Wout, Hpad, Wpad, swap;
+    int64_t out_img_stride;  // floats
+    float sch, scw;          // np.float32(Hin / Hout), np.float32(Win / Wout)
+    float mean[3], stdv[3];
+};
+
+__global__ void preprocess_u8_kernel(const PreU8 a) {
+    const int64_t total = (int64_t)a.N * a.Hpad * a.Wpad;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % a.Wpad);
+        const int64_t r = i / a.Wpad;
+        const int y = (int)(r % a.Hpad), n = (int)(r / a.Hpad);
+        float* o = a.out + (int64_t)n * a.out_img_stride + ((int64_t)y * a.Wpad + x) * 3;
+        if (y >= a.Hout || x >= a.Wout) { o[0] = 0.0f; o[1] = 0.0f; o[2] = 0.0f; continue; }
+        const float sy = fmaxf(((float)y + 0.5f) * a.sch - 0.5f, 0.0f), sx = fmaxf(((float)x + 0.5f) * a.scw - 0.5f, 0.0f);
+        int y0 = (int)sy, x0 = (int)sx;
+        y0 = y0 < a.Hin - 1 ? y0 : a.Hin - 1;
+        x0 = x0 < a.Win - 1 ? x0 : a.Win - 1;
+        const int y1 = y0 + 1 < a.Hin - 1 ? y0 + 1 : a.Hin - 1, x1 = x0 + 1 < a.Win - 1 ? x0 + 1 : a.Win - 1;
+        const float ly1 = sy - (float)y0, lx1 = sx - (float)x0;
+        const float ly0 = 1.0f - ly1, lx0 = 1.0f - lx1;
+        const uint8_t* img = a.in + (int64_t)n * a.Hin * a.Win * 3;
+        const uint8_t* p00 = img + ((int64_t)y0 * a.Win + x0) * 3;
+        const uint8_t* p01 = img + ((int64_t)y0 * a.Win + x1) * 3;
+        const uint8_t* p10 = img + ((int64_t)y1 * a.Win + x0) * 3;
+        const uint8_t* p11 = img + ((int64_t)y1 * a.Win + x1) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float top = (float)p00[c] * lx0 + (float)p01[c] * lx1;
+            const float bot = (float)p10[c] * lx0 + (float)p11[c] * lx1;
+            const float v = top * ly0 + bot * ly1;
+            o[a.swap ? 2 - c : c] = (v - a.mean[c]) / a.stdv[c];
+        }
+    }
+}
+
 __global__ void map_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, int fn) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float v = x[i];
@@ -215,10 +260,30 @@ int pad_c3_c4_launch(const float* in, int64_t npix, float* out, hipStream_t st) 
     return ISEGMI_OK;
 }
 
+int preprocess_u8_launch(const uint8_t* in, int N, int Hin, int Win, float* out, int Hout, int Wout, int Hpad, int Wpad, int64_t out_img_stride,
+                         const float* mean3, const float* std3, int swap_rb, hipStream_t st) {
+    ARG_CHECK(in && out && mean3 && std3, "null");
+    ARG_CHECK(N > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0 && Hpad >= Hout && Wpad >= Wout, "preprocess geometry");
+    ARG_CHECK(out_img_stride >= (int64_t)Hpad * Wpad * 3, "output image stride");
+    PreU8 a;
+    a.in = in; a.out = out; a.N = N; a.Hin = Hin; a.Win = Win; a.Hout = Hout; a.Wout = Wout; a.Hpad = Hpad; a.Wpad = Wpad; a.swap = swap_rb ? 1 : 0;
+    a.out_img_stride = out_img_stride;
+    a.sch = (float)((double)Hin / (double)Hout);  // np.float32(i / o)
+    a.scw = (float)((double)Win / (double)Wout);
+    for (int c = 0; c < 3; ++c) { a.mean[c] = mean3[c]; a.stdv[c] = std3[c]; }
+    hipLaunchKernelGGL(preprocess_u8_kernel, dim3(grid_for((int64_t)N * Hpad * Wpad)), dim3(256), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    return ISEGMI_OK;
+}
+
 }  // namespace isegmi
 
 using namespace isegmi;
 
+extern "C" int isegmi_op_preprocess_u8(const uint8_t* d_in, int N, int Hin, int Win, float* d_out, int Hout, int Wout, int Hpad, int Wpad,
+                                       int64_t out_img_stride, const float* mean3, const float* std3, int swap_rb, void* stream) {
+    return preprocess_u8_launch(d_in, N, Hin, Win, d_out, Hout, Wout, Hpad, Wpad, out_img_stride, mean3, std3, swap_rb, (hipStream_t)stream);
+}
 extern "C" int isegmi_op_maxpool(const float* d_in, int N, int H, int W, int C, int k, int s, int p, float* d_out,
                                  void* stream) {
     return maxpool_launch(d_in, N, H, W, C, k, s, p, d_out, (hipStream_t)stream);

@@ -55,7 +55,6 @@ def _overlay(img, masks, boxes, classes):
 def cmd_eval(a):
     """Yolact eval.py: evalimage / evalimages (+ Detections.dump when --output_coco_json is given)."""
     from .coco import dump, yolact_results
-    from .transforms import yolact_transform
     from .yolact import Yolact, YolactConfig, postprocess
     # upstream eval.py --config: yolact_resnet50_config (default here), yolact_base_config (R101), yolact_im700_config, and the
     # YOLACT++ pair yolact_plus_resnet50_config / yolact_plus_base_config (DCNv2 backbones, 9 anchors, mask re-scoring)
@@ -76,7 +75,7 @@ def cmd_eval(a):
     for i, (src, dst) in enumerate(jobs):
         frame = _load_image_bgr(src)
         h, w = frame.shape[:2]
-        preds = net(yolact_transform(frame, net.size, darknet=cfg.backbone == "darknet53"))
+        preds = net(np.ascontiguousarray(frame, np.uint8)[None])  # device front end: FastBaseTransform (resize, normalise, RGB) on the GPU
         classes, scores, boxes, masks = postprocess(preds, w, h, score_threshold=a.score_threshold)
         mask_scores = None
         if isinstance(scores, list):  # YOLACT++ re-scoring: [box scores, mask scores] (upstream prep_display takes scores[0])

@@ -302,6 +302,40 @@ class MaskRCNN:
         assert self._hw.shape[0] == x.shape[0]
         return x.shape[0]
 
+    def upload_u8(self, images_bgr_u8, slot=0):
+        """to_image_list on the device (M1): a list of already-resized HxWx3 uint8 BGR images (what PIL's resize returns) -> mean-subtracted,
+        zero-padded fp32 batch in the input buffer, bit-identical to prepare_images() on the host; a quarter of the PCIe bytes."""
+        assert 0 < len(images_bgr_u8) <= self.max_batch
+        ims = [np.ascontiguousarray(im, np.uint8) for im in images_bgr_u8]
+        hw = np.array([im.shape[:2] for im in ims], np.int32)
+        assert hw[:, 0].max() <= self.H and hw[:, 1].max() <= self.W, "image larger than the padded input"
+        flat = np.concatenate([im.reshape(-1) for im in ims])
+        st = self._u8_staging(slot, flat.nbytes)
+        _ffi.check(_ffi.lib().isegmi_h2d(st.ptr, flat.ctypes.data_as(C.c_void_p), C.c_int64(flat.nbytes)))
+        d_out = self.input_buffer(slot).ptr.value
+        off = 0
+        for i, im in enumerate(ims):
+            h, w = int(hw[i, 0]), int(hw[i, 1])
+            self._preprocess_u8(st.ptr.value + off, 1, h, w, d_out + i * self.H * self.W * 3 * 4, h, w, self.H, self.W, PIXEL_MEAN, (1.0, 1.0, 1.0), False)
+            off += h * w * 3
+        self._hw = hw
+        return len(ims)
+
+    def upload_u8_async(self, pinned_u8, image_hw, slot=0):
+        """upload_u8 from a uint8 _ffi.PinnedBuffer holding the images back to back (each h x w x 3), on the engine's copy stream."""
+        hw = np.ascontiguousarray(image_hw, np.int32).reshape(-1, 2)
+        nbytes = int((hw[:, 0].astype(np.int64) * hw[:, 1] * 3).sum())
+        assert pinned_u8.nbytes >= nbytes and hw.shape[0] <= self.max_batch
+        st = self._u8_staging(slot, nbytes)
+        _ffi.check(_ffi.lib().isegmi_engine_upload_async(self._h, st.ptr, pinned_u8.ptr, C.c_int64(nbytes)))
+        d_out = self.input_buffer(slot).ptr.value
+        off = 0
+        for i in range(hw.shape[0]):
+            h, w = int(hw[i, 0]), int(hw[i, 1])
+            self._preprocess_u8(st.ptr.value + off, 1, h, w, d_out + i * self.H * self.W * 3 * 4, h, w, self.H, self.W, PIXEL_MEAN, (1.0, 1.0, 1.0), False)
+            off += h * w * 3
+        self._hw = hw
+
     def forward_device(self, n, slot=0):
         _ffi.check(_ffi.lib().isegmi_maskrcnn_forward(self._h, self.input_buffer(slot).ptr, self._hw.ctypes.data_as(C.c_void_p), n))
 
@@ -321,10 +355,11 @@ class MaskRCNN:
     fetch = None  # bound below (shared with Yolact)
     timings = None
 
-    def __call__(self, batch_nhwc3, image_hw):
+    def __call__(self, batch_nhwc3, image_hw=None):
         """-> list of BoxList (one per image, in network-input coordinates) with scores, labels, mask [n,1,28,28]
-        (14x14 for the C4 predictor)."""
-        n = self.upload(batch_nhwc3, image_hw)
+        (14x14 for the C4 predictor).  With image_hw = None the first argument is a list of already-resized uint8 BGR images and goes
+        through the device front end (upload_u8: mean subtraction and padding on the GPU)."""
+        n = self.upload_u8(batch_nhwc3) if image_hw is None else self.upload(batch_nhwc3, image_hw)
         self.forward_device(n)
         self.sync()
         cnt = self.fetch("det.count", n)
@@ -357,4 +392,6 @@ MaskRCNN.timings = _Y.timings
 MaskRCNN.input_buffer = _Y.input_buffer
 MaskRCNN.upload_async = _Y.upload_async
 MaskRCNN.mark_step = _Y.mark_step
+MaskRCNN._u8_staging = _Y._u8_staging
+MaskRCNN._preprocess_u8 = _Y._preprocess_u8
 MaskRCNN.step_times = _Y.step_times

@@ -12,8 +12,8 @@ import collections
 import numpy as np
 
 from .coco import COCO_CLASSES
-from .maskrcnn import BoxList, MaskRCNN, MaskRCNNConfig, prepare_images
-from .transforms import maskrcnn_resize
+from .maskrcnn import BoxList, MaskRCNN, MaskRCNNConfig
+from .transforms import maskrcnn_resize_u8
 
 
 class COCODemo:
@@ -56,10 +56,10 @@ class COCODemo:
     def compute_prediction(self, original_image):
         """-> BoxList in ORIGINAL image coordinates with scores, labels and mask [n,1,H,W] uint8 (Masker output)."""
         h, w = original_image.shape[:2]
-        resized = maskrcnn_resize(original_image, self.min_image_size, self.max_image_size)
-        x, hw = prepare_images([resized], self.cfg.SIZE_DIVISIBILITY)
-        model = self._model(x.shape[1], x.shape[2])
-        (pred,) = model(x, hw)
+        resized = maskrcnn_resize_u8(original_image, self.min_image_size, self.max_image_size)
+        d = self.cfg.SIZE_DIVISIBILITY
+        model = self._model(-(-resized.shape[0] // d) * d, -(-resized.shape[1] // d) * d)
+        (pred,) = model([resized])  # device front end: the bytes cross PCIe, mean subtraction + padding (to_image_list) run on the GPU
         model.paste_device(h, w, [(w, h)])
         model.sync()
         n = len(pred)

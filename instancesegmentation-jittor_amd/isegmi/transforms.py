@@ -24,14 +24,19 @@ def get_size(w, h, min_size=800, max_size=1333):
     return oh, ow
 
 
-def maskrcnn_resize(image_bgr_u8, min_size=800, max_size=1333):
-    """HxWx3 uint8 BGR -> resized float32 BGR 0..255 (PIL bilinear, as torchvision F.resize on a PIL image)."""
+def maskrcnn_resize_u8(image_bgr_u8, min_size=800, max_size=1333):
+    """HxWx3 uint8 BGR -> resized uint8 BGR (PIL bilinear, as torchvision F.resize on a PIL image; PIL rounds back to bytes)."""
     from PIL import Image
     h, w = image_bgr_u8.shape[:2]
     oh, ow = get_size(w, h, min_size, max_size)
     rgb = Image.fromarray(np.ascontiguousarray(image_bgr_u8[:, :, ::-1]))
     rgb = rgb.resize((ow, oh), Image.BILINEAR)
-    return np.asarray(rgb, np.float32)[:, :, ::-1]
+    return np.ascontiguousarray(np.asarray(rgb, np.uint8)[:, :, ::-1])
+
+
+def maskrcnn_resize(image_bgr_u8, min_size=800, max_size=1333):
+    """The same as float32 BGR 0..255 (the input of prepare_images on the host path)."""
+    return maskrcnn_resize_u8(image_bgr_u8, min_size, max_size).astype(np.float32)
 
 
 def bilinear_resize(img, oh, ow):

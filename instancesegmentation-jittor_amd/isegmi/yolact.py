@@ -263,6 +263,49 @@ class Yolact:
         assert pinned.nbytes <= d.nbytes
         _ffi.check(_ffi.lib().isegmi_engine_upload_async(self._h, d.ptr, pinned.ptr, C.c_int64(pinned.nbytes)))
 
+    # -- device front end: bytes go over PCIe, the transform runs on the engine's stream ------------------------------------
+    def _u8_staging(self, slot, nbytes):
+        st = getattr(self, "_u8", None)
+        if st is None:
+            st = self._u8 = [None, None]
+        if st[slot] is None or st[slot].nbytes < nbytes:
+            if st[slot] is not None:
+                self.sync()  # a queued transform may still read the old buffer
+                st[slot].free()
+            st[slot] = _ffi.DeviceBuffer((int(nbytes),), np.uint8)
+        return st[slot]
+
+    def _preprocess_u8(self, d_u8_ptr, n, hin, win, d_out_ptr, hout, wout, hpad, wpad, mean, std, swap_rb):
+        m = (C.c_float * 3)(*[float(v) for v in mean]); sd = (C.c_float * 3)(*[float(v) for v in std])
+        _ffi.check(_ffi.lib().isegmi_engine_preprocess_u8(self._h, C.c_void_p(d_u8_ptr), n, hin, win, C.c_void_p(d_out_ptr), hout, wout, hpad, wpad,
+                                                          C.c_int64(hpad * wpad * 3), m, sd, 1 if swap_rb else 0))
+
+    def _u8_norm(self):
+        darknet = self.cfg.backbone == "darknet53"
+        return ((0.0, 0.0, 0.0), (255.0, 255.0, 255.0)) if darknet else (MEANS, STD)
+
+    def upload_u8(self, images_bgr_u8, slot=0):
+        """FastBaseTransform on the device (Y1): [N, H, W, 3] uint8 BGR images of one size -> bilinear resize to the network size, the
+        backbone's normalisation, RGB -- bit-identical to isegmi.transforms.yolact_transform on the host, a quarter of the PCIe bytes
+        (and none of the host's resize arithmetic).  The previous forward on this input slot must have completed, as for upload()."""
+        x = np.ascontiguousarray(images_bgr_u8, np.uint8)
+        assert x.ndim == 4 and x.shape[3] == 3 and x.shape[0] <= self.max_batch, x.shape
+        n, h, w = x.shape[:3]
+        st = self._u8_staging(slot, x.nbytes)
+        _ffi.check(_ffi.lib().isegmi_h2d(st.ptr, x.ctypes.data_as(C.c_void_p), C.c_int64(x.nbytes)))
+        mean, std = self._u8_norm()
+        self._preprocess_u8(st.ptr.value, n, h, w, self.input_buffer(slot).ptr.value, self.size, self.size, self.size, self.size, mean, std, True)
+        return n
+
+    def upload_u8_async(self, pinned_u8, n, h, w, slot=0):
+        """upload_u8 from a uint8 _ffi.PinnedBuffer on the engine's copy stream (see upload_async for the ordering)."""
+        nbytes = n * h * w * 3
+        assert pinned_u8.nbytes >= nbytes and n <= self.max_batch
+        st = self._u8_staging(slot, nbytes)
+        _ffi.check(_ffi.lib().isegmi_engine_upload_async(self._h, st.ptr, pinned_u8.ptr, C.c_int64(nbytes)))
+        mean, std = self._u8_norm()
+        self._preprocess_u8(st.ptr.value, n, h, w, self.input_buffer(slot).ptr.value, self.size, self.size, self.size, self.size, mean, std, True)
+
     def mark_step(self):
         _ffi.check(_ffi.lib().isegmi_engine_mark_step(self._h))
 
@@ -304,8 +347,11 @@ class Yolact:
         return [(ns[i], float(ms[i])) for i in range(cnt.value)]
 
     def __call__(self, batch_nhwc3):
-        """Upstream-shaped result: list (one per image) of {'detection': {...}|None, 'net': self}."""
-        n = self.upload(batch_nhwc3)
+        """Upstream-shaped result: list (one per image) of {'detection': {...}|None, 'net': self}.  A uint8 [N, H, W, 3] batch is taken as
+        raw BGR images of any one size and goes through the device front end (upload_u8: FastBaseTransform on the GPU); a float batch is
+        the already-transformed network input."""
+        raw = np.asarray(batch_nhwc3).dtype == np.uint8
+        n = self.upload_u8(batch_nhwc3) if raw else self.upload(batch_nhwc3)
         self.forward_device(n)
         self.sync()
         cnt = self.fetch("det.count", n)

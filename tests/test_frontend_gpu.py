@@ -1,0 +1,90 @@
+"""Device front end: uint8 images go over PCIe, resize / normalise / pad run on the engine's stream.
+Bit-identical to the host transforms (isegmi/transforms.py, fast_base_transform, prepare_images), which is what the engines were
+fed before and what the oracle's end-to-end tests consume."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _fetch_input(net, n, shape):
+    from isegmi import _ffi
+    out = np.empty((n,) + shape, np.float32)
+    net.sync()
+    _ffi.check(_ffi.lib().isegmi_d2h(out.ctypes.data_as(C.c_void_p), net.input_buffer(0).ptr, C.c_int64(out.nbytes)))
+    return out
+
+
+@pytest.mark.parametrize("hw", [(200, 200), (123, 171), (480, 640), (37, 29)])
+def test_yolact_upload_u8_equals_host_transform(hw):
+    from isegmi.transforms import yolact_transform
+    from isegmi.weights import yolact_state_dict
+    from isegmi.yolact import Yolact
+    rng = np.random.default_rng(hw[0] * 1000 + hw[1])
+    net = Yolact(yolact_state_dict(1234), max_batch=3, input_size=200)
+    imgs = rng.integers(0, 256, (3,) + hw + (3,), dtype=np.uint8)
+    imgs[0, :3, :5] = 0; imgs[1, -2:, -2:] = 255   # saturated corners
+    n = net.upload_u8(imgs)
+    got = _fetch_input(net, n, (200, 200, 3))
+    ref = np.concatenate([yolact_transform(im, 200) for im in imgs])
+    assert got.shape == ref.shape and np.array_equal(got, ref)
+    net.close()
+
+
+def test_yolact_upload_u8_same_detections_as_host_path():
+    from isegmi.transforms import yolact_transform
+    from isegmi.weights import yolact_state_dict
+    from isegmi.yolact import Yolact
+    rng = np.random.default_rng(5)
+    net = Yolact(yolact_state_dict(1234), max_batch=2, input_size=200)
+    imgs = rng.integers(0, 256, (2, 240, 320, 3), dtype=np.uint8)
+    host = net(np.concatenate([yolact_transform(im, 200) for im in imgs]))
+    a = [(o["detection"] or {}).get("score") for o in host]
+    n = net.upload_u8(imgs)
+    net.forward_device(n); net.sync()
+    cnt = net.fetch("det.count", n); score = net.fetch("det.score", n)
+    for i in range(n):
+        c = int(cnt[i])
+        assert (a[i] is None and c == 0) or np.array_equal(a[i], score[i, :c])
+    net.close()
+
+
+def test_yolact_upload_u8_async_and_darknet_norm():
+    from isegmi import _ffi
+    from isegmi.transforms import yolact_transform
+    from isegmi.weights import yolact_state_dict
+    from isegmi.yolact import Yolact, YolactConfig
+    rng = np.random.default_rng(9)
+    net = Yolact(yolact_state_dict(1234), max_batch=2, input_size=200)
+    pin = _ffi.PinnedBuffer((2, 150, 210, 3), np.uint8)
+    pin.array[...] = rng.integers(0, 256, pin.array.shape, dtype=np.uint8)
+    net.upload_u8_async(pin, 2, 150, 210)
+    got = _fetch_input(net, 2, (200, 200, 3))
+    ref = np.concatenate([yolact_transform(im, 200) for im in pin.array])
+    assert np.array_equal(got, ref)
+    net.close(); pin.free()
+    dk = Yolact(yolact_state_dict(7, backbone="darknet53"), cfg=YolactConfig.darknet53(), max_batch=1, input_size=200)
+    img = rng.integers(0, 256, (1, 90, 130, 3), dtype=np.uint8)
+    dk.upload_u8(img)
+    assert np.array_equal(_fetch_input(dk, 1, (200, 200, 3)), yolact_transform(img[0], 200, darknet=True))
+    dk.close()
+
+
+def test_maskrcnn_upload_u8_equals_prepare_images():
+    from isegmi.maskrcnn import MaskRCNN, MaskRCNNConfig, prepare_images
+    from isegmi.weights import maskrcnn_state_dict
+    rng = np.random.default_rng(3)
+    ims = [rng.integers(0, 256, (200, 333, 3), dtype=np.uint8), rng.integers(0, 256, (256, 190, 3), dtype=np.uint8)]
+    ref, hw = prepare_images([im.astype(np.float32) for im in ims])
+    net = MaskRCNN(maskrcnn_state_dict(1234, 50), ref.shape[1], ref.shape[2], cfg=MaskRCNNConfig(depth=50), max_batch=2)
+    n = net.upload_u8(ims)
+    got = _fetch_input(net, n, ref.shape[1:])
+    assert np.array_equal(got, ref) and np.array_equal(net._hw, hw)
+    # and the forward sees the same proposals / detections as with the host-prepared batch
+    net.forward_device(n); net.sync()
+    s_dev = net.fetch("det.score", n).copy()
+    net.upload(ref, hw); net.forward_device(n); net.sync()
+    assert np.array_equal(s_dev, net.fetch("det.score", n))
+    net.close()
