@@ -29,7 +29,7 @@ for it in range(rounds):
     act = int(rng.integers(0, 5))
     if act == 4 and res is None: act = 3
     ref = ora.conv2d(x, w, stride, pad, sc, sh, res, act)
-    for tile in (0, 3, 4, 5, 6):
+    for tile in (0, 3, 4, 5, 6, 10, 12):
         got = ffi.conv2d(x, w, stride, pad, sc, sh, res, act, tile)
         if not np.array_equal(got, ref): fail(("conv", it, tile, x.shape, w.shape, stride, pad, act))
 print("conv ok", rounds)
