@@ -955,15 +955,16 @@ int conv2d_f16_launch(const isegmi_conv_desc* d, const void* in, const void* w, 
         // measured tile on 12 of 14 layer shapes, worst 5 %): time ~ (blocks on the busiest CU) x BM x BN x (K / eff + epi),
         // eff = the tile's relative MFMA efficiency (a 64x64 tile cannot exceed ~1/2 of the MFMA rate: 32 FLOP per L2 byte), epi = the
         // tile's fixed cost in K units.  Tiles that share a CU (occ > 1) are assumed packed onto as few CUs as the dispatcher may choose.
-        // Round 2 built persistent forms of the loader-wave tiles (32-39) and refitted (eff, epi) on an in-model sweep
-        // (profiles/r02_conv_f16_tile_sweep.txt): ahead per layer and in the single-process layer report, BEHIND in bench.py on the same
-        // box (R101 bs 8: 759 vs 770 img/s, conv 9.66 vs 9.43 ms per step, two runs each) -- so the round-1 table stands and the
-        // persistent tiles stay selectable by id only.
+        // Round 2 built persistent forms of the loader-wave tiles (32-39).  Swapped in with the round-1 parameters they are ahead in bench.py
+        // on the same box (R101 bs 8: 795 / 799 vs 790 / 792 img/s, conv 9.18 vs 9.21 ms per step); a refit of (eff, epi) on an in-model
+        // per-layer sweep (profiles/r02_conv_f16_tile_sweep.txt) looked better per layer and measured BEHIND end to end (759 vs 770 img/s),
+        // so the round-1 parameters stand (profiles/r02_experiments.txt).
         static const struct { int id, bm, bn, occ; double eff, epi; } T[] = {
             {1, 256, 256, 1, 1.0, 64}, {2, 256, 128, 1, 0.95, 64}, {3, 128, 128, 2, 0.85, 64}, {4, 64, 64, 3, 0.6, 64}, {5, 64, 128, 3, 0.75, 64},
             {6, 64, 256, 2, 0.75, 64}, {7, 128, 256, 1, 0.95, 64}, {8, 128, 64, 2, 0.6, 64}, {9, 192, 256, 1, 1.0, 64}, {10, 192, 128, 2, 1.0, 64},
             {11, 160, 256, 1, 0.88, 64},
-            {12, 192, 256, 1, 1.11, 64}, {13, 256, 256, 1, 1.08, 64}, {14, 256, 128, 1, 0.97, 64}, {16, 160, 256, 1, 0.975, 64}, {17, 192, 256, 1, 1.14, 64}, {19, 128, 256, 1, 1.0, 64}, {20, 192, 128, 2, 1.04, 64},
+            // (12 / 13 / 14 / 17 / 19 in their persistent forms 32 / 33 / 34 / 37 / 39, same parameters)
+            {32, 192, 256, 1, 1.11, 64}, {33, 256, 256, 1, 1.08, 64}, {34, 256, 128, 1, 0.97, 64}, {16, 160, 256, 1, 0.975, 64}, {37, 192, 256, 1, 1.14, 64}, {39, 128, 256, 1, 1.0, 64}, {20, 192, 128, 2, 1.04, 64},
             {26, 192, 256, 1, 1.18, 64}, {27, 256, 128, 1, 1.03, 64}, {28, 160, 256, 1, 1.0, 64}, {29, 192, 256, 1, 1.21, 64}};
         const bool strip_ok = d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1;
         double best = 0.0;
