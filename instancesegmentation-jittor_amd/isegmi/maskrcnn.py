@@ -306,7 +306,9 @@ class MaskRCNN:
         """to_image_list on the device (M1): a list of already-resized HxWx3 uint8 BGR images (what PIL's resize returns) -> mean-subtracted,
         zero-padded fp32 batch in the input buffer, bit-identical to prepare_images() on the host; a quarter of the PCIe bytes."""
         assert 0 < len(images_bgr_u8) <= self.max_batch
-        ims = [np.ascontiguousarray(im, np.uint8) for im in images_bgr_u8]
+        ims = [np.ascontiguousarray(im) for im in images_bgr_u8]
+        if any(im.dtype != np.uint8 or im.ndim != 3 or im.shape[2] != 3 for im in ims):
+            raise TypeError("upload_u8 takes HxWx3 uint8 images: a float batch goes through upload(batch, image_hw)")
         hw = np.array([im.shape[:2] for im in ims], np.int32)
         assert hw[:, 0].max() <= self.H and hw[:, 1].max() <= self.W, "image larger than the padded input"
         flat = np.concatenate([im.reshape(-1) for im in ims])

@@ -288,7 +288,9 @@ class Yolact:
         """FastBaseTransform on the device (Y1): [N, H, W, 3] uint8 BGR images of one size -> bilinear resize to the network size, the
         backbone's normalisation, RGB -- bit-identical to isegmi.transforms.yolact_transform on the host, a quarter of the PCIe bytes
         (and none of the host's resize arithmetic).  The previous forward on this input slot must have completed, as for upload()."""
-        x = np.ascontiguousarray(images_bgr_u8, np.uint8)
+        x = np.ascontiguousarray(images_bgr_u8)
+        if x.dtype != np.uint8:
+            raise TypeError("upload_u8 takes uint8 images (got %s): a float batch is the already-transformed input of upload()" % x.dtype)
         assert x.ndim == 4 and x.shape[3] == 3 and x.shape[0] <= self.max_batch, x.shape
         n, h, w = x.shape[:3]
         st = self._u8_staging(slot, x.nbytes)

@@ -88,3 +88,17 @@ def test_maskrcnn_upload_u8_equals_prepare_images():
     net.upload(ref, hw); net.forward_device(n); net.sync()
     assert np.array_equal(s_dev, net.fetch("det.score", n))
     net.close()
+
+
+def test_upload_u8_rejects_float_input():
+    from isegmi.maskrcnn import MaskRCNN, MaskRCNNConfig
+    from isegmi.weights import maskrcnn_state_dict, yolact_state_dict
+    from isegmi.yolact import Yolact
+    net = Yolact(yolact_state_dict(1234), max_batch=1, input_size=200)
+    with pytest.raises(TypeError):
+        net.upload_u8(np.zeros((1, 200, 200, 3), np.float32))
+    net.close()
+    m = MaskRCNN(maskrcnn_state_dict(1234, 50), 64, 64, cfg=MaskRCNNConfig(depth=50), max_batch=1)
+    with pytest.raises(TypeError):
+        m([np.zeros((64, 64, 3), np.float32)])  # image_hw forgotten: must not be truncated to bytes silently
+    m.close()
