@@ -951,25 +951,26 @@ int conv2d_f16_launch(const isegmi_conv_desc* d, const void* in, const void* w, 
         return launch_g<64, 64, 2, 2, 3, 3, true>(k, st);
     }
     if (tile == 0) {
-        // Cost model fitted to tools/conv_f16_bench.py on MI355X (profiles/r01_conv_f16_tiles_v2.txt; picks within 1 % of the best
-        // measured tile on 12 of 14 layer shapes, worst 5 %): time ~ (blocks on the busiest CU) x BM x BN x (K / eff + epi),
-        // eff = the tile's relative MFMA efficiency (a 64x64 tile cannot exceed ~1/2 of the MFMA rate: 32 FLOP per L2 byte), epi = the
-        // tile's fixed cost in K units.  Tiles that share a CU (occ > 1) are assumed packed onto as few CUs as the dispatcher may choose.
-        // Round 2 built persistent forms of the loader-wave tiles (32-39).  Swapped in with the round-1 parameters they are ahead in bench.py
-        // on the same box (R101 bs 8: 795 / 799 vs 790 / 792 img/s, conv 9.18 vs 9.21 ms per step); a refit of (eff, epi) on an in-model
-        // per-layer sweep (profiles/r02_conv_f16_tile_sweep.txt) looked better per layer and measured BEHIND end to end (759 vs 770 img/s),
-        // so the round-1 parameters stand (profiles/r02_experiments.txt).
+        // Cost model: time ~ (blocks on the busiest CU) x BM x BN x (K / eff + epi) -- eff = the tile's relative MFMA efficiency (a 64x64
+        // tile cannot exceed ~1/2 of the MFMA rate: 32 FLOP per L2 byte), epi = its per-tile fixed cost in K units (ring fill + epilogue:
+        // small for the persistent kernels, which overlap both with the neighbouring tiles).  Tiles that share a CU (occ > 1) are assumed
+        // packed onto as few CUs as the dispatcher may choose.  Round 2: persistent forms of the loader-wave tiles (32-39), and (eff, epi)
+        // refitted on an in-model sweep of R101 bs 8 and R50 bs 2 with every generic tile forced in turn (tools/conv_tile_sweep.py ... f16
+        // -> profiles/r02_conv_f16_tile_sweep.txt).  Same-box A/B in bench.py, R101 bs 8, two runs each: round-1 table 815 / 813 img/s
+        // (conv 8.98 ms per step), persistent ids with the round-1 parameters 855 / 853 (8.53), refit 865 / 864 (8.33 ms = 656 TF/s).
+        // The non-persistent big tiles 1 / 2 / 7 / 9 / 11 / 12-14 / 17 / 19 left the candidate list.
         static const struct { int id, bm, bn, occ; double eff, epi; } T[] = {
-            {1, 256, 256, 1, 1.0, 64}, {2, 256, 128, 1, 0.95, 64}, {3, 128, 128, 2, 0.85, 64}, {4, 64, 64, 3, 0.6, 64}, {5, 64, 128, 3, 0.75, 64},
-            {6, 64, 256, 2, 0.75, 64}, {7, 128, 256, 1, 0.95, 64}, {8, 128, 64, 2, 0.6, 64}, {9, 192, 256, 1, 1.0, 64}, {10, 192, 128, 2, 1.0, 64},
-            {11, 160, 256, 1, 0.88, 64},
-            // (12 / 13 / 14 / 17 / 19 in their persistent forms 32 / 33 / 34 / 37 / 39, same parameters)
-            {32, 192, 256, 1, 1.11, 64}, {33, 256, 256, 1, 1.08, 64}, {34, 256, 128, 1, 0.97, 64}, {16, 160, 256, 1, 0.975, 64}, {37, 192, 256, 1, 1.14, 64}, {39, 128, 256, 1, 1.0, 64}, {20, 192, 128, 2, 1.04, 64},
-            {26, 192, 256, 1, 1.18, 64}, {27, 256, 128, 1, 1.03, 64}, {28, 160, 256, 1, 1.0, 64}, {29, 192, 256, 1, 1.21, 64}};
+            {3, 128, 128, 2, 0.613, 176}, {4, 64, 64, 3, 0.642, 106}, {5, 64, 128, 3, 0.751, 79}, {6, 64, 256, 2, 0.452, 266}, {10, 192, 128, 2, 0.772, 91},
+            {16, 160, 256, 1, 0.529, 200}, {20, 192, 128, 2, 0.300, 60},
+            // persistent, 4 loader waves (32: 8 MFMA waves of 96x64; 37: 12 of 64x64)
+            {32, 192, 256, 1, 0.929, 447}, {33, 256, 256, 1, 0.423, 122}, {34, 256, 128, 1, 1.043, 127}, {37, 192, 256, 1, 1.197, 83}, {39, 128, 256, 1, 1.032, 99},
+            // row-strip variants (3x3 / stride 1 / pad 1 only: ~2.7x fewer A bytes through the CU's fill path) + 4 loader waves; measured
+            // level with tile 37 on every 3x3 layer of the sweep
+            {26, 192, 256, 1, 1.18, 83}, {27, 256, 128, 1, 1.03, 127}, {28, 160, 256, 1, 0.5, 200}, {29, 192, 256, 1, 1.21, 83}};
         const bool strip_ok = d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1;
         double best = 0.0;
         for (const auto& t : T) {
-            if (t.id >= 26 && !(strip_ok && (t.bm - 1) / d->W + 2 <= 32)) continue;
+            if (t.id >= 26 && t.id <= 29 && !(strip_ok && (t.bm - 1) / d->W + 2 <= 32)) continue;
             const int64_t blocks = (int64_t)cdiv(k.M, t.bm) * cdiv(d->Cout, t.bn);
             int64_t per_cu = (blocks + 255) / 256;
             if (t.occ > 1 && blocks <= 256 * t.occ) per_cu = blocks < t.occ ? blocks : t.occ;
