@@ -14,6 +14,8 @@
 //   C. bitonic sort of <= KCAP 64-bit keys (ordered score << 32 | ~index) in LDS.
 #include "../../include/isegmi.h"
 #include "common.h"
+#include <mutex>
+#include <unordered_map>
 
 namespace isegmi {
 
@@ -37,6 +39,11 @@ struct TopkArgs {
     int* out_idx;           // [rows][k]
     int* out_cnt;           // [rows] (optional)
     int seg_len, seg_take;  // SEG kernels: the row is nseg segments of seg_len keys, of which only the first seg_take count
+    // two-level form for a few very long rows (topk_launch): level 1 runs one block per (row, slice) -- block b = row * slices + slice takes
+    // keys [slice * slice_len, ...) of its row, writes its k best to out row b (indices in the full row; the tail past its own count holds
+    // the smallest key, never selected); level 2 selects over a row's slices * k candidates and reports remap[row][position]
+    int slices, slice_len;
+    const int* remap;
 };
 
 // SEG: the logical row is the concatenation of the first seg_take keys of every seg_len-long segment (element e lives at
@@ -54,10 +61,12 @@ __global__ __launch_bounds__(NT) void topk_kernel(const TopkArgs a) {
     __shared__ unsigned w_gt[NW], w_eq[NW];
     __shared__ unsigned sel_digit, sel_kk;
 
-    const int row = blockIdx.x;
+    const int row = a.slices > 0 ? (int)blockIdx.x / a.slices : (int)blockIdx.x;
+    const int orow = blockIdx.x;                                   // output row
+    const int slice_off = a.slices > 0 ? ((int)blockIdx.x - row * a.slices) * a.slice_len : 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* keys = a.keys + (int64_t)row * a.row_stride;
-    const int n = a.n;
+    const float* keys = a.keys + (int64_t)row * a.row_stride + slice_off;
+    const int n = a.slices > 0 ? (a.n - slice_off < a.slice_len ? a.n - slice_off : a.slice_len) : a.n;
     auto phys = [&](int e) { return SEG ? (e / a.seg_take) * a.seg_len + (e % a.seg_take) : e; };
     int k_eff = a.k < n ? a.k : n;
     if (a.limit) {
@@ -65,7 +74,9 @@ __global__ __launch_bounds__(NT) void topk_kernel(const TopkArgs a) {
         k_eff = k_eff < l ? k_eff : l;
     }
     if (k_eff <= 0) {
-        if (tid == 0 && a.out_cnt) a.out_cnt[row] = 0;
+        if (a.slices > 0)
+            for (int i = tid; i < a.k; i += NT) { a.out_vals[(int64_t)orow * a.k + i] = ord2f(0u); a.out_idx[(int64_t)orow * a.k + i] = -1; }
+        if (tid == 0 && a.out_cnt) a.out_cnt[orow] = 0;
         return;
     }
 
@@ -170,6 +181,16 @@ __global__ __launch_bounds__(NT) void topk_kernel(const TopkArgs a) {
     for (int i = k_eff + tid; i < KCAP; i += NT) sbuf[i] = 0ull;
     __syncthreads();
 
+    if (a.slices > 0) {  // level 1 of the two-level form: the survivors leave in INDEX order, unsorted -- level 2 only needs equal keys to
+                         // appear in index order (they do: the compaction is ordered and the slices follow one another), and sorts itself
+        for (int i = tid; i < a.k; i += NT) {
+            const unsigned long long kx = sbuf[i];
+            const bool real = i < k_eff;
+            a.out_vals[(int64_t)orow * a.k + i] = real ? ord2f((unsigned)(kx >> 32)) : ord2f(0u);
+            a.out_idx[(int64_t)orow * a.k + i] = real ? (int)(0xffffffffu - (unsigned)(kx & 0xffffffffull)) + slice_off : -1;
+        }
+        return;
+    }
     // ---- C. bitonic sort, descending
     for (int size = 2; size <= KCAP; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
@@ -185,17 +206,54 @@ __global__ __launch_bounds__(NT) void topk_kernel(const TopkArgs a) {
     }
     for (int i = tid; i < k_eff; i += NT) {
         const unsigned long long kx = sbuf[i];
-        a.out_vals[(int64_t)row * a.k + i] = ord2f((unsigned)(kx >> 32));
-        a.out_idx[(int64_t)row * a.k + i] = (int)(0xffffffffu - (unsigned)(kx & 0xffffffffull));
+        const int pos = (int)(0xffffffffu - (unsigned)(kx & 0xffffffffull));
+        a.out_vals[(int64_t)orow * a.k + i] = ord2f((unsigned)(kx >> 32));
+        a.out_idx[(int64_t)orow * a.k + i] = a.remap ? a.remap[(int64_t)row * a.n + pos] : pos;
     }
-    if (tid == 0 && a.out_cnt) a.out_cnt[row] = k_eff;
+    if (tid == 0 && a.out_cnt) a.out_cnt[orow] = k_eff;
+}
+
+// Candidate buffers of the two-level top-k: one grow-only pair per stream (calls on one stream are ordered; the RPN levels run on
+// different streams concurrently and must not share).  Never freed: at most a few MB per stream.
+static int topk_scratch(hipStream_t st, size_t elems, float** vals, int** idx) {
+    struct S { float* v = nullptr; int* i = nullptr; size_t cap = 0; };
+    static std::mutex mu;
+    static std::unordered_map<void*, S> pool;
+    std::lock_guard<std::mutex> g(mu);
+    S& s = pool[(void*)st];
+    if (s.cap < elems) {
+        if (s.v) { HIP_TRY(hipStreamSynchronize(st)); HIP_TRY(hipFree(s.v)); HIP_TRY(hipFree(s.i)); s.v = nullptr; s.i = nullptr; s.cap = 0; }
+        HIP_TRY(hipMalloc((void**)&s.v, elems * sizeof(float)));
+        HIP_TRY(hipMalloc((void**)&s.i, elems * sizeof(int)));
+        s.cap = elems;
+    }
+    *vals = s.v; *idx = s.i;
+    return ISEGMI_OK;
 }
 
 int topk_launch(const float* keys, int64_t row_stride, int rows, int n, int k, const int* limit, int rows_per_limit,
                 float* out_vals, int* out_idx, int* out_cnt, hipStream_t st) {
     ARG_CHECK(rows >= 0 && n >= 0 && k > 0 && k <= 8192, "topk sizes (k <= 8192)");
     if (rows == 0) return ISEGMI_OK;
-    TopkArgs a{keys, row_stride, n, k, limit, rows_per_limit > 0 ? rows_per_limit : 1, out_vals, out_idx, out_cnt, 0, 0};
+    TopkArgs a{keys, row_stride, n, k, limit, rows_per_limit > 0 ? rows_per_limit : 1, out_vals, out_idx, out_cnt, 0, 0, 0, 0, nullptr};
+    // A few very long rows (RPN pre-NMS top-k: one row of up to 201 600 anchors per image and level): a row's five latency-bound passes in
+    // ONE block took 56-108 us with the rest of the chip idle.  Two levels instead: every (row, slice of ~12 K keys) block keeps its k best
+    // (select + ordered compaction, no sort), then the row's slices * k candidates go through the full kernel.  Exact: a global top-k key is
+    // in its slice's top-k, and the (key desc, index asc) order survives because equal keys reach level 2 in index order.
+    if (limit == nullptr && k > 256 && k <= 1024 && rows <= 32 && n >= 40000) {  // break-even with one level at ~32 K keys (tools/topk_time.py)
+        int slices = (n + 12287) / 12288;
+        if (slices > 32) slices = 32;
+        const int slice_len = (n + slices - 1) / slices;
+        float* cv = nullptr; int* ci = nullptr;
+        { const int rc = topk_scratch(st, (size_t)rows * slices * k, &cv, &ci); if (rc != ISEGMI_OK) return rc; }
+        TopkArgs l1 = a;
+        l1.slices = slices; l1.slice_len = slice_len; l1.out_vals = cv; l1.out_idx = ci; l1.out_cnt = nullptr;
+        hipLaunchKernelGGL((topk_kernel<1024, 1024>), dim3(rows * slices), dim3(1024), 0, st, l1);
+        TopkArgs l2{cv, (int64_t)slices * k, slices * k, k, nullptr, 1, out_vals, out_idx, out_cnt, 0, 0, 0, 0, ci};
+        hipLaunchKernelGGL((topk_kernel<1024, 1024>), dim3(rows), dim3(1024), 0, st, l2);
+        HIP_TRY(hipGetLastError());
+        return ISEGMI_OK;
+    }
     // wide blocks when the rows alone cannot fill the chip (bs=1 Detect: 80 class rows of 19 248 priors, then ONE row of 16 000
     // candidates): a row's five passes over its keys are latency-bound per thread, so 1024 threads cut them ~3x
     const bool wide = n > 65536 || (n > 8192 && rows < 256);
@@ -220,7 +278,7 @@ int topk_segmented_launch(const float* keys, int64_t row_stride, int rows, int n
                           int rows_per_limit, float* out_vals, int* out_idx, int* out_cnt, hipStream_t st) {
     ARG_CHECK(rows >= 0 && nseg > 0 && seg_len > 0 && seg_take > 0 && seg_take <= seg_len && k > 0 && k <= 128, "segmented topk sizes (k <= 128)");
     if (rows == 0) return ISEGMI_OK;
-    TopkArgs a{keys, row_stride, nseg * seg_take, k, limit, rows_per_limit > 0 ? rows_per_limit : 1, out_vals, out_idx, out_cnt, seg_len, seg_take};
+    TopkArgs a{keys, row_stride, nseg * seg_take, k, limit, rows_per_limit > 0 ? rows_per_limit : 1, out_vals, out_idx, out_cnt, seg_len, seg_take, 0, 0, nullptr};
     hipLaunchKernelGGL((topk_kernel<1024, 128, true>), dim3(rows), dim3(1024), 0, st, a);
     HIP_TRY(hipGetLastError());
     return ISEGMI_OK;

@@ -25,6 +25,29 @@ def test_topk_matches_oracle(ffi, rows, n, k):
         assert np.array_equal(vals[r, : cnt[r]], s)
 
 
+@pytest.mark.parametrize("rows,n,k,mode", [(8, 201600, 1000, "uniform"), (2, 50400, 1000, "ties"), (3, 40000, 600, "uniform"), (1, 100000, 1000, "equal"),
+                                           (2, 131072, 1024, "few"), (4, 45000, 257, "neg"), (1, 400000, 1000, "ties")])
+def test_topk_two_level_long_rows(ffi, rows, n, k, mode):
+    """Few very long rows (the RPN pre-NMS top-k) go through slices: per-slice top-k, then top-k of the candidates.  Same total order
+    (key descending, index ascending), ties across slice borders included."""
+    rng = np.random.default_rng(n + k)
+    if mode == "uniform":
+        keys = rng.uniform(0, 1, (rows, n))
+    elif mode == "ties":
+        keys = rng.integers(0, 7, (rows, n)) / 8.0          # thousands of equal keys at the threshold, spread over every slice
+    elif mode == "equal":
+        keys = np.full((rows, n), 0.5)
+    elif mode == "few":
+        keys = np.zeros((rows, n)); keys[:, rng.integers(0, n, 300)] = rng.uniform(1, 2, 300)   # fewer distinct winners than k
+    else:
+        keys = -np.abs(rng.standard_normal((rows, n)))
+    keys = keys.astype(np.float32)
+    vals, idx, cnt = ffi.topk(keys, k)
+    for r in range(rows):
+        s, i = ora.topk(keys[r], k)
+        assert cnt[r] == len(s) and np.array_equal(idx[r, : cnt[r]], i) and np.array_equal(vals[r, : cnt[r]], s)
+
+
 def test_topk_all_equal_and_negative(ffi):
     keys = np.full((2, 5000), 0.5, np.float32)
     keys[1] = -np.arange(5000, dtype=np.float32)
