@@ -41,6 +41,7 @@ struct ConvK {
     int64_t out_img_stride, out_pix_stride;
     int mtiles, ntiles;
     int mfast;  // tile order within an XCD: 1 = M fastest (weights larger than the input), 0 = Cout fastest
+    int m_begin;  // first output row of this launch's tile grid (0, or the start of the small-tile tail of a hybrid launch)
 };
 
 constexpr int LDS_ROW = 36;
@@ -314,19 +315,17 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK p) {
 //  * The residual is requested before the LAST chunk's MFMAs instead of after them (one memory round trip per tile, all of a
 //    K = 64 layer's tile time besides the loads themselves).
 template <int RING, bool EARLY>
-__global__ __launch_bounds__(256, 4) void conv_mfma_v2_kernel(const ConvK p) {
+__device__ __forceinline__ void conv_v2_body(const ConvK& p, float* smem, const int bid, const int nwg) {
     constexpr int BM = 64, BN = 64;
     constexpr int STAGE = (BM + BN) * LDS_ROW;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform, and known to be (scalar address arithmetic)
     const int wm = wave >> 1, wn = wave & 1;
-    const int nwg = gridDim.x, bid = blockIdx.x;
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
     const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
     const int nt = p.mfast ? logical / p.mtiles : logical % p.ntiles;
     const int mt = p.mfast ? logical % p.mtiles : logical / p.ntiles;
-    const int m0 = mt * BM, n0 = nt * BN;
+    const int m0 = p.m_begin + mt * BM, n0 = nt * BN;
 
     // loader: thread covers row tid>>2 of the A and of the B tile, 8 consecutive k (g = tid&3) of the 32-chunk
     const int lrow = tid >> 2, g = tid & 3;
@@ -481,6 +480,12 @@ __global__ __launch_bounds__(256, 4) void conv_mfma_v2_kernel(const ConvK p) {
     epi_finish(p, acc, sc, sh, ep);
 }
 
+template <int RING, bool EARLY>
+__global__ __launch_bounds__(256, 4) void conv_mfma_v2_kernel(const ConvK p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    conv_v2_body<RING, EARLY>(p, smem, (int)blockIdx.x, (int)gridDim.x);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Small-M / latency-bound variant: block tile 32x32, four waves, each wave ONE 16x16 tile on
 // v_mfma_f32_16x16x4_f32 (lane (i, q) supplies k = 4s + q; the instruction is the same ordered fmaf chain, 4 k deep).
@@ -518,26 +523,24 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define EXPERIMENT_MODE 0
 #endif
 template <int RING, bool LW, int WN = 1>
-__global__ __launch_bounds__(LW ? 512 : 256) void conv_mfma16_kernel(const ConvK p) {
+__device__ __forceinline__ void conv_mfma16_body(const ConvK& p, float* smem16, const int bid, const int nwg) {
     static_assert(WN == 1 || !LW, "the loader-wave variant runs one tile per wave");
     constexpr int BM = 32, BN = 32 * WN;
     constexpr int ROW = 34;  // floats; pitch = 2 mod 32: bank = 2*row + k for the fragment reads
     constexpr int STAGE = (BM + BN) * ROW;
     constexpr int NST = LW ? 3 : 2;  // LDS stages (LW: chunk t computed while t+1 is read into registers and t+2 written)
-    __shared__ __attribute__((aligned(16))) float smem16[NST * STAGE];
 
     const int tid = threadIdx.x & 255;
     const bool loader = LW && __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) != 0;  // wave-uniform, and known to be
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform, and known to be (scalar address arithmetic)
     const int wm = wave >> 1, wn = wave & 1;
-    const int nwg = gridDim.x, bid = blockIdx.x;
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
     const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
     // an XCD's consecutive tiles walk the operand that is SMALLER in bytes, so its L2 holds all of that one and only an
     // eighth of the larger
     const int nt = p.mfast ? logical / p.mtiles : logical % p.ntiles;
     const int mt = p.mfast ? logical % p.mtiles : logical / p.ntiles;
-    const int m0 = mt * BM, n0 = nt * BN;
+    const int m0 = p.m_begin + mt * BM, n0 = nt * BN;
 
     // loader: thread covers row tid>>3 (32 rows) and 4 consecutive k (g8 = tid&7) of the 32-chunk
     const int lrow = tid >> 3, g8 = tid & 7;
@@ -799,6 +802,29 @@ __global__ __launch_bounds__(LW ? 512 : 256) void conv_mfma16_kernel(const ConvK
     }
 }
 
+template <int RING, bool LW, int WN = 1>
+__global__ __launch_bounds__(LW ? 512 : 256) void conv_mfma16_kernel(const ConvK p) {
+    constexpr int STAGE16 = (32 + 32 * WN) * 34;
+    __shared__ __attribute__((aligned(16))) float smem16[(LW ? 3 : 2) * STAGE16];
+    conv_mfma16_body<RING, LW, WN>(p, smem16, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// HYBRID launch (tiles 13 / 14 = v2 with loads 2 / 4 chunks ahead): a grid of 64x64 tiles that does not divide over the 256 CUs
+// (528 tiles: two per CU and sixteen left over; 1050: four per CU and 26 left over) loses up to a third of a layer to the CUs
+// that carry one tile more than the others -- the 16x16x4 kernels' finer tiles fix the balance but pay for it on every tile.
+// Here the rows that fill the chip evenly run on the 64x64 v2 tile and ONLY the remaining rows on 32x32 blocks, in one launch:
+// blocks [0, nmain) are v2 tiles of rows [0, m_begin of the tail), the others 32x32 tiles of the tail rows (four times as many,
+// a quarter of the work each, dispatched last so that the launch ends on short blocks).  Same numerics in both parts (one
+// k-ordered chain per output).  tools/hybrid_tail_experiment.py measured the idea with two concurrent launches: 9-15 % ahead
+// of the best single kernel on 528 / 616 / 1056 / 1192-tile layers.
+template <int RING>
+__global__ __launch_bounds__(256, 4) void conv_hybrid_kernel(const ConvK pm, const ConvK pt, const int nmain) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if ((int)blockIdx.x < nmain) conv_v2_body<RING, false>(pm, smem, (int)blockIdx.x, nmain);
+    else conv_mfma16_body<4, false, 1>(pt, smem, (int)blockIdx.x - nmain, (int)gridDim.x - nmain);
+}
+
 static inline int perm8(int e) { return 4 * (e & 1) + (e >> 1); }
 static bool is_stem(const isegmi_conv_desc* d) { return d->Cin == 4 && d->R == 7 && d->S == 7; }
 static int cout_pad(const isegmi_conv_desc* d) { return cdiv(d->Cout, 128) * 128; }
@@ -811,7 +837,7 @@ static int check_desc(const isegmi_conv_desc* d) {
     ARG_CHECK(is_stem(d) || (d->Cin > 0 && d->Cin % 32 == 0), "Cin must be a multiple of 32 (or the Cin=4 7x7 stem)");
     ARG_CHECK(d->H + 2 * d->pad >= d->R && d->W + 2 * d->pad >= d->S, "kernel larger than padded input");
     ARG_CHECK(d->act >= 0 && d->act <= 4, "act");
-    ARG_CHECK(d->tile >= 0 && d->tile <= 12, "tile");
+    ARG_CHECK(d->tile >= 0 && d->tile <= 14, "tile");
     return ISEGMI_OK;
 }
 
@@ -855,6 +881,7 @@ int conv2d_launch(const isegmi_conv_desc* d, const float* in, const float* w, co
     k.in_bytes = (unsigned)in_bytes;
     k.w_bytes = (unsigned)((int64_t)cout_pad(d) * k.wrow * 4);
     k.mfast = (int64_t)k.w_bytes > in_bytes ? 1 : 0;
+    k.m_begin = 0;
     k.act = d->act;
     k.out_div = d->out_div > 0 ? d->out_div : k.Ho * k.Wo;
     k.out_pix_stride = d->out_pix_stride > 0 ? d->out_pix_stride : d->Cout;
@@ -885,6 +912,10 @@ int conv2d_launch(const isegmi_conv_desc* d, const float* in, const float* w, co
         else if (t64 <= 176) tile = 5;
         else if (nck <= 2 && d->Cout > 32) tile = v2;  // K = 64: after the one-add epilogue the 64x64 v2 tile leads at every grid size
         else if (d->Cout <= 32 || t64 <= 480) tile = 4;
+        // hybrid launch (tile 13: v2 on the rows that fill the CUs a whole number of times, 32x32 blocks on the rest) wherever the
+        // left-over 64x64 tiles are few: 3-12 % ahead of the rule below on 526-2400-tile layers in the fourth sweep
+        // (profiles/r02_conv_tile_sweep_v4.txt), behind it once the tail passes ~15 % of the layer (616, 1228 tiles)
+        else if (t64 >= 513 && t64 <= 2600 && t64 % 256 != 0 && (t64 % 256) * 100 <= t64 * 15) tile = 13;
         else if (t64 <= 512) tile = v2;
         else if (t64 <= 640) tile = nck >= 32 ? 6 : 4;
         else if (t64 <= 1024) tile = v2;
@@ -892,6 +923,27 @@ int conv2d_launch(const isegmi_conv_desc* d, const float* in, const float* w, co
         else tile = v2;
     }
     if (tile >= 4 && is_stem(d)) tile = 3;  // only the original 64x64 kernel has the stem path
+    if (tile == 13 || tile == 14) {  // hybrid: whole-CU multiples of 64x64 tiles on v2, the remaining rows on 32x32 blocks, one launch
+        const int nt64 = cdiv(d->Cout, 64);
+        const int64_t mt64 = cdiv(k.M, 64);
+        const int ncu = 256;
+        int64_t main_mt = (mt64 * nt64 / ncu) * ncu / nt64;   // 64-row tile rows whose tiles fill the CUs a whole number of times
+        if (main_mt * 64 > k.M) main_mt = k.M / 64;
+        if (main_mt <= 0 || main_mt >= mt64) {                 // nothing to split: the plain v2 launch
+            tile = tile == 13 ? 10 : 12;
+        } else {
+            ConvK km = k, kt = k;
+            km.mtiles = (int)main_mt; km.ntiles = nt64;
+            kt.m_begin = (int)(main_mt * 64);
+            kt.mtiles = cdiv(k.M - kt.m_begin, 32); kt.ntiles = cdiv(d->Cout, 32);
+            const int nmain = km.mtiles * km.ntiles, ntail = kt.mtiles * kt.ntiles;
+            const size_t lds = 2 * (size_t)(64 + 64) * LDS_ROW * sizeof(float);
+            if (tile == 13) hipLaunchKernelGGL((conv_hybrid_kernel<2>), dim3((unsigned)(nmain + ntail)), dim3(256), lds, st, km, kt, nmain);
+            else hipLaunchKernelGGL((conv_hybrid_kernel<4>), dim3((unsigned)(nmain + ntail)), dim3(256), lds, st, km, kt, nmain);
+            HIP_TRY(hipGetLastError());
+            return ISEGMI_OK;
+        }
+    }
     if (tile >= 7) {
         ARG_CHECK(tile != 8 && tile != 11, "tiles 8 / 11 (ring of 3) were dropped: the LDS stage of an unrolled position is its parity");
         k.mtiles = cdiv(k.M, 64);

@@ -24,7 +24,7 @@ CASES = [
 
 
 @pytest.mark.parametrize("case", CASES)
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 9, 10, 12])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 9, 10, 12, 13, 14])
 def test_conv_bit_exact(ffi, case, tile):
     N, H, W, Cin, Cout, R, stride, pad = case
     rng = np.random.default_rng(hash(case) % (2**32))
