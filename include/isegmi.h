@@ -53,7 +53,8 @@ typedef struct isegmi_conv_desc {
     int32_t Cout, R, S, stride, pad;
     int32_t act;                     /* 0 none, 1 relu, 2 tanh, 3 LeakyReLU(0.1), 4 LeakyReLU(0.1) then + residual (DarkNet block); fp32 only for 2-4 */
     int32_t tile;                    /* 0 auto; fp32: 1: 128x128  2: 128x64  3: 64x64 (round-1 schedule; the stem)  4: 32x32 on 16x16x4 MFMA  5: 32x32 with four loader waves, software-pipelined  6: 32x64, two 16x16 tiles per wave (block tile MxN)
-                                        10 / 12: 64x64, v2 schedule, loads 2 / 4 chunks ahead (the default for large grids)  7 / 9: the same with the early LDS store (measured slower; kept for A/B);
+                                        10 / 12: 64x64, v2 schedule, loads 2 / 4 chunks ahead (the default for large grids)  7 / 9: the same with the early LDS store (measured slower; kept for A/B)
+                                        13 / 14: hybrid launch -- v2 tiles (loads 2 / 4 ahead) on the rows that fill the CUs a whole number of times, 32x32 blocks on the left-over rows (the default for 513-2600-tile grids with a small left-over);
                                         fp16: 1: 256x256  2: 256x128  3: 128x128  4: 64x64  5: 64x128  6: 64x256  7: 128x256  8: 128x64  9: 192x256  10: 192x128  11: 160x256;
                                         12/13/14/16: 192x256, 256x256, 256x128, 160x256 with 4 loader waves, 17: 192x256 as 12 MFMA + 4 loader waves, 19: 128x256 + 4, 20: 192x128 as 6 + 2;
                                         26/27/28/29: row-strip kernel for 3x3/1/1 (192x256, 256x128, 160x256, 192x256 on 12 MFMA waves) with 4 loader waves;

@@ -904,7 +904,8 @@ int conv2d_launch(const isegmi_conv_desc* d, const float* in, const float* w, co
         //     instructions, profiles/r02_conv_tile_sweep_v2.txt): the loader-wave variant (tile 5) up to 176 tiles, the 32x32 block
         //     (tile 4) to 480 tiles, the 32x64 block (tile 6) for K >= 1024 where a grid sits just past a whole number of 64x64
         //     rounds (513-640, 1025-1100);
-        //   * outputs of at most 32 channels never use a 64-wide tile (padding them to 64 wastes half the MFMA work).
+        //   * outputs of at most 32 channels never use a 64-wide tile (padding them to 64 wastes half the MFMA work);
+        //   * fourth sweep (profiles/r02_conv_tile_sweep_v4.txt): the hybrid launch (tile 13) wherever a 513-2600-tile grid leaves few tiles over.
         const int64_t t64 = (int64_t)cdiv(k.M, 64) * cdiv(d->Cout, 64);
         const int nck = k.nchunks;
         const int v2 = nck >= 72 ? 12 : 10;
