@@ -77,3 +77,31 @@ def test_spatial_bit_exact(ffi):
     assert np.array_equal(ffi.resize_bilinear(a, 38, 46, None, 1), ora.resize_bilinear(a, 38, 46, None, 1))
     lat = _rand(rng, (2, 38, 46, 32))
     assert np.array_equal(ffi.upsample_nearest2x_add(a, lat), ora.upsample_nearest2x_add(a, lat))
+
+
+HYBRID_CASES = [
+    # shapes whose 64x64-tile grid is larger than the 256 CUs and does not divide over them: the hybrid launch really splits
+    (1, 184, 184, 32, 64, 1, 1, 0),     # 529 m-tiles x 1: 512 v2 tiles + 17 tiles' rows on 32x32 blocks
+    (1, 150, 150, 64, 128, 3, 1, 1),    # 352 x 2: 256 m-tile rows on v2, 96 on the small blocks (3x3 taps, padding)
+    (2, 101, 97, 64, 72, 3, 2, 1),      # stride 2, Cout not a multiple of 32, M = 2 * 51 * 49 = 4998 (M % 32 != 0): 79 x 2 < 256 -> plain v2 fallback
+    (3, 83, 79, 32, 200, 1, 1, 0),      # 308 x 4 = 1232: 256 m-tile rows main, M % 64 != 0 in the tail
+]
+
+
+@pytest.mark.parametrize("case", HYBRID_CASES)
+@pytest.mark.parametrize("tile", [13, 14])
+def test_conv_hybrid_split_bit_exact(ffi, case, tile):
+    """Tiles 13 / 14: v2 tiles on the rows that fill the CUs a whole number of times + 32x32 blocks on the left-over rows, one launch."""
+    N, H, W, Cin, Cout, R, stride, pad = case
+    rng = np.random.default_rng(hash(case) % (2**32))
+    x = _rand(rng, (N, H, W, Cin))
+    w = _rand(rng, (Cout, R, R, Cin), (2.0 / (R * R * Cin)) ** 0.5)
+    sc = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+    sh = _rand(rng, (Cout,), 0.1)
+    Ho = (H + 2 * pad - R) // stride + 1
+    Wo = (W + 2 * pad - R) // stride + 1
+    res = _rand(rng, (N, Ho, Wo, Cout))
+    for act, use_res in [(1, True), (0, False)]:
+        ref = ora.conv2d(x, w, stride, pad, sc, sh, res if use_res else None, act)
+        got = ffi.conv2d(x, w, stride, pad, sc, sh, res if use_res else None, act, tile)
+        assert np.array_equal(got, ref)
