@@ -223,6 +223,8 @@ int isegmi_op_mask_logits_select(const float* d_feat, int R, int HW, int C, cons
 /* Masker(threshold, padding=1) paste (A.8): masks [N][K][M][M], boxes [N][K][4] -> u8 [N][K][im_h][im_w] */
 int isegmi_op_paste_masks(const float* d_masks, const float* d_boxes, const int32_t* d_counts, int N,
                           int K, int M, int im_h, int im_w, float thr, uint8_t* d_out, void* stream);
+/* AnchorGenerator.grid_anchors (M5, A.3): d_out [(y*grid_w + x)*A + a][4] = d_base[a] + (x, y, x, y) * stride */
+int isegmi_op_grid_anchors(const float* d_base, int A, int stride, int grid_h, int grid_w, float* d_out, void* stream);
 /* one RPN level (A.4) for N images: fused head [N][HW][A*5] (A logits then A*4 deltas per pixel) */
 int isegmi_op_rpn_level(const float* d_head, const float* d_anchors, const int32_t* d_image_hw, int N,
                         int HW, int A, int pre_nms, int post_nms, float nms_thr, float min_size,
@@ -231,6 +233,37 @@ int isegmi_op_rpn_level(const float* d_head, const float* d_anchors, const int32
                         int32_t* d_out_cnt, void* d_ws_nms /* optional: N * 131072 bytes, the suppression
                         matrix of the chip-wide NMS used when pre_nms <= 1024; NULL = single-block NMS */,
                         void* stream);
+
+/* ---- COCO run-length encoding on the device (the on-disk format behind inference() / tools/test_net.py,
+ * README.md:344-347, annotation layout README.md:55-66; Yolact eval.py Detections.add_mask / dump, README.md:243-249) ----
+ * pycocotools rleEncode + rleToString restated: for every valid slot (n, k), k < d_count[n], of the uint8 planes d_masks [N][K][plane_h][plane_w]
+ * the column-major run lengths of the top-left (h_n, w_n) window (d_image_hw [N][2], NULL = the whole plane), starting with the run of
+ * zeros, and their compressed ASCII string.  Slot m = n*K + k owns runs d_out_counts[d_out_run_off[m] .. d_out_run_off[m+1]) and characters
+ * d_out_chars[d_out_str_off[m] .. d_out_str_off[m+1]); invalid slots own nothing.  d_out_status [4] = {total runs, total chars,
+ * overflow bits (1: runs > cap_runs, 2: chars > cap_chars; the outputs are then incomplete), 0}.  Bit-identical to isegmi/coco.py
+ * rle_counts / rle_to_string.  Workspace sizes: isegmi_rle_workspace. */
+typedef struct isegmi_rle_args {
+    int32_t N, K, plane_h, plane_w;
+    int32_t cap_runs;                 /* entries of d_out_counts / d_ws_starts / d_ws_len: a multiple of 1024 */
+    int32_t cap_chars;                /* bytes of d_out_chars */
+    const uint8_t* d_masks;
+    const int32_t* d_count;           /* [N] or NULL (all K slots valid) */
+    const int32_t* d_image_hw;        /* [N][2] or NULL */
+    void* d_ws_trans;                 /* workspace, sizes from isegmi_rle_workspace */
+    int32_t* d_ws_col;
+    int32_t* d_ws_nruns;
+    int32_t* d_ws_tile;
+    uint8_t* d_ws_len;
+    uint32_t* d_ws_starts;
+    int32_t* d_out_run_off;           /* [N*K + 1] */
+    uint32_t* d_out_counts;           /* [cap_runs] */
+    int32_t* d_out_str_off;           /* [N*K + 1] */
+    uint8_t* d_out_chars;             /* [cap_chars] */
+    int32_t* d_out_status;            /* [4] */
+} isegmi_rle_args;
+int isegmi_rle_workspace(int N, int K, int plane_h, int plane_w, int cap_runs, int64_t* trans_bytes, int64_t* col_bytes,
+                         int64_t* nruns_bytes, int64_t* tile_bytes, int64_t* len_bytes, int64_t* starts_bytes);
+int isegmi_op_rle_encode(const isegmi_rle_args* a, void* stream);
 
 /* ---- model engine ----
  * Replaces the model object the reference builds inside COCODemo(cfg, ...) (README.md:320-324)
@@ -258,11 +291,20 @@ int isegmi_yolact_forward(isegmi_engine* e, const float* d_images_nhwc3, int N);
  * engine's (H,W); h_image_hw [N][2] = unpadded (h,w).  Results: det.count/box/score/label [N][cap],
  * det.mask28 [N][cap][28][28], proposals, rpn.* ... in named buffers. */
 int isegmi_maskrcnn_forward(isegmi_engine* e, const float* d_images_nhwc3, const int32_t* h_image_hw, int N);
+/* The same on a padded canvas (H, W) <= the engine's (H, W): d_images is [N][H][W][3] contiguous.  upstream's to_image_list pads every
+ * BATCH to its own size (max over its images, rounded up to SIZE_DIVISIBILITY), so one engine -- weights packed once, buffers sized once
+ * for the largest canvas -- serves every batch of a data set (COCODemo / inference(), README.md:320-331, 344-347).  The host sets the
+ * per-level base anchors as tensors "anchor_base.<l>" [A][4] and the strides as params "anchor_stride<l>"; the grid is laid out on the
+ * device for the current canvas (isegmi_op_grid_anchors). */
+int isegmi_maskrcnn_forward_canvas(isegmi_engine* e, const float* d_images_nhwc3, const int32_t* h_image_hw, int N, int H, int W);
 /* Masker paste of the last forward into (out_h,out_w) planes; boxes first scaled by h_ratios_wh [N][2] =
  * (out_w/w_i, out_h/h_i) like BoxList.resize -> det.masks u8 [N][cap][out_h][out_w], det.box_resized */
 int isegmi_maskrcnn_paste(isegmi_engine* e, const float* h_ratios_wh, int out_h, int out_w);
 /* postprocess (Y7): masks of the last forward at (out_h,out_w) -> det.masks u8, det.box_int i64 */
 int isegmi_yolact_postprocess(isegmi_engine* e, int out_h, int out_w);
+/* the same with image n assembled at ITS (h, w) = h_image_hw[n] inside a common plane of the batch's maximum size (a batch of images of
+ * different original sizes; upstream's evalimage postprocesses one image at a time at its own size) */
+int isegmi_yolact_postprocess_sizes(isegmi_engine* e, const int32_t* h_image_hw, int N);
 int isegmi_engine_sync(isegmi_engine* e);
 int isegmi_engine_stream(isegmi_engine* e, void** stream);
 /* asynchronous H2D of an input batch from PINNED host memory on the engine's copy stream: ordered after the previous
@@ -278,9 +320,26 @@ int isegmi_engine_step_times(isegmi_engine* e, float* ms, int cap, int* count);
 /* dtype: 0 f32, 1 i32, 2 u8, 3 i64; shape4 receives up to 4 dims */
 int isegmi_engine_buffer_info(isegmi_engine* e, const char* name, void** d_ptr, int64_t* bytes,
                               int32_t* dtype, int64_t* shape4, int32_t* ndim);
+/* device memory held by the engine: packed weights + constant tensors, and activation / workspace / output buffers (bytes) */
+int isegmi_engine_memory(isegmi_engine* e, int64_t* weight_bytes, int64_t* buffer_bytes);
 /* per-stage hipEvent timings of the last synchronised forward (set_param "timing" 1 first) */
 int isegmi_engine_get_timings(isegmi_engine* e, char* names, int names_cap, float* ms, int ms_cap,
                               int* count);
+
+/* ---- device-side COCO output (README.md:344-347, 243-249): what inference() / eval ship per batch ----
+ * isegmi_engine_rle: isegmi_op_rle_encode over det.masks of the last postprocess / paste on the results stream; h_image_hw [N][2] = every
+ *   image's own (h, w) inside the mask planes (NULL: the whole plane) -> buffers rle.run_off / rle.counts / rle.str_off / rle.chars /
+ *   rle.status.  Capacities: params "rle_cap_runs" / "rle_cap_chars" (default 256 Ki entries / bytes per image of max_batch).
+ * isegmi_engine_pack_coco_records: ONE block of fixed size for n_block image slots (>= the last forward's batch: a short last batch still
+ *   fills a block of the per-step size; the extra slots carry count 0) (layout: csrc/results.cpp, mirrored by isegmi/dist.py):
+ *   status, boxes in original-image coordinates, counts, scores, labels, [mask scores], string offsets, RLE strings.
+ * isegmi_engine_download_*: the block's asynchronous D2H into pinned memory on a download stream (two slots). */
+int isegmi_engine_rle(isegmi_engine* e, const int32_t* h_image_hw);
+int isegmi_engine_coco_record_bytes(isegmi_engine* e, int N, int64_t* bytes, int64_t* chars_offset);
+int isegmi_engine_pack_coco_records(isegmi_engine* e, void* d_dst, int64_t cap, int n_block, int64_t* bytes);
+int isegmi_engine_download_async(isegmi_engine* e, int slot, void* h_dst_pinned, const void* d_src, int64_t bytes);
+int isegmi_engine_download_fence(isegmi_engine* e, int slot);
+int isegmi_engine_download_wait(isegmi_engine* e, int slot);
 
 /* one contiguous record block of the last Yolact forward for the all-gather:
  * [count i32 N][box f32 N*K*4][score f32 N*K][class i32 N*K][coeff f32 N*K*32]([proto f32 N*PH*PW*32]) */

@@ -860,6 +860,18 @@ static int launch(const isegmi_conv_desc* d, ConvK& k, hipStream_t st) {
     return ISEGMI_OK;
 }
 
+// compute units of the current device (256 on an MI355X in SPX mode; fewer in a partitioned mode): queried once per device
+int device_cu_count() {
+    static int cached[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+    if (cached[dev] == 0) {
+        int n = 0;
+        cached[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    return cached[dev];
+}
+
 int conv2d_launch(const isegmi_conv_desc* d, const float* in, const float* w, const float* scale, const float* shift,
                   const float* res, float* out, hipStream_t st) {
     int rc = check_desc(d);
@@ -908,6 +920,7 @@ int conv2d_launch(const isegmi_conv_desc* d, const float* in, const float* w, co
         //   * fourth sweep (profiles/r02_conv_tile_sweep_v4.txt): the hybrid launch (tile 13) wherever a 513-2600-tile grid leaves few tiles over.
         const int64_t t64 = (int64_t)cdiv(k.M, 64) * cdiv(d->Cout, 64);
         const int nck = k.nchunks;
+        const int ncu = device_cu_count();
         const int v2 = nck >= 72 ? 12 : 10;
         if (is_stem(d)) tile = 3;
         else if (t64 <= 176) tile = 5;
@@ -916,7 +929,7 @@ int conv2d_launch(const isegmi_conv_desc* d, const float* in, const float* w, co
         // hybrid launch (tile 13: v2 on the rows that fill the CUs a whole number of times, 32x32 blocks on the rest) wherever the
         // left-over 64x64 tiles are few: 3-12 % ahead of the rule below on 526-2400-tile layers in the fourth sweep
         // (profiles/r02_conv_tile_sweep_v4.txt), behind it once the tail passes ~15 % of the layer (616, 1228 tiles)
-        else if (t64 >= 513 && t64 <= 2600 && t64 % 256 != 0 && (t64 % 256) * 100 <= t64 * 15) tile = 13;
+        else if (t64 >= 513 && t64 <= 2600 && t64 % ncu != 0 && (t64 % ncu) * 100 <= t64 * 15) tile = 13;
         else if (t64 <= 512) tile = v2;
         else if (t64 <= 640) tile = nck >= 32 ? 6 : 4;
         else if (t64 <= 1024) tile = v2;
@@ -927,7 +940,7 @@ int conv2d_launch(const isegmi_conv_desc* d, const float* in, const float* w, co
     if (tile == 13 || tile == 14) {  // hybrid: whole-CU multiples of 64x64 tiles on v2, the remaining rows on 32x32 blocks, one launch
         const int nt64 = cdiv(d->Cout, 64);
         const int64_t mt64 = cdiv(k.M, 64);
-        const int ncu = 256;
+        const int ncu = device_cu_count();
         int64_t main_mt = (mt64 * nt64 / ncu) * ncu / nt64;   // 64-row tile rows whose tiles fill the CUs a whole number of times
         if (main_mt * 64 > k.M) main_mt = k.M / 64;
         if (main_mt <= 0 || main_mt >= mt64) {                 // nothing to split: the plain v2 launch

@@ -163,6 +163,32 @@ int eng_input_consumed(Engine& e) {
     return ISEGMI_OK;
 }
 
+// The consumer of an uploaded buffer (the front-end kernel for a uint8 staging buffer, the forward for an input slot) waits for the
+// upload_async that filled it -- and only for that one.
+int eng_wait_upload(Engine& e, const void* d_ptr, hipStream_t st) {
+    const char* p = (const char*)d_ptr;
+    for (auto& u : e.uploads)
+        if (!u.waited && p >= u.dst && p < u.dst + u.bytes) { HIP_TRY(hipStreamWaitEvent(st, u.done, 0)); u.waited = true; }
+    return ISEGMI_OK;
+}
+
+hipStream_t eng_results_stream(Engine& e) { return (e.multi_stream && e.tail_pending) ? e.tail : e.stream; }
+
+int eng_stage_small(Engine& e, const void* h_src, size_t bytes, void* d_dst, hipStream_t st) {
+    if (bytes > (size_t)Engine::PIN_SLOT_BYTES) { set_error("eng_stage_small: array larger than a pinned ring slot"); return ISEGMI_ERR_ARG; }
+    if (e.capturing) { set_error("host array staged during graph capture"); return ISEGMI_ERR_STATE; }
+    if (e.pin_ring == nullptr) HIP_TRY(hipHostMalloc((void**)&e.pin_ring, (size_t)Engine::PIN_SLOTS * Engine::PIN_SLOT_BYTES, hipHostMallocDefault));
+    const int s = e.pin_next++ % Engine::PIN_SLOTS;
+    if (e.pin_ev[s] == nullptr) HIP_TRY(hipEventCreateWithFlags(&e.pin_ev[s], hipEventDisableTiming));
+    if (e.pin_used[s]) HIP_TRY(hipEventSynchronize(e.pin_ev[s]));  // the copy that last used this slot (PIN_SLOTS stagings ago) has long finished
+    char* slot = e.pin_ring + (size_t)s * Engine::PIN_SLOT_BYTES;
+    memcpy(slot, h_src, bytes);
+    HIP_TRY(hipMemcpyAsync(d_dst, slot, bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipEventRecord(e.pin_ev[s], st));
+    e.pin_used[s] = true;
+    return ISEGMI_OK;
+}
+
 void eng_graph_reset(Engine& e) {
     for (auto& kv : e.graphs) (void)hipGraphExecDestroy(kv.second);
     e.graphs.clear();
@@ -205,6 +231,9 @@ int eng_graph_run(Engine& e, const std::string& key, const std::function<int()>&
     if (e.tail_pending) { HIP_TRY(hipStreamWaitEvent(e.stream, e.tail_done, 0)); e.tail_pending = false; }
     HIP_TRY(hipGraphLaunch(it->second, e.stream));
     ++e.graph_replays;
+    // eng_input_consumed() is skipped under capture and never runs on a replay: the end of the graph is the (conservative) point
+    // after which the next upload_async may overwrite the input / staging buffer
+    if (e.in_done) { HIP_TRY(hipEventRecord(e.in_done, e.stream)); e.in_pending = true; }
     return ISEGMI_OK;
 }
 
@@ -509,7 +538,8 @@ int yolact_forward(Engine& e, const float* d_images, int N) {
     return ISEGMI_OK;
 }
 
-int yolact_postprocess(Engine& e, int h, int w) {
+// h_image_hw (optional, [N][2]): image n is assembled at its own (h_n, w_n) inside the common (h, w) plane
+int yolact_postprocess(Engine& e, int h, int w, const int32_t* h_image_hw) {
     const int N = e.last_N;
     if (N <= 0) { set_error("postprocess before forward"); return ISEGMI_ERR_STATE; }
     const int K = (int)e.param("max_num_detections", 100);
@@ -517,12 +547,21 @@ int yolact_postprocess(Engine& e, int h, int w) {
     const int PH = (int)proto.shape[1], PW = (int)proto.shape[2], md = (int)proto.shape[3];
     void *lo, *masks, *ib;
     hipStream_t rs = (e.multi_stream && e.tail_pending) ? e.tail : e.stream;  // results stream of the last forward
+    int* d_ihw = nullptr;
+    if (h_image_hw) {
+        for (int i = 0; i < N; ++i)
+            if (h_image_hw[2 * i] <= 0 || h_image_hw[2 * i] > h || h_image_hw[2 * i + 1] <= 0 || h_image_hw[2 * i + 1] > w) { set_error("postprocess: image size outside the plane"); return ISEGMI_ERR_ARG; }
+        void* q;
+        TRY(eng_buf(e, "pp.image_hw", (int64_t)e.max_batch * 8, &q, 1, {N, 2}));
+        d_ihw = (int*)q;
+        TRY(eng_stage_small(e, h_image_hw, (size_t)N * 8, d_ihw, rs));
+    }
     TRY(eng_buf(e, "ws.lo", (int64_t)N * K * PH * PW * 4, &lo));
     TRY(eng_buf(e, "det.masks", (int64_t)N * K * h * w, &masks, 2, {N, K, h, w}));
     TRY(eng_buf(e, "det.box_int", (int64_t)N * K * 4 * 8, &ib, 3, {N, K, 4}));
     TRY(yolact_masks_launch((const float*)proto.d, (const float*)e.bufs["det.coeff"].d, (const float*)e.bufs["det.box"].d,
                             (const int*)e.bufs["det.count"].d, N, PH, PW, md, K, h, w, (float*)lo, (uint8_t*)masks, (int64_t*)ib,
-                            rs));
+                            rs, d_ihw));
     if (e.convs.count("maskiou_net.2")) {
         // YOLACT++ fast mask re-scoring on the proto-resolution masks just written to ws.lo: first layer (1 input channel) and
         // the global-max / class pick as small dedicated kernels, the rest on the MFMA conv kernels over all N*K slots
@@ -572,7 +611,6 @@ extern "C" int isegmi_engine_create(int model_kind, int max_batch, int H, int W,
     if (er == hipSuccess) er = hipEventCreateWithFlags(&h->e.heads_done, hipEventDisableTiming);
     if (er == hipSuccess) er = hipStreamCreateWithFlags(&h->e.copy, hipStreamNonBlocking);
     if (er == hipSuccess) er = hipEventCreateWithFlags(&h->e.in_done, hipEventDisableTiming);
-    if (er == hipSuccess) er = hipEventCreateWithFlags(&h->e.up_done, hipEventDisableTiming);
     if (er != hipSuccess) { set_error(std::string("tail stream: ") + hipGetErrorString(er)); delete h; return ISEGMI_ERR_HIP; }
     h->e.cur = h->e.stream;
     *out = h;
@@ -593,7 +631,12 @@ extern "C" int isegmi_engine_destroy(isegmi_engine* h) {
     if (e.heads_done) (void)hipEventDestroy(e.heads_done);
     if (e.copy) { (void)hipStreamSynchronize(e.copy); (void)hipStreamDestroy(e.copy); }
     if (e.in_done) (void)hipEventDestroy(e.in_done);
-    if (e.up_done) (void)hipEventDestroy(e.up_done);
+    for (auto& u : e.uploads) if (u.done) (void)hipEventDestroy(u.done);
+    if (e.dl) { (void)hipStreamSynchronize(e.dl); (void)hipStreamDestroy(e.dl); }
+    if (e.dl_ready) (void)hipEventDestroy(e.dl_ready);
+    for (int i = 0; i < 2; ++i) if (e.dl_done[i]) (void)hipEventDestroy(e.dl_done[i]);
+    for (int i = 0; i < Engine::PIN_SLOTS; ++i) if (e.pin_ev[i]) (void)hipEventDestroy(e.pin_ev[i]);
+    if (e.pin_ring) (void)hipHostFree(e.pin_ring);
     for (auto& ev : e.step_marks) (void)hipEventDestroy(ev);
     for (auto& kv : e.convs) { (void)hipFree(kv.second.d_w); if (kv.second.d_scale) (void)hipFree(kv.second.d_scale); if (kv.second.d_shift) (void)hipFree(kv.second.d_shift); }
     for (auto& kv : e.tensors) (void)hipFree(kv.second.d);
@@ -673,6 +716,7 @@ extern "C" int isegmi_yolact_forward(isegmi_engine* h, const float* d_images_nhw
     ARG_CHECK(h->e.kind == 1, "engine is not a yolact engine");
     ARG_CHECK(N > 0 && N <= h->e.max_batch, "batch size");
     Engine& e = h->e;
+    TRY(eng_wait_upload(e, d_images_nhwc3, e.stream));
     char key[96];
     snprintf(key, sizeof(key), "yolact:%d:%p", N, (const void*)d_images_nhwc3);
     const int rc = eng_graph_run(e, key, [&]() { return yolact_forward(e, d_images_nhwc3, N); });
@@ -687,11 +731,24 @@ extern "C" int isegmi_yolact_postprocess(isegmi_engine* h, int out_h, int out_w)
     return yolact_postprocess(h->e, out_h, out_w);
 }
 
+extern "C" int isegmi_yolact_postprocess_sizes(isegmi_engine* h, const int32_t* h_image_hw, int N) {
+    ARG_CHECK(h && h_image_hw, "null");
+    ARG_CHECK(h->e.kind == 1, "engine is not a yolact engine");
+    ARG_CHECK(N == h->e.last_N, "postprocess_sizes: N must be the last forward's batch");
+    int ph = 0, pw = 0;
+    for (int i = 0; i < N; ++i) { ph = h_image_hw[2 * i] > ph ? h_image_hw[2 * i] : ph; pw = h_image_hw[2 * i + 1] > pw ? h_image_hw[2 * i + 1] : pw; }
+    ARG_CHECK(ph > 0 && pw > 0, "image sizes");
+    return yolact_postprocess(h->e, ph, pw, h_image_hw);
+}
+
 extern "C" int isegmi_engine_sync(isegmi_engine* h) {
     ARG_CHECK(h, "null");
+    if (h->e.copy) HIP_TRY(hipStreamSynchronize(h->e.copy));  // an upload_async without a consumer yet: the host may reuse its pinned source after sync()
     HIP_TRY(hipStreamSynchronize(h->e.stream));
     if (h->e.heads) HIP_TRY(hipStreamSynchronize(h->e.heads));
     if (h->e.tail) HIP_TRY(hipStreamSynchronize(h->e.tail));
+    if (h->e.dl) HIP_TRY(hipStreamSynchronize(h->e.dl));
+    h->e.in_pending = false;
     h->e.tail_pending = false;
     h->e.lat_pending = false;
     h->e.heads_pending = false;
@@ -701,15 +758,31 @@ extern "C" int isegmi_engine_sync(isegmi_engine* h) {
 
 // Asynchronous input upload: `h_src` must be pinned host memory (isegmi_malloc_host) that stays untouched until the forward
 // consuming `d_dst` has been enqueued and the engine synchronised (or a later upload_async to the same d_dst returned and was
-// synchronised).  The copy runs on the engine's copy stream, after the previous forward has consumed ITS input (so one device
-// buffer may be reused every step, two alternate without any wait), and the next forward is ordered behind the copy.
+// synchronised).  The copy runs on the engine's copy stream, after the last enqueued forward has consumed ITS input (so one device
+// buffer may be reused every step, two alternate without any wait).  Each destination has its own completion event and only the
+// consumer of that destination (isegmi_engine_preprocess_u8 reading it, or the forward taking it as its input) waits on it: an upload
+// of batch i+1 enqueued BEFORE forward i does not hold forward i back.
 extern "C" int isegmi_engine_upload_async(isegmi_engine* h, void* d_dst, const void* h_src, int64_t bytes) {
     ARG_CHECK(h && d_dst && h_src && bytes > 0, "upload args");
     Engine& e = h->e;
     if (e.in_pending) { HIP_TRY(hipStreamWaitEvent(e.copy, e.in_done, 0)); e.in_pending = false; }
     HIP_TRY(hipMemcpyAsync(d_dst, h_src, (size_t)bytes, hipMemcpyHostToDevice, e.copy));
-    HIP_TRY(hipEventRecord(e.up_done, e.copy));
-    HIP_TRY(hipStreamWaitEvent(e.stream, e.up_done, 0));
+    Engine::Upload* u = nullptr;
+    for (auto& x : e.uploads) if (x.dst == (const char*)d_dst) u = &x;
+    if (!u) {
+        if (e.uploads.size() >= 8) {  // destinations come and go (staging buffers are re-allocated when they grow): recycle a consumed entry
+            for (auto& x : e.uploads) if (x.waited) { u = &x; break; }
+            ARG_CHECK(u != nullptr, "more than 8 upload destinations with unconsumed uploads");
+        } else {
+            e.uploads.emplace_back();
+            u = &e.uploads.back();
+            HIP_TRY(hipEventCreateWithFlags(&u->done, hipEventDisableTiming));
+        }
+        u->dst = (const char*)d_dst;
+    }
+    u->bytes = bytes;
+    HIP_TRY(hipEventRecord(u->done, e.copy));
+    u->waited = false;
     return ISEGMI_OK;
 }
 
@@ -717,6 +790,7 @@ extern "C" int isegmi_engine_upload_async(isegmi_engine* h, void* d_dst, const v
 extern "C" int isegmi_engine_preprocess_u8(isegmi_engine* h, const uint8_t* d_u8, int N, int Hin, int Win, float* d_out, int Hout, int Wout,
                                            int Hpad, int Wpad, int64_t out_img_stride, const float* mean3, const float* std3, int swap_rb) {
     ARG_CHECK(h, "null");
+    TRY(eng_wait_upload(h->e, d_u8, h->e.stream));
     return preprocess_u8_launch(d_u8, N, Hin, Win, d_out, Hout, Wout, Hpad, Wpad, out_img_stride, mean3, std3, swap_rb, h->e.stream);
 }
 
@@ -768,6 +842,26 @@ extern "C" int isegmi_engine_buffer_info(isegmi_engine* h, const char* name, voi
     if (dtype) *dtype = b.dtype;
     if (ndim) *ndim = (int32_t)b.shape.size();
     if (shape4) for (size_t i = 0; i < 4; ++i) shape4[i] = i < b.shape.size() ? b.shape[i] : 1;
+    return ISEGMI_OK;
+}
+
+extern "C" int isegmi_engine_memory(isegmi_engine* h, int64_t* weight_bytes, int64_t* buffer_bytes) {
+    ARG_CHECK(h, "null");
+    int64_t wb = 0, bb = 0;
+    for (auto& kv : h->e.convs) {
+        const ConvLayer& L = kv.second;
+        isegmi_conv_desc d;
+        memset(&d, 0, sizeof(d));
+        d.N = 1; d.H = L.R; d.W = L.S; d.Cin = L.Cin; d.Cout = L.Cout; d.R = L.R; d.S = L.S; d.stride = 1;
+        int64_t n = 0;
+        if (L.f16) { if (isegmi_conv_packed_halfs(&d, &n) == 0) wb += n * 2; }
+        else if (isegmi_conv_packed_floats(&d, &n) == 0) wb += n * 4;
+        wb += (L.d_scale ? L.Cout * 4 : 0) + (L.d_shift ? L.Cout * 4 : 0);
+    }
+    for (auto& kv : h->e.tensors) wb += kv.second.bytes;
+    for (auto& kv : h->e.bufs) bb += kv.second.bytes;
+    if (weight_bytes) *weight_bytes = wb;
+    if (buffer_bytes) *buffer_bytes = bb;
     return ISEGMI_OK;
 }
 

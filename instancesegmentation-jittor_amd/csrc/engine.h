@@ -39,7 +39,9 @@ struct StageTime {
 
 struct Engine {
     int kind = 0;  // 1 yolact, 2 maskrcnn
-    int max_batch = 0, H = 0, W = 0;
+    int max_batch = 0, H = 0, W = 0;       // H, W: the LARGEST network input (padded canvas) this engine serves
+    int cur_H = 0, cur_W = 0;              // Mask R-CNN: padded canvas of the current forward (<= H, W; to_image_list pads each batch to its own size)
+    int anchor_H = -1, anchor_W = -1;      // canvas the anchors.* buffers were generated for
     hipStream_t stream = nullptr;          // main stream (all results are complete on it when a forward returns)
     hipStream_t side[3] = {nullptr, nullptr, nullptr};  // side streams for independent branches
     hipStream_t cur = nullptr;             // stream the next launch goes to
@@ -64,12 +66,29 @@ struct Engine {
     std::map<std::string, int> graph_warm;
     int64_t graph_captures = 0, graph_replays = 0, graph_failures = 0;
     // asynchronous input upload (isegmi_engine_upload_async): pinned host -> device on a copy stream; in_done marks the point
-    // where the last forward has consumed its input buffer (WAR for the next upload), up_done the end of the last upload
+    // where the last forward has consumed its input buffer (WAR for the next upload; recorded at the end of a hipGraph replay)
     hipStream_t copy = nullptr;
-    hipEvent_t in_done = nullptr, up_done = nullptr;
+    hipEvent_t in_done = nullptr;
     bool in_pending = false;
+    // one completion event per upload destination (input slot / uint8 staging buffer): the consumer of a buffer waits for ITS upload
+    // only, so the copy of batch i+1 really overlaps forward i
+    struct Upload { const char* dst = nullptr; int64_t bytes = 0; hipEvent_t done = nullptr; bool waited = true; };
+    std::vector<Upload> uploads;
     // per-step completion marks on the results stream (isegmi_engine_mark_step / _step_times): true per-step latency samples
     std::vector<hipEvent_t> step_marks;
+    // small host arrays that change from step to step (image sizes, resize ratios) reach the device through a ring of pinned slots: a
+    // truly asynchronous copy on the consumer's own stream instead of a synchronous hipMemcpy of pageable memory
+    char* pin_ring = nullptr;
+    static constexpr int PIN_SLOTS = 32, PIN_SLOT_BYTES = 4096;
+    hipEvent_t pin_ev[PIN_SLOTS] = {};
+    bool pin_used[PIN_SLOTS] = {};
+    int pin_next = 0;
+    int hw_slot = 0;                       // Mask R-CNN image_hw lives in two device buffers used alternately (WAR against the previous forward's tail)
+    // asynchronous download of a step's record block (device-side COCO output) on its own stream: two slots, like the RCCL records
+    hipStream_t dl = nullptr;
+    hipEvent_t dl_ready = nullptr;
+    hipEvent_t dl_done[2] = {nullptr, nullptr};
+    bool dl_used[2] = {false, false};
     bool fp16 = false;                     // fp16 storage + f16 MFMA convs (BASELINE configs[4]); set before loading weights
     std::vector<hipEvent_t> ev_pool;
     size_t ev_next = 0;
@@ -112,6 +131,9 @@ int eng_graph_run(Engine& e, const std::string& key, const std::function<int()>&
 void eng_graph_reset(Engine& e);
 int eng_tail_end(Engine& e);
 int eng_input_consumed(Engine& e);  // call right after the last kernel that reads the caller's input buffer
+int eng_wait_upload(Engine& e, const void* d_ptr, hipStream_t st);
+int eng_stage_small(Engine& e, const void* h_src, size_t bytes, void* d_dst, hipStream_t st);  // host array -> pinned ring slot -> async H2D on st
+hipStream_t eng_results_stream(Engine& e);  // the stream the last forward's results complete on  // st waits for a pending upload_async whose destination holds d_ptr
 int eng_conv_stem_f16(Engine& e, const std::string& layer, const Tensor& halo, int H, int W, const std::string& out_name, Tensor* out);
 int eng_conv_into(Engine& e, const std::string& layer, const Tensor& in, int stride, int pad, int act, void* dst, int out_div,
                   int64_t out_img_stride, int64_t out_pix_stride, bool out_f32 = false);
@@ -128,7 +150,7 @@ struct SideScope {
 };
 
 int yolact_forward(Engine& e, const float* d_images, int N);
-int yolact_postprocess(Engine& e, int h, int w);
+int yolact_postprocess(Engine& e, int h, int w, const int32_t* h_image_hw = nullptr);
 int maskrcnn_forward(Engine& e, const float* d_images, int N);
 int eng_next_event(Engine& e, hipEvent_t* ev);
 int maskrcnn_paste(Engine& e, const float* h_ratios_wh, int out_h, int out_w);
@@ -165,7 +187,8 @@ int topk_launch(const float* keys, int64_t row_stride, int rows, int n, int k, c
                 float* out_vals, int* out_idx, int* out_cnt, hipStream_t st);
 int yolact_detect_launch(const isegmi_yolact_detect_args* a, hipStream_t st);
 int yolact_masks_launch(const float* proto, const float* coeffs, const float* boxes, const int* count, int N, int PH, int PW,
-                        int mask_dim, int K, int h, int w, float* ws_lo, uint8_t* out_masks, int64_t* out_boxes, hipStream_t st);
+                        int mask_dim, int K, int h, int w, float* ws_lo, uint8_t* out_masks, int64_t* out_boxes, hipStream_t st,
+                        const int* image_hw = nullptr);
 
 }  // namespace isegmi
 

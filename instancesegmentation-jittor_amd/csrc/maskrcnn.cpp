@@ -18,6 +18,7 @@ int rpn_decode_nms_launch(const float* head, const float* anchors, const float* 
                           const int* image_hw, int N, int HWA, int A, int CH, int pre_nms, int post_nms, float thr, float min_size,
                           int ge, int level, int L, int post_cap, float* out_boxes, float* out_scores, int* out_cnt, void* nms_ws,
                           hipStream_t st);
+int grid_anchors_launch(const float* base, int A, int stride, int gh, int gw, float* out, hipStream_t st);
 int sum_counts_launch(const int* cnt, int N, int L, int* total, hipStream_t st);
 int gather_proposals_launch(const float* cand_boxes, const float* fin_vals, const int* fin_idx, const int* fin_cnt, int N,
                             int cand_per_img, int K, float* props, float* prop_scores, int* prop_cnt, hipStream_t st);
@@ -32,6 +33,9 @@ int paste_masks_launch(const float* masks, const float* boxes, const int* counts
 int scale_boxes_launch(const float* boxes, const float* ratios, int N, int K, float* out, hipStream_t st);
 int topk_launch(const float* keys, int64_t row_stride, int rows, int n, int k, const int* limit, int rows_per_limit, float* out_vals,
                 int* out_idx, int* out_cnt, hipStream_t st);
+int64_t topk_scratch_elems(int rows, int n, int k);
+int topk_launch_ws(const float* keys, int64_t row_stride, int rows, int n, int k, const int* limit, int rows_per_limit, float* out_vals,
+                   int* out_idx, int* out_cnt, float* ws_vals, int* ws_idx, hipStream_t st);
 
 #define TRY(x)               \
     do {                     \
@@ -47,35 +51,50 @@ static int need_tensor(Engine& e, const std::string& name, int64_t bytes, const 
     return ISEGMI_OK;
 }
 
-// image_hw is caller memory: copy synchronously, but only when it changed (steady-state batches skip it).  Kept out of
-// maskrcnn_forward so that the forward's enqueue code is capturable into a hipGraph.
+// image_hw is caller memory and changes from batch to batch on real data: it reaches the device through the pinned ring (asynchronous
+// copy on the main stream) into one of TWO device buffers used alternately -- the previous forward's RoI heads (tail stream) may still
+// read theirs; the one before that finished before the previous forward's WAR wait on tail_done, which precedes this copy in stream
+// order.  Kept out of maskrcnn_forward so that the forward's enqueue code is capturable into a hipGraph.
 int maskrcnn_set_image_hw(Engine& e, const int32_t* h_image_hw, int N) {
-    void* p;
-    TRY(eng_buf(e, "image_hw", (int64_t)N * 8, &p, 1, {N, 2}));
     std::vector<int32_t> now(h_image_hw, h_image_hw + 2 * N);
-    if (now != e.last_hw || e.last_hw_ptr != (const void*)p) {
-        // the previous forward's RoI heads (tail stream) may still read image_hw
-        if (e.tail_pending && e.tail) HIP_TRY(hipStreamSynchronize(e.tail));
-        HIP_TRY(hipMemcpyAsync(p, h_image_hw, (size_t)N * 8, hipMemcpyHostToDevice, e.stream));
-        HIP_TRY(hipStreamSynchronize(e.stream));
-        e.last_hw = now;
-        e.last_hw_ptr = p;
-    }
+    if (now == e.last_hw && e.last_hw_ptr != nullptr) return ISEGMI_OK;  // steady-state batches: the current buffer already holds it
+    e.hw_slot ^= 1;
+    void* p;
+    TRY(eng_buf(e, e.hw_slot ? "image_hw.1" : "image_hw.0", (int64_t)e.max_batch * 8, &p, 1, {N, 2}));
+    TRY(eng_stage_small(e, h_image_hw, (size_t)N * 8, p, e.stream));
+    e.last_hw = now;
+    e.last_hw_ptr = p;
     return ISEGMI_OK;
 }
 
 static int maskrcnn_c4_forward(Engine& e, const float* d_images, int N);
 
+// Anchors of one level for the current canvas: the host sets the A base anchors ("anchor_base.<l>", generate_anchors) and the stride
+// ("anchor_stride<l>"); the grid is laid out on the device whenever the canvas changed (always under graph capture, so that a replayed graph
+// never depends on which canvas ran last).  Runs on the main stream, after the forward's WAR wait on the previous forward's tail.
+static int level_anchors(Engine& e, int l, int A, int gh, int gw, bool regen, const float** out) {
+    const std::string ls = std::to_string(l);
+    const RawBuf* base;
+    TRY(need_tensor(e, "anchor_base." + ls, (int64_t)A * 16, &base));
+    const int stride = (int)e.param("anchor_stride" + ls, 0.0f);
+    if (stride <= 0) { set_error("anchor_stride" + ls + " not set"); return ISEGMI_ERR_STATE; }
+    void* q;
+    TRY(eng_buf(e, "anchors." + ls, (int64_t)gh * gw * A * 16, &q, 0, {(int64_t)gh * gw * A, 4}));
+    if (regen) TRY(grid_anchors_launch((const float*)base->d, A, stride, gh, gw, (float*)q, e.stream));
+    *out = (const float*)q;
+    return ISEGMI_OK;
+}
+
 int maskrcnn_forward(Engine& e, const float* d_images, int N) {
     if (e.param("arch_c4", 0.0f) != 0.0f) return maskrcnn_c4_forward(e, d_images, N);
-    const int H = e.H, W = e.W;
+    const int H = e.cur_H, W = e.cur_W;
+    const bool regen_anchors = e.capturing || e.anchor_H != H || e.anchor_W != W;
     if (H % 32 || W % 32) { set_error("Mask R-CNN input must be padded to a multiple of 32"); return ISEGMI_ERR_ARG; }
     e.cur = e.stream;
 #define st e.cur
     eng_mark(e, "start");
     void* p;
-    TRY(eng_buf(e, "image_hw", (int64_t)N * 8, &p, 1, {N, 2}));
-    int* d_hw = (int*)p;
+    int* d_hw = (int*)e.last_hw_ptr;  // maskrcnn_set_image_hw
 
     const int dt = e.fp16 ? 1 : 0;  // storage type of everything after the stem
     Tensor x4, s, x;
@@ -155,8 +174,8 @@ int maskrcnn_forward(Engine& e, const float* d_images, int N) {
         TRY(eng_conv(e, "rpn.head.conv", P[l], 1, 1, 1, nullptr, "rpn.t" + ls, &t));
         TRY(eng_conv(e, "rpn.head.cls_bbox", t, 1, 0, 0, nullptr, "rpn.head" + ls, &head, /*out_f32=*/true));
         const int HW = head.H * head.W, HWA = HW * A;
-        const RawBuf* anc;
-        TRY(need_tensor(e, "anchors." + ls, (int64_t)HWA * 16, &anc));
+        const float* anc;
+        TRY(level_anchors(e, l, A, head.H, head.W, regen_anchors, &anc));
         float *prob, *tkv;
         int *tki, *tkc;
         void* q;
@@ -166,12 +185,18 @@ int maskrcnn_forward(Engine& e, const float* d_images, int N) {
         TRY(eng_buf(e, "rpn.tk_cnt" + ls, (int64_t)N * 4, &q, 1)); tkc = (int*)q;
         void* nms_ws = nullptr;  // suppression matrix of the chip-wide NMS (one per level: the levels run concurrently)
         if (pre_nms <= 1024) TRY(eng_buf(e, "rpn.nms_ws" + ls, (int64_t)N * 131072, &nms_ws, 1));
+        // candidate buffers of the two-level top-k (long rows): engine-owned, one pair per level (the levels run concurrently)
+        float* tws_v = nullptr; int* tws_i = nullptr;
+        if (const int64_t we = topk_scratch_elems(N, HWA, pre_nms)) {
+            TRY(eng_buf(e, "rpn.tk_ws_vals" + ls, we * 4, &q)); tws_v = (float*)q;
+            TRY(eng_buf(e, "rpn.tk_ws_idx" + ls, we * 4, &q, 1)); tws_i = (int*)q;
+        }
         const int sk = l % 3;
         TRY(eng_fork(e, sk));
         SideScope sc(e, sk);
         TRY(rpn_sigmoid_launch(head.d, (int64_t)N * HWA, A, CH, prob, st));
-        TRY(topk_launch(prob, HWA, N, HWA, pre_nms, nullptr, 1, tkv, tki, tkc, st));
-        TRY(rpn_decode_nms_launch(head.d, (const float*)anc->d, tkv, tki, tkc, d_hw, N, HWA, A, CH, pre_nms, post_nms, rpn_thr, rpn_min,
+        TRY(topk_launch_ws(prob, HWA, N, HWA, pre_nms, nullptr, 1, tkv, tki, tkc, tws_v, tws_i, st));
+        TRY(rpn_decode_nms_launch(head.d, anc, tkv, tki, tkc, d_hw, N, HWA, A, CH, pre_nms, post_nms, rpn_thr, rpn_min,
                                   ge, l, L, post_nms, cand_boxes, cand_scores, cand_cnt, nms_ws, st));
         return ISEGMI_OK;
     };
@@ -189,6 +214,7 @@ int maskrcnn_forward(Engine& e, const float* d_images, int N) {
         else TRY(maxpool_launch(P[3].d, N, P[3].H, P[3].W, P[3].C, 1, 2, 0, P[4].d, st));
         TRY(rpn_level(4));
     }
+    e.anchor_H = H; e.anchor_W = W;
     // From here on everything runs on the TAIL stream: it (not the main stream) joins the side streams, so the main
     // stream is free the moment its last RPN convolution is queued and the next forward's backbone starts underneath
     // the remaining per-level selection kernels, proposal merge and RoI heads (all latency-bound or small grids).
@@ -311,7 +337,8 @@ static int res5_head(Engine& e, const std::string& prefix, const std::string& ta
 }
 
 static int maskrcnn_c4_forward(Engine& e, const float* d_images, int N) {
-    const int H = e.H, W = e.W;
+    const int H = e.cur_H, W = e.cur_W;
+    const bool regen_anchors = e.capturing || e.anchor_H != H || e.anchor_W != W;
     if (H % 16 || W % 16) { set_error("Mask R-CNN C4 input must be padded to a multiple of 16"); return ISEGMI_ERR_ARG; }
     if (e.fp16) { set_error("the C4 configuration is fp32 only"); return ISEGMI_ERR_STATE; }
     if (e.multi_stream && e.tail_pending && !e.capturing) HIP_TRY(hipStreamWaitEvent(e.stream, e.tail_done, 0));
@@ -319,8 +346,7 @@ static int maskrcnn_c4_forward(Engine& e, const float* d_images, int N) {
     hipStream_t st = e.stream;
     eng_mark(e, "start");
     void* p;
-    TRY(eng_buf(e, "image_hw", (int64_t)N * 8, &p, 1, {N, 2}));
-    int* d_hw = (int*)p;
+    int* d_hw = (int*)e.last_hw_ptr;  // maskrcnn_set_image_hw
     Tensor x4, s, x;
     TRY(eng_act(e, "input4", N, H, W, 4, &x4));
     TRY(pad_c3_c4_launch(d_images, (int64_t)N * H * W, x4.d, st));
@@ -363,8 +389,9 @@ static int maskrcnn_c4_forward(Engine& e, const float* d_images, int N) {
     TRY(eng_conv(e, "rpn.head.cls_bbox", t, 1, 0, 0, nullptr, "rpn.head", &head));
     if (head.C != CH) { set_error("C4 rpn.head.cls_bbox must have 15 + 60 outputs"); return ISEGMI_ERR_STATE; }
     const int HWA = head.H * head.W * A;
-    const RawBuf* anc;
-    TRY(need_tensor(e, "anchors.0", (int64_t)HWA * 16, &anc));
+    const float* anc;
+    TRY(level_anchors(e, 0, A, head.H, head.W, regen_anchors, &anc));
+    e.anchor_H = H; e.anchor_W = W;
     const int R = post_nms;
     float *prob, *tkv, *props, *prop_scores;
     int *tki, *tkc, *prop_cnt;
@@ -380,7 +407,7 @@ static int maskrcnn_c4_forward(Engine& e, const float* d_images, int N) {
     // one level: the NMS output (score order) IS the proposal list (select_over_all_levels only runs for > 1 level)
     void* nms_ws = nullptr;
     if (pre_nms <= 1024) TRY(eng_buf(e, "rpn.nms_ws", (int64_t)N * 131072, &nms_ws, 1));
-    TRY(rpn_decode_nms_launch(head.d, (const float*)anc->d, tkv, tki, tkc, d_hw, N, HWA, A, CH, pre_nms, post_nms, rpn_thr, rpn_min, ge, 0, 1,
+    TRY(rpn_decode_nms_launch(head.d, anc, tkv, tki, tkc, d_hw, N, HWA, A, CH, pre_nms, post_nms, rpn_thr, rpn_min, ge, 0, 1,
                               R, props, prop_scores, prop_cnt, nms_ws, st));
     eng_mark(e, "rpn");
 
@@ -448,14 +475,14 @@ int maskrcnn_paste(Engine& e, const float* h_ratios_wh, int out_h, int out_w) {
     if (N <= 0) { set_error("paste before forward"); return ISEGMI_ERR_STATE; }
     const int cap = (int)e.param("detections_per_img", 100);
     void *p, *rb, *rt;
-    TRY(eng_buf(e, "ws.ratios", (int64_t)N * 8, &rt));
+    TRY(eng_buf(e, "ws.ratios", (int64_t)e.max_batch * 8, &rt));
     hipStream_t ps = (e.multi_stream && e.tail_pending) ? e.tail : e.stream;  // results stream of the last forward
     e.cur = ps;
     {
+        // in stream order behind every earlier reader of ws.ratios (the previous paste ran on a results stream this one is ordered behind)
         std::vector<float> now(h_ratios_wh, h_ratios_wh + 2 * N);
         if (now != e.last_ratios || e.last_ratios_ptr != (const void*)rt) {
-            HIP_TRY(hipMemcpyAsync(rt, h_ratios_wh, (size_t)N * 8, hipMemcpyHostToDevice, ps));
-            HIP_TRY(hipStreamSynchronize(ps));
+            TRY(eng_stage_small(e, h_ratios_wh, (size_t)N * 8, rt, ps));
             e.last_ratios = now;
             e.last_ratios_ptr = rt;
         }
@@ -476,21 +503,31 @@ int maskrcnn_paste(Engine& e, const float* h_ratios_wh, int out_h, int out_w) {
 
 using namespace isegmi;
 
-extern "C" int isegmi_maskrcnn_forward(isegmi_engine* h, const float* d_images, const int32_t* h_image_hw, int N) {
+extern "C" int isegmi_maskrcnn_forward_canvas(isegmi_engine* h, const float* d_images, const int32_t* h_image_hw, int N, int H, int W) {
     ARG_CHECK(h && d_images && h_image_hw, "null");
     ARG_CHECK(h->e.kind == 2, "engine is not a Mask R-CNN engine");
     ARG_CHECK(N > 0 && N <= h->e.max_batch, "batch size");
+    ARG_CHECK(H > 0 && W > 0 && H <= h->e.H && W <= h->e.W, "canvas must fit inside the engine's maximum input size");
     for (int i = 0; i < N; ++i)
-        ARG_CHECK(h_image_hw[2 * i] > 0 && h_image_hw[2 * i] <= h->e.H && h_image_hw[2 * i + 1] > 0 && h_image_hw[2 * i + 1] <= h->e.W,
-                  "image_hw must fit inside the padded input");
+        ARG_CHECK(h_image_hw[2 * i] > 0 && h_image_hw[2 * i] <= H && h_image_hw[2 * i + 1] > 0 && h_image_hw[2 * i + 1] <= W,
+                  "image_hw must fit inside the padded canvas");
     Engine& e = h->e;
+    TRY(eng_wait_upload(e, d_images, e.stream));
     TRY(maskrcnn_set_image_hw(e, h_image_hw, N));
-    char key[96];
-    snprintf(key, sizeof(key), "maskrcnn:%d:%p", N, (const void*)d_images);
+    e.cur_H = H; e.cur_W = W;
+    char key[160];  // everything a captured graph bakes in: batch, canvas, input pointer, and which of the two image_hw buffers is current
+    snprintf(key, sizeof(key), "maskrcnn:%d:%dx%d:%p:%p", N, H, W, (const void*)d_images, e.last_hw_ptr);
+    const bool graph_on = e.param("graph", 0.0f) != 0.0f;
     const int rc = eng_graph_run(e, key, [&]() { return maskrcnn_forward(e, d_images, N); });
+    if (graph_on) { e.anchor_H = -1; e.anchor_W = -1; }  // a replay leaves ITS canvas's anchors behind, whatever the bookkeeping says
     e.cur = e.stream;
     if (rc == ISEGMI_OK) e.last_N = N;
     return rc;
+}
+
+extern "C" int isegmi_maskrcnn_forward(isegmi_engine* h, const float* d_images, const int32_t* h_image_hw, int N) {
+    ARG_CHECK(h, "null");
+    return isegmi_maskrcnn_forward_canvas(h, d_images, h_image_hw, N, h->e.H, h->e.W);
 }
 
 // h_ratios_wh [N][2] = (out_w / w_i, out_h / h_i) as float, computed by the host like BoxList.resize

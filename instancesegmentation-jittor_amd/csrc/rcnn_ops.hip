@@ -899,6 +899,28 @@ int nms_launch(const float* boxes, const float* scores, int problems, int n, flo
     return ISEGMI_OK;
 }
 
+// AnchorGenerator.grid_anchors (A.3) on the device: out[(y * gw + x) * A + a] = base[a] + (x*stride, y*stride, x*stride, y*stride) -- one
+// fp32 add per coordinate, exactly the host's numpy arithmetic (the shifts are small integers, exact in fp32).  Lets ONE engine serve any
+// padded canvas: the anchors of a level are regenerated when the canvas changes instead of being a per-canvas constant tensor.
+__global__ void grid_anchors_kernel(const float* __restrict__ base, int A, int stride, int gw, int64_t total, float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t cell = i / A;
+        const int a = (int)(i - cell * A);
+        const int y = (int)(cell / gw), x = (int)(cell - (int64_t)y * gw);
+        const float sx = (float)(x * stride), sy = (float)(y * stride);
+        const float4 b = *(const float4*)(base + a * 4);
+        *(float4*)(out + i * 4) = make_float4(sx + b.x, sy + b.y, sx + b.z, sy + b.w);
+    }
+}
+
+int grid_anchors_launch(const float* base, int A, int stride, int gh, int gw, float* out, hipStream_t st) {
+    const int64_t total = (int64_t)gh * gw * A;
+    if (total <= 0) return ISEGMI_OK;
+    hipLaunchKernelGGL(grid_anchors_kernel, dim3(grid_for(total)), dim3(256), 0, st, base, A, stride, gw, total, out);
+    HIP_TRY(hipGetLastError());
+    return ISEGMI_OK;
+}
+
 int rpn_sigmoid_launch(const float* head, int64_t total, int A, int CH, float* prob, hipStream_t st) {
     hipLaunchKernelGGL(rpn_sigmoid_kernel, dim3(grid_for(total)), dim3(256), 0, st, head, total, A, CH, prob);
     HIP_TRY(hipGetLastError());
@@ -1086,6 +1108,11 @@ extern "C" int isegmi_op_paste_masks(const float* d_masks, const float* d_boxes,
 // One RPN level for N images (parity-test entry; the engine calls the same launchers):
 // head [N][HW][A*5] -> boxes/scores [N][post_nms] (+count).  Workspaces: prob [N][HWA], tk_* [N][pre_nms]; d_ws_nms: optional
 // N * 128 KiB for the chip-wide NMS (pre_nms <= 1024), NULL = single-block NMS.
+extern "C" int isegmi_op_grid_anchors(const float* d_base, int A, int stride, int grid_h, int grid_w, float* d_out, void* stream) {
+    ARG_CHECK(d_base && d_out && A > 0 && stride > 0 && grid_h > 0 && grid_w > 0, "grid_anchors args");
+    return grid_anchors_launch(d_base, A, stride, grid_h, grid_w, d_out, (hipStream_t)stream);
+}
+
 extern "C" int isegmi_op_rpn_level(const float* d_head, const float* d_anchors, const int32_t* d_image_hw, int N, int HW, int A,
                                    int pre_nms, int post_nms, float nms_thr, float min_size, int nms_ge, float* d_ws_prob,
                                    float* d_ws_tk_vals, int32_t* d_ws_tk_idx, int32_t* d_ws_tk_cnt, float* d_out_boxes,

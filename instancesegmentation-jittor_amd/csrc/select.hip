@@ -213,8 +213,9 @@ __global__ __launch_bounds__(NT) void topk_kernel(const TopkArgs a) {
     if (tid == 0 && a.out_cnt) a.out_cnt[orow] = k_eff;
 }
 
-// Candidate buffers of the two-level top-k: one grow-only pair per stream (calls on one stream are ordered; the RPN levels run on
-// different streams concurrently and must not share).  Never freed: at most a few MB per stream.
+// Candidate buffers of the two-level top-k for callers that bring none (the op-level C ABI): one grow-only pair per stream (calls on
+// one stream are ordered).  The engines pass their own named buffers instead (topk_launch_ws), so nothing captured into a hipGraph
+// or shared between engines ever points into this pool.
 static int topk_scratch(hipStream_t st, size_t elems, float** vals, int** idx) {
     struct S { float* v = nullptr; int* i = nullptr; size_t cap = 0; };
     static std::mutex mu;
@@ -231,8 +232,18 @@ static int topk_scratch(hipStream_t st, size_t elems, float** vals, int** idx) {
     return ISEGMI_OK;
 }
 
-int topk_launch(const float* keys, int64_t row_stride, int rows, int n, int k, const int* limit, int rows_per_limit,
-                float* out_vals, int* out_idx, int* out_cnt, hipStream_t st) {
+// Number of (value, index) candidate pairs the two-level path needs for this problem; 0 = the one-level path is taken.
+static int topk_two_level_slices(int rows, int n, int k, const int* limit) {
+    if (limit != nullptr || k <= 256 || k > 1024 || rows > 32 || n < 40000) return 0;  // break-even with one level at ~32 K keys (tools/topk_time.py)
+    int slices = (n + 12287) / 12288;
+    return slices > 32 ? 32 : slices;
+}
+int64_t topk_scratch_elems(int rows, int n, int k) { return (int64_t)rows * topk_two_level_slices(rows, n, k, nullptr) * k; }
+
+// ws_vals / ws_idx: caller-owned candidate buffers of topk_scratch_elems() entries each (the engine passes named buffers so that
+// captured graphs never hold pointers this file could free); NULL = the per-stream grow-only pool above (op-level calls).
+int topk_launch_ws(const float* keys, int64_t row_stride, int rows, int n, int k, const int* limit, int rows_per_limit,
+                   float* out_vals, int* out_idx, int* out_cnt, float* ws_vals, int* ws_idx, hipStream_t st) {
     ARG_CHECK(rows >= 0 && n >= 0 && k > 0 && k <= 8192, "topk sizes (k <= 8192)");
     if (rows == 0) return ISEGMI_OK;
     TopkArgs a{keys, row_stride, n, k, limit, rows_per_limit > 0 ? rows_per_limit : 1, out_vals, out_idx, out_cnt, 0, 0, 0, 0, nullptr};
@@ -240,12 +251,10 @@ int topk_launch(const float* keys, int64_t row_stride, int rows, int n, int k, c
     // ONE block took 56-108 us with the rest of the chip idle.  Two levels instead: every (row, slice of ~12 K keys) block keeps its k best
     // (select + ordered compaction, no sort), then the row's slices * k candidates go through the full kernel.  Exact: a global top-k key is
     // in its slice's top-k, and the (key desc, index asc) order survives because equal keys reach level 2 in index order.
-    if (limit == nullptr && k > 256 && k <= 1024 && rows <= 32 && n >= 40000) {  // break-even with one level at ~32 K keys (tools/topk_time.py)
-        int slices = (n + 12287) / 12288;
-        if (slices > 32) slices = 32;
+    if (const int slices = topk_two_level_slices(rows, n, k, limit)) {
         const int slice_len = (n + slices - 1) / slices;
-        float* cv = nullptr; int* ci = nullptr;
-        { const int rc = topk_scratch(st, (size_t)rows * slices * k, &cv, &ci); if (rc != ISEGMI_OK) return rc; }
+        float* cv = ws_vals; int* ci = ws_idx;
+        if (cv == nullptr || ci == nullptr) { const int rc = topk_scratch(st, (size_t)rows * slices * k, &cv, &ci); if (rc != ISEGMI_OK) return rc; }
         TopkArgs l1 = a;
         l1.slices = slices; l1.slice_len = slice_len; l1.out_vals = cv; l1.out_idx = ci; l1.out_cnt = nullptr;
         hipLaunchKernelGGL((topk_kernel<1024, 1024>), dim3(rows * slices), dim3(1024), 0, st, l1);
@@ -271,6 +280,11 @@ int topk_launch(const float* keys, int64_t row_stride, int rows, int n, int k, c
     }
     HIP_TRY(hipGetLastError());
     return ISEGMI_OK;
+}
+
+int topk_launch(const float* keys, int64_t row_stride, int rows, int n, int k, const int* limit, int rows_per_limit,
+                float* out_vals, int* out_idx, int* out_cnt, hipStream_t st) {
+    return topk_launch_ws(keys, row_stride, rows, n, k, limit, rows_per_limit, out_vals, out_idx, out_cnt, nullptr, nullptr, st);
 }
 
 // top-k over the first seg_take keys of each of nseg segments of seg_len keys per row (k <= 128); indices refer to the full row

@@ -244,11 +244,16 @@ __global__ __launch_bounds__(256) void yolact_proto_masks_kernel(const float* __
 // TB/s whatever its store width: a wave's 64 lanes span two image rows, so nearly every wave met some window and walked the
 // per-pixel path with most lanes idle.)  grid (chunks, K, N); one thread per window pixel, byte stores coalesced by the lanes of
 // a row segment; the four taps come from the proto-resolution masks (L2 / Infinity Cache resident).
+// image_hw (optional, [N][2]): image n is upsampled to ITS (h_n, w_n) inside the common (h, w) plane (a batch of images of different
+// original sizes, each postprocess()ed at its own size as upstream's per-image evalimage does); NULL = every image at (h, w).
 __global__ __launch_bounds__(256) void yolact_upsample_masks_kernel(const float* __restrict__ lo, const float* __restrict__ boxes,
                                                                      const int* __restrict__ count, int PH, int PW, int K, int h, int w,
-                                                                     uint8_t* __restrict__ out) {
+                                                                     const int* __restrict__ image_hw, uint8_t* __restrict__ out) {
     const int n = blockIdx.z, d = blockIdx.y;
     if (d >= count[n]) return;
+    const int plane_w = w;
+    const int64_t plane = (int64_t)h * w;
+    if (image_hw) { h = image_hw[2 * n]; w = image_hw[2 * n + 1]; }
     const float4 b = *(const float4*)(boxes + ((int64_t)n * K + d) * 4);
     float x1, x2, y1, y2;
     sanitize(b.x, b.z, PW, 1.0f, x1, x2);
@@ -265,7 +270,7 @@ __global__ __launch_bounds__(256) void yolact_upsample_masks_kernel(const float*
     const int area = ww * wh;
     const float sy = dm_div((float)PH, (float)h), sx = dm_div((float)PW, (float)w);  // dm_bil_coef's scale, hoisted
     const float* m = lo + ((int64_t)n * K + d) * PH * PW;
-    uint8_t* o = out + ((int64_t)n * K + d) * h * w;
+    uint8_t* o = out + ((int64_t)n * K + d) * plane;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < area; i += gridDim.x * 256) {
         const int ry = i / ww;
         const int y = oy0 + ry, x = ox0 + (i - ry * ww);
@@ -275,14 +280,15 @@ __global__ __launch_bounds__(256) void yolact_upsample_masks_kernel(const float*
         float top = lx0 * m[y0 * PW + x0]; top = fmaf(lx1, m[y0 * PW + xb], top);
         float bot = lx0 * m[yb * PW + x0]; bot = fmaf(lx1, m[yb * PW + xb], bot);
         float v = ly0 * top; v = fmaf(ly1, bot, v);
-        o[y * w + x] = v > 0.5f ? (uint8_t)1 : (uint8_t)0;
+        o[y * plane_w + x] = v > 0.5f ? (uint8_t)1 : (uint8_t)0;
     }
 }
 
 // integer boxes (A.9 last line): sanitize(pad 0) against (w,h) then truncate to int64.
 __global__ void yolact_int_boxes_kernel(const float* __restrict__ boxes, const int* __restrict__ count, int K, int h, int w,
-                                        int64_t* __restrict__ out) {
+                                        const int* __restrict__ image_hw, int64_t* __restrict__ out) {
     const int n = blockIdx.x;
+    if (image_hw) { h = image_hw[2 * n]; w = image_hw[2 * n + 1]; }
     for (int d = threadIdx.x; d < K; d += blockDim.x) {
         int64_t* o = out + ((int64_t)n * K + d) * 4;
         if (d < count[n]) {
@@ -403,7 +409,8 @@ int maskiou_rescore_launch(const float* feat, int N, int K, int HW, int C, const
 }
 
 int yolact_masks_launch(const float* proto, const float* coeffs, const float* boxes, const int* count, int N, int PH, int PW,
-                        int mask_dim, int K, int h, int w, float* ws_lo, uint8_t* out_masks, int64_t* out_boxes, hipStream_t st) {
+                        int mask_dim, int K, int h, int w, float* ws_lo, uint8_t* out_masks, int64_t* out_boxes, hipStream_t st,
+                        const int* image_hw) {
     ARG_CHECK(mask_dim == MD, "mask_dim must be 32");
     ARG_CHECK(N > 0 && K > 0 && K <= 128 && h > 0 && w > 0, "mask sizes");
     const size_t lds = (size_t)K * (MD + 4) * sizeof(float);
@@ -416,10 +423,10 @@ int yolact_masks_launch(const float* proto, const float* coeffs, const float* bo
     int chunks = (int)cdiv64((int64_t)h * w, 2048);
     if (chunks > 32) chunks = 32;
     hipLaunchKernelGGL(yolact_upsample_masks_kernel, dim3((unsigned)chunks, (unsigned)K, (unsigned)N), dim3(256), 0, st, ws_lo, boxes, count, PH, PW, K, h, w,
-                       out_masks);
+                       image_hw, out_masks);
     HIP_TRY(hipGetLastError());
     if (out_boxes) {
-        hipLaunchKernelGGL(yolact_int_boxes_kernel, dim3(N), dim3(128), 0, st, boxes, count, K, h, w, out_boxes);
+        hipLaunchKernelGGL(yolact_int_boxes_kernel, dim3(N), dim3(128), 0, st, boxes, count, K, h, w, image_hw, out_boxes);
         HIP_TRY(hipGetLastError());
     }
     return ISEGMI_OK;
@@ -437,5 +444,5 @@ extern "C" int isegmi_op_yolact_masks(const float* d_proto, const float* d_coeff
                                       int N, int PH, int PW, int mask_dim, int K, int h, int w, float* d_ws_lo,
                                       uint8_t* d_out_masks, int64_t* d_out_boxes, void* stream) {
     return yolact_masks_launch(d_proto, d_coeffs, d_boxes, d_count, N, PH, PW, mask_dim, K, h, w, d_ws_lo, d_out_masks, d_out_boxes,
-                               (hipStream_t)stream);
+                               (hipStream_t)stream, nullptr);
 }

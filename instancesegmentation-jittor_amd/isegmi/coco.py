@@ -122,6 +122,42 @@ def yolact_results(image_id, classes, scores, boxes_xyxy_int, masks=None, mask_s
     return out
 
 
+def results_from_records(rec, image_ids, image_hw, kind, K=100, score_threshold=None, top_k=None):
+    """One rank's unpacked record block (isegmi.dist.unpack_coco_records: the device-side output of a step) -> COCO result dicts, the
+    same records maskrcnn_results / yolact_results build from host arrays: bbox conversion and category map here, `segmentation.counts`
+    straight from the device-made strings.  image_ids / image_hw: per image slot of the batch (None id = an empty padding slot).
+    score_threshold / top_k (Yolact eval.py --score_threshold / --top_k): keep score > threshold, then the first top_k (score order)."""
+    out = []
+    count, box, score, label, so, chars = rec["count"], rec["box"], rec["score"], rec["label"], rec["str_off"], rec["chars"]
+    ms = rec.get("mscore")
+    for n, iid in enumerate(image_ids):
+        c = int(count[n])
+        if iid is None or c == 0:
+            continue
+        h, w = int(image_hw[n][0]), int(image_hw[n][1])
+        b = np.asarray(box[n, :c], np.float64)
+        if kind == 2:   # prepare_for_coco_detection: xyxy -> xywh with the legacy +1
+            bb = np.stack([b[:, 0], b[:, 1], b[:, 2] - b[:, 0] + 1.0, b[:, 3] - b[:, 1] + 1.0], 1).tolist()
+            cats = [COCO_CATEGORY_IDS[int(l) - 1] for l in label[n, :c]]
+        else:           # Detections.add_bbox: [x1, y1, w, h] rounded to 0.1
+            bb = (np.round(np.stack([b[:, 0], b[:, 1], b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]], 1) * 10) / 10).tolist()
+            cats = [COCO_CATEGORY_IDS[int(l)] for l in label[n, :c]]
+        sc = np.asarray(score[n, :c], np.float64).tolist()
+        offs = so[n * K:n * K + c + 1].tolist()
+        keep = range(c)
+        if score_threshold is not None:
+            keep = [k for k in keep if score[n, k] > np.float32(score_threshold)]
+        if top_k is not None:
+            keep = list(keep)[:top_k]
+        for k in keep:
+            d = {"image_id": int(iid), "category_id": cats[k], "bbox": bb[k], "score": sc[k],
+                 "segmentation": {"size": [h, w], "counts": chars[offs[k]:offs[k + 1]].decode("ascii")}}
+            if ms is not None:
+                d["mask_score"] = float(ms[n, k])
+            out.append(d)
+    return out
+
+
 def dump(results, path):
     with open(path, "w") as f:
         json.dump(results, f)

@@ -162,8 +162,18 @@ class BoxList:
         return b
 
 
+def padded_canvas(image_hw, divisibility=32):
+    """to_image_list: the canvas of a batch = max height / width over its images, rounded up to SIZE_DIVISIBILITY."""
+    hw = np.asarray(image_hw, np.int64).reshape(-1, 2)
+    return (int(-(-hw[:, 0].max() // divisibility) * divisibility), int(-(-hw[:, 1].max() // divisibility) * divisibility))
+
+
 class MaskRCNN:
-    """GeneralizedRCNN engine wrapper: `model = MaskRCNN(sd, H, W)`; `preds = model(batch, image_hw)`."""
+    """GeneralizedRCNN engine wrapper: `model = MaskRCNN(sd, H, W)`; `preds = model(batch, image_hw)`.
+
+    (H, W) is the LARGEST padded canvas the engine serves.  Every batch runs on its own canvas (to_image_list pads a batch to the maximum
+    size of its images, rounded up to SIZE_DIVISIBILITY; the RPN sees the padding, so results depend on the canvas exactly as upstream's
+    do): weights are packed once, anchors are laid out on the device per canvas, and `reserve()` sizes every buffer once."""
 
     KIND = 2
 
@@ -191,6 +201,19 @@ class MaskRCNN:
             self.set_param(k, float(v))
         self._d_in = _ffi.DeviceBuffer((max_batch, H, W, 3))
         self._hw = None
+        self._canvas = (H, W)
+
+    def reserve(self):
+        """Size every activation / workspace / output buffer for the largest canvas and batch by running one forward + paste on a zero batch
+        (buffers only ever grow, so no forward re-allocates afterwards).  Returns memory()."""
+        self._d_in.zero()
+        self._hw = np.tile(np.array([[self.H, self.W]], np.int32), (self.max_batch, 1))
+        self._canvas = (self.H, self.W)
+        self.forward_device(self.max_batch)
+        self.paste_device(self.H, self.W)
+        self.sync()
+        return self.memory()
+
 
     def set_param(self, name, value):
         _ffi.check(_ffi.lib().isegmi_engine_set_param(self._h, name.encode(), C.c_float(value)))
@@ -248,11 +271,10 @@ class MaskRCNN:
             self._set_conv_krsc("roi_heads.mask.predictor.conv5_mask.%d" % ab, wab, None, sd["roi_heads.mask.predictor.conv5_mask.bias"])
         self._set_tensor("mask_logits.w", sd["roi_heads.mask.predictor.mask_fcn_logits.weight"].reshape(81, 256).astype(np.float32))
         self._set_tensor("mask_logits.b", sd["roi_heads.mask.predictor.mask_fcn_logits.bias"].astype(np.float32))
-        self.anchors = []
-        for l, ((gh, gw), stride, size) in enumerate(zip(level_shapes(self.H, self.W), cfg.ANCHOR_STRIDE, cfg.ANCHOR_SIZES)):
-            a = grid_anchors(gh, gw, stride, generate_anchors(stride, size, cfg.ASPECT_RATIOS))
-            self.anchors.append(a)
-            self._set_tensor("anchors.%d" % l, a)
+        # AnchorGenerator: the A base anchors per level go over; the engine lays the grid out for each batch's canvas (isegmi_op_grid_anchors)
+        for l, (stride, size) in enumerate(zip(cfg.ANCHOR_STRIDE, cfg.ANCHOR_SIZES)):
+            self._set_tensor("anchor_base.%d" % l, generate_anchors(stride, size, cfg.ASPECT_RATIOS))
+            self.set_param("anchor_stride%d" % l, float(stride))
 
     def _load_bottlenecks(self, sd, src_prefix, dst_prefix, nblocks):
         for b in range(nblocks):
@@ -289,57 +311,67 @@ class MaskRCNN:
             self._set_conv_krsc("roi_heads.mask.predictor.conv5_mask.%d" % ab, wab, None, sd["roi_heads.mask.predictor.conv5_mask.bias"])
         self._set_tensor("mask_logits.w", sd["roi_heads.mask.predictor.mask_fcn_logits.weight"].reshape(81, 256).astype(np.float32))
         self._set_tensor("mask_logits.b", sd["roi_heads.mask.predictor.mask_fcn_logits.bias"].astype(np.float32))
-        a = grid_anchors(self.H // 16, self.W // 16, 16, generate_anchors_multi(16, cfg.ANCHOR_SIZES, cfg.ASPECT_RATIOS))
-        self.anchors = [a]
-        self._set_tensor("anchors.0", a)
+        self._set_tensor("anchor_base.0", generate_anchors_multi(16, cfg.ANCHOR_SIZES, cfg.ASPECT_RATIOS))
+        self.set_param("anchor_stride0", 16.0)
 
     # -- execution -----------------------------------------------------------------------------
-    def upload(self, batch_nhwc3, image_hw):
+    def _set_canvas(self, H, W):
+        d = self.cfg.SIZE_DIVISIBILITY
+        if H % d or W % d or H > self.H or W > self.W:
+            raise ValueError("canvas %dx%d: must be a multiple of %d and fit inside the engine's %dx%d" % (H, W, d, self.H, self.W))
+        self._canvas = (int(H), int(W))
+
+    def upload(self, batch_nhwc3, image_hw, slot=0):
+        """An already-normalised, zero-padded fp32 batch [n, H, W, 3] (prepare_images); its (H, W) is the canvas of the next forward."""
         x = np.ascontiguousarray(batch_nhwc3, np.float32)
-        assert x.ndim == 4 and x.shape[1:] == (self.H, self.W, 3) and x.shape[0] <= self.max_batch, x.shape
-        _ffi.check(_ffi.lib().isegmi_h2d(self._d_in.ptr, x.ctypes.data_as(C.c_void_p), C.c_int64(x.nbytes)))
+        assert x.ndim == 4 and x.shape[3] == 3 and x.shape[0] <= self.max_batch, x.shape
+        self._set_canvas(x.shape[1], x.shape[2])
+        _ffi.check(_ffi.lib().isegmi_h2d(self.input_buffer(slot).ptr, x.ctypes.data_as(C.c_void_p), C.c_int64(x.nbytes)))
         self._hw = np.ascontiguousarray(image_hw, np.int32).reshape(-1, 2)
         assert self._hw.shape[0] == x.shape[0]
         return x.shape[0]
 
-    def upload_u8(self, images_bgr_u8, slot=0):
+    def upload_u8(self, images_bgr_u8, slot=0, canvas=None):
         """to_image_list on the device (M1): a list of already-resized HxWx3 uint8 BGR images (what PIL's resize returns) -> mean-subtracted,
-        zero-padded fp32 batch in the input buffer, bit-identical to prepare_images() on the host; a quarter of the PCIe bytes."""
+        zero-padded fp32 batch in the input buffer, bit-identical to prepare_images() on the host; a quarter of the PCIe bytes.  The batch's
+        canvas is the padded maximum of its image sizes unless `canvas` = (H, W) forces a larger one."""
         assert 0 < len(images_bgr_u8) <= self.max_batch
         ims = [np.ascontiguousarray(im) for im in images_bgr_u8]
         if any(im.dtype != np.uint8 or im.ndim != 3 or im.shape[2] != 3 for im in ims):
             raise TypeError("upload_u8 takes HxWx3 uint8 images: a float batch goes through upload(batch, image_hw)")
         hw = np.array([im.shape[:2] for im in ims], np.int32)
-        assert hw[:, 0].max() <= self.H and hw[:, 1].max() <= self.W, "image larger than the padded input"
+        self._set_canvas(*(canvas or padded_canvas(hw, self.cfg.SIZE_DIVISIBILITY)))
         flat = np.concatenate([im.reshape(-1) for im in ims])
         st = self._u8_staging(slot, flat.nbytes)
         _ffi.check(_ffi.lib().isegmi_h2d(st.ptr, flat.ctypes.data_as(C.c_void_p), C.c_int64(flat.nbytes)))
-        d_out = self.input_buffer(slot).ptr.value
-        off = 0
-        for i, im in enumerate(ims):
-            h, w = int(hw[i, 0]), int(hw[i, 1])
-            self._preprocess_u8(st.ptr.value + off, 1, h, w, d_out + i * self.H * self.W * 3 * 4, h, w, self.H, self.W, PIXEL_MEAN, (1.0, 1.0, 1.0), False)
-            off += h * w * 3
-        self._hw = hw
+        self._front_end(st, hw, slot)
         return len(ims)
 
-    def upload_u8_async(self, pinned_u8, image_hw, slot=0):
-        """upload_u8 from a uint8 _ffi.PinnedBuffer holding the images back to back (each h x w x 3), on the engine's copy stream."""
-        hw = np.ascontiguousarray(image_hw, np.int32).reshape(-1, 2)
-        nbytes = int((hw[:, 0].astype(np.int64) * hw[:, 1] * 3).sum())
-        assert pinned_u8.nbytes >= nbytes and hw.shape[0] <= self.max_batch
-        st = self._u8_staging(slot, nbytes)
-        _ffi.check(_ffi.lib().isegmi_engine_upload_async(self._h, st.ptr, pinned_u8.ptr, C.c_int64(nbytes)))
+    def _front_end(self, st, hw, slot):
+        """build_transform's normalisation + to_image_list on the device: image i of the staging buffer -> plane i of the canvas batch."""
+        H, W = self._canvas
+        assert hw[:, 0].max() <= H and hw[:, 1].max() <= W, "image larger than the padded canvas"
         d_out = self.input_buffer(slot).ptr.value
         off = 0
         for i in range(hw.shape[0]):
             h, w = int(hw[i, 0]), int(hw[i, 1])
-            self._preprocess_u8(st.ptr.value + off, 1, h, w, d_out + i * self.H * self.W * 3 * 4, h, w, self.H, self.W, PIXEL_MEAN, (1.0, 1.0, 1.0), False)
+            self._preprocess_u8(st.ptr.value + off, 1, h, w, d_out + i * H * W * 3 * 4, h, w, H, W, PIXEL_MEAN, (1.0, 1.0, 1.0), False)
             off += h * w * 3
         self._hw = hw
 
+    def upload_u8_async(self, pinned_u8, image_hw, slot=0, canvas=None):
+        """upload_u8 from a uint8 _ffi.PinnedBuffer holding the images back to back (each h x w x 3), on the engine's copy stream."""
+        hw = np.ascontiguousarray(image_hw, np.int32).reshape(-1, 2)
+        nbytes = int((hw[:, 0].astype(np.int64) * hw[:, 1] * 3).sum())
+        assert pinned_u8.nbytes >= nbytes and hw.shape[0] <= self.max_batch
+        self._set_canvas(*(canvas or padded_canvas(hw, self.cfg.SIZE_DIVISIBILITY)))
+        st = self._u8_staging(slot, nbytes)
+        _ffi.check(_ffi.lib().isegmi_engine_upload_async(self._h, st.ptr, pinned_u8.ptr, C.c_int64(nbytes)))
+        self._front_end(st, hw, slot)
+
     def forward_device(self, n, slot=0):
-        _ffi.check(_ffi.lib().isegmi_maskrcnn_forward(self._h, self.input_buffer(slot).ptr, self._hw.ctypes.data_as(C.c_void_p), n))
+        H, W = self._canvas
+        _ffi.check(_ffi.lib().isegmi_maskrcnn_forward_canvas(self._h, self.input_buffer(slot).ptr, self._hw.ctypes.data_as(C.c_void_p), n, H, W))
 
     def paste_device(self, out_h, out_w, orig_sizes_wh=None):
         """Masker paste into (out_h, out_w); orig_sizes_wh [N,2] are the sizes boxes are resized to (default: no resize)."""
@@ -397,3 +429,5 @@ MaskRCNN.mark_step = _Y.mark_step
 MaskRCNN._u8_staging = _Y._u8_staging
 MaskRCNN._preprocess_u8 = _Y._preprocess_u8
 MaskRCNN.step_times = _Y.step_times
+for _n in ("rle_device", "coco_record_bytes", "pack_coco_records", "download_async", "download_fence", "download_wait", "memory"):
+    setattr(MaskRCNN, _n, getattr(_Y, _n))

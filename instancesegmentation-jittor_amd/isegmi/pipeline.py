@@ -1,0 +1,113 @@
+"""Step pipeline of the device-side COCO output: every step's detections leave the GPU as ONE fixed-size record block (boxes in
+original-image coordinates, scores, labels, pycocotools RLE strings; csrc/results.cpp) -- downloaded asynchronously into pinned memory
+(one rank) or all-gathered over RCCL (several ranks) -- while the next step already runs.  `submit()` hands back the records
+of the PREVIOUS step, so the host unpacks step t-1 while the GPU computes step t.  Used by isegmi.predictor.inference (Mask R-CNN,
+tools/test_net.py path, README.md:344-347), isegmi.yolact.evaluate (eval.py path, README.md:243-249) and bench.py's value_e2e.
+"""
+import numpy as np
+
+from . import _ffi
+from .dist import coco_record_layout, unpack_coco_records
+
+
+class RecordPipeline:
+    def __init__(self, net, batch, gather=None):
+        """net: Yolact / MaskRCNN wrapper; batch: images per step (fixed: the block size depends on it; a short last batch is padded by the
+        caller's bookkeeping, empty image slots simply carry count 0); gather: an isegmi.dist.RcclGather sized net.coco_record_bytes(batch)."""
+        self.net, self.batch, self.gather = net, int(batch), gather
+        self.kind = net.KIND
+        self.K = int(net.cfg.max_num_detections if self.kind == 1 else net.cfg.DETECTIONS_PER_IMG)
+        self.has_mscore = bool(self.kind == 1 and getattr(net, "has_maskiou", False))
+        self.nbytes, self.chars_off = net.coco_record_bytes(self.batch)
+        secs, coff, _ = coco_record_layout(self.batch, self.K, self.kind, self.has_mscore, 0)
+        assert coff == self.chars_off, (coff, self.chars_off)
+        self.cap_chars = self.nbytes - self.chars_off
+        if gather is None:
+            self.dev = [_ffi.DeviceBuffer((self.nbytes,), np.uint8) for _ in range(2)]
+            self.pin = [_ffi.PinnedBuffer((self.nbytes,), np.uint8) for _ in range(2)]
+        else:
+            assert gather.nbytes == self.nbytes, (gather.nbytes, self.nbytes)
+        self.step = 0
+        self.pending = []  # (slot, meta) of steps whose records have not been handed out yet
+
+    def _emit(self, slot):
+        if self.gather is None:
+            self.net.download_fence(slot)        # the slot's previous download has left the device buffer
+            self.net.pack_coco_records(self.dev[slot], self.batch)
+            self.net.download_async(slot, self.pin[slot], self.dev[slot], self.nbytes)
+        else:
+            self.gather.gather_coco_from(self.net, self.batch)
+
+    def _collect(self, slot):
+        """-> list over ranks of unpacked record dicts (one entry when there is no gather)."""
+        if self.gather is None:
+            self.net.download_wait(slot)
+            return [self._unpack(self.pin[slot].array)]
+        newest = (self.gather.step - 1) % self.gather.SLOTS
+        blocks = self.gather.fetch(previous=(slot != newest))
+        return [self._unpack(blocks[r]) for r in range(self.gather.world)]
+
+    def _unpack(self, buf):
+        r = unpack_coco_records(buf, self.batch, self.K, self.kind, self.has_mscore, self.cap_chars)
+        return {k: (v if isinstance(v, bytes) else np.array(v)) for k, v in r.items()}  # copies: the pinned slot is reused two steps later
+
+    def submit(self, meta=None):
+        """Call after net.rle_device() of the current step.  Returns (meta, [records per rank]) of the previous step, or None."""
+        slot = self.step % 2
+        out = None
+        if len(self.pending) == 2:  # the slot about to be reused still holds an unread step
+            out = self._pop()
+        self._emit(slot)
+        self.pending.append((slot, meta))
+        self.step += 1
+        if out is None and len(self.pending) == 2:
+            out = self._pop()
+        return out
+
+    def submit_empty(self, meta=None):
+        """A step without a batch on this rank (several ranks, image list not divisible): contributes an all-zero block to the all-gather."""
+        assert self.gather is not None, "only the multi-rank pipeline has collective steps"
+        slot = self.step % 2
+        self.gather.gather_empty()
+        self.pending.append((slot, meta))
+        self.step += 1
+        return self._pop() if len(self.pending) == 2 else None
+
+    def _pop(self):
+        slot, meta = self.pending.pop(0)
+        return meta, self._collect(slot)
+
+    def flush(self):
+        """Records of the steps still in flight, oldest first."""
+        out = []
+        while self.pending:
+            out.append(self._pop())
+        return out
+
+    def close(self):
+        if self.gather is None:
+            self.net.sync()
+            for b in self.dev + self.pin:
+                b.free()
+            self.dev, self.pin = [], []
+
+
+def schedule_batches(group_keys, batch_size):
+    """maskrcnn-benchmark's GroupedBatchSampler over a sequential sampler (the test loader, README.md:344-347): images with the same
+    group key form batches of `batch_size` in data-set order (the last batch of a group may be short), and the batches are then ordered
+    by their first image.  -> list of lists of image indices."""
+    groups = {}
+    for i, k in enumerate(group_keys):
+        groups.setdefault(k, []).append(i)
+    batches = [idx[j:j + batch_size] for idx in groups.values() for j in range(0, len(idx), batch_size)]
+    batches.sort(key=lambda b: b[0])
+    return batches
+
+
+def make_gather(net, batch, rank, world):
+    """The RCCL all-gather of a multi-rank run (None for one rank): unique id from rank 0 through the stdlib rendezvous of isegmi.dist."""
+    if world <= 1:
+        return None
+    from .dist import RcclGather, rendezvous_unique_id
+    uid = rendezvous_unique_id(rank, world, RcclGather.unique_id)
+    return RcclGather(rank, world, uid, net.coco_record_bytes(batch)[0])

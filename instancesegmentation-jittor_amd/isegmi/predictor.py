@@ -7,8 +7,6 @@
 compute_prediction / select_top_predictions follow the upstream demo ([UPSTREAM-RECALL], SURVEY 3.1);
 overlay drawing is plain numpy (cv2 is not in the image): mask tint + box outline, no text.
 """
-import collections
-
 import numpy as np
 
 from .coco import COCO_CLASSES
@@ -19,9 +17,8 @@ from .transforms import maskrcnn_resize_u8
 class COCODemo:
     CATEGORIES = ("__background",) + COCO_CLASSES
 
-    MAX_ENGINES = 4   # one engine per distinct padded input size (weights + activation buffers each): least recently used is closed
-
-    def __init__(self, cfg=None, min_image_size=800, confidence_threshold=0.5, state_dict=None, max_image_size=1333, device=0):
+    def __init__(self, cfg=None, min_image_size=800, confidence_threshold=0.5, state_dict=None, max_image_size=1333, device=0, max_batch=2,
+                 fp16=False):
         if cfg is not None and not isinstance(cfg, MaskRCNNConfig):   # the yacs-shaped node of isegmi.config (README.md:313-324)
             from .config import to_maskrcnn_config
             if state_dict is None and getattr(cfg.MODEL, "WEIGHT", ""):
@@ -37,28 +34,29 @@ class COCODemo:
                              "the reference's download URLs (README.md:266) cannot be fetched here")
         self.min_image_size, self.max_image_size = min_image_size, max_image_size
         self.confidence_threshold = confidence_threshold
-        self.state_dict, self.device = state_dict, device
-        self._models = collections.OrderedDict()
+        self.state_dict, self.device, self.max_batch, self.fp16 = state_dict, device, int(max_batch), bool(fp16)
+        self._model = None
 
-    def _model(self, H, W):
-        """Engine for the padded size (H, W).  Upstream pads a single image to the next multiple of 32 only, and the RPN sees the
-        padded area, so results depend on the exact canvas: one engine per canvas size, at most MAX_ENGINES alive (LRU)."""
-        key = (H, W)
-        if key in self._models:
-            self._models.move_to_end(key)
-            return self._models[key]
-        while len(self._models) >= self.MAX_ENGINES:
-            _, old = self._models.popitem(last=False)
-            old.close()
-        self._models[key] = MaskRCNN(self.state_dict, H, W, cfg=self.cfg, max_batch=1, device=self.device)
-        return self._models[key]
+    def engine(self, max_batch=None):
+        """THE engine of this predictor: weights packed once, every buffer sized once for the largest canvas the resize rule can produce
+        (long side max_image_size, either orientation, rounded up to SIZE_DIVISIBILITY).  Each batch then runs on its own padded canvas,
+        exactly as upstream's to_image_list pads it (results depend on the canvas: the RPN sees the padding)."""
+        want = int(max_batch or self.max_batch)
+        if self._model is not None and self._model.max_batch < want:
+            self._model.close()
+            self._model = None
+        if self._model is None:
+            d = self.cfg.SIZE_DIVISIBILITY
+            m = -(-max(self.max_image_size, self.min_image_size) // d) * d
+            self._model = MaskRCNN(self.state_dict, m, m, cfg=self.cfg, max_batch=want, device=self.device, fp16=self.fp16)
+            self.memory = self._model.reserve()  # (weight bytes, activation / workspace bytes): the predictor's peak device memory
+        return self._model
 
     def compute_prediction(self, original_image):
         """-> BoxList in ORIGINAL image coordinates with scores, labels and mask [n,1,H,W] uint8 (Masker output)."""
         h, w = original_image.shape[:2]
         resized = maskrcnn_resize_u8(original_image, self.min_image_size, self.max_image_size)
-        d = self.cfg.SIZE_DIVISIBILITY
-        model = self._model(-(-resized.shape[0] // d) * d, -(-resized.shape[1] // d) * d)
+        model = self.engine()
         (pred,) = model([resized])  # device front end: the bytes cross PCIe, mean subtraction + padding (to_image_list) run on the GPU
         model.paste_device(h, w, [(w, h)])
         model.sync()
@@ -101,18 +99,103 @@ class COCODemo:
         return image
 
     def close(self):
-        for m in self._models.values():
-            m.close()
-        self._models = collections.OrderedDict()
+        if self._model is not None:
+            self._model.close()
+            self._model = None
 
 
-def inference(predictor, images, image_ids=None):
-    """engine/inference.py-shaped evaluation loop: images (HxWx3 uint8 BGR) -> COCO-format result list
-    (bbox + segm) ready for json.dump (README.md:344-347)."""
-    from .coco import maskrcnn_results
-    results = []
-    for i, im in enumerate(images):
-        p = predictor.compute_prediction(im)
-        iid = image_ids[i] if image_ids is not None else i
-        results += maskrcnn_results(iid, p.bbox, p.get_field("scores"), p.get_field("labels"), p.get_field("mask")[:, 0])
-    return results
+def inference(predictor, images, image_ids=None, batch_size=None, group="canvas", rank=0, world=1, sizes=None, stats=None):
+    """engine/inference.py-shaped evaluation (README.md:344-347): images -> COCO-format result list (bbox + segm) ready for json.dump.
+
+    The path the benchmark measures, end to end: batches of `batch_size` resized uint8 images go up through pinned memory (double-buffered),
+    mean subtraction / padding, the forward, Masker paste at every image's ORIGINAL size, pycocotools RLE and the packing of one fixed-size
+    record block all run on the device; the block comes back asynchronously (one rank) or is all-gathered over RCCL (`world` ranks: the
+    batches of the global schedule go round-robin to the ranks) while the next batch computes.  Every rank returns the complete
+    list, ordered by image, detections in the engine's output order.
+
+    images: sequence of HxWx3 uint8 BGR arrays, or a callable i -> array together with sizes = [(h, w), ...] (lazy loading).
+    group:  "canvas" -- batch only images whose padded network canvas is identical, so every image's result equals its single-image
+            result (to_image_list pads a batch to its largest member and the RPN sees the padding); "aspect" -- upstream's
+            ASPECT_RATIO_GROUPING (portrait / landscape), results then depend on the batch composition exactly as upstream's do.
+    stats:  optional dict, receives steps / images / seconds of the device loop."""
+    import time
+    from .coco import results_from_records
+    from .pipeline import RecordPipeline, make_gather, schedule_batches
+    from .transforms import get_size
+    from .maskrcnn import padded_canvas
+    from . import _ffi
+    get = images if callable(images) else images.__getitem__
+    if sizes is None:
+        if callable(images):
+            raise ValueError("inference(): a callable image source needs sizes=[(h, w), ...]")
+        sizes = [im.shape[:2] for im in images]
+    n_img = len(sizes)
+    ids = list(image_ids) if image_ids is not None else list(range(n_img))
+    bs = int(batch_size or predictor.max_batch)
+    model = predictor.engine(bs)
+    cfg = predictor.cfg
+    rs = [get_size(w, h, predictor.min_image_size, predictor.max_image_size) for h, w in sizes]   # resized (h, w) per image
+    if group == "canvas":
+        keys = [padded_canvas([r], cfg.SIZE_DIVISIBILITY) for r in rs]
+    elif group == "aspect":
+        keys = [int(h >= w) for h, w in sizes]
+    else:
+        raise ValueError("group: 'canvas' or 'aspect'")
+    batches = schedule_batches(keys, bs)
+    gather = make_gather(model, bs, rank, world)
+    pipe = RecordPipeline(model, bs, gather)
+    pin = [_ffi.PinnedBuffer((bs * model.H * model.W * 3,), np.uint8) for _ in range(2)]
+    per_image = [None] * n_img
+
+    def consume(done):
+        if done is None:
+            return
+        step, recs = done
+        for r, rec in enumerate(recs):       # rank r ran batch step * world + r of the global schedule
+            j = step * world + r
+            if j >= len(batches):
+                continue
+            b = batches[j]
+            slot_ids = [ids[i] for i in b] + [None] * (bs - len(b))
+            slot_hw = [sizes[i] for i in b] + [(1, 1)] * (bs - len(b))
+            res = results_from_records(rec, slot_ids, slot_hw, 2, pipe.K)
+            by_id = {}
+            for d in res:
+                by_id.setdefault(d["image_id"], []).append(d)
+            for i in b:
+                per_image[i] = by_id.get(ids[i], [])
+
+    t0 = time.perf_counter()
+    nsteps = -(-len(batches) // world)
+    for step in range(nsteps):
+        j = step * world + rank
+        if j >= len(batches):
+            consume(pipe.submit_empty(step))
+            continue
+        b = batches[j]
+        slot = step & 1
+        off, hw = 0, []
+        for i in b:                          # host: PIL resize (image decode / resize is outside the hot path, SURVEY 8d) into pinned memory
+            im = maskrcnn_resize_u8(get(i), predictor.min_image_size, predictor.max_image_size)
+            pin[slot].array[off:off + im.size] = im.reshape(-1)
+            off += im.size
+            hw.append(im.shape[:2])
+        model.upload_u8_async(pin[slot], hw, slot)
+        model.forward_device(len(b), slot)
+        oh = [sizes[i] for i in b]
+        model.paste_device(max(h for h, _ in oh), max(w for _, w in oh), [(w, h) for h, w in oh])
+        model.rle_device(oh)
+        consume(pipe.submit(step))
+    for done in pipe.flush():
+        consume(done)
+    model.sync()
+    if stats is not None:
+        stats.update(steps=nsteps, images=n_img, seconds=time.perf_counter() - t0, batches=len(batches), batch_size=bs, world=world)
+    pipe.close()
+    for p in pin:
+        p.free()
+    if gather is not None:
+        from .dist import rendezvous_cleanup
+        gather.close()
+        rendezvous_cleanup(rank, world)
+    return [d for r in per_image if r for d in r]

@@ -285,28 +285,50 @@ class Yolact:
         return ((0.0, 0.0, 0.0), (255.0, 255.0, 255.0)) if darknet else (MEANS, STD)
 
     def upload_u8(self, images_bgr_u8, slot=0):
-        """FastBaseTransform on the device (Y1): [N, H, W, 3] uint8 BGR images of one size -> bilinear resize to the network size, the
-        backbone's normalisation, RGB -- bit-identical to isegmi.transforms.yolact_transform on the host, a quarter of the PCIe bytes
-        (and none of the host's resize arithmetic).  The previous forward on this input slot must have completed, as for upload()."""
-        x = np.ascontiguousarray(images_bgr_u8)
-        if x.dtype != np.uint8:
-            raise TypeError("upload_u8 takes uint8 images (got %s): a float batch is the already-transformed input of upload()" % x.dtype)
-        assert x.ndim == 4 and x.shape[3] == 3 and x.shape[0] <= self.max_batch, x.shape
-        n, h, w = x.shape[:3]
-        st = self._u8_staging(slot, x.nbytes)
-        _ffi.check(_ffi.lib().isegmi_h2d(st.ptr, x.ctypes.data_as(C.c_void_p), C.c_int64(x.nbytes)))
-        mean, std = self._u8_norm()
-        self._preprocess_u8(st.ptr.value, n, h, w, self.input_buffer(slot).ptr.value, self.size, self.size, self.size, self.size, mean, std, True)
-        return n
+        """FastBaseTransform on the device (Y1): uint8 BGR images -- an [N, H, W, 3] array or a list of HxWx3 arrays of DIFFERENT sizes --
+        -> bilinear resize to the network size, the backbone's normalisation, RGB: bit-identical to isegmi.transforms.yolact_transform
+        on the host, a quarter of the PCIe bytes (and none of the host's resize arithmetic).  The previous forward on this input slot
+        must have completed, as for upload()."""
+        ims = self._as_u8_list(images_bgr_u8)
+        flat = ims[0].reshape(-1) if len(ims) == 1 else np.concatenate([im.reshape(-1) for im in ims])
+        st = self._u8_staging(slot, flat.nbytes)
+        _ffi.check(_ffi.lib().isegmi_h2d(st.ptr, flat.ctypes.data_as(C.c_void_p), C.c_int64(flat.nbytes)))
+        self._front_end(st, [im.shape[:2] for im in ims], slot)
+        return len(ims)
 
-    def upload_u8_async(self, pinned_u8, n, h, w, slot=0):
-        """upload_u8 from a uint8 _ffi.PinnedBuffer on the engine's copy stream (see upload_async for the ordering)."""
-        nbytes = n * h * w * 3
-        assert pinned_u8.nbytes >= nbytes and n <= self.max_batch
+    def _as_u8_list(self, images):
+        if isinstance(images, np.ndarray) and images.ndim == 4:
+            images = [images[i] for i in range(images.shape[0])] if images.shape[0] != 1 else [images[0]]
+        ims = [np.ascontiguousarray(im) for im in images]
+        if any(im.dtype != np.uint8 or im.ndim != 3 or im.shape[2] != 3 for im in ims):
+            raise TypeError("upload_u8 takes HxWx3 uint8 images: a float batch is the already-transformed input of upload()")
+        assert 0 < len(ims) <= self.max_batch, len(ims)
+        return ims
+
+    def _front_end(self, st, sizes_hw, slot):
+        """image i of the staging buffer (back to back, each h x w x 3) -> plane i of the network input; equal sizes go as one launch"""
+        mean, std = self._u8_norm()
+        d_out = self.input_buffer(slot).ptr.value
+        plane = self.size * self.size * 3 * 4
+        sizes = [(int(h), int(w)) for h, w in sizes_hw]
+        if len(set(sizes)) == 1:
+            h, w = sizes[0]
+            self._preprocess_u8(st.ptr.value, len(sizes), h, w, d_out, self.size, self.size, self.size, self.size, mean, std, True)
+            return
+        off = 0
+        for i, (h, w) in enumerate(sizes):
+            self._preprocess_u8(st.ptr.value + off, 1, h, w, d_out + i * plane, self.size, self.size, self.size, self.size, mean, std, True)
+            off += h * w * 3
+
+    def upload_u8_async(self, pinned_u8, n, h=None, w=None, slot=0, sizes_hw=None):
+        """upload_u8 from a uint8 _ffi.PinnedBuffer holding the images back to back, on the engine's copy stream (see upload_async for
+        the ordering): n images of one size (h, w), or sizes_hw = [(h, w), ...] per image."""
+        sizes = [(int(h), int(w))] * n if sizes_hw is None else [(int(a), int(b)) for a, b in sizes_hw]
+        nbytes = sum(a * b * 3 for a, b in sizes)
+        assert pinned_u8.nbytes >= nbytes and len(sizes) <= self.max_batch
         st = self._u8_staging(slot, nbytes)
         _ffi.check(_ffi.lib().isegmi_engine_upload_async(self._h, st.ptr, pinned_u8.ptr, C.c_int64(nbytes)))
-        mean, std = self._u8_norm()
-        self._preprocess_u8(st.ptr.value, n, h, w, self.input_buffer(slot).ptr.value, self.size, self.size, self.size, self.size, mean, std, True)
+        self._front_end(st, sizes, slot)
 
     def mark_step(self):
         _ffi.check(_ffi.lib().isegmi_engine_mark_step(self._h))
@@ -326,8 +348,47 @@ class Yolact:
     def postprocess_device(self, h, w):
         _ffi.check(_ffi.lib().isegmi_yolact_postprocess(self._h, h, w))
 
+    def postprocess_device_sizes(self, image_hw):
+        """postprocess with image n assembled at ITS (h, w) = image_hw[n] inside a common plane of the batch's maximum size."""
+        hw = np.ascontiguousarray(image_hw, np.int32).reshape(-1, 2)
+        _ffi.check(_ffi.lib().isegmi_yolact_postprocess_sizes(self._h, hw.ctypes.data_as(C.c_void_p), hw.shape[0]))
+
     def sync(self):
         _ffi.check(_ffi.lib().isegmi_engine_sync(self._h))
+
+    # -- device-side COCO output (shared with MaskRCNN): RLE of the masks, one fixed-size record block per batch ---------------------
+    def rle_device(self, image_hw=None):
+        """pycocotools RLE (counts + compressed strings) of det.masks of the last postprocess / paste, on the results stream; image_hw
+        [n, 2] = every image's own (h, w) inside the mask planes (None: the whole plane)."""
+        hw = None if image_hw is None else np.ascontiguousarray(image_hw, np.int32).reshape(-1, 2)
+        _ffi.check(_ffi.lib().isegmi_engine_rle(self._h, None if hw is None else hw.ctypes.data_as(C.c_void_p)))
+
+    def coco_record_bytes(self, n):
+        """(total bytes, offset of the strings) of the record block of a batch of n images (isegmi_engine_pack_coco_records)."""
+        nb, co = C.c_int64(), C.c_int64()
+        _ffi.check(_ffi.lib().isegmi_engine_coco_record_bytes(self._h, n, C.byref(nb), C.byref(co)))
+        return nb.value, co.value
+
+    def pack_coco_records(self, dev_buffer, n_block):
+        nb = C.c_int64()
+        _ffi.check(_ffi.lib().isegmi_engine_pack_coco_records(self._h, dev_buffer.ptr, C.c_int64(dev_buffer.nbytes), int(n_block), C.byref(nb)))
+        return nb.value
+
+    def download_async(self, slot, pinned, dev_buffer, nbytes):
+        _ffi.check(_ffi.lib().isegmi_engine_download_async(self._h, slot, pinned.ptr, dev_buffer.ptr, C.c_int64(nbytes)))
+
+    def download_fence(self, slot):
+        _ffi.check(_ffi.lib().isegmi_engine_download_fence(self._h, slot))
+
+    def download_wait(self, slot):
+        _ffi.check(_ffi.lib().isegmi_engine_download_wait(self._h, slot))
+
+    def memory(self):
+        """(weight_bytes, buffer_bytes) of device memory held by the engine (+ the input slots owned by this wrapper)."""
+        wb, bb = C.c_int64(), C.c_int64()
+        _ffi.check(_ffi.lib().isegmi_engine_memory(self._h, C.byref(wb), C.byref(bb)))
+        extra = self._d_in.nbytes + (self._d_in2.nbytes if getattr(self, "_d_in2", None) is not None else 0)
+        return wb.value, bb.value + extra
 
     def fetch(self, name, rows=None):
         """D2H copy of a named engine buffer (optionally only its first `rows` leading rows)."""
@@ -352,7 +413,7 @@ class Yolact:
         """Upstream-shaped result: list (one per image) of {'detection': {...}|None, 'net': self}.  A uint8 [N, H, W, 3] batch is taken as
         raw BGR images of any one size and goes through the device front end (upload_u8: FastBaseTransform on the GPU); a float batch is
         the already-transformed network input."""
-        raw = np.asarray(batch_nhwc3).dtype == np.uint8
+        raw = isinstance(batch_nhwc3, (list, tuple)) or np.asarray(batch_nhwc3).dtype == np.uint8
         n = self.upload_u8(batch_nhwc3) if raw else self.upload(batch_nhwc3)
         self.forward_device(n)
         self.sync()
@@ -409,3 +470,82 @@ def postprocess(det_output, w, h, batch_idx=0, score_threshold=0.0):
     if net.has_maskiou:  # upstream (rescore_mask, not rescore_bbox): scores = [box scores, box scores * mask IoU]
         scores = [scores, net._pp_mask_scores[i, :c][keep]]
     return d["class"][keep], scores, net._pp_boxes[i, :c][keep], net._pp_masks[i, :c][keep]
+
+
+def evaluate(net, images, image_ids=None, batch_size=None, score_threshold=0.0, top_k=None, rank=0, world=1, sizes=None, stats=None):
+    """eval.py's image evaluation as a data-set loop (README.md:243-249: --images / --output_coco_json): images -> COCO-format result list
+    (Detections.add_bbox / add_mask records) -- the path the benchmark measures, end to end.  Batches of `batch_size` raw uint8 BGR
+    images (any sizes) go up through pinned memory; FastBaseTransform, the forward, Detect, postprocess at every image's OWN size,
+    pycocotools RLE and the packing of one fixed-size record block run on the device; the block comes back asynchronously (one rank) or
+    is all-gathered over RCCL (`world` ranks, batches round-robin) while the next batch computes.
+
+    images: sequence of HxWx3 uint8 BGR arrays, or a callable i -> array together with sizes = [(h, w), ...]."""
+    import time
+    from .coco import results_from_records
+    from .pipeline import RecordPipeline, make_gather
+    get = images if callable(images) else images.__getitem__
+    if sizes is None:
+        if callable(images):
+            raise ValueError("evaluate(): a callable image source needs sizes=[(h, w), ...]")
+        sizes = [im.shape[:2] for im in images]
+    n_img = len(sizes)
+    ids = list(image_ids) if image_ids is not None else list(range(n_img))
+    bs = int(batch_size or net.max_batch)
+    assert bs <= net.max_batch
+    batches = [list(range(j, min(j + bs, n_img))) for j in range(0, n_img, bs)]
+    gather = make_gather(net, bs, rank, world)
+    pipe = RecordPipeline(net, bs, gather)
+    pin_bytes = max(sum(sizes[i][0] * sizes[i][1] * 3 for i in b) for b in batches) if batches else 1
+    pin = [_ffi.PinnedBuffer((pin_bytes,), np.uint8) for _ in range(2)]
+    per_image = [None] * n_img
+
+    def consume(done):
+        if done is None:
+            return
+        step, recs = done
+        for r, rec in enumerate(recs):
+            j = step * world + r
+            if j >= len(batches):
+                continue
+            b = batches[j]
+            res = results_from_records(rec, [ids[i] for i in b] + [None] * (bs - len(b)), [sizes[i] for i in b] + [(1, 1)] * (bs - len(b)), 1,
+                                       pipe.K, score_threshold, top_k)
+            by_id = {}
+            for d in res:
+                by_id.setdefault(d["image_id"], []).append(d)
+            for i in b:
+                per_image[i] = by_id.get(ids[i], [])
+
+    t0 = time.perf_counter()
+    nsteps = -(-len(batches) // world)
+    for step in range(nsteps):
+        j = step * world + rank
+        if j >= len(batches):
+            consume(pipe.submit_empty(step))
+            continue
+        b = batches[j]
+        slot = step & 1
+        off = 0
+        for i in b:
+            im = np.ascontiguousarray(get(i), np.uint8)
+            pin[slot].array[off:off + im.size] = im.reshape(-1)
+            off += im.size
+        hw = [sizes[i] for i in b]
+        net.upload_u8_async(pin[slot], len(b), slot=slot, sizes_hw=hw)
+        net.forward_device(len(b), slot)
+        net.postprocess_device_sizes(hw)
+        net.rle_device(hw)
+        consume(pipe.submit(step))
+    for done in pipe.flush():
+        consume(done)
+    net.sync()
+    if stats is not None:
+        stats.update(steps=nsteps, images=n_img, seconds=time.perf_counter() - t0, batches=len(batches), batch_size=bs, world=world)
+    pipe.close()
+    for p in pin:
+        p.free()
+    if gather is not None:
+        from .dist import rendezvous_cleanup
+        gather.close()
+        rendezvous_cleanup(rank, world)
+    return [d for r in per_image if r for d in r]

@@ -261,3 +261,22 @@ def yolact_masks(proto, coeffs, boxes, h, w):
     ob = np.empty((n, 4), np.int64)
     lib().ora_yolact_masks(_p(proto), I(PH), I(PW), I(K), _p(coeffs), _p(boxes), I(n), I(h), I(w), _p(out), _p(ob))
     return out, ob
+
+
+def rle_encode(mask):
+    """pycocotools rleEncode restated (ora_rle_encode): HxW binary mask -> column-major run lengths, zeros first (np.uint32)."""
+    m = np.ascontiguousarray(mask).astype(np.uint8)
+    h, w = m.shape
+    out = np.empty(h * w + 1, np.uint32)
+    lib().ora_rle_encode.restype = L
+    k = lib().ora_rle_encode(_p(m), I(h), I(w), I(w), _p(out))
+    return out[:k].copy()
+
+
+def rle_to_string(counts):
+    """pycocotools rleToString restated (ora_rle_to_string) -> str."""
+    c = np.ascontiguousarray(counts, np.uint32)
+    buf = C.create_string_buffer(7 * c.size + 1)
+    lib().ora_rle_to_string.restype = L
+    n = lib().ora_rle_to_string(_p(c), L(c.size), buf)
+    return buf.raw[:n].decode("ascii")

@@ -875,4 +875,46 @@ ORA_API void ora_yolact_proto_masks(const float* proto, int PH, int PW, int K, c
     }
 }
 
+/* ---- COCO mask run-length encoding (the on-disk format behind inference() / tools/test_net.py, README.md:344-347, and Yolact eval.py's
+ * Detections.add_mask / dump, README.md:243-249).  The algorithm lives in a third-party dependency that is absent from /root/reference and
+ * from this image: pycocotools (cocoapi, common/maskApi.c), un-pinned by the reference (its README installs no specific version).  Restated
+ * from the published maskApi.c: rleEncode walks the mask in COLUMN-major order and emits run lengths starting with the run of zeros (so a
+ * mask whose first pixel is set starts with a 0 count); rleToString writes every count -- from the fourth on as the difference to the count
+ * two runs back -- as little-endian groups of 5 bits, bit 5 = "more groups follow", + 48.  PARITY UNPINNED like the rest of the oracle; pinned
+ * by the hand-computed cases of tests/test_coco_cpu.py and tests/test_oracle_cpu.py. */
+/* mask: h x w row-major uint8 (non-zero = set), row pitch `pitch`; counts: capacity h*w + 1.  Returns the number of counts. */
+ORA_API int64_t ora_rle_encode(const uint8_t* mask, int h, int w, int pitch, uint32_t* counts) {
+    int64_t k = 0;
+    uint32_t c = 0;
+    int p = 0;
+    for (int x = 0; x < w; ++x)
+        for (int y = 0; y < h; ++y) {
+            const int v = mask[(size_t)y * pitch + x] != 0;
+            if (v != p) { counts[k++] = c; c = 0; p = v; }
+            ++c;
+        }
+    counts[k++] = c;
+    return k;
+}
+
+/* s: capacity 7 * m + 1 (a count below 2^32 and its difference need at most 7 groups).  Returns the string length (no terminator counted). */
+ORA_API int64_t ora_rle_to_string(const uint32_t* counts, int64_t m, char* s) {
+    int64_t p = 0;
+    for (int64_t i = 0; i < m; ++i) {
+        long long x = (long long)counts[i];
+        if (i > 2) x -= (long long)counts[i - 2];
+        int more = 1;
+        while (more) {
+            char c = (char)(x & 0x1f);
+            x >>= 5;
+            more = (c & 0x10) ? x != -1 : x != 0;
+            if (more) c |= 0x20;
+            c += 48;
+            s[p++] = c;
+        }
+    }
+    s[p] = 0;
+    return p;
+}
+
 ORA_API int ora_version(void) { return 1; }

@@ -109,6 +109,8 @@ def _dry_load_maskrcnn(sd, cfg, H=64, W=96):
     m.convs, m.tensors = {}, {}
     m._set_conv_krsc = lambda name, w, scale=None, shift=None: m.convs.__setitem__(name, np.asarray(w).shape)
     m._set_tensor = lambda name, a: m.tensors.__setitem__(name, np.asarray(a).shape)
+    m.params = {}
+    m.set_param = lambda name, value: m.params.__setitem__(name, value)
     t = _Tracking(sd)
     (m._load_c4 if cfg.is_c4 else m._load)(t)
     return m, t
@@ -172,7 +174,7 @@ def test_importer_takes_complete_maskrcnn_checkpoints(tmp_path, family, depth):
     assert set(out) == set(sd) and all(np.array_equal(out[k], sd[k]) for k in sd)
     m, t = _dry_load_maskrcnn(out, MaskRCNNConfig(depth=depth))
     assert t.read == set(out), sorted(set(out) - t.read)[:5]          # the loader consumed every tensor of the checkpoint
-    assert "backbone.body.layer3.%d.conv3" % (22 if depth == 101 else 5) in m.convs and "anchors.4" in m.tensors
+    assert "backbone.body.layer3.%d.conv3" % (22 if depth == 101 else 5) in m.convs and "anchor_base.4" in m.tensors
     # (b) Detectron / Caffe2 pkl naming ({"blobs": {...}} with momentum blobs and the per-level copies of the shared RPN head)
     blobs = {}
     for k, v in sd.items():

@@ -29,10 +29,24 @@ for it in range(rounds):
     act = int(rng.integers(0, 5))
     if act == 4 and res is None: act = 3
     ref = ora.conv2d(x, w, stride, pad, sc, sh, res, act)
-    for tile in (0, 3, 4, 5, 6, 10, 12):
+    for tile in (0, 3, 4, 5, 6, 10, 12, 13, 14):
         got = ffi.conv2d(x, w, stride, pad, sc, sh, res, act, tile)
         if not np.array_equal(got, ref): fail(("conv", it, tile, x.shape, w.shape, stride, pad, act))
 print("conv ok", rounds)
+
+# ---- conv, grids large enough (> 512 64x64 tiles with a ragged remainder) for the hybrid launch (tiles 13 / 14, and the auto rule) to split
+for it in range(max(rounds // 8, 3)):
+    N = int(rng.integers(1, 3)); H = int(rng.integers(120, 200)); W = int(rng.integers(120, 200))
+    Cin = 32 * int(rng.integers(1, 3)); Cout = int(rng.choice([64, 65, 96, 128])); R = int(rng.choice([1, 3])); stride = 1; pad = R // 2
+    x = rng.standard_normal((N, H, W, Cin)).astype(np.float32); w = (rng.standard_normal((Cout, R, R, Cin)) * 0.1).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, Cout).astype(np.float32); sh = rng.standard_normal(Cout).astype(np.float32)
+    res = rng.standard_normal((N, H, W, Cout)).astype(np.float32) if rng.uniform() < 0.5 else None
+    act = int(rng.integers(0, 2))
+    ref = ora.conv2d(x, w, stride, pad, sc, sh, res, act)
+    for tile in (0, 13, 14):
+        got = ffi.conv2d(x, w, stride, pad, sc, sh, res, act, tile)
+        if not np.array_equal(got, ref): fail(("conv-hybrid", it, tile, x.shape, w.shape, act))
+print("conv hybrid ok")
 
 # ---- RPN level: chip-wide vs single-block vs oracle
 for it in range(rounds):
