@@ -6,7 +6,11 @@
   (`python -m torch.distributed.run --nproc-per-node N bench.py ...`, before any HIP call), relays rank 0's JSON line and
   exits with the children's code.  N > 1 inside such an environment (RANK/WORLD_SIZE set): one rank per GPU.
 
-A "step" = one pass of the hot path over one batch of synthetic input that is already resident in HBM.
+A "step" = one pass of the hot path over one batch of synthetic input, as SURVEY.md 8(d) defines the metric: the H2D of the input is
+INSIDE the step (the uint8 images go up through pinned memory on a copy stream, double-buffered; FastBaseTransform / build_transform +
+to_image_list run on the device), image decode / resize is outside.  `value_resident` repeats the K steps with the batch already in HBM,
+`value_e2e` with everything a user of inference() / evaluate() gets: uint8 upload -> forward -> masks -> RLE on the device -> one
+record block per step back in pinned host memory (N = 1) or all-gathered over RCCL (N > 1).
 Default workload = BASELINE.json configs[1]: Yolact R50-FPN 550x550, bs=8 per GPU: backbone -> FPN -> protonet +
 prediction heads -> Detect (softmax, decode, fast-NMS) -> postprocess (mask assembly at 550x550, uint8)
 [-> RCCL all-gather of detection records when N>1].  At N=1 the default run ALSO measures BASELINE configs[2] /
@@ -34,12 +38,12 @@ import numpy as np  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32-input MFMA peak (spec)
 PEAK_F16_MFMA_TFLOPS = 2500.0  # dense f16 MFMA peak (spec, no sparsity)
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
 
 
 def pmc_traffic(name):
     """HBM bytes per conv launch from the committed PMC summary (tools/pmc_summary.py), or None."""
-    for rnd in (PROFILE_ROUND, "r01"):
+    for rnd in (PROFILE_ROUND, "r02", "r01"):
         try:
             with open(os.path.join(ROOT, "profiles", "%s_%s" % (rnd, name))) as f:
                 return json.load(f)["conv_mfma_kernel_all"]["hbm_bytes_per_launch"], "%s_%s" % (rnd, name)
@@ -51,8 +55,9 @@ def pmc_traffic(name):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--spawn-timeout", type=float, default=900.0, help="--gpus N > 1 started from a plain shell: seconds before the child ranks are killed")
     ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (default 8 yolact, 2 maskrcnn)")
     ap.add_argument("--model", default="yolact", choices=["yolact", "maskrcnn"])
     ap.add_argument("--depth", type=int, default=50, choices=[50, 101], help="maskrcnn: ResNet depth")
@@ -64,7 +69,8 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=8, help="images the CPU oracle is timed on")
     ap.add_argument("--no-latency", action="store_true", help="skip the extra bs=1 latency pass")
     ap.add_argument("--no-maskrcnn", action="store_true", help="default yolact run: skip the extra Mask R-CNN R50-FPN measurement")
-    ap.add_argument("--no-h2d", action="store_true", help="skip the extra timed loop that includes the pinned-host H2D of every batch")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the extra timed loops (batch resident in HBM; fp32 upload)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end loop (uint8 upload -> ... -> RLE -> record block on the host)")
     ap.add_argument("--single-stream", action="store_true", help="profiling aid: run the timed region on one stream too, so that "
                     "rocprofv3 per-kernel durations are not inflated by overlapping launches (throughput drops ~20 %%)")
     return ap.parse_args()
@@ -89,11 +95,24 @@ def spawn_ranks(a):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
-    lines = [ln for ln in r.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
-    if r.returncode != 0 or not lines:
-        sys.stderr.write("bench.py: the %d-rank run failed (rc %d)\n" % (a.gpus, r.returncode))
-        raise SystemExit(r.returncode or 1)
+    # fresh child processes in their own process group; a rank that dies before the first all-gather leaves the others blocked in RCCL,
+    # so the whole group is killed at the time limit and the failure is reported instead of waiting for the caller's own limit
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, start_new_session=True)
+    try:
+        out, _ = proc.communicate(timeout=a.spawn_timeout)
+    except subprocess.TimeoutExpired:
+        import signal
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        except OSError:
+            pass
+        proc.wait()
+        sys.stderr.write("bench.py: the %d-rank run did not finish within %.0f s; its process group was killed\n" % (a.gpus, a.spawn_timeout))
+        raise SystemExit(124)
+    lines = [ln for ln in out.decode(errors="replace").splitlines() if ln.startswith("{")]
+    if proc.returncode != 0 or not lines:
+        sys.stderr.write("bench.py: the %d-rank run failed (rc %d)\n" % (a.gpus, proc.returncode))
+        raise SystemExit(proc.returncode or 1)
     sys.stdout.write(lines[-1] + "\n")
     sys.stdout.flush()
     raise SystemExit(0)
@@ -198,18 +217,24 @@ def roofline_pass(net, step, full_sync, steps, single_stream):
     return f.value, m.value, l.value
 
 
-def h2d_region(upload, run, full_sync, dist, steps):
-    """The timed region once more with a pinned-host asynchronous H2D of every batch inside the step: `upload(slot)` sends batch i+1
-    to the other input buffer on the copy stream while batch i computes."""
+def e2e_region(net, pipe, upload, run_rle, full_sync, dist, steps):
+    """K steps of the product path: uint8 upload (pinned, copy stream) -> forward -> masks -> RLE -> record block -> pinned host memory
+    (or RCCL all-gather), the host collecting step i-1's block while step i runs (isegmi.pipeline.RecordPipeline).  Returns
+    (elapsed, number of record blocks collected, total RLE characters, host seconds spent unpacking)."""
     upload(0)
     dist.barrier(); full_sync()
+    blocks = chars = 0
     t0 = time.perf_counter()
     for i in range(steps):
-        if i + 1 < steps:
-            upload((i + 1) & 1)
-        run(i & 1)
+        upload((i + 1) & 1)
+        run_rle(i & 1)
+        done = pipe.submit(i)
+        if done is not None:
+            blocks += 1; chars += sum(len(r["chars"]) for r in done[1])
+    for done in pipe.flush():
+        blocks += 1; chars += sum(len(r["chars"]) for r in done[1])
     full_sync(); dist.barrier()
-    return dist.max(time.perf_counter() - t0)
+    return dist.max(time.perf_counter() - t0), blocks, chars
 
 
 def latency_pass(net, run1, iters=13, drop=3):
@@ -264,6 +289,8 @@ def bench_yolact(a, dist):
         imgs = fast_base_transform(raw)
     net.upload(imgs)
     gather = dist.make_gather(record_bytes(a.batch))
+    pin8 = _ffi.PinnedBuffer(raw_u8.shape, np.uint8)
+    pin8.array[...] = raw_u8
 
     def run(slot=0):
         net.forward_device(a.batch, slot)
@@ -271,7 +298,14 @@ def bench_yolact(a, dist):
         if gather is not None:
             gather.gather_from(net)
 
-    def step(i):
+    def upload_u8(slot):  # what cv2.imread hands FastBaseTransform: the uint8 images cross PCIe, the transform runs on the device
+        net.upload_u8_async(pin8, a.batch, size, size, slot)
+
+    def step(i):          # H2D of the input inside the step; batch i+1 goes up on the copy stream while batch i computes
+        upload_u8((i + 1) & 1)
+        run(i & 1)
+
+    def step_resident(i):
         run(0)
 
     def full_sync():
@@ -280,31 +314,66 @@ def bench_yolact(a, dist):
             gather.wait()
         _ffi.sync()
 
-    for _ in range(max(a.warmup, 1 if gather is not None else 0)):
-        run()
+    upload_u8(0)
+    for i in range(max(a.warmup, 1 if gather is not None else 0)):
+        step(i)
     full_sync()
+    upload_u8(0)
     elapsed, step_ms = timed_region(net, step, full_sync, dist, a.steps)
-    conv_flops, conv_ms, conv_launches = roofline_pass(net, step, full_sync, a.steps, a.single_stream)
-    # what the GPU produced for the bench batch (compared with the oracle below, before anything else runs a forward)
+    # what the GPU produced for the bench batch through the timed path (device front end + forward + postprocess); compared with the oracle below
+    net.upload(imgs)
+    conv_flops, conv_ms, conv_launches = roofline_pass(net, step_resident, full_sync, a.steps, a.single_stream)
     gpu = {k: net.fetch(k, a.batch) for k in ("det.count", "det.prior", "det.class", "det.score", "det.box", "det.coeff", "det.masks", "det.box_int")}
     rccl = None
     if gather is not None:
         from isegmi.dist import unpack_records
         blocks = gather.fetch()
         rccl = {"rccl_ranks": int(gather.world), "ranks_with_records": int(sum(1 for r in range(world) if unpack_records(blocks[r], a.batch)["count"].any()))}
-    h2d_elapsed = h2d_u8_elapsed = None
+    resident_elapsed = h2d_elapsed = e2e = None
     if not a.no_h2d:
+        resident_elapsed, _ = timed_region(net, step_resident, full_sync, dist, a.steps)
         pinned = _ffi.PinnedBuffer(imgs.shape)
         pinned.array[...] = imgs
-        h2d_elapsed = h2d_region(lambda slot: net.upload_async(pinned, slot), run, full_sync, dist, a.steps)
-        pinned.free()
-        # the same with the device front end: the uint8 images cross PCIe (a quarter of the bytes), FastBaseTransform runs on the engine's stream
-        pin8 = _ffi.PinnedBuffer(raw_u8.shape, np.uint8)
-        pin8.array[...] = raw_u8
-        h2d_u8_elapsed = h2d_region(lambda slot: net.upload_u8_async(pin8, a.batch, size, size, slot), run, full_sync, dist, a.steps)
-        net.upload(imgs)
+
+        def step_f32(i):
+            net.upload_async(pinned, (i + 1) & 1)
+            run(i & 1)
+        net.upload_async(pinned, 0)
+        h2d_elapsed, _ = timed_region(net, step_f32, full_sync, dist, a.steps)
         full_sync()
-        pin8.free()
+        pinned.free()
+    if not a.no_e2e:
+        from isegmi.pipeline import RecordPipeline
+        cgather = dist.make_gather(net.coco_record_bytes(a.batch)[0]) if gather is not None else None
+        pipe = RecordPipeline(net, a.batch, cgather)
+        hw8 = [(size, size)] * a.batch
+
+        def run_rle(slot):
+            net.forward_device(a.batch, slot)
+            net.postprocess_device(size, size)
+            net.rle_device()
+        e2e_sync = (lambda: (full_sync(), cgather.wait())) if cgather is not None else full_sync
+        e2e_region(net, pipe, upload_u8, run_rle, e2e_sync, dist, max(2, a.warmup // 2))
+        e2e_elapsed, blocks, chars = e2e_region(net, pipe, upload_u8, run_rle, e2e_sync, dist, a.steps)
+        e2e = {"elapsed": e2e_elapsed, "blocks": blocks, "chars_per_step": chars / max(blocks, 1), "record_bytes": pipe.nbytes}
+        # the strings the device made for the bench batch, against the host encoder on the uint8 planes (rank 0, after the timed loops)
+        net.upload(imgs); net.forward_device(a.batch); net.postprocess_device(size, size); net.rle_device(); full_sync()
+        from isegmi.coco import rle_counts, rle_to_string
+        so, ch = net.fetch("rle.str_off"), net.fetch("rle.chars").tobytes()
+        mk, cn = net.fetch("det.masks", a.batch), net.fetch("det.count", a.batch)
+        K = pipe.K
+        e2e["rle_checked"] = 0
+        e2e["rle_ok"] = True
+        for i in range(a.batch):
+            for k in range(0, int(cn[i]), 7):  # every 7th detection: the host encoder takes ~3 ms per 550x550 mask
+                e2e["rle_ok"] &= ch[so[i * K + k]:so[i * K + k + 1]].decode() == rle_to_string(rle_counts(mk[i, k]))
+                e2e["rle_checked"] += 1
+        pipe.close()
+        if cgather is not None:
+            cgather.close()
+    net.upload(imgs)
+    full_sync()
+    pin8.free()
     counts = gpu["det.count"]
     value = a.batch * world * a.steps / elapsed
     if rank != 0:
@@ -315,23 +384,32 @@ def bench_yolact(a, dist):
         "value": round(value, 2), "unit": "img/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f16" if a.fp16 else "f32", "data": "synthetic",
-        "config": {"workload": "%s %dx%d bs=%d/GPU random weights: backbone+FPN+protonet+heads+Detect(fast-NMS)+%dx%d mask assembly%s" % (
+        "config": {"workload": "%s %dx%d bs=%d/GPU random weights: uint8 upload + FastBaseTransform on the device + backbone+FPN+protonet+heads+Detect(fast-NMS)+%dx%d mask assembly%s" % (
                        yname, size, size, a.batch, size, size, " (BASELINE configs[1])" if a.yolact_config == "resnet50" and not a.fp16 else " (variant, not configs[1])"),
                    "global_batch": a.batch * world, "parallelism": "batch-sharded x%d, RCCL all-gather of detections" % world,
                    "detections_per_image_rank0": [int(c) for c in counts]},
+        "value_note": "SURVEY 8(d): the H2D of every batch is inside the step (%.1f MB of uint8 images per batch through pinned memory on a copy stream, double-buffered; the transform runs on the engine's stream); results stay on the device (value_e2e ships them)" % (raw_u8.nbytes / 1e6),
         "roofline": roofline_dict(("conv_f16_glds / conv3x3_f16_strip kernels (all conv launches of a step, v_mfma_f32_32x32x16_f16)" if a.fp16 else
                                    "conv_mfma_v2_kernel + conv_mfma16_kernel + conv_mfma_kernel (all conv launches of a step; v_mfma_f32_32x32x2_f32 on 64x64 tiles, v_mfma_f32_16x16x4_f32 on the 32x32 / 32x64 blocks of small grids)"),
                                   conv_flops, conv_ms, conv_launches, a.steps, ypeak, None if (a.fp16 or a.yolact_config != "resnet50") else "pmc_yolact.json"),
         "step_ms": {"mean": round(elapsed / a.steps * 1e3, 3), "p50": round(pct(step_ms, 0.5), 3), "p90": round(pct(step_ms, 0.9), 3),
-                    "note": "intervals between consecutive per-step completion events on the results stream (pipelined multi-stream run)"},
+                    "note": "intervals between consecutive per-step completion events on the results stream (pipelined multi-stream run)" +
+                            ("; the RCCL all-gather runs on its own stream behind these marks and is not inside them (it is inside `value`)" if gather is not None else "")},
         "mean_ms_per_image": round(elapsed / a.steps * 1e3 / a.batch, 3),
         "p50_ms_per_image": round(pct(step_ms, 0.5) / a.batch, 3),
     }
-    if h2d_elapsed is not None:
-        out["value_incl_h2d"] = round(a.batch * world * a.steps / h2d_elapsed, 2)
-        out["h2d_note"] = "same K steps with a pinned-host async H2D of every batch (%.1f MB) on a copy stream, double-buffered input; `value` itself has the batch resident in HBM" % (imgs.nbytes / 1e6)
-        out["value_incl_h2d_u8"] = round(a.batch * world * a.steps / h2d_u8_elapsed, 2)
-        out["h2d_u8_note"] = "the same with the device front end: the uint8 images cross PCIe (%.1f MB per batch) and FastBaseTransform runs on the engine's stream (isegmi_engine_preprocess_u8, bit-identical to the host transform)" % (raw_u8.nbytes / 1e6)
+    if resident_elapsed is not None:
+        out["value_resident"] = round(a.batch * world * a.steps / resident_elapsed, 2)
+        out["value_incl_h2d_f32"] = round(a.batch * world * a.steps / h2d_elapsed, 2)
+        out["h2d_note"] = "value_resident: the same K steps with the batch already in HBM; value_incl_h2d_f32: with the host-transformed fp32 batch (%.1f MB) uploaded every step instead of the uint8 images" % (imgs.nbytes / 1e6)
+    if e2e is not None:
+        out["value_e2e"] = round(a.batch * world * a.steps / e2e["elapsed"], 2)
+        out["e2e"] = {"ms_per_step": round(e2e["elapsed"] / a.steps * 1e3, 3), "record_block_bytes": int(e2e["record_bytes"]),
+                      "rle_chars_per_step": int(e2e["chars_per_step"]), "blocks_collected": int(e2e["blocks"]),
+                      "device_rle_equals_host_encoder": bool(e2e["rle_ok"]), "masks_checked": int(e2e["rle_checked"]),
+                      "note": "uint8 upload -> forward -> mask assembly -> pycocotools RLE on the device -> one fixed-size record block per step (boxes, scores, classes, RLE strings) "
+                              "downloaded into pinned host memory%s while the next step runs; the %d MB of uint8 mask planes never leave the GPU" % (
+                                  " / all-gathered over RCCL" if gather is not None else "", int(a.batch * 100 * size * size / 1e6))}
     if rccl:
         out.update(rccl)
     if not a.no_latency:
@@ -416,13 +494,24 @@ def bench_maskrcnn(a, dist, summary=False):
         from isegmi.dist import maskrcnn_record_bytes
         gather = dist.make_gather(maskrcnn_record_bytes(batch, M=14 if c4 else 28))
 
+    flat = np.concatenate([im.reshape(-1) for im in imgs_u8])
+    pin8 = _ffi.PinnedBuffer(flat.shape, np.uint8)
+    pin8.array[...] = flat
+
     def run(slot=0):
         model.forward_device(batch, slot)
         model.paste_device(800, 1333)
         if gather is not None:
             gather.gather_from(model)
 
-    def step(i):
+    def upload_u8(slot):  # what PIL's resize hands build_transform: uint8 images over PCIe, mean subtraction + to_image_list padding on the device
+        model.upload_u8_async(pin8, hw, slot)
+
+    def step(i):          # H2D of the input inside the step
+        upload_u8((i + 1) & 1)
+        run(i & 1)
+
+    def step_resident(i):
         run(0)
 
     def full_sync():
@@ -432,11 +521,14 @@ def bench_maskrcnn(a, dist, summary=False):
         _ffi.sync()
 
     steps, warmup = a.steps, a.warmup
-    for _ in range(max(warmup, 1 if gather is not None else 0)):
-        run()
+    upload_u8(0)
+    for i in range(max(warmup, 1 if gather is not None else 0)):
+        step(i)
     full_sync()
+    upload_u8(0)
     elapsed, step_ms = timed_region(model, step, full_sync, dist, steps)
-    flops, ms, launches = roofline_pass(model, step, full_sync, steps, a.single_stream)
+    model.upload(x, hw)
+    flops, ms, launches = roofline_pass(model, step_resident, full_sync, steps, a.single_stream)
     names = ("det.count", "det.score", "det.label", "det.box", "det.mask14" if c4 else "det.mask28", "det.masks", "proposal_count", "proposals")
     gpu = {k: model.fetch(k, batch) for k in names}
     rccl = None
@@ -444,27 +536,55 @@ def bench_maskrcnn(a, dist, summary=False):
         from isegmi.dist import unpack_maskrcnn_records
         blocks = gather.fetch()
         rccl = {"rccl_ranks": int(gather.world), "ranks_with_records": int(sum(1 for r in range(world) if unpack_maskrcnn_records(blocks[r], batch, M=14 if c4 else 28)["count"].any()))}
-    h2d_elapsed = h2d_u8_elapsed = None
+    resident_elapsed = h2d_elapsed = e2e = None
     if not a.no_h2d:
+        resident_elapsed, _ = timed_region(model, step_resident, full_sync, dist, steps)
         pinned = _ffi.PinnedBuffer(x.shape)
         pinned.array[...] = x
-        h2d_elapsed = h2d_region(lambda slot: model.upload_async(pinned, slot), run, full_sync, dist, steps)
-        flat = np.concatenate([im.reshape(-1) for im in imgs_u8])
-        pin8 = _ffi.PinnedBuffer(flat.shape, np.uint8)
-        pin8.array[...] = flat
-        h2d_u8_elapsed = h2d_region(lambda slot: model.upload_u8_async(pin8, hw, slot), run, full_sync, dist, steps)
-        pin8.free()
-        model.upload(x, hw)
+
+        def step_f32(i):
+            model.upload_async(pinned, (i + 1) & 1)
+            run(i & 1)
+        model.upload_async(pinned, 0)
+        h2d_elapsed, _ = timed_region(model, step_f32, full_sync, dist, steps)
         full_sync()
         pinned.free()
+    if not a.no_e2e:
+        from isegmi.pipeline import RecordPipeline
+        cgather = dist.make_gather(model.coco_record_bytes(batch)[0]) if gather is not None else None
+        pipe = RecordPipeline(model, batch, cgather)
+
+        def run_rle(slot):
+            model.forward_device(batch, slot)
+            model.paste_device(800, 1333)
+            model.rle_device()
+        e2e_sync = (lambda: (full_sync(), cgather.wait())) if cgather is not None else full_sync
+        e2e_region(model, pipe, upload_u8, run_rle, e2e_sync, dist, max(2, warmup // 2))
+        e2e_elapsed, nblocks, chars = e2e_region(model, pipe, upload_u8, run_rle, e2e_sync, dist, steps)
+        e2e = {"elapsed": e2e_elapsed, "blocks": nblocks, "chars_per_step": chars / max(nblocks, 1), "record_bytes": pipe.nbytes}
+        model.upload(x, hw); model.forward_device(batch); model.paste_device(800, 1333); model.rle_device(); full_sync()
+        from isegmi.coco import rle_counts, rle_to_string
+        so, ch = model.fetch("rle.str_off"), model.fetch("rle.chars").tobytes()
+        mk, cn = model.fetch("det.masks", batch), model.fetch("det.count", batch)
+        e2e["rle_checked"], e2e["rle_ok"] = 0, True
+        for i in range(batch):
+            for k in range(0, int(cn[i]), 9):  # every 9th detection: the host encoder takes ~10 ms per 800x1333 mask
+                e2e["rle_ok"] &= ch[so[i * pipe.K + k]:so[i * pipe.K + k + 1]].decode() == rle_to_string(rle_counts(mk[i, k]))
+                e2e["rle_checked"] += 1
+        pipe.close()
+        if cgather is not None:
+            cgather.close()
+    model.upload(x, hw)
+    full_sync()
+    pin8.free()
     if rank != 0:
         return None, model, gather
     value = batch * world * steps / elapsed
     traffic_file = "pmc_r101f16.json" if (fp16 and depth == 101 and batch == 8 and not c4) else None if (fp16 or c4 or depth != 50 or batch != 2) else "pmc_maskrcnn.json"
     roof = roofline_dict("conv_f16_glds / conv3x3_f16_strip kernels (all conv launches of a step)" if fp16 else "conv_mfma_v2_kernel + conv_mfma16_kernel + conv_mfma_kernel (all conv launches of a step)",
                          flops, ms, launches, steps, peak, traffic_file)
-    workload = ("Mask R-CNN %s 1333x800 (padded 800x1344) bs=%d/GPU random weights, %s: conv1-4 + single-map RPN (6000 -> 1000) + RoIAlign + conv5 head + NMS + shared-extractor mask branch + paste (the README.md:263-273 config; not a BASELINE config)" % (tag, batch, prec)) if c4 else \
-        "Mask R-CNN %s 1333x800 (padded 800x1344) bs=%d/GPU random weights, %s: backbone+FPN+RPN+RoIAlign+box head+NMS+mask head+paste (BASELINE configs[%d])" % (tag, batch, prec, 4 if fp16 else 2)
+    workload = ("Mask R-CNN %s 1333x800 (padded 800x1344) bs=%d/GPU random weights, %s: uint8 upload + conv1-4 + single-map RPN (6000 -> 1000) + RoIAlign + conv5 head + NMS + shared-extractor mask branch + paste (the README.md:263-273 config; not a BASELINE config)" % (tag, batch, prec)) if c4 else \
+        "Mask R-CNN %s 1333x800 (padded 800x1344) bs=%d/GPU random weights, %s: uint8 upload + mean/pad on the device + backbone+FPN+RPN+RoIAlign+box head+NMS+mask head+paste (BASELINE configs[%d])" % (tag, batch, prec, 4 if fp16 else 2)
     out = {"metric": "images/sec (Mask R-CNN %s 1333x800, bs=%d per GPU, %s)" % (tag, batch, prec),
            "value": round(value, 3), "unit": "img/s", "n_gpus": world, "steps": steps, "warmup": warmup,
            "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -473,13 +593,20 @@ def bench_maskrcnn(a, dist, summary=False):
                       "proposals_per_image": [int(c) for c in gpu["proposal_count"]], "detections_per_image": [int(c) for c in gpu["det.count"]]},
            "roofline": roof,
            "step_ms": {"mean": round(elapsed / steps * 1e3, 3), "p50": round(pct(step_ms, 0.5), 3), "p90": round(pct(step_ms, 0.9), 3),
-                       "note": "intervals between consecutive per-step completion events on the results stream (pipelined multi-stream run)"},
+                       "note": "intervals between consecutive per-step completion events on the results stream (pipelined multi-stream run)" +
+                               ("; the RCCL all-gather runs on its own stream behind these marks and is not inside them (it is inside `value`)" if gather is not None else "")},
            "mean_ms_per_image": round(elapsed / steps * 1e3 / batch, 3), "p50_ms_per_image": round(pct(step_ms, 0.5) / batch, 3)}
-    if h2d_elapsed is not None:
-        out["value_incl_h2d"] = round(batch * world * steps / h2d_elapsed, 3)
-        out["h2d_note"] = "same K steps with a pinned-host async H2D of every batch (%.1f MB) on a copy stream, double-buffered input" % (x.nbytes / 1e6)
-        out["value_incl_h2d_u8"] = round(batch * world * steps / h2d_u8_elapsed, 3)
-        out["h2d_u8_note"] = "the same with the device front end: uint8 images (%.1f MB per batch), mean subtraction and padding on the engine's stream" % (flat.nbytes / 1e6)
+    out["value_note"] = "SURVEY 8(d): the H2D of every batch is inside the step (%.1f MB of uint8 images through pinned memory on a copy stream, double-buffered; mean subtraction + to_image_list padding on the engine's stream); results stay on the device (value_e2e ships them)" % (flat.nbytes / 1e6)
+    if resident_elapsed is not None:
+        out["value_resident"] = round(batch * world * steps / resident_elapsed, 3)
+        out["value_incl_h2d_f32"] = round(batch * world * steps / h2d_elapsed, 3)
+        out["h2d_note"] = "value_resident: the same K steps with the batch already in HBM; value_incl_h2d_f32: with the host-normalised fp32 batch (%.1f MB) uploaded every step" % (x.nbytes / 1e6)
+    if e2e is not None:
+        out["value_e2e"] = round(batch * world * steps / e2e["elapsed"], 3)
+        out["e2e"] = {"ms_per_step": round(e2e["elapsed"] / steps * 1e3, 3), "record_block_bytes": int(e2e["record_bytes"]), "rle_chars_per_step": int(e2e["chars_per_step"]),
+                      "blocks_collected": int(e2e["blocks"]), "device_rle_equals_host_encoder": bool(e2e["rle_ok"]), "masks_checked": int(e2e["rle_checked"]),
+                      "note": "uint8 upload -> forward -> Masker paste at 800x1333 -> pycocotools RLE on the device -> one fixed-size record block per step in pinned host memory%s while the next step runs; the %d MB of uint8 mask planes never leave the GPU" % (
+                          " / all-gathered over RCCL" if gather is not None else "", int(batch * 100 * 800 * 1333 / 1e6))}
     if rccl:
         out.update(rccl)
     if not a.no_latency:
@@ -522,7 +649,7 @@ def bench_maskrcnn(a, dist, summary=False):
         out["parity_note"] = "%d images: proposals, detection count, score, label, box, 28x28 masks and the masks pasted at 800x1333 all bit-equal" % batch
     if summary:
         keep = {"workload": out["config"]["workload"], "img_per_s": out["value"], "batch": batch, "ms_per_step": out["ms_per_step"], "steps": steps, "warmup": warmup,
-                "step_ms": out["step_ms"], "value_incl_h2d": out.get("value_incl_h2d"), "value_incl_h2d_u8": out.get("value_incl_h2d_u8"), "bs1": out.get("bs1"),
+                "step_ms": out["step_ms"], "value_resident": out.get("value_resident"), "value_e2e": out.get("value_e2e"), "e2e": out.get("e2e"), "bs1": out.get("bs1"),
                 "roofline": {k: roof[k] for k in ("achieved", "peak", "unit", "frac", "conv_ms_per_step", "launches_per_step", "algorithmic_gflop_per_step")},
                 "detections_per_image": out["config"]["detections_per_image"], "proposals_per_image": out["config"]["proposals_per_image"],
                 "cpu_baseline": out.get("cpu_baseline"), "parity_vs_oracle_on_bench_batch": out.get("parity_vs_oracle_on_bench_batch"),

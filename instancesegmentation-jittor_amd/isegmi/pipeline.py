@@ -104,9 +104,10 @@ def schedule_batches(group_keys, batch_size):
     return batches
 
 
-def make_gather(net, batch, rank, world):
-    """The RCCL all-gather of a multi-rank run (None for one rank): unique id from rank 0 through the stdlib rendezvous of isegmi.dist."""
-    if world <= 1:
+def make_gather(net, batch, rank, world, force=False):
+    """The RCCL all-gather of a multi-rank run (None for one rank unless `force`: a world of one still goes through RCCL, for tests on a
+    one-GPU box): unique id from rank 0 through the stdlib rendezvous of isegmi.dist."""
+    if world <= 1 and not force:
         return None
     from .dist import RcclGather, rendezvous_unique_id
     uid = rendezvous_unique_id(rank, world, RcclGather.unique_id)

@@ -104,7 +104,7 @@ class COCODemo:
             self._model = None
 
 
-def inference(predictor, images, image_ids=None, batch_size=None, group="canvas", rank=0, world=1, sizes=None, stats=None):
+def inference(predictor, images, image_ids=None, batch_size=None, group="canvas", rank=0, world=1, sizes=None, stats=None, force_gather=False):
     """engine/inference.py-shaped evaluation (README.md:344-347): images -> COCO-format result list (bbox + segm) ready for json.dump.
 
     The path the benchmark measures, end to end: batches of `batch_size` resized uint8 images go up through pinned memory (double-buffered),
@@ -142,7 +142,7 @@ def inference(predictor, images, image_ids=None, batch_size=None, group="canvas"
     else:
         raise ValueError("group: 'canvas' or 'aspect'")
     batches = schedule_batches(keys, bs)
-    gather = make_gather(model, bs, rank, world)
+    gather = make_gather(model, bs, rank, world, force_gather)
     pipe = RecordPipeline(model, bs, gather)
     pin = [_ffi.PinnedBuffer((bs * model.H * model.W * 3,), np.uint8) for _ in range(2)]
     per_image = [None] * n_img

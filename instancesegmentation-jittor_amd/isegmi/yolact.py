@@ -472,7 +472,7 @@ def postprocess(det_output, w, h, batch_idx=0, score_threshold=0.0):
     return d["class"][keep], scores, net._pp_boxes[i, :c][keep], net._pp_masks[i, :c][keep]
 
 
-def evaluate(net, images, image_ids=None, batch_size=None, score_threshold=0.0, top_k=None, rank=0, world=1, sizes=None, stats=None):
+def evaluate(net, images, image_ids=None, batch_size=None, score_threshold=0.0, top_k=None, rank=0, world=1, sizes=None, stats=None, force_gather=False):
     """eval.py's image evaluation as a data-set loop (README.md:243-249: --images / --output_coco_json): images -> COCO-format result list
     (Detections.add_bbox / add_mask records) -- the path the benchmark measures, end to end.  Batches of `batch_size` raw uint8 BGR
     images (any sizes) go up through pinned memory; FastBaseTransform, the forward, Detect, postprocess at every image's OWN size,
@@ -493,7 +493,7 @@ def evaluate(net, images, image_ids=None, batch_size=None, score_threshold=0.0, 
     bs = int(batch_size or net.max_batch)
     assert bs <= net.max_batch
     batches = [list(range(j, min(j + bs, n_img))) for j in range(0, n_img, bs)]
-    gather = make_gather(net, bs, rank, world)
+    gather = make_gather(net, bs, rank, world, force_gather)
     pipe = RecordPipeline(net, bs, gather)
     pin_bytes = max(sum(sizes[i][0] * sizes[i][1] * 3 for i in b) for b in batches) if batches else 1
     pin = [_ffi.PinnedBuffer((pin_bytes,), np.uint8) for _ in range(2)]

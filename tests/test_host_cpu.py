@@ -219,29 +219,34 @@ def test_world2_gloo_detection_gather(tmp_path):
     assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists()
 
 
-def test_cocodemo_engine_cache_is_bounded(monkeypatch):
-    """COCODemo keeps one engine per padded canvas size; beyond MAX_ENGINES the least recently used one is closed."""
+def test_cocodemo_holds_exactly_one_engine(monkeypatch):
+    """COCODemo builds ONE engine at the largest canvas the resize rule can produce (either orientation) and keeps it for every image;
+    only a larger batch size than it was built for replaces it."""
     from isegmi import predictor
 
     class Fake:
         alive = 0
 
-        def __init__(self, sd, H, W, **kw):
-            self.key = (H, W); Fake.alive += 1
+        def __init__(self, sd, H, W, cfg=None, max_batch=1, **kw):
+            self.key, self.max_batch = (H, W), max_batch; Fake.alive += 1
+
+        def reserve(self):
+            return (1, 2)
 
         def close(self):
             Fake.alive -= 1
     monkeypatch.setattr(predictor, "MaskRCNN", Fake)
-    demo = predictor.COCODemo(state_dict={"x": 0})
-    sizes = [(800, 1344), (800, 1216), (832, 1344), (800, 1088), (768, 1344), (800, 1344)]
-    for hw in sizes:
-        m = demo._model(*hw)
-        assert m.key == hw and Fake.alive <= predictor.COCODemo.MAX_ENGINES
-    assert Fake.alive == predictor.COCODemo.MAX_ENGINES
-    first = demo._model(800, 1088)
-    assert demo._model(800, 1088) is first          # a hit re-uses the engine and refreshes its age
+    demo = predictor.COCODemo(state_dict={"x": 0}, max_batch=2)
+    e = demo.engine()
+    assert e.key == (1344, 1344) and e.max_batch == 2 and demo.memory == (1, 2)
+    assert demo.engine() is e and demo.engine(1) is e and Fake.alive == 1
+    e4 = demo.engine(4)
+    assert e4 is not e and e4.max_batch == 4 and Fake.alive == 1
     demo.close()
     assert Fake.alive == 0
+    small = predictor.COCODemo(state_dict={"x": 0}, min_image_size=192, max_image_size=320)
+    assert small.engine().key == (320, 320)
+    small.close()
 
 
 def test_bench_gpus_n_without_devices_fails_loudly():

@@ -1,0 +1,200 @@
+"""The product path that the benchmark measures: batched, pipelined inference() / evaluate() with device-side COCO output (RLE strings
+made on the GPU, one fixed-size record block per step, asynchronous download or RCCL all-gather), ONE engine for every canvas.
+Checked record for record against (a) the same images run one at a time, (b) the host-side path (masks fetched as uint8 planes, RLE in
+numpy) and (c) the CPU oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _images(rng, shapes):
+    from conftest import smooth_field
+    out = []
+    for i, (h, w) in enumerate(shapes):
+        im = smooth_field(100 + i, h, w) if i % 2 else rng.integers(0, 256, (h, w, 3))
+        out.append(np.ascontiguousarray(im, np.uint8) if im.dtype != np.uint8 else im)
+    return out
+
+
+@pytest.fixture(scope="module")
+def sd():
+    from isegmi.weights import maskrcnn_state_dict
+    return maskrcnn_state_dict(1234)
+
+
+def _same(a, b):
+    assert len(a) == len(b), (len(a), len(b))
+    for x, y in zip(a, b):
+        assert x == y, (x["image_id"], {k: (x[k], y[k]) for k in x if x[k] != y[k] and k != "segmentation"})
+
+
+def test_inference_batched_equals_single_image_and_host_path(ffi, sd):
+    """nine images of three sizes (three different padded canvases) at bs = 2 and 3: every record -- bbox, score, category, RLE string --
+    equals the bs = 1 run and the host-side path (compute_prediction -> uint8 planes over PCIe -> numpy RLE)."""
+    from isegmi.coco import maskrcnn_results
+    from isegmi.predictor import COCODemo, inference
+    rng = np.random.default_rng(31)
+    shapes = [(150, 200), (200, 150), (120, 200), (150, 200), (120, 200), (200, 150), (150, 200), (120, 200), (150, 200)]
+    images = _images(rng, shapes)
+    ids = [100 + i for i in range(len(images))]
+    demo = COCODemo(None, min_image_size=192, confidence_threshold=0.0, state_dict=sd, max_image_size=320, max_batch=3)
+    eng = demo.engine()
+    host = []
+    for im, iid in zip(images, ids):
+        p = demo.compute_prediction(im)
+        host += maskrcnn_results(iid, p.bbox, p.get_field("scores"), p.get_field("labels"), p.get_field("mask")[:, 0])
+    assert len(host) > 20
+    st1, st2 = {}, {}
+    one = inference(demo, images, image_ids=ids, batch_size=1, stats=st1)
+    two = inference(demo, images, image_ids=ids, batch_size=2, stats=st2)
+    three = inference(demo, lambda i: images[i], image_ids=ids, batch_size=3, sizes=shapes)   # lazy loading
+    assert demo.engine() is eng, "one engine serves every canvas and batch size"
+    assert st1["steps"] == 9 and st2["steps"] == 5 and st2["batches"] == 5   # canvases: 5 + 2 + 2 images -> 3 + 1 + 1 batches of <= 2
+    _same(one, host)
+    _same(two, one)
+    _same(three, one)
+    wb, bb = demo.memory
+    assert wb > 150e6 and bb > 0
+    demo.close()
+
+
+def test_one_engine_six_canvases_match_oracle(ffi, sd):
+    """COCODemo holds exactly ONE engine (weights packed once, buffers sized once); six images with six different padded canvases each
+    equal the oracle run on that image's own canvas.  Peak device memory is reported."""
+    from isegmi.maskrcnn import prepare_images
+    from isegmi.predictor import COCODemo
+    from isegmi.transforms import maskrcnn_resize
+    from oracle.maskrcnn_ref import MaskRCNNRef
+    rng = np.random.default_rng(17)
+    shapes = [(150, 200), (200, 150), (120, 200), (100, 100), (90, 200), (200, 130)]
+    demo = COCODemo(None, min_image_size=160, confidence_threshold=0.0, state_dict=sd, max_image_size=288, max_batch=1)
+    eng = demo.engine()
+    mem0 = eng.memory()
+    ref = MaskRCNNRef(sd)
+    canvases = set()
+    for im in _images(rng, shapes):
+        h, w = im.shape[:2]
+        pred = demo.compute_prediction(im)
+        x, hw = prepare_images([maskrcnn_resize(im, 160, 288)])
+        canvases.add(x.shape[1:3])
+        rd = ref.forward(x, hw)[0]
+        ratio = (np.float32(w / hw[0, 1]), np.float32(h / hw[0, 0]))
+        rm, rb = MaskRCNNRef.paste(rd, h, w, ratio)
+        assert len(pred) == len(rd["score"]) > 0
+        assert np.array_equal(pred.bbox, rb) and np.array_equal(pred.get_field("scores"), rd["score"]) and np.array_equal(pred.get_field("labels"), rd["label"])
+        assert np.array_equal(pred.get_field("mask")[:, 0], rm)
+    assert len(canvases) == 6 and demo.engine() is eng
+    mem1 = eng.memory()
+    assert mem1[0] == mem0[0] and mem1[1] <= mem0[1] + 8 * 1024 * 1024, "reserve() sized the buffers once (only the paste planes follow the image size)"
+    print("one engine, six canvases: weights %.1f MB, buffers %.1f MB" % (mem1[0] / 1e6, mem1[1] / 1e6))
+    demo.close()
+
+
+def test_mixed_canvas_batch_equals_forced_canvas_runs(ffi, sd):
+    """upstream's ASPECT_RATIO_GROUPING batches images of different sizes; to_image_list pads the batch to its largest member.  A batch's
+    result for an image then equals that image run ALONE on the batch's canvas (and in general differs from its own-canvas result)."""
+    from isegmi.maskrcnn import MaskRCNN, padded_canvas
+    from isegmi.transforms import maskrcnn_resize_u8
+    rng = np.random.default_rng(3)
+    ims = [maskrcnn_resize_u8(im, 160, 288) for im in _images(rng, [(150, 200), (100, 200), (140, 150)])]
+    model = MaskRCNN(sd, 288, 288, max_batch=3)
+    canvas = padded_canvas([im.shape[:2] for im in ims])
+    batch = model(ims)
+    assert model._canvas == canvas
+    differs = False
+    for i, im in enumerate(ims):
+        n = model.upload_u8([im], canvas=canvas)
+        model.forward_device(n); model.sync()
+        c = int(model.fetch("det.count", 1)[0])
+        assert c == len(batch[i])
+        assert np.array_equal(model.fetch("det.box", 1)[0, :c], batch[i].bbox) and np.array_equal(model.fetch("det.score", 1)[0, :c], batch[i].get_field("scores"))
+        assert np.array_equal(model.fetch("det.mask28", 1)[0, :c], batch[i].get_field("mask")[:, 0])
+        (own,) = model([im])
+        differs |= len(own) != c or not np.array_equal(own.bbox, batch[i].bbox)
+    assert differs, "at least one image sees a different canvas in the batch than alone"
+    model.close()
+
+
+def test_inference_through_rccl_world1_and_aspect_grouping(ffi, sd):
+    """the multi-rank transport (RCCL all-gather of the record blocks, two slots) with a world of one, and upstream's aspect grouping"""
+    from isegmi.predictor import COCODemo, inference
+    rng = np.random.default_rng(5)
+    shapes = [(150, 200), (200, 150), (120, 200), (150, 200), (200, 140)]
+    images = _images(rng, shapes)
+    demo = COCODemo(None, min_image_size=160, confidence_threshold=0.0, state_dict=sd, max_image_size=288, max_batch=2)
+    plain = inference(demo, images, batch_size=2)
+    rccl = inference(demo, images, batch_size=2, force_gather=True)
+    _same(rccl, plain)
+    st = {}
+    asp = inference(demo, images, batch_size=2, group="aspect", stats=st)
+    assert st["batches"] == 3 and {d["image_id"] for d in asp} == {d["image_id"] for d in plain}
+    demo.close()
+
+
+def test_yolact_evaluate_matches_host_path(ffi):
+    """evaluate(): ragged image sizes in one batch, masks assembled at every image's own size on the device, RLE on the device ==
+    net() + postprocess() + yolact_results() (host RLE) one image at a time; score threshold / top_k applied to the records."""
+    from isegmi.coco import yolact_results
+    from isegmi.weights import yolact_state_dict
+    from isegmi.yolact import Yolact, evaluate, postprocess
+    rng = np.random.default_rng(12)
+    shapes = [(120, 160), (90, 200), (160, 120), (120, 160), (100, 100)]
+    images = _images(rng, shapes)
+    net = Yolact(yolact_state_dict(1234), max_batch=3, input_size=200)
+    host = []
+    for i, im in enumerate(images):
+        preds = net(im[None])
+        classes, scores, boxes, masks = postprocess(preds, im.shape[1], im.shape[0], score_threshold=0.15)
+        host += yolact_results(i, classes[:15], scores[:15], boxes[:15], masks[:15])
+    assert len(host) > 5
+    st = {}
+    got = evaluate(net, images, batch_size=3, score_threshold=0.15, top_k=15, stats=st)
+    assert st["steps"] == 2
+    _same(got, host)
+    _same(evaluate(net, images, batch_size=2, score_threshold=0.15, top_k=15, force_gather=True), host)
+    net.close()
+
+
+def test_graph_replay_with_double_buffered_async_uploads(ffi):
+    """hipGraph replay + upload_async into alternating input slots on CHANGING inputs, twelve steps queued WITHOUT any host
+    synchronisation: every step's scores equal a synchronised eager run of the same input.  (A replay must mark the point where its input
+    was consumed, or the upload two steps later overwrites a staging / input buffer the replay still reads.)"""
+    import ctypes as C
+    from isegmi.weights import yolact_state_dict
+    from isegmi.yolact import Yolact
+    rng = np.random.default_rng(2)
+    net = Yolact(yolact_state_dict(1234), max_batch=2, input_size=200)
+    batches = [rng.integers(0, 256, (2, 150, 180, 3), dtype=np.uint8) for _ in range(4)]
+    want = []
+    for b in batches:
+        n = net.upload_u8(b); net.forward_device(n); net.sync()
+        want.append({k: net.fetch(k, 2) for k in ("det.count", "det.score")})
+    pins = []
+    for b in batches:
+        p = ffi.PinnedBuffer(b.shape, np.uint8); p.array[...] = b; pins.append(p)
+    for graph in (0.0, 1.0):
+        net.set_param("graph", graph)
+        order = [0, 1, 2, 3, 0, 1, 2, 3, 3, 2, 1, 0]
+        outs = [ffi.PinnedBuffer((2, 100), np.float32) for _ in order]
+        src = C.c_void_p()
+        for step, bi in enumerate(order):
+            slot = step & 1
+            net.upload_u8_async(pins[bi], 2, 150, 180, slot=slot)
+            net.forward_device(2, slot)
+            ffi.check(ffi.lib().isegmi_engine_buffer_info(net._h, b"det.score", C.byref(src), None, None, None, None))
+            ffi.check(ffi.lib().isegmi_engine_download_async(net._h, slot, outs[step].ptr, src, C.c_int64(2 * 100 * 4)))
+            ffi.check(ffi.lib().isegmi_engine_download_fence(net._h, slot))  # the next forward's Detect waits (on the device) for this copy
+        net.sync()
+        for step, bi in enumerate(order):
+            c = want[bi]["det.count"]
+            for i in range(2):
+                assert np.array_equal(outs[step].array[i, :c[i]], want[bi]["det.score"][i, :c[i]]), (graph, step, bi, i)
+        for o in outs:
+            o.free()
+    cap, rep, fail = C.c_int64(), C.c_int64(), C.c_int64()
+    ffi.check(ffi.lib().isegmi_engine_graph_stats(net._h, C.byref(cap), C.byref(rep), C.byref(fail)))
+    assert cap.value == 2 and rep.value >= 8 and fail.value == 0   # one graph per input slot
+    for p in pins:
+        p.free()
+    net.close()

@@ -1,0 +1,134 @@
+"""Host logic of the device-side COCO output (no GPU): the record block's layout (mirror of csrc/results.cpp), records -> COCO dicts against
+the host-array path, the test loader's batch schedule, the torch-free rendezvous, and the oracle's RLE restatement against hand-computed
+answers and isegmi/coco.py."""
+import multiprocessing as mp
+import os
+import re
+
+import numpy as np
+import pytest
+
+
+def test_oracle_rle_known_answers_and_agreement_with_host_encoder():
+    from isegmi import coco
+    from oracle import ora
+    m = np.array([[0, 1], [1, 1]], np.uint8)                       # column-major 0 1 1 1
+    assert list(ora.rle_encode(m)) == [1, 3] and ora.rle_to_string([1, 3]) == "13"
+    assert list(ora.rle_encode(np.ones((2, 2), np.uint8))) == [0, 4]          # first pixel set: leading 0
+    assert list(ora.rle_encode(np.zeros((3, 2), np.uint8))) == [6]
+    assert ora.rle_to_string([32]) == "P1" and ora.rle_to_string([0, 4]) == "04"
+    # the fourth count on is a difference to the count two back: 5 100 2000 40-100=-60 ...; negative values use the sign bit rule
+    counts = [5, 100, 2000, 40, 1, 70000, 3]
+    s = ora.rle_to_string(counts)
+    assert coco.rle_from_string(s) == counts and s == coco.rle_to_string(counts)
+    rng = np.random.default_rng(0)
+    for h, w in ((1, 1), (3, 5), (64, 64), (65, 63), (138, 138)):
+        for dens in (0.0, 0.05, 0.5, 1.0):
+            mm = (rng.uniform(0, 1, (h, w)) < dens).astype(np.uint8)
+            a = ora.rle_encode(mm)
+            assert list(a) == coco.rle_counts(mm) and int(a.sum()) == h * w
+            assert ora.rle_to_string(a) == coco.rle_to_string(a)
+            assert np.array_equal(coco.rle_decode({"size": [h, w], "counts": ora.rle_to_string(a)}), mm)
+
+
+@pytest.mark.parametrize("kind,mscore", [(2, False), (1, False), (1, True)])
+def test_record_block_roundtrip_and_results(kind, mscore):
+    from isegmi import coco
+    from isegmi.dist import CocoRecordError, coco_record_layout, pack_coco_records, unpack_coco_records
+    rng = np.random.default_rng(kind)
+    n, K, h, w = 3, 5, 40, 50
+    count = np.array([4, 0, 2], np.int32)
+    masks = (rng.uniform(0, 1, (n, K, h, w)) < 0.4).astype(np.uint8)
+    masks[:, :, 10:30, 5:45] = 1
+    if kind == 2:
+        box = np.sort(rng.uniform(0, 40, (n, K, 4)).astype(np.float32), -1)[..., [0, 1, 2, 3]]
+        label = rng.integers(1, 81, (n, K)).astype(np.int32)
+    else:
+        box = np.sort(rng.integers(0, 40, (n, K, 4)), -1).astype(np.int64)
+        label = rng.integers(0, 80, (n, K)).astype(np.int32)
+    score = np.sort(rng.uniform(0.1, 1, (n, K)).astype(np.float32), -1)[:, ::-1]
+    ms = rng.uniform(0, 1, (n, K)).astype(np.float32) if mscore else None
+    chars, so = b"", [0]
+    for i in range(n):
+        for k in range(K):
+            if k < count[i]:
+                chars += coco.rle_to_string(coco.rle_counts(masks[i, k])).encode()
+            so.append(len(chars))
+    cap = len(chars) + 100
+    status = np.array([0, len(chars), 0, 0], np.int32)
+    buf = pack_coco_records(status, box, count, score, label, np.array(so, np.int32), chars, n, K, kind, ms, cap)
+    secs, coff, total = coco_record_layout(n, K, kind, mscore, cap)
+    assert buf.size == total and coff % 8 == 0 and all(off % 4 == 0 for off, _, _, _ in secs.values()) and secs["box"][0] % 8 == 0
+    rec = unpack_coco_records(buf, n, K, kind, mscore, cap)
+    assert rec["chars"] == chars and np.array_equal(rec["box"], box) and np.array_equal(rec["count"], count)
+    ids, sizes = [7, 8, 9], [(h, w)] * n
+    got = coco.results_from_records(rec, ids, sizes, kind, K)
+    want = []
+    for i in range(n):
+        c = count[i]
+        if kind == 2:
+            want += coco.maskrcnn_results(ids[i], box[i, :c], score[i, :c], label[i, :c], masks[i, :c])
+        else:
+            want += coco.yolact_results(ids[i], label[i, :c], score[i, :c], box[i, :c], masks[i, :c], None if ms is None else ms[i, :c])
+    assert got == want and len(got) == 6
+    if kind == 1:   # eval.py --score_threshold / --top_k on the records
+        thr = float(np.sort(score[0, :4])[1])
+        f = coco.results_from_records(rec, ids, sizes, kind, K, score_threshold=thr, top_k=1)
+        assert [d["image_id"] for d in f] == [7, 9] and all(d["score"] > thr for d in f)
+    assert coco.results_from_records(rec, [7, None, 9], sizes, kind, K) == [d for d in want if d["image_id"] != 8]
+    bad = buf.copy(); bad[8:12] = np.array([2], np.int32).view(np.uint8)
+    with pytest.raises(CocoRecordError):
+        unpack_coco_records(bad, n, K, kind, mscore, cap)
+    # an all-zero block (a rank without a batch in the last step) is a valid, empty record
+    z = unpack_coco_records(np.zeros(total, np.uint8), n, K, kind, mscore, cap)
+    assert coco.results_from_records(z, ids, sizes, kind, K) == []
+
+
+def test_schedule_batches_is_the_grouped_batch_sampler():
+    from isegmi.pipeline import schedule_batches
+    assert schedule_batches(["a", "b", "a", "a", "b", "a"], 2) == [[0, 2], [1, 4], [3, 5]]
+    assert schedule_batches([0] * 5, 2) == [[0, 1], [2, 3], [4]]
+    assert schedule_batches([], 4) == []
+    b = schedule_batches([i % 3 for i in range(20)], 4)
+    assert sorted(i for x in b for i in x) == list(range(20)) and all(len({i % 3 for i in x}) == 1 for x in b) and [x[0] for x in b] == sorted(x[0] for x in b)
+
+
+def _rdzv_rank(rank, world, d, q):
+    os.environ.update(ISEGMI_RDZV_DIR=d, MASTER_PORT="4711", TORCHELASTIC_RUN_ID="t")
+    from isegmi.dist import rendezvous_cleanup, rendezvous_unique_id
+    uid = rendezvous_unique_id(rank, world, lambda: bytes(range(128)), timeout=30.0)
+    q.put((rank, uid))
+    if rank == 0:
+        import time
+        time.sleep(0.5)
+        rendezvous_cleanup(rank, world)
+
+
+def test_rendezvous_without_torch(tmp_path):
+    """rank 0's 128-byte id reaches the other ranks through the file rendezvous; a stale file of a crashed run is not taken"""
+    stale = tmp_path / "isegmi_uid_4711_t_3"
+    stale.write_bytes(b"\\xff" * 128)
+    os.utime(stale, (1, 1))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_rdzv_rank, args=(r, 3, str(tmp_path), q)) for r in (1, 2, 0)]
+    for p in ps[:2]:
+        p.start()
+    import time
+    time.sleep(0.3)
+    ps[2].start()
+    got = dict(q.get(timeout=60) for _ in range(3))
+    for p in ps:
+        p.join(30)
+    assert all(got[r] == bytes(range(128)) for r in range(3))
+    assert not stale.exists()
+
+
+def test_package_imports_no_torch_and_no_oracle():
+    """north_star: host code is Python over a thin C ABI -- no PyTorch, no Triton in the product; the oracle is test infrastructure"""
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "instancesegmentation-jittor_amd", "isegmi")
+    pat = re.compile(r"^\\s*(import|from)\\s+(torch|triton|oracle)\\b", re.M)
+    for f in sorted(os.listdir(root)):
+        if f.endswith(".py"):
+            src = open(os.path.join(root, f)).read()
+            assert not pat.search(src), f
