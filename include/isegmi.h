@@ -58,7 +58,7 @@ typedef struct isegmi_conv_desc {
                                         fp16: 1: 256x256  2: 256x128  3: 128x128  4: 64x64  5: 64x128  6: 64x256  7: 128x256  8: 128x64  9: 192x256  10: 192x128  11: 160x256;
                                         12/13/14/16: 192x256, 256x256, 256x128, 160x256 with 4 loader waves, 17: 192x256 as 12 MFMA + 4 loader waves, 19: 128x256 + 4, 20: 192x128 as 6 + 2;
                                         26/27/28/29: row-strip kernel for 3x3/1/1 (192x256, 256x128, 160x256, 192x256 on 12 MFMA waves) with 4 loader waves;
-                                        32/33/34/37/39: persistent forms of 12/13/14/17/19 (a block walks several tiles, the loader waves stream the next tile during the epilogue);
+                                        32/34/37/39: persistent forms of 12/14/17/19 (a block walks several tiles, the loader waves stream the next tile during the epilogue);
                                         + 2048 (test hook): persistent kernels on an 8-block grid */
     int32_t out_div;                 /* output pixels per "image" for addressing; 0 -> Ho*Wo */
     int64_t out_img_stride;          /* floats; 0 -> out_div*out_pix_stride */

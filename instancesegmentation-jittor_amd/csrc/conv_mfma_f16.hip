@@ -51,74 +51,102 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // Shared epilogue (fp32 math): y = fmaf(acc, scale, shift) + residual -> act -> fp16 (or fp32) NHWC store.  Vector path: each
 // wave transposes its 32-row fp32 strips through a private LDS region (all staging LDS is free by now) so that residual
 // loads and output stores are 16 B per lane; strided destinations / Cout % 8 != 0 take the per-element path.
+// vector path of conv_f16_epilogue (32-row strips through the wave's private LDS region).  RES: a residual is added -- its 16-B loads run
+// a rolling window of two passes ahead of their use (see epi8_prefetch: a load awaited on the spot also drains the previous pass's stores);
+// without a residual no load is issued at all (round 2 sent a dropped out-of-range load per pass and waited for it).
+template <int TM, int TN, bool RES>
+__device__ __forceinline__ void conv_f16_epilogue_vec(const ConvKH& p, f32x16h (&acc)[TM][TN], char* smemg, int wave, int lane, int wm, int wn, int m0, int n0) {
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr int PITCH = TN * 32 + 4;
+    constexpr int LPR = TN * 4, RPP = 64 / LPR, NPASS = 32 / RPP, NQ = TM * NPASS, D = 2 < NQ ? 2 : NQ;
+    const int lr = lane & 31, lh = lane >> 5;
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)(RES ? (const void*)p.res : (const void*)p.out), 0, RES ? p.res_bytes : 0u, 0x00020000);
+    const unsigned esz = p.out_f32 ? 4u : 2u;
+    float* ew = (float*)smemg + wave * 32 * PITCH;
+    const int er = lane / LPR, ec = (lane % LPR) * 8;
+    const int co8 = n0 + wn * TN * 32 + ec;
+    const bool cok8 = co8 < p.Cout;
+    // pass q covers tile rows RPP q ..: a lane's offsets advance by one stride per pass; rows past M are behind the descriptors' ranges
+    // (contiguous destinations; strided ones take the general arithmetic)
+    const unsigned rstep = (unsigned)p.Cout * (2u * RPP), ostep = (unsigned)p.out_pix_stride * esz * RPP;
+    unsigned rnext = cok8 ? ((unsigned)(m0 + wm * TM * 32 + er) * (unsigned)p.Cout + (unsigned)co8) * 2u : OOB;
+    unsigned onext = cok8 ? ((unsigned)(m0 + wm * TM * 32 + er) * (unsigned)p.out_pix_stride + (unsigned)co8) * esz : OOB;
+    u32x4h rw[D];
+    if (RES) {
+#pragma unroll
+        for (int q = 0; q < D; ++q) { rw[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, rnext, 0, 0); rnext += rstep; }
+    }
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int co = n0 + (wn * TN + b) * 32 + lr;
+            const bool cok = co < p.Cout;
+            const float sc = (cok && p.scale) ? p.scale[co] : 1.0f;
+            const float sh = (cok && p.shift) ? p.shift[co] : 0.0f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) ew[((e & 3) + 8 * (e >> 2) + 4 * lh) * PITCH + b * 32 + lr] = fmaf(acc[a][b][e], sc, sh);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int q = a * NPASS + ps;
+            const int rr = ps * RPP + er;
+            const f32x4h v0 = *(const f32x4h*)(ew + rr * PITCH + ec);
+            const f32x4h v1 = *(const f32x4h*)(ew + rr * PITCH + ec + 4);
+            unsigned ooff;
+            if (p.contiguous) { ooff = onext; onext += ostep; }
+            else {
+                const int m = m0 + wm * TM * 32 + q * RPP + er;
+                const int ni = m / p.out_div, pi = m - ni * p.out_div;
+                ooff = (m < p.M && cok8) ? (unsigned)(((int64_t)ni * p.out_img_stride + (int64_t)pi * p.out_pix_stride + co8) * esz) : OOB;
+            }
+            float y[8];
+            if (RES) {
+                const f16x8 rh = __builtin_bit_cast(f16x8, rw[q % D]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) y[i] = (i < 4 ? v0[i] : v1[i - 4]) + (float)rh[i];
+                if (q + D < NQ) { rw[q % D] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, rnext, 0, 0); rnext += rstep; }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) y[i] = i < 4 ? v0[i] : v1[i - 4];
+            }
+            if (p.act == 1) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) y[i] = y[i] > 0.0f ? y[i] : 0.0f;
+            }
+            if (p.out_f32) {
+                u32x4h o0, o1;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { o0[i] = __builtin_bit_cast(unsigned, y[i]); o1[i] = __builtin_bit_cast(unsigned, y[i + 4]); }
+                __builtin_amdgcn_raw_buffer_store_b128(o0, rs_out, ooff, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(o1, rs_out, ooff >= OOB ? OOB : ooff + 16u, 0, 0);
+            } else {
+                f16x8 o;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] = (half_t)y[i];
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4h, o), rs_out, ooff, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
 template <int TM, int TN>
 __device__ __forceinline__ void conv_f16_epilogue(const ConvKH& p, f32x16h (&acc)[TM][TN], char* smemg, int wave, int lane, int wm, int wn,
                                                   int m0, int n0) {
     constexpr unsigned OOB = 0x80000000u;
     const int lr = lane & 31, lh = lane >> 5;
-    // ---- epilogue (fp32 math): y = fmaf(acc, scale, shift) + residual -> act -> fp16 (or fp32) NHWC store
+    if (p.vec_epi) {  // uniform
+        if (p.res) conv_f16_epilogue_vec<TM, TN, true>(p, acc, smemg, wave, lane, wm, wn, m0, n0);
+        else conv_f16_epilogue_vec<TM, TN, false>(p, acc, smemg, wave, lane, wm, wn, m0, n0);
+        return;
+    }
+    // ---- per-element path (strided destinations with Cout % 8 != 0: the RPN / prediction heads): y = fmaf(acc, scale, shift) + residual -> act
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? (const void*)p.res : (const void*)p.out), 0, p.res ? p.res_bytes : 0u, 0x00020000);
     const unsigned esz = p.out_f32 ? 4u : 2u;
-    if (p.vec_epi) {
-        constexpr int PITCH = TN * 32 + 4;
-        constexpr int LPR = TN * 4, RPP = 64 / LPR, NPASS = 32 / RPP;
-        float* ew = (float*)smemg + wave * 32 * PITCH;
-        const int er = lane / LPR, ec = (lane % LPR) * 8;
-        const int co8 = n0 + wn * TN * 32 + ec;
-        const bool cok8 = co8 < p.Cout;
-#pragma unroll
-        for (int a = 0; a < TM; ++a) {
-#pragma unroll
-            for (int b = 0; b < TN; ++b) {
-                const int co = n0 + (wn * TN + b) * 32 + lr;
-                const bool cok = co < p.Cout;
-                const float sc = (cok && p.scale) ? p.scale[co] : 1.0f;
-                const float sh = (cok && p.shift) ? p.shift[co] : 0.0f;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) ew[((e & 3) + 8 * (e >> 2) + 4 * lh) * PITCH + b * 32 + lr] = fmaf(acc[a][b][e], sc, sh);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int ps = 0; ps < NPASS; ++ps) {
-                const int rr = ps * RPP + er;
-                const int m = m0 + (wm * TM + a) * 32 + rr;
-                const bool ok = m < p.M && cok8;
-                const f32x4h v0 = *(const f32x4h*)(ew + rr * PITCH + ec);
-                const f32x4h v1 = *(const f32x4h*)(ew + rr * PITCH + ec + 4);
-                const unsigned roff = ok ? ((unsigned)m * (unsigned)p.Cout + (unsigned)co8) * 2u : OOB;
-                const u32x4h rraw = __builtin_amdgcn_raw_buffer_load_b128(rs_res, roff, 0, 0);
-                const f16x8 rh = __builtin_bit_cast(f16x8, rraw);
-                unsigned ooff;
-                if (p.contiguous) ooff = ((unsigned)m * (unsigned)p.out_pix_stride + (unsigned)co8) * esz;
-                else {
-                    const int ni = m / p.out_div, pi = m - ni * p.out_div;
-                    ooff = (unsigned)(((int64_t)ni * p.out_img_stride + (int64_t)pi * p.out_pix_stride + co8) * esz);
-                }
-                if (!ok) ooff = OOB;
-                float y[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    float t = (i < 4 ? v0[i] : v1[i - 4]) + (float)rh[i];
-                    y[i] = p.act == 1 ? (t > 0.0f ? t : 0.0f) : t;
-                }
-                if (p.out_f32) {
-                    u32x4h o0, o1;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) { o0[i] = __builtin_bit_cast(unsigned, y[i]); o1[i] = __builtin_bit_cast(unsigned, y[i + 4]); }
-                    __builtin_amdgcn_raw_buffer_store_b128(o0, rs_out, ooff, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(o1, rs_out, ok ? ooff + 16u : OOB, 0, 0);
-                } else {
-                    f16x8 o;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) o[i] = (half_t)y[i];
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4h, o), rs_out, ooff, 0, 0);
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-        return;
-    }
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
         unsigned rowoff[16], resoff[16];
@@ -368,19 +396,57 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, OCC) void conv_f16_glds_kernel
 // scratch (the loader refills it only after barrier #t+1, which needs the MFMA waves), so no LDS is set aside for it.  The
 // epilogue transposes 8 rows at a time (2.2 KB per wave).  Tile order: virtual block v = bid + i * grid keeps v & 7 = bid & 7,
 // so the XCD-aware remap of the one-tile kernel applies to v unchanged.
+// Round 3: the residual of a tile is REQUESTED BEFORE its K loop and consumed strip by strip behind a rolling window.  Before, every
+// 8-row strip issued its residual load and waited for it on the spot -- and on gfx9 a wave's stores count in the same vmcnt as its loads, so
+// the wait also drained the previous strip's stores: eight exposed memory round trips per 64x64 wave tile, on layers whose K loop is four
+// 16-MFMA chunks (R101 res4 conv3: 14.7 % MfmaUtil at 3.9 TB/s, on neither roof).  Now the first EPI_D strips' residuals are in flight
+// during the K loop (the MFMA waves issue no other vector-memory instruction there), strip q's slot is refilled with strip q + EPI_D's
+// right after use, and the counted waits the compiler derives from program order never drain the stores of the strip just written.
+// Offsets: a lane's residual / output offset is ONE add per strip -- lane base (its row inside the strip, its 8 channels; the out-of-range
+// constant for a column past Cout) plus a wave-uniform row term; rows past M fall behind descriptors cut at M rows (contiguous
+// destinations; strided ones keep the general arithmetic).
+constexpr int EPI_D = 2;
+
 template <int TM, int TN>
-__device__ __forceinline__ void conv_f16_epilogue_rows8(const ConvKH& p, f32x16h (&acc)[TM][TN], float* ew, int lane, int wm, int wn, int m0, int n0) {
+struct Epi8 {
     static_assert(TN == 2 || TN == 4, "8-row strips are 64 or 128 channels wide");
+    static constexpr int LPR = TN * 4, RPP = 64 / LPR, NPASS = 8 / RPP, NQ = TM * 4 * NPASS;  // passes (b128 per lane) per wave tile
+    static constexpr int D = EPI_D < NQ ? EPI_D : NQ;
+    u32x4h r[D];
+    unsigned rnext;   // residual offset (bytes) of the next pass to request, or >= OOB for a column past Cout; pass q covers tile rows RPP q ..
+};
+
+// before the K loop: the first D residual passes of the wave's tile
+template <int TM, int TN>
+__device__ __forceinline__ void epi8_prefetch(const ConvKH& p, Epi8<TM, TN>& E, int lane, int wm, int wn, int m0, int n0) {
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr int LPR = Epi8<TM, TN>::LPR, RPP = Epi8<TM, TN>::RPP;
+    if (p.res == nullptr) return;  // uniform
+    const int er = lane / LPR, ec = (lane % LPR) * 8;
+    const int co8 = n0 + wn * TN * 32 + ec;
+    E.rnext = co8 < p.Cout ? ((unsigned)(m0 + wm * TM * 32 + er) * (unsigned)p.Cout + (unsigned)co8) * 2u : OOB;
+    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, p.res_bytes, 0x00020000);
+    const unsigned rstep = (unsigned)p.Cout * (2u * RPP);
+#pragma unroll
+    for (int q = 0; q < Epi8<TM, TN>::D; ++q) { E.r[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, E.rnext, 0, 0); E.rnext += rstep; }
+}
+
+template <int TM, int TN, bool RES>
+__device__ __forceinline__ void epi8_finish_impl(const ConvKH& p, f32x16h (&acc)[TM][TN], Epi8<TM, TN>& E, float* ew, int lane, int wm, int wn, int m0, int n0) {
     constexpr unsigned OOB = 0x80000000u;
     constexpr int PITCH = TN * 32 + 4;
-    constexpr int LPR = TN * 4, RPP = 64 / LPR, NPASS = 8 / RPP;
+    constexpr int LPR = Epi8<TM, TN>::LPR, RPP = Epi8<TM, TN>::RPP, NPASS = Epi8<TM, TN>::NPASS, NQ = Epi8<TM, TN>::NQ, D = Epi8<TM, TN>::D;
     const int lr = lane & 31, lh = lane >> 5;
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? (const void*)p.res : (const void*)p.out), 0, p.res ? p.res_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)(RES ? (const void*)p.res : (const void*)p.out), 0, RES ? p.res_bytes : 0u, 0x00020000);
     const unsigned esz = p.out_f32 ? 4u : 2u;
     const int er = lane / LPR, ec = (lane % LPR) * 8;
     const int co8 = n0 + wn * TN * 32 + ec;
     const bool cok8 = co8 < p.Cout;
+    const unsigned rstep = (unsigned)p.Cout * (2u * RPP);
+    // contiguous destination: offset = lane base + pass * step, rows past M are out of the descriptor's range
+    const unsigned ostep = (unsigned)p.out_pix_stride * esz * RPP;
+    unsigned onext = cok8 ? ((unsigned)(m0 + wm * TM * 32 + er) * (unsigned)p.out_pix_stride + (unsigned)co8) * esz : OOB;
     float sc[TN], sh[TN];
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
@@ -400,33 +466,37 @@ __device__ __forceinline__ void conv_f16_epilogue_rows8(const ConvKH& p, f32x16h
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int ps = 0; ps < NPASS; ++ps) {
+                const int q = (a * 4 + g) * NPASS + ps;
                 const int rr = ps * RPP + er;
-                const int m = m0 + (wm * TM + a) * 32 + 8 * g + rr;
-                const bool ok = m < p.M && cok8;
                 const f32x4h v0 = *(const f32x4h*)(ew + rr * PITCH + ec);
                 const f32x4h v1 = *(const f32x4h*)(ew + rr * PITCH + ec + 4);
-                const unsigned roff = ok ? ((unsigned)m * (unsigned)p.Cout + (unsigned)co8) * 2u : OOB;
-                const u32x4h rraw = __builtin_amdgcn_raw_buffer_load_b128(rs_res, roff, 0, 0);
-                const f16x8 rh = __builtin_bit_cast(f16x8, rraw);
                 unsigned ooff;
-                if (p.contiguous) ooff = ((unsigned)m * (unsigned)p.out_pix_stride + (unsigned)co8) * esz;
+                if (p.contiguous) { ooff = onext; onext += ostep; }
                 else {
+                    const int m = m0 + wm * TM * 32 + q * RPP + er;
                     const int ni = m / p.out_div, pi = m - ni * p.out_div;
-                    ooff = (unsigned)(((int64_t)ni * p.out_img_stride + (int64_t)pi * p.out_pix_stride + co8) * esz);
+                    ooff = (m < p.M && cok8) ? (unsigned)(((int64_t)ni * p.out_img_stride + (int64_t)pi * p.out_pix_stride + co8) * esz) : OOB;
                 }
-                if (!ok) ooff = OOB;
                 float y[8];
+                if (RES) {
+                    const f16x8 rh = __builtin_bit_cast(f16x8, E.r[q % D]);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    float t = (i < 4 ? v0[i] : v1[i - 4]) + (float)rh[i];
-                    y[i] = p.act == 1 ? (t > 0.0f ? t : 0.0f) : t;
+                    for (int i = 0; i < 8; ++i) y[i] = (i < 4 ? v0[i] : v1[i - 4]) + (float)rh[i];
+                    if (q + D < NQ) { E.r[q % D] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, E.rnext, 0, 0); E.rnext += rstep; }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) y[i] = i < 4 ? v0[i] : v1[i - 4];
+                }
+                if (p.act == 1) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) y[i] = y[i] > 0.0f ? y[i] : 0.0f;
                 }
                 if (p.out_f32) {
                     u32x4h o0, o1;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) { o0[i] = __builtin_bit_cast(unsigned, y[i]); o1[i] = __builtin_bit_cast(unsigned, y[i + 4]); }
                     __builtin_amdgcn_raw_buffer_store_b128(o0, rs_out, ooff, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(o1, rs_out, ok ? ooff + 16u : OOB, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(o1, rs_out, ooff >= OOB ? OOB : ooff + 16u, 0, 0);
                 } else {
                     f16x8 o;
 #pragma unroll
@@ -439,9 +509,23 @@ __device__ __forceinline__ void conv_f16_epilogue_rows8(const ConvKH& p, f32x16h
     }
 }
 
+template <int TM, int TN>
+__device__ __forceinline__ void epi8_finish(const ConvKH& p, f32x16h (&acc)[TM][TN], Epi8<TM, TN>& E, float* ew, int lane, int wm, int wn, int m0, int n0) {
+    if (p.res) epi8_finish_impl<TM, TN, true>(p, acc, E, ew, lane, wm, wn, m0, n0);   // uniform
+    else epi8_finish_impl<TM, TN, false>(p, acc, E, ew, lane, wm, wn, m0, n0);
+}
+
 template <int BM, int BN, int WM, int WN, int NSTAGE, int OCC, int LW>
-__global__ __launch_bounds__((WM * WN + LW) * 64, OCC) void conv_f16_persist_kernel(const ConvKH p) {
+__global__ __launch_bounds__((WM * WN + LW) * 64, OCC) void conv_f16_persist_kernel(const ConvKH p_arg) {
     static_assert(LW > 0 && NSTAGE >= 2 && NSTAGE <= 3, "loader waves, a 2- or 3-deep ring");
+    // Kernel arguments are read where they are used, per role: taken by value the ~45 dwords of ConvKH are all loaded at entry and stay
+    // live in SGPRs across both roles' loops (29 SGPR spills in round 2: the epilogue re-read its buffer descriptors with v_readlane before
+    // every store group).  Each role reads the fields it needs from the kernarg segment behind an opaque copy of its address (the empty asm
+    // keeps the loads from being hoisted back to the entry block); the epilogue's fields are re-read per tile, right in front of it.
+    (void)p_arg;
+    typedef const ConvKH __attribute__((address_space(4)))* karg_t;
+    karg_t kp0 = (karg_t)__builtin_amdgcn_kernarg_segment_ptr();
+    const int p_mtiles = kp0->mtiles, p_ntiles = kp0->ntiles, p_nchunks = kp0->nchunks;
     constexpr int NW = WM * WN, NL = LW;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int PA = BM / 8, PB = BN / 8;
@@ -456,18 +540,21 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, OCC) void conv_f16_persist_ker
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int total = p.mtiles * p.ntiles, G = (int)gridDim.x, bid = (int)blockIdx.x;
+    const int total = p_mtiles * p_ntiles, G = (int)gridDim.x, bid = (int)blockIdx.x;
     const int q8 = total >> 3, r8g = total & 7;
     auto tile_origin = [&](int v, int& m0, int& n0) {  // v = bid + i * G: same XCD as bid (G is a multiple of 8 or the whole grid)
         const int xcd = v & 7;
         const int logical = (xcd < r8g ? xcd * (q8 + 1) : r8g * (q8 + 1) + (xcd - r8g) * q8) + (v >> 3);
-        const int nt = logical % p.ntiles, mt = logical / p.ntiles;
+        const int nt = logical % p_ntiles, mt = logical / p_ntiles;
         m0 = mt * BM; n0 = nt * BN;
     };
     const int my_tiles = (total - bid + G - 1) / G;  // >= 1: the launcher never starts more blocks than tiles
 
     if (wave >= NW) {
         // ---------------- loader waves
+        karg_t kl = kp0;
+        asm volatile("" : "+s"(kl));
+        const ConvKH& p = *(const ConvKH*)kl;
         const int lw = wave - NW;
         const int r8 = lane >> 3, cs = lane & 7;
         const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
@@ -564,7 +651,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, OCC) void conv_f16_persist_ker
         return;
     }
 
-    // ---------------- MFMA waves
+    // ---------------- MFMA waves (K loop: tile geometry only; the epilogue reads its arguments per tile)
     const int wm = wave / WN, wn = wave % WN;
     const int lr = lane & 31, lh = lane >> 5;
     const int swz = lr * 128 + ((lh ^ ((lr >> 1) & 7)) << 4);  // k-step s adds ^ (s << 5)
@@ -603,15 +690,25 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, OCC) void conv_f16_persist_ker
             for (int b = 0; b < TN; ++b)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.0f;
+        Epi8<TM, TN> E;
+        {
+            karg_t k1 = kp0;
+            asm volatile("" : "+s"(k1));
+            const ConvKH& p = *(const ConvKH*)k1;
+            if (p.vec_epi) epi8_prefetch<TM, TN>(p, E, lane, wm, wn, m0, n0);  // the tile's first residual strips travel under its K loop
+        }
         int last = 0;
-        for (int t = 0; t < p.nchunks; ++t) {
+        for (int t = 0; t < p_nchunks; ++t) {
             asm volatile("s_barrier" ::: "memory");
             chunk(st);
             last = st;
             st = st + 1 == NSTAGE ? 0 : st + 1;
         }
         asm volatile("s_barrier" ::: "memory");  // E: every MFMA wave has read the last chunk; its stage is now scratch
-        if (p.vec_epi) conv_f16_epilogue_rows8<TM, TN>(p, acc, (float*)(smemg + last * STAGEB) + wave * 8 * (TN * 32 + 4), lane, wm, wn, m0, n0);
+        karg_t k2 = kp0;
+        asm volatile("" : "+s"(k2));
+        const ConvKH& p = *(const ConvKH*)k2;
+        if (p.vec_epi) epi8_finish<TM, TN>(p, acc, E, (float*)(smemg + last * STAGEB) + wave * 8 * (TN * 32 + 4), lane, wm, wn, m0, n0);
         else conv_f16_epilogue<TM, TN>(p, acc, smemg, wave, lane, wm, wn, m0, n0);  // per-element path: no LDS
     }
 }
@@ -963,7 +1060,7 @@ int conv2d_f16_launch(const isegmi_conv_desc* d, const void* in, const void* w, 
             {3, 128, 128, 2, 0.613, 176}, {4, 64, 64, 3, 0.642, 106}, {5, 64, 128, 3, 0.751, 79}, {6, 64, 256, 2, 0.452, 266}, {10, 192, 128, 2, 0.772, 91},
             {16, 160, 256, 1, 0.529, 200}, {20, 192, 128, 2, 0.300, 60},
             // persistent, 4 loader waves (32: 8 MFMA waves of 96x64; 37: 12 of 64x64)
-            {32, 192, 256, 1, 0.929, 447}, {33, 256, 256, 1, 0.423, 122}, {34, 256, 128, 1, 1.043, 127}, {37, 192, 256, 1, 1.197, 83}, {39, 128, 256, 1, 1.032, 99},
+            {32, 192, 256, 1, 0.929, 447}, {34, 256, 128, 1, 1.043, 127}, {37, 192, 256, 1, 1.197, 83}, {39, 128, 256, 1, 1.032, 99},
             // row-strip variants (3x3 / stride 1 / pad 1 only: ~2.7x fewer A bytes through the CU's fill path) + 4 loader waves; measured
             // level with tile 37 on every 3x3 layer of the sweep
             {26, 192, 256, 1, 1.18, 83}, {27, 256, 128, 1, 1.03, 127}, {28, 160, 256, 1, 0.5, 200}, {29, 192, 256, 1, 1.21, 83}};
@@ -1008,10 +1105,10 @@ int conv2d_f16_launch(const isegmi_conv_desc* d, const void* in, const void* w, 
         case 17: return launch_g<192, 256, 3, 4, 2, 1, false, 4>(k, st);  // 12 MFMA waves (64x64 each) + 4 loader waves
         case 19: return launch_g<128, 256, 2, 4, 3, 1, false, 4>(k, st);  // 128x256, 3-deep ring, 8 MFMA + 4 loader waves
         case 20: return launch_g<192, 128, 3, 2, 2, 2, false, 2>(k, st);  // 6 MFMA + 2 loader waves, 2 blocks/CU  // wave tile 160x32; 20 A pieces over 8 waves (partial round)
-        // persistent forms of 12 / 13 / 14 / 17 / 19 (loader waves stream the next tile during this tile's epilogue); the two-blocks-
+        // persistent forms of 12 / 14 / 17 / 19 (loader waves stream the next tile during this tile's epilogue; 13's 256x256 form was dropped in
+        // round 3: 128 accumulator registers + the residual window spill, and the cost model never chose it); the two-blocks-
         // per-CU tile 20 has no persistent form: 128 registers per wave do not hold its accumulators next to the tile loop (it spilled)
         case 32: return launch_p<192, 256, 2, 4, 2, 1, 4>(k, st, few);
-        case 33: return launch_p<256, 256, 2, 4, 2, 1, 4>(k, st, few);
         case 34: return launch_p<256, 128, 4, 2, 3, 1, 4>(k, st, few);
         case 37: return launch_p<192, 256, 3, 4, 2, 1, 4>(k, st, few);
         case 39: return launch_p<128, 256, 2, 4, 3, 1, 4>(k, st, few);

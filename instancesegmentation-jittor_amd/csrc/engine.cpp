@@ -164,11 +164,32 @@ int eng_input_consumed(Engine& e) {
 }
 
 // The consumer of an uploaded buffer (the front-end kernel for a uint8 staging buffer, the forward for an input slot) waits for the
-// upload_async that filled it -- and only for that one.
-int eng_wait_upload(Engine& e, const void* d_ptr, hipStream_t st) {
+// upload_async / front-end launches that filled [d_ptr, d_ptr + bytes) -- and only for those.
+int eng_wait_upload(Engine& e, const void* d_ptr, int64_t bytes, hipStream_t st) {
     const char* p = (const char*)d_ptr;
     for (auto& u : e.uploads)
-        if (!u.waited && p >= u.dst && p < u.dst + u.bytes) { HIP_TRY(hipStreamWaitEvent(st, u.done, 0)); u.waited = true; }
+        if (!u.waited && p < u.dst + u.bytes && u.dst < p + bytes) { HIP_TRY(hipStreamWaitEvent(st, u.done, 0)); u.waited = true; }
+    return ISEGMI_OK;
+}
+
+// Registers "the copy stream has, up to here, written [d_dst, d_dst + bytes)": one completion event per destination.
+static int eng_note_upload(Engine& e, const void* d_dst, int64_t bytes) {
+    Engine::Upload* u = nullptr;
+    for (auto& x : e.uploads) if (x.dst == (const char*)d_dst) u = &x;
+    if (!u) {
+        if (e.uploads.size() >= 64) {  // destinations come and go (staging buffers are re-allocated when they grow): recycle a consumed entry
+            for (auto& x : e.uploads) if (x.waited) { u = &x; break; }
+            if (u == nullptr) { set_error("more than 64 upload destinations with unconsumed uploads"); return ISEGMI_ERR_STATE; }
+        } else {
+            e.uploads.emplace_back();
+            u = &e.uploads.back();
+            HIP_TRY(hipEventCreateWithFlags(&u->done, hipEventDisableTiming));
+        }
+        u->dst = (const char*)d_dst;
+    }
+    u->bytes = bytes;
+    HIP_TRY(hipEventRecord(u->done, e.copy));
+    u->waited = false;
     return ISEGMI_OK;
 }
 
@@ -716,7 +737,7 @@ extern "C" int isegmi_yolact_forward(isegmi_engine* h, const float* d_images_nhw
     ARG_CHECK(h->e.kind == 1, "engine is not a yolact engine");
     ARG_CHECK(N > 0 && N <= h->e.max_batch, "batch size");
     Engine& e = h->e;
-    TRY(eng_wait_upload(e, d_images_nhwc3, e.stream));
+    TRY(eng_wait_upload(e, d_images_nhwc3, (int64_t)N * e.H * e.W * 3 * 4, e.stream));
     char key[96];
     snprintf(key, sizeof(key), "yolact:%d:%p", N, (const void*)d_images_nhwc3);
     const int rc = eng_graph_run(e, key, [&]() { return yolact_forward(e, d_images_nhwc3, N); });
@@ -767,31 +788,30 @@ extern "C" int isegmi_engine_upload_async(isegmi_engine* h, void* d_dst, const v
     Engine& e = h->e;
     if (e.in_pending) { HIP_TRY(hipStreamWaitEvent(e.copy, e.in_done, 0)); e.in_pending = false; }
     HIP_TRY(hipMemcpyAsync(d_dst, h_src, (size_t)bytes, hipMemcpyHostToDevice, e.copy));
-    Engine::Upload* u = nullptr;
-    for (auto& x : e.uploads) if (x.dst == (const char*)d_dst) u = &x;
-    if (!u) {
-        if (e.uploads.size() >= 8) {  // destinations come and go (staging buffers are re-allocated when they grow): recycle a consumed entry
-            for (auto& x : e.uploads) if (x.waited) { u = &x; break; }
-            ARG_CHECK(u != nullptr, "more than 8 upload destinations with unconsumed uploads");
-        } else {
-            e.uploads.emplace_back();
-            u = &e.uploads.back();
-            HIP_TRY(hipEventCreateWithFlags(&u->done, hipEventDisableTiming));
-        }
-        u->dst = (const char*)d_dst;
-    }
-    u->bytes = bytes;
-    HIP_TRY(hipEventRecord(u->done, e.copy));
-    u->waited = false;
-    return ISEGMI_OK;
+    return eng_note_upload(e, d_dst, bytes);
 }
 
-// Device front end on the engine's main stream (behind any upload_async, in front of the next forward): see preprocess_u8_kernel.
+// Device front end (see preprocess_u8_kernel).  When its uint8 source is the destination of a pending upload_async the kernel goes to the
+// COPY stream, right behind that copy: batch i+1's transform then runs under forward i instead of sitting in the main stream in front of
+// it (where it would hold forward i back until upload i+1 has crossed PCIe), and the forward that takes d_out as its input waits for it
+// like for an upload.  Otherwise (synchronous isegmi_h2d of the bytes) it runs on the main stream, in front of the next forward.
 extern "C" int isegmi_engine_preprocess_u8(isegmi_engine* h, const uint8_t* d_u8, int N, int Hin, int Win, float* d_out, int Hout, int Wout,
                                            int Hpad, int Wpad, int64_t out_img_stride, const float* mean3, const float* std3, int swap_rb) {
-    ARG_CHECK(h, "null");
-    TRY(eng_wait_upload(h->e, d_u8, h->e.stream));
-    return preprocess_u8_launch(d_u8, N, Hin, Win, d_out, Hout, Wout, Hpad, Wpad, out_img_stride, mean3, std3, swap_rb, h->e.stream);
+    ARG_CHECK(h && N > 0, "preprocess args");
+    Engine& e = h->e;
+    const int64_t src_bytes = (int64_t)N * Hin * Win * 3, dst_bytes = (int64_t)N * out_img_stride * 4;
+    bool on_copy = false;  // the source holds an upload the main stream has not been ordered behind: stay on the copy stream, behind it
+    for (auto& u : e.uploads) {
+        const char* p = (const char*)d_u8;
+        if (!u.waited && p < u.dst + u.bytes && u.dst < p + src_bytes) on_copy = true;
+    }
+    if (on_copy) {
+        // d_out's previous reader is fenced by upload_async's wait on in_done, which precedes the copy in this stream
+        TRY(preprocess_u8_launch(d_u8, N, Hin, Win, d_out, Hout, Wout, Hpad, Wpad, out_img_stride, mean3, std3, swap_rb, e.copy));
+        return eng_note_upload(e, d_out, dst_bytes);
+    }
+    TRY(eng_wait_upload(e, d_u8, src_bytes, e.stream));
+    return preprocess_u8_launch(d_u8, N, Hin, Win, d_out, Hout, Wout, Hpad, Wpad, out_img_stride, mean3, std3, swap_rb, e.stream);
 }
 
 // Records a completion mark for the step just enqueued on the stream its results finish on; isegmi_engine_step_times returns

@@ -131,7 +131,7 @@ int eng_graph_run(Engine& e, const std::string& key, const std::function<int()>&
 void eng_graph_reset(Engine& e);
 int eng_tail_end(Engine& e);
 int eng_input_consumed(Engine& e);  // call right after the last kernel that reads the caller's input buffer
-int eng_wait_upload(Engine& e, const void* d_ptr, hipStream_t st);
+int eng_wait_upload(Engine& e, const void* d_ptr, int64_t bytes, hipStream_t st);  // st waits for every pending upload / front-end write into [d_ptr, d_ptr + bytes)
 int eng_stage_small(Engine& e, const void* h_src, size_t bytes, void* d_dst, hipStream_t st);  // host array -> pinned ring slot -> async H2D on st
 hipStream_t eng_results_stream(Engine& e);  // the stream the last forward's results complete on  // st waits for a pending upload_async whose destination holds d_ptr
 int eng_conv_stem_f16(Engine& e, const std::string& layer, const Tensor& halo, int H, int W, const std::string& out_name, Tensor* out);

@@ -512,7 +512,7 @@ extern "C" int isegmi_maskrcnn_forward_canvas(isegmi_engine* h, const float* d_i
         ARG_CHECK(h_image_hw[2 * i] > 0 && h_image_hw[2 * i] <= H && h_image_hw[2 * i + 1] > 0 && h_image_hw[2 * i + 1] <= W,
                   "image_hw must fit inside the padded canvas");
     Engine& e = h->e;
-    TRY(eng_wait_upload(e, d_images, e.stream));
+    TRY(eng_wait_upload(e, d_images, (int64_t)N * H * W * 3 * 4, e.stream));
     TRY(maskrcnn_set_image_hw(e, h_image_hw, N));
     e.cur_H = H; e.cur_W = W;
     char key[160];  // everything a captured graph bakes in: batch, canvas, input pointer, and which of the two image_hw buffers is current

@@ -16,7 +16,7 @@ CASES = [(2, 19, 23, 64, 48, 3, 1, 1), (3, 14, 14, 128, 96, 3, 1, 1), (1, 30, 30
 
 # 32-40: the persistent loader-wave kernels; + 2048 = their test hook, an 8-block grid, so that these small shapes make a block walk
 # several tiles (the stream of the next tile entering the ring during the epilogue of this one)
-PERSIST = [32, 33, 34, 37, 39]
+PERSIST = [32, 34, 37, 39]
 
 
 @pytest.mark.parametrize("case", CASES)

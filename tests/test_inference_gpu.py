@@ -67,7 +67,7 @@ def test_one_engine_six_canvases_match_oracle(ffi, sd):
     from isegmi.transforms import maskrcnn_resize
     from oracle.maskrcnn_ref import MaskRCNNRef
     rng = np.random.default_rng(17)
-    shapes = [(150, 200), (200, 150), (120, 200), (100, 100), (90, 200), (200, 130)]
+    shapes = [(150, 200), (200, 150), (120, 200), (100, 100), (100, 250), (200, 130)]
     demo = COCODemo(None, min_image_size=160, confidence_threshold=0.0, state_dict=sd, max_image_size=288, max_batch=1)
     eng = demo.engine()
     mem0 = eng.memory()
@@ -142,17 +142,23 @@ def test_yolact_evaluate_matches_host_path(ffi):
     shapes = [(120, 160), (90, 200), (160, 120), (120, 160), (100, 100)]
     images = _images(rng, shapes)
     net = Yolact(yolact_state_dict(1234), max_batch=3, input_size=200)
-    host = []
-    for i, im in enumerate(images):
-        preds = net(im[None])
-        classes, scores, boxes, masks = postprocess(preds, im.shape[1], im.shape[0], score_threshold=0.15)
-        host += yolact_results(i, classes[:15], scores[:15], boxes[:15], masks[:15])
-    assert len(host) > 5
+    def host_path(thr, top_k):
+        out = []
+        for i, im in enumerate(images):
+            preds = net(im[None])
+            classes, scores, boxes, masks = postprocess(preds, im.shape[1], im.shape[0], score_threshold=thr)
+            out += yolact_results(i, classes[:top_k], scores[:top_k], boxes[:top_k], masks[:top_k])
+        return out
+    host = host_path(0.0, 15)
+    assert len(host) == 15 * len(images)
+    thr = float(np.median([d["score"] for d in host]))   # --score_threshold on the records: about half of the detections pass
+    host_thr = host_path(thr, 100)
+    assert 0 < len(host_thr)
     st = {}
-    got = evaluate(net, images, batch_size=3, score_threshold=0.15, top_k=15, stats=st)
+    got = evaluate(net, images, batch_size=3, score_threshold=0.0, top_k=15, stats=st)
     assert st["steps"] == 2
     _same(got, host)
-    _same(evaluate(net, images, batch_size=2, score_threshold=0.15, top_k=15, force_gather=True), host)
+    _same(evaluate(net, images, batch_size=2, score_threshold=thr, top_k=100, force_gather=True), host_thr)
     net.close()
 
 
