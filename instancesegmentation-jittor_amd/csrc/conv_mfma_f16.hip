@@ -421,11 +421,12 @@ template <int TM, int TN>
 __device__ __forceinline__ void epi8_prefetch(const ConvKH& p, Epi8<TM, TN>& E, int lane, int wm, int wn, int m0, int n0) {
     constexpr unsigned OOB = 0x80000000u;
     constexpr int LPR = Epi8<TM, TN>::LPR, RPP = Epi8<TM, TN>::RPP;
-    if (p.res == nullptr) return;  // uniform
+    // no branch on p.res here: a conditional prefetch makes the window a phi, and the compiler then parks the loaded registers in copies
+    // behind an s_waitcnt vmcnt(0) in FRONT of the K loop; without a residual the descriptor is empty and the loads return zeros unused
     const int er = lane / LPR, ec = (lane % LPR) * 8;
     const int co8 = n0 + wn * TN * 32 + ec;
     E.rnext = co8 < p.Cout ? ((unsigned)(m0 + wm * TM * 32 + er) * (unsigned)p.Cout + (unsigned)co8) * 2u : OOB;
-    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, p.res_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? (const void*)p.res : (const void*)p.out), 0, p.res ? p.res_bytes : 0u, 0x00020000);
     const unsigned rstep = (unsigned)p.Cout * (2u * RPP);
 #pragma unroll
     for (int q = 0; q < Epi8<TM, TN>::D; ++q) { E.r[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, E.rnext, 0, 0); E.rnext += rstep; }

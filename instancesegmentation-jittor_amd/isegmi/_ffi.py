@@ -20,8 +20,10 @@ _lib = None
 
 
 def lib():
-    global _lib
+    global _lib, LIB_PATH
     if _lib is None:
+        if os.environ.get("ISEGMI_LIB"):  # development hook: same-box A/B of two builds of libisegmi.so (tools/ab_f16.sh)
+            LIB_PATH = os.environ["ISEGMI_LIB"]
         if not os.path.exists(LIB_PATH):
             raise IsegmiError(
                 "libisegmi.so not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "

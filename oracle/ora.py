@@ -280,3 +280,9 @@ def rle_to_string(counts):
     lib().ora_rle_to_string.restype = L
     n = lib().ora_rle_to_string(_p(c), L(c.size), buf)
     return buf.raw[:n].decode("ascii")
+
+
+def set_conv_sum_mode(mode):
+    """0: the oracle's k-ordered fmaf chain (default); 1: 16-term partial sums added to the accumulator -- a second, equally valid fp32
+    association, used ONLY to measure how far two correct evaluations of the fp16-storage network drift apart (ora_set_conv_sum_mode)."""
+    lib().ora_set_conv_sum_mode(I(int(mode)))

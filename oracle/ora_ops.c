@@ -126,6 +126,14 @@ ORA_API void ora_map_f32(const float* x, float* y, int64_t n, int fn) {
  * Output element (n, p=ho*Wo+wo, co) is written at
  *   out[n*out_img_stride + p*out_pix_stride + co].
  * Reached from README.md:331 (run_on_opencv_image) / README.md:243 (eval.py). */
+/* Summation-order switch of ora_conv2d (default 0 = THE oracle: one k-ordered fmaf chain per output).  Mode 1 restates the same sum in
+ * another, equally valid fp32 association -- the one an f16 MFMA implies: every run of 16 consecutive k is summed on its own from +0 and
+ * the partial sum is then added to the accumulator.  It exists only to MEASURE how far two correct fp32 evaluations of the fp16-storage
+ * network drift apart (tests/test_maskrcnn_e2e_gpu.py derives the fp16 path's tolerance from it); nothing is ever checked against mode 1
+ * as if it were the truth. */
+static int g_conv_sum_mode = 0;
+ORA_API void ora_set_conv_sum_mode(int mode) { g_conv_sum_mode = mode; }
+
 ORA_API void ora_conv2d(const float* in, int N, int H, int W, int Cin,
                         const float* w, int Cout, int R, int S, int stride, int pad,
                         const float* scale, const float* shift, const float* residual, int act,
@@ -168,6 +176,25 @@ ORA_API void ora_conv2d(const float* in, int N, int H, int W, int Cin,
                                               : zrow;
                             }
                             const float* wk = wt + (size_t)((r * S + s) * Cin) * Cp + cb;
+                            if (g_conv_sum_mode == 1 && Cin % 16 == 0) {  /* 16-term partial sums (see ora_set_conv_sum_mode) */
+                                for (int c0 = 0; c0 < Cin; c0 += 16) {
+                                    float part[PB][32];
+                                    memset(part, 0, sizeof(part));
+                                    for (int c = c0; c < c0 + 16; ++c, wk += Cp)
+                                        for (int p = 0; p < PB; ++p) {
+                                            const float a = rows[p][c];
+                                            for (int j = 0; j < 32; ++j) part[p][j] = fmaf(a, wk[j], part[p][j]);
+                                        }
+                                    for (int p = 0; p < PB; ++p) {
+#ifdef __AVX2__
+                                        for (int j = 0; j < 4; ++j) acc[p][j] = _mm256_add_ps(acc[p][j], _mm256_loadu_ps(part[p] + 8 * j));
+#else
+                                        for (int j = 0; j < 32; ++j) acc[p][j] += part[p][j];
+#endif
+                                    }
+                                }
+                                continue;
+                            }
                             for (int c = 0; c < Cin; ++c, wk += Cp) {
 #ifdef __AVX2__
                                 const __m256 w0 = _mm256_load_ps(wk), w1 = _mm256_load_ps(wk + 8),

@@ -180,16 +180,34 @@ def test_maskrcnn_full_size_bs2_bit_exact(ffi, sd):
     model.close()
 
 
+def _match(ref_det, box, label, score):
+    """reference detections matched by a detection of the same label at IoU >= 0.9 -> (matched mask, index of the partner, |score difference| of the matches)"""
+    n = len(ref_det["score"])
+    if n == 0 or len(score) == 0:
+        return np.zeros(n, bool), np.zeros(n, np.int64), np.zeros(0, np.float32)
+    iou = _iou(ref_det["box"], box)
+    ok = (iou >= 0.9) & (ref_det["label"][:, None] == np.asarray(label)[None, :])
+    j = np.argmax(np.where(ok, iou, -1.0), axis=1)
+    m = ok.any(axis=1)
+    return m, j, np.abs(ref_det["score"][m] - np.asarray(score)[j[m]])
+
+
 def test_maskrcnn_r101_fp16_bs8_full_size(ffi):
-    """BASELINE configs[4] per-GPU shape: R101-FPN, fp16 storage / f16 MFMA, eight 1333x800 images per forward, 1000 proposals.
-    Image 0 is compared with the fp16-emulating oracle under the tolerance stated in
-    test_maskrcnn_fp16_path_close_to_fp16_oracle (features 5e-3 of the tensor's max; >= 90 % of the oracle's detections matched
-    at IoU >= 0.9, same label, |score diff| <= 0.03); all eight images are checked for the properties that do not need the
-    oracle: 1000 proposals, counts within the cap, boxes inside the image, class-major / score-descending order, labels in range, masks in [0, 1],
-    and determinism of a second forward (the tile family, and with it the fp16 summation grouping, depends on the batch size, so
-    a batch-of-one rerun is not required to be bit-identical in this mode)."""
+    """BASELINE configs[4] per-GPU shape: R101-FPN, fp16 storage / f16 MFMA, eight 1333x800 images per forward, 1000 proposals -- ALL EIGHT
+    images against the fp16-emulating oracle, under a tolerance that is DERIVED, not picked ("fp16 tolerance"):
+
+    the engine and the oracle round to fp16 at the same points and multiply exactly; they differ only in the fp32 ASSOCIATION of each
+    convolution's sum (the f16 MFMA adds sixteen products at a time, the oracle walks one chain).  Either association is a correct fp32
+    evaluation, so the yardstick is how far two correct evaluations drift apart: the oracle is run a second time with 16-term partial sums
+    (ora.set_conv_sum_mode(1); ~1e-6 per layer, amplified by fp16 re-rounding -- one fp16 ulp is 4.9e-4 -- over ~105 layers) and the engine
+    must stay within 3x of the oracle's own drift on every measure: FPN features (max error relative to the tensor's max), the share of
+    the oracle's detections found again (same label, IoU >= 0.9), the score differences of those, and their 28x28 masks.  north_star's 1e-4
+    on scores is an fp32 statement; what fp16 storage does to it is printed by this test (measured, not assumed).
+    Also checked on all eight: 1000 proposals, counts within the cap, boxes inside the image, class-major / score-descending order, labels
+    in range, masks in [0, 1], determinism of a second forward."""
     from isegmi.maskrcnn import MaskRCNN, MaskRCNNConfig, prepare_images
     from isegmi.weights import maskrcnn_state_dict
+    from oracle import ora
     sd101 = maskrcnn_state_dict(1234, depth=101)
     rng = np.random.default_rng(20261003)
     imgs = [rng.uniform(0, 255, (800, 1333, 3)).astype(np.float32) for _ in range(8)]
@@ -198,6 +216,7 @@ def test_maskrcnn_r101_fp16_bs8_full_size(ffi):
     out = model(x, hw)
     names = ("det.count", "det.score", "det.label", "det.box", "det.mask28", "proposal_count")
     first = {k: model.fetch(k, 8) for k in names}
+    gP = {nm: model.fetch(nm, 8).astype(np.float32) for nm in ("P2", "P5")}
     assert (first["proposal_count"] == 1000).all()
     for n in range(8):
         bl = out[n]
@@ -215,28 +234,55 @@ def test_maskrcnn_r101_fp16_bs8_full_size(ffi):
         assert all((np.diff(sc[lab == c_]) <= 0).all() for c_ in np.unique(lab))
         m = bl.get_field("mask")
         assert m.shape == (c, 1, 28, 28) and (m >= 0).all() and (m <= 1).all()
-    out2 = model(x, hw)  # determinism
+    model(x, hw)  # determinism
     for k in names:
         assert np.array_equal(model.fetch(k, 8), first[k]), k
-    ref = MaskRCNNRef(sd101, depth=101, fp16=True)
-    rd = ref.forward(x[:1], hw[:1])[0]
-    for name in ("P2", "P5"):
-        g = model.fetch(name, 1).astype(np.float32)
-        r = ref.feats[name]
-        assert np.abs(g - r).max() <= 5e-3 * np.abs(r).max(), name
-    bl = out[0]
-    assert abs(len(bl) - len(rd["score"])) <= 5
-    iou = _iou(rd["box"], bl.bbox)
-    same = rd["label"][:, None] == bl.get_field("labels")[None, :]
-    close = np.abs(rd["score"][:, None] - bl.get_field("scores")[None, :]) <= 0.03
-    matched = np.any((iou >= 0.9) & same & close, axis=1)
-    assert matched.mean() >= 0.9, matched.mean()
-    j = np.argmax(np.where(same & close, iou, -1), axis=1)
-    d = np.abs(bl.get_field("mask")[j[matched], 0] - rd["mask28"][matched])
-    assert np.percentile(d, 99) <= 0.05
     model.paste_device(800, 1333); model.sync()
     assert model.fetch("det.masks", 8).any()
     model.close()
+
+    # ---- the oracle, twice: its own chain (the reference) and the 16-term association (the yardstick)
+    ref = MaskRCNNRef(sd101, depth=101, fp16=True)
+    rd = ref.forward(x, hw)
+    rP = {nm: ref.feats[nm] for nm in ("P2", "P5")}
+    ora.set_conv_sum_mode(1)
+    try:
+        ref2 = MaskRCNNRef(sd101, depth=101, fp16=True)
+        rd2 = ref2.forward(x, hw)
+        r2P = {nm: ref2.feats[nm] for nm in ("P2", "P5")}
+    finally:
+        ora.set_conv_sum_mode(0)
+    F = 3.0   # the engine may drift at most this many times further from the oracle than the oracle's second association does
+    ULP = 2.0 ** -11
+    e_self_max = e_gpu_max = 0.0
+    for nm in ("P2", "P5"):
+        for n in range(8):
+            top = np.abs(rP[nm][n]).max()
+            e_self, e_gpu = np.abs(r2P[nm][n] - rP[nm][n]).max() / top, np.abs(gP[nm][n] - rP[nm][n]).max() / top
+            assert e_gpu <= F * max(e_self, ULP), (nm, n, e_gpu, e_self)
+            e_self_max, e_gpu_max = max(e_self_max, float(e_self)), max(e_gpu_max, float(e_gpu))
+    ds_self, ds_gpu, dm_self, dm_gpu = [], [], [], []
+    for n in range(8):
+        bl = out[n]
+        g_lab, g_sc, g_mask = bl.get_field("labels").astype(rd[n]["label"].dtype), bl.get_field("scores"), bl.get_field("mask")[:, 0]
+        m_s, j_s, d_s = _match(rd[n], rd2[n]["box"], rd2[n]["label"], rd2[n]["score"])
+        m_g, j_g, d_g = _match(rd[n], bl.bbox, g_lab, g_sc)
+        assert abs(len(bl) - len(rd[n]["score"])) <= max(5, F * abs(len(rd2[n]["score"]) - len(rd[n]["score"]))), n
+        # share of the reference's detections found again: the engine may fall short of 100 % by at most F x the yardstick's shortfall (+ 5 %)
+        assert m_g.mean() >= 1.0 - F * (1.0 - m_s.mean()) - 0.05, (n, m_g.mean(), m_s.mean())
+        ds_self.append(d_s); ds_gpu.append(d_g)
+        if m_s.any():
+            dm_self.append(np.abs(rd2[n]["mask28"][j_s[m_s]] - rd[n]["mask28"][m_s]).ravel())
+        if m_g.any():
+            dm_gpu.append(np.abs(g_mask[j_g[m_g]] - rd[n]["mask28"][m_g]).ravel())
+    ds_self, ds_gpu = np.concatenate(ds_self), np.concatenate(ds_gpu)
+    dm_self, dm_gpu = np.concatenate(dm_self), np.concatenate(dm_gpu)
+    p99 = lambda a: float(np.percentile(a, 99)) if len(a) else 0.0
+    print("fp16 path vs fp16-emulating oracle, 8 images: matched %d of %d; score |diff| p99 %.2e max %.2e (oracle's own drift: p99 %.2e max %.2e); "
+          "mask |diff| p99 %.2e (%.2e); P2 / P5 relative error: engine max %.2e, oracle's own drift max %.2e" % (
+              len(ds_gpu), sum(len(r["score"]) for r in rd), p99(ds_gpu), ds_gpu.max(), p99(ds_self), ds_self.max(), p99(dm_gpu), p99(dm_self),
+              e_gpu_max, e_self_max))
+    assert p99(ds_gpu) <= F * max(p99(ds_self), ULP) and p99(dm_gpu) <= F * max(p99(dm_self), ULP)
 
 
 def test_maskrcnn_back_to_back_forwards(ffi, sd):
