@@ -69,6 +69,14 @@ int maskrcnn_set_image_hw(Engine& e, const int32_t* h_image_hw, int N) {
 
 static int maskrcnn_c4_forward(Engine& e, const float* d_images, int N);
 
+// rows of every per-image detection buffer: DETECTIONS_PER_IMG, or more when "detections_cap" is set -- upstream's kth-value rule keeps every
+// detection whose score ties with the 100th, so an image can return more than DETECTIONS_PER_IMG; the extra rows hold those ties
+int maskrcnn_det_cap(Engine& e) {
+    const int dpi = (int)e.param("detections_per_img", 100);
+    const int cap = (int)e.param("detections_cap", 0.0f);
+    return cap > dpi ? cap : dpi;
+}
+
 // Anchors of one level for the current canvas: the host sets the A base anchors ("anchor_base.<l>", generate_anchors) and the stride
 // ("anchor_stride<l>"); the grid is laid out on the device whenever the canvas changed (always under graph capture, so that a replayed graph
 // never depends on which canvas ran last).  Runs on the main stream, after the forward's WAR wait on the previous forward's tail.
@@ -157,7 +165,9 @@ int maskrcnn_forward(Engine& e, const float* d_images, int N) {
     const int fpn_post = (int)e.param("rpn_fpn_post_nms_top_n", 1000);
     const float rpn_thr = e.param("rpn_nms_thresh", 0.7f), rpn_min = e.param("rpn_min_size", 0.0f);
     const int ge = (int)e.param("nms_ge", 0);
-    if (pre_nms > 1024 || post_nms > 1024 || fpn_post > 1024) { set_error("RPN top-n values above 1024 are not supported"); return ISEGMI_ERR_ARG; }
+    // per level up to 6144 (above 1024 the single-block NMS with 96 KB of boxes in LDS takes over from the chip-wide bitmask NMS); the merged
+    // list feeds the per-class box NMS, whose suppression matrix holds 1024 proposals per image
+    if (pre_nms > 6144 || post_nms > 6144 || fpn_post > 1024) { set_error("RPN: PRE / POST_NMS_TOP_N_TEST <= 6144 per level, FPN_POST_NMS_TOP_N_TEST <= 1024"); return ISEGMI_ERR_ARG; }
     float *cand_boxes, *cand_scores;
     int *cand_cnt, *cand_total;
     TRY(eng_buf(e, "rpn.cand_boxes", (int64_t)N * L * post_nms * 16, &p, 0, {N, L * post_nms, 4})); cand_boxes = (float*)p;
@@ -254,7 +264,7 @@ int maskrcnn_forward(Engine& e, const float* d_images, int N) {
     TRY(eng_conv(e, "roi_heads.box.feature_extractor.fc6", roi7, 1, 0, 1, nullptr, "box.fc6", &f6));
     TRY(eng_conv(e, "roi_heads.box.feature_extractor.fc7", f6, 1, 0, 1, nullptr, "box.fc7", &f7));
     TRY(eng_conv(e, "roi_heads.box.predictor.cls_bbox", f7, 1, 0, 0, nullptr, "box.cls_bbox", &cb, /*out_f32=*/true));
-    const int ncls = 81, cap = (int)e.param("detections_per_img", 100), dpi = cap;
+    const int ncls = 81, dpi = (int)e.param("detections_per_img", 100), cap = maskrcnn_det_cap(e);
     if (cb.C != ncls * 5) { set_error("cls_bbox layer must have 81+324 outputs"); return ISEGMI_ERR_STATE; }
     isegmi_box_post_args a;
     memset(&a, 0, sizeof(a));
@@ -423,7 +433,7 @@ static int maskrcnn_c4_forward(Engine& e, const float* d_images, int N) {
     TRY(eng_act(e, "box.pooled", N * R, 1, 1, f5.C, &pooled));
     TRY(avgpool_full_launch(f5.d, (int64_t)N * R, f5.H * f5.W, f5.C, pooled.d, st));
     TRY(eng_conv(e, "roi_heads.box.predictor.cls_bbox", pooled, 1, 0, 0, nullptr, "box.cls_bbox", &cb));
-    const int ncls = 81, cap = (int)e.param("detections_per_img", 100), dpi = cap;
+    const int ncls = 81, dpi = (int)e.param("detections_per_img", 100), cap = maskrcnn_det_cap(e);
     if (cb.C != ncls * 5) { set_error("cls_bbox layer must have 81+324 outputs"); return ISEGMI_ERR_STATE; }
     isegmi_box_post_args a;
     memset(&a, 0, sizeof(a));
@@ -473,7 +483,7 @@ static int maskrcnn_c4_forward(Engine& e, const float* d_images, int N) {
 int maskrcnn_paste(Engine& e, const float* h_ratios_wh, int out_h, int out_w) {
     const int N = e.last_N;
     if (N <= 0) { set_error("paste before forward"); return ISEGMI_ERR_STATE; }
-    const int cap = (int)e.param("detections_per_img", 100);
+    const int cap = maskrcnn_det_cap(e);
     void *p, *rb, *rt;
     TRY(eng_buf(e, "ws.ratios", (int64_t)e.max_batch * 8, &rt));
     hipStream_t ps = (e.multi_stream && e.tail_pending) ? e.tail : e.stream;  // results stream of the last forward
@@ -546,7 +556,7 @@ extern "C" int isegmi_maskrcnn_pack_records(isegmi_engine* h, void* d_dst, int64
     ARG_CHECK(e.kind == 2, "engine is not a Mask R-CNN engine");
     const int N = e.last_N;
     ARG_CHECK(N > 0, "pack before forward");
-    const int K = (int)e.param("detections_per_img", 100);
+    const int K = maskrcnn_det_cap(e);
     hipStream_t rs = (e.multi_stream && e.tail_pending) ? e.tail : e.stream;  // results stream
     const bool c4 = e.param("arch_c4", 0.0f) != 0.0f;  // MaskRCNNC4Predictor: 14x14 masks
     const int64_t msz = c4 ? 196 : 784;

@@ -26,7 +26,8 @@ int rle_encode_launch(const isegmi_rle_args* a, hipStream_t st);
         if (_rc) return _rc; \
     } while (0)
 
-static int det_cap(Engine& e) { return (int)(e.kind == 1 ? e.param("max_num_detections", 100) : e.param("detections_per_img", 100)); }
+int maskrcnn_det_cap(Engine& e);
+static int det_cap(Engine& e) { return e.kind == 1 ? (int)e.param("max_num_detections", 100) : maskrcnn_det_cap(e); }
 static int rle_cap_chars(Engine& e) { return (int)e.param("rle_cap_chars", 262144.0f * e.max_batch); }
 static int rle_cap_runs(Engine& e) {
     int c = (int)e.param("rle_cap_runs", 262144.0f * e.max_batch);

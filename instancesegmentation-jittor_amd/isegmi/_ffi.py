@@ -343,11 +343,12 @@ class BoxPostArgs(C.Structure):
                                           "d_out_boxes", "d_out_scores", "d_out_labels")]
 
 
-def box_postprocess(logits, regr, props, prop_cnt, image_hw, score_thr=0.05, nms_thr=0.5, det_per_img=100, nms_ge=0):
-    """logits [N,R,ncls], regr [N,R,4*ncls], props [N,R,4] -> list of (boxes, scores, labels)."""
+def box_postprocess(logits, regr, props, prop_cnt, image_hw, score_thr=0.05, nms_thr=0.5, det_per_img=100, nms_ge=0, cap=0):
+    """logits [N,R,ncls], regr [N,R,4*ncls], props [N,R,4] -> list of (boxes, scores, labels).  cap > det_per_img: rows for the detections
+    that tie with the det_per_img-th score (upstream's kth-value rule keeps them)."""
     logits = np.ascontiguousarray(logits, np.float32)
     N, R, ncls = logits.shape
-    cap = det_per_img
+    cap = max(det_per_img, cap)
     b = dict(d_logits=DeviceBuffer.from_numpy(logits), d_regr=DeviceBuffer.from_numpy(np.ascontiguousarray(regr, np.float32)),
              d_props=DeviceBuffer.from_numpy(np.ascontiguousarray(props, np.float32)),
              d_prop_cnt=DeviceBuffer.from_numpy(np.ascontiguousarray(prop_cnt, np.int32)),

@@ -34,6 +34,9 @@ class MaskRCNNConfig:
     ROI_SCORE_THRESH: float = 0.05
     ROI_NMS: float = 0.5
     DETECTIONS_PER_IMG: int = 100
+    DETECTIONS_CAP: int = 0  # rows per image in the detection buffers; 0 = DETECTIONS_PER_IMG.  upstream's kth-value cut keeps every detection that
+    #                          TIES with the 100th score, so an image can return more than DETECTIONS_PER_IMG: set e.g. 128 to receive those ties
+    #                          (the mask head then runs over that many RoI slots per image); with 0 ties past the 100th row are cut in output order
     NMS_GE: int = 0  # SURVEY App. A.6 switch: 0 suppress on iou > thr (CUDA kernel), 1 on >= (CPU loop)
     CONV_BODY: str = "R-50-FPN"  # "R-50-FPN" / "R-101-FPN" (depth) or "R-50-C4" (the yaml README.md:263-273 prints)
 
@@ -47,6 +50,10 @@ class MaskRCNNConfig:
     @property
     def is_c4(self):
         return self.CONV_BODY.endswith("-C4")
+
+    @property
+    def det_cap(self):
+        return max(self.DETECTIONS_PER_IMG, self.DETECTIONS_CAP)
 
 
 # ---------------------------------------------------------------------------------------- anchors (A.3)
@@ -197,7 +204,8 @@ class MaskRCNN:
         for k, v in (("resnet_depth", cfg.depth), ("rpn_pre_nms_top_n", cfg.RPN_PRE_NMS_TOP_N_TEST),
                      ("rpn_post_nms_top_n", cfg.RPN_POST_NMS_TOP_N_TEST), ("rpn_fpn_post_nms_top_n", cfg.RPN_FPN_POST_NMS_TOP_N_TEST),
                      ("rpn_nms_thresh", cfg.RPN_NMS_THRESH), ("rpn_min_size", cfg.RPN_MIN_SIZE), ("roi_score_thresh", cfg.ROI_SCORE_THRESH),
-                     ("roi_nms_thresh", cfg.ROI_NMS), ("detections_per_img", cfg.DETECTIONS_PER_IMG), ("nms_ge", cfg.NMS_GE)):
+                     ("roi_nms_thresh", cfg.ROI_NMS), ("detections_per_img", cfg.DETECTIONS_PER_IMG), ("detections_cap", cfg.DETECTIONS_CAP),
+                     ("nms_ge", cfg.NMS_GE)):
             self.set_param(k, float(v))
         self._d_in = _ffi.DeviceBuffer((max_batch, H, W, 3))
         self._hw = None

@@ -16,7 +16,7 @@ class RecordPipeline:
         caller's bookkeeping, empty image slots simply carry count 0); gather: an isegmi.dist.RcclGather sized net.coco_record_bytes(batch)."""
         self.net, self.batch, self.gather = net, int(batch), gather
         self.kind = net.KIND
-        self.K = int(net.cfg.max_num_detections if self.kind == 1 else net.cfg.DETECTIONS_PER_IMG)
+        self.K = int(net.cfg.max_num_detections if self.kind == 1 else net.cfg.det_cap)
         self.has_mscore = bool(self.kind == 1 and getattr(net, "has_maskiou", False))
         self.nbytes, self.chars_off = net.coco_record_bytes(self.batch)
         secs, coff, _ = coco_record_layout(self.batch, self.K, self.kind, self.has_mscore, 0)

@@ -5,7 +5,8 @@
 
 `cfg` is a MaskRCNNConfig (the handful of inference constants the path needs, keyed like the yaml).
 compute_prediction / select_top_predictions follow the upstream demo ([UPSTREAM-RECALL], SURVEY 3.1);
-overlay drawing is plain numpy (cv2 is not in the image): mask tint + box outline, no text.
+overlay drawing is numpy + PIL (cv2 is not in the image): mask tint, box outline and the "class score" label upstream's
+overlay_class_names writes at the box's top-left corner (PIL's built-in font instead of cv2.putText's Hershey face).
 """
 import numpy as np
 
@@ -96,6 +97,21 @@ class COCODemo:
             y1, y2 = max(0, min(H - 1, y1)), max(0, min(H - 1, y2))
             image[y1:y2 + 1, [x1, x2]] = colors[k]
             image[[y1, y2], x1:x2 + 1] = colors[k]
+        return self.overlay_class_names(image, predictions)
+
+    def overlay_class_names(self, image, predictions):
+        """demo/predictor.py overlay_class_names: "<class name>: <score>" in white at the top-left corner of every box (README.md:331-334:
+        the image run_on_opencv_image returns carries boxes, masks AND labels)."""
+        if len(predictions) == 0 or not predictions.has_field("scores"):
+            return image
+        from PIL import Image, ImageDraw
+        pil = Image.fromarray(np.ascontiguousarray(image[:, :, ::-1]))   # BGR -> RGB for PIL
+        draw = ImageDraw.Draw(pil)
+        scores, labels = predictions.get_field("scores").tolist(), predictions.get_field("labels").tolist()
+        for box, score, label in zip(predictions.bbox, scores, labels):
+            x, y = int(box[0]), int(box[1])
+            draw.text((max(0, x), max(0, y)), "%s: %.2f" % (self.CATEGORIES[int(label)], score), fill=(255, 255, 255))
+        image[...] = np.asarray(pil, np.uint8)[:, :, ::-1]
         return image
 
     def close(self):

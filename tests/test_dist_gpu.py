@@ -106,3 +106,65 @@ def test_rccl_queued_steps_without_host_sync(ffi):
             assert np.array_equal(rec["cls"][i, :c], ref["det.class"][i, :c])
             assert np.array_equal(rec["coeff"][i, :c], ref["det.coeff"][i, :c])
     g.close(); net.close()
+
+
+_TWO_RANK_WORKER = r'''
+import json, os, sys
+root, out = sys.argv[1], sys.argv[2]
+sys.path[:0] = [root, os.path.join(root, "instancesegmentation-jittor_amd")]
+import numpy as np
+from isegmi.predictor import COCODemo, inference
+from isegmi.weights import maskrcnn_state_dict
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+rng = np.random.default_rng(11)
+images = [rng.integers(0, 256, s + (3,)).astype(np.uint8) for s in [(150, 200), (200, 150), (150, 200), (120, 200), (150, 200)]]
+demo = COCODemo(None, min_image_size=160, confidence_threshold=0.0, state_dict=maskrcnn_state_dict(1234), max_image_size=288, max_batch=2, device=0)
+try:
+    res = inference(demo, images, batch_size=2, rank=rank, world=world)
+except Exception as e:  # RCCL may refuse two ranks on one device
+    open(out + ".err%d" % rank, "w").write(repr(e))
+    raise
+json.dump(res, open(out + ".%d" % rank, "w"))
+'''
+
+
+def test_two_ranks_share_one_gpu_through_rccl(ffi, tmp_path):
+    """SURVEY 8(e) on the hardware at hand: TWO processes (ranks 0 and 1 of a world of 2, file rendezvous, no torch) run the sharded
+    inference() on the ONE visible GPU and all-gather their record blocks through RCCL; both must end with the complete result list, equal to
+    the single-rank run.  (A real multi-GPU node is the driver's; RCCL builds that refuse two ranks on one device make this a skip.)"""
+    import json
+    import subprocess
+    import sys
+    import os
+    from isegmi.predictor import COCODemo, inference
+    from isegmi.weights import maskrcnn_state_dict
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "w.py"
+    script.write_text(_TWO_RANK_WORKER)
+    out = str(tmp_path / "res")
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_PORT="29777", ISEGMI_RUN_ID="t2r%d" % os.getpid(),
+                   ISEGMI_RDZV_DIR=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG="WARN")
+        procs.append(subprocess.Popen([sys.executable, str(script), root, out], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.skip("two ranks on one device did not finish (RCCL duplicate-device bring-up hangs on this build)")
+        logs.append(o.decode(errors="replace"))
+    if any(p.returncode != 0 for p in procs):
+        msg = "\n".join(l[-600:] for l in logs)
+        if "uplicate" in msg or "invalid usage" in msg.lower() or "ncclCommInitRank" in msg:
+            pytest.skip("this RCCL refuses two ranks on one device: " + msg[-300:])
+        pytest.fail(msg)
+    got = [json.load(open(out + ".%d" % r)) for r in range(2)]
+    rng = np.random.default_rng(11)
+    images = [rng.integers(0, 256, s + (3,)).astype(np.uint8) for s in [(150, 200), (200, 150), (150, 200), (120, 200), (150, 200)]]
+    demo = COCODemo(None, min_image_size=160, confidence_threshold=0.0, state_dict=maskrcnn_state_dict(1234), max_image_size=288, max_batch=2)
+    want = inference(demo, images, batch_size=2)
+    demo.close()
+    assert got[0] == got[1] == json.loads(json.dumps(want)) and len(want) > 20

@@ -249,6 +249,25 @@ def test_cocodemo_holds_exactly_one_engine(monkeypatch):
     small.close()
 
 
+def test_overlay_draws_mask_box_and_class_label():
+    """run_on_opencv_image's overlay (README.md:331-334): mask tint, box outline and the "class: score" text at the box corner"""
+    from isegmi.maskrcnn import BoxList
+    from isegmi.predictor import COCODemo
+    demo = COCODemo.__new__(COCODemo)
+    demo.confidence_threshold = 0.5
+    image = np.zeros((100, 160, 3), np.uint8)
+    bl = BoxList([[10, 20, 80, 90]], (160, 100))
+    bl.add_field("scores", np.array([0.87], np.float32)); bl.add_field("labels", np.array([1]))
+    m = np.zeros((1, 1, 100, 160), np.uint8); m[0, 0, 50:80, 30:60] = 1
+    bl.add_field("mask", m)
+    out = demo.overlay(image.copy(), bl)
+    color = COCODemo.compute_colors_for_labels([1])[0]
+    assert (out[20, 10:81] == color).all() and (out[20:91, 80] == color).all()          # box outline
+    assert (out[60, 40] == (0.5 * color).astype(np.uint8)).all()                         # tinted mask
+    text = (out[21:36, 11:75] > 180).all(-1)
+    assert text.sum() > 30, "the class label is written at the box's top-left corner"
+
+
 def test_bench_gpus_n_without_devices_fails_loudly():
     """`python bench.py --gpus 2` outside a torch.distributed environment starts its own two ranks; with no HIP device they fail,
     and the parent must exit non-zero without printing a JSON line (never a silent 1-GPU run reported as n_gpus=1)."""

@@ -139,8 +139,9 @@ def test_yolact_evaluate_matches_host_path(ffi):
     from isegmi.weights import yolact_state_dict
     from isegmi.yolact import Yolact, evaluate, postprocess
     rng = np.random.default_rng(12)
-    shapes = [(120, 160), (90, 200), (160, 120), (120, 160), (100, 100)]
-    images = _images(rng, shapes)
+    # random-weight Yolact fires on pixel noise only: images at or above the 200-px network size (the resize keeps their noise), all pure noise
+    shapes = [(240, 320), (200, 260), (320, 240), (240, 320), (200, 200)]
+    images = [rng.integers(0, 256, (h, w, 3)).astype(np.uint8) for h, w in shapes]
     net = Yolact(yolact_state_dict(1234), max_batch=3, input_size=200)
     def host_path(thr, top_k):
         out = []

@@ -112,6 +112,28 @@ def _iou(a, b):
     return inter / (aa[:, None] + ab[None, :] - inter)
 
 
+def test_maskrcnn_rpn_top_n_2000_and_detection_cap(ffi, sd):
+    """RPN PRE / POST_NMS_TOP_N_TEST = 2000 per level (above the chip-wide bitmask NMS's 1024: the 6144-box single-block NMS takes the level) and
+    a detection capacity above DETECTIONS_PER_IMG (rows for kth-value ties): still bit-exact against the oracle."""
+    import dataclasses
+    from isegmi.maskrcnn import MaskRCNN, MaskRCNNConfig, prepare_images
+    rng = np.random.default_rng(77)
+    x, hw = prepare_images([rng.uniform(0, 255, (250, 340, 3)).astype(np.float32), rng.uniform(0, 255, (256, 300, 3)).astype(np.float32)])
+    cfg = dataclasses.replace(MaskRCNNConfig(), RPN_PRE_NMS_TOP_N_TEST=2000, RPN_POST_NMS_TOP_N_TEST=2000, DETECTIONS_CAP=128)
+    model = MaskRCNN(sd, x.shape[1], x.shape[2], cfg=cfg, max_batch=2)
+    out = model(x, hw)
+    rd = MaskRCNNRef(sd, pre_nms=2000, post_nms=2000, fpn_post=1000).forward(x, hw)
+    pc = model.fetch("proposal_count", 2); pr = model.fetch("proposals", 2)
+    assert model.fetch("det.box", 2).shape == (2, 128, 4)
+    for n in range(2):
+        r = rd[n]
+        assert pc[n] == len(r["proposals"]) == 1000 and np.array_equal(pr[n, : pc[n]], r["proposals"])
+        bl = out[n]
+        assert len(bl) == len(r["score"]) and np.array_equal(bl.get_field("scores"), r["score"]) and np.array_equal(bl.bbox, r["box"])
+        assert np.array_equal(bl.get_field("labels"), r["label"].astype(np.int64)) and np.array_equal(bl.get_field("mask")[:, 0], r["mask28"])
+    model.close()
+
+
 def test_maskrcnn_fp16_path_close_to_fp16_oracle(ffi, sd):
     """BASELINE configs[4] numerics: fp16 storage + f16 MFMA, fp32 accumulate.  TOLERANCE (stated): the 16-term sum
     inside one f16 MFMA is unordered, so features are compared at 5e-3 of the tensor's max magnitude against an oracle

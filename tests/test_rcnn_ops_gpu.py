@@ -189,6 +189,21 @@ def test_box_postprocess_matches_oracle(ffi):
         k = cnt[n]
         rb, rs, rl = ora.box_postprocess(logits3[n, :k], regr[n, :k] * 0.05, props3[n, :k], float(hw[n, 1]), float(hw[n, 0]), cap=100)
         assert np.array_equal(got[n][2], rl) and np.array_equal(got[n][1], rs) and np.array_equal(got[n][0], rb)
+    # exact ties at the kth value: upstream's `cls_scores >= kthvalue` keeps ALL of them, so more than det_per_img detections come back
+    # when the buffers have the rows for them (cap > det_per_img); with the default capacity the list is cut at det_per_img in output order
+    Rt = 300
+    gx, gy = np.meshgrid(np.arange(20) * 60.0, np.arange(15) * 50.0)
+    propt = np.stack([gx.ravel(), gy.ravel(), gx.ravel() + 40, gy.ravel() + 30], 1).astype(np.float32)[None]   # disjoint boxes: NMS keeps all
+    logt = np.full((1, Rt, ncls), -4.0, np.float32)
+    logt[0, :60, 5] = 3.0; logt[0, 60:210, 9] = 2.0      # 60 high scores of class 5, then 150 IDENTICAL scores of class 9: 210 survivors
+    regt = np.zeros((1, Rt, 4 * ncls), np.float32)
+    cntt, hwt = np.array([Rt], np.int32), np.array([[800, 1333]], np.int32)
+    for cap, want in ((100, 100), (128, 128), (256, 210)):
+        (gb, gs, gl), = ffi.box_postprocess(logt, regt, propt, cntt, hwt, cap=cap)
+        rb, rs, rl = ora.box_postprocess(logt[0], regt[0], propt[0], 1333.0, 800.0, cap=cap)
+        assert len(rs) == want == len(gs), (cap, len(rs), len(gs))
+        assert np.array_equal(gl, rl) and np.array_equal(gs, rs) and np.array_equal(gb, rb)
+    assert (gl == 5).sum() == 60 and (gl == 9).sum() == 150 and len(np.unique(gs[gl == 9])) == 1
     # fewer than det_per_img survivors: everything kept, order preserved
     logits2 = logits.copy(); logits2[..., 0] += 6.0
     got = ffi.box_postprocess(logits2, regr, props, cnt, hw)
