@@ -139,10 +139,12 @@ def test_yolact_evaluate_matches_host_path(ffi):
     from isegmi.weights import yolact_state_dict
     from isegmi.yolact import Yolact, evaluate, postprocess
     rng = np.random.default_rng(12)
-    # random-weight Yolact fires on pixel noise only: images at or above the 200-px network size (the resize keeps their noise), all pure noise
+    # random weights score resized images low: nms_conf_thresh 0 lets Detect keep them, so that every image yields its 100 detections
+    import dataclasses
+    from isegmi.yolact import YolactConfig
     shapes = [(240, 320), (200, 260), (320, 240), (240, 320), (200, 200)]
     images = [rng.integers(0, 256, (h, w, 3)).astype(np.uint8) for h, w in shapes]
-    net = Yolact(yolact_state_dict(1234), max_batch=3, input_size=200)
+    net = Yolact(yolact_state_dict(1234), dataclasses.replace(YolactConfig(), nms_conf_thresh=0.0), max_batch=3, input_size=200)
     def host_path(thr, top_k):
         out = []
         for i, im in enumerate(images):

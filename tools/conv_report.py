@@ -1,5 +1,5 @@
 """Per-layer conv report on the GPU, single stream (dev tool):
-   python tools/conv_report.py [batch] [tile] [yolact|maskrcnn] [fp16] [depth]"""
+   python tools/conv_report.py [batch] [tile] [yolact|maskrcnn] [fp16|fp32] [depth] [H W]     (H W: Mask R-CNN image size before padding, default 800 1333)"""
 import ctypes as C, sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path[:0] = [ROOT, os.path.join(ROOT, "instancesegmentation-jittor_amd")]
 import numpy as np
@@ -9,6 +9,7 @@ tile = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 model = sys.argv[3] if len(sys.argv) > 3 else "yolact"
 fp16 = len(sys.argv) > 4 and sys.argv[4] == "fp16"
 depth = int(sys.argv[5]) if len(sys.argv) > 5 else 50
+IH, IW = (int(sys.argv[6]), int(sys.argv[7])) if len(sys.argv) > 7 else (800, 1333)
 rng = np.random.default_rng(1)
 if model == "yolact":
     from isegmi.weights import yolact_state_dict
@@ -19,7 +20,7 @@ if model == "yolact":
 else:
     from isegmi.weights import maskrcnn_state_dict
     from isegmi.maskrcnn import MaskRCNN, MaskRCNNConfig, prepare_images
-    x, hw = prepare_images([rng.uniform(0, 255, (800, 1333, 3)).astype(np.float32) for _ in range(bs)])
+    x, hw = prepare_images([rng.uniform(0, 255, (IH, IW, 3)).astype(np.float32) for _ in range(bs)])
     net = MaskRCNN(maskrcnn_state_dict(1234, depth), x.shape[1], x.shape[2], cfg=MaskRCNNConfig(depth=depth), max_batch=bs, fp16=fp16)
     net.upload(x, hw)
     step = lambda: net.forward_device(bs)

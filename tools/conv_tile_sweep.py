@@ -6,13 +6,24 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tiles = [int(t) for t in (sys.argv[1] if len(sys.argv) > 1 else "3,4,5,6,12").split(",")]
 runs = [("yolact", 1), ("yolact", 8), ("maskrcnn", 1), ("maskrcnn", 2)]
 extra = []
+canvases = {}
+if len(sys.argv) > 2 and sys.argv[2] == "canvases":  # fp32, plus the padded canvases COCODemo produces on COCO images (800x1088, 800x1216, 608x800 ...)
+    sizes = [(800, 1088), (800, 1216), (608, 800), (800, 800), (1216, 800)]
+    runs += [("maskrcnn", 100 + 10 * i + b) for i in range(len(sizes)) for b in (1, 2)]
+    canvases = {100 + 10 * i + b: (b, sizes[i]) for i in range(len(sizes)) for b in (1, 2)}
 if len(sys.argv) > 2 and sys.argv[2] == "f16":  # the fp16 family: R101 bs 8 (configs[4]) and R50 bs 2
     runs = [("maskrcnn", 8), ("maskrcnn", 2)]
     extra = {8: ["fp16", "101"], 2: ["fp16", "50"]}
 rows = {}
 for model, bs in runs:
     for t in tiles:
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "conv_report.py"), str(bs), str(t), model] + (extra[bs] if extra else []), capture_output=True, text=True, timeout=600).stdout
+        if bs in canvases:
+            b, (ih, iw) = canvases[bs]
+            args = [str(b), str(t), model, "fp32", "50", str(ih), str(iw)]
+        else:
+            args = [str(bs), str(t), model] + (extra[bs] if extra else [])
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "conv_report.py")] + args, capture_output=True, text=True, timeout=600).stdout
+        print("swept", model, bs, "tile", t, file=sys.stderr, flush=True)
         for ln in out.splitlines():
             m = re.match(r"(\S+) \[M=(\d+) K=(\d+) Cout=(\d+) (\d)x\d/(\d)\]\s+([\d.]+) GF\s+([\d.]+) ms", ln)
             if not m:
