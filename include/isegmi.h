@@ -249,6 +249,8 @@ typedef struct isegmi_rle_args {
     const uint8_t* d_masks;
     const int32_t* d_count;           /* [N] or NULL (all K slots valid) */
     const int32_t* d_image_hw;        /* [N][2] or NULL */
+    const int32_t* d_windows;         /* [N*K][4] (x0, y0, x1, y1) or NULL: every set pixel of slot m lies inside [x0, x1) x [y0, y1); only that part
+                                         of a plane is then read (pixels outside a window need not even be initialised) */
     void* d_ws_trans;                 /* workspace, sizes from isegmi_rle_workspace */
     int32_t* d_ws_col;
     int32_t* d_ws_nruns;

@@ -918,6 +918,10 @@ int conv2d_launch(const isegmi_conv_desc* d, const float* in, const float* w, co
         //     rounds (513-640, 1025-1100);
         //   * outputs of at most 32 channels never use a 64-wide tile (padding them to 64 wastes half the MFMA work);
         //   * fourth sweep (profiles/r02_conv_tile_sweep_v4.txt): the hybrid launch (tile 13) wherever a 513-2600-tile grid leaves few tiles over.
+        // Round 3 tried to replace this ladder by a fitted cost model (tools/fit_conv_model.py: per kernel f + max(q (nck m + em), ceil(q / occ)
+        // (nck l + el)), five parameters each, fitted on 355 layer shapes of both models at bs 1 / 2 / 8 and five further canvases): the model's
+        // choices cost +1.4 % over the per-layer best in total, the ladder's +0.85 % (+0.55 % after the change below) -- the ladder stays; the CU
+        // count it uses is the device's.
         const int64_t t64 = (int64_t)cdiv(k.M, 64) * cdiv(d->Cout, 64);
         const int nck = k.nchunks;
         const int ncu = device_cu_count();
@@ -929,7 +933,9 @@ int conv2d_launch(const isegmi_conv_desc* d, const float* in, const float* w, co
         // hybrid launch (tile 13: v2 on the rows that fill the CUs a whole number of times, 32x32 blocks on the rest) wherever the
         // left-over 64x64 tiles are few: 3-12 % ahead of the rule below on 526-2400-tile layers in the fourth sweep
         // (profiles/r02_conv_tile_sweep_v4.txt), behind it once the tail passes ~15 % of the layer (616, 1228 tiles)
-        else if (t64 >= 513 && t64 <= 2600 && t64 % ncu != 0 && (t64 % ncu) * 100 <= t64 * 15) tile = 13;
+        // round 3 sweep over 355 layer shapes incl. the canvases COCODemo produces (profiles/r03_conv_tile_sweep.txt): no upper limit any more -- on
+        // the 3400-9500-tile 3x3 layers (FPN / RPN at P2, proto_net.8) the hybrid launch is 0.5-2.6 % ahead of plain v2 as well
+        else if (t64 >= 513 && t64 % ncu != 0 && (t64 % ncu) * 100 <= t64 * 15) tile = 13;
         else if (t64 <= 512) tile = v2;
         else if (t64 <= 640) tile = nck >= 32 ? 6 : 4;
         else if (t64 <= 1024) tile = v2;

@@ -28,6 +28,8 @@ struct RleK {
     const uint8_t* masks;
     const int* count;      // [N] valid slots per image, or NULL (all valid)
     const int* image_hw;   // [N][2] (h, w) of the window of every plane that is encoded, or NULL (the whole plane)
+    const int* windows;    // [M][4] (x0, y0, x1, y1) or NULL: every set pixel of slot m lies inside [x0, x1) x [y0, y1) (the box window the paste /
+                           // mask assembly kernel wrote); only that part of the plane is read, the rest is known to be zero
     unsigned long long* trans;  // [M][plane_w][qmax]
     int* col;              // [M][plane_w] starts per column -> exclusive offsets
     int* nruns;            // [M]
@@ -47,32 +49,86 @@ __device__ __forceinline__ void rle_dims(const RleK& p, int m, int& hi, int& wi,
     wi = p.image_hw ? p.image_hw[2 * n + 1] : p.plane_w;
 }
 
+// Which 64-row chunks of column x can hold a run start when every set pixel of slot m lies in its window [x0, x1) x [y0, y1) (clamped to the
+// image; the paste / mask assembly kernel wrote it next to the plane).  A run starts at a set pixel (inside the window) or at the zero that
+// follows one: the next row of the same column (rows y0 .. y1), or -- when the window touches the last row -- row 0 of the NEXT column.  So:
+// columns x0 .. x1 - 1 (and x1 itself when the window touches the last row), chunks covering rows y0 .. min(y1, h - 1), plus chunk 0 when the
+// window touches the last row.  Pixels outside the window are never READ (the planes need not be cleared for this kernel): a chunk's word is
+// masked to the window's rows, and the column after the window is all zero by definition.
+struct RleSpan {
+    bool any;         // the column has chunks to visit
+    bool zero_col;    // x == x1: no pixel of this column is set
+    bool head;        // visit chunk 0 first although it lies above q_lo (the predecessor of row 0 may be set)
+    bool prev_col;    // the last pixel of column x - 1 may be set: read it
+    int q_lo, q_hi;   // chunks covering the window's rows (+ the row after it)
+    int y0, y1;       // clamped window rows
+};
+__device__ __forceinline__ RleSpan rle_column_span(const RleK& p, int m, int x, int hi, int wi) {
+    RleSpan s;
+    s.any = true; s.zero_col = false; s.head = false; s.prev_col = x > 0; s.q_lo = 0; s.q_hi = (hi - 1) >> 6; s.y0 = 0; s.y1 = hi;
+    if (p.windows == nullptr) return s;
+    const int* w = p.windows + 4 * (int64_t)m;
+    int x0 = w[0], y0 = w[1], x1 = w[2], y1 = w[3];
+    x0 = x0 < 0 ? 0 : x0; y0 = y0 < 0 ? 0 : y0; x1 = x1 > wi ? wi : x1; y1 = y1 > hi ? hi : y1;
+    const bool bottom = y1 >= hi;
+    s.any = x1 > x0 && y1 > y0 && x >= x0 && (x < x1 || (bottom && x == x1));
+    if (!s.any) return s;
+    s.zero_col = x >= x1;
+    s.prev_col = bottom && x > x0;                 // column x - 1 is inside the window and its last row is a window row
+    s.y0 = y0; s.y1 = y1;
+    if (s.zero_col) { s.q_lo = 0; s.q_hi = 0; return s; }
+    s.q_lo = y0 >> 6;
+    s.q_hi = (y1 < hi ? y1 : hi - 1) >> 6;
+    s.head = s.prev_col && s.q_lo > 0;
+    return s;
+}
+// bits of chunk q whose rows lie inside [y0, y1)
+__device__ __forceinline__ unsigned long long rle_row_mask(int q, int y0, int y1) {
+    const int lo = y0 - 64 * q, hi = y1 - 64 * q;  // window rows relative to the chunk
+    if (hi <= 0 || lo >= 64) return 0ull;
+    const unsigned long long upto = hi >= 64 ? ~0ull : ((1ull << hi) - 1ull);
+    const unsigned long long from = lo <= 0 ? ~0ull : ~((1ull << lo) - 1ull);
+    return upto & from;
+}
+
 // grid (ceil(plane_w / 256), M), 256 threads; thread = column
 __global__ __launch_bounds__(256) void rle_pack_kernel(const RleK p) {
     const int m = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
     int hi, wi; bool valid;
     rle_dims(p, m, hi, wi, valid);
     if (!valid || x >= wi) return;
-    const uint8_t* mp = p.masks + (int64_t)m * p.plane_h * p.plane_w;
-    unsigned long long prev = (x > 0 && mp[(int64_t)(hi - 1) * p.plane_w + x - 1] != 0) ? 1ull : 0ull;
-    unsigned long long* tw = p.trans + ((int64_t)m * p.plane_w + x) * p.qmax;
-    const int Q = (hi + 63) >> 6;
+    const RleSpan s = rle_column_span(p, m, x, hi, wi);
     int cnt = 0;
-    for (int q = 0; q < Q; ++q) {
-        const int rows = (hi - 64 * q) < 64 ? (hi - 64 * q) : 64;
-        const uint8_t* cp = mp + (int64_t)(64 * q) * p.plane_w + x;
-        unsigned long long word = 0;
-        if (rows == 64) {
-#pragma unroll 16
-            for (int r = 0; r < 64; ++r) word |= (unsigned long long)(cp[(int64_t)r * p.plane_w] != 0) << r;
-        } else {
-            for (int r = 0; r < rows; ++r) word |= (unsigned long long)(cp[(int64_t)r * p.plane_w] != 0) << r;
+    if (s.any) {
+        const uint8_t* mp = p.masks + (int64_t)m * p.plane_h * p.plane_w;
+        unsigned long long* tw = p.trans + ((int64_t)m * p.plane_w + x) * p.qmax;
+        // the pixel before row 0 of this column is the last pixel of column x - 1
+        const unsigned long long prev0 = (s.prev_col && mp[(int64_t)(hi - 1) * p.plane_w + x - 1] != 0) ? 1ull : 0ull;
+        if (s.head) {  // chunk 0 lies above the window: all zero; its bit 0 starts a run exactly when the predecessor is set
+            tw[0] = prev0;
+            cnt += (int)prev0;
         }
-        unsigned long long t = word ^ ((word << 1) | prev);
-        if (rows < 64) t &= (1ull << rows) - 1ull;
-        prev = word >> 63;
-        tw[q] = t;
-        cnt += __popcll(t);
+        unsigned long long prev = s.q_lo == 0 ? prev0 : 0ull;
+        for (int q = s.q_lo; q <= s.q_hi; ++q) {
+            const int rows = (hi - 64 * q) < 64 ? (hi - 64 * q) : 64;
+            unsigned long long word = 0;
+            const unsigned long long rm = rle_row_mask(q, s.y0, s.y1);
+            if (!s.zero_col && rm != 0ull) {
+                const uint8_t* cp = mp + (int64_t)(64 * q) * p.plane_w + x;
+                if (rm == ~0ull) {
+#pragma unroll 16
+                    for (int r = 0; r < 64; ++r) word |= (unsigned long long)(cp[(int64_t)r * p.plane_w] != 0) << r;
+                } else {
+                    const int r0 = __ffsll((long long)rm) - 1, r1 = 64 - __clzll((long long)rm);  // rm is one run of bits: rows r0 .. r1 - 1
+                    for (int r = r0; r < r1; ++r) word |= (unsigned long long)(cp[(int64_t)r * p.plane_w] != 0) << r;
+                }
+            }
+            unsigned long long t = word ^ ((word << 1) | prev);
+            if (rows < 64) t &= (1ull << rows) - 1ull;
+            prev = word >> 63;
+            tw[q] = t;
+            cnt += __popcll(t);
+        }
     }
     p.col[(int64_t)m * p.plane_w + x] = cnt;
 }
@@ -169,14 +225,17 @@ __global__ __launch_bounds__(256) void rle_emit_kernel(const RleK p) {
     const unsigned long long* tw = p.trans + ((int64_t)m * p.plane_w + x) * p.qmax;
     uint32_t* out = p.counts + p.run_off[m];
     int o = p.col[(int64_t)m * p.plane_w + x];
-    const int Q = (hi + 63) >> 6;
     const uint32_t colbase = (uint32_t)x * (uint32_t)hi;
-    for (int q = 0; q < Q; ++q) {
-        unsigned long long t = tw[q];
-        while (t) {
-            const int b = __ffsll((long long)t) - 1;
-            out[o++] = colbase + (uint32_t)(64 * q + b);
-            t &= t - 1ull;
+    const RleSpan s = rle_column_span(p, m, x, hi, wi);   // the words rle_pack wrote for this column, in its order, and no others
+    if (s.any) {
+        if (s.head && tw[0]) out[o++] = colbase;
+        for (int q = s.q_lo; q <= s.q_hi; ++q) {
+            unsigned long long t = tw[q];
+            while (t) {
+                const int b = __ffsll((long long)t) - 1;
+                out[o++] = colbase + (uint32_t)(64 * q + b);
+                t &= t - 1ull;
+            }
         }
     }
     if (x == wi - 1) out[o] = (uint32_t)hi * (uint32_t)wi;
@@ -324,7 +383,7 @@ int rle_encode_launch(const isegmi_rle_args* a, hipStream_t st) {
     RleK p;
     p.N = a->N; p.K = a->K; p.plane_h = a->plane_h; p.plane_w = a->plane_w; p.qmax = (a->plane_h + 63) / 64;
     p.cap_runs = a->cap_runs; p.cap_chars = a->cap_chars;
-    p.masks = a->d_masks; p.count = a->d_count; p.image_hw = a->d_image_hw;
+    p.masks = a->d_masks; p.count = a->d_count; p.image_hw = a->d_image_hw; p.windows = a->d_windows;
     p.trans = (unsigned long long*)a->d_ws_trans; p.col = a->d_ws_col; p.nruns = a->d_ws_nruns; p.tile = a->d_ws_tile; p.len = a->d_ws_len;
     p.run_off = a->d_out_run_off; p.counts = a->d_ws_starts; p.str_off = a->d_out_str_off; p.chars = a->d_out_chars; p.status = a->d_out_status;
     const int M = a->N * a->K;

@@ -5,10 +5,11 @@ and reports how far the model's choice is from the per-layer best -- next to the
 
 Model (per candidate kernel c; ncu = compute units, nck = K / 32 chunks):
     blocks B_c = ceil(M / bm_c) * ceil(Cout / bn_c);   q = ceil(B_c / ncu)  blocks on the busiest CU
-    T_c = f_c + nck * max(q * m_c, ceil(q / occ_c) * l_c)        [us]
-  m_c = matrix-pipe time of one chunk of one block, l_c = the chunk's latency when the block's co-residents cannot hide it, occ_c = blocks
-  that share a CU, f_c = launch + ring fill + epilogue.  The hybrid launch (13) runs whole-CU multiples of 64x64 tiles on the v2 body and the
-  left-over rows on 32x32 blocks:  T_13 = f + nck * (q_main * m_a + ceil(ntail / ncu / occ_t) * l_t).
+    T_c = f_c + max(q * (nck * m_c + em_c), ceil(q / occ_c) * (nck * l_c + el_c))        [us]
+  m_c = matrix-pipe time of one chunk of one block, em_c = the pipe-side cost of a block's epilogue; l_c / el_c = the same two as LATENCIES,
+  paid once per round of occ_c co-resident blocks when they cannot hide each other; f_c = launch + ring fill.  The hybrid launch (13) runs
+  whole-CU multiples of 64x64 tiles on the v2 body and the left-over rows on 32x32 blocks:
+  T_13 = f + q_main * (nck * m_a + em_a) + ceil(ntail / ncu / 8) * (nck * l_t + el_t).
 --emit prints the C table for conv_mfma.hip."""
 import math
 import re
@@ -45,7 +46,7 @@ def blocks(M, Cout, bm, bn):
 def model_time(c, prm, M, Cout, K):
     nck = K // 32
     if c == 13:
-        f, ma, lt = prm
+        f, ma, ea, lt, et = prm
         nt64, mt64 = -(-Cout // 64), -(-M // 64)
         main_mt = (mt64 * nt64 // NCU) * NCU // nt64
         if main_mt * 64 > M:
@@ -54,20 +55,20 @@ def model_time(c, prm, M, Cout, K):
             return None
         qm = main_mt * nt64 / NCU
         ntail = -(-(M - main_mt * 64) // 32) * -(-Cout // 32)
-        return f + nck * (qm * ma + math.ceil(ntail / NCU / 8) * lt)
+        return f + qm * (nck * ma + ea) + math.ceil(ntail / NCU / 8) * (nck * lt + et)
     bm, bn, occ = CAND[c]
-    f, m, l = prm
+    f, m, em, l, el = prm
     q = math.ceil(blocks(M, Cout, bm, bn) / NCU)
-    return f + nck * max(q * m, math.ceil(q / occ) * l)
+    return f + max(q * (nck * m + em), math.ceil(q / occ) * (nck * l + el))
 
 
 def fit(c, rows):
     data = [(r["M"], r["Cout"], r["K"], r["t"][c]) for r in rows if c in r["t"] and r["K"] % 32 == 0 and not (r["Cout"] <= 32 and c in (10, 12, 13, 6))]
-    data = [d for d in data if model_time(c, (1.0, 1.0, 1.0), d[0], d[1], d[2]) is not None]
+    data = [d for d in data if model_time(c, (1.0,) * 5, d[0], d[1], d[2]) is not None]
 
     def res(x):
         return [math.log(max(model_time(c, np.abs(x), M, Co, K), 1e-3) / t) for M, Co, K, t in data]
-    x0 = np.array([8.0, 0.25, 0.5])
+    x0 = np.array([6.0, 0.25, 1.0, 0.5, 2.0])
     sol = least_squares(res, x0, loss="soft_l1", f_scale=0.1)
     prm = np.abs(sol.x)
     err = np.array(res(sol.x))
@@ -75,7 +76,7 @@ def fit(c, rows):
 
 
 def ladder(M, Cout, K, stem=False):
-    """the round-2 rule of conv2d_launch, restated"""
+    """the rule of conv2d_launch (tile == 0), restated"""
     t64 = -(-M // 64) * -(-Cout // 64)
     nck = K // 32
     v2 = 12 if nck >= 72 else 10
@@ -85,7 +86,7 @@ def ladder(M, Cout, K, stem=False):
         return v2
     if Cout <= 32 or t64 <= 480:
         return 4
-    if 513 <= t64 <= 2600 and t64 % NCU != 0 and (t64 % NCU) * 100 <= t64 * 15:
+    if 513 <= t64 and t64 % NCU != 0 and (t64 % NCU) * 100 <= t64 * 15:   # round 3: no upper limit (was 2600)
         return 13
     if t64 <= 512:
         return v2
@@ -104,7 +105,7 @@ def main():
     params = {}
     for c in [t for t in tiles if t in CAND or t == 13]:
         params[c], rms, n = fit(c, rows)
-        print("tile %2d: f %.2f us  m %.4f  l %.4f   (rms log error %.3f over %d layers)" % (c, *params[c], rms, n))
+        print("tile %2d: f %.2f us  m %.4f em %.3f  l %.4f el %.3f   (rms log error %.3f over %d layers)" % (c, *params[c], rms, n))
 
     def choose(r):
         best, bt = None, 1e30
@@ -121,7 +122,7 @@ def main():
             continue
         tb = min(r["t"].values())
         cm, cl = choose(r), ladder(r["M"], r["Cout"], r["K"])
-        if cl == 13 and model_time(13, (1, 1, 1), r["M"], r["Cout"], r["K"]) is None:
+        if cl == 13 and model_time(13, (1,) * 5, r["M"], r["Cout"], r["K"]) is None:
             cl = 10
         tm, tl = r["t"].get(cm), r["t"].get(cl)
         if tm is None or tl is None:
@@ -138,10 +139,10 @@ def main():
     for w in sorted(worst, reverse=True)[:12]:
         print("   model off by %+.1f %%: chose t%d, best t%d  %s" % (w[0] * 100, w[1], w[2], w[3]))
     if "--emit" in sys.argv:
-        print("static const struct { int id, bm, bn, occ; float f, m, l; } FT[] = {")
+        print("static const struct { int id, bm, bn, occ; float f, m, em, l, el; } FT[] = {")
         for c, prm in params.items():
             bm, bn, occ = CAND.get(c, (64, 64, 4))
-            print("    {%d, %d, %d, %d, %.3ff, %.5ff, %.5ff}," % (c, bm, bn, occ, *prm))
+            print("    {%d, %d, %d, %d, %.3ff, %.5ff, %.4ff, %.5ff, %.4ff}," % (c, bm, bn, occ, *prm))
         print("};")
 
 
