@@ -580,9 +580,11 @@ int yolact_postprocess(Engine& e, int h, int w, const int32_t* h_image_hw) {
     TRY(eng_buf(e, "ws.lo", (int64_t)N * K * PH * PW * 4, &lo));
     TRY(eng_buf(e, "det.masks", (int64_t)N * K * h * w, &masks, 2, {N, K, h, w}));
     TRY(eng_buf(e, "det.box_int", (int64_t)N * K * 4 * 8, &ib, 3, {N, K, 4}));
+    void* wq;
+    TRY(eng_buf(e, "det.mask_window", (int64_t)e.max_batch * K * 16, &wq, 1, {N, K, 4}));
     TRY(yolact_masks_launch((const float*)proto.d, (const float*)e.bufs["det.coeff"].d, (const float*)e.bufs["det.box"].d,
                             (const int*)e.bufs["det.count"].d, N, PH, PW, md, K, h, w, (float*)lo, (uint8_t*)masks, (int64_t*)ib,
-                            rs, d_ihw));
+                            rs, d_ihw, (int*)wq, e.param("sparse_masks", 0.0f) == 0.0f));
     if (e.convs.count("maskiou_net.2")) {
         // YOLACT++ fast mask re-scoring on the proto-resolution masks just written to ws.lo: first layer (1 input channel) and
         // the global-max / class pick as small dedicated kernels, the rest on the MFMA conv kernels over all N*K slots

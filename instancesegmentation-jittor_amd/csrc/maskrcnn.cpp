@@ -29,7 +29,7 @@ int box_postprocess_launch(const isegmi_box_post_args* a, hipStream_t st);
 int mask_logits_select_launch(const float* feat, int R, int HW, int C, const float* w, const float* b, const int* labels, float* out,
                               hipStream_t st);
 int paste_masks_launch(const float* masks, const float* boxes, const int* counts, int N, int K, int M, int im_h, int im_w, float thr,
-                       uint8_t* out, hipStream_t st);
+                       uint8_t* out, hipStream_t st, int* win, bool clear);
 int scale_boxes_launch(const float* boxes, const float* ratios, int N, int K, float* out, hipStream_t st);
 int topk_launch(const float* keys, int64_t row_stride, int rows, int n, int k, const int* limit, int rows_per_limit, float* out_vals,
                 int* out_idx, int* out_cnt, hipStream_t st);
@@ -501,8 +501,13 @@ int maskrcnn_paste(Engine& e, const float* h_ratios_wh, int out_h, int out_w) {
     TRY(scale_boxes_launch((const float*)e.bufs["det.box"].d, (const float*)rt, N, cap, (float*)rb, ps));
     TRY(eng_buf(e, "det.masks", (int64_t)N * cap * out_h * out_w, &p, 2, {N, cap, out_h, out_w}));
     const bool c4 = e.param("arch_c4", 0.0f) != 0.0f;  // MaskRCNNC4Predictor emits 14x14 masks
+    void* wq;
+    TRY(eng_buf(e, "det.mask_window", (int64_t)e.max_batch * cap * 16, &wq, 1, {N, cap, 4}));
+    // "sparse_masks": the planes are read through their windows only (isegmi_engine_rle: the device-side COCO output), so the 107 MB per image of
+    // zero background need not be written; det.masks is then NOT a full binary plane (pixels outside a window are undefined)
     TRY(paste_masks_launch((const float*)e.bufs[c4 ? "det.mask14" : "det.mask28"].d, (const float*)rb, (const int*)e.bufs["det.count"].d, N,
-                           cap, c4 ? 14 : 28, out_h, out_w, e.param("mask_threshold", 0.5f), (uint8_t*)p, ps));
+                           cap, c4 ? 14 : 28, out_h, out_w, e.param("mask_threshold", 0.5f), (uint8_t*)p, ps, (int*)wq,
+                           e.param("sparse_masks", 0.0f) == 0.0f));
     if (ps == e.tail) HIP_TRY(hipEventRecord(e.tail_done, e.tail));
     e.cur = e.stream;
     eng_mark(e, "paste");

@@ -817,7 +817,7 @@ __global__ __launch_bounds__(256) void mask_logits_select_kernel(const float* __
 // masks [N][K][M][M]; boxes [N][K][4] in output-image coordinates; counts [N]; out [N][K][im_h][im_w] u8.
 __global__ __launch_bounds__(256) void paste_masks_kernel(const float* __restrict__ masks, const float* __restrict__ boxes,
                                                            const int* __restrict__ counts, int K, int M, int im_h, int im_w, float thr,
-                                                           uint8_t* __restrict__ out) {
+                                                           uint8_t* __restrict__ out, int* __restrict__ win) {
     const int n = blockIdx.z, d = blockIdx.y;
     if (d >= counts[n]) return;
     const float4 b = *(const float4*)(boxes + ((int64_t)n * K + d) * 4);
@@ -836,6 +836,8 @@ __global__ __launch_bounds__(256) void paste_masks_kernel(const float* __restric
     const int y_0 = y1 > 0 ? y1 : 0, y_1 = (y2 + 1) < im_h ? (y2 + 1) : im_h;
     const float* m = masks + ((int64_t)n * K + d) * M * M;
     uint8_t* o = out + ((int64_t)n * K + d) * im_h * im_w;
+    // the window every set pixel of this plane lies in: [x_0, x_1) x [y_0, y_1) -- the run-length encoder reads nothing else of the plane
+    if (win != nullptr && blockIdx.x == 0 && threadIdx.x == 0) { int* wq = win + ((int64_t)n * K + d) * 4; wq[0] = x_0; wq[1] = y_0; wq[2] = x_1; wq[3] = y_1; }
     // The plane was zeroed by the memset node ahead of this launch: only the rows the box touches are visited, and a
     // word is stored only if one of its 4 pixels lies inside the box (paste cost ~ box area, not image area).
     const int64_t total = (int64_t)im_h * im_w;
@@ -1060,11 +1062,13 @@ int mask_logits_select_launch(const float* feat, int R, int HW, int C, const flo
     return ISEGMI_OK;
 }
 
+// clear: zero the planes first (the kernel writes only the rows of each box, and inside them only the words that touch the box); a caller that
+// reads the planes through the windows alone (`win` [N][K][4], the run-length encoder) may skip it.
 int paste_masks_launch(const float* masks, const float* boxes, const int* counts, int N, int K, int M, int im_h, int im_w, float thr,
-                       uint8_t* out, hipStream_t st) {
-    HIP_TRY(hipMemsetAsync(out, 0, (size_t)N * K * im_h * im_w, st));
+                       uint8_t* out, hipStream_t st, int* win, bool clear) {
+    if (clear) HIP_TRY(hipMemsetAsync(out, 0, (size_t)N * K * im_h * im_w, st));
     const unsigned bx = grid_for((int64_t)im_h * im_w, 1024) > 64 ? 64 : grid_for((int64_t)im_h * im_w, 1024);
-    hipLaunchKernelGGL(paste_masks_kernel, dim3(bx, K, N), dim3(256), 0, st, masks, boxes, counts, K, M, im_h, im_w, thr, out);
+    hipLaunchKernelGGL(paste_masks_kernel, dim3(bx, K, N), dim3(256), 0, st, masks, boxes, counts, K, M, im_h, im_w, thr, out, win);
     HIP_TRY(hipGetLastError());
     return ISEGMI_OK;
 }
@@ -1102,7 +1106,7 @@ extern "C" int isegmi_op_mask_logits_select(const float* d_feat, int R, int HW, 
 
 extern "C" int isegmi_op_paste_masks(const float* d_masks, const float* d_boxes, const int32_t* d_counts, int N, int K, int M,
                                      int im_h, int im_w, float thr, uint8_t* d_out, void* stream) {
-    return paste_masks_launch(d_masks, d_boxes, d_counts, N, K, M, im_h, im_w, thr, d_out, (hipStream_t)stream);
+    return paste_masks_launch(d_masks, d_boxes, d_counts, N, K, M, im_h, im_w, thr, d_out, (hipStream_t)stream, nullptr, true);
 }
 
 // One RPN level for N images (parity-test entry; the engine calls the same launchers):

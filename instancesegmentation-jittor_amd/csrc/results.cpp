@@ -73,6 +73,12 @@ int eng_rle(Engine& e, const int32_t* h_image_hw) {
     a.N = N; a.K = K; a.plane_h = ph; a.plane_w = pw; a.cap_runs = rle_cap_runs(e); a.cap_chars = rle_cap_chars(e);
     a.d_masks = (const uint8_t*)mit->second.d;
     a.d_count = (const int32_t*)e.bufs["det.count"].d;
+    {   // the windows the paste / mask assembly kernel wrote next to the planes: only they are read
+        auto wit = e.bufs.find("det.mask_window");
+        if (wit != e.bufs.end() && wit->second.d != nullptr && wit->second.shape.size() == 3 && wit->second.shape[0] == N && wit->second.shape[1] == K)
+            a.d_windows = (const int32_t*)wit->second.d;
+        else if (e.param("sparse_masks", 0.0f) != 0.0f) { set_error("rle: sparse_masks is set but the last postprocess / paste left no windows"); return ISEGMI_ERR_STATE; }
+    }
     void* q;
     if (h_image_hw) {
         for (int i = 0; i < N; ++i)

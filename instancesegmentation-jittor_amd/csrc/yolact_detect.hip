@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void yolact_proto_masks_kernel(const float* __
 // original sizes, each postprocess()ed at its own size as upstream's per-image evalimage does); NULL = every image at (h, w).
 __global__ __launch_bounds__(256) void yolact_upsample_masks_kernel(const float* __restrict__ lo, const float* __restrict__ boxes,
                                                                      const int* __restrict__ count, int PH, int PW, int K, int h, int w,
-                                                                     const int* __restrict__ image_hw, uint8_t* __restrict__ out) {
+                                                                     const int* __restrict__ image_hw, uint8_t* __restrict__ out, int* __restrict__ win) {
     const int n = blockIdx.z, d = blockIdx.y;
     if (d >= count[n]) return;
     const int plane_w = w;
@@ -266,6 +266,8 @@ __global__ __launch_bounds__(256) void yolact_upsample_masks_kernel(const float*
     ox0 = ox0 < 0 ? 0 : ox0; ox1 = ox1 > w ? w : ox1;
     oy0 = oy0 < 0 ? 0 : oy0; oy1 = oy1 > h ? h : oy1;
     const int ww = ox1 - ox0, wh = oy1 - oy0;
+    // the window every set pixel of this plane lies in (the run-length encoder reads nothing else of the plane)
+    if (win != nullptr && blockIdx.x == 0 && threadIdx.x == 0) { int* wq = win + ((int64_t)n * K + d) * 4; wq[0] = ox0; wq[1] = oy0; wq[2] = ox1; wq[3] = oy1; }
     if (ww <= 0 || wh <= 0) return;
     const int area = ww * wh;
     const float sy = dm_div((float)PH, (float)h), sx = dm_div((float)PW, (float)w);  // dm_bil_coef's scale, hoisted
@@ -410,7 +412,7 @@ int maskiou_rescore_launch(const float* feat, int N, int K, int HW, int C, const
 
 int yolact_masks_launch(const float* proto, const float* coeffs, const float* boxes, const int* count, int N, int PH, int PW,
                         int mask_dim, int K, int h, int w, float* ws_lo, uint8_t* out_masks, int64_t* out_boxes, hipStream_t st,
-                        const int* image_hw) {
+                        const int* image_hw, int* win, bool clear) {
     ARG_CHECK(mask_dim == MD, "mask_dim must be 32");
     ARG_CHECK(N > 0 && K > 0 && K <= 128 && h > 0 && w > 0, "mask sizes");
     const size_t lds = (size_t)K * (MD + 4) * sizeof(float);
@@ -418,12 +420,12 @@ int yolact_masks_launch(const float* proto, const float* coeffs, const float* bo
                        PW, K, ws_lo);
     HIP_TRY(hipGetLastError());
     ARG_CHECK((int64_t)h * w < (1ll << 31), "h * w must stay below 2^31");
-    HIP_TRY(hipMemsetAsync(out_masks, 0, (size_t)N * K * h * w, st));
+    if (clear) HIP_TRY(hipMemsetAsync(out_masks, 0, (size_t)N * K * h * w, st));  // skipped when the planes are read through their windows only
     // chunks per detection: a full-image window is h*w pixels; 256 threads x ~8 pixels per thread and chunk
     int chunks = (int)cdiv64((int64_t)h * w, 2048);
     if (chunks > 32) chunks = 32;
     hipLaunchKernelGGL(yolact_upsample_masks_kernel, dim3((unsigned)chunks, (unsigned)K, (unsigned)N), dim3(256), 0, st, ws_lo, boxes, count, PH, PW, K, h, w,
-                       image_hw, out_masks);
+                       image_hw, out_masks, win);
     HIP_TRY(hipGetLastError());
     if (out_boxes) {
         hipLaunchKernelGGL(yolact_int_boxes_kernel, dim3(N), dim3(128), 0, st, boxes, count, K, h, w, image_hw, out_boxes);
@@ -444,5 +446,5 @@ extern "C" int isegmi_op_yolact_masks(const float* d_proto, const float* d_coeff
                                       int N, int PH, int PW, int mask_dim, int K, int h, int w, float* d_ws_lo,
                                       uint8_t* d_out_masks, int64_t* d_out_boxes, void* stream) {
     return yolact_masks_launch(d_proto, d_coeffs, d_boxes, d_count, N, PH, PW, mask_dim, K, h, w, d_ws_lo, d_out_masks, d_out_boxes,
-                               (hipStream_t)stream, nullptr);
+                               (hipStream_t)stream, nullptr, nullptr, true);
 }

@@ -446,13 +446,14 @@ def conv2d_f16(x, w_krsc, stride=1, pad=0, scale=None, shift=None, residual=None
 # ---------------------------------------------------------------- COCO RLE on the device
 class RleArgs(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("N", "K", "plane_h", "plane_w", "cap_runs", "cap_chars")] + \
-               [(n, C.c_void_p) for n in ("d_masks", "d_count", "d_image_hw", "d_ws_trans", "d_ws_col", "d_ws_nruns", "d_ws_tile", "d_ws_len",
+               [(n, C.c_void_p) for n in ("d_masks", "d_count", "d_image_hw", "d_windows", "d_ws_trans", "d_ws_col", "d_ws_nruns", "d_ws_tile", "d_ws_len",
                                           "d_ws_starts", "d_out_run_off", "d_out_counts", "d_out_str_off", "d_out_chars", "d_out_status")]
 
 
-def rle_encode(masks, count=None, image_hw=None, cap_runs=None, cap_chars=None):
+def rle_encode(masks, count=None, image_hw=None, cap_runs=None, cap_chars=None, windows=None):
     """masks [N,K,h,w] uint8 -> (run_off [N*K+1], counts, str_off [N*K+1], chars bytes, status [4]): pycocotools rleEncode + rleToString of
-    every valid slot (k < count[n]) over the top-left image_hw[n] window of its plane (host convenience wrapper of isegmi_op_rle_encode)."""
+    every valid slot (k < count[n]) over the top-left image_hw[n] window of its plane (host convenience wrapper of isegmi_op_rle_encode).
+    windows [N, K, 4] (x0, y0, x1, y1): every set pixel of a slot lies inside its window; nothing outside it is read."""
     masks = np.ascontiguousarray(masks, np.uint8)
     N, K, h, w = masks.shape
     cap_runs = int(cap_runs or max(1024, -(-(masks.size + N * K) // 1024) * 1024))  # worst case: every pixel starts a run
@@ -463,9 +464,10 @@ def rle_encode(masks, count=None, image_hw=None, cap_runs=None, cap_chars=None):
     dm = DeviceBuffer.from_numpy(masks)
     dc = None if count is None else DeviceBuffer.from_numpy(np.ascontiguousarray(count, np.int32))
     dh = None if image_hw is None else DeviceBuffer.from_numpy(np.ascontiguousarray(image_hw, np.int32).reshape(N, 2))
+    dwin = None if windows is None else DeviceBuffer.from_numpy(np.ascontiguousarray(windows, np.int32).reshape(N, K, 4))
     ro = DeviceBuffer((N * K + 1,), np.int32); cn = DeviceBuffer((cap_runs,), np.uint32); so = DeviceBuffer((N * K + 1,), np.int32)
     ch = DeviceBuffer((cap_chars,), np.uint8); stt = DeviceBuffer((4,), np.int32)
-    a = RleArgs(N, K, h, w, cap_runs, cap_chars, dm.ptr, _ptr(dc), _ptr(dh), ws[0].ptr, ws[1].ptr, ws[2].ptr, ws[3].ptr, ws[4].ptr, ws[5].ptr,
+    a = RleArgs(N, K, h, w, cap_runs, cap_chars, dm.ptr, _ptr(dc), _ptr(dh), _ptr(dwin), ws[0].ptr, ws[1].ptr, ws[2].ptr, ws[3].ptr, ws[4].ptr, ws[5].ptr,
                 ro.ptr, cn.ptr, so.ptr, ch.ptr, stt.ptr)
     check(lib().isegmi_op_rle_encode(C.byref(a), None))
     sync()

@@ -90,3 +90,44 @@ def test_rle_mask_rcnn_sized_planes(ffi):
     b = ffi.rle_encode(masks, np.array([5], np.int32))
     assert all(np.array_equal(np.asarray(x), np.asarray(y)) if not isinstance(x, bytes) else x == y for x, y in zip(a, b))
     _check(ffi, masks, np.array([5], np.int32))
+
+
+def test_rle_reads_only_the_windows(ffi):
+    """with per-slot windows (what the paste / mask assembly kernels leave next to the planes) nothing outside a window is read: the planes
+    carry GARBAGE there and the result still equals the encoding of the clean masks -- windows touching every border, single pixels, a
+    window ending exactly on a 64-row chunk boundary, an empty window"""
+    rng = np.random.default_rng(21)
+    N, K, h, w = 2, 9, 200, 150
+    clean = np.zeros((N, K, h, w), np.uint8)
+    wins = np.zeros((N, K, 4), np.int32)
+    boxes = [(10, 20, 90, 130), (0, 0, 150, 200), (0, 60, 40, 200), (100, 0, 150, 64), (30, 64, 31, 128), (149, 199, 150, 200), (0, 0, 1, 1), (5, 5, 5, 5), (20, 100, 60, 192)]
+    for n in range(N):
+        for k, (x0, y0, x1, y1) in enumerate(boxes):
+            wins[n, k] = (x0, y0, x1, y1)
+            if x1 > x0 and y1 > y0:
+                clean[n, k, y0:y1, x0:x1] = (rng.uniform(0, 1, (y1 - y0, x1 - x0)) < (0.5 if (n + k) % 2 else 0.95)).astype(np.uint8)
+    clean[0, 1] = 1                                   # full plane: window = the image, every column ends set
+    clean[1, 2, 60:200, 0:40] = 1                     # solid block touching the left and bottom borders
+    dirty = clean.copy()
+    for n in range(N):
+        for k, (x0, y0, x1, y1) in enumerate(boxes):
+            g = rng.integers(1, 255, (h, w)).astype(np.uint8)
+            g[y0:y1, x0:x1] = clean[n, k, y0:y1, x0:x1]
+            dirty[n, k] = g
+    count = np.array([9, 9], np.int32)
+    ro, cn, so, ch, st = ffi.rle_encode(dirty, count, None, windows=wins)
+    assert st[2] == 0
+    for n in range(N):
+        for k in range(K):
+            m = n * K + k
+            ref = ora.rle_encode(clean[n, k])
+            assert np.array_equal(cn[ro[m]:ro[m + 1]], ref), (n, k, cn[ro[m]:ro[m + 1]][:6], ref[:6])
+            assert ch[so[m]:so[m + 1]].decode("ascii") == ora.rle_to_string(ref)
+    # windows + per-image sizes smaller than the plane (the window is clamped to the image)
+    hw = np.array([[180, 120], [200, 150]], np.int32)
+    ro, cn, so, ch, st = ffi.rle_encode(dirty, count, hw, windows=wins)
+    for n in range(N):
+        for k in range(K):
+            m = n * K + k
+            ref = ora.rle_encode(clean[n, k, :hw[n, 0], :hw[n, 1]])
+            assert np.array_equal(cn[ro[m]:ro[m + 1]], ref), (n, k)
