@@ -190,14 +190,25 @@ def timed_region(net, step, full_sync, dist, steps):
     full_sync()
     net.step_times()  # drop stale marks
     net.mark_step()
+    # The producer keeps at most two steps in flight: after enqueueing step i it waits (on a completion EVENT, not a device sync) for step
+    # i - 1, as any loop that consumes its results does (isegmi.pipeline.RecordPipeline collects step i - 1's records at that point).  An
+    # unbounded loop lets the host run ~15 steps ahead until the hardware queues fill; while they fill, every step of the upload pipeline
+    # takes 0.1-0.2 ms longer than the one before (9.2 -> 11.1 ms over 17 steps, then back to 8.3: gpurun_out r3 experiments, DESIGN.md
+    # section 5) -- a start-up transient of the queueing, not of the kernels.  ISEGMI_BENCH_DEPTH=0 restores the unbounded loop.
+    depth = int(os.environ.get("ISEGMI_BENCH_DEPTH", "1"))
     t0 = time.perf_counter()
     for i in range(steps):
         step(i)
         net.mark_step()
+        if depth > 0:
+            net.wait_mark(depth)
     full_sync()
     dist.barrier()
     elapsed = dist.max(time.perf_counter() - t0)
-    return elapsed, net.step_times()
+    st = net.step_times()
+    if os.environ.get("ISEGMI_BENCH_DUMP_STEPS") == "1":  # diagnostics: every step's completion interval
+        sys.stderr.write("step intervals (ms): " + " ".join("%.2f" % v for v in st) + "\n")
+    return elapsed, st
 
 
 def roofline_pass(net, step, full_sync, steps, single_stream):
@@ -356,19 +367,19 @@ def bench_yolact(a, dist):
         e2e_region(net, pipe, upload_u8, run_rle, e2e_sync, dist, max(2, a.warmup // 2))
         e2e_elapsed, blocks, chars = e2e_region(net, pipe, upload_u8, run_rle, e2e_sync, dist, a.steps)
         e2e = {"elapsed": e2e_elapsed, "blocks": blocks, "chars_per_step": chars / max(blocks, 1), "record_bytes": pipe.nbytes}
+        K = pipe.K
+        pipe.close()   # full mask planes again (while the pipeline is open only the box windows of the planes are written)
         # the strings the device made for the bench batch, against the host encoder on the uint8 planes (rank 0, after the timed loops)
         net.upload(imgs); net.forward_device(a.batch); net.postprocess_device(size, size); net.rle_device(); full_sync()
         from isegmi.coco import rle_counts, rle_to_string
         so, ch = net.fetch("rle.str_off"), net.fetch("rle.chars").tobytes()
         mk, cn = net.fetch("det.masks", a.batch), net.fetch("det.count", a.batch)
-        K = pipe.K
         e2e["rle_checked"] = 0
         e2e["rle_ok"] = True
         for i in range(a.batch):
             for k in range(0, int(cn[i]), 7):  # every 7th detection: the host encoder takes ~3 ms per 550x550 mask
                 e2e["rle_ok"] &= ch[so[i * K + k]:so[i * K + k + 1]].decode() == rle_to_string(rle_counts(mk[i, k]))
                 e2e["rle_checked"] += 1
-        pipe.close()
         if cgather is not None:
             cgather.close()
     net.upload(imgs)
@@ -562,6 +573,8 @@ def bench_maskrcnn(a, dist, summary=False):
         e2e_region(model, pipe, upload_u8, run_rle, e2e_sync, dist, max(2, warmup // 2))
         e2e_elapsed, nblocks, chars = e2e_region(model, pipe, upload_u8, run_rle, e2e_sync, dist, steps)
         e2e = {"elapsed": e2e_elapsed, "blocks": nblocks, "chars_per_step": chars / max(nblocks, 1), "record_bytes": pipe.nbytes}
+        K = pipe.K
+        pipe.close()   # full mask planes again
         model.upload(x, hw); model.forward_device(batch); model.paste_device(800, 1333); model.rle_device(); full_sync()
         from isegmi.coco import rle_counts, rle_to_string
         so, ch = model.fetch("rle.str_off"), model.fetch("rle.chars").tobytes()
@@ -569,9 +582,8 @@ def bench_maskrcnn(a, dist, summary=False):
         e2e["rle_checked"], e2e["rle_ok"] = 0, True
         for i in range(batch):
             for k in range(0, int(cn[i]), 9):  # every 9th detection: the host encoder takes ~10 ms per 800x1333 mask
-                e2e["rle_ok"] &= ch[so[i * pipe.K + k]:so[i * pipe.K + k + 1]].decode() == rle_to_string(rle_counts(mk[i, k]))
+                e2e["rle_ok"] &= ch[so[i * K + k]:so[i * K + k + 1]].decode() == rle_to_string(rle_counts(mk[i, k]))
                 e2e["rle_checked"] += 1
-        pipe.close()
         if cgather is not None:
             cgather.close()
     model.upload(x, hw)

@@ -319,6 +319,8 @@ int isegmi_engine_preprocess_u8(isegmi_engine* e, const uint8_t* d_u8, int N, in
 /* per-step completion marks on the results stream; step_times returns the intervals between consecutive marks (ms) */
 int isegmi_engine_mark_step(isegmi_engine* e);
 int isegmi_engine_step_times(isegmi_engine* e, float* ms, int cap, int* count);
+/* host wait for the mark `back` marks before the newest (0 = newest): a producer loop's bound on the steps it keeps in flight */
+int isegmi_engine_wait_mark(isegmi_engine* e, int back);
 /* dtype: 0 f32, 1 i32, 2 u8, 3 i64; shape4 receives up to 4 dims */
 int isegmi_engine_buffer_info(isegmi_engine* e, const char* name, void** d_ptr, int64_t* bytes,
                               int32_t* dtype, int64_t* shape4, int32_t* ndim);

@@ -829,6 +829,16 @@ extern "C" int isegmi_engine_mark_step(isegmi_engine* h) {
     return ISEGMI_OK;
 }
 
+// Host wait for the completion mark `back` marks before the newest one (0 = the newest): bounds how many steps a producer loop keeps in flight
+// without synchronising the whole engine.
+extern "C" int isegmi_engine_wait_mark(isegmi_engine* h, int back) {
+    ARG_CHECK(h && back >= 0, "wait_mark args");
+    Engine& e = h->e;
+    if ((size_t)back >= e.step_marks.size()) return ISEGMI_OK;
+    HIP_TRY(hipEventSynchronize(e.step_marks[e.step_marks.size() - 1 - (size_t)back]));
+    return ISEGMI_OK;
+}
+
 extern "C" int isegmi_engine_step_times(isegmi_engine* h, float* ms, int cap, int* count) {
     ARG_CHECK(h && ms && count && cap >= 0, "step_times args");
     Engine& e = h->e;

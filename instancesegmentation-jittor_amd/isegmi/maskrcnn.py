@@ -437,5 +437,5 @@ MaskRCNN.mark_step = _Y.mark_step
 MaskRCNN._u8_staging = _Y._u8_staging
 MaskRCNN._preprocess_u8 = _Y._preprocess_u8
 MaskRCNN.step_times = _Y.step_times
-for _n in ("rle_device", "coco_record_bytes", "pack_coco_records", "download_async", "download_fence", "download_wait", "memory"):
+for _n in ("wait_mark", "rle_device", "coco_record_bytes", "pack_coco_records", "download_async", "download_fence", "download_wait", "memory"):
     setattr(MaskRCNN, _n, getattr(_Y, _n))

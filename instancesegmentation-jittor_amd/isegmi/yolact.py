@@ -333,6 +333,10 @@ class Yolact:
     def mark_step(self):
         _ffi.check(_ffi.lib().isegmi_engine_mark_step(self._h))
 
+    def wait_mark(self, back=0):
+        """host wait for the completion mark `back` marks before the newest one: bounds the steps a producer loop keeps in flight"""
+        _ffi.check(_ffi.lib().isegmi_engine_wait_mark(self._h, int(back)))
+
     def step_times(self, cap=65536):
         """Intervals (ms) between consecutive mark_step() completion marks; clears the marks."""
         ms = (C.c_float * cap)(); cnt = C.c_int()
