@@ -132,3 +132,22 @@ def test_package_imports_no_torch_and_no_oracle():
         if f.endswith(".py"):
             src = open(os.path.join(root, f)).read()
             assert not pat.search(src), f
+
+
+def test_launcher_sets_rank_environment_and_propagates_failure(tmp_path):
+    """python -m isegmi.launch --nproc N ...: N fresh processes with the RANK / WORLD_SIZE environment, the file rendezvous works between
+    them, a failing rank takes the group down and its code is the launcher's"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "instancesegmentation-jittor_amd")
+    w = tmp_path / "w.py"
+    w.write_text("import os, sys\nsys.path.insert(0, %r)\nfrom isegmi.dist import rendezvous_unique_id, rendezvous_cleanup\n"
+                 "r, n = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])\nuid = rendezvous_unique_id(r, n, lambda: bytes([7]) * 128, timeout=30)\n"
+                 "open(os.path.join(%r, 'ok%%d' %% r), 'wb').write(uid)\nimport time; time.sleep(0.3); rendezvous_cleanup(r, n)\n"
+                 "sys.exit(3 if (r == 1 and len(sys.argv) > 1) else 0)\n" % (pkg, str(tmp_path)))
+    env = dict(os.environ, PYTHONPATH=pkg, ISEGMI_RDZV_DIR=str(tmp_path))
+    r = subprocess.run([sys.executable, "-m", "isegmi.launch", "--nproc", "3", str(w)], env=env, timeout=120)
+    assert r.returncode == 0 and all((tmp_path / ("ok%d" % i)).read_bytes() == bytes([7]) * 128 for i in range(3))
+    r = subprocess.run([sys.executable, "-m", "isegmi.launch", "--nproc", "2", str(w), "fail"], env=env, timeout=120)
+    assert r.returncode == 3
