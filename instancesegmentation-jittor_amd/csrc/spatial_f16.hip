@@ -188,6 +188,56 @@ __global__ __launch_bounds__(256) void roi_align_f16_c8_kernel(const RoiLevelsH 
     rh = rh > 1.0f ? rh : 1.0f;
     const float bh = dm_div(rh, (float)PH), bw = dm_div(rw, (float)PW);
     const float cnt = (float)(g * g);
+    if (g == 2) {
+        // sampling_ratio 2 (every FPN head): the bin's four samples are set up first -- tap offsets and weights; a sample outside the map gets
+        // zero weights on clamped taps, which adds the same +0 the scalar form's `continue` skips -- then all SIXTEEN 16-byte taps are
+        // requested before the first is used (round 2 issued four at a time behind a branch per sample: 200 us per R101 bs=8 call at 2.7 TB/s)
+        for (int b = slot; b < nb; b += bpp) {
+            const int ph = b / PW, pw = b - ph * PW;
+            int off[4][4];
+            float wt[4][4];
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx) {
+                const int iy = sidx >> 1, ix = sidx & 1;
+                float y = sh + (float)ph * bh + dm_div(((float)iy + 0.5f) * bh, 2.0f);
+                float x = sw + (float)pw * bw + dm_div(((float)ix + 0.5f) * bw, 2.0f);
+                const bool inside = !(y < -1.0f || y > (float)H || x < -1.0f || x > (float)W);
+                if (y <= 0.0f) y = 0.0f;
+                if (x <= 0.0f) x = 0.0f;
+                int yl = (int)y, xl = (int)x, yh, xh;
+                if (!inside) { yl = 0; xl = 0; y = 0.0f; x = 0.0f; }
+                if (yl >= H - 1) { yh = yl = H - 1; y = (float)yl; } else yh = yl + 1;
+                if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else xh = xl + 1;
+                const float ly = y - (float)yl, lx = x - (float)xl, hy = 1.0f - ly, hx = 1.0f - lx;
+                wt[sidx][0] = inside ? hy * hx : 0.0f; wt[sidx][1] = inside ? hy * lx : 0.0f;
+                wt[sidx][2] = inside ? ly * hx : 0.0f; wt[sidx][3] = inside ? ly * lx : 0.0f;
+                off[sidx][0] = (yl * W + xl) * C; off[sidx][1] = (yl * W + xh) * C; off[sidx][2] = (yh * W + xl) * C; off[sidx][3] = (yh * W + xh) * C;
+            }
+            h8 v[4][4];
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[sidx][t] = *(const h8*)(f + off[sidx][t]);
+            float acc[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = 0.0f;
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float q = wt[sidx][0] * (float)v[sidx][0][i];
+                    q = q + wt[sidx][1] * (float)v[sidx][1][i];
+                    q = q + wt[sidx][2] * (float)v[sidx][2][i];
+                    q = q + wt[sidx][3] * (float)v[sidx][3][i];
+                    acc[i] = acc[i] + q;
+                }
+            h8 r;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) r[i] = (half_t)dm_div(acc[i], cnt);
+            *(h8*)(o + (int64_t)b * C) = r;
+        }
+        return;
+    }
     for (int b = slot; b < nb; b += bpp) {
         const int ph = b / PW, pw = b - ph * PW;
         float acc[8];
@@ -247,6 +297,47 @@ __global__ __launch_bounds__(256) void mask_logits_select_f16_kernel(const half_
             acc = fmaf(v.z, wr[4 * c4 + 2], acc); acc = fmaf(v.w, wr[4 * c4 + 3], acc);
         }
         out[(int64_t)r * HW + p] = dm_sigmoid(fmaf(acc, 1.0f, bias));
+    }
+}
+
+// C = 256 form (round 3): the wave reads a pixel's 256 channels as ONE coalesced 512-B run (32 lanes x 16 B; two pixels per wave-instruction)
+// instead of every lane walking its own pixel's 512 bytes 8 at a time (64 cache lines per instruction, each line touched 16 times: 118 us per
+// R101 bs=8 step against a 64 us HBM floor).  Lane l holds the label's weights for channels 8 (l & 31) .. + 7; the dot product is finished by a
+// butterfly over the 32 lanes -- a different fp32 association than the scalar chain (fp16 path: parity by tolerance).
+__global__ __launch_bounds__(256) void mask_logits_select_f16_c256_kernel(const half_t* __restrict__ feat, int HW, const float* __restrict__ w,
+                                                                           const float* __restrict__ b, const int* __restrict__ labels,
+                                                                           float* __restrict__ out) {
+    const int r = blockIdx.x;
+    const int lab = labels[r];
+    if (lab <= 0) {
+        for (int p = threadIdx.x; p < HW; p += 256) out[(int64_t)r * HW + p] = 0.0f;
+        return;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane >> 5, l32 = lane & 31;
+    float wr[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) wr[i] = w[(int64_t)lab * 256 + l32 * 8 + i];
+    const float bias = b[lab];
+    const half_t* base = feat + (int64_t)r * HW * 256 + l32 * 8;
+    constexpr int U = 4;  // pixels in flight per lane
+    for (int q0 = wave * 2; q0 < HW; q0 += 8 * U) {  // wave-uniform trip count: both halves of the wave reach every shuffle
+        const int p0 = q0 + sub;
+        h8 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int p = p0 + 8 * u;
+            v[u] = *(const h8*)(base + (int64_t)(p < HW ? p : q0) * 256);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc = fmaf((float)v[u][i], wr[i], acc);
+#pragma unroll
+            for (int d = 16; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+            const int p = p0 + 8 * u;
+            if (l32 == 0 && p < HW) out[(int64_t)r * HW + p] = dm_sigmoid(fmaf(acc, 1.0f, bias));
+        }
     }
 }
 
@@ -370,7 +461,10 @@ int mask_logits_select_f16_launch(const void* feat, int R, int HW, int C, const 
                                   hipStream_t st) {
     ARG_CHECK(C % 4 == 0, "C % 4");
     if (R == 0) return ISEGMI_OK;
-    hipLaunchKernelGGL(mask_logits_select_f16_kernel, dim3(R), dim3(256), (size_t)C * sizeof(float), st, (const half_t*)feat, HW, C, w, b, labels, out);
+    if (C == 256 && ((uintptr_t)feat & 15) == 0)
+        hipLaunchKernelGGL(mask_logits_select_f16_c256_kernel, dim3(R), dim3(256), 0, st, (const half_t*)feat, HW, w, b, labels, out);
+    else
+        hipLaunchKernelGGL(mask_logits_select_f16_kernel, dim3(R), dim3(256), (size_t)C * sizeof(float), st, (const half_t*)feat, HW, C, w, b, labels, out);
     HIP_TRY(hipGetLastError());
     return ISEGMI_OK;
 }
