@@ -383,7 +383,11 @@ int yolact_forward(Engine& e, const float* d_images, int N) {
                 SideScope sc(e, 0);
                 TRY(eng_conv(e, nm + ".downsample.0", x, st, 0, 0, nullptr, nm + ".ds", &idt));
             }
-            TRY(eng_conv(e, nm + ".conv1", x, 1, 0, 1, nullptr, nm + ".t1", &t1));
+            // buffers by liveness (see maskrcnn.cpp): one t1 / t2 per stage, two alternating block outputs, the stage's final output on its own
+            // (C3-C5 are read by the lateral convs of the pipelined heads phase; the lat_done fence below guards exactly those)
+            const bool alias = e.param("alias_buffers", 1.0f) != 0.0f;  // 0: one buffer per layer output (rounds 1-2; kept for A/B)
+            const std::string sg = alias ? "res" + std::to_string(li + 2) : nm;
+            TRY(eng_conv(e, nm + ".conv1", x, 1, 0, 1, nullptr, sg + ".t1", &t1));
             if (e.convs.count(nm + ".conv2.conv_offset_mask")) {
                 // DCNv2 3x3 (YOLACT++ backbones): offsets + mask logits from a plain 3x3 -> the nine taps sampled into columns ->
                 // the deformable conv proper as a 1x1 over 9*C channels (weights handed over in KRSC order, bias folded into BN)
@@ -392,15 +396,15 @@ int yolact_forward(Engine& e, const float* d_images, int N) {
                 TRY(eng_conv(e, nm + ".conv2.conv_offset_mask", t1, st, 1, 0, nullptr, nm + ".om", &om));
                 TRY(eng_act(e, nm + ".col", N, om.H, om.W, 9 * t1.C, &col));
                 TRY(deform_im2col_launch((const float*)t1.d, N, t1.H, t1.W, t1.C, (const float*)om.d, 3, 3, st, 1, 1, (float*)col.d, e.cur));
-                TRY(eng_conv(e, nm + ".conv2", col, 1, 0, 1, nullptr, nm + ".t2", &t2));
+                TRY(eng_conv(e, nm + ".conv2", col, 1, 0, 1, nullptr, sg + ".t2", &t2));
             } else {
-                TRY(eng_conv(e, nm + ".conv2", t1, st, 1, 1, nullptr, nm + ".t2", &t2));
+                TRY(eng_conv(e, nm + ".conv2", t1, st, 1, 1, nullptr, sg + ".t2", &t2));
             }
             if (b == 0) TRY(eng_join(e, 0));
             // C3 (then C4, C5) is about to be overwritten: the previous step's lateral convs, running on the heads streams, must
             // have read them (they are the first thing of that phase, so this wait practically never blocks)
             if (li == 1 && b == blocks[1] - 1 && e.lat_pending) HIP_TRY(hipStreamWaitEvent(e.stream, e.lat_done, 0));
-            TRY(eng_conv(e, nm + ".conv3", t2, 1, 0, 1, &idt, nm + ".out", &y));
+            TRY(eng_conv(e, nm + ".conv3", t2, 1, 0, 1, &idt, !alias ? nm + ".out" : b == blocks[li] - 1 ? sg + ".C" : sg + (b & 1 ? ".outB" : ".outA"), &y));
             x = y;
         }
         outs[li] = x;

@@ -137,10 +137,16 @@ int maskrcnn_forward(Engine& e, const float* d_images, int N) {
                 SideScope sc(e, 0);
                 TRY(eng_conv(e, nm + ".downsample.0", x, sd, 0, 0, nullptr, nm + ".ds", &idt));
             }
-            TRY(eng_conv(e, nm + ".conv1", x, sd, 0, 1, nullptr, nm + ".t1", &t1));  // STRIDE_IN_1X1
-            TRY(eng_conv(e, nm + ".conv2", t1, 1, 1, 1, nullptr, nm + ".t2", &t2));
+            // Buffers by LIVENESS, not by layer (round 3): a stage owns one t1, one t2, two alternating block outputs and its final output
+            // C<l>.  Everything runs in order on the main stream (the shortcut of block 0 is joined before conv3), so a buffer's last reader
+            // is always enqueued before its next writer.  Besides the memory (R101 bs=8: 33 x 3 buffers -> 4 x 5), a dead activation is now
+            // overwritten while its lines still sit in the Infinity Cache instead of being written back to HBM behind the live traffic.
+            const bool alias = e.param("alias_buffers", 1.0f) != 0.0f;  // 0: one buffer per layer output (rounds 1-2; kept for A/B)
+            const std::string sg = alias ? "res" + std::to_string(li + 2) : nm;
+            TRY(eng_conv(e, nm + ".conv1", x, sd, 0, 1, nullptr, sg + ".t1", &t1));  // STRIDE_IN_1X1
+            TRY(eng_conv(e, nm + ".conv2", t1, 1, 1, 1, nullptr, sg + ".t2", &t2));
             if (b == 0) TRY(eng_join(e, 0));
-            TRY(eng_conv(e, nm + ".conv3", t2, 1, 0, 1, &idt, nm + ".out", &y));
+            TRY(eng_conv(e, nm + ".conv3", t2, 1, 0, 1, &idt, !alias ? nm + ".out" : b == blocks[li] - 1 ? sg + ".C" : sg + (b & 1 ? ".outB" : ".outA"), &y));
             x = y;
         }
         C[li] = x;

@@ -24,7 +24,7 @@ def _compare(net, ref, x, size, n):
     out = net(x)
     refd = ref.forward(x)
     for name in ("C3", "P3", "P5", "P7", "proto"):
-        eng_name = {"C3": "backbone.layers.1.3.out"}.get(name, name)
+        eng_name = {"C3": "res3.C"}.get(name, name)   # layer 1 = res3; a stage's final output has its own buffer
         got = net.fetch(eng_name, n)
         assert np.array_equal(got.reshape(ref.feats[name].shape), ref.feats[name]), name
     if net.fuse_heads:  # one (A*117)-wide conv: per pixel [Ax4 loc | Ax81 conf | Ax32 mask pre-tanh], A = 3 (9 for YOLACT++)
