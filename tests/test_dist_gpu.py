@@ -168,3 +168,29 @@ def test_two_ranks_share_one_gpu_through_rccl(ffi, tmp_path):
     want = inference(demo, images, batch_size=2)
     demo.close()
     assert got[0] == got[1] == json.loads(json.dumps(want)) and len(want) > 20
+
+
+@pytest.mark.parametrize("model_args", [["--no-maskrcnn"], ["--model", "maskrcnn"]])
+def test_bench_multi_rank_code_path_on_one_gpu(ffi, model_args):
+    """bench.py exactly as the driver launches it for N > 1 (`python -m torch.distributed.run ... bench.py --gpus N`), with one rank and
+    ISEGMI_BENCH_FORCE_DIST=1 so that the whole N > 1 code path runs on the one GPU at hand: gloo rendezvous, two RCCL communicators (the
+    raw-record gather inside `value`, the COCO-record gather inside `value_e2e`), barrier + max-reduce around the timed regions, ONE JSON line."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-latency"] + model_args
+    env = dict(os.environ, ISEGMI_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["ranks_with_records"] == 1 and d["value"] > 0 and d["value_e2e"] > 0
+    assert d["e2e"]["device_rle_equals_host_encoder"] is True and d["e2e"]["blocks_collected"] == 6
