@@ -120,7 +120,8 @@ class COCODemo:
             self._model = None
 
 
-def inference(predictor, images, image_ids=None, batch_size=None, group="canvas", rank=0, world=1, sizes=None, stats=None, force_gather=False):
+def inference(predictor, images, image_ids=None, batch_size=None, group="canvas", rank=0, world=1, sizes=None, stats=None, force_gather=False,
+              workers=4):
     """engine/inference.py-shaped evaluation (README.md:344-347): images -> COCO-format result list (bbox + segm) ready for json.dump.
 
     The path the benchmark measures, end to end: batches of `batch_size` resized uint8 images go up through pinned memory (double-buffered),
@@ -133,7 +134,9 @@ def inference(predictor, images, image_ids=None, batch_size=None, group="canvas"
     group:  "canvas" -- batch only images whose padded network canvas is identical, so every image's result equals its single-image
             result (to_image_list pads a batch to its largest member and the RPN sees the padding); "aspect" -- upstream's
             ASPECT_RATIO_GROUPING (portrait / landscape), results then depend on the batch composition exactly as upstream's do.
-    stats:  optional dict, receives steps / images / seconds of the device loop."""
+    stats:  optional dict, receives steps / images / seconds of the device loop.
+    workers: host threads that load + resize (PIL, which releases the GIL) the NEXT batch while the current one is enqueued and the previous
+            one's records are unpacked; 0 = inline."""
     import time
     from .coco import results_from_records
     from .pipeline import RecordPipeline, make_gather, schedule_batches
@@ -181,18 +184,35 @@ def inference(predictor, images, image_ids=None, batch_size=None, group="canvas"
             for i in b:
                 per_image[i] = by_id.get(ids[i], [])
 
+    def load(i):   # host: decode + PIL resize (outside the hot path)
+        return maskrcnn_resize_u8(get(i), predictor.min_image_size, predictor.max_image_size)
+    pool = None
+    if workers and workers > 0:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=int(workers))
+    mine = [j for j in range(rank, len(batches), world)]
+    prefetch = {}
+
+    def request(j):
+        if j is not None and j < len(batches) and j not in prefetch:
+            prefetch[j] = [pool.submit(load, i) for i in batches[j]] if pool else None
+
     t0 = time.perf_counter()
     nsteps = -(-len(batches) // world)
+    if mine:
+        request(mine[0])
     for step in range(nsteps):
         j = step * world + rank
         if j >= len(batches):
             consume(pipe.submit_empty(step))
             continue
         b = batches[j]
+        request(j + world)                   # the next batch of this rank resizes on the worker threads meanwhile
+        futs = prefetch.pop(j, None)
+        resized = [f.result() for f in futs] if futs else [load(i) for i in b]
         slot = step & 1
         off, hw = 0, []
-        for i in b:                          # host: PIL resize (image decode / resize is outside the hot path) into pinned memory
-            im = maskrcnn_resize_u8(get(i), predictor.min_image_size, predictor.max_image_size)
+        for im in resized:                   # into pinned memory, back to back
             pin[slot].array[off:off + im.size] = im.reshape(-1)
             off += im.size
             hw.append(im.shape[:2])
@@ -205,6 +225,8 @@ def inference(predictor, images, image_ids=None, batch_size=None, group="canvas"
     for done in pipe.flush():
         consume(done)
     model.sync()
+    if pool:
+        pool.shutdown()
     if stats is not None:
         stats.update(steps=nsteps, images=n_img, seconds=time.perf_counter() - t0, batches=len(batches), batch_size=bs, world=world)
     pipe.close()
