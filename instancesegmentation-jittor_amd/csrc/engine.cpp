@@ -48,6 +48,11 @@ static int timed_conv(Engine& e, const std::string& label, const isegmi_conv_des
         HIP_TRY(hipEventCreate(&b));
         HIP_TRY(hipEventRecord(a, e.cur));
     }
+    if (e.conv_trace) {  // dev tools (tools/conv_traffic.py): the launch order, to join per-dispatch counters with layers
+        const int Ho = (d->H + 2 * d->pad - d->R) / d->stride + 1, Wo = (d->W + 2 * d->pad - d->S) / d->stride + 1;
+        fprintf(stderr, "convlaunch\t%s\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\n", label.c_str(), d->N, d->H, d->W, d->Cin, d->Cout, d->R, d->stride, Ho * Wo * d->N,
+                res ? 1 : 0);
+    }
     int rc = L->f16 ? conv2d_f16_launch(d, in, L->d_w, L->d_scale, L->d_shift, res, out, out_f32 ? 1 : 0, e.cur)
                     : conv2d_launch(d, in, L->d_w, L->d_scale, L->d_shift, res, (float*)out, e.cur);
     if (e.conv_timing) {
@@ -681,6 +686,7 @@ extern "C" int isegmi_engine_set_param(isegmi_engine* h, const char* name, float
     h->e.params[name] = value;
     if (std::string(name) == "timing") h->e.timing = value != 0.0f;
     if (std::string(name) == "conv_timing") h->e.conv_timing = value != 0.0f;
+    if (std::string(name) == "conv_trace") h->e.conv_trace = value != 0.0f;
     if (std::string(name) == "multi_stream") h->e.multi_stream = value != 0.0f;
     if (std::string(name) == "fp16") h->e.fp16 = value != 0.0f;
     return ISEGMI_OK;

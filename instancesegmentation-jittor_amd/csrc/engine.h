@@ -110,6 +110,7 @@ struct Engine {
     bool conv_timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> conv_evs;
     std::vector<std::pair<std::string, double>> conv_ev_info;  // (label, flops) per pending event pair
+    bool conv_trace = false;  // param "conv_trace": one stderr line per conv launch
     std::map<std::string, std::pair<double, double>> conv_layers;  // label -> (flops, ms) accumulated
     double conv_flops_pending = 0, conv_flops = 0, conv_ms = 0;
     int64_t conv_launches = 0;

@@ -1,0 +1,90 @@
+"""Per-LAYER HBM traffic of the conv launches (dev tool): joins rocprofv3's per-dispatch FETCH_SIZE / WRITE_SIZE with the engine's launch order.
+
+  on the GPU box, one pass per counter (tools/conv_traffic.sh does both and the join):
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d D1 -o run -- python3 tools/conv_traffic.py run yolact 8 2> fetch.log
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d D2 -o run -- python3 tools/conv_traffic.py run yolact 8 2> write.log
+    python tools/conv_traffic.py join fetch.log D1 D2 > profiles/rNN_conv_traffic_<tag>.txt
+
+"run" drives the model on ONE stream: 2 warm steps, one step with the engine's "conv_trace" on (one stderr line per conv launch, in order), 3 more.
+"join" averages the last 3 steps' counters per launch position.  FETCH_SIZE is doubled (the gfx950 wide-read undercount, MI355X guide; every A / B tile
+load of the conv kernels is 16 B per lane), both counters are KB.  Algorithmic bytes = input + weights + residual + output, each once."""
+import csv
+import glob
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CONV_KERNELS = ("conv_mfma", "conv_hybrid_kernel", "conv_f16_glds_kernel", "conv_f16_persist_kernel", "conv3x3_f16_strip_kernel")
+STEPS_WARM, STEPS_AFTER = 2, 3
+
+
+def run(argv):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "instancesegmentation-jittor_amd")]
+    import numpy as np
+    model, bs = argv[0], int(argv[1])
+    fp16 = "fp16" in argv
+    depth = 101 if "101" in argv else 50
+    rng = np.random.default_rng(1)
+    if model == "yolact":
+        from isegmi.weights import yolact_state_dict
+        from isegmi.yolact import Yolact, fast_base_transform
+        net = Yolact(yolact_state_dict(1234), max_batch=bs, fp16=fp16)
+        net.upload(fast_base_transform(rng.uniform(0, 255, (bs, 550, 550, 3)).astype(np.float32)))
+    else:
+        from isegmi.weights import maskrcnn_state_dict
+        from isegmi.maskrcnn import MaskRCNN, MaskRCNNConfig, prepare_images
+        x, hw = prepare_images([rng.uniform(0, 255, (800, 1333, 3)).astype(np.float32) for _ in range(bs)])
+        net = MaskRCNN(maskrcnn_state_dict(1234, depth), x.shape[1], x.shape[2], cfg=MaskRCNNConfig(depth=depth), max_batch=bs, fp16=fp16)
+        net.upload(x, hw)
+    net.set_param("multi_stream", 0.0)
+    for _ in range(STEPS_WARM):
+        net.forward_device(bs)
+    net.sync()
+    net.set_param("conv_trace", 1.0)
+    net.forward_device(bs)
+    net.sync()
+    net.set_param("conv_trace", 0.0)
+    for _ in range(STEPS_AFTER):
+        net.forward_device(bs)
+    net.sync()
+
+
+def counters(d, name):
+    path = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
+    rows = [(int(r["Dispatch_Id"]), float(r["Counter_Value"])) for r in csv.DictReader(open(path))
+            if r["Counter_Name"] == name and any(k in r["Kernel_Name"] for k in CONV_KERNELS)]
+    rows.sort()
+    return [v for _, v in rows]
+
+
+def join(argv):
+    log, dfetch, dwrite = argv[:3]
+    esz = 2 if "fp16" in argv else 4
+    layers = []
+    for ln in open(log, errors="replace"):
+        if ln.startswith("convlaunch\t"):
+            p = ln.rstrip("\n").split("\t")
+            layers.append((p[1],) + tuple(int(v) for v in p[2:]))
+    L = len(layers)
+    f, w = counters(dfetch, "FETCH_SIZE"), counters(dwrite, "WRITE_SIZE")
+    nsteps = STEPS_WARM + 1 + STEPS_AFTER
+    assert L and len(f) == nsteps * L and len(w) == nsteps * L, (L, len(f), len(w))
+    out = []
+    for i, (name, N, H, W, Cin, Cout, R, stride, M, res) in enumerate(layers):
+        fb = sum(f[(nsteps - 1 - s) * L + i] for s in range(STEPS_AFTER)) / STEPS_AFTER * 1024.0 * 2.0
+        wb = sum(w[(nsteps - 1 - s) * L + i] for s in range(STEPS_AFTER)) / STEPS_AFTER * 1024.0
+        cin = 3 if (R == 7 and Cin == 4) else Cin
+        rd = (N * H * W * Cin + R * R * cin * Cout) * esz + (M * Cout * esz if res else 0)
+        wr = M * Cout * esz
+        out.append((fb + wb - rd - wr, name, M, R * R * Cin, Cout, R, stride, res, rd, fb, wr, wb))
+    tr = sum(o[8] for o in out); tf = sum(o[9] for o in out); tw = sum(o[10] for o in out); tb = sum(o[11] for o in out)
+    print("%d conv launches per step; read: algorithmic %.1f MB, FETCH_SIZE x2 %.1f MB (%.2fx); write: algorithmic %.1f MB, WRITE_SIZE %.1f MB (%.2fx); "
+          "total %.2f GB vs %.2f GB algorithmic = %.2fx" % (L, tr / 1e6, tf / 1e6, tf / tr, tw / 1e6, tb / 1e6, tb / tw, (tf + tb) / 1e9, (tr + tw) / 1e9, (tf + tb) / (tr + tw)))
+    print("%-60s %8s %6s %5s %4s %3s | %9s %9s %6s | %9s %9s %6s | %9s" % ("layer (sorted by excess bytes)", "M", "K", "Cout", "RxS", "res", "read MB", "fetched", "x", "write MB", "written", "x", "excess MB"))
+    for ex, name, M, K, Cout, R, stride, res, rd, fb, wr, wb in sorted(out, reverse=True):
+        print("%-60s %8d %6d %5d %dx%d/%d %2d | %9.2f %9.2f %6.2f | %9.2f %9.2f %6.2f | %9.2f" % (name[:60], M, K, Cout, R, R, stride, res, rd / 1e6, fb / 1e6, fb / max(rd, 1), wr / 1e6, wb / 1e6,
+                                                                                             wb / max(wr, 1), ex / 1e6))
+
+
+if __name__ == "__main__":
+    {"run": run, "join": join}[sys.argv[1]](sys.argv[2:])
