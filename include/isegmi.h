@@ -47,7 +47,9 @@ int isegmi_sync(void);
 /* ---- convolution family: M2 M3 M4 M8 M10 M11 Y2 Y3 Y4 Y5 ----
  * Implicit-GEMM convolution on v_mfma_f32_32x32x2_f32 with fused per-channel affine
  * (folded BN or bias), residual add and activation.  Per output element the accumulation is
- * a k-ordered fmaf chain over (r, s, cin) from +0 -- bit-identical to the oracle. */
+ * ONE fmaf chain from +0 over the R*S*Cin products, walked in groups of 128 input channels
+ * (outermost), then (r, s), then the group's channels -- plain (r, s, cin) for Cin <= 128 and for
+ * 1x1 convolutions -- bit-identical to the oracle (oracle/ora_ops.c, ora_conv2d). */
 typedef struct isegmi_conv_desc {
     int32_t N, H, W, Cin;            /* input NHWC; Cin % 32 == 0, or Cin == 4 with R==S==7 (stem) */
     int32_t Cout, R, S, stride, pad;

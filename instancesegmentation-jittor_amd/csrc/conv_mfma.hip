@@ -35,16 +35,30 @@ struct ConvK {
     float* out;
     int N, H, W, Cin, Cout, R, S, stride, pad, Ho, Wo, M;
     int nchunks, cin_chunks;
+    int kgroup;  // K order: channel groups of kgroup 32-chunks outermost, then (r, s), then the group's chunks (kgroup == cin_chunks: plain (r, s, cin))
     int64_t wrow;
     unsigned in_bytes, out_bytes, res_bytes, w_bytes;
+    int64_t in_touched;  // host only (conv_set_band)
     int act, out_div, contiguous;
     int64_t out_img_stride, out_pix_stride;
     int mtiles, ntiles;
-    int mfast;  // tile order within an XCD: 1 = M fastest (weights larger than the input), 0 = Cout fastest
+    int nband;  // tile order: Cout tiles in BANDS of nband; a band's tiles are walked pixel rows outermost, the band's Cout tiles innermost, band after
+                // band; every XCD takes a contiguous eighth of that walk (nband == ntiles: Cout fastest; nband == 1: M fastest).  See conv_set_band().
     int m_begin;  // first output row of this launch's tile grid (0, or the start of the small-tile tail of a hybrid launch)
 };
 
+// logical tile index (contiguous per XCD) -> (pixel-row tile, Cout tile); all scalar
+__device__ __forceinline__ void conv_tile_of(const ConvK& p, const int logical, int& mt, int& nt) {
+    const int per = p.mtiles * p.nband;  // tiles of a full band
+    const int band = logical / per, rem = logical - band * per;
+    const int nb0 = band * p.nband;
+    const int bw = min(p.nband, p.ntiles - nb0);  // the last band may be narrower
+    mt = rem / bw;
+    nt = nb0 + (rem - mt * bw);
+}
+
 constexpr int LDS_ROW = 36;
+constexpr int CONV_KGROUP_CHUNKS = 4;  // 128 input channels per K group (ORA_CONV_CGROUP in the oracle)
 
 
 
@@ -150,8 +164,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK p) {
     // an XCD's consecutive tiles walk the operand that is SMALLER in bytes, so its L2 holds all of that one and only an
     // eighth of the larger (weights on small-M layers: res5 / P5-P7 heads / everything at bs=1 were re-streaming the whole
     // filter bank from HBM into every XCD)
-    const int nt = p.mfast ? logical / p.mtiles : logical % p.ntiles;
-    const int mt = p.mfast ? logical % p.mtiles : logical / p.ntiles;
+    int mt, nt;
+    conv_tile_of(p, logical, mt, nt);
     const int m0 = mt * BM, n0 = nt * BN;
 
     // ---- loader state: thread covers row (tid>>2)+64*j, 8-group g = tid&3 of the 32-chunk
@@ -182,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK p) {
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     u32x4 ra[APASS][2];
     u32x4 rb[BPASS][2];
-    int kr = 0, ks = 0, kc = 0;  // (r, s, cin-chunk) of the NEXT chunk to load
+    int kr = 0, ks = 0, kc = 0, kg = 0, glen = p.kgroup;  // (r, s, chunk within the channel group, group base) of the NEXT chunk to load
 
     auto load_chunk = [&](int chunk) {
 #pragma unroll
@@ -198,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK p) {
             } else {
                 const int hi = hi0[j] + kr, wi = wi0[j] + ks;
                 const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-                const unsigned off = ((unsigned)((nb[j] + hi) * p.W + wi) * (unsigned)p.Cin + (unsigned)(kc * 32 + g * 8)) * 4u;
+                const unsigned off = ((unsigned)((nb[j] + hi) * p.W + wi) * (unsigned)p.Cin + (unsigned)((kg + kc) * 32 + g * 8)) * 4u;
                 const unsigned o0 = ok ? off : OOB;
                 ra[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, o0, 0, 0);
                 ra[j][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, ok ? off + 16u : OOB, 0, 0);
@@ -206,12 +220,18 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK p) {
         }
 #pragma unroll
         for (int j = 0; j < BPASS; ++j) {
-            const float* src = wsrc + (int64_t)(64 * j) * p.wrow + chunk * 32;
+            const float* src = wsrc + (int64_t)(64 * j) * p.wrow + (STEM ? chunk : (kr * p.S + ks) * p.cin_chunks + kg + kc) * 32;
             rb[j][0] = *(const u32x4*)src;
             rb[j][1] = *(const u32x4*)(src + 4);
         }
         if (!STEM) {
-            if (++kc == p.cin_chunks) { kc = 0; if (++ks == p.S) { ks = 0; ++kr; } }
+            if (++kc == glen) {
+                kc = 0;
+                if (++ks == p.S) {
+                    ks = 0;
+                    if (++kr == p.R) { kr = 0; kg += glen; glen = min(p.kgroup, p.cin_chunks - kg); if (glen <= 0) { glen = 1; kg = 0; } }
+                }
+            }
         }
     };
     auto store_chunk = [&](int stage) {
@@ -323,8 +343,8 @@ __device__ __forceinline__ void conv_v2_body(const ConvK& p, float* smem, const 
     const int wm = wave >> 1, wn = wave & 1;
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
     const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int nt = p.mfast ? logical / p.mtiles : logical % p.ntiles;
-    const int mt = p.mfast ? logical % p.mtiles : logical / p.ntiles;
+    int mt, nt;
+    conv_tile_of(p, logical, mt, nt);
     const int m0 = p.m_begin + mt * BM, n0 = nt * BN;
 
     // loader: thread covers row tid>>2 of the A and of the B tile, 8 consecutive k (g = tid&3) of the 32-chunk
@@ -366,7 +386,7 @@ __device__ __forceinline__ void conv_v2_body(const ConvK& p, float* smem, const 
     //    registers into b128 order (8 v_mov per chunk), and all LDS addresses are per-stage constants with immediate offsets.
     const u32x4 rs_null = u32x4{rs_in.x, rs_in.y, 0u, rs_in.w};
     u32x4 ra[RING][2], rb[RING][2];
-    int kr = 0, ks = 0, kc = 0, chunk = 0;  // position of the next chunk to load (strictly in order)
+    int kr = 0, ks = 0, kc = 0, kg = 0, glen = p.kgroup, chunk = 0;  // position of the next chunk to load (strictly in order)
     const bool taps = p.R * p.S > 1 || p.pad > 0;  // 1x1 / pad 0: every tap of a row < M is inside the image
     // round 2, second pass: the two remaining instructions went too -- the lane's voffset (pixel base + tap offset, or the
     // out-of-range constant for a padding tap / a row past M) is rebuilt only when the tap changes, behind a scalar branch; the
@@ -377,21 +397,27 @@ __device__ __forceinline__ void conv_v2_body(const ConvK& p, float* smem, const 
     auto load_chunk = [&](int slot) {
         const bool live = chunk < p.nchunks;
         const u32x4 rsa = live ? rs_in : rs_null, rsb = live ? rs_w : rs_null;  // scalar selects
-        const unsigned soffb = (unsigned)chunk * 128u;
+        const unsigned soffb = (unsigned)((kr * p.S + ks) * p.cin_chunks + kg + kc) * 128u;   // scalar: the chunk's place in the (r, s, cin) packed weight row
         asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(ra[slot][0]) : "v"(avoff), "s"(rsa), "s"(soffa) : "memory");
         asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:16" : "=v"(ra[slot][1]) : "v"(avoff), "s"(rsa), "s"(soffa) : "memory");
         asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(rb[slot][0]) : "v"(wbase), "s"(rsb), "s"(soffb) : "memory");
         asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:16" : "=v"(rb[slot][1]) : "v"(wbase), "s"(rsb), "s"(soffb) : "memory");
         ++chunk;
         soffa += 128u;
-        if (++kc == p.cin_chunks) {  // uniform: next tap -- the only place with per-lane work
+        if (++kc == glen) {  // uniform: next tap (of this channel group, or the first of the next group) -- the only place with per-lane work
             kc = 0;
-            soffa = 0;
-            if (++ks == p.S) { ks = 0; ++kr; }
+            if (++ks == p.S) {
+                ks = 0;
+                if (++kr == p.R) { kr = 0; kg += glen; glen = min(p.kgroup, p.cin_chunks - kg); if (glen <= 0) { glen = 1; kg = 0; } }  // past the end: loads are dead
+            }
+            soffa = (unsigned)kg * 128u;
             int tr = __builtin_amdgcn_readfirstlane(kr), ts = __builtin_amdgcn_readfirstlane(ks);
             asm volatile("" : "+s"(tr), "+s"(ts));  // keeps the tap change behind its branch: speculated, its VALU work would run every chunk
-            const bool okt = taps ? (unsigned)(hi0 + tr) < (unsigned)p.H && (unsigned)(wi0 + ts) < (unsigned)p.W : ok0;
-            avoff = okt ? abase + (unsigned)((tr * p.W + ts) * p.Cin) * 4u : OOB;
+            // branch-free on purpose (bitwise &, no short circuit): with && hipcc built this from three exec-mask regions (s_and_saveexec + branches),
+            // ~70 cycles per tap change; this form is 2 v_add + 2 v_cmp + v_add + v_cndmask
+            const unsigned inb = (unsigned)((unsigned)(hi0 + tr) < (unsigned)p.H) & (unsigned)((unsigned)(wi0 + ts) < (unsigned)p.W);  // 1x1 / pad 0: hi0 = wi0 = 0
+            const unsigned tapv = abase + (unsigned)((tr * p.W + ts) * p.Cin) * 4u;
+            avoff = inb ? tapv : OOB;
         }
     };
     // LDS addresses (floats): per-thread constants; the stage is a compile-time term wherever the loop is unrolled over it
@@ -538,8 +564,8 @@ __device__ __forceinline__ void conv_mfma16_body(const ConvK& p, float* smem16, 
     const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
     // an XCD's consecutive tiles walk the operand that is SMALLER in bytes, so its L2 holds all of that one and only an
     // eighth of the larger
-    const int nt = p.mfast ? logical / p.mtiles : logical % p.ntiles;
-    const int mt = p.mfast ? logical % p.mtiles : logical / p.ntiles;
+    int mt, nt;
+    conv_tile_of(p, logical, mt, nt);
     const int m0 = p.m_begin + mt * BM, n0 = nt * BN;
 
     // loader: thread covers row tid>>3 (32 rows) and 4 consecutive k (g8 = tid&7) of the 32-chunk
@@ -578,7 +604,7 @@ __device__ __forceinline__ void conv_mfma16_body(const ConvK& p, float* smem16, 
     const u32x4 rs_in = make_rsrc(p.in, p.in_bytes), rs_w = make_rsrc(p.w, p.w_bytes);
     const u32x4 rs_null = u32x4{rs_in.x, rs_in.y, 0u, rs_in.w};
     u32x4 ra[RING], rb[RING][WN];
-    int kr = 0, ks = 0, kc = 0, chunk = 0;  // position of the next chunk to load (they are loaded strictly in order)
+    int kr = 0, ks = 0, kc = 0, kg = 0, glen = p.kgroup, chunk = 0;  // position of the next chunk to load (they are loaded strictly in order)
     // Per-chunk vector work is ZERO instructions (see conv_mfma_v2_kernel: every VALU instruction costs matrix-pipe cycles): the
     // lane's voffset = pixel base + tap offset, or the out-of-range constant for a padding tap / a row past M, is rebuilt only
     // when the tap changes (a scalar branch); the cin chunk inside the tap and B's chunk offset ride in the scalar offset
@@ -591,7 +617,7 @@ __device__ __forceinline__ void conv_mfma16_body(const ConvK& p, float* smem16, 
     auto load_chunk = [&](int slot) {
         const bool live = chunk < p.nchunks && !EXPERIMENT_NO_LOADS;
         const u32x4 rsa = live ? rs_in : rs_null, rsb = live ? rs_w : rs_null;
-        const unsigned soffb = (unsigned)chunk * 128u;
+        const unsigned soffb = (unsigned)((kr * p.S + ks) * p.cin_chunks + kg + kc) * 128u;
         asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(ra[slot]) : "v"(avoff), "s"(rsa), "s"(soffa) : "memory");
 #pragma unroll
         for (int t = 0; t < WN; ++t) {  // weight rows lrow and lrow + 32
@@ -600,14 +626,20 @@ __device__ __forceinline__ void conv_mfma16_body(const ConvK& p, float* smem16, 
         }
         ++chunk;
         soffa += 128u;
-        if (++kc == p.cin_chunks) {  // uniform: next tap
+        if (++kc == glen) {  // uniform: next tap (of this channel group, or the first of the next group)
             kc = 0;
-            soffa = 0;
-            if (++ks == p.S) { ks = 0; ++kr; }
+            if (++ks == p.S) {
+                ks = 0;
+                if (++kr == p.R) { kr = 0; kg += glen; glen = min(p.kgroup, p.cin_chunks - kg); if (glen <= 0) { glen = 1; kg = 0; } }
+            }
+            soffa = (unsigned)kg * 128u;
             int tr = __builtin_amdgcn_readfirstlane(kr), ts = __builtin_amdgcn_readfirstlane(ks);
             asm volatile("" : "+s"(tr), "+s"(ts));  // keeps the tap change behind its branch: speculated, its VALU work would run every chunk
-            const bool okt = taps ? (unsigned)(hi0 + tr) < (unsigned)p.H && (unsigned)(wi0 + ts) < (unsigned)p.W : ok0;
-            avoff = okt ? abase + (unsigned)((tr * p.W + ts) * p.Cin) * 4u : OOB;
+            // branch-free on purpose (bitwise &, no short circuit): with && hipcc built this from three exec-mask regions (s_and_saveexec + branches),
+            // ~70 cycles per tap change; this form is 2 v_add + 2 v_cmp + v_add + v_cndmask
+            const unsigned inb = (unsigned)((unsigned)(hi0 + tr) < (unsigned)p.H) & (unsigned)((unsigned)(wi0 + ts) < (unsigned)p.W);  // 1x1 / pad 0: hi0 = wi0 = 0
+            const unsigned tapv = abase + (unsigned)((tr * p.W + ts) * p.Cin) * 4u;
+            avoff = inb ? tapv : OOB;
         }
     };
     // A arrives in natural k order (two 8-byte stores: rows are only 8-byte aligned at this pitch); the packed weight row
@@ -841,10 +873,43 @@ static int check_desc(const isegmi_conv_desc* d) {
     return ISEGMI_OK;
 }
 
+// Tile order of a launch (k.mtiles / k.ntiles set).  Each of the 8 XCDs has its own 4 MB L2 and takes a contiguous eighth of the tile walk, so the
+// walk decides how often the two operands cross the fabric.  With nb bands of Cout tiles: nb <= 8 -- a band is shared by 8 / nb XCDs, each on its
+// own range of pixel rows: the input is fetched nb times in total, the filter bank 8 / nb times; nb > 8 -- every XCD walks all pixel rows for each of
+// its bands: the input 8 times (once per XCD if the XCD's tiles are all resident at once, else once per band), the bank once.  A band whose filters
+// (bn * nband * K * 4 bytes) do not stay in L2 next to the streaming input is fetched again by every group of pixel-row tiles the XCD runs one after
+// the other.  Rounds 1-2 knew only nb = 1 ("Cout fastest") and nb = ntiles ("M fastest", whenever the bank was larger than the input): res5's 1x1
+// layers, the stride-2 3x3, the 351-wide Yolact head and Mask R-CNN's fc6 fetched 4-9x their operands (profiles/r03_conv_traffic_*.txt).
+static void conv_set_band(ConvK& k, const int bn, const int blocks_per_cu, const int64_t in_touched) {
+    static int legacy = -1;
+    if (legacy < 0) { const char* e = getenv("ISEGMI_CONV_BAND"); legacy = (e && atoi(e) == 0) ? 1 : 0; }
+    if (legacy) { k.nband = (int64_t)k.w_bytes > (int64_t)k.in_bytes ? 1 : k.ntiles; return; }
+    const double A = (double)in_touched, B = (double)k.nchunks * 128.0 * bn * k.ntiles;
+    const double l2_keep = 2.5e6;                       // of the 4 MB: what a resident operand may take next to the streaming one
+    const double slots = 32.0 * blocks_per_cu;          // resident blocks of one XCD
+    const double tiles_xcd = (double)k.mtiles * k.ntiles / 8.0;
+    const double rounds = tiles_xcd / slots > 1.0 ? tiles_xcd / slots : 1.0;
+    double best = 0;
+    int best_bw = k.ntiles;
+    for (int nb = 1; nb <= k.ntiles; nb *= 2) {
+        const int bw = cdiv(k.ntiles, nb), nbands = cdiv(k.ntiles, bw);
+        const double band_b = B / nbands;
+        double a, b;
+        if (nbands <= 8) { a = A * nbands; b = B * (8.0 / nbands); }
+        else { a = A * 8.0 * (rounds > 1.0 ? nbands / 8.0 : 1.0); b = B; }
+        if (band_b > l2_keep && rounds > 1.0) b *= rounds;   // not resident: streamed again by every round of pixel-row tiles
+        const double cost = a + b;
+        if (nb == 1 || cost < best * 0.97) { best = cost; best_bw = bw; }  // ties and near-ties stay with the wider band
+        if (bw == 1) break;
+    }
+    k.nband = best_bw;
+}
+
 template <int BM, int BN, int WM, int WN>
 static int launch(const isegmi_conv_desc* d, ConvK& k, hipStream_t st) {
     k.mtiles = cdiv(k.M, BM);
     k.ntiles = cdiv(d->Cout, BN);
+    conv_set_band(k, BN, 2, k.in_touched);
     const size_t lds = 2 * (size_t)(BM + BN) * LDS_ROW * sizeof(float);
     const dim3 grid((unsigned)(k.mtiles * k.ntiles)), block(256);
     if (is_stem(d)) {
@@ -887,12 +952,20 @@ int conv2d_launch(const isegmi_conv_desc* d, const float* in, const float* w, co
     k.M = (int)M64;
     k.nchunks = n_chunks(d);
     k.cin_chunks = is_stem(d) ? 1 : d->Cin / 32;
+    // K order (the numerics contract with oracle/ora_ops.c, ora_conv2d): input channels in groups of 128 (= 4 chunks) outermost, then (r, s), then
+    // the group's chunks.  With all of Cin inside every tap (rounds 1-2) the concurrently running tiles of an XCD streamed their whole activation
+    // window once PER TAP through a 4 MB L2 that also holds the filter bank: 3x3 layers fetched their input 3.7-4.2x (proto_net, FPN / RPN heads,
+    // the mask head) and res5's 3x3s 26x; with 128-channel groups the window of one group stays in L2 for its nine taps: 10.2 -> 8.5 GB fetched
+    // + written per Yolact step (1.51x -> 1.26x algorithmic), 9.8 -> 8.6 GB Mask R-CNN (profiles/r03_conv_traffic_*.txt).  Groups of 32 or 64
+    // channels fetch no less (1.22-1.27x) and pay for twice / four times the tap changes (+0.7 % / +1.8 % conv time; 128: +0.1-0.9 %).
+    k.kgroup = (d->R * d->S == 1 || is_stem(d)) ? k.cin_chunks : (k.cin_chunks < CONV_KGROUP_CHUNKS ? k.cin_chunks : CONV_KGROUP_CHUNKS);
     k.wrow = (int64_t)k.nchunks * 32;
     const int64_t in_bytes = (int64_t)d->N * d->H * d->W * d->Cin * 4;
     ARG_CHECK(in_bytes < (1ll << 31), "conv input must be < 2 GiB (32-bit buffer offsets)");
     k.in_bytes = (unsigned)in_bytes;
     k.w_bytes = (unsigned)((int64_t)cout_pad(d) * k.wrow * 4);
-    k.mfast = (int64_t)k.w_bytes > in_bytes ? 1 : 0;
+    // input bytes the launch really reads: a strided 1x1 skips (stride^2 - 1) / stride^2 of the pixels
+    k.in_touched = (d->R == 1 && d->S == 1 && d->stride > 1) ? in_bytes / ((int64_t)d->stride * d->stride) : in_bytes;
     k.m_begin = 0;
     k.act = d->act;
     k.out_div = d->out_div > 0 ? d->out_div : k.Ho * k.Wo;
@@ -956,6 +1029,9 @@ int conv2d_launch(const isegmi_conv_desc* d, const float* in, const float* w, co
             km.mtiles = (int)main_mt; km.ntiles = nt64;
             kt.m_begin = (int)(main_mt * 64);
             kt.mtiles = cdiv(k.M - kt.m_begin, 32); kt.ntiles = cdiv(d->Cout, 32);
+            const int64_t in_tail = (int64_t)((double)k.in_touched * (k.M - kt.m_begin) / k.M);
+            conv_set_band(km, 64, 4, k.in_touched - in_tail);
+            conv_set_band(kt, 32, 4, in_tail);
             const int nmain = km.mtiles * km.ntiles, ntail = kt.mtiles * kt.ntiles;
             const size_t lds = 2 * (size_t)(64 + 64) * LDS_ROW * sizeof(float);
             if (tile == 13) hipLaunchKernelGGL((conv_hybrid_kernel<2>), dim3((unsigned)(nmain + ntail)), dim3(256), lds, st, km, kt, nmain);
@@ -969,6 +1045,7 @@ int conv2d_launch(const isegmi_conv_desc* d, const float* in, const float* w, co
         k.mtiles = cdiv(k.M, 64);
         k.ntiles = cdiv(d->Cout, 64);
         const size_t lds = 2 * (size_t)(64 + 64) * LDS_ROW * sizeof(float);
+        conv_set_band(k, 64, 4, k.in_touched);
         const dim3 g7((unsigned)(k.mtiles * k.ntiles));
         if (tile == 7) hipLaunchKernelGGL((conv_mfma_v2_kernel<2, true>), g7, dim3(256), lds, st, k);
         else if (tile == 9) hipLaunchKernelGGL((conv_mfma_v2_kernel<4, true>), g7, dim3(256), lds, st, k);
@@ -980,6 +1057,7 @@ int conv2d_launch(const isegmi_conv_desc* d, const float* in, const float* w, co
     if (tile >= 4) {
         k.mtiles = cdiv(k.M, 32);
         k.ntiles = cdiv(d->Cout, tile == 6 ? 64 : 32);
+        conv_set_band(k, tile == 6 ? 64 : 32, tile == 4 ? 8 : 4, k.in_touched);
         const dim3 g16((unsigned)(k.mtiles * k.ntiles));
         if (tile == 5) hipLaunchKernelGGL((conv_mfma16_kernel<8, true>), g16, dim3(512), 0, st, k);
         else if (tile == 6) hipLaunchKernelGGL((conv_mfma16_kernel<4, false, 2>), g16, dim3(256), 0, st, k);

@@ -119,8 +119,13 @@ ORA_API void ora_map_f32(const float* x, float* y, int64_t n, int fn) {
 
 /* ------------------------------------------------------------ conv family -- */
 /* Appendix A.1 conv2d (cross-correlation, zero padding), NHWC activations,
- * weights [Cout][R][S][Cin].  acc = fmaf chain over (r, s, c) in that order
- * from +0 (padding taps contribute fmaf(0,w,acc)); then
+ * weights [Cout][R][S][Cin].  acc = ONE fmaf chain from +0 over the K = R*S*Cin
+ * products (padding taps contribute fmaf(0,w,acc)), walked in this order: input
+ * channels in groups of ORA_CONV_CGROUP = 128 outermost, then (r, s), then the
+ * group's channels ascending -- for Cin <= 128 and for every 1x1 convolution that
+ * is plain (r, s, c).  (Any order is a valid fp32 evaluation of the sum; this one
+ * is the contract with the HIP kernels since round 3: walking all of Cin per tap
+ * made every tap re-fetch the activation window through a thrashing L2.)  Then
  *   y = fmaf(acc, scale[co], shift[co]);  y += residual;  act(y)
  * act: 0 none, 1 relu, 2 tanh.  scale==NULL means 1, shift==NULL means 0.
  * Output element (n, p=ho*Wo+wo, co) is written at
@@ -132,6 +137,7 @@ ORA_API void ora_map_f32(const float* x, float* y, int64_t n, int fn) {
  * network drift apart (tests/test_maskrcnn_e2e_gpu.py derives the fp16 path's tolerance from it); nothing is ever checked against mode 1
  * as if it were the truth. */
 static int g_conv_sum_mode = 0;
+#define ORA_CONV_CGROUP 128
 ORA_API void ora_set_conv_sum_mode(int mode) { g_conv_sum_mode = mode; }
 
 ORA_API void ora_conv2d(const float* in, int N, int H, int W, int Cin,
@@ -164,8 +170,10 @@ ORA_API void ora_conv2d(const float* in, int N, int H, int W, int Cin,
                     for (int p = 0; p < PB; ++p)
                         for (int j = 0; j < 32; ++j) acc[p][j] = 0.0f;
 #endif
+                    for (int cg = 0; cg < Cin; cg += ORA_CONV_CGROUP)
                     for (int r = 0; r < R; ++r)
                         for (int s = 0; s < S; ++s) {
+                            const int cge = cg + ORA_CONV_CGROUP < Cin ? cg + ORA_CONV_CGROUP : Cin;
                             const float* rows[PB];
                             const int hi = ho * stride + r - pad;
                             for (int p = 0; p < PB; ++p) {
@@ -175,9 +183,9 @@ ORA_API void ora_conv2d(const float* in, int N, int H, int W, int Cin,
                                               ? in + (((size_t)n * H + hi) * W + wi) * Cin
                                               : zrow;
                             }
-                            const float* wk = wt + (size_t)((r * S + s) * Cin) * Cp + cb;
+                            const float* wk = wt + (size_t)((r * S + s) * Cin + cg) * Cp + cb;
                             if (g_conv_sum_mode == 1 && Cin % 16 == 0) {  /* 16-term partial sums (see ora_set_conv_sum_mode) */
-                                for (int c0 = 0; c0 < Cin; c0 += 16) {
+                                for (int c0 = cg; c0 < cge; c0 += 16) {
                                     float part[PB][32];
                                     memset(part, 0, sizeof(part));
                                     for (int c = c0; c < c0 + 16; ++c, wk += Cp)
@@ -195,7 +203,7 @@ ORA_API void ora_conv2d(const float* in, int N, int H, int W, int Cin,
                                 }
                                 continue;
                             }
-                            for (int c = 0; c < Cin; ++c, wk += Cp) {
+                            for (int c = cg; c < cge; ++c, wk += Cp) {
 #ifdef __AVX2__
                                 const __m256 w0 = _mm256_load_ps(wk), w1 = _mm256_load_ps(wk + 8),
                                              w2 = _mm256_load_ps(wk + 16), w3 = _mm256_load_ps(wk + 24);

@@ -46,6 +46,33 @@ def test_conv_vs_torch_and_fma_chain():
                     a, b = float(xp[n, ho + r, wo + s, c]), float(w[co, r, s, c])
                     acc = np.float32(math.fma(a, b, float(acc))) if hasattr(math, "fma") else np.float32(np.float64(a) * np.float64(b) + np.float64(acc))
         assert y[n, ho, wo, co] == acc
+    # more than 128 input channels: groups of 128 channels outermost, then (r, s), then the group's channels (round 3; ora_conv2d's header)
+    x = rng.standard_normal((1, 5, 6, 320)).astype(np.float32); w = (rng.standard_normal((8, 3, 3, 320)) * 0.05).astype(np.float32)
+    y = ora.conv2d(x, w, 1, 1)
+    xp = np.pad(x, ((0, 0), (1, 1), (1, 1), (0, 0)))
+    differs = 0
+    for (ho, wo, co) in ((0, 0, 0), (2, 3, 5), (4, 5, 7), (1, 1, 2), (3, 2, 6)):
+        acc, plain = np.float32(0), np.float32(0)
+        fma = lambda a, b, c: np.float32(math.fma(a, b, float(c))) if hasattr(math, "fma") else np.float32(np.float64(a) * np.float64(b) + np.float64(c))
+        for cg in range(0, 320, 128):
+            for r in range(3):
+                for s in range(3):
+                    for c in range(cg, min(cg + 128, 320)):
+                        acc = fma(float(xp[0, ho + r, wo + s, c]), float(w[co, r, s, c]), acc)
+        for r in range(3):
+            for s in range(3):
+                for c in range(320):
+                    plain = fma(float(xp[0, ho + r, wo + s, c]), float(w[co, r, s, c]), plain)
+        assert y[0, ho, wo, co] == acc
+        differs += int(plain != acc)
+    assert differs > 0   # the two orders are different roundings of the same sum: the test would not notice the order otherwise
+    # a 1x1 convolution has one tap: the grouped order IS the plain one
+    w1 = (rng.standard_normal((4, 1, 1, 320)) * 0.05).astype(np.float32)
+    y1 = ora.conv2d(x, w1, 1, 0)
+    acc = np.float32(0)
+    for c in range(320):
+        acc = fma(float(x[0, 2, 3, c]), float(w1[1, 0, 0, c]), acc)
+    assert y1[0, 2, 3, 1] == acc
 
 
 def test_pool_resize_deconv_vs_torch():
