@@ -339,7 +339,7 @@ int isegmi_engine_get_timings(isegmi_engine* e, char* names, int names_cap, floa
  * isegmi_engine_pack_coco_records: ONE block of fixed size for n_block image slots (>= the last forward's batch: a short last batch still
  *   fills a block of the per-step size; the extra slots carry count 0) (layout: csrc/results.cpp, mirrored by isegmi/dist.py):
  *   status, boxes in original-image coordinates, counts, scores, labels, [mask scores], string offsets, RLE strings.
- * isegmi_engine_download_*: the block's asynchronous D2H into pinned memory on a download stream (two slots). */
+ * isegmi_engine_download_*: the block's asynchronous D2H into pinned memory on the results stream, behind its producer (two slots). */
 int isegmi_engine_rle(isegmi_engine* e, const int32_t* h_image_hw);
 int isegmi_engine_coco_record_bytes(isegmi_engine* e, int N, int64_t* bytes, int64_t* chars_offset);
 int isegmi_engine_pack_coco_records(isegmi_engine* e, void* d_dst, int64_t cap, int n_block, int64_t* bytes);
@@ -369,7 +369,7 @@ typedef struct isegmi_comm isegmi_comm;
 int isegmi_comm_unique_id(void* out128);                       /* rank 0; ship the 128 bytes to all ranks */
 int isegmi_comm_create(const void* uid128, int rank, int world, isegmi_comm** out);
 int isegmi_comm_destroy(isegmi_comm* c);
-/* d_recv holds world*bytes; ordered after work already queued on producer_stream; own stream */
+/* d_recv holds world*bytes; runs on producer_stream behind the work already queued there (NULL: the communicator's own stream) */
 int isegmi_comm_allgather(isegmi_comm* c, const void* d_send, void* d_recv, int64_t bytes,
                           void* producer_stream);
 int isegmi_comm_wait(isegmi_comm* c);

@@ -3,7 +3,7 @@
 // The reference tree has no communication code; upstream maskrcnn-benchmark
 // all-gathers pickled {image_id: BoxList} dicts in engine/inference.py.  Here images shard by batch
 // across ranks (one process per GPU) and the ONLY exchange is one ncclAllGather of fixed-capacity
-// records per batch, issued on its own stream so it overlaps the next batch's backbone.
+// records per batch, issued on the engine's results stream behind the kernel that packed them (it overlaps the next batch's backbone).
 // librccl.so is dlopen'ed lazily: single-GPU use never touches it.
 #include <dlfcn.h>
 #include <string.h>
@@ -116,13 +116,17 @@ extern "C" int isegmi_comm_fence_producer(isegmi_comm* c, int slot, void* produc
 }
 
 // All-gather `bytes` bytes from every rank through slot `slot` (0 or 1): d_recv holds world*bytes, rank r's block at r*bytes.
-// Ordered after everything already enqueued on `producer_stream`; runs on the comm's own stream.
+// Runs ON `producer_stream` (the engine's results stream), right behind the kernel that packed the block; on the comm's own stream only when
+// there is no producer (a rank's empty step).  Rounds 1-2 always used the comm's stream: one more stream for the runtime to fold onto its four
+// hardware queues -- on the measured box it shared the MAIN stream's queue, so the collective of step i (enqueued after forward i, waiting for
+// step i's last kernel) sat in front of forward i+1's backbone in that in-order queue and the cross-step overlap was gone: bench.py through its
+// N > 1 code path on one GPU (world-1 communicators, tools/forced_dist_bench.sh) read 926 img/s against 961 without the collective.  On the
+// results stream the collective only holds back the NEXT step's Detect / postprocess chain, which starts a whole backbone + heads later.
 extern "C" int isegmi_comm_allgather_slot(isegmi_comm* c, int slot, const void* d_send, void* d_recv, int64_t bytes, void* producer_stream) {
     ARG_CHECK(c && d_send && d_recv && bytes > 0 && slot >= 0 && slot < COMM_SLOTS, "allgather args");
-    HIP_TRY(hipEventRecord(c->ready, (hipStream_t)producer_stream));
-    HIP_TRY(hipStreamWaitEvent(c->stream, c->ready, 0));
-    RCCL_TRY(R.allgather(d_send, d_recv, (size_t)bytes, /*ncclInt8*/ 0, c->comm, c->stream));
-    HIP_TRY(hipEventRecord(c->done[slot], c->stream));
+    hipStream_t s = producer_stream ? (hipStream_t)producer_stream : c->stream;
+    RCCL_TRY(R.allgather(d_send, d_recv, (size_t)bytes, /*ncclInt8*/ 0, c->comm, s));
+    HIP_TRY(hipEventRecord(c->done[slot], s));
     c->used[slot] = true;
     return ISEGMI_OK;
 }

@@ -664,8 +664,6 @@ extern "C" int isegmi_engine_destroy(isegmi_engine* h) {
     if (e.copy) { (void)hipStreamSynchronize(e.copy); (void)hipStreamDestroy(e.copy); }
     if (e.in_done) (void)hipEventDestroy(e.in_done);
     for (auto& u : e.uploads) if (u.done) (void)hipEventDestroy(u.done);
-    if (e.dl) { (void)hipStreamSynchronize(e.dl); (void)hipStreamDestroy(e.dl); }
-    if (e.dl_ready) (void)hipEventDestroy(e.dl_ready);
     for (int i = 0; i < 2; ++i) if (e.dl_done[i]) (void)hipEventDestroy(e.dl_done[i]);
     for (int i = 0; i < Engine::PIN_SLOTS; ++i) if (e.pin_ev[i]) (void)hipEventDestroy(e.pin_ev[i]);
     if (e.pin_ring) (void)hipHostFree(e.pin_ring);
@@ -780,7 +778,6 @@ extern "C" int isegmi_engine_sync(isegmi_engine* h) {
     HIP_TRY(hipStreamSynchronize(h->e.stream));
     if (h->e.heads) HIP_TRY(hipStreamSynchronize(h->e.heads));
     if (h->e.tail) HIP_TRY(hipStreamSynchronize(h->e.tail));
-    if (h->e.dl) HIP_TRY(hipStreamSynchronize(h->e.dl));
     h->e.in_pending = false;
     h->e.tail_pending = false;
     h->e.lat_pending = false;

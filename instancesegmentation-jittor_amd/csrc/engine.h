@@ -85,8 +85,6 @@ struct Engine {
     int pin_next = 0;
     int hw_slot = 0;                       // Mask R-CNN image_hw lives in two device buffers used alternately (WAR against the previous forward's tail)
     // asynchronous download of a step's record block (device-side COCO output) on its own stream: two slots, like the RCCL records
-    hipStream_t dl = nullptr;
-    hipEvent_t dl_ready = nullptr;
     hipEvent_t dl_done[2] = {nullptr, nullptr};
     bool dl_used[2] = {false, false};
     bool fp16 = false;                     // fp16 storage + f16 MFMA convs (BASELINE configs[4]); set before loading weights

@@ -183,25 +183,26 @@ extern "C" int isegmi_engine_pack_coco_records(isegmi_engine* h, void* d_dst, in
 }
 
 static int dl_init(Engine& e) {
-    if (e.dl) return ISEGMI_OK;
-    HIP_TRY(hipStreamCreateWithFlags(&e.dl, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&e.dl_ready, hipEventDisableTiming));
+    if (e.dl_done[0]) return ISEGMI_OK;
     for (int i = 0; i < 2; ++i) HIP_TRY(hipEventCreateWithFlags(&e.dl_done[i], hipEventDisableTiming));
     return ISEGMI_OK;
 }
 
-// Asynchronous D2H of `bytes` at d_src into PINNED host memory on the engine's download stream, ordered behind everything enqueued so
-// far on the results stream; two slots so that step t+1 may produce while step t's block is still in flight:
+// Asynchronous D2H of `bytes` at d_src into PINNED host memory, ordered behind everything enqueued so far on the results stream; two slots so that step t+1 may produce while step t's block is still in flight:
 //   download_fence(slot): later work on the results stream waits for the slot's previous download (call before overwriting its d_src);
 //   download_wait(slot):  host wait, after which h_dst holds the block.
 extern "C" int isegmi_engine_download_async(isegmi_engine* h, int slot, void* h_dst_pinned, const void* d_src, int64_t bytes) {
     ARG_CHECK(h && h_dst_pinned && d_src && bytes > 0 && slot >= 0 && slot < 2, "download args");
     Engine& e = h->e;
     TRY(dl_init(e));
-    HIP_TRY(hipEventRecord(e.dl_ready, eng_results_stream(e)));
-    HIP_TRY(hipStreamWaitEvent(e.dl, e.dl_ready, 0));
-    HIP_TRY(hipMemcpyAsync(h_dst_pinned, d_src, (size_t)bytes, hipMemcpyDeviceToHost, e.dl));
-    HIP_TRY(hipEventRecord(e.dl_done[slot], e.dl));
+    // The copy rides on the RESULTS stream itself, right behind the kernels that produced the block.  A download stream of its own (first
+    // version) is one more stream for the runtime to fold onto its four hardware queues, and it landed on the MAIN stream's: the copy of step i --
+    // enqueued after forward i, waiting for step i's last kernel -- then sat in that in-order queue in front of forward i+1's backbone, and the
+    // whole cross-step overlap was gone (tools/e2e_timeline.py: backbone i+1 started 70 us after copy i; value_e2e 5 % under value at 8.3 ms
+    // per step, 19 % at 2.3 ms).
+    hipStream_t rs = eng_results_stream(e);
+    HIP_TRY(hipMemcpyAsync(h_dst_pinned, d_src, (size_t)bytes, hipMemcpyDeviceToHost, rs));
+    HIP_TRY(hipEventRecord(e.dl_done[slot], rs));
     e.dl_used[slot] = true;
     return ISEGMI_OK;
 }

@@ -146,7 +146,7 @@ class RcclGather:
     """RCCL all-gather of the engine's packed detection records (device side).
 
     Two (send, recv) slots alternate between steps: step t packs into / gathers through slot t % 2 while step t-1's
-    all-gather may still be in flight on the comm stream.  Before a slot is re-packed the producer stream waits (on the
+    all-gather may still be in flight on the engine's results stream.  Before a slot is re-packed the producer stream waits (on the
     device, isegmi_comm_fence_producer) for that slot's previous all-gather, so consecutive `gather_from` calls need no
     host synchronisation in between and ranks never see records of mixed steps.  `fetch()` returns the records of the
     most recent `gather_from`; `fetch(previous=True)` those of the one before (still intact: the other slot)."""
@@ -177,7 +177,7 @@ class RcclGather:
         return self.recvs[(self.step - 1) % self.SLOTS]
 
     def gather_from(self, net, with_proto=False):
-        """Pack the last forward's records on the engine's results stream, then all-gather on the comm stream (async)."""
+        """Pack the last forward's records on the engine's results stream, then all-gather right behind it on the same stream (async)."""
         L = _ffi.lib()
         slot = self.step % self.SLOTS
         send, recv = self.sends[slot], self.recvs[slot]
@@ -218,6 +218,12 @@ class RcclGather:
         self.sends[slot].zero()  # synchronous memset: rare (at most once per rank and data set)
         _ffi.check(L.isegmi_comm_allgather_slot(self._c, slot, self.sends[slot].ptr, self.recvs[slot].ptr, C.c_int64(self.nbytes), None))
         self.step += 1
+
+    def fence_results_stream(self, net):
+        """Later work on the engine's results stream waits (on the device) for the most recent gather's slot."""
+        st = C.c_void_p()
+        _ffi.check(_ffi.lib().isegmi_engine_stream(net._h, C.byref(st)))
+        _ffi.check(_ffi.lib().isegmi_comm_fence_producer(self._c, (self.step - 1) % self.SLOTS, st))
 
     def wait(self):
         _ffi.check(_ffi.lib().isegmi_comm_wait(self._c))

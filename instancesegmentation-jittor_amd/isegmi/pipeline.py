@@ -27,6 +27,10 @@ class RecordPipeline:
             self.pin = [_ffi.PinnedBuffer((self.nbytes,), np.uint8) for _ in range(2)]
         else:
             assert gather.nbytes == self.nbytes, (gather.nbytes, self.nbytes)
+            self.dev = []
+            # every rank's blocks come down asynchronously too, behind the all-gather on the results stream (a synchronous copy of world x
+            # 2 MB into pageable memory per step would be host time the producer loop does not have at 2-3 ms per step)
+            self.pin = [_ffi.PinnedBuffer((self.nbytes * gather.world,), np.uint8) for _ in range(2)]
         self.step = 0
         self.pending = []  # (slot, meta) of steps whose records have not been handed out yet
         # the mask planes are consumed by the run-length encoder alone, through the box windows the paste / mask assembly kernels leave next to
@@ -40,14 +44,14 @@ class RecordPipeline:
             self.net.download_async(slot, self.pin[slot], self.dev[slot], self.nbytes)
         else:
             self.gather.gather_coco_from(self.net, self.batch)
+            self.net.download_async(slot, self.pin[slot], self.gather.recv, self.nbytes * self.gather.world)
 
     def _collect(self, slot):
         """-> list over ranks of unpacked record dicts (one entry when there is no gather)."""
+        self.net.download_wait(slot)
         if self.gather is None:
-            self.net.download_wait(slot)
             return [self._unpack(self.pin[slot].array)]
-        newest = (self.gather.step - 1) % self.gather.SLOTS
-        blocks = self.gather.fetch(previous=(slot != newest))
+        blocks = self.pin[slot].array.reshape(self.gather.world, self.nbytes)
         return [self._unpack(blocks[r]) for r in range(self.gather.world)]
 
     def _unpack(self, buf):
@@ -71,7 +75,9 @@ class RecordPipeline:
         """A step without a batch on this rank (several ranks, image list not divisible): contributes an all-zero block to the all-gather."""
         assert self.gather is not None, "only the multi-rank pipeline has collective steps"
         slot = self.step % 2
-        self.gather.gather_empty()
+        self.gather.gather_empty()                      # on the communicator's own stream (no producer)
+        self.gather.fence_results_stream(self.net)      # the copy below is ordered behind it
+        self.net.download_async(slot, self.pin[slot], self.gather.recv, self.nbytes * self.gather.world)
         self.pending.append((slot, meta))
         self.step += 1
         return self._pop() if len(self.pending) == 2 else None
@@ -90,10 +96,9 @@ class RecordPipeline:
     def close(self):
         self.net.sync()
         self.net.set_param("sparse_masks", 0.0)
-        if self.gather is None:
-            for b in self.dev + self.pin:
-                b.free()
-            self.dev, self.pin = [], []
+        for b in self.dev + self.pin:
+            b.free()
+        self.dev, self.pin = [], []
 
 
 def schedule_batches(group_keys, batch_size):
