@@ -1,5 +1,5 @@
 """Where the host time of one e2e step goes (upload -> forward -> masks -> RLE -> record block -> pinned memory -> unpack), and the device step
-interval next to the plain pipelined step's: python tools/e2e_host_time.py [yolact|maskrcnn] [fp16] [steps]"""
+interval next to the plain pipelined step's: python tools/e2e_host_time.py [yolact|maskrcnn] [fp16] [d101] [bsN] [steps]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "instancesegmentation-jittor_amd")]
@@ -24,8 +24,9 @@ if model == "yolact":
 else:
     from isegmi.weights import maskrcnn_state_dict
     from isegmi.maskrcnn import MaskRCNN, MaskRCNNConfig
-    bs = 2
-    net = MaskRCNN(maskrcnn_state_dict(1234, 50), 800, 1344, cfg=MaskRCNNConfig(depth=50), max_batch=bs, fp16=fp16)
+    bs = ([int(a[2:]) for a in sys.argv if a.startswith("bs")] or [2])[0]
+    depth = 101 if "d101" in sys.argv else 50
+    net = MaskRCNN(maskrcnn_state_dict(1234, depth), 800, 1344, cfg=MaskRCNNConfig(depth=depth), max_batch=bs, fp16=fp16)
     raw = rng.integers(0, 256, (bs, 800, 1333, 3), dtype=np.uint8)
     pin = _ffi.PinnedBuffer(raw.shape, np.uint8); pin.array[...] = raw
     hw = [(800, 1333)] * bs
