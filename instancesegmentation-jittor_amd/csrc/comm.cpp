@@ -10,16 +10,20 @@
 
 #include "../../include/isegmi.h"
 #include "common.h"
+#include <rccl/rccl.h>
 
 namespace isegmi {
 
-typedef struct { char internal[128]; } ncclUniqueId_t;
-typedef void* ncclComm_tt;
-typedef int (*fn_getuid)(ncclUniqueId_t*);
-typedef int (*fn_initrank)(ncclComm_tt*, int, ncclUniqueId_t, int);
-typedef int (*fn_allgather)(const void*, void*, size_t, int, ncclComm_tt, hipStream_t);
-typedef int (*fn_destroy)(ncclComm_tt);
-typedef const char* (*fn_errstr)(int);
+// Types and prototypes come from RCCL's own header (round 3; rounds 1-2 re-declared them by hand); the library itself is still resolved at
+// run time, so a single-GPU process never loads it.
+typedef ncclUniqueId ncclUniqueId_t;
+typedef ncclComm_t ncclComm_tt;
+typedef decltype(&ncclGetUniqueId) fn_getuid;
+typedef decltype(&ncclCommInitRank) fn_initrank;
+typedef decltype(&ncclAllGather) fn_allgather;
+typedef decltype(&ncclCommDestroy) fn_destroy;
+typedef decltype(&ncclGetErrorString) fn_errstr;
+static_assert(sizeof(ncclUniqueId) == 128, "isegmi_comm_unique_id hands out 128 bytes");
 
 static struct {
     void* so = nullptr;
@@ -46,8 +50,8 @@ static int load_rccl() {
 
 #define RCCL_TRY(expr)                                                                                   \
     do {                                                                                                 \
-        int _r = (expr);                                                                                 \
-        if (_r != 0) {                                                                                   \
+        ncclResult_t _r = (expr);                                                                        \
+        if (_r != ncclSuccess) {                                                                                   \
             set_error(std::string(#expr) + " -> " + (R.errstr ? R.errstr(_r) : "rccl error"));          \
             return ISEGMI_ERR_RCCL;                                                                      \
         }                                                                                                \
@@ -87,8 +91,8 @@ extern "C" int isegmi_comm_create(const void* uid128, int rank, int world, isegm
     c->rank = rank; c->world = world;
     ncclUniqueId_t id;
     memcpy(&id, uid128, sizeof(id));
-    int r = R.initrank(&c->comm, world, id, rank);
-    if (r != 0) { set_error(std::string("ncclCommInitRank -> ") + (R.errstr ? R.errstr(r) : "?")); delete c; return ISEGMI_ERR_RCCL; }
+    ncclResult_t r = R.initrank(&c->comm, world, id, rank);
+    if (r != ncclSuccess) { set_error(std::string("ncclCommInitRank -> ") + (R.errstr ? R.errstr(r) : "?")); delete c; return ISEGMI_ERR_RCCL; }
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
     for (int i = 0; i < COMM_SLOTS; ++i) HIP_TRY(hipEventCreateWithFlags(&c->done[i], hipEventDisableTiming));
@@ -125,7 +129,7 @@ extern "C" int isegmi_comm_fence_producer(isegmi_comm* c, int slot, void* produc
 extern "C" int isegmi_comm_allgather_slot(isegmi_comm* c, int slot, const void* d_send, void* d_recv, int64_t bytes, void* producer_stream) {
     ARG_CHECK(c && d_send && d_recv && bytes > 0 && slot >= 0 && slot < COMM_SLOTS, "allgather args");
     hipStream_t s = producer_stream ? (hipStream_t)producer_stream : c->stream;
-    RCCL_TRY(R.allgather(d_send, d_recv, (size_t)bytes, /*ncclInt8*/ 0, c->comm, s));
+    RCCL_TRY(R.allgather(d_send, d_recv, (size_t)bytes, ncclInt8, c->comm, s));
     HIP_TRY(hipEventRecord(c->done[slot], s));
     c->used[slot] = true;
     return ISEGMI_OK;
