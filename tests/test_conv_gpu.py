@@ -43,6 +43,36 @@ def test_conv_bit_exact(ffi, case, tile):
         assert np.array_equal(got, ref), "max abs diff %g" % np.max(np.abs(got - ref))
 
 
+# Round 3: the K walk (128-channel groups outermost) with a ragged last group, and the banded tile walk over the XCDs with a last band narrower
+# than the others (conv_set_band picks 2 / 3 / 6 / 11 / 4-wide bands for these shapes; a wrong tile decode leaves tiles uncomputed or computed twice)
+WALK_CASES = [
+    # N, H, W, Cin, Cout, R, stride, pad, tiles
+    (1, 14, 14, 320, 96, 3, 1, 1, (0, 3, 4, 5, 6, 10)),      # channel groups 128 + 128 + 64
+    (2, 9, 9, 640, 40, 3, 2, 1, (0, 3, 4, 5)),               # five groups, stride 2
+    (2, 12, 12, 256, 160, 1, 1, 0, (0, 3, 4, 5, 6, 10)),     # 5 Cout tiles of 32 in bands of 3
+    (4, 12, 12, 256, 352, 1, 1, 0, (0, 4, 5, 6, 10)),        # 11 in bands of 6
+    (2, 20, 20, 256, 672, 1, 1, 0, (0, 4, 5, 10)),           # 21 in bands of 11
+    (4, 56, 56, 512, 416, 3, 1, 1, (0, 10, 13)),             # 1372 64x64 tiles, 7 Cout tiles in bands of 4 + 3, four channel groups
+]
+
+
+@pytest.mark.parametrize("case", WALK_CASES)
+def test_conv_k_groups_and_tile_bands_bit_exact(ffi, case):
+    N, H, W, Cin, Cout, R, stride, pad, tiles = case
+    rng = np.random.default_rng(hash(case[:8]) % (2**32))
+    x = _rand(rng, (N, H, W, Cin))
+    w = _rand(rng, (Cout, R, R, Cin), (2.0 / (R * R * Cin)) ** 0.5)
+    sc = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+    sh = _rand(rng, (Cout,), 0.1)
+    Ho = (H + 2 * pad - R) // stride + 1
+    Wo = (W + 2 * pad - R) // stride + 1
+    res = _rand(rng, (N, Ho, Wo, Cout))
+    ref = ora.conv2d(x, w, stride, pad, sc, sh, res, 1)
+    for tile in tiles:
+        got = ffi.conv2d(x, w, stride, pad, sc, sh, res, 1, tile)
+        assert np.array_equal(got, ref), "tile %d: max abs diff %g" % (tile, np.max(np.abs(got - ref)))
+
+
 def test_stem_bit_exact(ffi):
     rng = np.random.default_rng(7)
     x3 = _rand(rng, (2, 70, 62, 3), 50.0)
