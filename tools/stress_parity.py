@@ -19,7 +19,8 @@ def fail(msg):
 # ---- conv, forced tiles
 for it in range(rounds):
     N = int(rng.integers(1, 3)); H = int(rng.integers(3, 40)); W = int(rng.integers(3, 40))
-    Cin = 32 * int(rng.integers(1, 5)); Cout = int(rng.choice([5, 16, 31, 32, 33, 64, 65, 96, 130, 200]))
+    # round 3: up to 640 input channels (the K walk's 128-channel groups, ragged last group) and up to 1100 outputs (banded tile walk, narrow last band)
+    Cin = 32 * int(rng.integers(1, 5) if it % 2 == 0 else rng.integers(5, 21)); Cout = int(rng.choice([5, 16, 31, 32, 33, 64, 65, 96, 130, 200, 260, 352, 416, 700, 1100]))
     R = int(rng.choice([1, 3])); stride = int(rng.choice([1, 2])); pad = R // 2 if rng.uniform() < 0.8 else 0
     if H + 2 * pad < R or W + 2 * pad < R: continue
     x = rng.standard_normal((N, H, W, Cin)).astype(np.float32); w = (rng.standard_normal((Cout, R, R, Cin)) * 0.1).astype(np.float32)
