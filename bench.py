@@ -71,6 +71,7 @@ def parse():
     ap.add_argument("--no-maskrcnn", action="store_true", help="default yolact run: skip the extra Mask R-CNN R50-FPN measurement")
     ap.add_argument("--no-h2d", action="store_true", help="skip the extra timed loops (batch resident in HBM; fp32 upload)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end loop (uint8 upload -> ... -> RLE -> record block on the host)")
+    ap.add_argument("--param", action="append", default=[], metavar="NAME=VALUE", help="engine parameter for A/B runs (isegmi_engine_set_param), repeatable")
     ap.add_argument("--single-stream", action="store_true", help="profiling aid: run the timed region on one stream too, so that "
                     "rocprofv3 per-kernel durations are not inflated by overlapping launches (throughput drops ~20 %%)")
     return ap.parse_args()
@@ -289,6 +290,8 @@ def bench_yolact(a, dist):
     ypeak = PEAK_F16_MFMA_TFLOPS if a.fp16 else PEAK_F32_MFMA_TFLOPS
     if a.single_stream:
         net.set_param("multi_stream", 0.0)
+    for kv in a.param:
+        net.set_param(kv.split("=")[0], float(kv.split("=")[1]))
     size = net.size
     rng = np.random.default_rng(20261003 + rank)
     raw_u8 = rng.integers(0, 256, (a.batch, size, size, 3), dtype=np.uint8)  # what cv2.imread hands FastBaseTransform
@@ -496,6 +499,8 @@ def bench_maskrcnn(a, dist, summary=False):
     model = MaskRCNN(sd, x.shape[1], x.shape[2], cfg=mcfg, max_batch=batch, device=dist.local_rank, fp16=fp16)
     if a.single_stream:
         model.set_param("multi_stream", 0.0)
+    for kv in a.param:
+        model.set_param(kv.split("=")[0], float(kv.split("=")[1]))
     tag = "R50-C4" if c4 else "R%d-FPN" % depth
     prec = "fp16 storage / f16 MFMA, fp32 accumulate" if fp16 else "fp32"
     peak = PEAK_F16_MFMA_TFLOPS if fp16 else PEAK_F32_MFMA_TFLOPS

@@ -313,7 +313,9 @@ struct HeadsScope {
     hipStream_t s, sd[3];
     bool on = false;
     explicit HeadsScope(Engine& e_) : e(e_), s(e_.stream) { for (int k = 0; k < 3; ++k) sd[k] = e.side[k]; }
-    void enter() { on = true; e.stream = e.heads; for (int k = 0; k < 3; ++k) e.side[k] = e.hside[k]; e.cur = e.heads; }
+    // wide = the group's branches (three laterals, protonet || prediction heads per level) on the group's own three side streams; otherwise they
+    // queue on the heads stream one after the other (see yolact_forward)
+    void enter(bool wide) { on = true; e.stream = e.heads; for (int k = 0; k < 3; ++k) e.side[k] = wide ? e.hside[k] : e.heads; e.cur = e.heads; }
     ~HeadsScope() { if (on) { e.stream = s; for (int k = 0; k < 3; ++k) e.side[k] = sd[k]; e.cur = s; } }
 };
 
@@ -422,7 +424,13 @@ int yolact_forward(Engine& e, const float* d_images, int N) {
         TRY(eng_next_event(e, &ev));
         HIP_TRY(hipEventRecord(ev, e.stream));
         HIP_TRY(hipStreamWaitEvent(e.heads, ev, 0));
-        hscope.enter();
+        // Side streams for the heads group only where a forward is latency-bound (small batches: bs=1 p50 1.98 vs 2.24 ms).  At the bench batch two
+        // concurrent streams of chip-filling convolutions (backbone i+1 || heads i) leave nothing for more streams to fill, and every extra stream
+        // is one more for the runtime to fold onto its four in-order hardware queues, where a branch then waits behind kernels of the other group
+        // it does not depend on: without them +1-4 % (Yolact fp32 / yolact_base / fp16 bs=8; profiles/r03_experiments.txt 3c).  Parameter
+        // "heads_side_streams": 1 always, 0 never, default by batch size.
+        const float hs = e.param("heads_side_streams", -1.0f);
+        hscope.enter(hs < 0.0f ? N <= 2 : hs != 0.0f);
     } else if (e.heads_pending) {  // mode switch without a sync in between: an earlier pipelined heads phase writes the same buffers
         HIP_TRY(hipStreamWaitEvent(e.stream, e.heads_done, 0));
         e.heads_pending = false;
