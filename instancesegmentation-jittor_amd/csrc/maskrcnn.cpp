@@ -207,14 +207,34 @@ int maskrcnn_forward(Engine& e, const float* d_images, int N) {
             TRY(eng_buf(e, "rpn.tk_ws_vals" + ls, we * 4, &q)); tws_v = (float*)q;
             TRY(eng_buf(e, "rpn.tk_ws_idx" + ls, we * 4, &q, 1)); tws_i = (int*)q;
         }
+        auto select = [&]() -> int {
+            TRY(rpn_sigmoid_launch(head.d, (int64_t)N * HWA, A, CH, prob, st));
+            TRY(topk_launch_ws(prob, HWA, N, HWA, pre_nms, nullptr, 1, tkv, tki, tkc, tws_v, tws_i, st));
+            TRY(rpn_decode_nms_launch(head.d, anc, tkv, tki, tkc, d_hw, N, HWA, A, CH, pre_nms, post_nms, rpn_thr, rpn_min,
+                                      ge, l, L, post_nms, cand_boxes, cand_scores, cand_cnt, nms_ws, st));
+            return ISEGMI_OK;
+        };
+        // Batches of two or more (throughput): the level's selection goes straight to the TAIL stream, which is idle here (the main stream waited for the
+        // previous forward's RoI heads before the FPN output convs) and takes everything after the RPN convs anyway; the five levels' chains then run one
+        // after the other under the remaining RPN convs and the next forward's backbone.  One image (latency): on three side streams, level l on stream
+        // l % 3, in parallel.  Fewer busy streams = fewer collisions on the runtime's four in-order hardware queues: +0.8 % R50 fp32 bs=2, +1.1 % R101 fp16
+        // bs=8, +2.1 % R50 fp16 bs=2; bs=1 p50 5.62 -> 5.79 ms if forced there (profiles/r03_experiments.txt 3e).  "rpn_select_on_tail": 1 / 0 force.
+        const float sel_tail = e.param("rpn_select_on_tail", -1.0f);
+        if (e.multi_stream && !e.capturing && (sel_tail < 0.0f ? N >= 2 : sel_tail != 0.0f)) {
+            hipEvent_t ev;
+            TRY(eng_next_event(e, &ev));
+            HIP_TRY(hipEventRecord(ev, e.cur));
+            HIP_TRY(hipStreamWaitEvent(e.tail, ev, 0));
+            hipStream_t saved = e.cur;
+            e.cur = e.tail;
+            const int rc = select();
+            e.cur = saved;
+            return rc;
+        }
         const int sk = l % 3;
         TRY(eng_fork(e, sk));
         SideScope sc(e, sk);
-        TRY(rpn_sigmoid_launch(head.d, (int64_t)N * HWA, A, CH, prob, st));
-        TRY(topk_launch_ws(prob, HWA, N, HWA, pre_nms, nullptr, 1, tkv, tki, tkc, tws_v, tws_i, st));
-        TRY(rpn_decode_nms_launch(head.d, anc, tkv, tki, tkc, d_hw, N, HWA, A, CH, pre_nms, post_nms, rpn_thr, rpn_min,
-                                  ge, l, L, post_nms, cand_boxes, cand_scores, cand_cnt, nms_ws, st));
-        return ISEGMI_OK;
+        return select();
     };
     // WAR: the previous forward's RoI heads (tail stream) still gather from P2..P5 and read proposals / det buffers;
     // everything up to here (backbone, top-down chain) was free to run underneath them.
