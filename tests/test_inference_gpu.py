@@ -165,6 +165,42 @@ def test_yolact_evaluate_matches_host_path(ffi):
     net.close()
 
 
+def test_record_pipeline_empty_step_between_full_ones(ffi):
+    """A rank's EMPTY step (several ranks, image list not divisible: an all-zero block goes into the all-gather on the communicator's own
+    stream, and the asynchronous download behind it is fenced on the device) between two full steps of the same batch, through RCCL with a
+    world of one: the full steps' records are identical, the empty one carries no detection, nothing is lost or reordered."""
+    from isegmi.pipeline import RecordPipeline, make_gather
+    from isegmi.weights import yolact_state_dict
+    from isegmi.yolact import Yolact
+    rng = np.random.default_rng(5)
+    import dataclasses
+    from isegmi.yolact import YolactConfig
+    net = Yolact(yolact_state_dict(1234), dataclasses.replace(YolactConfig(), nms_conf_thresh=0.0), max_batch=2, input_size=200)
+    raw = rng.integers(0, 256, (2, 200, 200, 3), dtype=np.uint8)
+    gather = make_gather(net, 2, 0, 1, force=True)
+    pipe = RecordPipeline(net, 2, gather)
+    outs = []
+    def full(tag):
+        net.upload_u8(raw)
+        net.forward_device(2)
+        net.postprocess_device(200, 200)
+        net.rle_device()
+        return pipe.submit(tag)
+    for done in (full("a"), pipe.submit_empty("empty"), full("b"), pipe.submit_empty("empty2")):
+        if done is not None:
+            outs.append(done)
+    outs += pipe.flush()
+    pipe.close()
+    gather.close()
+    net.close()
+    assert [m for m, _ in outs] == ["a", "empty", "b", "empty2"]
+    ra, re_, rb, re2 = (recs[0] for _, recs in outs)
+    assert int(ra["count"].sum()) > 0 and int(re_["count"].sum()) == 0 and int(re2["count"].sum()) == 0
+    assert len(re_["chars"]) == 0
+    for k in ra:
+        assert (ra[k] == rb[k]) if isinstance(ra[k], bytes) else np.array_equal(ra[k], rb[k]), k
+
+
 def test_graph_replay_with_double_buffered_async_uploads(ffi):
     """hipGraph replay + upload_async into alternating input slots on CHANGING inputs, twelve steps queued WITHOUT any host
     synchronisation: every step's scores equal a synchronised eager run of the same input.  (A replay must mark the point where its input
