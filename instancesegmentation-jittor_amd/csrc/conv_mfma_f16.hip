@@ -12,6 +12,21 @@
 #include "detmath.h"
 #include <type_traits>
 
+// Cache policy (the buffer instructions' aux field: 0 default, 2 = nt) of the fp16 kernels' three big streams, settable per build for A/B
+// (tools/ab_cache_policy.sh, R101 bs=8, same box, two runs each; profiles/r03_experiments.txt 5):
+//   activation (A operand) LDS-DMA loads nt: conv 8.47 -> 8.80 ms per step -- tiles of several Cout bands and the taps of a 3x3 re-read A through L2;
+//   residual loads nt: 7.99 -> 7.94 ms (read once, written three layers ago: nothing to keep) -- adopted;
+//   output stores nt: no change.
+#ifndef CONV_F16_A_AUX
+#define CONV_F16_A_AUX 0
+#endif
+#ifndef CONV_F16_RES_AUX
+#define CONV_F16_RES_AUX 2
+#endif
+#ifndef CONV_F16_OUT_AUX
+#define CONV_F16_OUT_AUX 0
+#endif
+
 namespace isegmi {
 
 typedef _Float16 half_t;
@@ -75,7 +90,7 @@ __device__ __forceinline__ void conv_f16_epilogue_vec(const ConvKH& p, f32x16h (
     u32x4h rw[D];
     if (RES) {
 #pragma unroll
-        for (int q = 0; q < D; ++q) { rw[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, rnext, 0, 0); rnext += rstep; }
+        for (int q = 0; q < D; ++q) { rw[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, rnext, 0, CONV_F16_RES_AUX); rnext += rstep; }
     }
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
@@ -107,7 +122,7 @@ __device__ __forceinline__ void conv_f16_epilogue_vec(const ConvKH& p, f32x16h (
                 const f16x8 rh = __builtin_bit_cast(f16x8, rw[q % D]);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) y[i] = (i < 4 ? v0[i] : v1[i - 4]) + (float)rh[i];
-                if (q + D < NQ) { rw[q % D] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, rnext, 0, 0); rnext += rstep; }
+                if (q + D < NQ) { rw[q % D] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, rnext, 0, CONV_F16_RES_AUX); rnext += rstep; }
             } else {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) y[i] = i < 4 ? v0[i] : v1[i - 4];
@@ -120,13 +135,13 @@ __device__ __forceinline__ void conv_f16_epilogue_vec(const ConvKH& p, f32x16h (
                 u32x4h o0, o1;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { o0[i] = __builtin_bit_cast(unsigned, y[i]); o1[i] = __builtin_bit_cast(unsigned, y[i + 4]); }
-                __builtin_amdgcn_raw_buffer_store_b128(o0, rs_out, ooff, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(o1, rs_out, ooff >= OOB ? OOB : ooff + 16u, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(o0, rs_out, ooff, 0, CONV_F16_OUT_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(o1, rs_out, ooff >= OOB ? OOB : ooff + 16u, 0, CONV_F16_OUT_AUX);
             } else {
                 f16x8 o;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) o[i] = (half_t)y[i];
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4h, o), rs_out, ooff, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4h, o), rs_out, ooff, 0, CONV_F16_OUT_AUX);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -275,7 +290,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, OCC) void conv_f16_glds_kernel
             // (named operands: hipcc 7.2 silently drops the host stub of the kernel when this builtin takes expressions)
             const __amdgpu_buffer_rsrc_t rs = live ? rs_in : rs_in0;
             const unsigned voff = avoff[i];
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(sA + (lw + i * NL) * 1024), 16, voff, soffa, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(sA + (lw + i * NL) * 1024), 16, voff, soffa, 0, CONV_F16_A_AUX);
         } else {
             const int j = i - PPA;
             if (PB % NL != 0 && lw + j * NL >= PB) return;
@@ -429,7 +444,7 @@ __device__ __forceinline__ void epi8_prefetch(const ConvKH& p, Epi8<TM, TN>& E, 
     const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? (const void*)p.res : (const void*)p.out), 0, p.res ? p.res_bytes : 0u, 0x00020000);
     const unsigned rstep = (unsigned)p.Cout * (2u * RPP);
 #pragma unroll
-    for (int q = 0; q < Epi8<TM, TN>::D; ++q) { E.r[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, E.rnext, 0, 0); E.rnext += rstep; }
+    for (int q = 0; q < Epi8<TM, TN>::D; ++q) { E.r[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, E.rnext, 0, CONV_F16_RES_AUX); E.rnext += rstep; }
 }
 
 template <int TM, int TN, bool RES>
@@ -483,7 +498,7 @@ __device__ __forceinline__ void epi8_finish_impl(const ConvKH& p, f32x16h (&acc)
                     const f16x8 rh = __builtin_bit_cast(f16x8, E.r[q % D]);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) y[i] = (i < 4 ? v0[i] : v1[i - 4]) + (float)rh[i];
-                    if (q + D < NQ) { E.r[q % D] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, E.rnext, 0, 0); E.rnext += rstep; }
+                    if (q + D < NQ) { E.r[q % D] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, E.rnext, 0, CONV_F16_RES_AUX); E.rnext += rstep; }
                 } else {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) y[i] = i < 4 ? v0[i] : v1[i - 4];
@@ -496,13 +511,13 @@ __device__ __forceinline__ void epi8_finish_impl(const ConvKH& p, f32x16h (&acc)
                     u32x4h o0, o1;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) { o0[i] = __builtin_bit_cast(unsigned, y[i]); o1[i] = __builtin_bit_cast(unsigned, y[i + 4]); }
-                    __builtin_amdgcn_raw_buffer_store_b128(o0, rs_out, ooff, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(o1, rs_out, ooff >= OOB ? OOB : ooff + 16u, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(o0, rs_out, ooff, 0, CONV_F16_OUT_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b128(o1, rs_out, ooff >= OOB ? OOB : ooff + 16u, 0, CONV_F16_OUT_AUX);
                 } else {
                     f16x8 o;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) o[i] = (half_t)y[i];
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4h, o), rs_out, ooff, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4h, o), rs_out, ooff, 0, CONV_F16_OUT_AUX);
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -606,7 +621,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, OCC) void conv_f16_persist_ker
                 // (named operands: hipcc 7.2 silently drops the host stub of the kernel when this builtin takes expressions)
                 const __amdgpu_buffer_rsrc_t rs = live ? rs_in : rs_in0;
                 const unsigned voff = avoff[i];
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(sA + (lw + i * NL) * 1024), 16, voff, soffa, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(sA + (lw + i * NL) * 1024), 16, voff, soffa, 0, CONV_F16_A_AUX);
             }
 #pragma unroll
             for (int j = 0; j < PPB; ++j) {
@@ -819,7 +834,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, 1) void conv3x3_f16_strip_kern
             const int sp = t * SP3 + spl;
             if (spl >= SP3 || sp >= SP || sp * 8 >= SR) continue;  // wave-uniform
             const unsigned voff = avoff[t][j];  // (a named operand: hipcc 7.2 silently drops the host stub of the kernel otherwise)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(dst + sp * 1024), 16, voff, soff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(dst + sp * 1024), 16, voff, soff, 0, CONV_F16_A_AUX);
         }
     };
     auto next_group = [&]() {
