@@ -22,6 +22,10 @@
 #include "common.h"
 #include "detmath.h"
 
+#ifndef CONV_F32_RES_AUX  // cache policy of the residual loads (0 default, 2 = nt); see conv_mfma_f16.hip
+#define CONV_F32_RES_AUX 0
+#endif
+
 namespace isegmi {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -88,7 +92,7 @@ __device__ __forceinline__ void epi_begin(const ConvK& p, int row0, int co, Epi&
         for (int e = 0; e < 16; ++e) ep.off[e] = base + (unsigned)((e & 3) + 8 * (e >> 2)) * pitch;
         if (p.res) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) ep.rv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ep.rs_res, ep.off[e], 0, 0));
+            for (int e = 0; e < 16; ++e) ep.rv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ep.rs_res, ep.off[e], 0, CONV_F32_RES_AUX));
         } else {
 #pragma unroll
             for (int e = 0; e < 16; ++e) ep.rv[e] = 0.0f;
@@ -99,7 +103,7 @@ __device__ __forceinline__ void epi_begin(const ConvK& p, int row0, int co, Epi&
         for (int e = 0; e < 16; ++e) {
             const int m = row0 + (e & 3) + 8 * (e >> 2);
             const unsigned resoff = m < p.M ? (unsigned)m * (unsigned)p.Cout * 4u : OOB;
-            ep.rv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ep.rs_res, (resoff | cooff) >= OOB ? OOB : resoff + cooff, 0, 0));
+            ep.rv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ep.rs_res, (resoff | cooff) >= OOB ? OOB : resoff + cooff, 0, CONV_F32_RES_AUX));
             unsigned rowoff;
             if (p.contiguous) rowoff = m < p.M ? (unsigned)m * (unsigned)p.out_pix_stride * 4u : OOB;
             else {
@@ -782,7 +786,7 @@ __device__ __forceinline__ void conv_mfma16_body(const ConvK& p, float* smem16, 
             for (int e = 0; e < 4; ++e) ooff[e] = base + (unsigned)e * pitch;
             if (p.res) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) rv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_res, ooff[e], 0, 0));
+                for (int e = 0; e < 4; ++e) rv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_res, ooff[e], 0, CONV_F32_RES_AUX));
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) rv[e] = 0.0f;
@@ -799,7 +803,7 @@ __device__ __forceinline__ void conv_mfma16_body(const ConvK& p, float* smem16, 
                     off = (unsigned)(((int64_t)ni * p.out_img_stride + (int64_t)pi * p.out_pix_stride + co) * 4);
                 }
                 ooff[e] = ok ? off : OOB;
-                rv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_res, ok ? ((unsigned)m * (unsigned)p.Cout + (unsigned)co) * 4u : OOB, 0, 0));
+                rv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_res, ok ? ((unsigned)m * (unsigned)p.Cout + (unsigned)co) * 4u : OOB, 0, CONV_F32_RES_AUX));
             }
         }
         float yv[4];
