@@ -26,8 +26,21 @@
 #ifndef CONV_F16_OUT_AUX
 #define CONV_F16_OUT_AUX 0
 #endif
+// wave priority (s_setprio 0..3) of the loader waves / the MFMA waves of the loader-wave kernels; -1: left alone
+#ifndef CONV_F16_LOADER_PRIO
+#define CONV_F16_LOADER_PRIO -1
+#endif
+#ifndef CONV_F16_MFMA_PRIO
+#define CONV_F16_MFMA_PRIO -1
+#endif
 
 namespace isegmi {
+
+__device__ __forceinline__ void conv_f16_role_prio(const bool loader) {
+    if (loader) { if (CONV_F16_LOADER_PRIO >= 0) __builtin_amdgcn_s_setprio(CONV_F16_LOADER_PRIO < 0 ? 0 : CONV_F16_LOADER_PRIO); }
+    else if (CONV_F16_MFMA_PRIO >= 0) __builtin_amdgcn_s_setprio(CONV_F16_MFMA_PRIO < 0 ? 0 : CONV_F16_MFMA_PRIO);
+}
+
 
 typedef _Float16 half_t;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -344,6 +357,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, OCC) void conv_f16_glds_kernel
         }
     }
     int wr = NSTAGE - 1;
+    if (LW > 0) conv_f16_role_prio(wave >= NW);
     if (LW > 0 && wave >= NW) {  // loader wave: same barrier sequence as the MFMA waves, no matrix work
         for (int t = 0; t < p.nchunks; ++t) {
             asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NSTAGE - 2) * PP) : "memory");
@@ -566,6 +580,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, OCC) void conv_f16_persist_ker
     };
     const int my_tiles = (total - bid + G - 1) / G;  // >= 1: the launcher never starts more blocks than tiles
 
+    conv_f16_role_prio(wave >= NW);
     if (wave >= NW) {
         // ---------------- loader waves
         karg_t kl = kp0;
@@ -896,6 +911,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, 1) void conv3x3_f16_strip_kern
         issue_b(0);
         next_b();
     }
+    if (LW > 0) conv_f16_role_prio(wave >= NW);
     if (LW > 0 && wave >= NW) {  // loader wave: the MFMA waves' barrier sequence, loads only
         int u = 0;
         for (int gi = 0; gi < ngroups; ++gi) {
