@@ -4,6 +4,7 @@
 // top-down, relu'd 3x3 preds, two stride-2 downsamples) -> protonet on P3 -> shared prediction head
 // on P3..P7 -> Detect -> postprocess.  BN is folded into the conv epilogue (scale, shift) by the
 // Python host (isegmi/yolact.py) exactly once, in fp32.
+#include <mutex>
 #include "engine.h"
 
 #include <string.h>
@@ -633,6 +634,47 @@ int yolact_postprocess(Engine& e, int h, int w, const int32_t* h_image_hw) {
 
 using namespace isegmi;
 
+// ---- process-wide pool of stream sets.  An engine BORROWS its ten streams (main, 3 side, tail, heads, 3 heads-side, copy) and hands them back
+// when it is destroyed; the next engine of the process gets the very same streams.  Why not create / destroy per engine: the runtime places a
+// new stream on one of its four in-order hardware queues by what the process has created (and destroyed) so far, and an engine's speed depends on
+// which of its streams end up sharing a queue -- Mask R-CNN bs=2 ran 220.0 img/s as the first engine of a process and 204.8 as the second, after a
+// Yolact engine had been created and closed (tools/second_engine_probe.py; the default bench.py line's embedded configs[2] figure was such a second
+// engine).  With the pool every engine that follows a closed one sees the first one's placement.  Engines alive at the same time get sets of their own.
+namespace {
+struct StreamSet { int dev = 0; bool used = false; hipStream_t s[10] = {nullptr}; };
+std::mutex g_sets_mu;
+std::vector<StreamSet*> g_sets;
+
+int acquire_streams(StreamSet** out) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_sets_mu);
+    for (StreamSet* ss : g_sets)
+        if (!ss->used && ss->dev == dev) { ss->used = true; *out = ss; return ISEGMI_OK; }
+    StreamSet* ss = new StreamSet();
+    ss->dev = dev;
+    hipError_t er = hipStreamCreate(&ss->s[0]);
+    for (int i = 1; i < 10 && er == hipSuccess; ++i) er = hipStreamCreateWithFlags(&ss->s[i], hipStreamNonBlocking);
+    if (er != hipSuccess) {
+        for (int i = 0; i < 10; ++i) if (ss->s[i]) (void)hipStreamDestroy(ss->s[i]);
+        delete ss;
+        set_error(std::string("hipStreamCreate: ") + hipGetErrorString(er));
+        return ISEGMI_ERR_HIP;
+    }
+    ss->used = true;
+    g_sets.push_back(ss);
+    *out = ss;
+    return ISEGMI_OK;
+}
+
+void release_streams(StreamSet* ss) {
+    if (!ss) return;
+    for (int i = 0; i < 10; ++i) (void)hipStreamSynchronize(ss->s[i]);
+    std::lock_guard<std::mutex> lk(g_sets_mu);
+    ss->used = false;
+}
+}  // namespace
+
 
 extern "C" int isegmi_engine_create(int model_kind, int max_batch, int H, int W, isegmi_engine** out) {
     ARG_CHECK(out, "null out");
@@ -640,18 +682,20 @@ extern "C" int isegmi_engine_create(int model_kind, int max_batch, int H, int W,
     ARG_CHECK(max_batch > 0 && H > 0 && W > 0, "sizes");
     isegmi_engine* h = new isegmi_engine();
     h->e.kind = model_kind; h->e.max_batch = max_batch; h->e.H = H; h->e.W = W;
-    hipError_t er = hipStreamCreate(&h->e.stream);
-    for (int i = 0; i < 3 && er == hipSuccess; ++i) er = hipStreamCreateWithFlags(&h->e.side[i], hipStreamNonBlocking);
-    if (er != hipSuccess) { set_error(std::string("hipStreamCreate: ") + hipGetErrorString(er)); delete h; return ISEGMI_ERR_HIP; }
-    if (er == hipSuccess) er = hipStreamCreateWithFlags(&h->e.tail, hipStreamNonBlocking);
-    if (er == hipSuccess) er = hipEventCreateWithFlags(&h->e.tail_done, hipEventDisableTiming);
-    if (er == hipSuccess) er = hipStreamCreateWithFlags(&h->e.heads, hipStreamNonBlocking);
-    for (int i = 0; i < 3 && er == hipSuccess; ++i) er = hipStreamCreateWithFlags(&h->e.hside[i], hipStreamNonBlocking);
+    StreamSet* ss = nullptr;
+    if (acquire_streams(&ss) != ISEGMI_OK) { delete h; return ISEGMI_ERR_HIP; }
+    h->e.stream_set = ss;
+    h->e.stream = ss->s[0];
+    for (int i = 0; i < 3; ++i) h->e.side[i] = ss->s[1 + i];
+    h->e.tail = ss->s[4];
+    h->e.heads = ss->s[5];
+    for (int i = 0; i < 3; ++i) h->e.hside[i] = ss->s[6 + i];
+    h->e.copy = ss->s[9];
+    hipError_t er = hipEventCreateWithFlags(&h->e.tail_done, hipEventDisableTiming);
     if (er == hipSuccess) er = hipEventCreateWithFlags(&h->e.lat_done, hipEventDisableTiming);
     if (er == hipSuccess) er = hipEventCreateWithFlags(&h->e.heads_done, hipEventDisableTiming);
-    if (er == hipSuccess) er = hipStreamCreateWithFlags(&h->e.copy, hipStreamNonBlocking);
     if (er == hipSuccess) er = hipEventCreateWithFlags(&h->e.in_done, hipEventDisableTiming);
-    if (er != hipSuccess) { set_error(std::string("tail stream: ") + hipGetErrorString(er)); delete h; return ISEGMI_ERR_HIP; }
+    if (er != hipSuccess) { set_error(std::string("engine events: ") + hipGetErrorString(er)); release_streams(ss); delete h; return ISEGMI_ERR_HIP; }
     h->e.cur = h->e.stream;
     *out = h;
     return ISEGMI_OK;
@@ -660,16 +704,14 @@ extern "C" int isegmi_engine_create(int model_kind, int max_batch, int H, int W,
 extern "C" int isegmi_engine_destroy(isegmi_engine* h) {
     if (!h) return ISEGMI_OK;
     Engine& e = h->e;
-    (void)hipStreamSynchronize(e.stream);
+    if (e.stream_set) for (int i = 0; i < 10; ++i) (void)hipStreamSynchronize(((StreamSet*)e.stream_set)->s[i]);  // nothing of this engine is in flight any more
     eng_graph_reset(e);
     if (e.heads) { (void)hipStreamSynchronize(e.heads); }
-    if (e.tail) { (void)hipStreamSynchronize(e.tail); (void)hipStreamDestroy(e.tail); }
+    if (e.tail) (void)hipStreamSynchronize(e.tail);
     if (e.tail_done) (void)hipEventDestroy(e.tail_done);
-    for (int i = 0; i < 3; ++i) if (e.hside[i]) (void)hipStreamDestroy(e.hside[i]);
-    if (e.heads) (void)hipStreamDestroy(e.heads);
     if (e.lat_done) (void)hipEventDestroy(e.lat_done);
     if (e.heads_done) (void)hipEventDestroy(e.heads_done);
-    if (e.copy) { (void)hipStreamSynchronize(e.copy); (void)hipStreamDestroy(e.copy); }
+    if (e.copy) (void)hipStreamSynchronize(e.copy);
     if (e.in_done) (void)hipEventDestroy(e.in_done);
     for (auto& u : e.uploads) if (u.done) (void)hipEventDestroy(u.done);
     for (int i = 0; i < 2; ++i) if (e.dl_done[i]) (void)hipEventDestroy(e.dl_done[i]);
@@ -680,8 +722,7 @@ extern "C" int isegmi_engine_destroy(isegmi_engine* h) {
     for (auto& kv : e.tensors) (void)hipFree(kv.second.d);
     for (auto& kv : e.bufs) (void)hipFree(kv.second.d);
     for (auto& ev : e.ev_pool) (void)hipEventDestroy(ev);
-    for (int i = 0; i < 3; ++i) if (e.side[i]) (void)hipStreamDestroy(e.side[i]);
-    (void)hipStreamDestroy(e.stream);
+    release_streams((StreamSet*)e.stream_set);  // back to the process-wide pool (synchronised there), not destroyed
     delete h;
     return ISEGMI_OK;
 }

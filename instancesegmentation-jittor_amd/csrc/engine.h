@@ -85,6 +85,7 @@ struct Engine {
     int pin_next = 0;
     int hw_slot = 0;                       // Mask R-CNN image_hw lives in two device buffers used alternately (WAR against the previous forward's tail)
     // asynchronous download of a step's record block (device-side COCO output) on its own stream: two slots, like the RCCL records
+    void* stream_set = nullptr;  // the pooled set the ten streams below belong to (engine.cpp: acquire_streams / release_streams)
     hipEvent_t dl_done[2] = {nullptr, nullptr};
     bool dl_used[2] = {false, false};
     bool fp16 = false;                     // fp16 storage + f16 MFMA convs (BASELINE configs[4]); set before loading weights
