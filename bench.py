@@ -408,7 +408,7 @@ def bench_yolact(a, dist):
                                   conv_flops, conv_ms, conv_launches, a.steps, ypeak, None if (a.fp16 or a.yolact_config != "resnet50") else "pmc_yolact.json"),
         "step_ms": {"mean": round(elapsed / a.steps * 1e3, 3), "p50": round(pct(step_ms, 0.5), 3), "p90": round(pct(step_ms, 0.9), 3),
                     "note": "intervals between consecutive per-step completion events on the results stream (pipelined multi-stream run)" +
-                            ("; the RCCL all-gather runs on its own stream behind these marks and is not inside them (it is inside `value`)" if gather is not None else "")},
+                            ("; the RCCL all-gather of the step runs on that stream in front of its mark, so it is inside these intervals" if gather is not None else "")},
         "mean_ms_per_image": round(elapsed / a.steps * 1e3 / a.batch, 3),
         "p50_ms_per_image": round(pct(step_ms, 0.5) / a.batch, 3),
     }
@@ -611,7 +611,7 @@ def bench_maskrcnn(a, dist, summary=False):
            "roofline": roof,
            "step_ms": {"mean": round(elapsed / steps * 1e3, 3), "p50": round(pct(step_ms, 0.5), 3), "p90": round(pct(step_ms, 0.9), 3),
                        "note": "intervals between consecutive per-step completion events on the results stream (pipelined multi-stream run)" +
-                               ("; the RCCL all-gather runs on its own stream behind these marks and is not inside them (it is inside `value`)" if gather is not None else "")},
+                               ("; the RCCL all-gather of the step runs on that stream in front of its mark, so it is inside these intervals" if gather is not None else "")},
            "mean_ms_per_image": round(elapsed / steps * 1e3 / batch, 3), "p50_ms_per_image": round(pct(step_ms, 0.5) / batch, 3)}
     out["value_note"] = "SURVEY 8(d): the H2D of every batch is inside the step (%.1f MB of uint8 images through pinned memory on a copy stream, double-buffered; mean subtraction + to_image_list padding on the engine's stream); results stay on the device (value_e2e ships them)" % (flat.nbytes / 1e6)
     if resident_elapsed is not None:
