@@ -158,9 +158,11 @@ ORA_API void ora_conv2d(const float* in, int N, int H, int W, int Cin,
 #pragma omp parallel for collapse(2) schedule(dynamic, 4)
     for (int n = 0; n < N; ++n)
         for (int ho = 0; ho < Ho; ++ho) {
-            for (int wo0 = 0; wo0 < Wo; wo0 += PB) {
+            /* channel block outside the pixel groups: one block's weights (K x 32 floats) serve a whole output row from the core's L2 instead of being
+             * streamed again for every four pixels (order of evaluation only: each output's chain is untouched) */
+            for (int cb = 0; cb < Cp; cb += CB) {
+                for (int wo0 = 0; wo0 < Wo; wo0 += PB) {
                 const int np = (Wo - wo0) < PB ? (Wo - wo0) : PB;
-                for (int cb = 0; cb < Cp; cb += CB) {
 #ifdef __AVX2__
                     __m256 acc[PB][4];
                     for (int p = 0; p < PB; ++p)
