@@ -85,6 +85,18 @@ int isegmi_pack_conv_weights_f16(const isegmi_conv_desc* d, const float* h_w_krs
 int isegmi_op_conv2d_f16(const isegmi_conv_desc* d, const void* d_in, const void* d_wpacked,
                          const float* d_scale, const float* d_shift, const void* d_residual, void* d_out,
                          int out_f32, void* stream);
+/* Fused identity bottleneck, fp16 (M2 `BottleneckWithFixedBatchNorm`, blocks 1.. of res2 / res3 under configs[4]):
+ * out = relu(bn3(conv1x1(relu(bn2(conv3x3(relu(bn1(conv1x1(x)))))))) + x) in ONE launch; the two Cmid-channel intermediates stay in LDS as
+ * fp16 (rounded where the three-launch path rounds them when it stores them: results are bit-identical to three isegmi_op_conv2d_f16
+ * calls with (r, s, cin)-ordered tiles), x is read once, out written once.  (Cin, Cmid) = (256, 64) or (512, 128); Cout = Cin = 4 Cmid;
+ * weights are the isegmi_pack_conv_weights_f16 images of the three layers, scale / shift the folded FrozenBN of each. */
+typedef struct isegmi_bottleneck_desc {
+    int32_t N, H, W, Cin, Cmid;
+    int32_t flags;                   /* bit 0 (test hook): 8-block grid, so that small shapes exercise the multi-tile stream */
+} isegmi_bottleneck_desc;
+int isegmi_op_bottleneck_f16(const isegmi_bottleneck_desc* d, const void* d_x, const void* d_w1, const float* d_s1, const float* d_b1,
+                             const void* d_w2, const float* d_s2, const float* d_b2, const void* d_w3, const float* d_s3,
+                             const float* d_b3, void* d_out, void* stream);
 /* fp16 stem (M2 `StemWithFixedBatchNorm` conv1 under configs[4]): desc Cin=4 R=S=7 stride=2 pad=3 with H, W the image
  * size; d_in of isegmi_op_conv2d_f16 is then the haloed fp16 image [N][H+6][(W+7)&~1][4] this op writes from the fp32
  * NHWC C=3 batch (3 zero pixels on every side, zero 4th channel); weights are given as [Cout][7][7][4]. */

@@ -160,6 +160,9 @@ int conv2d_launch(const isegmi_conv_desc* d, const float* in, const float* w, co
                   const float* res, float* out, hipStream_t st);
 int conv2d_f16_launch(const isegmi_conv_desc* d, const void* in, const void* w, const float* scale, const float* shift, const void* res,
                       void* out, int out_f32, hipStream_t st);
+bool bottleneck_f16_supported(int Cin, int Cmid);
+int bottleneck_f16_launch(const isegmi_bottleneck_desc* d, const void* x, const void* w1, const float* s1, const float* b1, const void* w2,
+                          const float* s2, const float* b2, const void* w3, const float* s3, const float* b3, void* out, hipStream_t st);
 int pad_c3_to_f16_halo_launch(const float* in, int N, int H, int W, void* out, hipStream_t st);
 int avgpool_full_launch(const float* x, int64_t R, int HW, int C, float* out, hipStream_t st);
 int resize_bilinear_f16_launch(const void* in, int N, int H, int W, int C, int Ho, int Wo, const void* add, int relu, void* out, hipStream_t st);
