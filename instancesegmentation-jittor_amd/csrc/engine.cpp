@@ -103,6 +103,49 @@ int eng_conv(Engine& e, const std::string& layer, const Tensor& in, int stride, 
     return timed_conv(e, layer, &d, in.d, L, residual ? residual->d : nullptr, out->d, out_f32);
 }
 
+// fp16 identity bottleneck `block` (conv1 / conv2 / conv3 of an upstream-named ResNet block, stride 1, no projection) as ONE launch of the
+// fused kernel (csrc/bottleneck_f16.hip) when the block's shape has one; *fused tells the caller whether it ran (else: three eng_conv calls)
+int eng_bottleneck_f16(Engine& e, const std::string& block, const Tensor& x, const std::string& out_name, Tensor* out, bool* fused) {
+    *fused = false;
+    if (x.dt != 1 || e.param("fused_bottleneck", 1.0f) == 0.0f) return ISEGMI_OK;
+    auto c1 = e.convs.find(block + ".conv1"), c2 = e.convs.find(block + ".conv2"), c3 = e.convs.find(block + ".conv3");
+    if (c1 == e.convs.end() || c2 == e.convs.end() || c3 == e.convs.end()) return ISEGMI_OK;
+    const ConvLayer &L1 = c1->second, &L2 = c2->second, &L3 = c3->second;
+    const int Cmid = L1.Cout;
+    if (!(L1.f16 && L2.f16 && L3.f16) || L1.Cin != x.C || L3.Cout != x.C || L2.Cin != Cmid || L2.Cout != Cmid || L3.Cin != Cmid || L1.R != 1 || L2.R != 3 ||
+        L2.S != 3 || L3.R != 1 || !bottleneck_f16_supported(x.C, Cmid) || !L1.d_scale || !L1.d_shift || !L2.d_scale || !L2.d_shift || !L3.d_scale || !L3.d_shift)
+        return ISEGMI_OK;
+    if ((int64_t)x.N * x.H * x.W * x.C * 2 >= (1ll << 31)) return ISEGMI_OK;
+    int rc = eng_act(e, out_name, x.N, x.H, x.W, x.C, out, 1);
+    if (rc) return rc;
+    if ((const void*)out->d == (const void*)x.d) { set_error("bottleneck " + block + ": in-place"); return ISEGMI_ERR_STATE; }
+    isegmi_bottleneck_desc d;
+    memset(&d, 0, sizeof(d));
+    d.N = x.N; d.H = x.H; d.W = x.W; d.Cin = x.C; d.Cmid = Cmid;
+    hipEvent_t a = nullptr, b = nullptr;
+    if (e.conv_timing) {
+        HIP_TRY(hipEventCreate(&a));
+        HIP_TRY(hipEventCreate(&b));
+        HIP_TRY(hipEventRecord(a, e.cur));
+    }
+    const int M = x.N * x.H * x.W;
+    if (e.conv_trace) fprintf(stderr, "convlaunch\t%s.fused\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\n", block.c_str(), x.N, x.H, x.W, x.C, x.C, 3, 1, M, 1);
+    rc = bottleneck_f16_launch(&d, x.d, L1.d_w, L1.d_scale, L1.d_shift, L2.d_w, L2.d_scale, L2.d_shift, L3.d_w, L3.d_scale, L3.d_shift, out->d, e.cur);
+    if (rc) return rc;
+    if (e.conv_timing) {
+        HIP_TRY(hipEventRecord(b, e.cur));
+        e.conv_evs.push_back({a, b});
+        // algorithmic FLOPs of the three convolutions (the halo the fused kernel recomputes for conv1 is not counted)
+        const double fl = 2.0 * M * ((double)x.C * Cmid * 2 + 9.0 * Cmid * Cmid);
+        e.conv_flops_pending += fl;
+        char geo[160];
+        snprintf(geo, sizeof(geo), "%s.fused [M=%d C=%d Cmid=%d 1x1+3x3+1x1]", block.c_str(), M, x.C, Cmid);
+        e.conv_ev_info.push_back({geo, fl});
+    }
+    *fused = true;
+    return ISEGMI_OK;
+}
+
 // fp16 stem: `halo` is the [N][H+6][(W+7)&~1][4] fp16 image of pad_c3_to_f16_halo; H, W the image size
 int eng_conv_stem_f16(Engine& e, const std::string& layer, const Tensor& halo, int H, int W, const std::string& out_name, Tensor* out) {
     const ConvLayer* L;
@@ -395,6 +438,13 @@ int yolact_forward(Engine& e, const float* d_images, int N) {
             // (C3-C5 are read by the lateral convs of the pipelined heads phase; the lat_done fence below guards exactly those)
             const bool alias = e.param("alias_buffers", 1.0f) != 0.0f;  // 0: one buffer per layer output (rounds 1-2; kept for A/B)
             const std::string sg = alias ? "res" + std::to_string(li + 2) : nm;
+            const std::string out_name = !alias ? nm + ".out" : b == blocks[li] - 1 ? sg + ".C" : sg + (b & 1 ? ".outB" : ".outA");
+            if (b > 0 && dt) {  // fp16 identity blocks of res2 / res3: one launch, t1 / t2 stay in LDS (csrc/bottleneck_f16.hip)
+                if (li == 1 && b == blocks[1] - 1 && e.lat_pending) HIP_TRY(hipStreamWaitEvent(e.stream, e.lat_done, 0));  // (see below)
+                bool fused = false;
+                TRY(eng_bottleneck_f16(e, nm, x, out_name, &y, &fused));
+                if (fused) { x = y; continue; }
+            }
             TRY(eng_conv(e, nm + ".conv1", x, 1, 0, 1, nullptr, sg + ".t1", &t1));
             if (e.convs.count(nm + ".conv2.conv_offset_mask")) {
                 // DCNv2 3x3 (YOLACT++ backbones): offsets + mask logits from a plain 3x3 -> the nine taps sampled into columns ->
@@ -412,7 +462,7 @@ int yolact_forward(Engine& e, const float* d_images, int N) {
             // C3 (then C4, C5) is about to be overwritten: the previous step's lateral convs, running on the heads streams, must
             // have read them (they are the first thing of that phase, so this wait practically never blocks)
             if (li == 1 && b == blocks[1] - 1 && e.lat_pending) HIP_TRY(hipStreamWaitEvent(e.stream, e.lat_done, 0));
-            TRY(eng_conv(e, nm + ".conv3", t2, 1, 0, 1, &idt, !alias ? nm + ".out" : b == blocks[li] - 1 ? sg + ".C" : sg + (b & 1 ? ".outB" : ".outA"), &y));
+            TRY(eng_conv(e, nm + ".conv3", t2, 1, 0, 1, &idt, out_name, &y));
             x = y;
         }
         outs[li] = x;

@@ -134,6 +134,7 @@ int eng_input_consumed(Engine& e);  // call right after the last kernel that rea
 int eng_wait_upload(Engine& e, const void* d_ptr, int64_t bytes, hipStream_t st);  // st waits for every pending upload / front-end write into [d_ptr, d_ptr + bytes)
 int eng_stage_small(Engine& e, const void* h_src, size_t bytes, void* d_dst, hipStream_t st);  // host array -> pinned ring slot -> async H2D on st
 hipStream_t eng_results_stream(Engine& e);  // the stream the last forward's results complete on  // st waits for a pending upload_async whose destination holds d_ptr
+int eng_bottleneck_f16(Engine& e, const std::string& block, const Tensor& x, const std::string& out_name, Tensor* out, bool* fused);
 int eng_conv_stem_f16(Engine& e, const std::string& layer, const Tensor& halo, int H, int W, const std::string& out_name, Tensor* out);
 int eng_conv_into(Engine& e, const std::string& layer, const Tensor& in, int stride, int pad, int act, void* dst, int out_div,
                   int64_t out_img_stride, int64_t out_pix_stride, bool out_f32 = false);

@@ -143,10 +143,15 @@ int maskrcnn_forward(Engine& e, const float* d_images, int N) {
             // overwritten while its lines still sit in the Infinity Cache instead of being written back to HBM behind the live traffic.
             const bool alias = e.param("alias_buffers", 1.0f) != 0.0f;  // 0: one buffer per layer output (rounds 1-2; kept for A/B)
             const std::string sg = alias ? "res" + std::to_string(li + 2) : nm;
-            TRY(eng_conv(e, nm + ".conv1", x, sd, 0, 1, nullptr, sg + ".t1", &t1));  // STRIDE_IN_1X1
-            TRY(eng_conv(e, nm + ".conv2", t1, 1, 1, 1, nullptr, sg + ".t2", &t2));
-            if (b == 0) TRY(eng_join(e, 0));
-            TRY(eng_conv(e, nm + ".conv3", t2, 1, 0, 1, &idt, !alias ? nm + ".out" : b == blocks[li] - 1 ? sg + ".C" : sg + (b & 1 ? ".outB" : ".outA"), &y));
+            const std::string out_name = !alias ? nm + ".out" : b == blocks[li] - 1 ? sg + ".C" : sg + (b & 1 ? ".outB" : ".outA");
+            bool fused = false;
+            if (b > 0) TRY(eng_bottleneck_f16(e, nm, x, out_name, &y, &fused));  // fp16 identity blocks of res2 / res3: one launch, t1 / t2 stay in LDS
+            if (!fused) {
+                TRY(eng_conv(e, nm + ".conv1", x, sd, 0, 1, nullptr, sg + ".t1", &t1));  // STRIDE_IN_1X1
+                TRY(eng_conv(e, nm + ".conv2", t1, 1, 1, 1, nullptr, sg + ".t2", &t2));
+                if (b == 0) TRY(eng_join(e, 0));
+                TRY(eng_conv(e, nm + ".conv3", t2, 1, 0, 1, &idt, out_name, &y));
+            }
             x = y;
         }
         C[li] = x;

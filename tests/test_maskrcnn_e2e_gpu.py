@@ -168,6 +168,37 @@ def test_maskrcnn_fp16_path_close_to_fp16_oracle(ffi, sd):
     model.close()
 
 
+def test_maskrcnn_fp16_fused_bottleneck_equals_three_launches(ffi, sd):
+    """configs[4] engine with the fused identity bottlenecks of res2 / res3 (default) against the same engine with `fused_bottleneck` 0:
+    res2's fused blocks are bit-identical to the three launches whatever tile those pick (one 64-channel chunk per tap: one K order); res3's
+    3x3 may run on the row-strip kernel, which walks K as (r, cin, s) -- another correct fp32 association -- so C3 and everything after it
+    is held to the fp16 yardstick of test_maskrcnn_fp16_path_close_to_fp16_oracle.  The fused path must actually run: five conv launches
+    per step become... fewer (2 + 3 identity blocks x 3 launches -> 5 launches)."""
+    import ctypes as C
+    from isegmi.maskrcnn import MaskRCNN, prepare_images
+    rng = np.random.default_rng(99)
+    x, hw = prepare_images([rng.uniform(0, 255, (250, 340, 3)).astype(np.float32), rng.uniform(0, 255, (230, 300, 3)).astype(np.float32)])
+    outs = {}
+    for fused in (1, 0):
+        model = MaskRCNN(sd, x.shape[1], x.shape[2], max_batch=2, fp16=True)
+        model.set_param("fused_bottleneck", float(fused))
+        model.set_param("multi_stream", 0.0)
+        model.set_param("conv_timing", 1.0)
+        bl = model(x, hw)
+        f, m, l = C.c_double(), C.c_double(), C.c_int64()
+        ffi.check(ffi.lib().isegmi_engine_conv_stats(model._h, C.byref(f), C.byref(m), C.byref(l)))
+        outs[fused] = dict(C2=model.fetch("res2.C", 2), C3=model.fetch("res3.C", 2), P2=model.fetch("P2", 2), n=[len(b) for b in bl], launches=l.value, flops=f.value)
+        model.close()
+    a, b = outs[1], outs[0]
+    assert b["launches"] - a["launches"] == 2 * (2 + 3), (a["launches"], b["launches"])   # five identity blocks: 3 launches -> 1
+    assert abs(a["flops"] - b["flops"]) <= 1e-6 * b["flops"]                               # the roofline's algorithmic FLOPs do not change
+    assert np.array_equal(a["C2"], b["C2"])
+    for k in ("C3", "P2"):
+        d = np.abs(a[k].astype(np.float32) - b[k].astype(np.float32))
+        assert d.max() <= 5e-3 * np.abs(b[k].astype(np.float32)).max(), k
+    assert all(abs(i - j) <= 5 for i, j in zip(a["n"], b["n"]))
+
+
 def test_maskrcnn_full_size_bs2_bit_exact(ffi, sd):
     """BASELINE configs[2] at its own workload: two 1333x800 images -> one 2x800x1344 batch, fp32, 1000 proposals per image.
     Proposals, boxes, scores, labels, 28x28 masks and the masks pasted at 800x1333 are all compared exactly."""
