@@ -45,7 +45,8 @@ struct BtlK {
     half_t* out;
     int N, H, W;                 // x is [N][H][W][CIN]; identity block: the output has the same geometry
     int tiles_x, tiles_y, total;
-    unsigned x_bytes, out_bytes, w1_bytes, w2_bytes, w3_bytes;
+    unsigned x_bytes, out_bytes, res_bytes, w1_bytes, w2_bytes, w3_bytes;
+    int exp_flags;  // TIMING-ONLY experiments: 32 the loader waves issue nothing, 64 the MFMA waves only keep the barriers
 };
 
 template <int CIN_, int CMID_, int TH_, int TW_>
@@ -68,6 +69,7 @@ struct BtlCfg {
     // vmcnt wait is uniform; each goes to its own KiB at the unused end of the stage -- hipcc merges LDS-DMA builtins that are identical, and
     // a merged piece makes the count one short (seen: garbage in t1 on cold caches)
     static constexpr int STAGEB = max3(P1_BYTES, P2_BYTES + (PP - PP2) * 1024, P3_BYTES + (PP - PP3) * 1024);
+    static constexpr int RD = CMID == 64 ? 8 : 4; // residual passes (16 B per lane each) in flight: requested before conv2, refilled pass by pass
     static constexpr int EPITCH = 68;             // floats per scratch row (64 + 4)
     static constexpr int SCRATCH = NW * 8 * EPITCH * 4;
     static constexpr int REGION = MHP * P1B > MTP * P1B + SCRATCH ? MHP * P1B : MTP * P1B + SCRATCH;
@@ -84,6 +86,22 @@ struct BtlCfg {
 // 16-B column swizzle of row `r` of a t1 / t2 image (conflict-free ds_read_b128 over rows at one logical column)
 template <int NCOL>
 __device__ __forceinline__ int mid_sw(int r) { return NCOL == 8 ? ((r >> 1) & 7) : (r & 15); }
+
+// Pins the interleave of a K-loop body of NG groups, each RPG fragment reads (ds_read_b128) feeding MPG MFMAs, as a software pipeline whose
+// reads run LA groups ahead of the MFMAs that consume them.  Left to itself hipcc keeps ONE read in flight per MFMA (s_waitcnt lgkmcnt(1) in
+// front of every v_mfma): with two MFMA waves per SIMD that exposes an LDS latency per MFMA and the waves ran at a third of the matrix rate.
+template <int NG, int RPG, int MPG, int LA>
+__device__ __forceinline__ void pipeline_reads_mfmas() {
+    constexpr int L = LA < NG ? LA : NG;
+    __builtin_amdgcn_sched_group_barrier(0x100, L * RPG, 0);
+#pragma unroll
+    for (int i = 0; i < NG - L; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, MPG, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, RPG, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < L; ++i) __builtin_amdgcn_sched_group_barrier(0x008, MPG, 0);
+}
 
 template <class CF>
 __global__ __launch_bounds__((CF::NW + CF::LW) * 64, 1) void bottleneck_f16_kernel(const BtlK p) {
@@ -163,6 +181,7 @@ __global__ __launch_bounds__((CF::NW + CF::LW) * 64, 1) void bottleneck_f16_kern
             }
         };
         auto issue = [&](int stage) {  // this wave's PP pieces of the next step of the stream, then advance the stream
+            if (p.exp_flags & 32) return;
             char* base = ring + stage * STAGEB;
             if (!live) { dummies(base, PP); return; }
             if (iphase == 0) {
@@ -262,10 +281,15 @@ __global__ __launch_bounds__((CF::NW + CF::LW) * 64, 1) void bottleneck_f16_kern
     }
     float* const ew = (float*)(mid + MTP * P1B) + wave * 8 * CF::EPITCH;
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, p.out_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, p.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, p.res_bytes, 0x00020000);
 
     int st = 0;
     auto next_stage = [&]() { st = st + 1 == NSTAGE ? 0 : st + 1; };
+    if (p.exp_flags & 64) {
+        for (int i = 0; i < my_tiles; ++i)
+            for (int t = 0; t < S1 + S2 + 1 + S3; ++t) asm volatile("s_barrier" ::: "memory");
+        return;
+    }
     for (int v = bid; v < total; v += G) {
         int n, y0, x0;
         tile_origin(v, n, y0, x0);
@@ -302,6 +326,7 @@ __global__ __launch_bounds__((CF::NW + CF::LW) * 64, 1) void bottleneck_f16_kern
                             acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, xf, acc[b], 0, 0, 0);
                         }
                     }
+                    pipeline_reads_mfmas<4, 1 + NCT1, NCT1, 2>();
                 }
                 next_stage();
             }
@@ -322,7 +347,7 @@ __global__ __launch_bounds__((CF::NW + CF::LW) * 64, 1) void bottleneck_f16_kern
                             float y = fmaf(acc[b][4 * g + i], sc[i], sh[i]);
                             // the fp32 value is rounded to fp32 FIRST, as in the three-launch path (which parks it in LDS): left to itself hipcc folds
                             // fmaf + the fp16 conversion into v_fma_mixlo_f16, ONE rounding -- 1-ulp differences in 3e-5 of the elements
-                            asm volatile("" : "+v"(y));
+                            asm("" : "+v"(y));
                             y = y > 0.0f ? y : 0.0f;
                             o[i] = (half_t)(in_img ? y : 0.0f);
                         }
@@ -331,6 +356,22 @@ __global__ __launch_bounds__((CF::NW + CF::LW) * 64, 1) void bottleneck_f16_kern
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // t1 is complete at the next barrier
         }
+
+        // ---- the residual (this tile's pixels of x: L2 hits, the loaders have just streamed them) is REQUESTED here, a whole phase before the
+        // epilogue adds it: RD passes of 16 B per lane in flight, refilled as the epilogue consumes them.  (With two passes requested right
+        // before conv3's short K loop every pass of the epilogue waited out most of a memory latency.)
+        const int er = lane_t >> 3, ec = (lane_t & 7) * 8;
+        auto strip_off = [&](int slab, int q) -> unsigned {  // byte offset of this lane's 8 channels in pass q (8 pixels of the wave's tile)
+            const int m = (wm3 * TM3) * 32 + q * 8 + er;
+            const int y = m / TW, x = m - y * TW;
+            const bool ok = (m < MT) & (y0 + y < p.H) & (x0 + x < p.W);
+            return ok ? (unsigned)((((n * p.H + y0 + y) * p.W + x0 + x) * COUT + slab * 256 + wn3 * 64 + ec) * 2) : OOB;
+        };
+        constexpr int NQ = TM3 * 4, RD = CF::RD, NSLAB = COUT / 256;
+        static_assert(NQ % RD == 0, "residual window");
+        u32x4h rw[RD];
+#pragma unroll
+        for (int q = 0; q < RD; ++q) rw[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, strip_off(0, q), 0, 0);
 
         // ---- conv2: t2[m][c] = relu(bn2(sum_{tap, k} t1[j(m) + tap][k] w2[c][tap][k]))
         {
@@ -361,6 +402,7 @@ __global__ __launch_bounds__((CF::NW + CF::LW) * 64, 1) void bottleneck_f16_kern
                         }
                     }
                 }
+                pipeline_reads_mfmas<G2 * 4, NCW + NPW, NCW * NPW, 4>();
                 next_stage();
             }
             asm volatile("s_barrier" ::: "memory");  // X: every wave has read t1 for the last time; t2 and the scratch overwrite it
@@ -378,7 +420,7 @@ __global__ __launch_bounds__((CF::NW + CF::LW) * 64, 1) void bottleneck_f16_kern
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             float y = fmaf(acc[i][b][4 * g + k], sc[k], sh[k]);
-                            asm volatile("" : "+v"(y));  // (see conv1: no v_fma_mixlo_f16)
+                            asm("" : "+v"(y));  // (see conv1: no v_fma_mixlo_f16)
                             o[k] = (half_t)(y > 0.0f ? y : 0.0f);
                         }
                         *(u32x2h*)(mid + m * P1B + (((c0 >> 3) ^ swm) << 4) + 8 * lh) = __builtin_bit_cast(u32x2h, o);
@@ -388,15 +430,7 @@ __global__ __launch_bounds__((CF::NW + CF::LW) * 64, 1) void bottleneck_f16_kern
         }
 
         // ---- conv3 + bn3 + residual + ReLU, one 256-cout slab at a time
-        const int er = lane_t >> 3, ec = (lane_t & 7) * 8;
-        auto strip_off = [&](int slab, int q) -> unsigned {  // byte offset of this lane's 8 channels in pass q (8 pixels of the wave's tile)
-            const int m = (wm3 * TM3) * 32 + q * 8 + er;
-            const int y = m / TW, x = m - y * TW;
-            const bool ok = (m < MT) & (y0 + y < p.H) & (x0 + x < p.W);
-            return ok ? (unsigned)((((n * p.H + y0 + y) * p.W + x0 + x) * COUT + slab * 256 + wn3 * 64 + ec) * 2) : OOB;
-        };
-        constexpr int NQ = TM3 * 4, D = 2;
-        for (int slab = 0; slab < COUT / 256; ++slab) {
+        for (int slab = 0; slab < NSLAB; ++slab) {
             f32x16h acc[TM3][2];
 #pragma unroll
             for (int a = 0; a < TM3; ++a)
@@ -411,9 +445,6 @@ __global__ __launch_bounds__((CF::NW + CF::LW) * 64, 1) void bottleneck_f16_kern
                 sc[b] = p.s3[co];
                 sh[b] = p.b3[co];
             }
-            u32x4h rw[D];
-#pragma unroll
-            for (int q = 0; q < D; ++q) rw[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, strip_off(slab, q), 0, 0);
             for (int kc = 0; kc < KM; ++kc) {
                 asm volatile("s_barrier" ::: "memory");
                 const char* sb = ring + st * STAGEB;
@@ -429,6 +460,7 @@ __global__ __launch_bounds__((CF::NW + CF::LW) * 64, 1) void bottleneck_f16_kern
 #pragma unroll
                         for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
                 }
+                pipeline_reads_mfmas<4, TM3 + 2, TM3 * 2, 2>();
                 next_stage();
             }
 #pragma unroll
@@ -440,12 +472,16 @@ __global__ __launch_bounds__((CF::NW + CF::LW) * 64, 1) void bottleneck_f16_kern
                     for (int b = 0; b < 2; ++b)
 #pragma unroll
                         for (int k = 0; k < 4; ++k) ew[(k + 4 * lh) * CF::EPITCH + b * 32 + lr] = fmaf(acc[a][b][4 * g + k], sc[b], sh[b]);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    // (no waits around the scratch: a wave's LDS instructions execute in issue order, so these reads see the writes above and the next
+                    // pass's writes cannot overtake them; the compiler keeps the program order of accesses that may alias and waits only where a
+                    // read's RESULT is used -- passes overlap instead of paying two LDS round trips each)
                     const f32x4h v0 = *(const f32x4h*)(ew + er * CF::EPITCH + ec);
                     const f32x4h v1 = *(const f32x4h*)(ew + er * CF::EPITCH + ec + 4);
                     const unsigned ooff = strip_off(slab, q);
-                    const f16x8 rh = __builtin_bit_cast(f16x8, rw[q % D]);
-                    if (q + D < NQ) rw[q % D] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, strip_off(slab, q + D), 0, 0);
+                    const f16x8 rh = __builtin_bit_cast(f16x8, rw[q % RD]);
+                    // refill the slot with the pass RD further on (this slab's, or the next slab's first ones; NQ % RD == 0 keeps slots static)
+                    if (q + RD < NQ) rw[q % RD] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, strip_off(slab, q + RD), 0, 0);
+                    else if (slab + 1 < NSLAB) rw[q % RD] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, strip_off(slab + 1, q + RD - NQ), 0, 0);
                     f16x8 o;
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
@@ -453,7 +489,6 @@ __global__ __launch_bounds__((CF::NW + CF::LW) * 64, 1) void bottleneck_f16_kern
                         o[k] = (half_t)(y > 0.0f ? y : 0.0f);
                     }
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4h, o), rs_out, ooff, 0, 0);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
             }
         }
@@ -506,7 +541,14 @@ int bottleneck_f16_launch(const isegmi_bottleneck_desc* d, const void* x, const 
     k.w1_bytes = (unsigned)(pad128(d->Cmid) * d->Cin * 2);
     k.w2_bytes = (unsigned)(pad128(d->Cmid) * 9 * d->Cmid * 2);
     k.w3_bytes = (unsigned)(pad128(4 * d->Cmid) * d->Cmid * 2);
+    k.res_bytes = k.out_bytes;
     const int few = d->flags & 1;  // TEST HOOK: 8-block grid, so that small shapes exercise the multi-tile stream
+    // TIMING-ONLY experiments (results wrong): the range check drops every x load (2) / residual load (4) / output store (8) / weight load (16)
+    if (d->flags & 2) k.x_bytes = 0;
+    if (d->flags & 4) k.res_bytes = 0;
+    if (d->flags & 8) k.out_bytes = 0;
+    if (d->flags & 16) k.w1_bytes = k.w2_bytes = k.w3_bytes = 0;
+    k.exp_flags = d->flags & (32 | 64);
     if (d->Cin == 256) return launch_btl<BtlCfg<256, 64, 8, 16>>(k, st, few);
     return launch_btl<BtlCfg<512, 128, 8, 14>>(k, st, few);
 }

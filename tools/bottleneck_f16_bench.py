@@ -39,6 +39,13 @@ for (N, H, W, Cin, Cmid) in [(8, 200, 336, 256, 64), (8, 100, 168, 512, 128), (2
     def fused():
         _ffi.check(L.isegmi_op_bottleneck_f16(C.byref(bd), dx.ptr, *[b.ptr for b in ws], of.ptr, None))
 
+    if os.environ.get("VARIANTS"):
+        line = "N%d %dx%d C%d:" % (N, H, W, Cin)
+        for name, fl_ in (("full", 0), ("no x", 2), ("no res", 4), ("no store", 8), ("no w", 16), ("no x/res", 6), ("no x/res/store", 14), ("no mem", 30), ("no mem, loaders idle", 30 | 32), ("no mem, mfma idle", 30 | 64), ("mfma idle (loads real)", 64)):
+            bd.flags = fl_
+            line += "  %s %.3f" % (name, timeit(fused) * 1e3)
+        bd.flags = 0
+        print(line, flush=True)
     a, b = timeit(three), timeit(fused)
     a2, b2 = timeit(three), timeit(fused)
     fl = 2.0 * N * H * W * (Cin * Cmid * 2 + 9 * Cmid * Cmid)
