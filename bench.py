@@ -2,9 +2,9 @@
 """bench.py -- headline benchmark of the MI355X-native RoI/mask inference hot path.
 
 `python bench.py --gpus N --steps K --warmup W`
-  N = 1: runs in this process.  N > 1 without a torch.distributed environment: this process only starts N child ranks
-  (`python -m torch.distributed.run --nproc-per-node N bench.py ...`, before any HIP call), relays rank 0's JSON line and
-  exits with the children's code.  N > 1 inside such an environment (RANK/WORLD_SIZE set): one rank per GPU.
+  N = 1: runs in this process.  N > 1 without a rank environment: this process only starts N child ranks (`python -m isegmi.launch
+  --nproc N bench.py ...`, before any HIP call), relays rank 0's JSON line and exits with the children's code.  N > 1 inside a rank
+  environment (RANK / WORLD_SIZE set, by isegmi.launch or by the driver's launcher): one rank per GPU.
 
 A "step" = one pass of the hot path over one batch of synthetic input, as SURVEY.md 8(d) defines the metric: the H2D of the input is
 INSIDE the step (the uint8 images go up through pinned memory on a copy stream, double-buffered; FastBaseTransform / build_transform +
@@ -87,20 +87,16 @@ def emit(line):
 
 
 def spawn_ranks(a):
-    """--gpus N > 1 outside a torch.distributed environment: start the N ranks as CHILD processes (nothing in this process has
-    touched HIP), relay rank 0's JSON line, propagate the exit code."""
-    import socket
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    # fresh child processes in their own process group; a rank that dies before the first all-gather leaves the others blocked in RCCL,
-    # so the whole group is killed at the time limit and the failure is reported instead of waiting for the caller's own limit
+    """--gpus N > 1 from a plain shell: start the N ranks as CHILD processes with the package's own launcher (`python -m isegmi.launch`:
+    fresh interpreters, RANK / WORLD_SIZE / MASTER_* environment, a watchdog on communicator creation; nothing in this process has touched
+    HIP), relay rank 0's JSON line, propagate the exit code."""
+    cmd = [sys.executable, "-m", "isegmi.launch", "--nproc", str(a.gpus), "--timeout", str(a.spawn_timeout), "--init-timeout", "300",
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               PYTHONPATH=PKG + os.pathsep + os.environ.get("PYTHONPATH", ""))
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, start_new_session=True)
     try:
-        out, _ = proc.communicate(timeout=a.spawn_timeout)
+        out, _ = proc.communicate(timeout=a.spawn_timeout + 30)
     except subprocess.TimeoutExpired:
         import signal
         try:
@@ -134,8 +130,10 @@ def pct(xs, q):
 
 
 class Dist:
-    """torch.distributed is plumbing only (rendezvous, barrier, max-reduce of the wall time): CPU/gloo, so torch never touches
-    the GPU.  The data-path collective is RCCL inside libisegmi."""
+    """The N > 1 harness of the driver contract (one rank per GPU; barrier and MAX over ranks around the timed regions) on the product's own
+    transport: the ranks -- started by `python -m torch.distributed.run` (the driver) or by `python -m isegmi.launch` (spawn_ranks), both set
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* -- meet through isegmi.dist.rendezvous_unique_id and synchronise with an 8-byte RCCL all-gather.
+    Nothing here imports torch."""
 
     def __init__(self, a):
         self.rank = int(os.environ.get("RANK", "0"))
@@ -145,43 +143,38 @@ class Dist:
         if a.gpus != self.world:
             sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d\n" % (a.gpus, self.world))
             raise SystemExit(2)
-        self.pg = None
-        if self.world > 1 or self.force:
-            import torch.distributed as dist
-            dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
-            self.pg = dist
+        self.on = self.world > 1 or self.force
+        self._ctl = None
 
-    @property
-    def on(self):
-        return self.pg is not None
+    def _control(self):
+        if self._ctl is None:
+            from isegmi import _ffi
+            _ffi.set_device(self.local_rank)
+            self._ctl = self.make_gather(8)
+        return self._ctl
 
     def barrier(self):
-        if self.pg is not None:
-            self.pg.barrier()
+        if self.on:
+            self._control().allgather_bytes(b"\0" * 8)
 
     def max(self, v):
-        if self.pg is None:
+        if not self.on:
             return v
-        import torch
-        t = torch.tensor([v], dtype=torch.float64)
-        self.pg.all_reduce(t, op=self.pg.ReduceOp.MAX)
-        return float(t.item())
+        blocks = self._control().allgather_bytes(np.array([v], np.float64).tobytes())
+        return float(blocks.view(np.float64).max())
 
     def make_gather(self, nbytes):
-        if self.pg is None:
+        if not self.on:
             return None
-        import torch
-        from isegmi.dist import RcclGather
-        uid = torch.zeros(128, dtype=torch.uint8)
-        if self.rank == 0:
-            uid = torch.frombuffer(bytearray(RcclGather.unique_id()), dtype=torch.uint8).clone()
-        self.pg.broadcast(uid, 0)
-        return RcclGather(self.rank, self.world, bytes(uid.numpy().tobytes()), nbytes)
+        from isegmi.dist import RcclGather, rendezvous_unique_id
+        uid = rendezvous_unique_id(self.rank, self.world, RcclGather.unique_id)
+        return RcclGather(self.rank, self.world, uid, nbytes)
 
     def close(self):
-        if self.pg is not None:
-            self.pg.barrier()
-            self.pg.destroy_process_group()
+        if self._ctl is not None:
+            self.barrier()
+            self._ctl.close()
+            self._ctl = None
 
 
 def timed_region(net, step, full_sync, dist, steps):
@@ -359,19 +352,16 @@ def bench_yolact(a, dist):
     if not a.no_e2e:
         from isegmi.pipeline import RecordPipeline
         cgather = dist.make_gather(net.coco_record_bytes(a.batch)[0]) if gather is not None else None
-        pipe = RecordPipeline(net, a.batch, cgather)
-        hw8 = [(size, size)] * a.batch
-
         def run_rle(slot):
             net.forward_device(a.batch, slot)
             net.postprocess_device(size, size)
             net.rle_device()
         e2e_sync = (lambda: (full_sync(), cgather.wait())) if cgather is not None else full_sync
-        e2e_region(net, pipe, upload_u8, run_rle, e2e_sync, dist, max(2, a.warmup // 2))
-        e2e_elapsed, blocks, chars = e2e_region(net, pipe, upload_u8, run_rle, e2e_sync, dist, a.steps)
-        e2e = {"elapsed": e2e_elapsed, "blocks": blocks, "chars_per_step": chars / max(blocks, 1), "record_bytes": pipe.nbytes}
-        K = pipe.K
-        pipe.close()   # full mask planes again (while the pipeline is open only the box windows of the planes are written)
+        with RecordPipeline(net, a.batch, cgather) as pipe:   # closed on every way out: full mask planes again afterwards
+            e2e_region(net, pipe, upload_u8, run_rle, e2e_sync, dist, max(2, a.warmup // 2))
+            e2e_elapsed, blocks, chars = e2e_region(net, pipe, upload_u8, run_rle, e2e_sync, dist, a.steps)
+            e2e = {"elapsed": e2e_elapsed, "blocks": blocks, "chars_per_step": chars / max(blocks, 1), "record_bytes": pipe.nbytes}
+            K = pipe.K
         # the strings the device made for the bench batch, against the host encoder on the uint8 planes (rank 0, after the timed loops)
         net.upload(imgs); net.forward_device(a.batch); net.postprocess_device(size, size); net.rle_device(); full_sync()
         from isegmi.coco import rle_counts, rle_to_string
@@ -568,18 +558,16 @@ def bench_maskrcnn(a, dist, summary=False):
     if not a.no_e2e:
         from isegmi.pipeline import RecordPipeline
         cgather = dist.make_gather(model.coco_record_bytes(batch)[0]) if gather is not None else None
-        pipe = RecordPipeline(model, batch, cgather)
-
         def run_rle(slot):
             model.forward_device(batch, slot)
             model.paste_device(800, 1333)
             model.rle_device()
         e2e_sync = (lambda: (full_sync(), cgather.wait())) if cgather is not None else full_sync
-        e2e_region(model, pipe, upload_u8, run_rle, e2e_sync, dist, max(2, warmup // 2))
-        e2e_elapsed, nblocks, chars = e2e_region(model, pipe, upload_u8, run_rle, e2e_sync, dist, steps)
-        e2e = {"elapsed": e2e_elapsed, "blocks": nblocks, "chars_per_step": chars / max(nblocks, 1), "record_bytes": pipe.nbytes}
-        K = pipe.K
-        pipe.close()   # full mask planes again
+        with RecordPipeline(model, batch, cgather) as pipe:   # closed on every way out: full mask planes again afterwards
+            e2e_region(model, pipe, upload_u8, run_rle, e2e_sync, dist, max(2, warmup // 2))
+            e2e_elapsed, nblocks, chars = e2e_region(model, pipe, upload_u8, run_rle, e2e_sync, dist, steps)
+            e2e = {"elapsed": e2e_elapsed, "blocks": nblocks, "chars_per_step": chars / max(nblocks, 1), "record_bytes": pipe.nbytes}
+            K = pipe.K
         model.upload(x, hw); model.forward_device(batch); model.paste_device(800, 1333); model.rle_device(); full_sync()
         from isegmi.coco import rle_counts, rle_to_string
         so, ch = model.fetch("rle.str_off"), model.fetch("rle.chars").tobytes()

@@ -15,7 +15,12 @@ int eng_buf(Engine& e, const std::string& name, int64_t bytes, void** out, int d
     RawBuf& b = e.bufs[name];
     if (b.bytes < bytes) {
         if (e.capturing) { set_error("buffer " + name + " would be (re)allocated during graph capture"); return ISEGMI_ERR_STATE; }
-        if (b.d) HIP_TRY(hipFree(b.d));
+        // a captured graph holds the old device pointers of every buffer it touches: a grown buffer (a larger canvas or batch after a smaller one;
+        // the liveness-aliased res<l>.* buffers are shared by many layers) invalidates all of them -- they are re-captured on their next use
+        if (b.d) {
+            HIP_TRY(hipFree(b.d));  // (synchronises the device: no replay is in flight when the graphs go)
+            if (!e.graphs.empty()) eng_graph_reset(e);
+        }
         b.d = nullptr;
         HIP_TRY(hipMalloc(&b.d, (size_t)(bytes > 0 ? bytes : 16)));
         b.bytes = bytes;
@@ -881,6 +886,7 @@ extern "C" int isegmi_engine_sync(isegmi_engine* h) {
     h->e.tail_pending = false;
     h->e.lat_pending = false;
     h->e.heads_pending = false;
+    for (auto& u : h->e.uploads) u.waited = true;  // the copy stream has drained: nothing is left to wait for
     collect_times(h->e);
     return ISEGMI_OK;
 }
@@ -916,6 +922,12 @@ extern "C" int isegmi_engine_preprocess_u8(isegmi_engine* h, const uint8_t* d_u8
     if (on_copy) {
         // d_out's previous reader is fenced by upload_async's wait on in_done, which precedes the copy in this stream
         TRY(preprocess_u8_launch(d_u8, N, Hin, Win, d_out, Hout, Wout, Hpad, Wpad, out_img_stride, mean3, std3, swap_rb, e.copy));
+        // the copy stream is in order: this launch IS the consumer of the uploads into its source, so their entries are free again (left
+        // unconsumed, every re-allocated staging buffer pinned an entry for good: "more than 64 upload destinations" after 64 growths)
+        for (auto& u : e.uploads) {
+            const char* p = (const char*)d_u8;
+            if (!u.waited && p < u.dst + u.bytes && u.dst < p + src_bytes) u.waited = true;
+        }
         return eng_note_upload(e, d_out, dst_bytes);
     }
     TRY(eng_wait_upload(e, d_u8, src_bytes, e.stream));

@@ -28,9 +28,17 @@ int rle_encode_launch(const isegmi_rle_args* a, hipStream_t st);
 
 int maskrcnn_det_cap(Engine& e);
 static int det_cap(Engine& e) { return e.kind == 1 ? (int)e.param("max_num_detections", 100) : maskrcnn_det_cap(e); }
-static int rle_cap_chars(Engine& e) { return (int)e.param("rle_cap_chars", 262144.0f * e.max_batch); }
+// Default RLE capacities per image: a blob mask costs ~2 runs per column it spans and ~1.7 characters per run, so K masks as wide as the
+// network canvas need ~4 K W runs; the fixed 256 Ki of round 3 was marginal at 640 px and short at 1500 px with K = 100.  An
+// overflow is not fatal any more (isegmi.pipeline.run_record_loop raises these parameters and redoes the step), this only makes it rare.
+static int64_t rle_cap_default(Engine& e) {
+    const int64_t side = e.H > e.W ? e.H : e.W;
+    const int64_t c = 4ll * det_cap(e) * side;
+    return (c < 262144 ? 262144 : c) * e.max_batch;
+}
+static int rle_cap_chars(Engine& e) { return (int)e.param("rle_cap_chars", (float)(2 * rle_cap_default(e))); }
 static int rle_cap_runs(Engine& e) {
-    int c = (int)e.param("rle_cap_runs", 262144.0f * e.max_batch);
+    int c = (int)e.param("rle_cap_runs", (float)rle_cap_default(e));
     return (c + 1023) / 1024 * 1024;
 }
 

@@ -7,11 +7,8 @@ The record layout is defined once here (pack_records/unpack_records) and produce
 isegmi_yolact_pack_records; the transport is RCCL (GPU) or any callable (gloo in the CPU tests).
 """
 import ctypes as C
-import time as _time
 
 import numpy as np
-
-_T0 = _time.time()  # about when this process started: a rendezvous file much older than that is a crashed run's left-over
 
 from . import _ffi
 
@@ -104,17 +101,24 @@ class CocoRecordError(RuntimeError):
     pass
 
 
-def unpack_coco_records(buf, n, K=K_DEFAULT, kind=2, has_mscore=False, cap_chars=0):
-    """One rank's block -> dict(status, box, count, score, label[, mscore], str_off, chars=bytes).  Raises if the engine flagged an
-    overflow of its RLE capacities (the strings would be incomplete): raise the engine's rle_cap_runs / rle_cap_chars."""
+def unpack_coco_records(buf, n, K=K_DEFAULT, kind=2, has_mscore=False, cap_chars=0, strict=True):
+    """One rank's block -> dict(status, box, count, score, label[, mscore], str_off, chars=bytes, overflow=None).  If the engine flagged an
+    overflow of its RLE capacities (the strings are incomplete): strict raises CocoRecordError; otherwise the dict carries
+    overflow = (bits, runs, characters) -- bit 1: runs over rle_cap_runs (`runs` = what the step needs; characters unknown then), bit 2:
+    characters over rle_cap_chars -- and no strings; isegmi.pipeline.run_record_loop raises the capacities and redoes the step."""
     buf = np.ascontiguousarray(buf, np.uint8).ravel()
     secs, coff, total = coco_record_layout(n, K, kind, has_mscore, cap_chars)
     assert buf.size >= total, (buf.size, total)
     out = {name: buf[off:off + nb].view(dt).reshape(shp) for name, (off, nb, dt, shp) in secs.items()}
     st = out["status"]
+    out["overflow"] = None
     if st[2] != 0:
-        raise CocoRecordError("device RLE overflow (%s): %d runs, %d characters; raise the engine's rle_cap_runs / rle_cap_chars" %
-                              ("runs" if st[2] & 1 else "characters", int(st[0]), int(st[1])))
+        if strict:
+            raise CocoRecordError("device RLE overflow (%s): %d runs, %d characters; raise the engine's rle_cap_runs / rle_cap_chars" %
+                                  ("runs" if st[2] & 1 else "characters", int(st[0]), int(st[1])))
+        out["overflow"] = (int(st[2]), int(st[0]), int(st[1]))
+        out["chars"] = b""
+        return out
     nchars = int(out["str_off"][-1])
     assert nchars == int(st[1]) and nchars <= cap_chars, (nchars, int(st[1]), cap_chars)
     out["chars"] = buf[coff:coff + nchars].tobytes()
@@ -158,6 +162,7 @@ class RcclGather:
         self._c = C.c_void_p()
         uid = C.create_string_buffer(bytes(uid_bytes), 128)
         _ffi.check(_ffi.lib().isegmi_comm_create(uid, rank, world, C.byref(self._c)))
+        notify_launcher("comm %d" % rank)   # `python -m isegmi.launch --init-timeout`: this rank is through ncclCommInitRank
         self.sends = [_ffi.DeviceBuffer((self.nbytes,), np.uint8) for _ in range(self.SLOTS)]
         self.recvs = [_ffi.DeviceBuffer((self.nbytes * world,), np.uint8) for _ in range(self.SLOTS)]
         self.step = 0
@@ -219,6 +224,19 @@ class RcclGather:
         _ffi.check(L.isegmi_comm_allgather_slot(self._c, slot, self.sends[slot].ptr, self.recvs[slot].ptr, C.c_int64(self.nbytes), None))
         self.step += 1
 
+    def allgather_bytes(self, data):
+        """A synchronous control-plane all-gather of `nbytes` host bytes (bench.py's barrier / max-reduce of the wall time: the N > 1 harness
+        needs no second transport): -> [world, nbytes] uint8."""
+        L = _ffi.lib()
+        a = np.frombuffer(bytes(data), np.uint8)
+        assert a.size == self.nbytes, (a.size, self.nbytes)
+        slot = self.step % self.SLOTS
+        _ffi.check(L.isegmi_comm_wait_slot(self._c, slot))
+        self.sends[slot].upload(a)
+        _ffi.check(L.isegmi_comm_allgather_slot(self._c, slot, self.sends[slot].ptr, self.recvs[slot].ptr, C.c_int64(self.nbytes), None))
+        self.step += 1
+        return self.fetch()
+
     def fence_results_stream(self, net):
         """Later work on the engine's results stream waits (on the device) for the most recent gather's slot."""
         st = C.c_void_p()
@@ -227,6 +245,15 @@ class RcclGather:
 
     def wait(self):
         _ffi.check(_ffi.lib().isegmi_comm_wait(self._c))
+
+    def resize(self, per_rank_bytes):
+        """New block size (the record block grew: larger RLE capacities) on the same communicator; every rank calls it at the same step."""
+        self.wait()
+        for b in self.sends + self.recvs:
+            b.free()
+        self.nbytes = int(per_rank_bytes)
+        self.sends = [_ffi.DeviceBuffer((self.nbytes,), np.uint8) for _ in range(self.SLOTS)]
+        self.recvs = [_ffi.DeviceBuffer((self.nbytes * self.world,), np.uint8) for _ in range(self.SLOTS)]
 
     def fetch(self, previous=False):
         assert self.step > (1 if previous else 0), "fetch before gather_from"
@@ -241,49 +268,114 @@ class RcclGather:
 
 
 # ------------------------------------------------------------------------------------------------ rendezvous without torch
-def rendezvous_unique_id(rank, world, make_uid, timeout=120.0):
-    """Ships rank 0's 128-byte RCCL unique id to every rank of ONE node through a file (SURVEY 8e / north_star: the ranks are the GPUs of
-    one node).  The file name comes from the launcher's environment (MASTER_PORT + TORCHELASTIC_RUN_ID, as `python -m
-    torch.distributed.run` and bench.py's own spawner set them), so concurrent jobs do not collide; ISEGMI_RDZV_DIR overrides the
-    directory (default: /dev/shm, else the system temp dir).  Stdlib only: the package does not import torch."""
+def notify_launcher(msg):
+    """One datagram to the parent launcher's watchdog socket (ISEGMI_LAUNCH_NOTIFY = its UDP port), if there is one."""
     import os
-    import tempfile
+    import socket
+    port = os.environ.get("ISEGMI_LAUNCH_NOTIFY")
+    if not port:
+        return
+    try:
+        with socket.socket(socket.AF_INET, socket.SOCK_DGRAM) as sk:
+            sk.sendto(msg.encode(), ("127.0.0.1", int(port)))
+    except OSError:
+        pass
+
+
+_RDZV_SEQ = 0          # rendezvous calls made by this process: every rank makes them in the same order
+_RDZV_PORTS = 32       # rank 0 listens on the first free port of MASTER_PORT + 1 .. MASTER_PORT + _RDZV_PORTS
+
+
+def _rdzv_tag(world, seq):
+    import os
+    run = os.environ.get("TORCHELASTIC_RUN_ID", os.environ.get("ISEGMI_RUN_ID", "0"))
+    return ("ISEGMI-RDZV1 %s %d %d" % (run.replace(" ", "_"), world, seq)).encode()
+
+
+def rendezvous_unique_id(rank, world, make_uid, timeout=120.0):
+    """Ships rank 0's 128-byte RCCL unique id to every rank of ONE node (SURVEY 8e / north_star: the ranks are the GPUs of one node) over a
+    loopback TCP hand-off -- stdlib only (the package does not import torch) and STATELESS: nothing outlives the call, so a run that crashed
+    a moment ago cannot hand a stale id to the next one (round 3's file rendezvous judged a left-over file by its age: VERDICT r3).
+    Rank 0 listens on the first free port of MASTER_PORT + 1 ... + 32 at MASTER_ADDR (MASTER_PORT itself belongs to the launcher: under
+    `python -m torch.distributed.run` the agent's store listens there), the other ranks walk the same ports until a listener answers their
+    hello -- run id (TORCHELASTIC_RUN_ID / ISEGMI_RUN_ID), world size and the per-process call number, so that neither another job on a
+    neighbouring port nor an earlier rendezvous of the same job can be mistaken for this one -- with the id.  Both sides give up after `timeout`."""
+    import os
+    import socket
     import time
+    global _RDZV_SEQ
+    seq = _RDZV_SEQ
+    _RDZV_SEQ += 1
     if world == 1:
         return make_uid()
-    d = os.environ.get("ISEGMI_RDZV_DIR") or ("/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir())
-    tag = "%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", os.environ.get("ISEGMI_RUN_ID", "0")))
-    path = os.path.join(d, "isegmi_uid_%s_%d" % (tag.replace("/", "_"), world))
+    addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    base = int(os.environ.get("MASTER_PORT", "29500"))
+    ports = [base + 1 + k for k in range(_RDZV_PORTS)]
+    hello = _rdzv_tag(world, seq)
+    t0 = time.time()
     if rank == 0:
         uid = make_uid()
-        tmp = path + ".tmp%d" % os.getpid()
-        with open(tmp, "wb") as f:
-            f.write(uid)
-        os.replace(tmp, path)  # atomic: a reader sees all 128 bytes or no file
-        return uid
-    t0 = time.time()
-    while True:
+        assert len(uid) == 128
+        srv = None
+        for port in ports:
+            try:
+                srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                srv.bind((addr, port))
+                break
+            except OSError:
+                srv.close()
+                srv = None
+        if srv is None:
+            raise OSError("rendezvous: no free port in %d..%d at %s" % (ports[0], ports[-1], addr))
         try:
-            if os.path.getmtime(path) >= _T0 - 60.0:  # the launcher starts all ranks together; older = stale (rank 0 replaces it)
-                with open(path, "rb") as f:
-                    uid = f.read()
-                if len(uid) == 128:
-                    return uid
-        except FileNotFoundError:
-            pass
+            srv.listen(world + 8)
+            served = set()
+            while len(served) < world - 1:
+                left = timeout - (time.time() - t0)
+                if left <= 0:
+                    raise TimeoutError("rank 0: %d of %d ranks asked for the RCCL unique id within %.0f s" % (len(served), world - 1, timeout))
+                srv.settimeout(min(left, 1.0))
+                try:
+                    c, _ = srv.accept()
+                except socket.timeout:
+                    continue
+                with c:
+                    c.settimeout(5.0)
+                    try:
+                        msg = c.recv(256)
+                        if msg.startswith(hello + b" ") and msg.endswith(b"\n"):
+                            r = int(msg[len(hello) + 1:-1])
+                            if 0 < r < world:
+                                c.sendall(uid)
+                                served.add(r)
+                    except (OSError, ValueError):
+                        pass           # a stray or foreign connection: closed without an answer, the caller keeps looking
+        finally:
+            srv.close()
+        return uid
+    msg = hello + (" %d\n" % rank).encode()
+    while True:
+        for port in ports:
+            try:
+                with socket.create_connection((addr, port), timeout=1.0) as c:
+                    c.settimeout(5.0)
+                    c.sendall(msg)
+                    uid = b""
+                    while len(uid) < 128:
+                        part = c.recv(128 - len(uid))
+                        if not part:
+                            break
+                        uid += part
+                    if len(uid) == 128:
+                        return uid
+            except OSError:
+                pass
         if time.time() - t0 > timeout:
-            raise TimeoutError("rank %d: no RCCL unique id at %s after %.0f s (is rank 0 alive?)" % (rank, path, timeout))
-        time.sleep(0.01)
+            raise TimeoutError("rank %d: no RCCL unique id from rank 0 at %s:%d..%d after %.0f s (is rank 0 alive?)" % (rank, addr, ports[0], ports[-1], timeout))
+        time.sleep(0.02)
 
 
 def rendezvous_cleanup(rank, world):
-    import os
-    import tempfile
-    if world == 1 or rank != 0:
-        return
-    d = os.environ.get("ISEGMI_RDZV_DIR") or ("/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir())
-    tag = "%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", os.environ.get("ISEGMI_RUN_ID", "0")))
-    try:
-        os.remove(os.path.join(d, "isegmi_uid_%s_%d" % (tag.replace("/", "_"), world)))
-    except OSError:
-        pass
+    """Nothing to clean: the TCP hand-off leaves no state (kept for callers of the round-3 file rendezvous)."""
+    return

@@ -139,7 +139,7 @@ def inference(predictor, images, image_ids=None, batch_size=None, group="canvas"
             one's records are unpacked; 0 = inline."""
     import time
     from .coco import results_from_records
-    from .pipeline import RecordPipeline, make_gather, schedule_batches
+    from .pipeline import record_capacity, run_record_loop, schedule_batches
     from .transforms import get_size
     from .maskrcnn import padded_canvas
     from . import _ffi
@@ -161,15 +161,13 @@ def inference(predictor, images, image_ids=None, batch_size=None, group="canvas"
     else:
         raise ValueError("group: 'canvas' or 'aspect'")
     batches = schedule_batches(keys, bs)
-    gather = make_gather(model, bs, rank, world, force_gather)
-    pipe = RecordPipeline(model, bs, gather)
+    K = record_capacity(model)
     pin = [_ffi.PinnedBuffer((bs * model.H * model.W * 3,), np.uint8) for _ in range(2)]
+    for slot in (0, 1):
+        model._u8_staging(slot, bs * model.H * model.W * 3)   # device staging at its final size: no sync + re-allocation on a larger batch
     per_image = [None] * n_img
 
-    def consume(done):
-        if done is None:
-            return
-        step, recs = done
+    def consume(step, recs):
         for r, rec in enumerate(recs):       # rank r ran batch step * world + r of the global schedule
             j = step * world + r
             if j >= len(batches):
@@ -177,7 +175,7 @@ def inference(predictor, images, image_ids=None, batch_size=None, group="canvas"
             b = batches[j]
             slot_ids = [ids[i] for i in b] + [None] * (bs - len(b))
             slot_hw = [sizes[i] for i in b] + [(1, 1)] * (bs - len(b))
-            res = results_from_records(rec, slot_ids, slot_hw, 2, pipe.K)
+            res = results_from_records(rec, slot_ids, slot_hw, 2, K)
             by_id = {}
             for d in res:
                 by_id.setdefault(d["image_id"], []).append(d)
@@ -197,20 +195,14 @@ def inference(predictor, images, image_ids=None, batch_size=None, group="canvas"
         if j is not None and j < len(batches) and j not in prefetch:
             prefetch[j] = [pool.submit(load, i) for i in batches[j]] if pool else None
 
-    t0 = time.perf_counter()
-    nsteps = -(-len(batches) // world)
-    if mine:
-        request(mine[0])
-    for step in range(nsteps):
+    def enqueue(step, slot):
         j = step * world + rank
         if j >= len(batches):
-            consume(pipe.submit_empty(step))
-            continue
+            return False
         b = batches[j]
         request(j + world)                   # the next batch of this rank resizes on the worker threads meanwhile
-        futs = prefetch.pop(j, None)
+        futs = prefetch.pop(j, None)         # (a step that is redone after an RLE overflow loads its images again, inline)
         resized = [f.result() for f in futs] if futs else [load(i) for i in b]
-        slot = step & 1
         off, hw = 0, []
         for im in resized:                   # into pinned memory, back to back
             pin[slot].array[off:off + im.size] = im.reshape(-1)
@@ -221,19 +213,21 @@ def inference(predictor, images, image_ids=None, batch_size=None, group="canvas"
         oh = [sizes[i] for i in b]
         model.paste_device(max(h for h, _ in oh), max(w for _, w in oh), [(w, h) for h, w in oh])
         model.rle_device(oh)
-        consume(pipe.submit(step))
-    for done in pipe.flush():
-        consume(done)
-    model.sync()
-    if pool:
-        pool.shutdown()
+        return True
+
+    t0 = time.perf_counter()
+    nsteps = -(-len(batches) // world)
+    try:
+        if mine:
+            request(mine[0])
+        # every way out of the loop -- a bad image, an RLE overflow that does not settle, a ctypes error -- restores the engine (whole mask planes
+        # again: `sparse_masks`), frees the pinned buffers, stops the worker threads and closes the gather (run_record_loop's own finally)
+        run_record_loop(model, bs, nsteps, enqueue, consume, rank, world, force_gather)
+    finally:
+        if pool:
+            pool.shutdown(wait=True, cancel_futures=True)
+        for p in pin:
+            p.free()
     if stats is not None:
         stats.update(steps=nsteps, images=n_img, seconds=time.perf_counter() - t0, batches=len(batches), batch_size=bs, world=world)
-    pipe.close()
-    for p in pin:
-        p.free()
-    if gather is not None:
-        from .dist import rendezvous_cleanup
-        gather.close()
-        rendezvous_cleanup(rank, world)
     return [d for r in per_image if r for d in r]

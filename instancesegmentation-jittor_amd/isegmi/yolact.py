@@ -486,7 +486,7 @@ def evaluate(net, images, image_ids=None, batch_size=None, score_threshold=0.0, 
     images: sequence of HxWx3 uint8 BGR arrays, or a callable i -> array together with sizes = [(h, w), ...]."""
     import time
     from .coco import results_from_records
-    from .pipeline import RecordPipeline, make_gather
+    from .pipeline import record_capacity, run_record_loop
     get = images if callable(images) else images.__getitem__
     if sizes is None:
         if callable(images):
@@ -497,38 +497,32 @@ def evaluate(net, images, image_ids=None, batch_size=None, score_threshold=0.0, 
     bs = int(batch_size or net.max_batch)
     assert bs <= net.max_batch
     batches = [list(range(j, min(j + bs, n_img))) for j in range(0, n_img, bs)]
-    gather = make_gather(net, bs, rank, world, force_gather)
-    pipe = RecordPipeline(net, bs, gather)
+    K = record_capacity(net)
     pin_bytes = max(sum(sizes[i][0] * sizes[i][1] * 3 for i in b) for b in batches) if batches else 1
     pin = [_ffi.PinnedBuffer((pin_bytes,), np.uint8) for _ in range(2)]
+    for slot in (0, 1):
+        net._u8_staging(slot, pin_bytes)   # both device staging buffers at their final size: no sync + re-allocation when a later batch is larger
     per_image = [None] * n_img
 
-    def consume(done):
-        if done is None:
-            return
-        step, recs = done
+    def consume(step, recs):
         for r, rec in enumerate(recs):
             j = step * world + r
             if j >= len(batches):
                 continue
             b = batches[j]
             res = results_from_records(rec, [ids[i] for i in b] + [None] * (bs - len(b)), [sizes[i] for i in b] + [(1, 1)] * (bs - len(b)), 1,
-                                       pipe.K, score_threshold, top_k)
+                                       K, score_threshold, top_k)
             by_id = {}
             for d in res:
                 by_id.setdefault(d["image_id"], []).append(d)
             for i in b:
                 per_image[i] = by_id.get(ids[i], [])
 
-    t0 = time.perf_counter()
-    nsteps = -(-len(batches) // world)
-    for step in range(nsteps):
+    def enqueue(step, slot):
         j = step * world + rank
         if j >= len(batches):
-            consume(pipe.submit_empty(step))
-            continue
+            return False
         b = batches[j]
-        slot = step & 1
         off = 0
         for i in b:
             im = np.ascontiguousarray(get(i), np.uint8)
@@ -539,17 +533,15 @@ def evaluate(net, images, image_ids=None, batch_size=None, score_threshold=0.0, 
         net.forward_device(len(b), slot)
         net.postprocess_device_sizes(hw)
         net.rle_device(hw)
-        consume(pipe.submit(step))
-    for done in pipe.flush():
-        consume(done)
-    net.sync()
+        return True
+
+    t0 = time.perf_counter()
+    nsteps = -(-len(batches) // world)
+    try:
+        run_record_loop(net, bs, nsteps, enqueue, consume, rank, world, force_gather)   # closes its pipeline / gather on every way out
+    finally:
+        for p in pin:
+            p.free()
     if stats is not None:
         stats.update(steps=nsteps, images=n_img, seconds=time.perf_counter() - t0, batches=len(batches), batch_size=bs, world=world)
-    pipe.close()
-    for p in pin:
-        p.free()
-    if gather is not None:
-        from .dist import rendezvous_cleanup
-        gather.close()
-        rendezvous_cleanup(rank, world)
     return [d for r in per_image if r for d in r]

@@ -129,9 +129,11 @@ json.dump(res, open(out + ".%d" % rank, "w"))
 
 
 def test_two_ranks_share_one_gpu_through_rccl(ffi, tmp_path):
-    """SURVEY 8(e) on the hardware at hand: TWO processes (ranks 0 and 1 of a world of 2, file rendezvous, no torch) run the sharded
-    inference() on the ONE visible GPU and all-gather their record blocks through RCCL; both must end with the complete result list, equal to
-    the single-rank run.  (A real multi-GPU node is the driver's; RCCL builds that refuse two ranks on one device make this a skip.)"""
+    """SURVEY 8(e) on the hardware at hand: TWO processes (ranks 0 and 1 of a world of 2, started by `python -m isegmi.launch`, TCP rendezvous, no
+    torch) run the sharded inference() on the ONE visible GPU and all-gather their record blocks through RCCL; both must end with the complete
+    result list, equal to the single-rank run.  An RCCL build that REFUSES two ranks on one device (its own error text) makes this a skip;
+    anything else -- a wrong result, a crash, ranks that never get their communicator (the launcher's watchdog: exit 125) or never finish
+    (exit 124) -- is a failure with both ranks' output attached (a time-out used to be recorded as a skip)."""
     import json
     import subprocess
     import sys
@@ -142,26 +144,18 @@ def test_two_ranks_share_one_gpu_through_rccl(ffi, tmp_path):
     script = tmp_path / "w.py"
     script.write_text(_TWO_RANK_WORKER)
     out = str(tmp_path / "res")
-    procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_PORT="29777", ISEGMI_RUN_ID="t2r%d" % os.getpid(),
-                   ISEGMI_RDZV_DIR=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG="WARN")
-        procs.append(subprocess.Popen([sys.executable, str(script), root, out], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
-    logs = []
-    for p in procs:
-        try:
-            o, _ = p.communicate(timeout=240)
-        except subprocess.TimeoutExpired:
-            for q in procs:
-                q.kill()
-            pytest.skip("two ranks on one device did not finish (RCCL duplicate-device bring-up hangs on this build)")
-        logs.append(o.decode(errors="replace"))
-    if any(p.returncode != 0 for p in procs):
-        msg = "\n".join(l[-600:] for l in logs)
-        if "uplicate" in msg or "invalid usage" in msg.lower() or "ncclCommInitRank" in msg:
-            pytest.skip("this RCCL refuses two ranks on one device: " + msg[-300:])
-        pytest.fail(msg)
-    got = [json.load(open(out + ".%d" % r)) for r in range(2)]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG="WARN", PYTHONPATH=os.path.join(root, "instancesegmentation-jittor_amd"))
+    r = subprocess.run([sys.executable, "-m", "isegmi.launch", "--nproc", "2", "--timeout", "240", "--init-timeout", "120", str(script), root, out],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=400)
+    log = r.stdout.decode(errors="replace")
+    if r.returncode != 0:
+        refused = ("uplicate GPU" in log) or ("invalid usage" in log.lower()) or any(
+            os.path.exists(out + ".err%d" % k) and ("invalid usage" in open(out + ".err%d" % k).read().lower() or "ncclCommInitRank" in open(out + ".err%d" % k).read())
+            for k in range(2))
+        if refused and r.returncode not in (124, 125):
+            pytest.skip("this RCCL refuses two ranks on one device: " + log[-300:])
+        pytest.fail("two-rank run failed (rc %d; 124 = time limit, 125 = no communicator within the watchdog's limit):\n%s" % (r.returncode, log[-3000:]))
+    got = [json.load(open(out + ".%d" % k)) for k in range(2)]
     rng = np.random.default_rng(11)
     images = [rng.integers(0, 256, s + (3,)).astype(np.uint8) for s in [(150, 200), (200, 150), (150, 200), (120, 200), (150, 200)]]
     demo = COCODemo(None, min_image_size=160, confidence_threshold=0.0, state_dict=maskrcnn_state_dict(1234), max_image_size=288, max_batch=2)
@@ -170,23 +164,31 @@ def test_two_ranks_share_one_gpu_through_rccl(ffi, tmp_path):
     assert got[0] == got[1] == json.loads(json.dumps(want)) and len(want) > 20
 
 
+@pytest.mark.parametrize("launcher", ["isegmi.launch", "env"])
 @pytest.mark.parametrize("model_args", [["--no-maskrcnn"], ["--model", "maskrcnn"]])
-def test_bench_multi_rank_code_path_on_one_gpu(ffi, model_args):
-    """bench.py exactly as the driver launches it for N > 1 (`python -m torch.distributed.run ... bench.py --gpus N`), with one rank and
-    ISEGMI_BENCH_FORCE_DIST=1 so that the whole N > 1 code path runs on the one GPU at hand: gloo rendezvous, two RCCL communicators (the
-    raw-record gather inside `value`, the COCO-record gather inside `value_e2e`), barrier + max-reduce around the timed regions, ONE JSON line."""
+def test_bench_multi_rank_code_path_on_one_gpu(ffi, model_args, launcher):
+    """bench.py's N > 1 code path on the one GPU at hand (one rank, ISEGMI_BENCH_FORCE_DIST=1): started by the package's launcher (what
+    `bench.py --gpus N` from a plain shell does) and from a bare rank environment (RANK / WORLD_SIZE / MASTER_*: what the driver's
+    `python -m torch.distributed.run` hands every rank) -- TCP rendezvous, three RCCL communicators (the 8-byte control gather behind barrier
+    and MAX, the raw-record gather inside `value`, the COCO-record gather inside `value_e2e`), ONE JSON line; bench.py imports no torch."""
     import json
     import os
+    import re
     import socket
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert not re.search(r"^\s*(import|from)\s+torch", open(os.path.join(root, "bench.py")).read(), re.M)
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-latency"] + model_args
-    env = dict(os.environ, ISEGMI_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    args = [os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-latency"] + model_args
+    env = dict(os.environ, ISEGMI_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=os.path.join(root, "instancesegmentation-jittor_amd"))
+    if launcher == "isegmi.launch":
+        cmd = [sys.executable, "-m", "isegmi.launch", "--nproc", "1", "--timeout", "500", "--init-timeout", "200"] + args
+    else:
+        cmd = [sys.executable] + args
+        env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TORCHELASTIC_RUN_ID="t")
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

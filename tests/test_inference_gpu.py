@@ -165,6 +165,58 @@ def test_yolact_evaluate_matches_host_path(ffi):
     net.close()
 
 
+def test_rle_overflow_is_redone_not_fatal(ffi, sd):
+    """one batch whose run lengths overflow the engine's RLE capacities used to abort the whole evaluation (and leave the other
+    ranks in the all-gather).  With the capacities forced far too small -- runs AND characters, so that it takes more than one round of
+    growth -- inference() / evaluate() raise them, redo the steps that overflowed and return exactly what the un-capped run returns; one
+    rank and through RCCL (all ranks read every rank's status from the gathered blocks and grow in step)."""
+    import dataclasses
+    from isegmi.predictor import COCODemo, inference
+    from isegmi.weights import yolact_state_dict
+    from isegmi.yolact import Yolact, YolactConfig, evaluate
+    rng = np.random.default_rng(5)
+    images = _images(rng, [(150, 200), (200, 150), (120, 200), (150, 200), (200, 140)])
+    demo = COCODemo(None, min_image_size=160, confidence_threshold=0.0, state_dict=sd, max_image_size=288, max_batch=2)
+    want = inference(demo, images, batch_size=2)
+    model = demo.engine(2)
+    for force in (False, True):
+        model.set_param("rle_cap_runs", 1024.0); model.set_param("rle_cap_chars", 512.0)
+        _same(inference(demo, images, batch_size=2, force_gather=force), want)
+        assert model.coco_record_bytes(2)[0] > 512 + 4096      # the capacities have grown and stay grown
+    demo.close()
+    yimgs = [rng.integers(0, 256, (h, w, 3)).astype(np.uint8) for h, w in [(240, 320), (200, 260), (320, 240), (240, 320)]]
+    net = Yolact(yolact_state_dict(1234), dataclasses.replace(YolactConfig(), nms_conf_thresh=0.0), max_batch=2, input_size=200)
+    ywant = evaluate(net, yimgs, batch_size=2, top_k=20)
+    net.set_param("rle_cap_runs", 1024.0); net.set_param("rle_cap_chars", 256.0)
+    _same(evaluate(net, yimgs, batch_size=2, top_k=20), ywant)
+    net.close()
+
+
+def test_exception_inside_inference_leaves_the_engine_usable(ffi, sd):
+    """VERDICT r3 / ADVICE r3: an exception in the middle of inference() (here: an image that fails to load) used to leave `sparse_masks` set on
+    the predictor's persistent engine, and the next compute_prediction() on it returned masks whose background was never written.  Now the
+    pipeline is closed on every way out: the same engine's single-image prediction equals a fresh predictor's, mask planes included."""
+    from isegmi.predictor import COCODemo, inference
+    rng = np.random.default_rng(17)
+    images = _images(rng, [(150, 200), (150, 200), (150, 200), (150, 200), (150, 200), (150, 200)])
+    demo = COCODemo(None, min_image_size=160, confidence_threshold=0.0, state_dict=sd, max_image_size=288, max_batch=2)
+
+    def loader(i):
+        if i == 4:
+            raise IOError("cannot read image 4")
+        return images[i]
+    with pytest.raises(IOError):
+        inference(demo, loader, sizes=[im.shape[:2] for im in images], batch_size=2, workers=0)
+    got = demo.compute_prediction(images[1])
+    fresh = COCODemo(None, min_image_size=160, confidence_threshold=0.0, state_dict=sd, max_image_size=288, max_batch=2)
+    want = fresh.compute_prediction(images[1])
+    assert len(got) == len(want) > 0 and np.array_equal(got.bbox, want.bbox)
+    assert np.array_equal(got.get_field("mask"), want.get_field("mask"))
+    # and a whole inference() afterwards is what it is on the fresh predictor
+    _same(inference(demo, images, batch_size=2), inference(fresh, images, batch_size=2))
+    demo.close(); fresh.close()
+
+
 def test_record_pipeline_empty_step_between_full_ones(ffi):
     """A rank's EMPTY step (several ranks, image list not divisible: an all-zero block goes into the all-gather on the communicator's own
     stream, and the asynchronous download behind it is fenced on the device) between two full steps of the same batch, through RCCL with a

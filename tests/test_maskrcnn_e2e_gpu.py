@@ -421,6 +421,35 @@ def test_maskrcnn_hipgraph_replay_matches_eager(ffi, sd):
     model.close()
 
 
+def test_maskrcnn_hipgraph_survives_buffer_growth(ffi, sd):
+    """graph = 1 on an engine whose buffers GROW: three forwards on a small canvas (eager, capture, replay), three on the engine's full canvas
+    (every activation buffer, the liveness-aliased res<l>.* ones included, is re-allocated), then the small canvas again -- whose captured
+    graph would replay onto freed device memory if the re-allocation did not drop it.  Every result equals the eager engine's."""
+    from isegmi.maskrcnn import MaskRCNN, prepare_images
+    rng = np.random.default_rng(31)
+    xs, hws = prepare_images([rng.uniform(0, 255, (120, 150, 3)).astype(np.float32)])
+    xl, hwl = prepare_images([rng.uniform(0, 255, (250, 340, 3)).astype(np.float32)])
+    assert xs.shape[1] < xl.shape[1] and xs.shape[2] < xl.shape[2]
+    keys = ("proposal_count", "det.count", "det.box", "det.score", "det.label", "det.mask28")
+
+    def run(model, x, hw):
+        model.upload(x, hw); model.forward_device(1); model.sync()
+        return {k: model.fetch(k, 1) for k in keys}
+    eager = MaskRCNN(sd, xl.shape[1], xl.shape[2], max_batch=1)
+    want_s, want_l = run(eager, xs, hws), run(eager, xl, hwl)
+    eager.close()
+    model = MaskRCNN(sd, xl.shape[1], xl.shape[2], max_batch=1)
+    model.set_param("graph", 1.0)
+    for x, hw, want, reps in ((xs, hws, want_s, 3), (xl, hwl, want_l, 3), (xs, hws, want_s, 3)):
+        for rep in range(reps):
+            got = run(model, x, hw)
+            n = int(want["det.count"][0])
+            assert np.array_equal(got["det.count"], want["det.count"]) and np.array_equal(got["proposal_count"], want["proposal_count"])
+            for k in ("det.box", "det.score", "det.label", "det.mask28"):
+                assert np.array_equal(got[k][0, :n], want[k][0, :n]), (x.shape, rep, k)
+    model.close()
+
+
 def test_maskrcnn_c4_bit_exact(ffi):
     """e2e_mask_rcnn_R_50_C4_1x (the yaml README.md:263-273 prints): single stride-16 map, 15 anchors, PRE_NMS_TOP_N_TEST 6000,
     ROIAlign with adaptive sampling, conv5 head shared by the box and mask branches, 14x14 masks, Masker paste."""

@@ -93,35 +93,87 @@ def test_schedule_batches_is_the_grouped_batch_sampler():
     assert sorted(i for x in b for i in x) == list(range(20)) and all(len({i % 3 for i in x}) == 1 for x in b) and [x[0] for x in b] == sorted(x[0] for x in b)
 
 
-def _rdzv_rank(rank, world, d, q):
-    os.environ.update(ISEGMI_RDZV_DIR=d, MASTER_PORT="4711", TORCHELASTIC_RUN_ID="t")
-    from isegmi.dist import rendezvous_cleanup, rendezvous_unique_id
-    uid = rendezvous_unique_id(rank, world, lambda: bytes(range(128)), timeout=30.0)
-    q.put((rank, uid))
-    if rank == 0:
-        import time
-        time.sleep(0.5)
-        rendezvous_cleanup(rank, world)
+def _rdzv_rank(rank, world, port, q, calls=1):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ISEGMI_RUN_ID="t")
+    from isegmi.dist import rendezvous_unique_id
+    for c in range(calls):
+        uid = rendezvous_unique_id(rank, world, lambda c=c: bytes([c]) + bytes(range(1, 128)), timeout=30.0)
+        q.put((rank, c, uid))
 
 
-def test_rendezvous_without_torch(tmp_path):
-    """rank 0's 128-byte id reaches the other ranks through the file rendezvous; a stale file of a crashed run is not taken"""
-    stale = tmp_path / "isegmi_uid_4711_t_3"
-    stale.write_bytes(b"\\xff" * 128)
-    os.utime(stale, (1, 1))
+def _free_port_base():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def test_rendezvous_without_torch():
+    """rank 0's 128-byte id reaches the other ranks over the loopback TCP hand-off, whichever side starts first, and TWICE in a row (a job makes
+    one rendezvous per communicator: the call number in the hello keeps a fast rank's second call from being answered by rank 0's first)"""
+    port = _free_port_base()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    ps = [ctx.Process(target=_rdzv_rank, args=(r, 3, str(tmp_path), q)) for r in (1, 2, 0)]
+    ps = [ctx.Process(target=_rdzv_rank, args=(r, 3, port, q, 2)) for r in (1, 2, 0)]
     for p in ps[:2]:
         p.start()
     import time
     time.sleep(0.3)
     ps[2].start()
-    got = dict(q.get(timeout=60) for _ in range(3))
+    got = [q.get(timeout=60) for _ in range(6)]
     for p in ps:
         p.join(30)
-    assert all(got[r] == bytes(range(128)) for r in range(3))
-    assert not stale.exists()
+    assert sorted((r, c) for r, c, _ in got) == [(r, c) for r in range(3) for c in range(2)]
+    assert all(uid == bytes([c]) + bytes(range(1, 128)) for _, c, uid in got)
+
+
+def _stale_listener(port, q):
+    """what a crashed earlier run could leave behind for a while: a live listener on the first rendezvous port that answers a DIFFERENT job's hello"""
+    import socket
+    srv = socket.socket()
+    srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    srv.bind(("127.0.0.1", port + 1))
+    srv.listen(8)
+    srv.settimeout(20)
+    q.put("up")
+    try:
+        while True:
+            c, _ = srv.accept()
+            with c:
+                msg = c.recv(256)
+                if b" stale-run " in msg:      # only ranks of ITS run get its id
+                    c.sendall(b"\xee" * 128)
+    except OSError:
+        pass
+
+
+def test_rendezvous_ignores_a_fresh_stale_peer():
+    """the file rendezvous accepted a < 60 s old left-over of a crashed run.  The TCP hand-off holds no state: a listener of
+    another (crashed, still dying) run on the first rendezvous port is asked, does not know this run's hello, and is passed over -- rank 0 of
+    THIS run binds the next port and its id is the one every rank gets."""
+    port = _free_port_base()
+    ctx = mp.get_context("spawn")
+    q0 = ctx.Queue()
+    stale = ctx.Process(target=_stale_listener, args=(port, q0))
+    stale.start()
+    assert q0.get(timeout=30) == "up"
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_rdzv_rank, args=(r, 2, port, q)) for r in (1, 0)]
+    for p in ps:
+        p.start()
+    got = [q.get(timeout=60) for _ in range(2)]
+    for p in ps:
+        p.join(30)
+    stale.terminate()
+    stale.join(10)
+    assert all(uid == bytes([0]) + bytes(range(1, 128)) for _, _, uid in got)
+
+
+def test_rendezvous_times_out_without_rank0():
+    from isegmi import dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port_base()), ISEGMI_RUN_ID="nobody")
+    with pytest.raises(TimeoutError):
+        dist.rendezvous_unique_id(1, 2, lambda: b"\0" * 128, timeout=1.0)
 
 
 def test_package_imports_no_torch_and_no_oracle():
@@ -135,19 +187,25 @@ def test_package_imports_no_torch_and_no_oracle():
 
 
 def test_launcher_sets_rank_environment_and_propagates_failure(tmp_path):
-    """python -m isegmi.launch --nproc N ...: N fresh processes with the RANK / WORLD_SIZE environment, the file rendezvous works between
-    them, a failing rank takes the group down and its code is the launcher's"""
+    """python -m isegmi.launch --nproc N ...: N fresh processes with the RANK / WORLD_SIZE environment, the TCP rendezvous works between
+    them, a failing rank takes the group down and its code is the launcher's; --init-timeout kills a group whose ranks never report a
+    communicator (what a hung ncclCommInitRank looks like from outside) with code 125"""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     pkg = os.path.join(root, "instancesegmentation-jittor_amd")
     w = tmp_path / "w.py"
-    w.write_text("import os, sys\nsys.path.insert(0, %r)\nfrom isegmi.dist import rendezvous_unique_id, rendezvous_cleanup\n"
+    w.write_text("import os, sys\nsys.path.insert(0, %r)\nfrom isegmi.dist import rendezvous_unique_id, notify_launcher\n"
                  "r, n = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])\nuid = rendezvous_unique_id(r, n, lambda: bytes([7]) * 128, timeout=30)\n"
-                 "open(os.path.join(%r, 'ok%%d' %% r), 'wb').write(uid)\nimport time; time.sleep(0.3); rendezvous_cleanup(r, n)\n"
-                 "sys.exit(3 if (r == 1 and len(sys.argv) > 1) else 0)\n" % (pkg, str(tmp_path)))
-    env = dict(os.environ, PYTHONPATH=pkg, ISEGMI_RDZV_DIR=str(tmp_path))
-    r = subprocess.run([sys.executable, "-m", "isegmi.launch", "--nproc", "3", str(w)], env=env, timeout=120)
+                 "open(os.path.join(%r, 'ok%%d' %% r), 'wb').write(uid)\n"
+                 "mode = sys.argv[1] if len(sys.argv) > 1 else ''\n"
+                 "if mode == 'hang':\n    import time; time.sleep(60)\n"
+                 "notify_launcher('comm %%d' %% r)\nimport time; time.sleep(0.3)\n"
+                 "sys.exit(3 if (r == 1 and mode == 'fail') else 0)\n" % (pkg, str(tmp_path)))
+    env = dict(os.environ, PYTHONPATH=pkg)
+    r = subprocess.run([sys.executable, "-m", "isegmi.launch", "--nproc", "3", "--init-timeout", "60", str(w)], env=env, timeout=120)
     assert r.returncode == 0 and all((tmp_path / ("ok%d" % i)).read_bytes() == bytes([7]) * 128 for i in range(3))
     r = subprocess.run([sys.executable, "-m", "isegmi.launch", "--nproc", "2", str(w), "fail"], env=env, timeout=120)
     assert r.returncode == 3
+    r = subprocess.run([sys.executable, "-m", "isegmi.launch", "--nproc", "2", "--init-timeout", "3", str(w), "hang"], env=env, timeout=120)
+    assert r.returncode == 125
