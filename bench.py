@@ -38,12 +38,12 @@ import numpy as np  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32-input MFMA peak (spec)
 PEAK_F16_MFMA_TFLOPS = 2500.0  # dense f16 MFMA peak (spec, no sparsity)
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
 
 
 def pmc_traffic(name):
     """HBM bytes per conv launch from the committed PMC summary (tools/pmc_summary.py), or None."""
-    for rnd in (PROFILE_ROUND, "r02", "r01"):
+    for rnd in (PROFILE_ROUND, "r03", "r02", "r01"):
         try:
             with open(os.path.join(ROOT, "profiles", "%s_%s" % (rnd, name))) as f:
                 return json.load(f)["conv_mfma_kernel_all"]["hbm_bytes_per_launch"], "%s_%s" % (rnd, name)
@@ -205,21 +205,86 @@ def timed_region(net, step, full_sync, dist, steps):
     return elapsed, st
 
 
+PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec; ~6.3 TB/s measured with a float4 copy)
+
+
+def op_stats(net):
+    """(label, us, algorithmic bytes, timed scopes) of the HBM-bound stages accumulated under `op_timing` since the last call."""
+    from isegmi import _ffi
+    cap = 64
+    names = C.create_string_buffer(16384)
+    us, by, ln, cnt = (C.c_double * cap)(), (C.c_double * cap)(), (C.c_int64 * cap)(), C.c_int()
+    _ffi.check(_ffi.lib().isegmi_engine_op_stats(net._h, names, 16384, us, by, ln, cap, C.byref(cnt)))
+    labels = names.value.decode().split("\n") if cnt.value else []
+    return [(labels[i], float(us[i]), float(by[i]), int(ln[i])) for i in range(cnt.value)]
+
+
+def hbm_rooflines(ops, steps, traffic=None):
+    """SURVEY 8(d) "Bounding roofline per stage": the HBM-bound stages as {kernel, bytes, us, frac} per step -- achieved = algorithmic bytes /
+    HIP-event time, against the 8 TB/s HBM peak; `traffic` = counter bytes (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE) from the committed PMC pass."""
+    out = []
+    for label, us, by, ln in sorted(ops, key=lambda t: -t[1]):
+        if us <= 0:
+            continue
+        gbs = by / us / 1e3 if by > 0 else None
+        out.append({"kernel": label, "bytes": int(by / max(steps, 1)), "us": round(us / max(steps, 1), 2), "launches": ln // max(steps, 1),
+                    "achieved": None if gbs is None else round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": None if gbs is None else round(gbs / PEAK_HBM_GBS, 4),
+                    "traffic": (traffic or {}).get(label)})
+    return out
+
+
 def roofline_pass(net, step, full_sync, steps, single_stream):
     """The same K steps again, single-stream, every conv launch bracketed by HIP events on the engine stream (per-launch
-    durations are not meaningful while launches from several streams overlap)."""
+    durations are not meaningful while launches from several streams overlap); the HBM-bound stages are bracketed the same way.
+    -> (conv FLOPs, conv ms, conv launches, [(stage label, us, algorithmic bytes, scopes)])"""
     from isegmi import _ffi
     f, m, l = C.c_double(), C.c_double(), C.c_int64()
     net.set_param("multi_stream", 0.0)
     net.set_param("conv_timing", 1.0)
+    net.set_param("op_timing", 1.0)
     _ffi.check(_ffi.lib().isegmi_engine_conv_stats(net._h, C.byref(f), C.byref(m), C.byref(l)))  # reset
+    op_stats(net)
     for i in range(steps):
         step(i)
     full_sync()
     _ffi.check(_ffi.lib().isegmi_engine_conv_stats(net._h, C.byref(f), C.byref(m), C.byref(l)))
+    ops = op_stats(net)
     net.set_param("conv_timing", 0.0)
+    net.set_param("op_timing", 0.0)
     net.set_param("multi_stream", 0.0 if single_stream else 1.0)
-    return f.value, m.value, l.value
+    return f.value, m.value, l.value, ops
+
+
+def rle_roofline(net, run_once, full_sync, batch, K, single_stream, reps=5):
+    """The RLE chain (csrc/rle.hip) as an HBM-bound stage: HIP-event time of the seven launches; algorithmic bytes = every valid mask's box
+    WINDOW of its uint8 plane read once (1 B per pixel; the windows are data: taken from det.mask_window after the pass) + 8 B per 64 window
+    pixels of run-start words written and read back."""
+    net.set_param("multi_stream", 0.0)   # (one stream: a stage's events must not bracket another stream's kernels)
+    net.set_param("op_timing", 1.0)
+    op_stats(net)
+    for _ in range(reps):
+        run_once()
+    full_sync()
+    allops = op_stats(net)
+    ops = [o for o in allops if o[0].startswith("rle")]
+    front = [o for o in allops if o[0].startswith("front end")]
+    net.set_param("op_timing", 0.0)
+    net.set_param("multi_stream", 0.0 if single_stream else 1.0)
+    if not ops:
+        return []
+    win, cn = net.fetch("det.mask_window", batch).reshape(batch, -1, 4).astype(np.int64), net.fetch("det.count", batch)
+    px = sum(int(max(0, w[2] - w[0]) * max(0, w[3] - w[1])) for i in range(batch) for w in win[i, :int(cn[i])])
+    label, us, _, ln = ops[0]
+    return [(label, us, (px + px / 64.0 * 16.0) * reps, ln)] + front
+
+
+def hbm_traffic(name):
+    """counter bytes per HBM-bound stage from the committed PMC summary (tools/hbm_kernel_traffic.py), or None"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "%s_%s" % (PROFILE_ROUND, name))) as f:
+            return json.load(f)
+    except Exception:
+        return None
 
 
 def e2e_region(net, pipe, upload, run_rle, full_sync, dist, steps):
@@ -329,14 +394,14 @@ def bench_yolact(a, dist):
     elapsed, step_ms = timed_region(net, step, full_sync, dist, a.steps)
     # what the GPU produced for the bench batch through the timed path (device front end + forward + postprocess); compared with the oracle below
     net.upload(imgs)
-    conv_flops, conv_ms, conv_launches = roofline_pass(net, step_resident, full_sync, a.steps, a.single_stream)
+    conv_flops, conv_ms, conv_launches, ops = roofline_pass(net, step_resident, full_sync, a.steps, a.single_stream)
     gpu = {k: net.fetch(k, a.batch) for k in ("det.count", "det.prior", "det.class", "det.score", "det.box", "det.coeff", "det.masks", "det.box_int")}
     rccl = None
     if gather is not None:
         from isegmi.dist import unpack_records
         blocks = gather.fetch()
         rccl = {"rccl_ranks": int(gather.world), "ranks_with_records": int(sum(1 for r in range(world) if unpack_records(blocks[r], a.batch)["count"].any()))}
-    resident_elapsed = h2d_elapsed = e2e = None
+    resident_elapsed = h2d_elapsed = e2e = rle_op = None
     if not a.no_h2d:
         resident_elapsed, _ = timed_region(net, step_resident, full_sync, dist, a.steps)
         pinned = _ffi.PinnedBuffer(imgs.shape)
@@ -363,7 +428,8 @@ def bench_yolact(a, dist):
             e2e = {"elapsed": e2e_elapsed, "blocks": blocks, "chars_per_step": chars / max(blocks, 1), "record_bytes": pipe.nbytes}
             K = pipe.K
         # the strings the device made for the bench batch, against the host encoder on the uint8 planes (rank 0, after the timed loops)
-        net.upload(imgs); net.forward_device(a.batch); net.postprocess_device(size, size); net.rle_device(); full_sync()
+        net.upload(imgs)
+        rle_op = rle_roofline(net, lambda: (upload_u8(0), net.forward_device(a.batch), net.postprocess_device(size, size), net.rle_device()), full_sync, a.batch, K, a.single_stream)
         from isegmi.coco import rle_counts, rle_to_string
         so, ch = net.fetch("rle.str_off"), net.fetch("rle.chars").tobytes()
         mk, cn = net.fetch("det.masks", a.batch), net.fetch("det.count", a.batch)
@@ -416,8 +482,19 @@ def bench_yolact(a, dist):
                                   " / all-gathered over RCCL" if gather is not None else "", int(a.batch * 100 * size * size / 1e6))}
     if rccl:
         out.update(rccl)
+    hbm = hbm_rooflines(ops, a.steps, hbm_traffic("hbm_stage_traffic_yolact.json") if (a.yolact_config == "resnet50" and not a.fp16) else None)
+    if rle_op:
+        hbm += hbm_rooflines(rle_op, 5)
+    out["roofline_hbm"] = hbm
+    out["roofline_hbm_note"] = ("SURVEY 8(d) HBM-bound stages, per step of %d images, in the single-stream pass of `roofline`: achieved = ALGORITHMIC bytes (each "
+                                "stage's compulsory reads + writes, SURVEY 8d) / HIP-event time on the launching stream; peak 8 TB/s (spec); frac well under 1 on a "
+                                "latency-bound selection stage says its grid is small, not that it moves many bytes" % a.batch)
     if not a.no_latency:
         out["bs1"] = latency_pass(net, lambda: (net.forward_device(1), net.postprocess_device(size, size)))
+        f1, m1, l1, _ = roofline_pass(net, lambda i: (net.forward_device(1), net.postprocess_device(size, size)), full_sync, 10, a.single_stream)
+        out["bs1"]["roofline"] = {"bound": "mfma", "achieved": round(f1 / (m1 * 1e-3) / 1e12, 2) if m1 > 0 else 0.0, "peak": ypeak, "unit": "TFLOP/s",
+                                  "frac": round(f1 / (m1 * 1e-3) / 1e12 / ypeak, 4) if m1 > 0 else 0.0, "conv_ms_per_image": round(m1 / 10, 3),
+                                  "pass": "10 single-stream bs=1 steps, HIP events around every conv launch"}
         net.set_param("timing", 1.0)
         net.forward_device(a.batch); net.postprocess_device(size, size); net.sync()
         out["stage_ms_bs%d" % a.batch] = {k: round(v, 3) for k, v in net.timings()}
@@ -534,7 +611,7 @@ def bench_maskrcnn(a, dist, summary=False):
     upload_u8(0)
     elapsed, step_ms = timed_region(model, step, full_sync, dist, steps)
     model.upload(x, hw)
-    flops, ms, launches = roofline_pass(model, step_resident, full_sync, steps, a.single_stream)
+    flops, ms, launches, ops = roofline_pass(model, step_resident, full_sync, steps, a.single_stream)
     names = ("det.count", "det.score", "det.label", "det.box", "det.mask14" if c4 else "det.mask28", "det.masks", "proposal_count", "proposals")
     gpu = {k: model.fetch(k, batch) for k in names}
     rccl = None
@@ -542,7 +619,7 @@ def bench_maskrcnn(a, dist, summary=False):
         from isegmi.dist import unpack_maskrcnn_records
         blocks = gather.fetch()
         rccl = {"rccl_ranks": int(gather.world), "ranks_with_records": int(sum(1 for r in range(world) if unpack_maskrcnn_records(blocks[r], batch, M=14 if c4 else 28)["count"].any()))}
-    resident_elapsed = h2d_elapsed = e2e = None
+    resident_elapsed = h2d_elapsed = e2e = rle_op = None
     if not a.no_h2d:
         resident_elapsed, _ = timed_region(model, step_resident, full_sync, dist, steps)
         pinned = _ffi.PinnedBuffer(x.shape)
@@ -568,7 +645,8 @@ def bench_maskrcnn(a, dist, summary=False):
             e2e_elapsed, nblocks, chars = e2e_region(model, pipe, upload_u8, run_rle, e2e_sync, dist, steps)
             e2e = {"elapsed": e2e_elapsed, "blocks": nblocks, "chars_per_step": chars / max(nblocks, 1), "record_bytes": pipe.nbytes}
             K = pipe.K
-        model.upload(x, hw); model.forward_device(batch); model.paste_device(800, 1333); model.rle_device(); full_sync()
+        model.upload(x, hw)
+        rle_op = rle_roofline(model, lambda: (upload_u8(0), model.forward_device(batch), model.paste_device(800, 1333), model.rle_device()), full_sync, batch, K, a.single_stream)
         from isegmi.coco import rle_counts, rle_to_string
         so, ch = model.fetch("rle.str_off"), model.fetch("rle.chars").tobytes()
         mk, cn = model.fetch("det.masks", batch), model.fetch("det.count", batch)
@@ -614,9 +692,19 @@ def bench_maskrcnn(a, dist, summary=False):
                           " / all-gathered over RCCL" if gather is not None else "", int(batch * 100 * 800 * 1333 / 1e6))}
     if rccl:
         out.update(rccl)
+    hbm = hbm_rooflines(ops, steps, hbm_traffic("hbm_stage_traffic_maskrcnn.json") if (not fp16 and not c4 and depth == 50 and batch == 2) else None)
+    if rle_op:
+        hbm += hbm_rooflines(rle_op, 5)
+    out["roofline_hbm"] = hbm
+    out["roofline_hbm_note"] = ("SURVEY 8(d) HBM-bound stages, per step of %d images, in the single-stream pass of `roofline`: achieved = ALGORITHMIC bytes / "
+                                "HIP-event time on the launching stream; peak 8 TB/s (spec)" % batch)
     if not a.no_latency:
         model.upload(x[:1], hw[:1])
         out["bs1"] = latency_pass(model, lambda: (model.forward_device(1), model.paste_device(800, 1333)), iters=11, drop=3)
+        f1, m1, l1, _ = roofline_pass(model, lambda i: (model.forward_device(1), model.paste_device(800, 1333)), full_sync, 10, a.single_stream)
+        out["bs1"]["roofline"] = {"bound": "mfma", "achieved": round(f1 / (m1 * 1e-3) / 1e12, 2) if m1 > 0 else 0.0, "peak": peak, "unit": "TFLOP/s",
+                                  "frac": round(f1 / (m1 * 1e-3) / 1e12 / peak, 4) if m1 > 0 else 0.0, "conv_ms_per_image": round(m1 / 10, 3),
+                                  "pass": "10 single-stream bs=1 steps, HIP events around every conv launch"}
         model.upload(x, hw)
         if not summary:
             model.set_param("timing", 1.0)
@@ -655,6 +743,7 @@ def bench_maskrcnn(a, dist, summary=False):
     if summary:
         keep = {"workload": out["config"]["workload"], "img_per_s": out["value"], "batch": batch, "ms_per_step": out["ms_per_step"], "steps": steps, "warmup": warmup,
                 "step_ms": out["step_ms"], "value_resident": out.get("value_resident"), "value_e2e": out.get("value_e2e"), "e2e": out.get("e2e"), "bs1": out.get("bs1"),
+                "roofline_hbm": out.get("roofline_hbm"),
                 "roofline": {k: roof[k] for k in ("achieved", "peak", "unit", "frac", "conv_ms_per_step", "launches_per_step", "algorithmic_gflop_per_step")},
                 "detections_per_image": out["config"]["detections_per_image"], "proposals_per_image": out["config"]["proposals_per_image"],
                 "cpu_baseline": out.get("cpu_baseline"), "parity_vs_oracle_on_bench_batch": out.get("parity_vs_oracle_on_bench_batch"),

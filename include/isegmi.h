@@ -370,6 +370,10 @@ int isegmi_maskrcnn_pack_records(isegmi_engine* e, void* d_dst, int64_t cap, int
 /* conv-kernel statistics since the last call (set_param "conv_timing" 1): algorithmic FLOPs, summed
  * HIP-event time (ms) of the conv launches on the engine stream, launch count; resets them */
 int isegmi_engine_conv_stats(isegmi_engine* e, double* flops, double* ms, int64_t* launches);
+/* HBM-bound (non-conv) stages under set_param("op_timing", 1): per stage label the summed HIP-event time (us, on the stream the stage is
+ * launched on), its ALGORITHMIC bytes and the number of timed scopes since the last call; labels joined by '\n' in `names`.
+ * Call after isegmi_engine_sync.  Resets the accumulators.  (bench.py: roofline_hbm) */
+int isegmi_engine_op_stats(isegmi_engine* e, char* names, int names_cap, double* us, double* bytes, int64_t* launches, int cap, int* count);
 
 /* per-layer text report (label, GFLOP, ms, TFLOP/s per line) accumulated under conv_timing; clears it */
 int isegmi_engine_conv_report(isegmi_engine* e, char* buf, int cap);

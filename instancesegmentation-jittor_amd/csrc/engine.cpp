@@ -625,7 +625,11 @@ int yolact_forward(Engine& e, const float* d_images, int N) {
         HIP_TRY(hipStreamWaitEvent(e.tail, ev, 0));
         ds = e.tail;
     }
-    TRY(yolact_detect_launch(&a, ds));
+    {
+        // confidences, box regressions and mask coefficients of every prior once (the fused head's [N][P][4 + 81 + 32] rows) + priors
+        OpScope op(e, ds, "yolact_detect (softmax + decode + per-class top-k + fast-NMS + gather)", (double)N * Ptot * ((double)(4 + nc + md) * 4) + (double)Ptot * 16);
+        TRY(yolact_detect_launch(&a, ds));
+    }
     if (pipe) { HIP_TRY(hipEventRecord(e.heads_done, e.stream)); e.heads_pending = true; }
     TRY(eng_tail_end(e));
     eng_mark(e, "detect");
@@ -655,9 +659,15 @@ int yolact_postprocess(Engine& e, int h, int w, const int32_t* h_image_hw) {
     TRY(eng_buf(e, "det.box_int", (int64_t)N * K * 4 * 8, &ib, 3, {N, K, 4}));
     void* wq;
     TRY(eng_buf(e, "det.mask_window", (int64_t)e.max_batch * K * 16, &wq, 1, {N, K, 4}));
-    TRY(yolact_masks_launch((const float*)proto.d, (const float*)e.bufs["det.coeff"].d, (const float*)e.bufs["det.box"].d,
-                            (const int*)e.bufs["det.count"].d, N, PH, PW, md, K, h, w, (float*)lo, (uint8_t*)masks, (int64_t*)ib,
-                            rs, d_ihw, (int*)wq, e.param("sparse_masks", 0.0f) == 0.0f));
+    {
+        // SURVEY 8d "Yolact assembly: read the prototypes + coefficients, write n x h x w" (uint8 planes; whole unless sparse_masks)
+        const bool whole = e.param("sparse_masks", 0.0f) == 0.0f;
+        OpScope op(e, rs, whole ? "yolact_masks (proto @ coeff -> sigmoid -> crop -> upsample -> threshold, whole uint8 planes)" : "yolact_masks (sparse: box windows only)",
+                   (double)N * PH * PW * md * 4 + (double)N * K * md * 4 + (whole ? (double)N * K * h * w : 0.0));
+        TRY(yolact_masks_launch((const float*)proto.d, (const float*)e.bufs["det.coeff"].d, (const float*)e.bufs["det.box"].d,
+                                (const int*)e.bufs["det.count"].d, N, PH, PW, md, K, h, w, (float*)lo, (uint8_t*)masks, (int64_t*)ib,
+                                rs, d_ihw, (int*)wq, whole));
+    }
     if (e.convs.count("maskiou_net.2")) {
         // YOLACT++ fast mask re-scoring on the proto-resolution masks just written to ws.lo: first layer (1 input channel) and
         // the global-max / class pick as small dedicated kernels, the rest on the MFMA conv kernels over all N*K slots
@@ -788,6 +798,7 @@ extern "C" int isegmi_engine_set_param(isegmi_engine* h, const char* name, float
     h->e.params[name] = value;
     if (std::string(name) == "timing") h->e.timing = value != 0.0f;
     if (std::string(name) == "conv_timing") h->e.conv_timing = value != 0.0f;
+    if (std::string(name) == "op_timing") h->e.op_timing = value != 0.0f;
     if (std::string(name) == "conv_trace") h->e.conv_trace = value != 0.0f;
     if (std::string(name) == "multi_stream") h->e.multi_stream = value != 0.0f;
     if (std::string(name) == "fp16") h->e.fp16 = value != 0.0f;
@@ -921,7 +932,10 @@ extern "C" int isegmi_engine_preprocess_u8(isegmi_engine* h, const uint8_t* d_u8
     }
     if (on_copy) {
         // d_out's previous reader is fenced by upload_async's wait on in_done, which precedes the copy in this stream
-        TRY(preprocess_u8_launch(d_u8, N, Hin, Win, d_out, Hout, Wout, Hpad, Wpad, out_img_stride, mean3, std3, swap_rb, e.copy));
+        {
+            OpScope op(e, e.copy, "front end (uint8 -> resize / normalise / pad -> fp32 input)", (double)src_bytes + (double)dst_bytes);
+            TRY(preprocess_u8_launch(d_u8, N, Hin, Win, d_out, Hout, Wout, Hpad, Wpad, out_img_stride, mean3, std3, swap_rb, e.copy));
+        }
         // the copy stream is in order: this launch IS the consumer of the uploads into its source, so their entries are free again (left
         // unconsumed, every re-allocated staging buffer pinned an entry for good: "more than 64 upload destinations" after 64 growths)
         for (auto& u : e.uploads) {
@@ -931,6 +945,7 @@ extern "C" int isegmi_engine_preprocess_u8(isegmi_engine* h, const uint8_t* d_u8
         return eng_note_upload(e, d_out, dst_bytes);
     }
     TRY(eng_wait_upload(e, d_u8, src_bytes, e.stream));
+    OpScope op(e, e.stream, "front end (uint8 -> resize / normalise / pad -> fp32 input)", (double)src_bytes + (double)dst_bytes);
     return preprocess_u8_launch(d_u8, N, Hin, Win, d_out, Hout, Wout, Hpad, Wpad, out_img_stride, mean3, std3, swap_rb, e.stream);
 }
 
@@ -1039,6 +1054,37 @@ extern "C" int isegmi_engine_conv_stats(isegmi_engine* h, double* flops, double*
     ARG_CHECK(h && flops && ms && launches, "null");
     *flops = h->e.conv_flops; *ms = h->e.conv_ms; *launches = h->e.conv_launches;
     h->e.conv_flops = 0; h->e.conv_ms = 0; h->e.conv_launches = 0;
+    return ISEGMI_OK;
+}
+
+// HBM-bound stages timed under "op_timing" (call after a sync): accumulates the pending event pairs, then returns per label the summed
+// HIP-event time (us), the summed ALGORITHMIC bytes and the number of timed scopes since the last call; `names` = labels joined
+// by '\n'.  Resets the accumulators.
+extern "C" int isegmi_engine_op_stats(isegmi_engine* h, char* names, int names_cap, double* us, double* bytes, int64_t* launches, int cap, int* count) {
+    ARG_CHECK(h && names && us && bytes && launches && count && names_cap > 0 && cap > 0, "op_stats args");
+    Engine& e = h->e;
+    for (auto& ev : e.op_evs) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess) {
+            auto& st = e.op_stats[ev.label];
+            st.us += (double)ms * 1e3; st.bytes += ev.bytes; st.launches += 1;
+        }
+        (void)hipEventDestroy(ev.a);
+        (void)hipEventDestroy(ev.b);
+    }
+    e.op_evs.clear();
+    std::string s;
+    int c = 0;
+    for (auto& kv : e.op_stats) {
+        if (c >= cap || (int)(s.size() + kv.first.size() + 2) > names_cap) break;
+        if (c) s += "\n";
+        s += kv.first;
+        us[c] = kv.second.us; bytes[c] = kv.second.bytes; launches[c] = kv.second.launches;
+        ++c;
+    }
+    memcpy(names, s.c_str(), s.size() + 1);
+    *count = c;
+    e.op_stats.clear();
     return ISEGMI_OK;
 }
 

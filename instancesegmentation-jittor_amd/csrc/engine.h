@@ -113,6 +113,13 @@ struct Engine {
     std::map<std::string, std::pair<double, double>> conv_layers;  // label -> (flops, ms) accumulated
     double conv_flops_pending = 0, conv_flops = 0, conv_ms = 0;
     int64_t conv_launches = 0;
+    // HIP-event timing of the HBM-bound (non-conv) stages with their ALGORITHMIC bytes (SURVEY 8d "Algorithmic bytes"): param "op_timing";
+    // isegmi_engine_op_stats accumulates and returns (label, us, bytes, launches) -- bench.py's roofline_hbm
+    bool op_timing = false;
+    struct OpEv { hipEvent_t a, b; const char* label; double bytes; };
+    std::vector<OpEv> op_evs;
+    struct OpStat { double us = 0, bytes = 0; int64_t launches = 0; };
+    std::map<std::string, OpStat> op_stats;
 
     float param(const std::string& k, float def) const {
         auto it = params.find(k);
@@ -148,6 +155,24 @@ struct SideScope {
     hipStream_t saved;
     SideScope(Engine& e_, int k) : e(e_), saved(e_.cur) { if (e.multi_stream) e.cur = e.side[k]; }
     ~SideScope() { e.cur = saved; }
+};
+
+// RAII: brackets the launches of one HBM-bound stage with HIP events on the stream they go to (no-op unless "op_timing" is set)
+struct OpScope {
+    Engine& e;
+    hipStream_t st;
+    const char* label;
+    double bytes;
+    hipEvent_t a = nullptr;
+    OpScope(Engine& e_, hipStream_t st_, const char* label_, double bytes_) : e(e_), st(st_), label(label_), bytes(bytes_) {
+        if (e.op_timing && !e.capturing && hipEventCreate(&a) == hipSuccess) (void)hipEventRecord(a, st);
+    }
+    ~OpScope() {
+        if (!a) return;
+        hipEvent_t b = nullptr;
+        if (hipEventCreate(&b) == hipSuccess) { (void)hipEventRecord(b, st); e.op_evs.push_back({a, b, label, bytes}); }
+        else (void)hipEventDestroy(a);
+    }
 };
 
 int yolact_forward(Engine& e, const float* d_images, int N);

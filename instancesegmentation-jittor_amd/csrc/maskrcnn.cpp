@@ -213,6 +213,9 @@ int maskrcnn_forward(Engine& e, const float* d_images, int N) {
             TRY(eng_buf(e, "rpn.tk_ws_idx" + ls, we * 4, &q, 1)); tws_i = (int*)q;
         }
         auto select = [&]() -> int {
+            // logits once (4 B per anchor) + deltas and anchors of the pre-NMS top-k (16 B each) + the kept boxes and scores (20 B)
+            OpScope op(e, st, "rpn_select (sigmoid + top-k + decode + NMS, per FPN level)",
+                       (double)N * ((double)HWA * 4 + (double)(pre_nms < HWA ? pre_nms : HWA) * 32 + (double)post_nms * 20));
             TRY(rpn_sigmoid_launch(head.d, (int64_t)N * HWA, A, CH, prob, st));
             TRY(topk_launch_ws(prob, HWA, N, HWA, pre_nms, nullptr, 1, tkv, tki, tkc, tws_v, tws_i, st));
             TRY(rpn_decode_nms_launch(head.d, anc, tkv, tki, tkc, d_hw, N, HWA, A, CH, pre_nms, post_nms, rpn_thr, rpn_min,
@@ -280,8 +283,11 @@ int maskrcnn_forward(Engine& e, const float* d_images, int N) {
     TRY(eng_buf(e, "proposals", (int64_t)N * R * 16, &p, 0, {N, R, 4})); props = (float*)p;
     TRY(eng_buf(e, "proposal_scores", (int64_t)N * R * 4, &p, 0, {N, R})); prop_scores = (float*)p;
     TRY(eng_buf(e, "proposal_count", (int64_t)N * 4, &p, 1, {N})); prop_cnt = (int*)p;
-    TRY(topk_launch(cand_scores, (int64_t)L * post_nms, N, L * post_nms, R, cand_total, 1, fin_vals, fin_idx, fin_cnt, st));
-    TRY(gather_proposals_launch(cand_boxes, fin_vals, fin_idx, fin_cnt, N, L * post_nms, R, props, prop_scores, prop_cnt, st));
+    {
+        OpScope op(e, st, "rpn_merge (top-k over the levels' candidates + gather)", (double)N * ((double)L * post_nms * 4 + (double)R * 40));
+        TRY(topk_launch(cand_scores, (int64_t)L * post_nms, N, L * post_nms, R, cand_total, 1, fin_vals, fin_idx, fin_cnt, st));
+        TRY(gather_proposals_launch(cand_boxes, fin_vals, fin_idx, fin_cnt, N, L * post_nms, R, props, prop_scores, prop_cnt, st));
+    }
     eng_mark(e, "proposals");
 
     // ---- box head
@@ -290,8 +296,14 @@ int maskrcnn_forward(Engine& e, const float* d_images, int N) {
     const float scales[4] = {0.25f, 0.125f, 0.0625f, 0.03125f};
     Tensor roi7, f6, f7, cb;
     TRY(eng_act(e, "box.roi_feat", N * R, 7, 7, 256, &roi7, dt));
-    if (dt) TRY(roi_align_f16_launch((const void* const*)feats, Hs, Ws, scales, 4, props, prop_cnt, N, R, 256, 7, 7, 2, 2, roi7.d, st));
-    else TRY(roi_align_launch(feats, Hs, Ws, scales, 4, props, prop_cnt, N, R, 256, 7, 7, 2, 2, -1, roi7.d, nullptr, st));
+    // SURVEY 8d "RoIAlign box: read rois + P2-P5 once (compulsory) + write the pooled features"
+    double feat_bytes = 0;
+    for (int l = 0; l < 4; ++l) feat_bytes += (double)N * Hs[l] * Ws[l] * 256 * (dt ? 2 : 4);
+    {
+        OpScope op(e, st, "roi_align 7x7 (box head)", feat_bytes + (double)N * R * 20 + (double)N * R * 49 * 256 * (dt ? 2 : 4));
+        if (dt) TRY(roi_align_f16_launch((const void* const*)feats, Hs, Ws, scales, 4, props, prop_cnt, N, R, 256, 7, 7, 2, 2, roi7.d, st));
+        else TRY(roi_align_launch(feats, Hs, Ws, scales, 4, props, prop_cnt, N, R, 256, 7, 7, 2, 2, -1, roi7.d, nullptr, st));
+    }
     TRY(eng_conv(e, "roi_heads.box.feature_extractor.fc6", roi7, 1, 0, 1, nullptr, "box.fc6", &f6));
     TRY(eng_conv(e, "roi_heads.box.feature_extractor.fc7", f6, 1, 0, 1, nullptr, "box.fc7", &f7));
     TRY(eng_conv(e, "roi_heads.box.predictor.cls_bbox", f7, 1, 0, 0, nullptr, "box.cls_bbox", &cb, /*out_f32=*/true));
@@ -314,14 +326,21 @@ int maskrcnn_forward(Engine& e, const float* d_images, int N) {
     TRY(eng_buf(e, "det.box", (int64_t)N * cap * 16, &p, 0, {N, cap, 4})); a.d_out_boxes = (float*)p;
     TRY(eng_buf(e, "det.score", (int64_t)N * cap * 4, &p, 0, {N, cap})); a.d_out_scores = (float*)p;
     TRY(eng_buf(e, "det.label", (int64_t)N * cap * 4, &p, 1, {N, cap})); a.d_out_labels = (int*)p;
-    TRY(box_postprocess_launch(&a, st));
+    {
+        // logits + box regressions of every proposal once, the proposals, the detections out
+        OpScope op(e, st, "box_postprocess (softmax + decode + per-class NMS + top-100)", (double)N * R * ((double)ncls * 5 * 4 + 16) + (double)N * cap * 24);
+        TRY(box_postprocess_launch(&a, st));
+    }
     eng_mark(e, "box_head");
 
     // ---- mask head
     Tensor m;
     TRY(eng_act(e, "mask.roi_feat", N * cap, 14, 14, 256, &m, dt));
-    if (dt) TRY(roi_align_f16_launch((const void* const*)feats, Hs, Ws, scales, 4, a.d_out_boxes, a.d_out_count, N, cap, 256, 14, 14, 2, 2, m.d, st));
-    else TRY(roi_align_launch(feats, Hs, Ws, scales, 4, a.d_out_boxes, a.d_out_count, N, cap, 256, 14, 14, 2, 2, -1, m.d, nullptr, st));
+    {
+        OpScope op(e, st, "roi_align 14x14 (mask head)", feat_bytes + (double)N * cap * 20 + (double)N * cap * 196 * 256 * (dt ? 2 : 4));
+        if (dt) TRY(roi_align_f16_launch((const void* const*)feats, Hs, Ws, scales, 4, a.d_out_boxes, a.d_out_count, N, cap, 256, 14, 14, 2, 2, m.d, st));
+        else TRY(roi_align_launch(feats, Hs, Ws, scales, 4, a.d_out_boxes, a.d_out_count, N, cap, 256, 14, 14, 2, 2, -1, m.d, nullptr, st));
+    }
     for (int i = 1; i <= 4; ++i) {
         Tensor o;
         TRY(eng_conv(e, "roi_heads.mask.feature_extractor.mask_fcn" + std::to_string(i), m, 1, 1, 1, nullptr, "mask.fcn" + std::to_string(i), &o));
@@ -343,8 +362,11 @@ int maskrcnn_forward(Engine& e, const float* d_images, int N) {
     TRY(need_tensor(e, "mask_logits.w", (int64_t)ncls * 256 * 4, &lw));
     TRY(need_tensor(e, "mask_logits.b", (int64_t)ncls * 4, &lb));
     TRY(eng_buf(e, "det.mask28", (int64_t)N * cap * 784 * 4, &p, 0, {N, cap, 28, 28}));
-    if (dt) TRY(mask_logits_select_f16_launch(up.d, N * cap, 784, 256, (const float*)lw->d, (const float*)lb->d, a.d_out_labels, (float*)p, st));
-    else TRY(mask_logits_select_launch(up.d, N * cap, 784, 256, (const float*)lw->d, (const float*)lb->d, a.d_out_labels, (float*)p, st));
+    {
+        OpScope op(e, st, "mask_logits_select (1x1 -> the label's channel + sigmoid)", (double)N * cap * 784 * (256.0 * (dt ? 2 : 4) + 4));
+        if (dt) TRY(mask_logits_select_f16_launch(up.d, N * cap, 784, 256, (const float*)lw->d, (const float*)lb->d, a.d_out_labels, (float*)p, st));
+        else TRY(mask_logits_select_launch(up.d, N * cap, 784, 256, (const float*)lw->d, (const float*)lb->d, a.d_out_labels, (float*)p, st));
+    }
     eng_mark(e, "mask_head");
     TRY(eng_tail_end(e));
     e.cur = e.stream;
@@ -536,9 +558,15 @@ int maskrcnn_paste(Engine& e, const float* h_ratios_wh, int out_h, int out_w) {
     TRY(eng_buf(e, "det.mask_window", (int64_t)e.max_batch * cap * 16, &wq, 1, {N, cap, 4}));
     // "sparse_masks": the planes are read through their windows only (isegmi_engine_rle: the device-side COCO output), so the 107 MB per image of
     // zero background need not be written; det.masks is then NOT a full binary plane (pixels outside a window are undefined)
-    TRY(paste_masks_launch((const float*)e.bufs[c4 ? "det.mask14" : "det.mask28"].d, (const float*)rb, (const int*)e.bufs["det.count"].d, N,
-                           cap, c4 ? 14 : 28, out_h, out_w, e.param("mask_threshold", 0.5f), (uint8_t*)p, ps, (int*)wq,
-                           e.param("sparse_masks", 0.0f) == 0.0f));
+    {
+        // SURVEY 8d "Mask paste: read 0.31 MB, write <= 106 MB u8 per image": the planes are written whole unless sparse_masks (windows only: the
+        // window bytes are data dependent and not counted here)
+        const bool whole = e.param("sparse_masks", 0.0f) == 0.0f;
+        OpScope op(e, ps, whole ? "paste_masks (Masker: resize + threshold + paste, whole uint8 planes)" : "paste_masks (sparse: box windows only)",
+                   (double)N * cap * (c4 ? 196 : 784) * 4 + (whole ? (double)N * cap * out_h * out_w : 0.0));
+        TRY(paste_masks_launch((const float*)e.bufs[c4 ? "det.mask14" : "det.mask28"].d, (const float*)rb, (const int*)e.bufs["det.count"].d, N,
+                               cap, c4 ? 14 : 28, out_h, out_w, e.param("mask_threshold", 0.5f), (uint8_t*)p, ps, (int*)wq, whole));
+    }
     if (ps == e.tail) HIP_TRY(hipEventRecord(e.tail_done, e.tail));
     e.cur = e.stream;
     eng_mark(e, "paste");

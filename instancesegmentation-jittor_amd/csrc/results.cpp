@@ -108,7 +108,12 @@ int eng_rle(Engine& e, const int32_t* h_image_hw) {
     TRY(eng_buf(e, "rle.str_off", ((int64_t)e.max_batch * K + 1) * 4, &q, 1, {(int64_t)N * K + 1})); a.d_out_str_off = (int32_t*)q;
     TRY(eng_buf(e, "rle.chars", (int64_t)a.cap_chars, &q, 2, {a.cap_chars})); a.d_out_chars = (uint8_t*)q;
     TRY(eng_buf(e, "rle.status", 16, &q, 1, {4})); a.d_out_status = (int32_t*)q;
-    TRY(rle_encode_launch(&a, rs));
+    {
+        // the chain reads each mask's box WINDOW of its uint8 plane once; the windows are data (on the device): the caller prices this stage from
+        // det.mask_window (bench.py), 0 here
+        OpScope op(e, rs, "rle (7 prefix-sum launches: pack, scans, emit, lengths, chars)", 0.0);
+        TRY(rle_encode_launch(&a, rs));
+    }
     if (rs == e.tail) HIP_TRY(hipEventRecord(e.tail_done, e.tail));  // reads det.masks / det.count: extend the WAR fence
     return ISEGMI_OK;
 }
