@@ -97,6 +97,11 @@ typedef struct isegmi_bottleneck_desc {
 int isegmi_op_bottleneck_f16(const isegmi_bottleneck_desc* d, const void* d_x, const void* d_w1, const float* d_s1, const float* d_b1,
                              const void* d_w2, const float* d_s2, const float* d_b2, const void* d_w3, const float* d_s3,
                              const float* d_b3, void* d_out, void* stream);
+/* The FIRST block of res2 (Cin = Cmid = 64, stride 1) with its projection shortcut d (1x1 64 -> 256 + BN) in the same launch:
+ * out = relu(bn3(conv3(...)) + fp16(bnd(conv1x1_d(x)))) -- the shortcut tensor is rounded to fp16 where the four-launch path stores it. */
+int isegmi_op_bottleneck_ds_f16(const isegmi_bottleneck_desc* d, const void* d_x, const void* d_w1, const float* d_s1, const float* d_b1,
+                                const void* d_w2, const float* d_s2, const float* d_b2, const void* d_w3, const float* d_s3,
+                                const float* d_b3, const void* d_wd, const float* d_sd, const float* d_bd, void* d_out, void* stream);
 /* fp16 stem (M2 `StemWithFixedBatchNorm` conv1 under configs[4]): desc Cin=4 R=S=7 stride=2 pad=3 with H, W the image
  * size; d_in of isegmi_op_conv2d_f16 is then the haloed fp16 image [N][H+6][(W+7)&~1][4] this op writes from the fp32
  * NHWC C=3 batch (3 zero pixels on every side, zero 4th channel); weights are given as [Cout][7][7][4]. */

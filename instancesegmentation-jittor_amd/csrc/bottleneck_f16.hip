@@ -41,17 +41,25 @@ struct BtlK {
     const float* s1; const float* b1;
     const float* s2; const float* b2;
     const float* s3; const float* b3;
+    const half_t* wd;            // projection shortcut (first block of a stage): 1x1 CIN -> COUT on x, its own folded BN
+    const float* sd; const float* bd;
     const half_t* res;
     half_t* out;
-    int N, H, W;                 // x is [N][H][W][CIN]; identity block: the output has the same geometry
+    int N, H, W;                 // x is [N][H][W][CIN]; the output has the same H x W (stride 1)
     int tiles_x, tiles_y, total;
-    unsigned x_bytes, out_bytes, res_bytes, w1_bytes, w2_bytes, w3_bytes;
+    unsigned x_bytes, out_bytes, res_bytes, w1_bytes, w2_bytes, w3_bytes, wd_bytes;
     int exp_flags;  // TIMING-ONLY experiments: 32 the loader waves issue nothing, 64 the MFMA waves only keep the barriers
 };
 
-template <int CIN_, int CMID_, int TH_, int TW_>
+// DS: the block has a PROJECTION shortcut (first block of res2: CIN = 64 -> COUT = 256, stride 1): the residual is
+//   r = fp16(bnd(conv1x1_d(x)))  -- rounded to fp16 as the three-launch path rounds the shortcut tensor when it stores it --
+// computed in two extra steps between conv2 and conv3 (the tile's centre pixels of x once more through the ring, L2 hits, next to one half
+// of the projection's weights each), transposed through the epilogue's scratch into the registers the identity kernel loads the residual into.
+template <int CIN_, int CMID_, int TH_, int TW_, bool DS_ = false>
 struct BtlCfg {
     static constexpr int CIN = CIN_, CMID = CMID_, COUT = 4 * CMID_, TH = TH_, TW = TW_;
+    static constexpr bool DS = DS_;
+    static constexpr int SD = DS_ ? 2 : 0;        // projection steps per tile
     static constexpr int NW = 8, LW = 4, NSTAGE = 3;
     static constexpr int HW2 = TW + 2, MH = (TH + 2) * (TW + 2), MHP = (MH + 31) / 32 * 32, MT = TH * TW, MTP = (MT + 31) / 32 * 32;
     static constexpr int KC1 = CIN / 64, KM = CMID / 64;
@@ -69,6 +77,7 @@ struct BtlCfg {
     // vmcnt wait is uniform; each goes to its own KiB at the unused end of the stage -- hipcc merges LDS-DMA builtins that are identical, and
     // a merged piece makes the count one short (seen: garbage in t1 on cold caches)
     static constexpr int STAGEB = max3(P1_BYTES, P2_BYTES + (PP - PP2) * 1024, P3_BYTES + (PP - PP3) * 1024);
+    static_assert(!DS_ || (CIN_ == 64 && CMID_ == 64), "the projection variant is res2's first block");
     static constexpr int RD = CMID == 64 ? 8 : 4; // residual passes (16 B per lane each) in flight: requested before conv2, refilled pass by pass
     static constexpr int EPITCH = 68;             // floats per scratch row (64 + 4)
     static constexpr int SCRATCH = NW * 8 * EPITCH * 4;
@@ -108,6 +117,8 @@ __global__ __launch_bounds__((CF::NW + CF::LW) * 64, 1) void bottleneck_f16_kern
     constexpr int CIN = CF::CIN, CMID = CF::CMID, COUT = CF::COUT, TH = CF::TH, TW = CF::TW, NW = CF::NW, NSTAGE = CF::NSTAGE;
     constexpr int HW2 = CF::HW2, MH = CF::MH, MHP = CF::MHP, MT = CF::MT, MTP = CF::MTP, KC1 = CF::KC1, KM = CF::KM, P1B = CF::P1B;
     constexpr int NCOL = CF::NCOL, CH2 = CF::CH2, G2 = CF::G2, S1 = CF::S1, S2 = CF::S2, S3 = CF::S3, PP = CF::PP, STAGEB = CF::STAGEB;
+    constexpr bool DS = CF::DS;
+    constexpr int SD = CF::SD;
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     char* const ring = smem;
@@ -146,7 +157,10 @@ __global__ __launch_bounds__((CF::NW + CF::LW) * 64, 1) void bottleneck_f16_kern
         const __amdgpu_buffer_rsrc_t rs_w2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2, 0, p.w2_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_w3 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w3, 0, p.w3_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, 0, 0x00020000);  // drops every load
-        unsigned w1off[PW1], w2off[PW2], w3off[PP3], avoff[PA1];
+        const __amdgpu_buffer_rsrc_t rs_wd = __builtin_amdgcn_make_buffer_rsrc((void*)(DS ? p.wd : p.w1), 0, DS ? p.wd_bytes : 0u, 0x00020000);
+        constexpr int PCD = DS ? MTP / 8 / LW : 1, PWD = 128 / 8 / LW;   // projection step: the tile's centre pixels of x + 128 rows of wd
+        static_assert(!DS || PCD + PWD == PP, "projection steps carry PP pieces");
+        unsigned w1off[PW1], w2off[PW2], w3off[PP3], avoff[PA1], cvoff[PCD], wdoff[PWD];
 #pragma unroll
         for (int i = 0; i < PW1; ++i) {
             const int row = (lw + i * LW) * 8 + r8, c = cs ^ ((row >> 1) & 7);
@@ -158,6 +172,11 @@ __global__ __launch_bounds__((CF::NW + CF::LW) * 64, 1) void bottleneck_f16_kern
             const int row = (lw + i * LW) * 8 + r8, c = cs ^ ((row >> 1) & 7);
             w3off[i] = (unsigned)(row * (CMID * 2) + c * 16);
         }
+#pragma unroll
+        for (int i = 0; i < PWD; ++i) {
+            const int row = (lw + i * LW) * 8 + r8, c = cs ^ ((row >> 1) & 7);
+            wdoff[i] = (unsigned)(row * (CIN * 2) + c * 16);
+        }
         auto setup_tile = [&](int v) {
             int n, y0, x0;
             tile_origin(v, n, y0, x0);
@@ -168,6 +187,15 @@ __global__ __launch_bounds__((CF::NW + CF::LW) * 64, 1) void bottleneck_f16_kern
                 const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
                 const bool ok = (j < MH) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
                 avoff[i] = ok ? (unsigned)((((n * p.H + iy) * p.W + ix) * CIN) * 2 + c * 16) : OOB;
+            }
+            if (DS) {
+#pragma unroll
+                for (int i = 0; i < PCD; ++i) {
+                    const int m = (lw + i * LW) * 8 + r8, c = cs ^ ((m >> 1) & 7);
+                    const int y = m / TW, x = m - y * TW;
+                    const bool ok = (m < MT) & (y0 + y < p.H) & (x0 + x < p.W);
+                    cvoff[i] = ok ? (unsigned)((((n * p.H + y0 + y) * p.W + x0 + x) * CIN) * 2 + c * 16) : OOB;
+                }
             }
         };
         int iv = bid, iphase = 0, iidx = 0;
@@ -208,7 +236,20 @@ __global__ __launch_bounds__((CF::NW + CF::LW) * 64, 1) void bottleneck_f16_kern
                     }
                 }
                 dummies(base, PP - PP2);
-                if (++iidx == S2) { iphase = 2; iidx = 0; }
+                if (++iidx == S2) { iphase = DS ? 2 : 3; iidx = 0; }
+            } else if (DS && iphase == 2) {   // projection step h: centre pixels of x [MTP x 64 ch] + rows 128 h .. of wd
+                const unsigned soffw = (unsigned)(iidx * 128 * CIN * 2), soff0 = 0u;
+#pragma unroll
+                for (int i = 0; i < PCD; ++i) {
+                    const unsigned voff = cvoff[i];
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(base + (lw + i * LW) * 1024), 16, voff, soff0, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < PWD; ++i) {
+                    const unsigned voff = wdoff[i];
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wd, (lds_ptr_t)(base + MTP * 128 + (lw + i * LW) * 1024), 16, voff, soffw, 0, 0);
+                }
+                if (++iidx == SD) { iphase = 3; iidx = 0; }
             } else {
                 const int slab = iidx / KM, kc = iidx - slab * KM;
                 const unsigned soff = (unsigned)(slab * 256 * CMID * 2 + kc * 128);
@@ -236,7 +277,7 @@ __global__ __launch_bounds__((CF::NW + CF::LW) * 64, 1) void bottleneck_f16_kern
                 wr = wr + 1 == NSTAGE ? 0 : wr + 1;
             }
             asm volatile("s_barrier" ::: "memory");  // X: see the MFMA waves
-            for (int t = 0; t < S3; ++t) {
+            for (int t = 0; t < SD + S3; ++t) {
                 asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NSTAGE - 2) * PP) : "memory");
                 issue(wr);
                 wr = wr + 1 == NSTAGE ? 0 : wr + 1;
@@ -287,7 +328,7 @@ __global__ __launch_bounds__((CF::NW + CF::LW) * 64, 1) void bottleneck_f16_kern
     auto next_stage = [&]() { st = st + 1 == NSTAGE ? 0 : st + 1; };
     if (p.exp_flags & 64) {
         for (int i = 0; i < my_tiles; ++i)
-            for (int t = 0; t < S1 + S2 + 1 + S3; ++t) asm volatile("s_barrier" ::: "memory");
+            for (int t = 0; t < S1 + S2 + 1 + SD + S3; ++t) asm volatile("s_barrier" ::: "memory");
         return;
     }
     for (int v = bid; v < total; v += G) {
@@ -369,9 +410,12 @@ __global__ __launch_bounds__((CF::NW + CF::LW) * 64, 1) void bottleneck_f16_kern
         };
         constexpr int NQ = TM3 * 4, RD = CF::RD, NSLAB = COUT / 256;
         static_assert(NQ % RD == 0, "residual window");
+        static_assert(!DS || (RD == NQ && NSLAB == 1), "the projection fills the whole residual window at once");
         u32x4h rw[RD];
+        if (!DS) {
 #pragma unroll
-        for (int q = 0; q < RD; ++q) rw[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, strip_off(0, q), 0, 0);
+            for (int q = 0; q < RD; ++q) rw[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, strip_off(0, q), 0, 0);
+        }
 
         // ---- conv2: t2[m][c] = relu(bn2(sum_{tap, k} t1[j(m) + tap][k] w2[c][tap][k]))
         {
@@ -429,6 +473,62 @@ __global__ __launch_bounds__((CF::NW + CF::LW) * 64, 1) void bottleneck_f16_kern
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // t2 is complete at the next barrier
         }
 
+        // ---- projection shortcut (DS): r[m][c] = fp16(bnd(sum_k x[m][k] wd[c][k])) for the tile's 128 pixels x 256 couts, in the conv3 layout (2 x 4
+        // waves of 64 x 64) so that its transposition lands in the residual window pass for pass; step h holds wd rows 128 h ..: the waves of
+        // that half of the couts multiply, the others only keep the barrier
+        if (DS) {
+            f32x16h acc[TM3][2];
+#pragma unroll
+            for (int a = 0; a < TM3; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.0f;
+            for (int h = 0; h < SD; ++h) {
+                asm volatile("s_barrier" ::: "memory");
+                if ((wn3 >> 1) == h) {  // uniform
+                    const char* sb = ring + st * STAGEB;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        f16x8 af[TM3], bf[2];
+#pragma unroll
+                        for (int a = 0; a < TM3; ++a) af[a] = *(const f16x8*)(sb + (wm3 * TM3 + a) * 4096 + (swz ^ (ks << 5)));
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) bf[b] = *(const f16x8*)(sb + MTP * 128 + ((wn3 & 1) * 2 + b) * 4096 + (swz ^ (ks << 5)));
+#pragma unroll
+                        for (int a = 0; a < TM3; ++a)
+#pragma unroll
+                            for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+                    }
+                    pipeline_reads_mfmas<4, TM3 + 2, TM3 * 2, 2>();
+                }
+                next_stage();
+            }
+            float sc[2], sh[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int co = (wn3 * 2 + b) * 32 + lr;
+                sc[b] = p.sd[co];
+                sh[b] = p.bd[co];
+            }
+#pragma unroll
+            for (int a = 0; a < TM3; ++a)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int q = a * 4 + g;
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) ew[(k + 4 * lh) * CF::EPITCH + b * 32 + lr] = fmaf(acc[a][b][4 * g + k], sc[b], sh[b]);
+                    const f32x4h v0 = *(const f32x4h*)(ew + er * CF::EPITCH + ec);
+                    const f32x4h v1 = *(const f32x4h*)(ew + er * CF::EPITCH + ec + 4);
+                    f16x8 o;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) o[k] = (half_t)(k < 4 ? v0[k] : v1[k - 4]);   // the shortcut tensor as the three-launch path stores it
+                    rw[q % RD] = __builtin_bit_cast(u32x4h, o);
+                }
+        }
+
         // ---- conv3 + bn3 + residual + ReLU, one 256-cout slab at a time
         for (int slab = 0; slab < NSLAB; ++slab) {
             f32x16h acc[TM3][2];
@@ -480,8 +580,10 @@ __global__ __launch_bounds__((CF::NW + CF::LW) * 64, 1) void bottleneck_f16_kern
                     const unsigned ooff = strip_off(slab, q);
                     const f16x8 rh = __builtin_bit_cast(f16x8, rw[q % RD]);
                     // refill the slot with the pass RD further on (this slab's, or the next slab's first ones; NQ % RD == 0 keeps slots static)
-                    if (q + RD < NQ) rw[q % RD] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, strip_off(slab, q + RD), 0, 0);
-                    else if (slab + 1 < NSLAB) rw[q % RD] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, strip_off(slab + 1, q + RD - NQ), 0, 0);
+                    if (!DS) {
+                        if (q + RD < NQ) rw[q % RD] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, strip_off(slab, q + RD), 0, 0);
+                        else if (slab + 1 < NSLAB) rw[q % RD] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, strip_off(slab + 1, q + RD - NQ), 0, 0);
+                    }
                     f16x8 o;
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
@@ -520,35 +622,44 @@ static int launch_btl(BtlK& k, hipStream_t st, int few) {
 }
 
 bool bottleneck_f16_supported(int Cin, int Cmid) { return (Cin == 256 && Cmid == 64) || (Cin == 512 && Cmid == 128); }
+bool bottleneck_f16_ds_supported(int Cin, int Cmid) { return Cin == 64 && Cmid == 64; }
 
 static int64_t pad128(int c) { return (int64_t)cdiv(c, 128) * 128; }
 
-// identity bottleneck: x [N][H][W][Cin] fp16 -> out [N][H][W][Cin]; w1 / w2 / w3 are the isegmi_pack_conv_weights_f16 images of the three layers
+// x [N][H][W][Cin] fp16 -> out [N][H][W][4 Cmid]; w1 / w2 / w3 (/ wd) are the isegmi_pack_conv_weights_f16 images of the layers.  wd == nullptr: identity
+// block (Cin == 4 Cmid, the residual is x); else the first block of res2 with its projection shortcut (Cin = Cmid = 64).
 int bottleneck_f16_launch(const isegmi_bottleneck_desc* d, const void* x, const void* w1, const float* s1, const float* b1, const void* w2,
-                          const float* s2, const float* b2, const void* w3, const float* s3, const float* b3, void* out, hipStream_t st) {
+                          const float* s2, const float* b2, const void* w3, const float* s3, const float* b3, const void* wd, const float* sd,
+                          const float* bd, void* out, hipStream_t st) {
     ARG_CHECK(d && x && w1 && w2 && w3 && out && s1 && b1 && s2 && b2 && s3 && b3, "null");
-    ARG_CHECK(bottleneck_f16_supported(d->Cin, d->Cmid), "fused bottleneck: (Cin, Cmid) must be (256, 64) or (512, 128)");
+    const bool ds = wd != nullptr;
+    if (ds) ARG_CHECK(sd && bd && bottleneck_f16_ds_supported(d->Cin, d->Cmid), "fused projection bottleneck: (Cin, Cmid) must be (64, 64) with the shortcut's scale / shift");
+    else ARG_CHECK(bottleneck_f16_supported(d->Cin, d->Cmid), "fused bottleneck: (Cin, Cmid) must be (256, 64) or (512, 128)");
     ARG_CHECK(d->N > 0 && d->H > 0 && d->W > 0, "shape");
     ARG_CHECK(x != out, "in-place");
     BtlK k;
     k.x = (const half_t*)x; k.w1 = (const half_t*)w1; k.w2 = (const half_t*)w2; k.w3 = (const half_t*)w3;
     k.s1 = s1; k.b1 = b1; k.s2 = s2; k.b2 = b2; k.s3 = s3; k.b3 = b3;
+    k.wd = (const half_t*)wd; k.sd = sd; k.bd = bd;
     k.res = (const half_t*)x; k.out = (half_t*)out;
     k.N = d->N; k.H = d->H; k.W = d->W;
-    const int64_t bytes = (int64_t)d->N * d->H * d->W * d->Cin * 2;
-    ARG_CHECK(bytes < (1ll << 31), "activation must be < 2 GiB");
-    k.x_bytes = k.out_bytes = (unsigned)bytes;
+    const int64_t xb = (int64_t)d->N * d->H * d->W * d->Cin * 2, ob = (int64_t)d->N * d->H * d->W * d->Cmid * 4 * 2;
+    ARG_CHECK(xb < (1ll << 31) && ob < (1ll << 31), "activation must be < 2 GiB");
+    k.x_bytes = (unsigned)xb;
+    k.out_bytes = (unsigned)ob;
     k.w1_bytes = (unsigned)(pad128(d->Cmid) * d->Cin * 2);
     k.w2_bytes = (unsigned)(pad128(d->Cmid) * 9 * d->Cmid * 2);
     k.w3_bytes = (unsigned)(pad128(4 * d->Cmid) * d->Cmid * 2);
-    k.res_bytes = k.out_bytes;
+    k.wd_bytes = ds ? (unsigned)(pad128(4 * d->Cmid) * d->Cin * 2) : 0u;
+    k.res_bytes = ds ? 0u : k.out_bytes;
     const int few = d->flags & 1;  // TEST HOOK: 8-block grid, so that small shapes exercise the multi-tile stream
     // TIMING-ONLY experiments (results wrong): the range check drops every x load (2) / residual load (4) / output store (8) / weight load (16)
     if (d->flags & 2) k.x_bytes = 0;
     if (d->flags & 4) k.res_bytes = 0;
     if (d->flags & 8) k.out_bytes = 0;
-    if (d->flags & 16) k.w1_bytes = k.w2_bytes = k.w3_bytes = 0;
+    if (d->flags & 16) k.w1_bytes = k.w2_bytes = k.w3_bytes = k.wd_bytes = 0;
     k.exp_flags = d->flags & (32 | 64);
+    if (ds) return launch_btl<BtlCfg<64, 64, 8, 16, true>>(k, st, few);
     if (d->Cin == 256) return launch_btl<BtlCfg<256, 64, 8, 16>>(k, st, few);
     return launch_btl<BtlCfg<512, 128, 8, 14>>(k, st, few);
 }
@@ -560,5 +671,12 @@ using namespace isegmi;
 extern "C" int isegmi_op_bottleneck_f16(const isegmi_bottleneck_desc* d, const void* d_x, const void* d_w1, const float* d_s1, const float* d_b1,
                                         const void* d_w2, const float* d_s2, const float* d_b2, const void* d_w3, const float* d_s3,
                                         const float* d_b3, void* d_out, void* stream) {
-    return bottleneck_f16_launch(d, d_x, d_w1, d_s1, d_b1, d_w2, d_s2, d_b2, d_w3, d_s3, d_b3, d_out, (hipStream_t)stream);
+    return bottleneck_f16_launch(d, d_x, d_w1, d_s1, d_b1, d_w2, d_s2, d_b2, d_w3, d_s3, d_b3, nullptr, nullptr, nullptr, d_out, (hipStream_t)stream);
+}
+
+extern "C" int isegmi_op_bottleneck_ds_f16(const isegmi_bottleneck_desc* d, const void* d_x, const void* d_w1, const float* d_s1, const float* d_b1,
+                                           const void* d_w2, const float* d_s2, const float* d_b2, const void* d_w3, const float* d_s3,
+                                           const float* d_b3, const void* d_wd, const float* d_sd, const float* d_bd, void* d_out, void* stream) {
+    ARG_CHECK(d_wd, "null");
+    return bottleneck_f16_launch(d, d_x, d_w1, d_s1, d_b1, d_w2, d_s2, d_b2, d_w3, d_s3, d_b3, d_wd, d_sd, d_bd, d_out, (hipStream_t)stream);
 }

@@ -108,20 +108,26 @@ int eng_conv(Engine& e, const std::string& layer, const Tensor& in, int stride, 
     return timed_conv(e, layer, &d, in.d, L, residual ? residual->d : nullptr, out->d, out_f32);
 }
 
-// fp16 identity bottleneck `block` (conv1 / conv2 / conv3 of an upstream-named ResNet block, stride 1, no projection) as ONE launch of the
-// fused kernel (csrc/bottleneck_f16.hip) when the block's shape has one; *fused tells the caller whether it ran (else: three eng_conv calls)
-int eng_bottleneck_f16(Engine& e, const std::string& block, const Tensor& x, const std::string& out_name, Tensor* out, bool* fused) {
+// fp16 bottleneck `block` (conv1 / conv2 / conv3 [/ downsample.0] of an upstream-named ResNet block, stride 1) as ONE launch of the fused kernel
+// (csrc/bottleneck_f16.hip) when the block's shape has one: identity blocks of res2 / res3, and -- `first` -- the first block of res2 with its
+// projection shortcut.  *fused tells the caller whether it ran (else: three or four eng_conv calls).
+int eng_bottleneck_f16(Engine& e, const std::string& block, const Tensor& x, bool first, const std::string& out_name, Tensor* out, bool* fused) {
     *fused = false;
-    if (x.dt != 1 || e.param("fused_bottleneck", 1.0f) == 0.0f) return ISEGMI_OK;
-    auto c1 = e.convs.find(block + ".conv1"), c2 = e.convs.find(block + ".conv2"), c3 = e.convs.find(block + ".conv3");
-    if (c1 == e.convs.end() || c2 == e.convs.end() || c3 == e.convs.end()) return ISEGMI_OK;
+    const float mode = e.param("fused_bottleneck", 1.0f);  // 1: every block that has a fused kernel (default); 2: identity blocks only; 0: none (A/B)
+    if (x.dt != 1 || mode == 0.0f || (first && mode == 2.0f)) return ISEGMI_OK;
+    auto c1 = e.convs.find(block + ".conv1"), c2 = e.convs.find(block + ".conv2"), c3 = e.convs.find(block + ".conv3"), cd = e.convs.find(block + ".downsample.0");
+    if (c1 == e.convs.end() || c2 == e.convs.end() || c3 == e.convs.end() || (first && cd == e.convs.end())) return ISEGMI_OK;
     const ConvLayer &L1 = c1->second, &L2 = c2->second, &L3 = c3->second;
-    const int Cmid = L1.Cout;
-    if (!(L1.f16 && L2.f16 && L3.f16) || L1.Cin != x.C || L3.Cout != x.C || L2.Cin != Cmid || L2.Cout != Cmid || L3.Cin != Cmid || L1.R != 1 || L2.R != 3 ||
-        L2.S != 3 || L3.R != 1 || !bottleneck_f16_supported(x.C, Cmid) || !L1.d_scale || !L1.d_shift || !L2.d_scale || !L2.d_shift || !L3.d_scale || !L3.d_shift)
+    const ConvLayer* LD = first ? &cd->second : nullptr;
+    const int Cmid = L1.Cout, Cout = L3.Cout;
+    if (!(L1.f16 && L2.f16 && L3.f16) || L1.Cin != x.C || Cout != 4 * Cmid || L2.Cin != Cmid || L2.Cout != Cmid || L3.Cin != Cmid || L1.R != 1 || L2.R != 3 ||
+        L2.S != 3 || L3.R != 1 || !L1.d_scale || !L1.d_shift || !L2.d_scale || !L2.d_shift || !L3.d_scale || !L3.d_shift)
         return ISEGMI_OK;
-    if ((int64_t)x.N * x.H * x.W * x.C * 2 >= (1ll << 31)) return ISEGMI_OK;
-    int rc = eng_act(e, out_name, x.N, x.H, x.W, x.C, out, 1);
+    if (first) {
+        if (!LD->f16 || LD->Cin != x.C || LD->Cout != Cout || LD->R != 1 || !LD->d_scale || !LD->d_shift || !bottleneck_f16_ds_supported(x.C, Cmid)) return ISEGMI_OK;
+    } else if (Cout != x.C || !bottleneck_f16_supported(x.C, Cmid)) return ISEGMI_OK;
+    if ((int64_t)x.N * x.H * x.W * Cout * 2 >= (1ll << 31)) return ISEGMI_OK;
+    int rc = eng_act(e, out_name, x.N, x.H, x.W, Cout, out, 1);
     if (rc) return rc;
     if ((const void*)out->d == (const void*)x.d) { set_error("bottleneck " + block + ": in-place"); return ISEGMI_ERR_STATE; }
     isegmi_bottleneck_desc d;
@@ -134,17 +140,18 @@ int eng_bottleneck_f16(Engine& e, const std::string& block, const Tensor& x, con
         HIP_TRY(hipEventRecord(a, e.cur));
     }
     const int M = x.N * x.H * x.W;
-    if (e.conv_trace) fprintf(stderr, "convlaunch\t%s.fused\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\n", block.c_str(), x.N, x.H, x.W, x.C, x.C, 3, 1, M, 1);
-    rc = bottleneck_f16_launch(&d, x.d, L1.d_w, L1.d_scale, L1.d_shift, L2.d_w, L2.d_scale, L2.d_shift, L3.d_w, L3.d_scale, L3.d_shift, out->d, e.cur);
+    if (e.conv_trace) fprintf(stderr, "convlaunch\t%s.fused\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\n", block.c_str(), x.N, x.H, x.W, x.C, Cout, 3, 1, M, 1);
+    rc = bottleneck_f16_launch(&d, x.d, L1.d_w, L1.d_scale, L1.d_shift, L2.d_w, L2.d_scale, L2.d_shift, L3.d_w, L3.d_scale, L3.d_shift,
+                               first ? LD->d_w : nullptr, first ? LD->d_scale : nullptr, first ? LD->d_shift : nullptr, out->d, e.cur);
     if (rc) return rc;
     if (e.conv_timing) {
         HIP_TRY(hipEventRecord(b, e.cur));
         e.conv_evs.push_back({a, b});
-        // algorithmic FLOPs of the three convolutions (the halo the fused kernel recomputes for conv1 is not counted)
-        const double fl = 2.0 * M * ((double)x.C * Cmid * 2 + 9.0 * Cmid * Cmid);
+        // algorithmic FLOPs of the convolutions the launch stands for (the halo the fused kernel recomputes for conv1 is not counted)
+        const double fl = 2.0 * M * ((double)x.C * Cmid + 9.0 * Cmid * Cmid + (double)Cmid * Cout + (first ? (double)x.C * Cout : 0.0));
         e.conv_flops_pending += fl;
         char geo[160];
-        snprintf(geo, sizeof(geo), "%s.fused [M=%d C=%d Cmid=%d 1x1+3x3+1x1]", block.c_str(), M, x.C, Cmid);
+        snprintf(geo, sizeof(geo), "%s.fused [M=%d Cin=%d Cmid=%d Cout=%d 1x1+3x3+1x1%s]", block.c_str(), M, x.C, Cmid, Cout, first ? "+proj" : "");
         e.conv_ev_info.push_back({geo, fl});
     }
     *fused = true;
@@ -434,21 +441,21 @@ int yolact_forward(Engine& e, const float* d_images, int N) {
             const std::string nm = "backbone.layers." + std::to_string(li) + "." + std::to_string(b);
             const int st = (b == 0 && li > 0) ? 2 : 1;
             Tensor idt = x, t1, t2, y;
-            if (b == 0) {  // the projection shortcut is independent of conv1 -> conv2: side stream
-                TRY(eng_fork(e, 0));
-                SideScope sc(e, 0);
-                TRY(eng_conv(e, nm + ".downsample.0", x, st, 0, 0, nullptr, nm + ".ds", &idt));
-            }
             // buffers by liveness (see maskrcnn.cpp): one t1 / t2 per stage, two alternating block outputs, the stage's final output on its own
             // (C3-C5 are read by the lateral convs of the pipelined heads phase; the lat_done fence below guards exactly those)
             const bool alias = e.param("alias_buffers", 1.0f) != 0.0f;  // 0: one buffer per layer output (rounds 1-2; kept for A/B)
             const std::string sg = alias ? "res" + std::to_string(li + 2) : nm;
             const std::string out_name = !alias ? nm + ".out" : b == blocks[li] - 1 ? sg + ".C" : sg + (b & 1 ? ".outB" : ".outA");
-            if (b > 0 && dt) {  // fp16 identity blocks of res2 / res3: one launch, t1 / t2 stay in LDS (csrc/bottleneck_f16.hip)
+            if (dt && (b > 0 || st == 1)) {  // fp16 identity blocks of res2 / res3 and res2's first block: one launch, t1 / t2 stay in LDS (csrc/bottleneck_f16.hip)
                 if (li == 1 && b == blocks[1] - 1 && e.lat_pending) HIP_TRY(hipStreamWaitEvent(e.stream, e.lat_done, 0));  // (see below)
                 bool fused = false;
-                TRY(eng_bottleneck_f16(e, nm, x, out_name, &y, &fused));
+                TRY(eng_bottleneck_f16(e, nm, x, b == 0, out_name, &y, &fused));
                 if (fused) { x = y; continue; }
+            }
+            if (b == 0) {  // the projection shortcut is independent of conv1 -> conv2: side stream
+                TRY(eng_fork(e, 0));
+                SideScope sc(e, 0);
+                TRY(eng_conv(e, nm + ".downsample.0", x, st, 0, 0, nullptr, nm + ".ds", &idt));
             }
             TRY(eng_conv(e, nm + ".conv1", x, 1, 0, 1, nullptr, sg + ".t1", &t1));
             if (e.convs.count(nm + ".conv2.conv_offset_mask")) {

@@ -132,11 +132,6 @@ int maskrcnn_forward(Engine& e, const float* d_images, int N) {
             const std::string nm = "backbone.body.layer" + std::to_string(li + 1) + "." + std::to_string(b);
             const int sd = (b == 0 && li > 0) ? 2 : 1;
             Tensor idt = x, t1, t2, y;
-            if (b == 0) {  // projection shortcut on a side stream, concurrent with conv1 -> conv2
-                TRY(eng_fork(e, 0));
-                SideScope sc(e, 0);
-                TRY(eng_conv(e, nm + ".downsample.0", x, sd, 0, 0, nullptr, nm + ".ds", &idt));
-            }
             // Buffers by LIVENESS, not by layer (round 3): a stage owns one t1, one t2, two alternating block outputs and its final output
             // C<l>.  Everything runs in order on the main stream (the shortcut of block 0 is joined before conv3), so a buffer's last reader
             // is always enqueued before its next writer.  Besides the memory (R101 bs=8: 33 x 3 buffers -> 4 x 5), a dead activation is now
@@ -145,8 +140,14 @@ int maskrcnn_forward(Engine& e, const float* d_images, int N) {
             const std::string sg = alias ? "res" + std::to_string(li + 2) : nm;
             const std::string out_name = !alias ? nm + ".out" : b == blocks[li] - 1 ? sg + ".C" : sg + (b & 1 ? ".outB" : ".outA");
             bool fused = false;
-            if (b > 0) TRY(eng_bottleneck_f16(e, nm, x, out_name, &y, &fused));  // fp16 identity blocks of res2 / res3: one launch, t1 / t2 stay in LDS
+            // fp16: the identity blocks of res2 / res3 and res2's first block (projection included) are ONE launch each, t1 / t2 stay in LDS
+            if (b > 0 || sd == 1) TRY(eng_bottleneck_f16(e, nm, x, b == 0, out_name, &y, &fused));
             if (!fused) {
+                if (b == 0) {  // projection shortcut on a side stream, concurrent with conv1 -> conv2
+                    TRY(eng_fork(e, 0));
+                    SideScope sc(e, 0);
+                    TRY(eng_conv(e, nm + ".downsample.0", x, sd, 0, 0, nullptr, nm + ".ds", &idt));
+                }
                 TRY(eng_conv(e, nm + ".conv1", x, sd, 0, 1, nullptr, sg + ".t1", &t1));  // STRIDE_IN_1X1
                 TRY(eng_conv(e, nm + ".conv2", t1, 1, 1, 1, nullptr, sg + ".t2", &t2));
                 if (b == 0) TRY(eng_join(e, 0));

@@ -447,6 +447,24 @@ class BottleneckDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("N", "H", "W", "Cin", "Cmid", "flags")]
 
 
+def bottleneck_ds_f16(x, w1, sb1, w2, sb2, w3, sb3, wd, sbd, flags=0):
+    """First block of res2 with its projection shortcut (isegmi_op_bottleneck_ds_f16): x fp16 [N,H,W,64]; wd [256,1,1,64].  Returns fp16 [N,H,W,256]."""
+    x = np.ascontiguousarray(x, np.float16)
+    N, H, W, Cin = x.shape
+    Cmid = w1.shape[0]
+    bufs = []
+    for w, (sc, sh) in ((w1, sb1), (w2, sb2), (w3, sb3), (wd, sbd)):
+        Cout, R, S, Ci = w.shape
+        d = make_conv_desc(N, H, W, Ci, Cout, R, S, 1, R // 2, 1, 0)
+        bufs += [DeviceBuffer.from_numpy(pack_conv_weights_f16(d, w)), DeviceBuffer.from_numpy(np.asarray(sc, np.float32)),
+                 DeviceBuffer.from_numpy(np.asarray(sh, np.float32))]
+    dx = DeviceBuffer.from_numpy(x)
+    do = DeviceBuffer((N, H, W, 4 * Cmid), np.float16)
+    bd = BottleneckDesc(N, H, W, Cin, Cmid, int(flags))
+    check(lib().isegmi_op_bottleneck_ds_f16(C.byref(bd), dx.ptr, *[b.ptr for b in bufs], do.ptr, None))
+    return do.numpy()
+
+
 def bottleneck_f16(x, w1, sb1, w2, sb2, w3, sb3, flags=0):
     """Fused identity bottleneck (isegmi_op_bottleneck_f16): x fp16 NHWC [N,H,W,Cin]; w1 [Cmid,1,1,Cin], w2 [Cmid,3,3,Cmid],
     w3 [Cin,1,1,Cmid] natural KRSC fp32 (rounded to fp16 by the packer); sb* = (scale, shift) of the folded BN.  Returns fp16 numpy."""

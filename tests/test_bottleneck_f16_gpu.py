@@ -62,3 +62,28 @@ def test_fused_bottleneck_close_to_oracle(ffi, ch):
     d = np.abs(got - ref)
     assert np.all(d <= np.abs(ref) * 2.0 ** -8 + 4e-3), float(d.max())
     assert np.mean(got == ref) >= 0.97
+
+
+@pytest.mark.parametrize("flags", [0, 1])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_fused_projection_bottleneck_equals_four_launches(ffi, shape, flags):
+    """res2's FIRST block (64 -> 64 -> 64 -> 256 with the 1x1 projection shortcut 64 -> 256) in one launch against conv1, conv2, the projection
+    and conv3 (+ the fp16 shortcut tensor as residual) as four launches: bit-identical."""
+    N, H, W = shape
+    rng = np.random.default_rng(H * 131 + W * 7 + N + 5)
+    x = np.maximum(rng.standard_normal((N, H, W, 64)), 0).astype(np.float16)  # the max-pooled stem output
+    def bn(c):
+        return rng.uniform(0.5, 1.5, c).astype(np.float32), (rng.standard_normal(c) * 0.1).astype(np.float32)
+    w1 = (rng.standard_normal((64, 1, 1, 64)) * (2.0 / 64) ** 0.5).astype(np.float16).astype(np.float32)
+    w2 = (rng.standard_normal((64, 3, 3, 64)) * (2.0 / 576) ** 0.5).astype(np.float16).astype(np.float32)
+    w3 = (rng.standard_normal((256, 1, 1, 64)) * (2.0 / 64) ** 0.5).astype(np.float16).astype(np.float32)
+    wd = (rng.standard_normal((256, 1, 1, 64)) * (2.0 / 64) ** 0.5).astype(np.float16).astype(np.float32)
+    sb1, sb2, sb3, sbd = bn(64), bn(64), bn(256), bn(256)
+    got = ffi.bottleneck_ds_f16(x, w1, sb1, w2, sb2, w3, sb3, wd, sbd, flags=flags)
+    t1 = ffi.conv2d_f16(x, w1, 1, 0, sb1[0], sb1[1], None, 1, 4)
+    t2 = ffi.conv2d_f16(t1, w2, 1, 1, sb2[0], sb2[1], None, 1, 4)
+    sc = ffi.conv2d_f16(x, wd, 1, 0, sbd[0], sbd[1], None, 0, 4)
+    ref = ffi.conv2d_f16(t2, w3, 1, 0, sb3[0], sb3[1], sc, 1, 4)
+    assert got.shape == ref.shape == (N, H, W, 256) and got.dtype == np.float16
+    assert np.array_equal(got, ref), "fused != four launches: %d of %d differ, max |d| %g" % (
+        int((got != ref).sum()), got.size, float(np.abs(got.astype(np.float32) - ref.astype(np.float32)).max()))
