@@ -345,6 +345,10 @@ int isegmi_engine_buffer_info(isegmi_engine* e, const char* name, void** d_ptr, 
                               int32_t* dtype, int64_t* shape4, int32_t* ndim);
 /* device memory held by the engine: packed weights + constant tensors, and activation / workspace / output buffers (bytes) */
 int isegmi_engine_memory(isegmi_engine* e, int64_t* weight_bytes, int64_t* buffer_bytes);
+/* Diagnostic: which of the engine's ten streams (0 main, 1-3 side, 4 tail, 5 heads, 6-8 heads-side, 9 copy) share an in-order hardware queue of the
+ * runtime (equal class numbers = one queue; found by a spin-kernel probe, ~2 ms; call on an idle engine).  An engine's throughput depends on this
+ * placement, which the runtime derives from the process's stream-creation history. */
+int isegmi_engine_stream_layout(isegmi_engine* e, int32_t* queue_class, int n);
 /* per-stage hipEvent timings of the last synchronised forward (set_param "timing" 1 first) */
 int isegmi_engine_get_timings(isegmi_engine* e, char* names, int names_cap, float* ms, int ms_cap,
                               int* count);

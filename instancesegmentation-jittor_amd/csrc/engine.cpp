@@ -706,14 +706,66 @@ int yolact_postprocess(Engine& e, int h, int w, const int32_t* h_image_hw) {
 
 using namespace isegmi;
 
+// ---- which of the engine's streams share an in-order hardware queue?  The runtime folds a process's streams onto GPU_MAX_HW_QUEUES (4) queues by
+// what the process has created so far; two streams of one queue serialise although the stream-level program says they may overlap (DESIGN section 4,
+// "Streams against four in-order hardware queues").  Probe: a one-wave kernel spins ~40 us on stream a, an empty kernel follows on stream b; b's
+// kernel ends before a's only if the two sit on different queues.  Streams are classed against one representative per class found so far.
+namespace {
+__global__ void probe_spin_kernel(long long cycles, int* sink) {
+    const long long t0 = clock64();
+    while (clock64() - t0 < cycles) {}
+    if (sink && cycles < 0) *sink = 1;
+}
+__global__ void probe_nop_kernel(int* sink) { if (sink && sink[0] == 0x7fffffff) sink[0] = 0; }
+
+int same_queue_once(hipStream_t a, hipStream_t b, bool* same) {
+    hipEvent_t s, ea, eb;
+    HIP_TRY(hipEventCreate(&s)); HIP_TRY(hipEventCreate(&ea)); HIP_TRY(hipEventCreate(&eb));
+    HIP_TRY(hipStreamSynchronize(a)); HIP_TRY(hipStreamSynchronize(b));
+    HIP_TRY(hipEventRecord(s, a));
+    hipLaunchKernelGGL(probe_spin_kernel, dim3(1), dim3(64), 0, a, 100000LL, (int*)nullptr);   // ~40-50 us at 2.1-2.4 GHz
+    HIP_TRY(hipEventRecord(ea, a));
+    hipLaunchKernelGGL(probe_nop_kernel, dim3(1), dim3(64), 0, b, (int*)nullptr);
+    HIP_TRY(hipEventRecord(eb, b));
+    HIP_TRY(hipStreamSynchronize(a)); HIP_TRY(hipStreamSynchronize(b));
+    float ta = 0.0f, tb = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&ta, s, ea));
+    HIP_TRY(hipEventElapsedTime(&tb, s, eb));
+    *same = tb > 0.7f * ta;   // b's empty kernel finished only when the spin had: it queued behind it
+    (void)hipEventDestroy(s); (void)hipEventDestroy(ea); (void)hipEventDestroy(eb);
+    return ISEGMI_OK;
+}
+
+// A stream's FIRST launch pays for the lazy creation of its queue state (longer than the spin: a fresh stream then looks as if it had waited), and a
+// launch can be late for other reasons: both streams are warmed up first, and "same queue" needs two probes out of two to say so.
+int same_queue(hipStream_t a, hipStream_t b, bool* same) {
+    hipLaunchKernelGGL(probe_nop_kernel, dim3(1), dim3(64), 0, a, (int*)nullptr);
+    hipLaunchKernelGGL(probe_nop_kernel, dim3(1), dim3(64), 0, b, (int*)nullptr);
+    HIP_TRY(hipStreamSynchronize(a)); HIP_TRY(hipStreamSynchronize(b));
+    bool s1 = false, s2 = false;
+    int rc = same_queue_once(a, b, &s1);
+    if (rc) return rc;
+    if (s1) { rc = same_queue_once(a, b, &s2); if (rc) return rc; }
+    *same = s1 && s2;
+    return ISEGMI_OK;
+}
+}  // namespace
+
 // ---- process-wide pool of stream sets.  An engine BORROWS its ten streams (main, 3 side, tail, heads, 3 heads-side, copy) and hands them back
 // when it is destroyed; the next engine of the process gets the very same streams.  Why not create / destroy per engine: the runtime places a
 // new stream on one of its four in-order hardware queues by what the process has created (and destroyed) so far, and an engine's speed depends on
 // which of its streams end up sharing a queue -- Mask R-CNN bs=2 ran 220.0 img/s as the first engine of a process and 204.8 as the second, after a
 // Yolact engine had been created and closed (tools/second_engine_probe.py; the default bench.py line's embedded configs[2] figure was such a second
 // engine).  With the pool every engine that follows a closed one sees the first one's placement.  Engines alive at the same time get sets of their own.
+// Round 4: the ten streams are no longer "the next ten the runtime hands out".  Which hardware queue a new stream lands on depends on every
+// stream the process created before (a foreign HIP library, another engine), and the placement decides the throughput: measured with the probe
+// above (tools/stream_layout_probe.py, Yolact bs 8): 986 img/s whenever the MAIN stream's queue carries neither the tail, nor the heads, nor the
+// copy stream and the tail's queue carries neither of the other two; 922 with heads + copy on main's queue (one or three foreign streams created
+// first), 913 with the tail on it (four or five).  So a set is built from up to 24 CANDIDATE streams whose queues are probed, and the roles are
+// dealt by queue class to reproduce the layout a fresh process gets (classes A main / side0 / heads-side1, B side2 / tail / heads-side2,
+// C side1 / heads / copy, D heads-side0); candidates not needed stay idle in the set (destroying them would shift the next set's placement).
 namespace {
-struct StreamSet { int dev = 0; bool used = false; hipStream_t s[10] = {nullptr}; };
+struct StreamSet { int dev = 0; bool used = false; hipStream_t s[10] = {nullptr}; std::vector<hipStream_t> spare; int placed = 0; };
 std::mutex g_sets_mu;
 std::vector<StreamSet*> g_sets;
 
@@ -725,14 +777,57 @@ int acquire_streams(StreamSet** out) {
         if (!ss->used && ss->dev == dev) { ss->used = true; *out = ss; return ISEGMI_OK; }
     StreamSet* ss = new StreamSet();
     ss->dev = dev;
-    hipError_t er = hipStreamCreate(&ss->s[0]);
-    for (int i = 1; i < 10 && er == hipSuccess; ++i) er = hipStreamCreateWithFlags(&ss->s[i], hipStreamNonBlocking);
-    if (er != hipSuccess) {
-        for (int i = 0; i < 10; ++i) if (ss->s[i]) (void)hipStreamDestroy(ss->s[i]);
+    std::vector<hipStream_t> cand;
+    std::vector<int> cls;            // queue class of each candidate (0 = the first candidate's queue)
+    std::vector<int> rep;            // one candidate per class
+    auto fail = [&](hipError_t er) {
+        for (hipStream_t c : cand) (void)hipStreamDestroy(c);
         delete ss;
         set_error(std::string("hipStreamCreate: ") + hipGetErrorString(er));
         return ISEGMI_ERR_HIP;
+    };
+    // classes in order of discovery: A = the main stream's queue, B, C, D the next three.  Role -> preferred classes (first available wins):
+    //   main A | tail B | heads C, copy C (never A, never the tail's) | side0 -- the backbone's projection shortcuts -- D or A, never behind the tail
+    //   or the heads phase (942 / 920 img/s when it was; 988 on D, 979 on A) | side1 C, side2 B, heads-side D / A / B as in a fresh process
+    static const int pref[10][3] = {{0, 0, 0}, {3, 0, -1}, {2, 3, -1}, {1, 3, -1}, {1, -1, -1}, {2, -1, -1}, {3, 0, -1}, {0, 3, -1}, {1, 3, -1}, {2, -1, -1}};
+    const bool probe = getenv("ISEGMI_STREAM_PLACEMENT") == nullptr || atoi(getenv("ISEGMI_STREAM_PLACEMENT")) != 0;  // 0: the round-3 behaviour (A/B)
+    const int need[4] = {1, 3, 3, 3};   // (A often gets no second stream from the runtime: side0 / heads-side1 then take D)
+    int have[4] = {0, 0, 0, 0};
+    const int max_cand = probe ? 24 : 10;
+    while ((int)cand.size() < max_cand) {
+        hipStream_t st = nullptr;
+        hipError_t er = cand.empty() ? hipStreamCreate(&st) : hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        if (er != hipSuccess) return fail(er);
+        cand.push_back(st);
+        int c = -1;
+        if (probe) {
+            for (size_t r = 0; r < rep.size() && c < 0; ++r) {
+                bool same = false;
+                if (same_queue(cand[rep[r]], st, &same) != ISEGMI_OK) return fail(hipErrorUnknown);
+                if (same) c = (int)r;
+            }
+            if (c < 0) { c = (int)rep.size(); rep.push_back((int)cand.size() - 1); }
+        } else {
+            c = 0;
+        }
+        cls.push_back(c);
+        if (c < 4) ++have[c];
+        if (cand.size() >= 10 && (!probe || (have[0] >= need[0] && have[1] >= need[1] && have[2] >= need[2] && have[3] >= need[3]))) break;
     }
+    // deal the roles: a candidate of a preferred class if there is one left, else any left-over candidate (fewer than four queues, or an odd
+    // distribution: correct either way, only the overlap differs)
+    std::vector<bool> taken(cand.size(), false);
+    ss->placed = 1;
+    for (int i = 0; i < 10; ++i) {
+        int pick = -1;
+        if (i == 0) pick = 0;       // the one blocking stream is the main stream
+        for (int q = 0; q < 3 && pick < 0 && probe; ++q)
+            for (size_t j = 1; j < cand.size() && pick < 0; ++j) if (!taken[j] && pref[i][q] >= 0 && cls[j] == pref[i][q]) pick = (int)j;
+        for (size_t j = 1; j < cand.size() && pick < 0; ++j) if (!taken[j]) { pick = (int)j; if (probe) ss->placed = 0; }
+        taken[pick] = true;
+        ss->s[i] = cand[pick];
+    }
+    for (size_t j = 0; j < cand.size(); ++j) if (!taken[j]) ss->spare.push_back(cand[j]);
     ss->used = true;
     g_sets.push_back(ss);
     *out = ss;
@@ -747,6 +842,27 @@ void release_streams(StreamSet* ss) {
 }
 }  // namespace
 
+
+// queue_class[i] for the engine's ten streams (0 main, 1-3 side, 4 tail, 5 heads, 6-8 heads-side, 9 copy): equal numbers share a hardware queue.
+// Call on an idle engine (it synchronises the streams).
+extern "C" int isegmi_engine_stream_layout(isegmi_engine* h, int32_t* queue_class, int n) {
+    ARG_CHECK(h && queue_class && n >= 10, "stream_layout args");
+    StreamSet* ss = (StreamSet*)h->e.stream_set;
+    ARG_CHECK(ss, "engine has no streams");
+    int reps[10], nrep = 0;
+    for (int i = 0; i < 10; ++i) {
+        int cls = -1;
+        for (int r = 0; r < nrep && cls < 0; ++r) {
+            bool same = false;
+            int rc = same_queue(ss->s[reps[r]], ss->s[i], &same);
+            if (rc) return rc;
+            if (same) cls = r;
+        }
+        if (cls < 0) { cls = nrep; reps[nrep++] = i; }
+        queue_class[i] = cls;
+    }
+    return ISEGMI_OK;
+}
 
 extern "C" int isegmi_engine_create(int model_kind, int max_batch, int H, int W, isegmi_engine** out) {
     ARG_CHECK(out, "null out");
