@@ -790,8 +790,13 @@ int acquire_streams(StreamSet** out) {
     //   main A | tail B | heads C, copy C (never A, never the tail's) | side0 -- the backbone's projection shortcuts -- D or A, never behind the tail
     //   or the heads phase (942 / 920 img/s when it was; 988 on D, 979 on A) | side1 C, side2 B, heads-side D / A / B as in a fresh process
     static const int pref[10][3] = {{0, 0, 0}, {3, 0, -1}, {2, 3, -1}, {1, 3, -1}, {1, -1, -1}, {2, -1, -1}, {3, 0, -1}, {0, 3, -1}, {1, 3, -1}, {2, -1, -1}};
+    int prefv[10][3];
+    memcpy(prefv, pref, sizeof(prefv));
+    if (const char* ov = getenv("ISEGMI_STREAM_LAYOUT")) {   // dev: ten class digits (0 = A .. 3 = D), role order main side0-2 tail heads hs0-2 copy
+        for (int i = 0; i < 10 && ov[i] >= '0' && ov[i] <= '3'; ++i) { prefv[i][0] = ov[i] - '0'; prefv[i][1] = prefv[i][2] = -1; }
+    }
     const bool probe = getenv("ISEGMI_STREAM_PLACEMENT") == nullptr || atoi(getenv("ISEGMI_STREAM_PLACEMENT")) != 0;  // 0: the round-3 behaviour (A/B)
-    const int need[4] = {1, 3, 3, 3};   // (A often gets no second stream from the runtime: side0 / heads-side1 then take D)
+    const int need[4] = {1, 4, 4, 4};   // (A often gets no second stream from the runtime: side0 / heads-side1 then take D)
     int have[4] = {0, 0, 0, 0};
     const int max_cand = probe ? 24 : 10;
     while ((int)cand.size() < max_cand) {
@@ -822,7 +827,7 @@ int acquire_streams(StreamSet** out) {
         int pick = -1;
         if (i == 0) pick = 0;       // the one blocking stream is the main stream
         for (int q = 0; q < 3 && pick < 0 && probe; ++q)
-            for (size_t j = 1; j < cand.size() && pick < 0; ++j) if (!taken[j] && pref[i][q] >= 0 && cls[j] == pref[i][q]) pick = (int)j;
+            for (size_t j = 1; j < cand.size() && pick < 0; ++j) if (!taken[j] && prefv[i][q] >= 0 && cls[j] == prefv[i][q]) pick = (int)j;
         for (size_t j = 1; j < cand.size() && pick < 0; ++j) if (!taken[j]) { pick = (int)j; if (probe) ss->placed = 0; }
         taken[pick] = true;
         ss->s[i] = cand[pick];
