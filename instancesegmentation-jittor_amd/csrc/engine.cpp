@@ -1064,12 +1064,9 @@ extern "C" int isegmi_engine_preprocess_u8(isegmi_engine* h, const uint8_t* d_u8
             OpScope op(e, e.copy, "front end (uint8 -> resize / normalise / pad -> fp32 input)", (double)src_bytes + (double)dst_bytes);
             TRY(preprocess_u8_launch(d_u8, N, Hin, Win, d_out, Hout, Wout, Hpad, Wpad, out_img_stride, mean3, std3, swap_rb, e.copy));
         }
-        // the copy stream is in order: this launch IS the consumer of the uploads into its source, so their entries are free again (left
-        // unconsumed, every re-allocated staging buffer pinned an entry for good: "more than 64 upload destinations" after 64 growths)
-        for (auto& u : e.uploads) {
-            const char* p = (const char*)d_u8;
-            if (!u.waited && p < u.dst + u.bytes && u.dst < p + src_bytes) u.waited = true;
-        }
+        // (The source's upload entry stays UNCONSUMED: a batch is several launches over one staging buffer -- one per image of a Mask R-CNN batch --
+        // and every one of them must find it and stay on the copy stream; marking it consumed here sent image 2 of a batch to the main stream,
+        // ahead of its H2D copy.  A staging buffer that is re-allocated goes through sync(), which clears every entry: nothing piles up.)
         return eng_note_upload(e, d_out, dst_bytes);
     }
     TRY(eng_wait_upload(e, d_u8, src_bytes, e.stream));

@@ -90,6 +90,38 @@ def test_maskrcnn_upload_u8_equals_prepare_images():
     net.close()
 
 
+def test_maskrcnn_async_front_end_of_every_image_waits_for_its_upload():
+    """A Mask R-CNN batch is ONE upload of the images back to back and one front-end launch PER IMAGE; every one of them has to run behind the
+    H2D copy.  (Round 4 regression: the first launch marked the upload consumed, the second image's launch went to the main stream ahead of the
+    copy and transformed whatever the staging buffer held before.)  Made deterministic: a 256 MB upload to a scratch buffer is queued on the copy
+    stream first, so the batch's own copy is late; the staging buffer still holds the PREVIOUS batch."""
+    from isegmi import _ffi
+    from isegmi.maskrcnn import MaskRCNN, MaskRCNNConfig, prepare_images
+    from isegmi.weights import maskrcnn_state_dict
+    import ctypes as C
+    rng = np.random.default_rng(8)
+    old = [rng.integers(0, 256, (200, 333, 3), dtype=np.uint8) for _ in range(2)]
+    new = [rng.integers(0, 256, (200, 333, 3), dtype=np.uint8) for _ in range(2)]
+    ref, hw = prepare_images([im.astype(np.float32) for im in new])
+    net = MaskRCNN(maskrcnn_state_dict(1234, 50), ref.shape[1], ref.shape[2], cfg=MaskRCNNConfig(depth=50), max_batch=2)
+    pin = _ffi.PinnedBuffer((2 * 200 * 333 * 3,), np.uint8)
+    big_h = _ffi.PinnedBuffer((256 << 20,), np.uint8)
+    big_d = _ffi.DeviceBuffer((256 << 20,), np.uint8)
+    for rep in range(3):
+        pin.array[...] = np.concatenate([im.reshape(-1) for im in old])
+        net.upload_u8_async(pin, hw, 0); net.sync()                      # the staging buffer now holds the old batch
+        pin.array[...] = np.concatenate([im.reshape(-1) for im in new])
+        _ffi.check(_ffi.lib().isegmi_engine_upload_async(net._h, big_d.ptr, big_h.ptr, C.c_int64(big_h.nbytes)))   # keeps the copy stream busy
+        net.upload_u8_async(pin, hw, 0)
+        net.forward_device(2)                                             # (orders the main stream behind the front end, as in the product loop)
+        net.sync()
+        got = _fetch_input(net, 2, ref.shape[1:])
+        assert np.array_equal(got[0], ref[0]), rep
+        assert np.array_equal(got[1], ref[1]), "image 2 of the batch was transformed before its upload had landed (rep %d)" % rep
+    pin.free(); big_h.free(); big_d.free()
+    net.close()
+
+
 def test_upload_u8_rejects_float_input():
     from isegmi.maskrcnn import MaskRCNN, MaskRCNNConfig
     from isegmi.weights import maskrcnn_state_dict, yolact_state_dict
