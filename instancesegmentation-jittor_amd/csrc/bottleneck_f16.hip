@@ -48,7 +48,8 @@ struct BtlK {
     int N, H, W;                 // x is [N][H][W][CIN]; the output has the same H x W (stride 1)
     int tiles_x, tiles_y, total;
     unsigned x_bytes, out_bytes, res_bytes, w1_bytes, w2_bytes, w3_bytes, wd_bytes;
-    int exp_flags;  // TIMING-ONLY experiments: 32 the loader waves issue nothing, 64 the MFMA waves only keep the barriers
+    int exp_flags;  // TIMING-ONLY experiments: 32 the loader waves issue nothing, 64 the MFMA waves only keep the barriers;
+                    // 128 / 256 / 512 / 1024 / 2048 / 4096: the MFMA waves skip conv1's K loop / its epilogue / conv2's K loop / its epilogue / conv3's K loop / its epilogue
 };
 
 // DS: the block has a PROJECTION shortcut (first block of res2: CIN = 64 -> COUT = 256, stride 1): the residual is
@@ -356,7 +357,7 @@ __global__ __launch_bounds__((CF::NW + CF::LW) * 64, 1) void bottleneck_f16_kern
                 for (int e = 0; e < 16; ++e) acc[b][e] = 0.0f;
             for (int kc = 0; kc < KC1; ++kc) {
                 asm volatile("s_barrier" ::: "memory");
-                if (act1) {  // uniform
+                if (act1 && !(p.exp_flags & 128)) {  // uniform
                     const char* sb = ring + st * STAGEB;
 #pragma unroll
                     for (int ks = 0; ks < 4; ++ks) {
@@ -371,7 +372,7 @@ __global__ __launch_bounds__((CF::NW + CF::LW) * 64, 1) void bottleneck_f16_kern
                 }
                 next_stage();
             }
-            if (act1) {
+            if (act1 && !(p.exp_flags & 256)) {
                 const int j = wave * 32 + lr;
                 const int hy = j / HW2, hx = j - hy * HW2;
                 const bool in_img = (j < MH) & ((unsigned)(y0 - 1 + hy) < (unsigned)p.H) & ((unsigned)(x0 - 1 + hx) < (unsigned)p.W);
@@ -430,6 +431,7 @@ __global__ __launch_bounds__((CF::NW + CF::LW) * 64, 1) void bottleneck_f16_kern
             for (int u = 0; u < S2; ++u) {
                 asm volatile("s_barrier" ::: "memory");
                 const char* sb = ring + st * STAGEB;
+                if (p.exp_flags & 512) { next_stage(); continue; }
 #pragma unroll
                 for (int g = 0; g < G2; ++g) {
                     const int q = u * G2 + g, tap = q / KM, kc = q % KM;
@@ -452,6 +454,7 @@ __global__ __launch_bounds__((CF::NW + CF::LW) * 64, 1) void bottleneck_f16_kern
             asm volatile("s_barrier" ::: "memory");  // X: every wave has read t1 for the last time; t2 and the scratch overwrite it
 #pragma unroll
             for (int i = 0; i < NPW; ++i) {
+                if (p.exp_flags & 1024) break;
                 const int m = (wp2 + NWP * i) * 32 + lr;
                 const int swm = mid_sw<NCOL>(m);
 #pragma unroll
@@ -548,6 +551,7 @@ __global__ __launch_bounds__((CF::NW + CF::LW) * 64, 1) void bottleneck_f16_kern
             for (int kc = 0; kc < KM; ++kc) {
                 asm volatile("s_barrier" ::: "memory");
                 const char* sb = ring + st * STAGEB;
+                if (p.exp_flags & 2048) { next_stage(); continue; }
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     f16x8 af[TM3], bf[2];
@@ -565,6 +569,7 @@ __global__ __launch_bounds__((CF::NW + CF::LW) * 64, 1) void bottleneck_f16_kern
             }
 #pragma unroll
             for (int a = 0; a < TM3; ++a) {
+                if (p.exp_flags & 4096) break;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {  // accumulator registers 4g..4g+3 = tile rows 8g + (0..3) + 4 * (lane >> 5)
                     const int q = a * 4 + g;
@@ -658,7 +663,7 @@ int bottleneck_f16_launch(const isegmi_bottleneck_desc* d, const void* x, const 
     if (d->flags & 4) k.res_bytes = 0;
     if (d->flags & 8) k.out_bytes = 0;
     if (d->flags & 16) k.w1_bytes = k.w2_bytes = k.w3_bytes = k.wd_bytes = 0;
-    k.exp_flags = d->flags & (32 | 64);
+    k.exp_flags = d->flags & (32 | 64 | 128 | 256 | 512 | 1024 | 2048 | 4096);
     if (ds) return launch_btl<BtlCfg<64, 64, 8, 16, true>>(k, st, few);
     if (d->Cin == 256) return launch_btl<BtlCfg<256, 64, 8, 16>>(k, st, few);
     return launch_btl<BtlCfg<512, 128, 8, 14>>(k, st, few);

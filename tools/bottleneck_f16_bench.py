@@ -41,7 +41,9 @@ for (N, H, W, Cin, Cmid) in [(8, 200, 336, 256, 64), (8, 100, 168, 512, 128), (2
 
     if os.environ.get("VARIANTS"):
         line = "N%d %dx%d C%d:" % (N, H, W, Cin)
-        for name, fl_ in (("full", 0), ("no x", 2), ("no res", 4), ("no store", 8), ("no w", 16), ("no x/res", 6), ("no x/res/store", 14), ("no mem", 30), ("no mem, loaders idle", 30 | 32), ("no mem, mfma idle", 30 | 64), ("mfma idle (loads real)", 64)):
+        for name, fl_ in (("full", 0), ("no x", 2), ("no res", 4), ("no store", 8), ("no w", 16), ("no x/res", 6), ("no x/res/store", 14), ("no mem", 30), ("no mem, loaders idle", 62), ("no mem, mfma idle", 30 | 64), ("mfma idle (loads real)", 64),
+                          ("no mem -c1", 62 | 128), ("no mem -e1", 62 | 256), ("no mem -c2", 62 | 512), ("no mem -e2", 62 | 1024), ("no mem -c3", 62 | 2048), ("no mem -e3", 62 | 4096),
+                          ("no mem only barriers+e3", 62 | 128 | 256 | 512 | 1024 | 2048), ("no mem no phases", 62 | 128 | 256 | 512 | 1024 | 2048 | 4096)):
             bd.flags = fl_
             line += "  %s %.3f" % (name, timeit(fused) * 1e3)
         bd.flags = 0
