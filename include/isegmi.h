@@ -59,7 +59,7 @@ typedef struct isegmi_conv_desc {
                                         13 / 14: hybrid launch -- v2 tiles (loads 2 / 4 ahead) on the rows that fill the CUs a whole number of times, 32x32 blocks on the left-over rows (the default for 513-2600-tile grids with a small left-over);
                                         fp16: 1: 256x256  2: 256x128  3: 128x128  4: 64x64  5: 64x128  6: 64x256  7: 128x256  8: 128x64  9: 192x256  10: 192x128  11: 160x256;
                                         12/13/14/16: 192x256, 256x256, 256x128, 160x256 with 4 loader waves, 17: 192x256 as 12 MFMA + 4 loader waves, 19: 128x256 + 4, 20: 192x128 as 6 + 2;
-                                        26/27/28/29: row-strip kernel for 3x3/1/1 (192x256, 256x128, 160x256, 192x256 on 12 MFMA waves) with 4 loader waves;
+                                        26/27/28/29: row-strip kernel for 3x3/1/1 (192x256, 256x128, 160x256, 192x256 on 12 MFMA waves) with 4 loader waves; 30/31: 29/26 with three B chunk buffers;
                                         32/34/37/39: persistent forms of 12/14/17/19 (a block walks several tiles, the loader waves stream the next tile during the epilogue);
                                         + 2048 (test hook): persistent kernels on an 8-block grid */
     int32_t out_div;                 /* output pixels per "image" for addressing; 0 -> Ho*Wo */

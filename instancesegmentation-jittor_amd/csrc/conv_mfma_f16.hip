@@ -62,6 +62,10 @@ struct ConvKH {
     int act, out_div, contiguous, out_f32, vec_epi;
     int64_t out_img_stride, out_pix_stride;
     int mtiles, ntiles;
+#ifdef ISEGMI_STRIP_TRACE
+    unsigned* trace;
+#endif
+    int dbg;  // TIMING-ONLY experiments (tile bit 4096): strip kernel loaders stop after the first two groups
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -754,8 +758,26 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, OCC) void conv_f16_persist_ker
 // Step u = (r, kc, s), s fastest: A strips are double-buffered per (r, kc) group and filled a third per step, B chunks
 // double-buffered per step; every step starts with `s_waitcnt vmcnt(0); s_barrier`.  K is walked as (r, kc, s) instead of
 // (r, s, kc): fp32 accumulation order differs from the generic kernel within the stated fp16 tolerance.
-template <int BM, int BN, int WM, int WN, int LW>
+// NB = 3 (round 4, loader-wave form only): THREE B buffers.  With two, a step's loads are issued after its opening barrier and must ALL have landed at the
+// next one; with three, step u issues its third of the next strip FIRST and then the B chunk of step u + 2 into the buffer step u - 1 read, and the wait in
+// front of the next barrier leaves exactly those B pieces in flight (`vmcnt(RB)`, in-order completion).  Worth +3 % on the 634-GF layer and no more: with
+// the loaders stopped after two groups (tile bit 4096) the kernel is only 8 % faster, and in a loop it holds the package at 1381 of its 1400 W
+// (profiles/r04_f16_power.txt): these layers are bound by the power cap, not by a pipe.  LDS: 2 strips + 3 B chunks = 163 840 B, all there is.
+#ifdef ISEGMI_STRIP_TRACE
+// development build only (-DISEGMI_STRIP_TRACE, tools/strip_trace.py): block 0 keeps four cycle stamps per step and wave in LDS behind the staging buffers and dumps them to p.trace
+#define STRIP_TRACE(u, slot)                                                                                      \
+    do {                                                                                                          \
+        if (bid == 0 && (u) < 64 && !(p.dbg & 16)) {                                                              \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                           \
+            *(volatile unsigned*)(smemg + TRACE_OFF + ((wave * 64 + (u)) * 4 + (slot)) * 4) = (unsigned)t_;        \
+        }                                                                                                         \
+    } while (0)
+#else
+#define STRIP_TRACE(u, slot) do {} while (0)
+#endif
+template <int BM, int BN, int WM, int WN, int LW, int NB = 2>
 __global__ __launch_bounds__((WM * WN + LW) * 64, 1) void conv3x3_f16_strip_kernel(const ConvKH p) {
+    static_assert(NB == 2 || (NB == 3 && LW > 0 && (BN / 8) % LW == 0), "the three-buffer form needs loader waves and whole B piece rounds");
     constexpr int NW = WM * WN;
     constexpr int NL = LW > 0 ? LW : NW;            // waves that issue loads (LW > 0: dedicated loader waves, see above)
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -764,6 +786,8 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, 1) void conv3x3_f16_strip_kern
     constexpr int SP3 = (SP + 2) / 3;               // strip pieces issued per step (a third of the strip)
     constexpr int RA = (SP3 + NL - 1) / NL, RB = (PB + NL - 1) / NL;  // piece rounds per loading wave and step
     constexpr int ABYTES = SR_CAP * 128, BBYTES = BN * 128;
+    constexpr int TRACE_OFF = 2 * ABYTES + NB * BBYTES;
+    (void)TRACE_OFF;
     extern __shared__ __attribute__((aligned(1024))) char smemg[];  // [A strip 0][A strip 1][B 0][B 1]
 
     const int tid = threadIdx.x;
@@ -867,7 +891,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, 1) void conv3x3_f16_strip_kern
     auto issue_b = [&](int bb) {
         if (b_u >= nsteps) return;
         const unsigned koff = (unsigned)(((b_r * 3 + b_s) * p.cin_chunks + b_kc) * 128);
-        char* dst = smemg + 2 * ABYTES + bb * BBYTES;
+        char* dst = smemg + 2 * ABYTES + bb * BBYTES;   // bb: 0 .. NB - 1
 #pragma unroll
         for (int j = 0; j < RB; ++j) {
             if (PB % NL != 0 && lw + j * NL >= PB) continue;
@@ -904,27 +928,51 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, 1) void conv3x3_f16_strip_kern
     const int swzb = lr * 128 + ((lh ^ ((lr >> 1) & 7)) << 4);
     const int b_off = 2 * ABYTES + wn * TN * 32 * 128;
 
-    // prologue: whole strip of group 0, B of step 0
+    // prologue: whole strip of group 0, B of step 0 (and of step 1 with three B buffers)
     if (loads) {
         issue_strip(0, 0); issue_strip(1, 0); issue_strip(2, 0);
         next_group();
         issue_b(0);
         next_b();
+        if (NB == 3) { issue_b(1); next_b(); }
     }
+#ifdef ISEGMI_STRIP_TRACE
+    unsigned long long tr_c0 = 0, tr_r0 = 0;
+    if (bid == 0) { tr_c0 = __builtin_amdgcn_s_memtime(); tr_r0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
     if (LW > 0) conv_f16_role_prio(wave >= NW);
     if (LW > 0 && wave >= NW) {  // loader wave: the MFMA waves' barrier sequence, loads only
         int u = 0;
         for (int gi = 0; gi < ngroups; ++gi) {
+            if ((p.dbg & 1) && gi >= 2) { b_u = nsteps + 1; s_gi = ngroups; }
 #pragma unroll
             for (int s = 0; s < 3; ++s, ++u) {
-                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-                issue_b((u + 1) & 1);
-                next_b();
-                issue_strip(s, (gi + 1) & 1);
+                if (NB == 3) {
+                    // landed: B(u) (issued two steps ago) and the strip third of the previous step; the B pieces issued last step (B(u + 1)) may still fly.
+                    // Once no B chunk is left to issue (the last two steps) nothing younger covers the older pieces: drain.
+                    if (b_u <= nsteps) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(RB) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                    issue_strip(s, (gi + 1) & 1);   // first: it has to be down at the NEXT barrier
+                    issue_b(s == 0 ? 2 : s - 1);     // B(u + 2) -> buffer (u + 2) % 3 = (s + 2) % 3 (u = 3 gi + s), which step u - 1 read
+                    next_b();
+                } else {
+                    STRIP_TRACE(u, 0);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    STRIP_TRACE(u, 1);
+                    asm volatile("s_barrier" ::: "memory");
+                    STRIP_TRACE(u, 2);
+                    issue_b((u + 1) & 1);
+                    next_b();
+                    issue_strip(s, (gi + 1) & 1);
+                    STRIP_TRACE(u, 3);
+                }
             }
             next_group();
         }
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef ISEGMI_STRIP_TRACE
+        if (bid == 0 && p.trace) for (int i = lane; i < 256; i += 64) p.trace[wave * 256 + i] = *(volatile unsigned*)(smemg + TRACE_OFF + (wave * 256 + i) * 4);
+#endif
         return;
     }
     // unrolled over two groups so that both LDS stages are compile-time terms (A buffer = gi & 1, B buffer = (gi + s) & 1, because
@@ -936,9 +984,11 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, 1) void conv3x3_f16_strip_kern
             const char* sa = smemg + gg * ABYTES;
 #pragma unroll
             for (int s = 0; s < 3; ++s) {
+                STRIP_TRACE((g0 + gg) * 3 + s, 0);
                 if (LW == 0) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
                 else asm volatile("s_barrier" ::: "memory");
-                const int ub = (gg + s) & 1;
+                STRIP_TRACE((g0 + gg) * 3 + s, 1);
+                const int ub = NB == 3 ? s : (gg + s) & 1;   // step u = 3 gi + s: u % 3 = s
                 const char* sb = smemg + b_off + ub * BBYTES;
                 f16x8 fa[2][TM], fb[2][TN];
 #pragma unroll
@@ -965,21 +1015,58 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, 1) void conv3x3_f16_strip_kern
         }
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    STRIP_TRACE(63, 0);
     conv_f16_epilogue<TM, TN>(p, acc, smemg, wave, lane, wm, wn, m0, n0);
+    STRIP_TRACE(63, 1);
+#ifdef ISEGMI_STRIP_TRACE
+    if (bid == 0 && p.trace && wave == 0 && lane == 0) {
+        const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        p.trace[4096] = (unsigned)(c1 - tr_c0); p.trace[4097] = (unsigned)(r1 - tr_r0);
+    }
+    if (bid == 0 && p.trace) for (int i = lane; i < 256; i += 64) p.trace[wave * 256 + i] = *(volatile unsigned*)(smemg + TRACE_OFF + (wave * 256 + i) * 4);
+#endif
 }
 
-template <int BM, int BN, int WM, int WN, int LW = 0>
+template <int BM, int BN, int WM, int WN, int LW = 0, int NB = 2>
 static int launch_strip(ConvKH& k, hipStream_t st) {
     k.mtiles = cdiv(k.M, BM);
     k.ntiles = cdiv(k.Cout, BN);
     constexpr int NW = WM * WN, TN = BN / WN / 32;
-    size_t lds = 2 * (size_t)(BM + 64) * 128 + 2 * (size_t)BN * 128;
+    size_t lds = 2 * (size_t)(BM + 64) * 128 + NB * (size_t)BN * 128;
+    static_assert(2 * (BM + 64) * 128 + NB * BN * 128 <= 163840, "LDS");
     const size_t epi = (size_t)NW * 32 * (TN * 32 + 4) * 4;
     if (epi > lds) lds = epi;
+    size_t lds_attr = lds;
+#ifdef ISEGMI_STRIP_TRACE
+    if (NB == 2) lds_attr = lds + 16384;
+    static unsigned* trace_buf = nullptr;
+    const bool tracing = NB == 2 && getenv("ISEGMI_STRIP_TRACE_DUMP") != nullptr;   // (NB = 3 fills the LDS: no room for the stamps)
+    if (tracing) {
+        lds = 2 * (size_t)(BM + 64) * 128 + NB * (size_t)BN * 128 + 16384;
+        if (!trace_buf) HIP_TRY(hipMalloc((void**)&trace_buf, 16448));
+        HIP_TRY(hipMemsetAsync(trace_buf, 0, 16448, st));
+    }
+    k.trace = tracing ? trace_buf : nullptr;
+    if (tracing && getenv("ISEGMI_STRIP_TRACE_LIGHT")) k.dbg |= 16;
+#endif
     static bool attr = false;
-    if (!attr) { HIP_TRY(hipFuncSetAttribute((const void*)conv3x3_f16_strip_kernel<BM, BN, WM, WN, LW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
-    hipLaunchKernelGGL((conv3x3_f16_strip_kernel<BM, BN, WM, WN, LW>), dim3((unsigned)(k.mtiles * k.ntiles)), dim3((NW + LW) * 64), lds, st, k);
+    if (!attr) { HIP_TRY(hipFuncSetAttribute((const void*)conv3x3_f16_strip_kernel<BM, BN, WM, WN, LW, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_attr)); attr = true; }
+    hipLaunchKernelGGL((conv3x3_f16_strip_kernel<BM, BN, WM, WN, LW, NB>), dim3((unsigned)(k.mtiles * k.ntiles)), dim3((NW + LW) * 64), lds, st, k);
     HIP_TRY(hipGetLastError());
+#ifdef ISEGMI_STRIP_TRACE
+    if (tracing) {
+        static unsigned host[4112];
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipMemcpy(host, trace_buf, 16448, hipMemcpyDeviceToHost));
+        FILE* f = fopen(getenv("ISEGMI_STRIP_TRACE_DUMP"), "w");
+        if (f) {
+            fprintf(f, "-1 -1 %u %u 0 0\n", host[4096], host[4097]);
+            for (int w = 0; w < NW + LW; ++w)
+                for (int u = 0; u < 64; ++u) fprintf(f, "%d %d %u %u %u %u\n", w, u, host[(w * 64 + u) * 4], host[(w * 64 + u) * 4 + 1], host[(w * 64 + u) * 4 + 2], host[(w * 64 + u) * 4 + 3]);
+            fclose(f);
+        }
+    }
+#endif
     return ISEGMI_OK;
 }
 
@@ -1073,6 +1160,7 @@ int conv2d_f16_launch(const isegmi_conv_desc* d, const void* in, const void* w, 
     if (tile & 256) { k.in_bytes = 0; k.w_bytes = 0; }
     if (tile & 512) k.in_bytes = 0;
     if (tile & 1024) k.w_bytes = 0;
+    k.dbg = (tile & 4096) ? 1 : 0;
     const bool few = (tile & 2048) != 0;  // TEST HOOK: persistent kernels run on an 8-block grid (multi-tile blocks on small shapes)
     tile &= 255;  // (bits 256 / 512 / 1024: TIMING-ONLY experiments, every A / B load dropped by the range check)
     if (stem) {
@@ -1095,11 +1183,12 @@ int conv2d_f16_launch(const isegmi_conv_desc* d, const void* in, const void* w, 
             {32, 192, 256, 1, 0.929, 447}, {34, 256, 128, 1, 1.043, 127}, {37, 192, 256, 1, 1.197, 83}, {39, 128, 256, 1, 1.032, 99},
             // row-strip variants (3x3 / stride 1 / pad 1 only: ~2.7x fewer A bytes through the CU's fill path) + 4 loader waves; measured
             // level with tile 37 on every 3x3 layer of the sweep
-            {26, 192, 256, 1, 1.18, 83}, {27, 256, 128, 1, 1.03, 127}, {28, 160, 256, 1, 0.5, 200}, {29, 192, 256, 1, 1.21, 83}};
+            {26, 192, 256, 1, 1.18, 83}, {27, 256, 128, 1, 1.03, 127}, {28, 160, 256, 1, 0.5, 200}, {29, 192, 256, 1, 1.21, 83},
+            {30, 192, 256, 1, 1.24, 83}};  // 29 with three B buffers (round 4): +3 % on the big layers, never slower (tools/conv_f16_bench.py)
         const bool strip_ok = d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1;
         double best = 0.0;
         for (const auto& t : T) {
-            if (t.id >= 26 && t.id <= 29 && !(strip_ok && (t.bm - 1) / d->W + 2 <= 32)) continue;
+            if (t.id >= 26 && t.id <= 31 && !(strip_ok && (t.bm - 1) / d->W + 2 <= 32)) continue;
             const int64_t blocks = (int64_t)cdiv(k.M, t.bm) * cdiv(d->Cout, t.bn);
             int64_t per_cu = (blocks + 255) / 256;
             if (t.occ > 1 && blocks <= 256 * t.occ) per_cu = blocks < t.occ ? blocks : t.occ;
@@ -1107,14 +1196,16 @@ int conv2d_f16_launch(const isegmi_conv_desc* d, const void* in, const void* w, 
             if (tile == 0 || c < best) { best = c; tile = t.id; }
         }
     }
-    if (tile >= 26 && tile <= 29) {
+    if (tile >= 26 && tile <= 31) {
         ARG_CHECK(d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1, "strip tiles are for 3x3 / stride 1 / pad 1");
-        const int bm = (tile == 26 || tile == 29) ? 192 : tile == 27 ? 256 : 160;
+        const int bm = tile == 27 ? 256 : tile == 28 ? 160 : 192;
         ARG_CHECK((bm - 1) / d->W + 2 <= 32, "strip tile: too many image-row segments (W too small)");
         switch (tile) {  // row strips + 4 loader waves
             case 26: return launch_strip<192, 256, 2, 4, 4>(k, st);
             case 27: return launch_strip<256, 128, 4, 2, 4>(k, st);
             case 29: return launch_strip<192, 256, 3, 4, 4>(k, st);  // 12 MFMA waves (64x64 each) + 4 loader waves
+            case 30: return launch_strip<192, 256, 3, 4, 4, 3>(k, st);  // the same with three B buffers and a counted wait (round 4)
+            case 31: return launch_strip<192, 256, 2, 4, 4, 3>(k, st);  // 8 MFMA waves (96x64 each), three B buffers
             default: return launch_strip<160, 256, 1, 8, 4>(k, st);
         }
     }

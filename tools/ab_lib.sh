@@ -1,9 +1,12 @@
 #!/bin/bash
-# Same-box A/B of two builds of libisegmi.so through bench.py: tools/ab_lib.sh <other/libisegmi.so> <bench args...>
-set -e
-other=$1; shift
+# same-box A/B of two builds of libisegmi.so on the R101 fp16 bs 8 bench: tools/ab_lib.sh <other lib> <outdir>  (two runs each, alternating)
+other=$1; out=${2:-gpurun_out/ab}; mkdir -p $out
 for rep in 1 2; do
-  for lib in "" "$other"; do
-    ISEGMI_LIB=$lib python bench.py "$@" --steps 40 --warmup 10 --no-cpu-baseline --no-latency --no-h2d 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%-50s value %.1f e2e %.1f conv ms/step %.3f frac %.4f' % ('${lib:-current build}', d['value'], d.get('value_e2e', 0), d['roofline']['conv_ms_per_step'], d['roofline']['frac']))"
-  done
+  ISEGMI_LIB=$other timeout -k 10 300 python bench.py --model maskrcnn --depth 101 --fp16 --batch 8 --no-cpu-baseline --no-latency --no-h2d --no-e2e > $out/other_$rep.json 2> $out/other_$rep.err || exit 1
+  timeout -k 10 300 python bench.py --model maskrcnn --depth 101 --fp16 --batch 8 --no-cpu-baseline --no-latency --no-h2d --no-e2e > $out/this_$rep.json 2> $out/this_$rep.err || exit 1
 done
+python - <<PY
+import json, glob
+for f in sorted(glob.glob("$out/*.json")):
+    j = json.loads(open(f).read().strip().splitlines()[-1]); print(f, j["value"], j["roofline"]["frac"], j["roofline"]["achieved"])
+PY

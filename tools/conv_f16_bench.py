@@ -21,7 +21,7 @@ for si, (N, H, W, Cin, Cout, R, st, pad) in enumerate(shapes):
     fl = 2.0 * N * ho * wo * Cout * R * R * Cin
     line = "N%d %dx%d Cin%d Cout%d %dx%d/%d  %.1f GF:" % (N, H, W, Cin, Cout, R, R, st, fl / 1e9)
     for tile in TILES:
-        if 26 <= (tile & 255) <= 29 and not (R == 3 and st == 1 and pad == 1):
+        if 26 <= (tile & 255) <= 31 and not (R == 3 and st == 1 and pad == 1):
             continue
         d = _ffi.make_conv_desc(N, H, W, Cin, Cout, R, R, st, pad, 1, tile)
         dx = _ffi.DeviceBuffer.from_numpy(x); dw = _ffi.DeviceBuffer.from_numpy(_ffi.pack_conv_weights_f16(d, w)); do = _ffi.DeviceBuffer((N, ho, wo, Cout), np.float16); dr = _ffi.DeviceBuffer((N, ho, wo, Cout), np.float16)
