@@ -106,6 +106,12 @@ int isegmi_op_bottleneck_ds_f16(const isegmi_bottleneck_desc* d, const void* d_x
  * size; d_in of isegmi_op_conv2d_f16 is then the haloed fp16 image [N][H+6][(W+7)&~1][4] this op writes from the fp32
  * NHWC C=3 batch (3 zero pixels on every side, zero 4th channel); weights are given as [Cout][7][7][4]. */
 int isegmi_op_pad_c3_to_f16_halo(const float* d_in_nhwc3, int N, int H, int W, void* d_out, void* stream);
+/* The whole stem in one launch (csrc/stem_pool_f16.hip): out = maxpool3x3/2/1(relu(bn(conv7x7/2/3(image)))) from the haloed image above, the packed
+ * stem weights (isegmi_pack_conv_weights_f16 of the Cin=4 R=S=7 desc, Cout = 64) and the folded FrozenBN; d_out = [N][Hp][Wp][64] fp16 with
+ * Hc = (H - 1) / 2 + 1, Hp = (Hc - 1) / 2 + 1.  Bit-identical to isegmi_op_conv2d_f16 (act 1) followed by the engine's fp16 max-pool (3, 2, 1; a max of fp16 values is exact);
+ * the conv output stays in LDS.  flags (test hooks): bit 0: 8-block grid (blocks walk many units); bit 1: the shortest units (every seam between row segments). */
+int isegmi_op_stem_pool_f16(int N, int H, int W, const void* d_halo, const void* d_w, const float* d_scale, const float* d_shift, void* d_out,
+                            int flags, void* stream);
 
 /* device front end (Y1 FastBaseTransform, README.md:243-249 `--image=...`; M1 build_transform + to_image_list, README.md:320-331): a uint8
  * [N][Hin][Win][3] batch -> fp32 NHWC3 [N][Hpad][Wpad][3]: bilinear (align_corners = False) to Hout x Wout (identity when the sizes match),

@@ -158,6 +158,41 @@ int eng_bottleneck_f16(Engine& e, const std::string& block, const Tensor& x, boo
     return ISEGMI_OK;
 }
 
+// fp16 stem conv + BN + ReLU + 3x3/2 max-pool as ONE launch (csrc/stem_pool_f16.hip); *fused = false (nothing launched) when the layer is not the 64-channel
+// stem or `fused_stem` is 0 (A/B against the two launches)
+int eng_stem_pool_f16(Engine& e, const std::string& layer, const Tensor& halo, int H, int W, const std::string& out_name, Tensor* out, bool* fused) {
+    *fused = false;
+    if (e.param("fused_stem", 1.0f) == 0.0f || halo.dt != 1) return ISEGMI_OK;
+    auto it = e.convs.find(layer);
+    if (it == e.convs.end()) return ISEGMI_OK;
+    const ConvLayer& L = it->second;
+    if (!L.f16 || L.Cin != 4 || L.R != 7 || L.S != 7 || !stem_pool_f16_supported(L.Cout) || !L.d_scale || !L.d_shift) return ISEGMI_OK;
+    const int Hc = (H + 6 - 7) / 2 + 1, Wc = (W + 6 - 7) / 2 + 1, Hp = (Hc + 2 - 3) / 2 + 1, Wp = (Wc + 2 - 3) / 2 + 1;
+    int rc = eng_act(e, out_name, halo.N, Hp, Wp, L.Cout, out, 1);
+    if (rc) return rc;
+    hipEvent_t a = nullptr, b = nullptr;
+    if (e.conv_timing) {
+        HIP_TRY(hipEventCreate(&a));
+        HIP_TRY(hipEventCreate(&b));
+        HIP_TRY(hipEventRecord(a, e.cur));
+    }
+    const int M = halo.N * Hc * Wc;
+    if (e.conv_trace) fprintf(stderr, "convlaunch\t%s.fused\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\n", layer.c_str(), halo.N, H, W, 4, L.Cout, 7, 2, M, 1);
+    rc = stem_pool_f16_launch(halo.N, H, W, halo.d, L.d_w, L.d_scale, L.d_shift, out->d, 0, e.cur);
+    if (rc) return rc;
+    if (e.conv_timing) {
+        HIP_TRY(hipEventRecord(b, e.cur));
+        e.conv_evs.push_back({a, b});
+        const double fl = 2.0 * M * 147.0 * L.Cout;   // the convolution's algorithmic FLOPs (7 x 7 x 3 taps), as the unfused layer counts them
+        e.conv_flops_pending += fl;
+        char geo[160];
+        snprintf(geo, sizeof(geo), "%s.fused [M=%d K=196 Cout=%d 7x7/2 + maxpool 3x3/2]", layer.c_str(), M, L.Cout);
+        e.conv_ev_info.push_back({geo, fl});
+    }
+    *fused = true;
+    return ISEGMI_OK;
+}
+
 // fp16 stem: `halo` is the [N][H+6][(W+7)&~1][4] fp16 image of pad_c3_to_f16_halo; H, W the image size
 int eng_conv_stem_f16(Engine& e, const std::string& layer, const Tensor& halo, int H, int W, const std::string& out_name, Tensor* out) {
     const ConvLayer* L;
@@ -387,6 +422,7 @@ int yolact_forward(Engine& e, const float* d_images, int N) {
     if (dt && e.convs.count("prediction_layers.0.head_cat") == 0) { set_error("fp16 Yolact needs the fused prediction head"); return ISEGMI_ERR_STATE; }
     Tensor x4;
     Tensor s, x;
+    bool stem_fused = false;
     Tensor outs[5];
     const bool darknet = e.param("darknet", 0.0f) != 0.0f;  // yolact_darknet53_config: DarkNetBackbone([1, 2, 8, 8, 4]), selected layers 2-4
     if (darknet) {
@@ -421,14 +457,15 @@ int yolact_forward(Engine& e, const float* d_images, int N) {
         TRY(eng_act(e, "input4h", N, H + 6, (W + 7) & ~1, 4, &x4, 1));
         TRY(pad_c3_to_f16_halo_launch(d_images, N, H, W, x4.d, e.cur));
         TRY(eng_input_consumed(e));
-        TRY(eng_conv_stem_f16(e, "backbone.conv1", x4, H, W, "stem", &s));
+        TRY(eng_stem_pool_f16(e, "backbone.conv1", x4, H, W, "pool", &x, &stem_fused));
+        if (!stem_fused) TRY(eng_conv_stem_f16(e, "backbone.conv1", x4, H, W, "stem", &s));
     } else {
         TRY(eng_act(e, "input4", N, H, W, 4, &x4));
         TRY(pad_c3_c4_launch(d_images, (int64_t)N * H * W, x4.d, e.cur));
         TRY(eng_input_consumed(e));
         TRY(eng_conv(e, "backbone.conv1", x4, 2, 3, 1, nullptr, "stem", &s));
     }
-    {
+    if (!stem_fused) {
         const int Ho = (s.H + 2 - 3) / 2 + 1, Wo = (s.W + 2 - 3) / 2 + 1;
         TRY(eng_act(e, "pool", N, Ho, Wo, s.C, &x, dt));
         if (dt) TRY(maxpool_to_f16_launch(s.d, 1, N, s.H, s.W, s.C, 3, 2, 1, x.d, e.cur));

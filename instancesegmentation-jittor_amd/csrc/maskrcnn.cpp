@@ -106,18 +106,20 @@ int maskrcnn_forward(Engine& e, const float* d_images, int N) {
 
     const int dt = e.fp16 ? 1 : 0;  // storage type of everything after the stem
     Tensor x4, s, x;
+    bool stem_fused = false;
     if (dt) {  // fp16: images are rounded to fp16 into a zero-haloed 4-channel buffer the stem kernel reads without bounds tests
         TRY(eng_act(e, "input4h", N, H + 6, (W + 7) & ~1, 4, &x4, 1));
         TRY(pad_c3_to_f16_halo_launch(d_images, N, H, W, x4.d, st));
         TRY(eng_input_consumed(e));
-        TRY(eng_conv_stem_f16(e, "backbone.body.stem.conv1", x4, H, W, "stem", &s));
+        TRY(eng_stem_pool_f16(e, "backbone.body.stem.conv1", x4, H, W, "pool", &x, &stem_fused));   // conv + BN + ReLU + max-pool in one launch
+        if (!stem_fused) TRY(eng_conv_stem_f16(e, "backbone.body.stem.conv1", x4, H, W, "stem", &s));
     } else {
         TRY(eng_act(e, "input4", N, H, W, 4, &x4));
         TRY(pad_c3_c4_launch(d_images, (int64_t)N * H * W, x4.d, st));
         TRY(eng_input_consumed(e));
         TRY(eng_conv(e, "backbone.body.stem.conv1", x4, 2, 3, 1, nullptr, "stem", &s));
     }
-    {
+    if (!stem_fused) {
         const int Ho = (s.H + 2 - 3) / 2 + 1, Wo = (s.W + 2 - 3) / 2 + 1;
         TRY(eng_act(e, "pool", N, Ho, Wo, s.C, &x, dt));
         if (dt) TRY(maxpool_to_f16_launch(s.d, 1, N, s.H, s.W, s.C, 3, 2, 1, x.d, st));

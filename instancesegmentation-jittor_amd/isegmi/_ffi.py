@@ -427,6 +427,22 @@ def stem_f16(x_nhwc3, w_krs4, scale=None, shift=None, tile=0):
     return do.numpy(), dh.numpy()
 
 
+def stem_pool_f16(x_nhwc3, w_krs4, scale, shift, flags=0):
+    """The fp16 stem in one launch (isegmi_op_stem_pool_f16): fp32 NHWC C=3 batch -> haloed fp16 image -> conv 7x7/2 + BN + ReLU + max-pool 3x3/2, fp16 out."""
+    x = np.ascontiguousarray(x_nhwc3, np.float32)
+    N, H, W, _ = x.shape
+    Cout = w_krs4.shape[0]
+    d = make_conv_desc(N, H, W, 4, Cout, 7, 7, 2, 3, 1, 0)
+    dx = DeviceBuffer.from_numpy(x); dh = DeviceBuffer((N, H + 6, (W + 7) & ~1, 4), np.float16)
+    check(lib().isegmi_op_pad_c3_to_f16_halo(dx.ptr, N, H, W, dh.ptr, None))
+    dw = DeviceBuffer.from_numpy(pack_conv_weights_f16(d, w_krs4))
+    ds = DeviceBuffer.from_numpy(np.asarray(scale, np.float32)); dsh = DeviceBuffer.from_numpy(np.asarray(shift, np.float32))
+    hc, wc = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    do = DeviceBuffer((N, (hc - 1) // 2 + 1, (wc - 1) // 2 + 1, Cout), np.float16)
+    check(lib().isegmi_op_stem_pool_f16(N, H, W, dh.ptr, dw.ptr, ds.ptr, dsh.ptr, do.ptr, int(flags), None))
+    return do.numpy()
+
+
 def conv2d_f16(x, w_krsc, stride=1, pad=0, scale=None, shift=None, residual=None, act=0, tile=0, out_f32=False):
     """x fp16-representable NHWC (any float dtype; cast to fp16), returns fp16 (or fp32 when out_f32) as numpy."""
     x = np.ascontiguousarray(x, np.float16)

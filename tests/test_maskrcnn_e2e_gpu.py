@@ -199,6 +199,36 @@ def test_maskrcnn_fp16_fused_bottleneck_equals_three_launches(ffi, sd):
     assert all(abs(i - j) <= 5 for i, j in zip(a["n"], b["n"]))
 
 
+def test_maskrcnn_fp16_fused_stem_equals_conv_then_pool(ffi, sd):
+    """configs[4] engine with the one-launch stem (conv 7x7/2 + BN + ReLU + max-pool, csrc/stem_pool_f16.hip; default) against the same engine with
+    `fused_stem` 0 (stem conv launch + max-pool launch): the pooled tensor -- and therefore every tensor and detection after it -- is BIT-identical;
+    the fused launch really runs (one conv launch per step either way, but no "stem" activation is allocated) and prices the same FLOPs."""
+    import ctypes as C
+    from isegmi.maskrcnn import MaskRCNN, prepare_images
+    rng = np.random.default_rng(77)
+    x, hw = prepare_images([rng.uniform(0, 255, (250, 340, 3)).astype(np.float32), rng.uniform(0, 255, (203, 317, 3)).astype(np.float32)])
+    outs = {}
+    for fused in (1, 0):
+        model = MaskRCNN(sd, x.shape[1], x.shape[2], max_batch=2, fp16=True)
+        model.set_param("fused_stem", float(fused))
+        model.set_param("conv_timing", 1.0)
+        bl = model(x, hw)
+        f, m, l = C.c_double(), C.c_double(), C.c_int64()
+        ffi.check(ffi.lib().isegmi_engine_conv_stats(model._h, C.byref(f), C.byref(m), C.byref(l)))
+        buf = C.create_string_buffer(1 << 18); ffi.check(ffi.lib().isegmi_engine_conv_report(model._h, buf, 1 << 18))
+        outs[fused] = dict(pool=model.fetch("pool", 2), C2=model.fetch("res2.C", 2), P2=model.fetch("P2", 2), boxes=[b.bbox.copy() for b in bl],
+                           scores=[b.get_field("scores").copy() for b in bl], launches=l.value, flops=f.value, report=buf.value.decode())
+        model.close()
+    a, b = outs[1], outs[0]
+    assert "stem.conv1.fused" in a["report"] and "stem.conv1.fused" not in b["report"]
+    assert a["launches"] == b["launches"] and abs(a["flops"] - b["flops"]) <= 1e-6 * b["flops"]
+    assert a["pool"].dtype == np.float16 and (a["pool"] > 0).any()
+    for k in ("pool", "C2", "P2"):
+        assert np.array_equal(a[k], b[k]), k
+    for i in range(2):
+        assert np.array_equal(a["boxes"][i], b["boxes"][i]) and np.array_equal(a["scores"][i], b["scores"][i])
+
+
 def test_maskrcnn_full_size_bs2_bit_exact(ffi, sd):
     """BASELINE configs[2] at its own workload: two 1333x800 images -> one 2x800x1344 batch, fp32, 1000 proposals per image.
     Proposals, boxes, scores, labels, 28x28 masks and the masks pasted at 800x1333 are all compared exactly."""

@@ -1,0 +1,47 @@
+"""The fused fp16 stem (csrc/stem_pool_f16.hip: conv 7x7/2 + BN + ReLU + max-pool 3x3/2 in one launch, configs[4]) against the two launches it
+replaces: the fp16 stem conv (isegmi_op_conv2d_f16 on the haloed image) followed by a 3x3/2/1 max-pool -- BIT-identical (the pool of fp16 values
+is exact, so the reference pool is taken in numpy over the conv launch's output).  Shapes: sizes that cut strips (30 pooled columns) and row
+segments at every residue, odd sizes, images smaller than one strip, several images; flags 1 = an 8-block grid (blocks walk many units),
+2 = the shortest units (a seam every three pooled rows)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _pool(x):  # 3x3 / 2 / pad 1 over fp16 NHWC, -inf padding
+    N, H, W, C = x.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    xp = np.full((N, 2 * Ho + 1, 2 * Wo + 1, C), -np.inf, np.float16)
+    xp[:, 1:H + 1, 1:W + 1] = x
+    out = np.full((N, Ho, Wo, C), -np.inf, np.float16)
+    for dr in range(3):
+        for dc in range(3):
+            out = np.maximum(out, xp[:, dr:dr + 2 * Ho:2, dc:dc + 2 * Wo:2])
+    return out
+
+
+def _case(rng, N, H, W):
+    x = rng.uniform(-120.0, 130.0, (N, H, W, 3)).astype(np.float32)
+    w = (rng.standard_normal((64, 7, 7, 4)) * (2.0 / 147.0) ** 0.5).astype(np.float16).astype(np.float32)
+    w[..., 3] = 0.0
+    sc = (rng.uniform(0.5, 1.5, 64) / 60.0).astype(np.float32); sh = (rng.standard_normal(64) * 0.3).astype(np.float32)
+    return x, w, sc, sh
+
+
+SHAPES = [(1, 32, 32), (2, 50, 70), (1, 37, 45), (1, 64, 33), (1, 123, 251), (3, 96, 128), (1, 200, 488), (2, 17, 9), (1, 5, 5)]
+
+
+@pytest.mark.parametrize("flags", [0, 1, 2, 3])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_fused_stem_equals_conv_then_pool(ffi, shape, flags):
+    N, H, W = shape
+    rng = np.random.default_rng(H * 1000 + W * 7 + N)
+    x, w, sc, sh = _case(rng, N, H, W)
+    conv, _ = ffi.stem_f16(x, w, sc, sh, 0)
+    ref = _pool(conv)
+    got = ffi.stem_pool_f16(x, w, sc, sh, flags)
+    assert got.shape == ref.shape and got.dtype == np.float16
+    assert np.isfinite(ref.astype(np.float32)).all() and (ref > 0).mean() > 0.3   # the case exercises the ReLU both ways
+    assert np.array_equal(got.view(np.uint16), ref.view(np.uint16)), "fused stem != conv + pool: %d of %d differ, max |d| %g" % (
+        int((got != ref).sum()), got.size, float(np.abs(got.astype(np.float32) - ref.astype(np.float32)).max()))
