@@ -45,3 +45,13 @@ def test_fused_stem_equals_conv_then_pool(ffi, shape, flags):
     assert np.isfinite(ref.astype(np.float32)).all() and (ref > 0).mean() > 0.3   # the case exercises the ReLU both ways
     assert np.array_equal(got.view(np.uint16), ref.view(np.uint16)), "fused stem != conv + pool: %d of %d differ, max |d| %g" % (
         int((got != ref).sum()), got.size, float(np.abs(got.astype(np.float32) - ref.astype(np.float32)).max()))
+
+
+def test_fused_stem_at_the_bench_size(ffi):
+    """configs[4]'s own canvas (800 x 1344; two of the eight images of a rank's batch): 12 strips x row segments chosen by the launcher's own cost model."""
+    rng = np.random.default_rng(4)
+    x, w, sc, sh = _case(rng, 2, 800, 1344)
+    conv, _ = ffi.stem_f16(x, w, sc, sh, 0)
+    got = ffi.stem_pool_f16(x, w, sc, sh, 0)
+    assert got.shape == (2, 200, 336, 64)
+    assert np.array_equal(got.view(np.uint16), _pool(conv).view(np.uint16))
