@@ -102,6 +102,12 @@ int isegmi_op_bottleneck_f16(const isegmi_bottleneck_desc* d, const void* d_x, c
 int isegmi_op_bottleneck_ds_f16(const isegmi_bottleneck_desc* d, const void* d_x, const void* d_w1, const float* d_s1, const float* d_b1,
                                 const void* d_w2, const float* d_s2, const float* d_b2, const void* d_w3, const float* d_s3,
                                 const float* d_b3, const void* d_wd, const float* d_sd, const float* d_bd, void* d_out, void* stream);
+/* RPNHead under configs[4] (M4: `t = relu(conv3x3(x)); logits, deltas = cls_logits(t), bbox_pred(t)`) as one launch: desc = the 3x3 / 1 / 1 conv (Cout 256,
+ * act 1, tile 0), d_w2packed / scale2 / shift2 = the fused cls + bbox 1x1 (256 -> cout2 <= 32 outputs, isegmi_pack_conv_weights_f16 image), d_out2 = fp32
+ * [M][cout2].  t is rounded to fp16 where the two-launch path stores it and never leaves the CU; results are bit-identical to isegmi_op_conv2d_f16 twice.
+ * *fused = 0 and NOTHING is launched when the layer is too small for the 192 x 256 row-strip tile the fusion lives on: the caller then runs the two launches. */
+int isegmi_op_conv3x3_head_f16(const isegmi_conv_desc* d, const void* d_in, const void* d_wpacked, const float* d_scale, const float* d_shift,
+                               const void* d_w2packed, const float* d_scale2, const float* d_shift2, int cout2, float* d_out2, int* fused, void* stream);
 /* fp16 stem (M2 `StemWithFixedBatchNorm` conv1 under configs[4]): desc Cin=4 R=S=7 stride=2 pad=3 with H, W the image
  * size; d_in of isegmi_op_conv2d_f16 is then the haloed fp16 image [N][H+6][(W+7)&~1][4] this op writes from the fp32
  * NHWC C=3 batch (3 zero pixels on every side, zero 4th channel); weights are given as [Cout][7][7][4]. */

@@ -66,6 +66,14 @@ struct ConvKH {
     unsigned* trace;
 #endif
     int dbg;  // TIMING-ONLY experiments (tile bit 4096): strip kernel loaders stop after the first two groups
+    // fused 1x1 head on the tile's result (192 x 256 row-strip tile only; see conv_f16_epilogue_head): packed [128][256] fp16 weights, scale / shift,
+    // fp32 [M][f_cout] output; f_w == nullptr: the ordinary epilogue
+    const half_t* f_w;
+    const float* f_scale;
+    const float* f_shift;
+    float* f_out;
+    int f_cout;
+    unsigned f_out_bytes;
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -749,6 +757,76 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, OCC) void conv_f16_persist_ker
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// FUSED 1x1 HEAD (round 4; RPNHead under configs[4]: `t = relu(conv3x3(x)); logits, deltas = cls_logits(t), bbox_pred(t)`).  On a 192 x 256
+// row-strip tile the block holds ALL 256 channels of its 192 pixels, so the 1x1 convolution that follows (256 -> f_cout <= 32 outputs: 3 objectness + 12
+// box deltas) can run on the tile before it ever leaves the CU: the BN + ReLU result goes to LDS as fp16 -- rounded exactly where the two-launch path
+// rounds it when it stores t -- in a row-major [pixel][256] image (16-B columns XOR-swizzled by the row), the head's packed weights (32 rows) next to
+// it, and six waves multiply one 32-pixel tile each on the same 16 k-steps the stand-alone 1x1 launch would walk.  t is never written (275 MB per
+// P2 level at R101 bs=8) nor read back.  Bit-identical to the two launches (tests/test_rpn_head_f16_gpu.py).
+template <int TM, int TN>
+__device__ __forceinline__ void conv_f16_epilogue_head(const ConvKH& p, f32x16h (&acc)[TM][TN], char* smemg, int wave, int lane, int wm, int wn, int m0) {
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr int BMH = 192, T_BYTES = BMH * 512;   // the tile image; the head's weights follow it (32 rows x 512 B)
+    const int lr = lane & 31, lh = lane >> 5;
+    const int tid = wave * 64 + lane;                // 12 MFMA waves: 768 threads
+    // head weights: rows 0..31 of the packed [128][256] image (zero rows past f_cout), 16 KB = 1024 16-B pieces
+    u32x4h wv[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int piece = tid + j * 768;
+        wv[j] = piece < 1024 ? *(const u32x4h*)((const char*)p.f_w + piece * 16) : u32x4h{0u, 0u, 0u, 0u};
+    }
+    // 1. y = relu(fmaf(acc, scale, shift)) -> fp16 -> T[row][channel]
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int co = (wn * TN + b) * 32 + lr;
+            const float sc = p.scale ? p.scale[co] : 1.0f, sh = p.shift ? p.shift[co] : 0.0f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (wm * TM + a) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                float y = fmaf(acc[a][b][e], sc, sh);
+                y = y > 0.0f ? y : 0.0f;
+                *(half_t*)(smemg + row * 512 + (((co >> 3) ^ (row & 15)) << 4) + (co & 7) * 2) = (half_t)y;
+            }
+        }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int piece = tid + j * 768;
+        if (piece < 1024) {
+            const int row = piece >> 5, c16 = piece & 31;
+            *(u32x4h*)(smemg + T_BYTES + row * 512 + ((c16 ^ (row & 15)) << 4)) = wv[j];
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the MFMA waves (the loader waves have left)
+    if (wave >= BMH / 32) return;
+    // 2. wave w: pixels 32 w .. + 31 of the tile x 32 head outputs, K = 256 in the order the stand-alone 1x1 launch walks it
+    f32x16h h;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) h[e] = 0.0f;
+    const int prow = wave * 32 + lr;
+    const char* pa = smemg + prow * 512;
+    const char* pb = smemg + T_BYTES + lr * 512;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+        const f16x8 fa = *(const f16x8*)(pa + (((ks * 2 + lh) ^ (prow & 15)) << 4));
+        const f16x8 fb = *(const f16x8*)(pb + (((ks * 2 + lh) ^ (lr & 15)) << 4));
+        h = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, h, 0, 0, 0);
+    }
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.f_out, 0, p.f_out_bytes, 0x00020000);
+    const bool cok = lr < p.f_cout;
+    const float sc2 = (cok && p.f_scale) ? p.f_scale[lr] : 1.0f, sh2 = (cok && p.f_shift) ? p.f_shift[lr] : 0.0f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        float y = fmaf(h[e], sc2, sh2);
+        y = y + 0.0f;   // the stand-alone launch's per-element epilogue adds its (absent) residual: -0 becomes +0 there, so here too
+        const unsigned off = (cok && m < p.M) ? ((unsigned)m * (unsigned)p.f_cout + (unsigned)lr) * 4u : OOB;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), rs, off, 0, 0);
+    }
+}
+
 // 3x3 / stride 1 / pad 1 with ROW-STRIP staging.  The generic kernel above stages a fresh BM-row A image for each of
 // the nine taps; here the three taps of one filter row share ONE strip: for filter row r and cin chunk kc the block
 // loads, per image-row segment its BM output pixels touch, [left neighbour | the segment's pixels | right neighbour]
@@ -1016,6 +1094,9 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, 1) void conv3x3_f16_strip_kern
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     STRIP_TRACE(63, 0);
+    if constexpr (BM == 192 && BN == 256 && WM == 3 && WN == 4 && NB == 3) {
+        if (p.f_w) { conv_f16_epilogue_head<TM, TN>(p, acc, smemg, wave, lane, wm, wn, m0); return; }   // uniform
+    }
     conv_f16_epilogue<TM, TN>(p, acc, smemg, wave, lane, wm, wn, m0, n0);
     STRIP_TRACE(63, 1);
 #ifdef ISEGMI_STRIP_TRACE
@@ -1117,8 +1198,26 @@ static int cout_pad_h(int Cout) { return cdiv(Cout, 128) * 128; }
 static bool is_stem_h(const isegmi_conv_desc* d) { return d->Cin == 4 && d->R == 7 && d->S == 7; }
 
 // fp16 conv: in/w/res are fp16; out is fp16, or fp32 when out_f32 (predictor heads feeding fp32 selection kernels)
+// `head` != nullptr: the 3x3 conv with the fused 1x1 head of conv_f16_epilogue_head (out is then unused and may be null); *head->fused tells whether the
+// launch happened -- from half a round of 192 x 256 row-strip tiles on (otherwise nothing is launched)
+struct ConvHeadF16 { const void* w; const float* scale; const float* shift; float* out; int cout; bool* fused; };
+static int conv2d_f16_launch_impl(const isegmi_conv_desc* d, const void* in, const void* w, const float* scale, const float* shift, const void* res,
+                                  void* out, int out_f32, hipStream_t st, const ConvHeadF16* head);
 int conv2d_f16_launch(const isegmi_conv_desc* d, const void* in, const void* w, const float* scale, const float* shift, const void* res,
                       void* out, int out_f32, hipStream_t st) {
+    return conv2d_f16_launch_impl(d, in, w, scale, shift, res, out, out_f32, st, nullptr);
+}
+int conv2d_f16_head_launch(const isegmi_conv_desc* d, const void* in, const void* w, const float* scale, const float* shift, const void* w2,
+                           const float* scale2, const float* shift2, int cout2, float* out2, bool* fused, hipStream_t st) {
+    ARG_CHECK(d && w2 && out2 && fused && cout2 > 0 && cout2 <= 32, "fused head: null / more than 32 outputs");
+    *fused = false;
+    if (!(d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1 && d->Cout == 256 && d->act == 1 && (d->tile & 255) == 0 && d->out_pix_stride == 0 && d->out_img_stride == 0))
+        return ISEGMI_OK;
+    const ConvHeadF16 h = {w2, scale2, shift2, out2, cout2, fused};
+    return conv2d_f16_launch_impl(d, in, w, scale, shift, nullptr, out2 /* never written: a non-null placeholder */, 0, st, &h);
+}
+static int conv2d_f16_launch_impl(const isegmi_conv_desc* d, const void* in, const void* w, const float* scale, const float* shift, const void* res,
+                                  void* out, int out_f32, hipStream_t st, const ConvHeadF16* head) {
     ARG_CHECK(d && in && w && out, "null");
     const bool stem = is_stem_h(d);
     ARG_CHECK(stem || (d->Cin > 0 && d->Cin % 64 == 0), "fp16 conv needs Cin % 64 == 0 (or the 7x7/2 Cin=4 stem)");
@@ -1161,6 +1260,7 @@ int conv2d_f16_launch(const isegmi_conv_desc* d, const void* in, const void* w, 
     if (tile & 512) k.in_bytes = 0;
     if (tile & 1024) k.w_bytes = 0;
     k.dbg = (tile & 4096) ? 1 : 0;
+    k.f_w = nullptr; k.f_scale = nullptr; k.f_shift = nullptr; k.f_out = nullptr; k.f_cout = 0; k.f_out_bytes = 0;
     const bool few = (tile & 2048) != 0;  // TEST HOOK: persistent kernels run on an 8-block grid (multi-tile blocks on small shapes)
     tile &= 255;  // (bits 256 / 512 / 1024: TIMING-ONLY experiments, every A / B load dropped by the range check)
     if (stem) {
@@ -1195,6 +1295,16 @@ int conv2d_f16_launch(const isegmi_conv_desc* d, const void* in, const void* w, 
             const double c = (double)per_cu * t.bm * t.bn * ((double)k.nchunks * 64.0 / t.eff + t.epi);
             if (tile == 0 || c < best) { best = c; tile = t.id; }
         }
+    }
+    if (head) {
+        // fused where the 192 x 256 row-strip tile is usable and the layer has at least half a round of such tiles (the fusion saves the 1x1 launch and t's
+        // round trip, worth more than the tile quantisation the cost model might avoid with another tile); smaller levels: the caller runs the two launches
+        if (!(191 / d->W + 2 <= 32) || cdiv(k.M, 192) < 128) return ISEGMI_OK;
+        const int64_t ob = (int64_t)k.M * head->cout * 4;
+        ARG_CHECK(ob < (1ll << 31), "fused head output must be < 2 GiB");
+        k.f_w = (const half_t*)head->w; k.f_scale = head->scale; k.f_shift = head->shift; k.f_out = head->out; k.f_cout = head->cout; k.f_out_bytes = (unsigned)ob;
+        *head->fused = true;
+        tile = 30;
     }
     if (tile >= 26 && tile <= 31) {
         ARG_CHECK(d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1, "strip tiles are for 3x3 / stride 1 / pad 1");
@@ -1274,6 +1384,15 @@ extern "C" int isegmi_pack_conv_weights_f16(const isegmi_conv_desc* d, const flo
             packed[(int64_t)co * K + k] = __builtin_bit_cast(uint16_t, h);
         }
     return ISEGMI_OK;
+}
+
+extern "C" int isegmi_op_conv3x3_head_f16(const isegmi_conv_desc* d, const void* d_in, const void* d_wpacked, const float* d_scale, const float* d_shift,
+                                          const void* d_w2packed, const float* d_scale2, const float* d_shift2, int cout2, float* d_out2, int* fused, void* stream) {
+    ARG_CHECK(fused, "null");
+    bool f = false;
+    const int rc = conv2d_f16_head_launch(d, d_in, d_wpacked, d_scale, d_shift, d_w2packed, d_scale2, d_shift2, cout2, d_out2, &f, (hipStream_t)stream);
+    *fused = f ? 1 : 0;
+    return rc;
 }
 
 extern "C" int isegmi_op_conv2d_f16(const isegmi_conv_desc* d, const void* d_in, const void* d_wpacked, const float* d_scale,

@@ -158,6 +158,46 @@ int eng_bottleneck_f16(Engine& e, const std::string& block, const Tensor& x, boo
     return ISEGMI_OK;
 }
 
+// RPNHead under fp16 (`t = relu(conv3x3(x)); head = cls_bbox(t)`) as ONE launch where the 3x3 runs on the 192 x 256 row-strip tile (csrc/conv_mfma_f16.hip,
+// conv_f16_epilogue_head): t stays in LDS.  *fused = false (nothing launched) for levels too small for that tile, or with `fused_rpn_head` 0.
+int eng_rpn_head_f16(Engine& e, const std::string& conv, const std::string& headl, const Tensor& x, const std::string& out_name, Tensor* out, bool* fused) {
+    *fused = false;
+    if (x.dt != 1 || e.param("fused_rpn_head", 1.0f) == 0.0f || e.param("conv_tile", 0) != 0.0f) return ISEGMI_OK;
+    auto ic = e.convs.find(conv), ih = e.convs.find(headl);
+    if (ic == e.convs.end() || ih == e.convs.end()) return ISEGMI_OK;
+    const ConvLayer &L = ic->second, &H = ih->second;
+    if (!L.f16 || !H.f16 || L.Cin != x.C || L.R != 3 || L.S != 3 || L.Cout != 256 || H.Cin != 256 || H.R != 1 || H.S != 1 || H.Cout > 32) return ISEGMI_OK;
+    int rc = eng_act(e, out_name, x.N, x.H, x.W, H.Cout, out, 0);
+    if (rc) return rc;
+    isegmi_conv_desc d;
+    memset(&d, 0, sizeof(d));
+    d.N = x.N; d.H = x.H; d.W = x.W; d.Cin = x.C; d.Cout = 256; d.R = 3; d.S = 3; d.stride = 1; d.pad = 1; d.act = 1;
+    hipEvent_t a = nullptr, b = nullptr;
+    if (e.conv_timing) {
+        HIP_TRY(hipEventCreate(&a));
+        HIP_TRY(hipEventCreate(&b));
+        HIP_TRY(hipEventRecord(a, e.cur));
+    }
+    rc = conv2d_f16_head_launch(&d, x.d, L.d_w, L.d_scale, L.d_shift, H.d_w, H.d_scale, H.d_shift, H.Cout, out->d, fused, e.cur);
+    if (rc) return rc;
+    if (!*fused) {
+        if (a) { HIP_TRY(hipEventDestroy(a)); HIP_TRY(hipEventDestroy(b)); }
+        return ISEGMI_OK;
+    }
+    const int M = x.N * x.H * x.W;
+    if (e.conv_trace) fprintf(stderr, "convlaunch\t%s+%s.fused\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\n", conv.c_str(), headl.c_str(), x.N, x.H, x.W, x.C, H.Cout, 3, 1, M, 0);
+    if (e.conv_timing) {
+        HIP_TRY(hipEventRecord(b, e.cur));
+        e.conv_evs.push_back({a, b});
+        const double fl = 2.0 * M * (9.0 * x.C * 256 + 256.0 * H.Cout);   // both convolutions' algorithmic FLOPs
+        e.conv_flops_pending += fl;
+        char geo[200];
+        snprintf(geo, sizeof(geo), "%s+%s.fused [M=%d K=%d Cout=256 3x3/1 + 1x1 -> %d]", conv.c_str(), headl.c_str(), M, 9 * x.C, H.Cout);
+        e.conv_ev_info.push_back({geo, fl});
+    }
+    return ISEGMI_OK;
+}
+
 // fp16 stem conv + BN + ReLU + 3x3/2 max-pool as ONE launch (csrc/stem_pool_f16.hip); *fused = false (nothing launched) when the layer is not the 64-channel
 // stem or `fused_stem` is 0 (A/B against the two launches)
 int eng_stem_pool_f16(Engine& e, const std::string& layer, const Tensor& halo, int H, int W, const std::string& out_name, Tensor* out, bool* fused) {

@@ -195,8 +195,12 @@ int maskrcnn_forward(Engine& e, const float* d_images, int N) {
     auto rpn_level = [&](int l) -> int {
         const std::string ls = std::to_string(l);
         Tensor t, head;
-        TRY(eng_conv(e, "rpn.head.conv", P[l], 1, 1, 1, nullptr, "rpn.t" + ls, &t));
-        TRY(eng_conv(e, "rpn.head.cls_bbox", t, 1, 0, 0, nullptr, "rpn.head" + ls, &head, /*out_f32=*/true));
+        bool head_fused = false;   // fp16, big levels: the 3x3 and the fused cls + bbox 1x1 in one launch, t stays in LDS
+        if (dt) TRY(eng_rpn_head_f16(e, "rpn.head.conv", "rpn.head.cls_bbox", P[l], "rpn.head" + ls, &head, &head_fused));
+        if (!head_fused) {
+            TRY(eng_conv(e, "rpn.head.conv", P[l], 1, 1, 1, nullptr, "rpn.t" + ls, &t));
+            TRY(eng_conv(e, "rpn.head.cls_bbox", t, 1, 0, 0, nullptr, "rpn.head" + ls, &head, /*out_f32=*/true));
+        }
         const int HW = head.H * head.W, HWA = HW * A;
         const float* anc;
         TRY(level_anchors(e, l, A, head.H, head.W, regen_anchors, &anc));

@@ -427,6 +427,21 @@ def stem_f16(x_nhwc3, w_krs4, scale=None, shift=None, tile=0):
     return do.numpy(), dh.numpy()
 
 
+def conv3x3_head_f16(x, w, scale, shift, w2, scale2, shift2):
+    """isegmi_op_conv3x3_head_f16: x fp16 NHWC [N,H,W,Cin]; w [256,3,3,Cin]; w2 [cout2,1,1,256].  Returns (fp32 [N,H,W,cout2] or None, fused flag)."""
+    x = np.ascontiguousarray(x, np.float16)
+    N, H, W, Cin = x.shape
+    cout2 = w2.shape[0]
+    d = make_conv_desc(N, H, W, Cin, 256, 3, 3, 1, 1, 1, 0)
+    d2 = make_conv_desc(N, H, W, 256, cout2, 1, 1, 1, 0, 0, 0)
+    dx = DeviceBuffer.from_numpy(x); dw = DeviceBuffer.from_numpy(pack_conv_weights_f16(d, w)); dw2 = DeviceBuffer.from_numpy(pack_conv_weights_f16(d2, w2))
+    bufs = [DeviceBuffer.from_numpy(np.asarray(a, np.float32)) for a in (scale, shift, scale2, shift2)]
+    do = DeviceBuffer((N, H, W, cout2), np.float32)
+    fused = C.c_int(0)
+    check(lib().isegmi_op_conv3x3_head_f16(C.byref(d), dx.ptr, dw.ptr, bufs[0].ptr, bufs[1].ptr, dw2.ptr, bufs[2].ptr, bufs[3].ptr, cout2, do.ptr, C.byref(fused), None))
+    return (do.numpy() if fused.value else None), bool(fused.value)
+
+
 def stem_pool_f16(x_nhwc3, w_krs4, scale, shift, flags=0):
     """The fp16 stem in one launch (isegmi_op_stem_pool_f16): fp32 NHWC C=3 batch -> haloed fp16 image -> conv 7x7/2 + BN + ReLU + max-pool 3x3/2, fp16 out."""
     x = np.ascontiguousarray(x_nhwc3, np.float32)

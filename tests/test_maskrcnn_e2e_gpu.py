@@ -229,6 +229,34 @@ def test_maskrcnn_fp16_fused_stem_equals_conv_then_pool(ffi, sd):
         assert np.array_equal(a["boxes"][i], b["boxes"][i]) and np.array_equal(a["scores"][i], b["scores"][i])
 
 
+def test_maskrcnn_fp16_fused_rpn_head_equals_two_launches(ffi, sd):
+    """configs[4] engine at the full canvas (2 x 800 x 1344) with the RPN head of the big levels as one launch (default) against `fused_rpn_head` 0: the
+    objectness / delta tensor of P2 is BIT-identical (both paths run the 3x3 on the row-strip tile), P3's within fp16 conv tolerance (the cost model may put
+    the stand-alone 3x3 on another tile = another fp32 association); two conv launches fewer, the same algorithmic FLOPs, the same detections up to ties."""
+    import ctypes as C
+    from isegmi.maskrcnn import MaskRCNN, prepare_images
+    rng = np.random.default_rng(5)
+    x, hw = prepare_images([rng.uniform(0, 255, (800, 1333, 3)).astype(np.float32), rng.uniform(0, 255, (750, 1200, 3)).astype(np.float32)])
+    outs = {}
+    for fused in (1, 0):
+        model = MaskRCNN(sd, x.shape[1], x.shape[2], max_batch=2, fp16=True)
+        model.set_param("fused_rpn_head", float(fused))
+        model.set_param("conv_timing", 1.0)
+        bl = model(x, hw)
+        f, m, l = C.c_double(), C.c_double(), C.c_int64()
+        ffi.check(ffi.lib().isegmi_engine_conv_stats(model._h, C.byref(f), C.byref(m), C.byref(l)))
+        outs[fused] = dict(h0=model.fetch("rpn.head0", 2), h1=model.fetch("rpn.head1", 2), n=[len(b) for b in bl], launches=l.value, flops=f.value)
+        model.close()
+    a, b = outs[1], outs[0]
+    assert b["launches"] - a["launches"] == 2, (a["launches"], b["launches"])   # P2 and P3 (P4's 8400 pixels are under half a round of tiles)
+    assert abs(a["flops"] - b["flops"]) <= 1e-6 * b["flops"]
+    assert a["h0"].shape == (2, 200, 336, 15) and a["h0"].dtype == np.float32
+    assert np.array_equal(a["h0"], b["h0"])
+    d = np.abs(a["h1"] - b["h1"])
+    assert d.max() <= 2e-2 and np.mean(d <= 1e-3) >= 0.99, float(d.max())
+    assert all(abs(i - j) <= 5 for i, j in zip(a["n"], b["n"]))
+
+
 def test_maskrcnn_full_size_bs2_bit_exact(ffi, sd):
     """BASELINE configs[2] at its own workload: two 1333x800 images -> one 2x800x1344 batch, fp32, 1000 proposals per image.
     Proposals, boxes, scores, labels, 28x28 masks and the masks pasted at 800x1333 are all compared exactly."""
