@@ -102,6 +102,11 @@ int isegmi_op_bottleneck_f16(const isegmi_bottleneck_desc* d, const void* d_x, c
 int isegmi_op_bottleneck_ds_f16(const isegmi_bottleneck_desc* d, const void* d_x, const void* d_w1, const float* d_s1, const float* d_b1,
                                 const void* d_w2, const float* d_s2, const float* d_b2, const void* d_w3, const float* d_s3,
                                 const float* d_b3, const void* d_wd, const float* d_sd, const float* d_bd, void* d_out, void* stream);
+/* FPN top-down step under configs[4] (M3: `last_inner = inner_block(feature) + interpolate(last_inner, scale_factor=2, mode="nearest")`) as one launch: desc = the
+ * lateral 1x1 / 1 / 0 conv (Cout % 8 == 0, W >= 8, tile 0), d_coarse = the coarser level [N][Hc][Wc][Cout] fp16; out = fp16(fp16(conv) + coarse[n][y/2][x/2]),
+ * bit-identical to isegmi_op_conv2d_f16 followed by the engine's nearest-2x add (the lateral result is rounded to fp16 where that path stores it). */
+int isegmi_op_conv1x1_up2x_add_f16(const isegmi_conv_desc* d, const void* d_in, const void* d_wpacked, const float* d_scale, const float* d_shift,
+                                   const void* d_coarse, int Hc, int Wc, void* d_out, void* stream);
 /* RPNHead under configs[4] (M4: `t = relu(conv3x3(x)); logits, deltas = cls_logits(t), bbox_pred(t)`) as one launch: desc = the 3x3 / 1 / 1 conv (Cout 256,
  * act 1, tile 0), d_w2packed / scale2 / shift2 = the fused cls + bbox 1x1 (256 -> cout2 <= 32 outputs, isegmi_pack_conv_weights_f16 image), d_out2 = fp32
  * [M][cout2].  t is rounded to fp16 where the two-launch path stores it and never leaves the CU; results are bit-identical to isegmi_op_conv2d_f16 twice.

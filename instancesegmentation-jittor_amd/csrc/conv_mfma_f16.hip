@@ -66,6 +66,7 @@ struct ConvKH {
     unsigned* trace;
 #endif
     int dbg;  // TIMING-ONLY experiments (tile bit 4096): strip kernel loaders stop after the first two groups
+    int res_up2x, rHc, rWc;   // residual = a [N][rHc][rWc][Cout] tensor read through nearest-2x upsampling (FPN top-down merge; tile 38 only)
     // fused 1x1 head on the tile's result (192 x 256 row-strip tile only; see conv_f16_epilogue_head): packed [128][256] fp16 weights, scale / shift,
     // fp32 [M][f_cout] output; f_w == nullptr: the ordinary epilogue
     const half_t* f_w;
@@ -455,10 +456,26 @@ struct Epi8 {
     static constexpr int D = EPI_D < NQ ? EPI_D : NQ;
     u32x4h r[D];
     unsigned rnext;   // residual offset (bytes) of the next pass to request, or >= OOB for a column past Cout; pass q covers tile rows RPP q ..
+    int ux, uy, un;   // UP2X: output pixel (x, y, image) of the next pass to request
 };
 
-// before the K loop: the first D residual passes of the wave's tile
+// UP2X (FPN top-down merge, SURVEY 8a M3: `last_inner = inner_lateral + interpolate(last_inner, scale_factor=2, mode="nearest")`): the residual of output pixel
+// (n, y, x) is pixel (n, min(y >> 1, Hc - 1), min(x >> 1, Wc - 1)) of the coarser level.  A lane's pass-to-pass step is RPP pixels along the row: the walk is
+// incremental (one wrap test per pass), the two divisions that start it are per tile.
 template <int TM, int TN>
+__device__ __forceinline__ unsigned epi8_up2x_next(const ConvKH& p, Epi8<TM, TN>& E, int co8) {
+    constexpr unsigned OOB = 0x80000000u;
+    int yc = E.uy >> 1, xc = E.ux >> 1;
+    yc = yc > p.rHc - 1 ? p.rHc - 1 : yc;
+    xc = xc > p.rWc - 1 ? p.rWc - 1 : xc;
+    const unsigned off = co8 < p.Cout ? ((unsigned)((E.un * p.rHc + yc) * p.rWc + xc) * (unsigned)p.Cout + (unsigned)co8) * 2u : OOB;   // images past N are past the range
+    E.ux += Epi8<TM, TN>::RPP;
+    if (E.ux >= p.Wo) { E.ux -= p.Wo; E.uy += 1; if (E.uy >= p.Ho) { E.uy = 0; E.un += 1; } }
+    return off;
+}
+
+// before the K loop: the first D residual passes of the wave's tile
+template <int TM, int TN, bool UP2X = false>
 __device__ __forceinline__ void epi8_prefetch(const ConvKH& p, Epi8<TM, TN>& E, int lane, int wm, int wn, int m0, int n0) {
     constexpr unsigned OOB = 0x80000000u;
     constexpr int LPR = Epi8<TM, TN>::LPR, RPP = Epi8<TM, TN>::RPP;
@@ -469,11 +486,21 @@ __device__ __forceinline__ void epi8_prefetch(const ConvKH& p, Epi8<TM, TN>& E, 
     E.rnext = co8 < p.Cout ? ((unsigned)(m0 + wm * TM * 32 + er) * (unsigned)p.Cout + (unsigned)co8) * 2u : OOB;
     const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? (const void*)p.res : (const void*)p.out), 0, p.res ? p.res_bytes : 0u, 0x00020000);
     const unsigned rstep = (unsigned)p.Cout * (2u * RPP);
+    if constexpr (UP2X) {
+        const int m = m0 + wm * TM * 32 + er, hw = p.Ho * p.Wo;
+        E.un = m / hw;
+        const int rem = m - E.un * hw;
+        E.uy = rem / p.Wo;
+        E.ux = rem - E.uy * p.Wo;
+#pragma unroll
+        for (int q = 0; q < Epi8<TM, TN>::D; ++q) E.r[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, epi8_up2x_next<TM, TN>(p, E, co8), 0, CONV_F16_RES_AUX);
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < Epi8<TM, TN>::D; ++q) { E.r[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, E.rnext, 0, CONV_F16_RES_AUX); E.rnext += rstep; }
 }
 
-template <int TM, int TN, bool RES>
+template <int TM, int TN, bool RES, bool UP2X = false>
 __device__ __forceinline__ void epi8_finish_impl(const ConvKH& p, f32x16h (&acc)[TM][TN], Epi8<TM, TN>& E, float* ew, int lane, int wm, int wn, int m0, int n0) {
     constexpr unsigned OOB = 0x80000000u;
     constexpr int PITCH = TN * 32 + 4;
@@ -522,9 +549,16 @@ __device__ __forceinline__ void epi8_finish_impl(const ConvKH& p, f32x16h (&acc)
                 float y[8];
                 if (RES) {
                     const f16x8 rh = __builtin_bit_cast(f16x8, E.r[q % D]);
+                    if constexpr (UP2X) {
+                        // the lateral conv's result is rounded to fp16 FIRST, as the two-launch path stores it before nearest2x_add_f16 adds the coarser level
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) y[i] = (i < 4 ? v0[i] : v1[i - 4]) + (float)rh[i];
-                    if (q + D < NQ) { E.r[q % D] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, E.rnext, 0, CONV_F16_RES_AUX); E.rnext += rstep; }
+                        for (int i = 0; i < 8; ++i) y[i] = (float)(half_t)(i < 4 ? v0[i] : v1[i - 4]) + (float)rh[i];
+                        if (q + D < NQ) E.r[q % D] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, epi8_up2x_next<TM, TN>(p, E, co8), 0, CONV_F16_RES_AUX);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) y[i] = (i < 4 ? v0[i] : v1[i - 4]) + (float)rh[i];
+                        if (q + D < NQ) { E.r[q % D] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, E.rnext, 0, CONV_F16_RES_AUX); E.rnext += rstep; }
+                    }
                 } else {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) y[i] = i < 4 ? v0[i] : v1[i - 4];
@@ -551,13 +585,14 @@ __device__ __forceinline__ void epi8_finish_impl(const ConvKH& p, f32x16h (&acc)
     }
 }
 
-template <int TM, int TN>
+template <int TM, int TN, bool UP2X = false>
 __device__ __forceinline__ void epi8_finish(const ConvKH& p, f32x16h (&acc)[TM][TN], Epi8<TM, TN>& E, float* ew, int lane, int wm, int wn, int m0, int n0) {
+    if constexpr (UP2X) { epi8_finish_impl<TM, TN, true, true>(p, acc, E, ew, lane, wm, wn, m0, n0); return; }
     if (p.res) epi8_finish_impl<TM, TN, true>(p, acc, E, ew, lane, wm, wn, m0, n0);   // uniform
     else epi8_finish_impl<TM, TN, false>(p, acc, E, ew, lane, wm, wn, m0, n0);
 }
 
-template <int BM, int BN, int WM, int WN, int NSTAGE, int OCC, int LW>
+template <int BM, int BN, int WM, int WN, int NSTAGE, int OCC, int LW, bool UP2X = false>
 __global__ __launch_bounds__((WM * WN + LW) * 64, OCC) void conv_f16_persist_kernel(const ConvKH p_arg) {
     static_assert(LW > 0 && NSTAGE >= 2 && NSTAGE <= 3, "loader waves, a 2- or 3-deep ring");
     // Kernel arguments are read where they are used, per role: taken by value the ~45 dwords of ConvKH are all loaded at entry and stay
@@ -738,7 +773,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, OCC) void conv_f16_persist_ker
             karg_t k1 = kp0;
             asm volatile("" : "+s"(k1));
             const ConvKH& p = *(const ConvKH*)k1;
-            if (p.vec_epi) epi8_prefetch<TM, TN>(p, E, lane, wm, wn, m0, n0);  // the tile's first residual strips travel under its K loop
+            if (p.vec_epi) epi8_prefetch<TM, TN, UP2X>(p, E, lane, wm, wn, m0, n0);  // the tile's first residual strips travel under its K loop
         }
         int last = 0;
         for (int t = 0; t < p_nchunks; ++t) {
@@ -751,7 +786,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, OCC) void conv_f16_persist_ker
         karg_t k2 = kp0;
         asm volatile("" : "+s"(k2));
         const ConvKH& p = *(const ConvKH*)k2;
-        if (p.vec_epi) epi8_finish<TM, TN>(p, acc, E, (float*)(smemg + last * STAGEB) + wave * 8 * (TN * 32 + 4), lane, wm, wn, m0, n0);
+        if (p.vec_epi) epi8_finish<TM, TN, UP2X>(p, acc, E, (float*)(smemg + last * STAGEB) + wave * 8 * (TN * 32 + 4), lane, wm, wn, m0, n0);
         else conv_f16_epilogue<TM, TN>(p, acc, smemg, wave, lane, wm, wn, m0, n0);  // per-element path: no LDS
     }
 }
@@ -1168,7 +1203,7 @@ static int launch_g(ConvKH& k, hipStream_t st) {
 
 // persistent loader-wave kernel: at most one block per CU slot, each walking tiles bid, bid + grid, ...; `few` (test hook) forces
 // an 8-block grid so that small test shapes exercise the multi-tile stream
-template <int BM, int BN, int WM, int WN, int NSTAGE, int OCC, int LW>
+template <int BM, int BN, int WM, int WN, int NSTAGE, int OCC, int LW, bool UP2X = false>
 static int launch_p(ConvKH& k, hipStream_t st, bool few) {
     k.mtiles = cdiv(k.M, BM);
     k.ntiles = cdiv(k.Cout, BN);
@@ -1179,7 +1214,7 @@ static int launch_p(ConvKH& k, hipStream_t st, bool few) {
     static bool attr = false;
     static int ncu = 0;
     if (!attr) {
-        HIP_TRY(hipFuncSetAttribute((const void*)conv_f16_persist_kernel<BM, BN, WM, WN, NSTAGE, OCC, LW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)conv_f16_persist_kernel<BM, BN, WM, WN, NSTAGE, OCC, LW, UP2X>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int dev = 0;
         HIP_TRY(hipGetDevice(&dev));
         HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
@@ -1189,7 +1224,7 @@ static int launch_p(ConvKH& k, hipStream_t st, bool few) {
     int64_t slots = few ? 8 : (int64_t)(ncu / 8) * 8 * OCC;  // a multiple of 8, so that a block's tiles stay on its XCD
     if (slots < 8) slots = 8;
     const unsigned grid = (unsigned)(total < slots ? total : slots);
-    hipLaunchKernelGGL((conv_f16_persist_kernel<BM, BN, WM, WN, NSTAGE, OCC, LW>), dim3(grid), dim3((NW + LW) * 64), lds, st, k);
+    hipLaunchKernelGGL((conv_f16_persist_kernel<BM, BN, WM, WN, NSTAGE, OCC, LW, UP2X>), dim3(grid), dim3((NW + LW) * 64), lds, st, k);
     HIP_TRY(hipGetLastError());
     return ISEGMI_OK;
 }
@@ -1200,12 +1235,23 @@ static bool is_stem_h(const isegmi_conv_desc* d) { return d->Cin == 4 && d->R ==
 // fp16 conv: in/w/res are fp16; out is fp16, or fp32 when out_f32 (predictor heads feeding fp32 selection kernels)
 // `head` != nullptr: the 3x3 conv with the fused 1x1 head of conv_f16_epilogue_head (out is then unused and may be null); *head->fused tells whether the
 // launch happened -- from half a round of 192 x 256 row-strip tiles on (otherwise nothing is launched)
-struct ConvHeadF16 { const void* w; const float* scale; const float* shift; float* out; int cout; bool* fused; };
+struct ConvHeadF16 { const void* w; const float* scale; const float* shift; float* out; int cout; bool* fused; int up_hc, up_wc; };   // up_hc > 0: not a head but the UP2X residual mode (res = the coarser level)
 static int conv2d_f16_launch_impl(const isegmi_conv_desc* d, const void* in, const void* w, const float* scale, const float* shift, const void* res,
                                   void* out, int out_f32, hipStream_t st, const ConvHeadF16* head);
 int conv2d_f16_launch(const isegmi_conv_desc* d, const void* in, const void* w, const float* scale, const float* shift, const void* res,
                       void* out, int out_f32, hipStream_t st) {
     return conv2d_f16_launch_impl(d, in, w, scale, shift, res, out, out_f32, st, nullptr);
+}
+// FPN top-down merge in the lateral conv's epilogue (UP2X, see epi8_up2x_next): out = fp16(fp16(conv1x1(x) + bias) + coarse[n, y >> 1, x >> 1]) -- the lateral
+// result is rounded to fp16 before the add exactly as the two-launch path (conv, then nearest2x_add_f16) stores it, so the result is bit-identical to it
+int conv2d_f16_up2x_launch(const isegmi_conv_desc* d, const void* in, const void* w, const float* scale, const float* shift, const void* coarse, int Hc, int Wc,
+                           void* out, hipStream_t st) {
+    ARG_CHECK(d && coarse && Hc > 0 && Wc > 0, "up2x: null / shape");
+    ARG_CHECK(d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0 && d->out_pix_stride == 0 && d->out_img_stride == 0 && d->Cout % 8 == 0 && d->W >= 8 &&
+              (d->tile & 255) == 0 && ((uintptr_t)coarse & 15) == 0, "up2x: a contiguous 1x1 / 1 / 0 conv with Cout % 8 == 0, W >= 8, tile 0");
+    ARG_CHECK((d->H + 1) / 2 <= Hc + 1 && (d->W + 1) / 2 <= Wc + 1, "up2x: the coarser level is about half the size");
+    const ConvHeadF16 h = {nullptr, nullptr, nullptr, nullptr, 0, nullptr, Hc, Wc};
+    return conv2d_f16_launch_impl(d, in, w, scale, shift, coarse, out, 0, st, &h);
 }
 int conv2d_f16_head_launch(const isegmi_conv_desc* d, const void* in, const void* w, const float* scale, const float* shift, const void* w2,
                            const float* scale2, const float* shift2, int cout2, float* out2, bool* fused, hipStream_t st) {
@@ -1213,7 +1259,7 @@ int conv2d_f16_head_launch(const isegmi_conv_desc* d, const void* in, const void
     *fused = false;
     if (!(d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1 && d->Cout == 256 && d->act == 1 && (d->tile & 255) == 0 && d->out_pix_stride == 0 && d->out_img_stride == 0))
         return ISEGMI_OK;
-    const ConvHeadF16 h = {w2, scale2, shift2, out2, cout2, fused};
+    const ConvHeadF16 h = {w2, scale2, shift2, out2, cout2, fused, 0, 0};
     return conv2d_f16_launch_impl(d, in, w, scale, shift, nullptr, out2 /* never written: a non-null placeholder */, 0, st, &h);
 }
 static int conv2d_f16_launch_impl(const isegmi_conv_desc* d, const void* in, const void* w, const float* scale, const float* shift, const void* res,
@@ -1295,6 +1341,14 @@ static int conv2d_f16_launch_impl(const isegmi_conv_desc* d, const void* in, con
             const double c = (double)per_cu * t.bm * t.bn * ((double)k.nchunks * 64.0 / t.eff + t.epi);
             if (tile == 0 || c < best) { best = c; tile = t.id; }
         }
+    }
+    k.res_up2x = 0; k.rHc = 0; k.rWc = 0;
+    if (head && head->up_hc > 0) {
+        ARG_CHECK(k.vec_epi, "up2x needs 16-byte aligned tensors");
+        const int64_t rb = (int64_t)d->N * head->up_hc * head->up_wc * d->Cout * 2;
+        ARG_CHECK(rb < (1ll << 31), "up2x: coarse level must be < 2 GiB");
+        k.res_up2x = 1; k.rHc = head->up_hc; k.rWc = head->up_wc; k.res_bytes = (unsigned)rb;
+        return launch_p<192, 256, 3, 4, 2, 1, 4, true>(k, st, few);   // "tile 38": tile 37 with the walked residual
     }
     if (head) {
         // fused where the 192 x 256 row-strip tile is usable and the layer has at least half a round of such tiles (the fusion saves the 1x1 launch and t's
@@ -1384,6 +1438,11 @@ extern "C" int isegmi_pack_conv_weights_f16(const isegmi_conv_desc* d, const flo
             packed[(int64_t)co * K + k] = __builtin_bit_cast(uint16_t, h);
         }
     return ISEGMI_OK;
+}
+
+extern "C" int isegmi_op_conv1x1_up2x_add_f16(const isegmi_conv_desc* d, const void* d_in, const void* d_wpacked, const float* d_scale, const float* d_shift,
+                                              const void* d_coarse, int Hc, int Wc, void* d_out, void* stream) {
+    return conv2d_f16_up2x_launch(d, d_in, d_wpacked, d_scale, d_shift, d_coarse, Hc, Wc, d_out, (hipStream_t)stream);
 }
 
 extern "C" int isegmi_op_conv3x3_head_f16(const isegmi_conv_desc* d, const void* d_in, const void* d_wpacked, const float* d_scale, const float* d_shift,

@@ -158,6 +158,43 @@ int eng_bottleneck_f16(Engine& e, const std::string& block, const Tensor& x, boo
     return ISEGMI_OK;
 }
 
+// FPN top-down step under fp16: out = lateral1x1(x) + nearest2x(coarse) as ONE launch (UP2X residual mode of the persistent conv kernel); bit-identical to the
+// lateral conv followed by nearest2x_add_f16.  *merged = false (nothing launched) with `fused_fpn_merge` 0 or a forced conv tile.
+int eng_conv_up2x_f16(Engine& e, const std::string& layer, const Tensor& x, const Tensor& coarse, const std::string& out_name, Tensor* out, bool* merged) {
+    *merged = false;
+    if (x.dt != 1 || coarse.dt != 1 || e.param("fused_fpn_merge", 1.0f) == 0.0f || e.param("conv_tile", 0) != 0.0f) return ISEGMI_OK;
+    auto it = e.convs.find(layer);
+    if (it == e.convs.end()) return ISEGMI_OK;
+    const ConvLayer& L = it->second;
+    if (!L.f16 || L.Cin != x.C || L.R != 1 || L.S != 1 || L.Cout != coarse.C || L.Cout % 8 != 0 || x.W < 8 || coarse.N != x.N) return ISEGMI_OK;
+    int rc = eng_act(e, out_name, x.N, x.H, x.W, L.Cout, out, 1);
+    if (rc) return rc;
+    isegmi_conv_desc d;
+    memset(&d, 0, sizeof(d));
+    d.N = x.N; d.H = x.H; d.W = x.W; d.Cin = x.C; d.Cout = L.Cout; d.R = 1; d.S = 1; d.stride = 1; d.pad = 0; d.act = 0;
+    hipEvent_t a = nullptr, b = nullptr;
+    if (e.conv_timing) {
+        HIP_TRY(hipEventCreate(&a));
+        HIP_TRY(hipEventCreate(&b));
+        HIP_TRY(hipEventRecord(a, e.cur));
+    }
+    const int M = x.N * x.H * x.W;
+    if (e.conv_trace) fprintf(stderr, "convlaunch\t%s.up2x\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\n", layer.c_str(), x.N, x.H, x.W, x.C, L.Cout, 1, 1, M, 1);
+    rc = conv2d_f16_up2x_launch(&d, x.d, L.d_w, L.d_scale, L.d_shift, coarse.d, coarse.H, coarse.W, out->d, e.cur);
+    if (rc) return rc;
+    if (e.conv_timing) {
+        HIP_TRY(hipEventRecord(b, e.cur));
+        e.conv_evs.push_back({a, b});
+        const double fl = 2.0 * M * (double)x.C * L.Cout;
+        e.conv_flops_pending += fl;
+        char geo[200];
+        snprintf(geo, sizeof(geo), "%s.up2x [M=%d K=%d Cout=%d 1x1/1 + nearest-2x top-down add]", layer.c_str(), M, x.C, L.Cout);
+        e.conv_ev_info.push_back({geo, fl});
+    }
+    *merged = true;
+    return ISEGMI_OK;
+}
+
 // RPNHead under fp16 (`t = relu(conv3x3(x)); head = cls_bbox(t)`) as ONE launch where the 3x3 runs on the 192 x 256 row-strip tile (csrc/conv_mfma_f16.hip,
 // conv_f16_epilogue_head): t stays in LDS.  *fused = false (nothing launched) for levels too small for that tile, or with `fused_rpn_head` 0.
 int eng_rpn_head_f16(Engine& e, const std::string& conv, const std::string& headl, const Tensor& x, const std::string& out_name, Tensor* out, bool* fused) {

@@ -142,6 +142,7 @@ int eng_wait_upload(Engine& e, const void* d_ptr, int64_t bytes, hipStream_t st)
 int eng_stage_small(Engine& e, const void* h_src, size_t bytes, void* d_dst, hipStream_t st);  // host array -> pinned ring slot -> async H2D on st
 hipStream_t eng_results_stream(Engine& e);  // the stream the last forward's results complete on  // st waits for a pending upload_async whose destination holds d_ptr
 int eng_bottleneck_f16(Engine& e, const std::string& block, const Tensor& x, bool first, const std::string& out_name, Tensor* out, bool* fused);
+int eng_conv_up2x_f16(Engine& e, const std::string& layer, const Tensor& x, const Tensor& coarse, const std::string& out_name, Tensor* out, bool* merged);
 int eng_rpn_head_f16(Engine& e, const std::string& conv, const std::string& headl, const Tensor& x, const std::string& out_name, Tensor* out, bool* fused);
 int eng_stem_pool_f16(Engine& e, const std::string& layer, const Tensor& halo, int H, int W, const std::string& out_name, Tensor* out, bool* fused);
 int eng_conv_stem_f16(Engine& e, const std::string& layer, const Tensor& halo, int H, int W, const std::string& out_name, Tensor* out);
@@ -188,6 +189,8 @@ int conv2d_launch(const isegmi_conv_desc* d, const float* in, const float* w, co
                   const float* res, float* out, hipStream_t st);
 int conv2d_f16_launch(const isegmi_conv_desc* d, const void* in, const void* w, const float* scale, const float* shift, const void* res,
                       void* out, int out_f32, hipStream_t st);
+int conv2d_f16_up2x_launch(const isegmi_conv_desc* d, const void* in, const void* w, const float* scale, const float* shift, const void* coarse, int Hc, int Wc,
+                           void* out, hipStream_t st);
 int conv2d_f16_head_launch(const isegmi_conv_desc* d, const void* in, const void* w, const float* scale, const float* shift, const void* w2,
                            const float* scale2, const float* shift2, int cout2, float* out2, bool* fused, hipStream_t st);
 bool stem_pool_f16_supported(int Cout);

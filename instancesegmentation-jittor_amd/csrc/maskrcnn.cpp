@@ -166,6 +166,11 @@ int maskrcnn_forward(Engine& e, const float* d_images, int N) {
     TRY(eng_conv(e, "backbone.fpn.fpn_inner4", C[3], 1, 0, 0, nullptr, "fpn.last4", &last[3]));
     for (int l = 2; l >= 0; --l) {
         const std::string ls = std::to_string(l + 1);
+        if (dt) {  // fp16: the merge with the coarser level in the lateral conv's own epilogue (one launch, the lateral tensor never exists)
+            bool merged = false;
+            TRY(eng_conv_up2x_f16(e, "backbone.fpn.fpn_inner" + ls, C[l], last[l + 1], "fpn.last" + ls, &last[l], &merged));
+            if (merged) continue;
+        }
         TRY(eng_conv(e, "backbone.fpn.fpn_inner" + ls, C[l], 1, 0, 0, nullptr, "fpn.lat" + ls, &lat));
         TRY(eng_act(e, "fpn.last" + ls, N, lat.H, lat.W, lat.C, &last[l], dt));
         if (dt) TRY(nearest2x_add_f16_launch(last[l + 1].d, N, last[l + 1].H, last[l + 1].W, last[l + 1].C, lat.d, lat.H, lat.W, last[l].d, st));

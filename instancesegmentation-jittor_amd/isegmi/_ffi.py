@@ -427,6 +427,19 @@ def stem_f16(x_nhwc3, w_krs4, scale=None, shift=None, tile=0):
     return do.numpy(), dh.numpy()
 
 
+def conv1x1_up2x_add_f16(x, w, scale, shift, coarse):
+    """isegmi_op_conv1x1_up2x_add_f16: x fp16 NHWC, w [Cout,1,1,Cin], coarse fp16 [N,Hc,Wc,Cout] -> fp16 [N,H,W,Cout]."""
+    x = np.ascontiguousarray(x, np.float16); coarse = np.ascontiguousarray(coarse, np.float16)
+    N, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    d = make_conv_desc(N, H, W, Cin, Cout, 1, 1, 1, 0, 0, 0)
+    dx = DeviceBuffer.from_numpy(x); dw = DeviceBuffer.from_numpy(pack_conv_weights_f16(d, w)); dc = DeviceBuffer.from_numpy(coarse)
+    ds = DeviceBuffer.from_numpy(np.asarray(scale, np.float32)); dsh = DeviceBuffer.from_numpy(np.asarray(shift, np.float32))
+    do = DeviceBuffer((N, H, W, Cout), np.float16)
+    check(lib().isegmi_op_conv1x1_up2x_add_f16(C.byref(d), dx.ptr, dw.ptr, ds.ptr, dsh.ptr, dc.ptr, coarse.shape[1], coarse.shape[2], do.ptr, None))
+    return do.numpy()
+
+
 def conv3x3_head_f16(x, w, scale, shift, w2, scale2, shift2):
     """isegmi_op_conv3x3_head_f16: x fp16 NHWC [N,H,W,Cin]; w [256,3,3,Cin]; w2 [cout2,1,1,256].  Returns (fp32 [N,H,W,cout2] or None, fused flag)."""
     x = np.ascontiguousarray(x, np.float16)

@@ -229,6 +229,35 @@ def test_maskrcnn_fp16_fused_stem_equals_conv_then_pool(ffi, sd):
         assert np.array_equal(a["boxes"][i], b["boxes"][i]) and np.array_equal(a["scores"][i], b["scores"][i])
 
 
+def test_maskrcnn_fp16_fused_fpn_merge_equals_conv_then_add(ffi, sd):
+    """configs[4] engine with the FPN top-down merge in the lateral conv's epilogue (default) against `fused_fpn_merge` 0 (lateral conv, then the nearest-2x
+    add kernel): every merged level, P2 and the detections are BIT-identical (the merged launch rounds the lateral result to fp16 before the add, as the
+    stored tensor is); same conv launches and FLOPs."""
+    import ctypes as C
+    from isegmi.maskrcnn import MaskRCNN, prepare_images
+    rng = np.random.default_rng(78)
+    x, hw = prepare_images([rng.uniform(0, 255, (250, 340, 3)).astype(np.float32), rng.uniform(0, 255, (203, 317, 3)).astype(np.float32)])
+    outs = {}
+    for fused in (1, 0):
+        model = MaskRCNN(sd, x.shape[1], x.shape[2], max_batch=2, fp16=True)
+        model.set_param("fused_fpn_merge", float(fused))
+        model.set_param("conv_timing", 1.0)
+        bl = model(x, hw)
+        f, m, l = C.c_double(), C.c_double(), C.c_int64()
+        ffi.check(ffi.lib().isegmi_engine_conv_stats(model._h, C.byref(f), C.byref(m), C.byref(l)))
+        buf = C.create_string_buffer(1 << 18); ffi.check(ffi.lib().isegmi_engine_conv_report(model._h, buf, 1 << 18))
+        outs[fused] = dict(l1=model.fetch("fpn.last1", 2), l2=model.fetch("fpn.last2", 2), l3=model.fetch("fpn.last3", 2), P2=model.fetch("P2", 2),
+                           boxes=[b.bbox.copy() for b in bl], launches=l.value, flops=f.value, report=buf.value.decode())
+        model.close()
+    a, b = outs[1], outs[0]
+    assert a["report"].count(".up2x") == 3 and ".up2x" not in b["report"]
+    assert a["launches"] == b["launches"] and abs(a["flops"] - b["flops"]) <= 1e-6 * b["flops"]
+    for k in ("l3", "l2", "l1", "P2"):
+        assert np.array_equal(a[k], b[k]), k
+    for i in range(2):
+        assert np.array_equal(a["boxes"][i], b["boxes"][i])
+
+
 def test_maskrcnn_fp16_fused_rpn_head_equals_two_launches(ffi, sd):
     """configs[4] engine at the full canvas (2 x 800 x 1344) with the RPN head of the big levels as one launch (default) against `fused_rpn_head` 0: the
     objectness / delta tensor of P2 is BIT-identical (both paths run the 3x3 on the row-strip tile), P3's within fp16 conv tolerance (the cost model may put
