@@ -14,7 +14,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CONV_KERNELS = ("conv_mfma", "conv_hybrid_kernel", "conv_f16_glds_kernel", "conv_f16_persist_kernel", "conv3x3_f16_strip_kernel", "bottleneck_f16_kernel")
+CONV_KERNELS = ("conv_mfma", "conv_hybrid_kernel", "conv_f16_glds_kernel", "conv_f16_persist_kernel", "conv3x3_f16_strip_kernel", "bottleneck_f16_kernel", "stem_pool_f16_kernel")
 STEPS_WARM, STEPS_AFTER = 2, 3
 
 
@@ -74,6 +74,19 @@ def join(argv):
         fb = sum(f[(nsteps - 1 - s) * L + i] for s in range(STEPS_AFTER)) / STEPS_AFTER * 1024.0 * 2.0
         wb = sum(w[(nsteps - 1 - s) * L + i] for s in range(STEPS_AFTER)) / STEPS_AFTER * 1024.0
         cin = 3 if (R == 7 and Cin == 4) else Cin
+        if name.endswith("conv1.fused") and R == 7:   # fused stem + max-pool: the haloed fp16 image once, the pooled tensor once
+            hc, wc = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+            rd = N * (H + 6) * ((W + 7) & ~1) * 4 * esz + 64 * 256 * esz
+            out.append((fb + wb - rd - N * ((hc - 1) // 2 + 1) * ((wc - 1) // 2 + 1) * Cout * esz, name, M, R * R * Cin, Cout, R, stride, res, rd, fb, N * ((hc - 1) // 2 + 1) * ((wc - 1) // 2 + 1) * Cout * esz, wb))
+            continue
+        if "+" in name and name.endswith(".fused"):   # 3x3 conv + fused 1x1 head: the input once, both weight banks, the fp32 head output (t never leaves the CU)
+            rd = (N * H * W * Cin + 9 * Cin * 256 + 256 * Cout) * esz
+            out.append((fb + wb - rd - M * Cout * 4, name, M, R * R * Cin, Cout, R, stride, res, rd, fb, M * Cout * 4, wb))
+            continue
+        if name.endswith(".up2x"):   # lateral 1x1 + nearest-2x top-down add: the coarser level (a quarter of the pixels) is the residual
+            rd = (N * H * W * Cin + Cin * Cout) * esz + (M // 4) * Cout * esz
+            out.append((fb + wb - rd - M * Cout * esz, name, M, R * R * Cin, Cout, R, stride, res, rd, fb, M * Cout * esz, wb))
+            continue
         if name.endswith(".fused"):   # fused bottleneck: x once (the residual re-read of the tile's centre is an L2 hit by design), the three / four weight banks, out once
             cmid = Cout // 4
             rd = (N * H * W * Cin + Cin * cmid + 9 * cmid * cmid + cmid * Cout + (Cin * Cout if Cin != Cout else 0)) * esz
