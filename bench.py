@@ -38,15 +38,17 @@ import numpy as np  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32-input MFMA peak (spec)
 PEAK_F16_MFMA_TFLOPS = 2500.0  # dense f16 MFMA peak (spec, no sparsity)
-PROFILE_ROUND = "r04"
+PROFILE_ROUND = "r05"
+ALLOW_STALE_TRAFFIC = False   # --allow-stale-traffic
 
 
 def pmc_traffic(name):
-    """HBM bytes per conv launch from the committed PMC summary (tools/pmc_summary.py), or None."""
-    for rnd in (PROFILE_ROUND, "r03", "r02", "r01"):
+    """HBM bytes per conv launch from THIS round's committed PMC summary (tools/pmc_summary.py), or None.  A summary of an older round
+    belongs to another binary: it is refused (traffic null, the note says so) unless --allow-stale-traffic, and then the note names it."""
+    for rnd in ((PROFILE_ROUND, "r04", "r03", "r02", "r01") if ALLOW_STALE_TRAFFIC else (PROFILE_ROUND,)):
         try:
             with open(os.path.join(ROOT, "profiles", "%s_%s" % (rnd, name))) as f:
-                return json.load(f)["conv_mfma_kernel_all"]["hbm_bytes_per_launch"], "%s_%s" % (rnd, name)
+                return json.load(f)["conv_mfma_kernel_all"]["hbm_bytes_per_launch"], "%s_%s%s" % (rnd, name, "" if rnd == PROFILE_ROUND else " (STALE: an older round's binary)")
         except Exception:
             continue
     return None, None
@@ -68,7 +70,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8, help="images the CPU oracle is timed on")
     ap.add_argument("--no-latency", action="store_true", help="skip the extra bs=1 latency pass")
-    ap.add_argument("--no-maskrcnn", action="store_true", help="default yolact run: skip the extra Mask R-CNN R50-FPN measurement")
+    ap.add_argument("--no-maskrcnn", action="store_true", help="default yolact run: skip the extra Mask R-CNN measurements (R50-FPN fp32 bs=2 = configs[2]; R101-FPN fp16 bs=8 = configs[4])")
+    ap.add_argument("--no-r101f16", action="store_true", help="default yolact run: skip the extra Mask R-CNN R101-FPN fp16 bs=8 measurement (configs[4] per-GPU shape)")
+    ap.add_argument("--no-box", action="store_true", help="skip the ~0.1 s box calibration (bare MFMA / copy loops)")
+    ap.add_argument("--allow-stale-traffic", action="store_true", help="roofline.traffic may come from an older round's committed PMC summary")
     ap.add_argument("--no-h2d", action="store_true", help="skip the extra timed loops (batch resident in HBM; fp32 upload)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end loop (uint8 upload -> ... -> RLE -> record block on the host)")
     ap.add_argument("--param", action="append", default=[], metavar="NAME=VALUE", help="engine parameter for A/B runs (isegmi_engine_set_param), repeatable")
@@ -132,8 +137,11 @@ def pct(xs, q):
 class Dist:
     """The N > 1 harness of the driver contract (one rank per GPU; barrier and MAX over ranks around the timed regions) on the product's own
     transport: the ranks -- started by `python -m torch.distributed.run` (the driver) or by `python -m isegmi.launch` (spawn_ranks), both set
-    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* -- meet through isegmi.dist.rendezvous_unique_id and synchronise with an 8-byte RCCL all-gather.
-    Nothing here imports torch."""
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* -- meet through isegmi.dist.rendezvous_unique_id ONCE and share ONE RCCL communicator per rank
+    for everything: the 8-byte control words (barrier, MAX), the detection-record blocks of the timed loops and the COCO record blocks of
+    the end-to-end loop (`make_gather` re-sizes the same isegmi.dist.RcclGather; round 4 built three communicators per rank -- three
+    ncclCommInitRank calls to hang in).  A control word goes out only on an idle communicator (RcclGather.allgather_bytes waits for this
+    rank's earlier gathers first), so the issue order of collectives is the program order on every rank.  Nothing here imports torch."""
 
     def __init__(self, a):
         self.rank = int(os.environ.get("RANK", "0"))
@@ -144,37 +152,51 @@ class Dist:
             sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d\n" % (a.gpus, self.world))
             raise SystemExit(2)
         self.on = self.world > 1 or self.force
-        self._ctl = None
+        self._g = None
+        self.rdzv_seconds = None
+        self.ranks = None
 
-    def _control(self):
-        if self._ctl is None:
+    def _gather(self):
+        if self._g is None:
             from isegmi import _ffi
+            from isegmi.dist import RcclGather, rendezvous_unique_id
             _ffi.set_device(self.local_rank)
-            self._ctl = self.make_gather(8)
-        return self._ctl
+            t0 = time.perf_counter()
+            uid = rendezvous_unique_id(self.rank, self.world, RcclGather.unique_id)
+            self.rdzv_seconds = time.perf_counter() - t0
+            self._g = RcclGather(self.rank, self.world, uid, 4096)
+            # who is there: every rank's (rank, device, seconds in ncclCommInitRank, seconds in the rendezvous) -- the first collective of the run
+            mine = np.array([self.rank, self.local_rank, self._g.init_seconds, self.rdzv_seconds], np.float64)
+            rows = self._g.allgather_bytes(mine.tobytes()).view(np.float64).reshape(self.world, 4)
+            self.ranks = [{"rank": int(r[0]), "device_id": int(r[1]), "comm_init_s": round(float(r[2]), 3), "rendezvous_s": round(float(r[3]), 3)} for r in rows]
+        return self._g
 
     def barrier(self):
         if self.on:
-            self._control().allgather_bytes(b"\0" * 8)
+            self._gather().allgather_bytes(b"\0" * 8)
 
     def max(self, v):
         if not self.on:
             return v
-        blocks = self._control().allgather_bytes(np.array([v], np.float64).tobytes())
+        blocks = self._gather().allgather_bytes(np.array([v], np.float64).tobytes())
         return float(blocks.view(np.float64).max())
 
     def make_gather(self, nbytes):
+        """The run's one RcclGather, sized for blocks of `nbytes` from here on (None at N = 1)."""
         if not self.on:
             return None
-        from isegmi.dist import RcclGather, rendezvous_unique_id
-        uid = rendezvous_unique_id(self.rank, self.world, RcclGather.unique_id)
-        return RcclGather(self.rank, self.world, uid, nbytes)
+        g = self._gather()
+        g.resize(nbytes)
+        return g
+
+    def info(self):
+        return {"rccl_communicators_per_rank": 1, "ranks": self.ranks} if self.on and self.ranks else None
 
     def close(self):
-        if self._ctl is not None:
+        if self._g is not None:
             self.barrier()
-            self._ctl.close()
-            self._ctl = None
+            self._g.close()
+            self._g = None
 
 
 def timed_region(net, step, full_sync, dist, steps):
@@ -319,14 +341,43 @@ def latency_pass(net, run1, iters=13, drop=3):
     return {"p50_ms_per_image": round(lat[len(lat) // 2], 3), "img_per_s": round(1e3 / lat[len(lat) // 2], 2)}
 
 
+STREAM_ROLES = ("main", "side0", "side1", "side2", "tail", "heads", "heads_side0", "heads_side1", "heads_side2", "copy")
+
+
+def stream_layout(net):
+    """Which of the engine's ten streams share an in-order hardware queue (isegmi_engine_stream_layout: equal numbers = one queue).  The
+    runtime folds a process's streams onto four queues by its stream-creation history; the engine deals its roles over probed candidates
+     -- printed so that a slow line can be told from a bad placement."""
+    from isegmi import _ffi
+    q = (C.c_int32 * 10)()
+    net.sync()
+    _ffi.check(_ffi.lib().isegmi_engine_stream_layout(net._h, q, 10))
+    cls = [int(v) for v in q]
+    ok = cls[0] not in (cls[4], cls[5], cls[9], cls[1]) and cls[4] not in (cls[5], cls[9])
+    return {"queue_class": dict(zip(STREAM_ROLES, cls)), "designed_partition": bool(ok),
+            "note": "main's queue carries neither tail, heads, copy nor side0; the tail's queue carries neither heads nor copy"}
+
+
+def box_calibration():
+    """Bare loops on this box right before the engines are built (~0.1 s): what the MFMA pipes and HBM of THIS device sustain."""
+    from isegmi import _ffi
+    b = _ffi.box_calibrate(30.0)
+    b["note"] = ("~30 ms each: dependent v_mfma_f32_32x32x2_f32 / v_mfma_f32_32x32x16_f16 chains on random register operands, four waves per SIMD, no memory traffic "
+                 "(nominal 157.3 / 2516 TF/s at 2.4 GHz: the quotient is the clock the box holds); float4 copy of 1 GiB, read + written bytes "
+                 "(~6.3 TB/s is what a copy reaches on this chip)")
+    return b
+
+
 def roofline_dict(kernel, flops, ms, launches, steps, peak, traffic_file):
     achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     traffic, src = pmc_traffic(traffic_file) if traffic_file else (None, None)
     return {"bound": "mfma", "kernel": kernel,
             "pass": "K single-stream steps right after the timed region, HIP events around every conv launch on the engine stream",
             "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
-            "traffic_note": ("HBM bytes per conv launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (profiles/%s; FETCH x2 gfx950 correction); not collected live" % src) if traffic else "null: no committed PMC pass for this configuration",
+            "traffic_note": ("HBM bytes per conv launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (profiles/%s; FETCH x2 gfx950 correction); not collected live" % src) if traffic else
+                            "null: no committed PMC pass of this round's binary for this configuration (an older round's summary is refused unless --allow-stale-traffic)",
             "algorithmic_gflop_per_step": round(flops / max(steps, 1) / 1e9, 2), "conv_ms_per_step": round(ms / max(steps, 1), 3),
+            "conv_ms_note": "single-stream figure: in the pipelined multi-stream timed region launches of two steps overlap, so conv_ms_per_step may exceed ms_per_step",
             "launches_per_step": launches // max(steps, 1), "avg_launch_us": round(ms * 1e3 / max(launches, 1), 2)}
 
 
@@ -439,8 +490,6 @@ def bench_yolact(a, dist):
             for k in range(0, int(cn[i]), 7):  # every 7th detection: the host encoder takes ~3 ms per 550x550 mask
                 e2e["rle_ok"] &= ch[so[i * K + k]:so[i * K + k + 1]].decode() == rle_to_string(rle_counts(mk[i, k]))
                 e2e["rle_checked"] += 1
-        if cgather is not None:
-            cgather.close()
     net.upload(imgs)
     full_sync()
     pin8.free()
@@ -544,14 +593,15 @@ def bench_yolact(a, dist):
 
 
 # ------------------------------------------------------------------------------------------------------------ Mask R-CNN
-def bench_maskrcnn(a, dist, summary=False):
+def bench_maskrcnn(a, dist, summary=None):
     """Mask R-CNN R50-FPN 1333x800 (padded 800x1344), bs=2 per GPU: BASELINE configs[2]; step = forward + Masker paste.
-    summary=True: the compact record the default (Yolact) run embeds under "maskrcnn"."""
+    summary: the compact records the default (Yolact) run embeds -- "r50": configs[2] under "maskrcnn"; "r101f16": the per-GPU shape of
+    configs[4] (R101-FPN, fp16 storage / f16 MFMA, bs=8) under "maskrcnn_r101_fp16" (no CPU leg: its full-size parity test runs under -m gpu)."""
     from isegmi import _ffi
     from isegmi.maskrcnn import MaskRCNN, MaskRCNNConfig, prepare_images
     from isegmi.weights import maskrcnn_state_dict
-    batch = 2 if summary else (a.batch or 2)
-    depth, fp16, c4 = (50, False, False) if summary else (a.depth, a.fp16, a.c4)
+    batch = {"r50": 2, "r101f16": 8}[summary] if summary else (a.batch or 2)
+    depth, fp16, c4 = {"r50": (50, False, False), "r101f16": (101, True, False)}[summary] if summary else (a.depth, a.fp16, a.c4)
     rank, world = dist.rank, dist.world
     if c4:
         from isegmi.weights import maskrcnn_c4_state_dict
@@ -620,7 +670,8 @@ def bench_maskrcnn(a, dist, summary=False):
         blocks = gather.fetch()
         rccl = {"rccl_ranks": int(gather.world), "ranks_with_records": int(sum(1 for r in range(world) if unpack_maskrcnn_records(blocks[r], batch, M=14 if c4 else 28)["count"].any()))}
     resident_elapsed = h2d_elapsed = e2e = rle_op = None
-    if not a.no_h2d:
+    lean = summary == "r101f16"   # (the embedded configs[4] block keeps the default run short: value, roofline, bs1)
+    if not a.no_h2d and not lean:
         resident_elapsed, _ = timed_region(model, step_resident, full_sync, dist, steps)
         pinned = _ffi.PinnedBuffer(x.shape)
         pinned.array[...] = x
@@ -632,7 +683,7 @@ def bench_maskrcnn(a, dist, summary=False):
         h2d_elapsed, _ = timed_region(model, step_f32, full_sync, dist, steps)
         full_sync()
         pinned.free()
-    if not a.no_e2e:
+    if not a.no_e2e and not lean:
         from isegmi.pipeline import RecordPipeline
         cgather = dist.make_gather(model.coco_record_bytes(batch)[0]) if gather is not None else None
         def run_rle(slot):
@@ -655,8 +706,6 @@ def bench_maskrcnn(a, dist, summary=False):
             for k in range(0, int(cn[i]), 9):  # every 9th detection: the host encoder takes ~10 ms per 800x1333 mask
                 e2e["rle_ok"] &= ch[so[i * K + k]:so[i * K + k + 1]].decode() == rle_to_string(rle_counts(mk[i, k]))
                 e2e["rle_checked"] += 1
-        if cgather is not None:
-            cgather.close()
     model.upload(x, hw)
     full_sync()
     pin8.free()
@@ -740,14 +789,19 @@ def bench_maskrcnn(a, dist, summary=False):
             ok &= np.array_equal(gpu["det.masks"][i, :c], pasted[i])
         out["parity_vs_oracle_on_bench_batch"] = bool(ok)
         out["parity_note"] = "%d images: proposals, detection count, score, label, box, 28x28 masks and the masks pasted at 800x1333 all bit-equal" % batch
+    out["stream_layout"] = stream_layout(model)
     if summary:
         keep = {"workload": out["config"]["workload"], "img_per_s": out["value"], "batch": batch, "ms_per_step": out["ms_per_step"], "steps": steps, "warmup": warmup,
-                "step_ms": out["step_ms"], "value_resident": out.get("value_resident"), "value_e2e": out.get("value_e2e"), "e2e": out.get("e2e"), "bs1": out.get("bs1"),
-                "roofline_hbm": out.get("roofline_hbm"),
-                "roofline": {k: roof[k] for k in ("achieved", "peak", "unit", "frac", "conv_ms_per_step", "launches_per_step", "algorithmic_gflop_per_step")},
+                "dtype": out["dtype"], "step_ms": out["step_ms"], "bs1": out.get("bs1"), "roofline_hbm": out.get("roofline_hbm"),
+                "roofline": {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "conv_ms_per_step", "launches_per_step", "algorithmic_gflop_per_step", "traffic", "traffic_note")},
                 "detections_per_image": out["config"]["detections_per_image"], "proposals_per_image": out["config"]["proposals_per_image"],
-                "cpu_baseline": out.get("cpu_baseline"), "parity_vs_oracle_on_bench_batch": out.get("parity_vs_oracle_on_bench_batch"),
-                "north_star_target": "Mask R-CNN R50-FPN 1333x800 bs=1 >= 30 img/s: bs1.img_per_s"}
+                "stream_layout": out["stream_layout"]}
+        if summary == "r50":
+            keep.update({"value_resident": out.get("value_resident"), "value_e2e": out.get("value_e2e"), "e2e": out.get("e2e"),
+                         "cpu_baseline": out.get("cpu_baseline"), "parity_vs_oracle_on_bench_batch": out.get("parity_vs_oracle_on_bench_batch"),
+                         "north_star_target": "Mask R-CNN R50-FPN 1333x800 bs=1 >= 30 img/s: bs1.img_per_s"})
+        else:
+            keep["parity_note"] = "fp16 is tolerance-parity, not index-exact: tests/test_maskrcnn_e2e_gpu.py::test_maskrcnn_r101_fp16_bs8_full_size (-m gpu) checks this shape against the fp16-emulating oracle"
         return keep, model, gather
     return out, model, gather
 
@@ -755,6 +809,8 @@ def bench_maskrcnn(a, dist, summary=False):
 def main():
     global _JSON_FD
     a = parse()
+    global ALLOW_STALE_TRAFFIC
+    ALLOW_STALE_TRAFFIC = bool(a.allow_stale_traffic)
     if a.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         spawn_ranks(a)
     sys.stdout.flush()
@@ -764,18 +820,30 @@ def main():
     from isegmi import _ffi
     if _ffi.device_count() < 1:
         raise SystemExit("no HIP device visible: bench.py measures the HIP path only (no CPU fallback)")
+    box = None
+    if not a.no_box and dist.rank == 0:
+        _ffi.set_device(dist.local_rank)
+        box = box_calibration()
     if a.model == "maskrcnn":
         out, net, gather = bench_maskrcnn(a, dist)
     else:
         out, net, gather = bench_yolact(a, dist)
-    if gather is not None:
-        gather.close()
+    if out is not None and a.model == "yolact":
+        out["stream_layout"] = stream_layout(net)
     net.close()
     if out is not None and a.model == "yolact" and dist.world == 1 and not dist.on and not a.no_maskrcnn and a.yolact_config == "resnet50" and not a.fp16:
-        m, model, _ = bench_maskrcnn(a, dist, summary=True)
+        m, model, _ = bench_maskrcnn(a, dist, summary="r50")
         out["maskrcnn"] = m
         model.close()
+        if not a.no_r101f16:
+            m, model, _ = bench_maskrcnn(a, dist, summary="r101f16")
+            out["maskrcnn_r101_fp16"] = m
+            model.close()
     if out is not None:
+        if box is not None:
+            out["box"] = box
+        if dist.info():
+            out.update(dist.info())
         emit(json.dumps(out))
     dist.close()
 

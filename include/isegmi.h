@@ -43,6 +43,11 @@ int isegmi_h2d(void* d_dst, const void* h_src, int64_t bytes);
 int isegmi_d2h(void* h_dst, const void* d_src, int64_t bytes);
 int isegmi_memset(void* d_ptr, int value, int64_t bytes);
 int isegmi_sync(void);
+/* Box calibration (diagnostic, not on the product path): what this device sustains on three bare loops of about ms_per_leg milliseconds each --
+ * dependent v_mfma_f32_32x32x2_f32 and v_mfma_f32_32x32x16_f16 chains on random register operands (four waves per SIMD, no memory traffic) and a
+ * float4 copy of 1 GiB (read + written bytes).  bench.py prints them as "box" so that a slow box can be told from a slow build (boxes of one pool
+ * differ by 3-12 %: MI355X_MICROARCH.md "DVFS give-back" 5). */
+int isegmi_box_calibrate(double ms_per_leg, double* mfma_f32_tflops, double* mfma_f16_tflops, double* hbm_copy_gbs);
 
 /* ---- convolution family: M2 M3 M4 M8 M10 M11 Y2 Y3 Y4 Y5 ----
  * Implicit-GEMM convolution on v_mfma_f32_32x32x2_f32 with fused per-channel affine
@@ -126,7 +131,8 @@ int isegmi_op_stem_pool_f16(int N, int H, int W, const void* d_halo, const void*
 
 /* device front end (Y1 FastBaseTransform, README.md:243-249 `--image=...`; M1 build_transform + to_image_list, README.md:320-331): a uint8
  * [N][Hin][Win][3] batch -> fp32 NHWC3 [N][Hpad][Wpad][3]: bilinear (align_corners = False) to Hout x Wout (identity when the sizes match),
- * out[.., swap_rb ? 2-c : c] = (v[c] - mean3[c]) / std3[c], zeros in the padding; bit-identical to the numpy transforms of isegmi/transforms.py */
+ * out[.., swap_rb ? 2-c : c] = (v[c] - mean3[c]) / std3[c], zeros in the padding; bit-identical to the oracle's ora_fast_base_transform /
+ * ora_build_transform (oracle/ora_ops.c: the rounding sequence is stated there) and to the numpy transforms of isegmi/transforms.py */
 int isegmi_op_preprocess_u8(const uint8_t* d_in, int N, int Hin, int Win, float* d_out, int Hout, int Wout, int Hpad, int Wpad,
                             int64_t out_img_stride, const float* mean3, const float* std3, int swap_rb, void* stream);
 

@@ -58,6 +58,13 @@ def sync():
     check(lib().isegmi_sync())
 
 
+def box_calibrate(ms_per_leg=30.0):
+    """{mfma_f32_tflops, mfma_f16_tflops, hbm_copy_gbs} of bare loops on the current device (isegmi_box_calibrate)."""
+    a, b, c = C.c_double(), C.c_double(), C.c_double()
+    check(lib().isegmi_box_calibrate(C.c_double(ms_per_leg), C.byref(a), C.byref(b), C.byref(c)))
+    return {"mfma_f32_tflops": round(a.value, 1), "mfma_f16_tflops": round(b.value, 1), "hbm_copy_gbs": round(c.value, 1)}
+
+
 class DeviceBuffer:
     """Owning device allocation with numpy shape/dtype metadata."""
 
@@ -191,6 +198,18 @@ def resize_bilinear(x, Ho, Wo, add=None, relu=0):
     dx = DeviceBuffer.from_numpy(x); do = DeviceBuffer((N, Ho, Wo, Cc))
     da = None if add is None else DeviceBuffer.from_numpy(np.asarray(add, np.float32))
     check(lib().isegmi_op_resize_bilinear(dx.ptr, N, H, W, Cc, Ho, Wo, _ptr(da), relu, do.ptr, None))
+    return do.numpy()
+
+
+def preprocess_u8(images_u8, Hout, Wout, Hpad, Wpad, mean3, std3, swap_rb):
+    """isegmi_op_preprocess_u8 (the device front end, M1 / Y1): [N, Hin, Win, 3] uint8 -> [N, Hpad, Wpad, 3] fp32."""
+    x = np.ascontiguousarray(images_u8)
+    if x.dtype != np.uint8 or x.ndim != 4 or x.shape[3] != 3:
+        raise TypeError("preprocess_u8 takes an [N, H, W, 3] uint8 batch")
+    N, H, W, _ = x.shape
+    dx = DeviceBuffer.from_numpy(x); do = DeviceBuffer((N, Hpad, Wpad, 3))
+    m = (C.c_float * 3)(*[float(v) for v in mean3]); sd = (C.c_float * 3)(*[float(v) for v in std3])
+    check(lib().isegmi_op_preprocess_u8(dx.ptr, N, H, W, do.ptr, Hout, Wout, Hpad, Wpad, C.c_int64(Hpad * Wpad * 3), m, sd, int(bool(swap_rb)), None))
     return do.numpy()
 
 

@@ -158,14 +158,26 @@ class RcclGather:
     SLOTS = 2
 
     def __init__(self, rank, world, uid_bytes, per_rank_bytes):
+        import time
         self.rank, self.world, self.nbytes = rank, world, int(per_rank_bytes)
         self._c = C.c_void_p()
         uid = C.create_string_buffer(bytes(uid_bytes), 128)
+        t0 = time.perf_counter()
         _ffi.check(_ffi.lib().isegmi_comm_create(uid, rank, world, C.byref(self._c)))
+        self.init_seconds = time.perf_counter() - t0   # ncclCommInitRank: the one call of a multi-rank run that can take (or hang for) long
         notify_launcher("comm %d" % rank)   # `python -m isegmi.launch --init-timeout`: this rank is through ncclCommInitRank
-        self.sends = [_ffi.DeviceBuffer((self.nbytes,), np.uint8) for _ in range(self.SLOTS)]
-        self.recvs = [_ffi.DeviceBuffer((self.nbytes * world,), np.uint8) for _ in range(self.SLOTS)]
+        self.capacity = 0
+        self.sends, self.recvs = [], []
+        self._alloc(self.nbytes)
+        self.slot_bytes = [0] * self.SLOTS   # block size of the gather each slot last carried (data blocks: nbytes; control words: fewer)
         self.step = 0
+
+    def _alloc(self, capacity):
+        for b in self.sends + self.recvs:
+            b.free()
+        self.capacity = int(capacity)
+        self.sends = [_ffi.DeviceBuffer((self.capacity,), np.uint8) for _ in range(self.SLOTS)]
+        self.recvs = [_ffi.DeviceBuffer((self.capacity * self.world,), np.uint8) for _ in range(self.SLOTS)]
 
     @staticmethod
     def unique_id():
@@ -197,6 +209,7 @@ class RcclGather:
         assert nb.value == self.nbytes, (nb.value, self.nbytes)
         _ffi.check(L.isegmi_engine_stream(net._h, C.byref(st)))
         _ffi.check(L.isegmi_comm_allgather_slot(self._c, slot, send.ptr, recv.ptr, C.c_int64(self.nbytes), st))
+        self.slot_bytes[slot] = self.nbytes
         self.step += 1
 
     def gather_coco_from(self, net, n_block):
@@ -213,6 +226,7 @@ class RcclGather:
         assert nb.value == self.nbytes, (nb.value, self.nbytes)
         _ffi.check(L.isegmi_engine_stream(net._h, C.byref(st)))
         _ffi.check(L.isegmi_comm_allgather_slot(self._c, slot, send.ptr, recv.ptr, C.c_int64(self.nbytes), st))
+        self.slot_bytes[slot] = self.nbytes
         self.step += 1
 
     def gather_empty(self):
@@ -222,18 +236,22 @@ class RcclGather:
         _ffi.check(L.isegmi_comm_wait_slot(self._c, slot))
         self.sends[slot].zero()  # synchronous memset: rare (at most once per rank and data set)
         _ffi.check(L.isegmi_comm_allgather_slot(self._c, slot, self.sends[slot].ptr, self.recvs[slot].ptr, C.c_int64(self.nbytes), None))
+        self.slot_bytes[slot] = self.nbytes
         self.step += 1
 
     def allgather_bytes(self, data):
-        """A synchronous control-plane all-gather of `nbytes` host bytes (bench.py's barrier / max-reduce of the wall time: the N > 1 harness
-        needs no second transport): -> [world, nbytes] uint8."""
+        """A synchronous control-plane all-gather of host bytes -- any size up to the slot capacity, the same on every rank (bench.py's
+        barrier / max-reduce of the wall time: the N > 1 harness needs neither a second transport nor a second communicator): -> [world, len]
+        uint8.  The communicator is idle when the word goes out: every earlier gather of this rank is waited for first, so the control
+        word can never overtake, or queue on another stream beside, a data block of the same communicator."""
         L = _ffi.lib()
         a = np.frombuffer(bytes(data), np.uint8)
-        assert a.size == self.nbytes, (a.size, self.nbytes)
+        assert 0 < a.size <= self.capacity, (a.size, self.capacity)
+        self.wait()
         slot = self.step % self.SLOTS
-        _ffi.check(L.isegmi_comm_wait_slot(self._c, slot))
-        self.sends[slot].upload(a)
-        _ffi.check(L.isegmi_comm_allgather_slot(self._c, slot, self.sends[slot].ptr, self.recvs[slot].ptr, C.c_int64(self.nbytes), None))
+        _ffi.check(L.isegmi_h2d(self.sends[slot].ptr, a.ctypes.data_as(C.c_void_p), C.c_int64(a.size)))
+        _ffi.check(L.isegmi_comm_allgather_slot(self._c, slot, self.sends[slot].ptr, self.recvs[slot].ptr, C.c_int64(a.size), None))
+        self.slot_bytes[slot] = int(a.size)
         self.step += 1
         return self.fetch()
 
@@ -247,19 +265,21 @@ class RcclGather:
         _ffi.check(_ffi.lib().isegmi_comm_wait(self._c))
 
     def resize(self, per_rank_bytes):
-        """New block size (the record block grew: larger RLE capacities) on the same communicator; every rank calls it at the same step."""
+        """New block size on the same communicator (the record block grew: larger RLE capacities; or the next phase of a run ships another
+        kind of block); every rank calls it at the same step.  Buffers only grow."""
         self.wait()
-        for b in self.sends + self.recvs:
-            b.free()
         self.nbytes = int(per_rank_bytes)
-        self.sends = [_ffi.DeviceBuffer((self.nbytes,), np.uint8) for _ in range(self.SLOTS)]
-        self.recvs = [_ffi.DeviceBuffer((self.nbytes * self.world,), np.uint8) for _ in range(self.SLOTS)]
+        if self.nbytes > self.capacity:
+            self._alloc(self.nbytes)
 
     def fetch(self, previous=False):
         assert self.step > (1 if previous else 0), "fetch before gather_from"
         slot = (self.step - (2 if previous else 1)) % self.SLOTS
         _ffi.check(_ffi.lib().isegmi_comm_wait_slot(self._c, slot))
-        return self.recvs[slot].numpy().reshape(self.world, self.nbytes)
+        nb = self.slot_bytes[slot]
+        out = np.empty((self.world, nb), np.uint8)
+        _ffi.check(_ffi.lib().isegmi_d2h(out.ctypes.data_as(C.c_void_p), self.recvs[slot].ptr, C.c_int64(self.world * nb)))
+        return out
 
     def close(self):
         if self._c:
@@ -286,10 +306,13 @@ _RDZV_SEQ = 0          # rendezvous calls made by this process: every rank makes
 _RDZV_PORTS = 32       # rank 0 listens on the first free port of MASTER_PORT + 1 .. MASTER_PORT + _RDZV_PORTS
 
 
-def _rdzv_tag(world, seq):
+def _rdzv_tag(world, seq, base_port):
+    """What identifies ONE rendezvous of ONE job on this node: the run id (ISEGMI_RUN_ID from isegmi.launch is unique per job;
+    TORCHELASTIC_RUN_ID is "none" for every default `python -m torch.distributed.run` job), the job's MASTER_PORT (two live jobs of one node
+    cannot share it: each job's launcher listens there), the world size and the per-process call number."""
     import os
     run = os.environ.get("TORCHELASTIC_RUN_ID", os.environ.get("ISEGMI_RUN_ID", "0"))
-    return ("ISEGMI-RDZV1 %s %d %d" % (run.replace(" ", "_"), world, seq)).encode()
+    return ("ISEGMI-RDZV2 %s %d %d %d" % (run.replace(" ", "_"), base_port, world, seq)).encode()
 
 
 def rendezvous_unique_id(rank, world, make_uid, timeout=120.0):
@@ -298,8 +321,10 @@ def rendezvous_unique_id(rank, world, make_uid, timeout=120.0):
     a moment ago cannot hand a stale id to the next one (round 3's file rendezvous judged a left-over file by its age: VERDICT r3).
     Rank 0 listens on the first free port of MASTER_PORT + 1 ... + 32 at MASTER_ADDR (MASTER_PORT itself belongs to the launcher: under
     `python -m torch.distributed.run` the agent's store listens there), the other ranks walk the same ports until a listener answers their
-    hello -- run id (TORCHELASTIC_RUN_ID / ISEGMI_RUN_ID), world size and the per-process call number, so that neither another job on a
-    neighbouring port nor an earlier rendezvous of the same job can be mistaken for this one -- with the id.  Both sides give up after `timeout`."""
+    hello -- run id, MASTER_PORT, world size and the per-process call number (`_rdzv_tag`) -- with that hello echoed in front of the id.
+    Two jobs whose port windows overlap (MASTER_PORT 29500 and 29501, the same default run id, the same world size: ADVICE r4) therefore
+    cannot take each other's id: a listener answers only its own job's hello, and a rank accepts only an answer that echoes its own.  Rank 0
+    counts a rank as served once per rendezvous, whatever else connected in between.  Both sides give up after `timeout`."""
     import os
     import socket
     import time
@@ -311,7 +336,7 @@ def rendezvous_unique_id(rank, world, make_uid, timeout=120.0):
     addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
     base = int(os.environ.get("MASTER_PORT", "29500"))
     ports = [base + 1 + k for k in range(_RDZV_PORTS)]
-    hello = _rdzv_tag(world, seq)
+    hello = _rdzv_tag(world, seq, base)
     t0 = time.time()
     if rank == 0:
         uid = make_uid()
@@ -341,13 +366,13 @@ def rendezvous_unique_id(rank, world, make_uid, timeout=120.0):
                 except socket.timeout:
                     continue
                 with c:
-                    c.settimeout(5.0)
+                    c.settimeout(1.0)   # a silent stray connection holds the (single-threaded) accept loop for at most this long
                     try:
                         msg = c.recv(256)
                         if msg.startswith(hello + b" ") and msg.endswith(b"\n"):
                             r = int(msg[len(hello) + 1:-1])
                             if 0 < r < world:
-                                c.sendall(uid)
+                                c.sendall(hello + b"\n" + uid)
                                 served.add(r)
                     except (OSError, ValueError):
                         pass           # a stray or foreign connection: closed without an answer, the caller keeps looking
@@ -355,20 +380,21 @@ def rendezvous_unique_id(rank, world, make_uid, timeout=120.0):
             srv.close()
         return uid
     msg = hello + (" %d\n" % rank).encode()
+    want = len(hello) + 1 + 128
     while True:
         for port in ports:
             try:
                 with socket.create_connection((addr, port), timeout=1.0) as c:
                     c.settimeout(5.0)
                     c.sendall(msg)
-                    uid = b""
-                    while len(uid) < 128:
-                        part = c.recv(128 - len(uid))
+                    ans = b""
+                    while len(ans) < want:
+                        part = c.recv(want - len(ans))
                         if not part:
                             break
-                        uid += part
-                    if len(uid) == 128:
-                        return uid
+                        ans += part
+                    if len(ans) == want and ans.startswith(hello + b"\n"):   # (anything else: another job's listener, or a stray service)
+                        return ans[-128:]
             except OSError:
                 pass
         if time.time() - t0 > timeout:

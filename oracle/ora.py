@@ -286,3 +286,35 @@ def set_conv_sum_mode(mode):
     """0: the oracle's k-ordered fmaf chain (default); 1: 16-term partial sums added to the accumulator -- a second, equally valid fp32
     association, used ONLY to measure how far two correct evaluations of the fp16-storage network drift apart (ora_set_conv_sum_mode)."""
     lib().ora_set_conv_sum_mode(I(int(mode)))
+
+
+# ---- front end (SURVEY 8a M1 / Y1): uint8 BGR images in, the networks' fp32 NHWC input out
+YOLACT_MEANS = (103.94, 116.78, 123.68)   # BGR, SURVEY 8a Y1
+YOLACT_STD = (57.38, 57.12, 58.40)
+PIXEL_MEAN = (102.9801, 115.9465, 122.7717)  # BGR, SURVEY App. A.0 (INPUT.PIXEL_MEAN; PIXEL_STD (1, 1, 1), TO_BGR255)
+
+
+def fast_base_transform(images_u8, size=550, darknet=False):
+    """FastBaseTransform (Y1): [N, H, W, 3] uint8 BGR -> [N, size, size, 3] fp32 RGB (ora_fast_base_transform)."""
+    x = np.ascontiguousarray(images_u8)
+    assert x.dtype == np.uint8 and x.ndim == 4 and x.shape[3] == 3
+    n, h, w, _ = x.shape
+    mean = _f((0.0, 0.0, 0.0) if darknet else YOLACT_MEANS)
+    std = _f((255.0, 255.0, 255.0) if darknet else YOLACT_STD)
+    out = np.empty((n, size, size, 3), np.float32)
+    lib().ora_fast_base_transform(_p(x), I(n), I(h), I(w), I(size), _p(mean), _p(std), I(1), _p(out))
+    return out
+
+
+def to_image_list(images_u8, divisibility=32):
+    """build_transform (after the PIL resize) + to_image_list (M1): list of [h, w, 3] uint8 BGR -> ([N, Hpad, Wpad, 3] fp32, image_sizes [N, 2])."""
+    hw = np.array([im.shape[:2] for im in images_u8], np.int32)
+    H = int(-(-int(hw[:, 0].max()) // divisibility) * divisibility)
+    W = int(-(-int(hw[:, 1].max()) // divisibility) * divisibility)
+    out = np.empty((len(images_u8), H, W, 3), np.float32)
+    mean = _f(PIXEL_MEAN)
+    for i, im in enumerate(images_u8):
+        a = np.ascontiguousarray(im)
+        assert a.dtype == np.uint8 and a.ndim == 3 and a.shape[2] == 3
+        lib().ora_build_transform(_p(a), I(a.shape[0]), I(a.shape[1]), I(H), I(W), _p(mean), _p(out[i]))
+    return out, hw

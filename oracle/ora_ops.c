@@ -954,4 +954,67 @@ ORA_API int64_t ora_rle_to_string(const uint32_t* counts, int64_t m, char* s) {
     return p;
 }
 
+/* ---- Front end: M1 (COCODemo.build_transform + to_image_list) and Y1 (FastBaseTransform) -- SURVEY.md 8a rows M1 / Y1, App. A.0 constants,
+ * App. A.1 bilinear rule; README.md:320-331 hands the predictor an HxWx3 uint8 BGR image, README.md:243 an image file read the same way.
+ * PARITY UNPINNED like the rest of the oracle.  uint8 in, fp32 NHWC out; the PIL resize of M1 (Resize(min 800, max 1333)) stays on the host in
+ * front of this (image decode / resize are outside the hot path).
+ *
+ * ora_fast_base_transform (Y1): img = F.interpolate(img, (S, S), mode='bilinear', align_corners=False) on the float image, then
+ *   (img - mean) / std per BGR channel, then BGR -> RGB (swap_rb); `yolact_darknet53_config` normalises with x / 255 instead, which is
+ *   mean 0 / std 255 here.  Rounding sequence (every operation individually rounded fp32; the file is built with -ffp-contract=off):
+ *     scale = (float)in / (float)out;  src = ((float)dst + 0.5f) * scale - 0.5f;  src = max(src, 0);  i0 = min((int)src, in - 1);
+ *     i1 = min(i0 + 1, in - 1);  l1 = src - (float)i0;  l0 = 1 - l1;
+ *     top = v00 * l0x + v01 * l1x;  bot = v10 * l0x + v11 * l1x;  v = top * l0y + bot * l1y;  out = (v - mean) / std   (IEEE division)
+ *   With in == out every l1 is exactly 0 and the resize is the identity: out = ((float)u8 - mean) / std. */
+ORA_API void ora_fast_base_transform(const uint8_t* img, int N, int H, int W, int S, const float* mean3, const float* std3, int swap_rb,
+                                     float* out) {
+    const float sch = (float)H / (float)S, scw = (float)W / (float)S;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int n = 0; n < N; ++n)
+        for (int y = 0; y < S; ++y) {
+            float sy = ((float)y + 0.5f) * sch - 0.5f;
+            if (sy < 0.0f) sy = 0.0f;
+            int y0 = (int)sy;
+            if (y0 > H - 1) y0 = H - 1;
+            const int y1 = y0 + 1 < H - 1 ? y0 + 1 : H - 1;
+            const float ly1 = sy - (float)y0, ly0 = 1.0f - ly1;
+            const uint8_t* im = img + (size_t)n * H * W * 3;
+            for (int x = 0; x < S; ++x) {
+                float sx = ((float)x + 0.5f) * scw - 0.5f;
+                if (sx < 0.0f) sx = 0.0f;
+                int x0 = (int)sx;
+                if (x0 > W - 1) x0 = W - 1;
+                const int x1 = x0 + 1 < W - 1 ? x0 + 1 : W - 1;
+                const float lx1 = sx - (float)x0, lx0 = 1.0f - lx1;
+                float* o = out + (((size_t)n * S + y) * S + x) * 3;
+                for (int c = 0; c < 3; ++c) {
+                    const float v00 = (float)im[((size_t)y0 * W + x0) * 3 + c], v01 = (float)im[((size_t)y0 * W + x1) * 3 + c];
+                    const float v10 = (float)im[((size_t)y1 * W + x0) * 3 + c], v11 = (float)im[((size_t)y1 * W + x1) * 3 + c];
+                    float top = v00 * lx0; { const float t = v01 * lx1; top = top + t; }
+                    float bot = v10 * lx0; { const float t = v11 * lx1; bot = bot + t; }
+                    float v = top * ly0; { const float t = bot * ly1; v = v + t; }
+                    v = v - mean3[c];
+                    o[swap_rb ? 2 - c : c] = v / std3[c];
+                }
+            }
+        }
+}
+
+/* ora_build_transform (M1, after the host's PIL resize): one already-resized h x w x 3 uint8 BGR image -> its slot of the batch tensor
+ *   to_image_list(images, SIZE_DIVISIBILITY) builds: ToTensor()*255 keeps BGR 0..255 (TO_BGR255), Normalize(mean = PIXEL_MEAN, std = (1, 1, 1)):
+ *   out[y, x, c] = (float)u8 - mean[c] (a division by 1 is exact and omitted), zero in the padding up to Hpad x Wpad (the batch's
+ *   largest (h, w), each rounded up to a multiple of SIZE_DIVISIBILITY = 32 by the caller).  The unpadded (h, w) is what the caller
+ *   remembers as image_sizes. */
+ORA_API void ora_build_transform(const uint8_t* img, int h, int w, int Hpad, int Wpad, const float* mean3, float* out) {
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < Hpad; ++y)
+        for (int x = 0; x < Wpad; ++x) {
+            float* o = out + ((size_t)y * Wpad + x) * 3;
+            if (y < h && x < w)
+                for (int c = 0; c < 3; ++c) o[c] = (float)img[((size_t)y * w + x) * 3 + c] - mean3[c];
+            else
+                o[0] = o[1] = o[2] = 0.0f;
+        }
+}
+
 ORA_API int ora_version(void) { return 1; }

@@ -63,6 +63,13 @@ def main():
     xd = r2.standard_normal((1, 9, 11, 8)).astype(np.float32)
     omd = r2.normal(0, 2.0, (1, 5, 6, 27)).astype(np.float32); omd[0, 0, :, :18] = np.round(omd[0, 0, :, :18])
     g["deform"] = dict(x=xd, om=omd, col=ora.deform_im2col(xd, omd, 3, 3, 2, 1, 1))
+    # front end (M1 / Y1): uint8 BGR in, the networks' fp32 input out; own generator (the fixtures above stay byte-stable)
+    r3 = np.random.default_rng(20261005)
+    yi = r3.integers(0, 256, (2, 37, 53, 3), dtype=np.uint8); yi[0, :2, :3] = 0; yi[1, -2:, -2:] = 255
+    mi = [r3.integers(0, 256, (45, 70, 3), dtype=np.uint8), r3.integers(0, 256, (61, 40, 3), dtype=np.uint8)]
+    mo, mhw = ora.to_image_list(mi)
+    g["frontend"] = dict(y_in=yi, y_out64=ora.fast_base_transform(yi, 64), y_out24=ora.fast_base_transform(yi, 24), y_dark=ora.fast_base_transform(yi, 64, darknet=True),
+                         m_in0=mi[0], m_in1=mi[1], m_out=mo, m_hw=mhw)
     only = sys.argv[1:]
     for k, v in g.items():
         if only and k not in only:

@@ -219,10 +219,58 @@ def test_box_postprocess_kth_value_cut():
     assert np.array_equal(s, s2[s2 >= thr])
 
 
-@pytest.mark.parametrize("name", ["conv", "conv1x1s2", "detmath", "nms", "roi_align", "yolact", "paste", "deform"])
+def test_front_end_known_answers():
+    """M1 / Y1 (App. A.0 constants, A.1 bilinear rule) on cases small enough to do by hand"""
+    # Y1, in == out: the resize is the identity -> ((float)u8 - mean) / std per BGR channel, then RGB order
+    x = np.array([[[[0, 128, 255], [10, 20, 30]]]], np.uint8)            # [1, 1, 2, 3]
+    y = ora.fast_base_transform(np.repeat(x, 2, 1), 2)
+    m, sd = np.float32(ora.YOLACT_MEANS), np.float32(ora.YOLACT_STD)
+    want = ((x[0, 0].astype(np.float32) - m) / sd)[:, ::-1]
+    assert np.array_equal(y[0, 0], want) and np.array_equal(y[0, 1], want)
+    # Y1, 2 -> 4 along a row of (0, 100): src = (d + .5) / 2 - .5 -> 0 (clamped), .25, .75, 1.25 -> values 0, 25, 75, 100 (the right tap clamps)
+    r = np.zeros((1, 1, 2, 3), np.uint8); r[0, 0, 1] = 100
+    y = ora.fast_base_transform(np.repeat(r, 2, 1), 4)                   # source 2 x 2 (both rows equal), target 4 x 4
+    v = np.array([0, 25, 75, 100], np.float32)
+    for c in range(3):
+        assert np.array_equal(y[0, 0, :, 2 - c], (v - m[c]) / sd[c]), c
+    assert np.array_equal(y[0, 0], y[0, 3])
+    # darknet53: x / 255, RGB
+    y = ora.fast_base_transform(np.full((1, 3, 3, 3), 255, np.uint8), 3, darknet=True)
+    assert np.array_equal(y, np.ones((1, 3, 3, 3), np.float32))
+    # M1: minus PIXEL_MEAN (BGR kept), zero padding to the batch's largest size rounded up to 32, unpadded sizes remembered
+    a = np.full((3, 40, 3), 200, np.uint8); b = np.full((33, 2, 3), 7, np.uint8)
+    out, hw = ora.to_image_list([a, b])
+    assert out.shape == (2, 64, 64, 3) and hw.tolist() == [[3, 40], [33, 2]]
+    pm = np.float32(ora.PIXEL_MEAN)
+    assert np.array_equal(out[0, :3, :40], np.broadcast_to(np.float32(200) - pm, (3, 40, 3))) and not out[0, 3:].any() and not out[0, :, 40:].any()
+    assert np.array_equal(out[1, :33, :2], np.broadcast_to(np.float32(7) - pm, (33, 2, 3))) and not out[1, 33:].any() and not out[1, :, 2:].any()
+
+
+def test_product_host_transforms_equal_oracle_front_end():
+    """the product's host-side transforms (the fallback of the device front end; what bench.py feeds `value_incl_h2d_f32`) are the same
+    functions as the oracle's front end, bit for bit"""
+    from isegmi.maskrcnn import prepare_images
+    from isegmi.transforms import yolact_transform
+    rng = np.random.default_rng(11)
+    for hw in ((200, 200), (123, 171), (480, 640), (37, 29)):
+        x = rng.integers(0, 256, (2,) + hw + (3,), dtype=np.uint8)
+        assert np.array_equal(ora.fast_base_transform(x, 200), np.concatenate([yolact_transform(im, 200) for im in x]))
+        assert np.array_equal(ora.fast_base_transform(x, 200, darknet=True), np.concatenate([yolact_transform(im, 200, darknet=True) for im in x]))
+    ims = [rng.integers(0, 256, (200, 333, 3), dtype=np.uint8), rng.integers(0, 256, (256, 190, 3), dtype=np.uint8)]
+    a, hw = ora.to_image_list(ims)
+    b, hw2 = prepare_images([im.astype(np.float32) for im in ims])
+    assert np.array_equal(a, b) and np.array_equal(hw, hw2)
+
+
+@pytest.mark.parametrize("name", ["conv", "conv1x1s2", "detmath", "nms", "roi_align", "yolact", "paste", "deform", "frontend"])
 def test_oracle_reproduces_golden(name):
     g = gold(name)
-    if name == "conv":
+    if name == "frontend":
+        assert np.array_equal(ora.fast_base_transform(g["y_in"], 64), g["y_out64"]) and np.array_equal(ora.fast_base_transform(g["y_in"], 24), g["y_out24"])
+        assert np.array_equal(ora.fast_base_transform(g["y_in"], 64, darknet=True), g["y_dark"])
+        out, hw = ora.to_image_list([g["m_in0"], g["m_in1"]])
+        assert np.array_equal(out, g["m_out"]) and np.array_equal(hw, g["m_hw"])
+    elif name == "conv":
         assert np.array_equal(ora.conv2d(g["x"], g["w"], 1, 1, g["scale"], g["shift"], g["res"], 1), g["y"])
     elif name == "conv1x1s2":
         assert np.array_equal(ora.conv2d(g["x"], g["w"], 2, 0), g["y"])

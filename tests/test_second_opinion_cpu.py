@@ -372,3 +372,24 @@ def test_masker_paste_against_torch():
             near[y0:y1, x0:x1] = (up - 0.5).abs()[(y0 - int(eb[1])):(y1 - int(eb[1])), (x0 - int(eb[0])):(x1 - int(eb[0]))] <= 1e-5
         assert not (d & ~near.numpy()).any(), i
     assert got.any()
+
+
+@pytest.mark.parametrize("hw,size", [((123, 171), 200), ((480, 640), 550), ((600, 400), 64), ((550, 550), 550)])
+def test_front_end_against_torch(hw, size):
+    """Y1 FastBaseTransform = F.interpolate(bilinear, align_corners=False) + (x - mean) / std + BGR -> RGB, M1 = x - PIXEL_MEAN + zero padding,
+    against torch on the CPU (a second opinion on the restatement, not the reference).  Tolerance: the source coordinate (dst + .5) * scale - .5
+    is rounded at the magnitude of the image size, so the interpolation weight carries ~1 ulp(size) of noise whatever the association --
+    times the 0..255 range over std (57): 3 ulp(max(h, w)) * 255 / 57"""
+    rng = np.random.default_rng(hw[0] + size)
+    x = rng.integers(0, 256, (2,) + hw + (3,), dtype=np.uint8)
+    t = F.interpolate(torch.from_numpy(x.astype(np.float32)).permute(0, 3, 1, 2), (size, size), mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+    t = ((t - torch.tensor(ora.YOLACT_MEANS)) / torch.tensor(ora.YOLACT_STD)).flip(-1).numpy()
+    got = ora.fast_base_transform(x, size)
+    assert got.shape == t.shape and np.max(np.abs(got - t)) < 3 * float(np.spacing(np.float32(max(hw)))) * 255 / 57
+    ims = [x[0], x[1, : hw[0] - 5, : hw[1] - 9]]
+    out, sizes = ora.to_image_list(ims)
+    H, W = -(-hw[0] // 32) * 32, -(-hw[1] // 32) * 32
+    want = torch.zeros(2, H, W, 3)
+    for i, im in enumerate(ims):
+        want[i, : im.shape[0], : im.shape[1]] = torch.from_numpy(im.astype(np.float32)) - torch.tensor(ora.PIXEL_MEAN)
+    assert np.array_equal(out, want.numpy()) and sizes.tolist() == [list(im.shape[:2]) for im in ims]
