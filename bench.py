@@ -301,7 +301,7 @@ def rle_roofline(net, run_once, full_sync, batch, K, single_stream, reps=5):
 
 
 def hbm_traffic(name):
-    """counter bytes per HBM-bound stage from the committed PMC summary (tools/hbm_kernel_traffic.py), or None"""
+    """counter bytes per HBM-bound stage from the committed PMC summary (tools/hbm_stage_traffic.py), or None"""
     try:
         with open(os.path.join(ROOT, "profiles", "%s_%s" % (PROFILE_ROUND, name))) as f:
             return json.load(f)

@@ -97,7 +97,8 @@ int isegmi_op_conv2d_f16(const isegmi_conv_desc* d, const void* d_in, const void
  * weights are the isegmi_pack_conv_weights_f16 images of the three layers, scale / shift the folded FrozenBN of each. */
 typedef struct isegmi_bottleneck_desc {
     int32_t N, H, W, Cin, Cmid;
-    int32_t flags;                   /* bit 0 (test hook): 8-block grid, so that small shapes exercise the multi-tile stream */
+    int32_t flags;                   /* bit 0 (test hook): 8-block grid, so that small shapes exercise the multi-tile stream; any other bit is rejected (ISEGMI_ERR_ARG) -- the
+                                        timing-only experiment bits of the development builds (-DISEGMI_EXPERIMENT_FLAGS) produce wrong results and do not exist in a release build */
 } isegmi_bottleneck_desc;
 int isegmi_op_bottleneck_f16(const isegmi_bottleneck_desc* d, const void* d_x, const void* d_w1, const float* d_s1, const float* d_b1,
                              const void* d_w2, const float* d_s2, const float* d_b2, const void* d_w3, const float* d_s3,

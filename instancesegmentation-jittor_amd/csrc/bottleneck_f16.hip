@@ -609,15 +609,9 @@ static int launch_btl(BtlK& k, hipStream_t st, int few) {
     const int64_t total = (int64_t)k.N * k.tiles_x * k.tiles_y;
     ARG_CHECK(total < (1 << 30), "too many tiles");
     k.total = (int)total;
-    static bool attr = false;
-    static int ncu = 0;
-    if (!attr) {
-        HIP_TRY(hipFuncSetAttribute((const void*)bottleneck_f16_kernel<CF>, hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS));
-        int dev = 0;
-        HIP_TRY(hipGetDevice(&dev));
-        HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-        attr = true;
-    }
+    static PerDeviceOnce attr;
+    if (attr.need()) HIP_TRY(hipFuncSetAttribute((const void*)bottleneck_f16_kernel<CF>, hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS));
+    const int ncu = device_cu_count();
     int64_t slots = few ? 8 : (int64_t)(ncu / 8) * 8;  // one block per CU; a multiple of 8 keeps a block's tiles on its XCD
     if (slots < 8) slots = 8;
     const unsigned grid = (unsigned)(total < slots ? total : slots);
@@ -657,6 +651,7 @@ int bottleneck_f16_launch(const isegmi_bottleneck_desc* d, const void* x, const 
     k.w3_bytes = (unsigned)(pad128(4 * d->Cmid) * d->Cmid * 2);
     k.wd_bytes = ds ? (unsigned)(pad128(4 * d->Cmid) * d->Cin * 2) : 0u;
     k.res_bytes = ds ? 0u : k.out_bytes;
+    ARG_CHECK(kExperimentFlags || (d->flags & ~1) == 0, "isegmi_bottleneck_desc.flags: only bit 0 exists in a release build (timing-only experiment bits need -DISEGMI_EXPERIMENT_FLAGS)");
     const int few = d->flags & 1;  // TEST HOOK: 8-block grid, so that small shapes exercise the multi-tile stream
     // TIMING-ONLY experiments (results wrong): the range check drops every x load (2) / residual load (4) / output store (8) / weight load (16)
     if (d->flags & 2) k.x_bytes = 0;

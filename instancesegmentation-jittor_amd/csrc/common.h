@@ -43,4 +43,26 @@ const char* get_error();
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// hipFuncSetAttribute acts on the CURRENT device: a call site remembers per device whether it has raised its kernel's dynamic-LDS limit
+// (a process-wide flag left a second device of the same process at the 64 KB default: ADVICE r4).
+struct PerDeviceOnce {
+    bool done[32] = {};
+    bool need() {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return true;
+        if (done[dev]) return false;
+        done[dev] = true;
+        return true;
+    }
+};
+int device_cu_count();   // compute units of the current device (cached per device; csrc/conv_mfma.hip)
+
+// Timing-only experiment switches (they drop loads / stores / whole phases: the results are WRONG) exist only in a build made with
+// -DISEGMI_EXPERIMENT_FLAGS (tools/build_variant.sh exp -DISEGMI_EXPERIMENT_FLAGS); a release build rejects their bits at the C ABI.
+#ifdef ISEGMI_EXPERIMENT_FLAGS
+constexpr bool kExperimentFlags = true;
+#else
+constexpr bool kExperimentFlags = false;
+#endif
+
 }  // namespace isegmi

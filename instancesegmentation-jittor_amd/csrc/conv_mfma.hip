@@ -917,12 +917,12 @@ static int launch(const isegmi_conv_desc* d, ConvK& k, hipStream_t st) {
     const size_t lds = 2 * (size_t)(BM + BN) * LDS_ROW * sizeof(float);
     const dim3 grid((unsigned)(k.mtiles * k.ntiles)), block(256);
     if (is_stem(d)) {
-        static bool attr = false;
-        if (!attr) { HIP_TRY(hipFuncSetAttribute((const void*)conv_mfma_kernel<BM, BN, WM, WN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+        static PerDeviceOnce attr;
+        if (attr.need()) HIP_TRY(hipFuncSetAttribute((const void*)conv_mfma_kernel<BM, BN, WM, WN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, true>), grid, block, lds, st, k);
     } else {
-        static bool attr = false;
-        if (!attr) { HIP_TRY(hipFuncSetAttribute((const void*)conv_mfma_kernel<BM, BN, WM, WN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+        static PerDeviceOnce attr;
+        if (attr.need()) HIP_TRY(hipFuncSetAttribute((const void*)conv_mfma_kernel<BM, BN, WM, WN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, false>), grid, block, lds, st, k);
     }
     HIP_TRY(hipGetLastError());

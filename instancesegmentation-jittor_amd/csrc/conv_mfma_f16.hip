@@ -1165,8 +1165,8 @@ static int launch_strip(ConvKH& k, hipStream_t st) {
     k.trace = tracing ? trace_buf : nullptr;
     if (tracing && getenv("ISEGMI_STRIP_TRACE_LIGHT")) k.dbg |= 16;
 #endif
-    static bool attr = false;
-    if (!attr) { HIP_TRY(hipFuncSetAttribute((const void*)conv3x3_f16_strip_kernel<BM, BN, WM, WN, LW, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_attr)); attr = true; }
+    static PerDeviceOnce attr;
+    if (attr.need()) HIP_TRY(hipFuncSetAttribute((const void*)conv3x3_f16_strip_kernel<BM, BN, WM, WN, LW, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_attr));
     hipLaunchKernelGGL((conv3x3_f16_strip_kernel<BM, BN, WM, WN, LW, NB>), dim3((unsigned)(k.mtiles * k.ntiles)), dim3((NW + LW) * 64), lds, st, k);
     HIP_TRY(hipGetLastError());
 #ifdef ISEGMI_STRIP_TRACE
@@ -1194,8 +1194,8 @@ static int launch_g(ConvKH& k, hipStream_t st) {
     size_t lds = (size_t)NSTAGE * (BM + BN) * 128;
     const size_t epi = (size_t)NW * 32 * (TN * 32 + 4) * 4;
     if (epi > lds) lds = epi;
-    static bool attr = false;
-    if (!attr) { HIP_TRY(hipFuncSetAttribute((const void*)conv_f16_glds_kernel<BM, BN, WM, WN, NSTAGE, OCC, STEM, LW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+    static PerDeviceOnce attr;
+    if (attr.need()) HIP_TRY(hipFuncSetAttribute((const void*)conv_f16_glds_kernel<BM, BN, WM, WN, NSTAGE, OCC, STEM, LW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((conv_f16_glds_kernel<BM, BN, WM, WN, NSTAGE, OCC, STEM, LW>), dim3((unsigned)(k.mtiles * k.ntiles)), dim3((NW + LW) * 64), lds, st, k);
     HIP_TRY(hipGetLastError());
     return ISEGMI_OK;
@@ -1211,15 +1211,9 @@ static int launch_p(ConvKH& k, hipStream_t st, bool few) {
     size_t lds = (size_t)NSTAGE * (BM + BN) * 128;
     const size_t epi = (size_t)NW * 32 * (TN * 32 + 4) * 4;  // the per-element epilogue path uses none; kept >= the one-tile kernel's request
     (void)epi;
-    static bool attr = false;
-    static int ncu = 0;
-    if (!attr) {
-        HIP_TRY(hipFuncSetAttribute((const void*)conv_f16_persist_kernel<BM, BN, WM, WN, NSTAGE, OCC, LW, UP2X>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        int dev = 0;
-        HIP_TRY(hipGetDevice(&dev));
-        HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-        attr = true;
-    }
+    static PerDeviceOnce attr;
+    if (attr.need()) HIP_TRY(hipFuncSetAttribute((const void*)conv_f16_persist_kernel<BM, BN, WM, WN, NSTAGE, OCC, LW, UP2X>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int ncu = device_cu_count();
     const int64_t total = (int64_t)k.mtiles * k.ntiles;
     int64_t slots = few ? 8 : (int64_t)(ncu / 8) * 8 * OCC;  // a multiple of 8, so that a block's tiles stay on its XCD
     if (slots < 8) slots = 8;
@@ -1302,6 +1296,7 @@ static int conv2d_f16_launch_impl(const isegmi_conv_desc* d, const void* in, con
     k.vec_epi = (d->Cout % 8 == 0 && (k.out_pix_stride & align_mask) == 0 && (k.out_img_stride & align_mask) == 0 && ((uintptr_t)out & 15) == 0 &&
                  (res == nullptr || ((uintptr_t)res & 15) == 0)) ? 1 : 0;
     int tile = d->tile;
+    ARG_CHECK(kExperimentFlags || (tile & ~(255 | 2048)) == 0, "conv tile: bits 256 / 512 / 1024 / 4096 are timing-only experiments (-DISEGMI_EXPERIMENT_FLAGS builds only)");
     if (tile & 256) { k.in_bytes = 0; k.w_bytes = 0; }
     if (tile & 512) k.in_bytes = 0;
     if (tile & 1024) k.w_bytes = 0;

@@ -945,11 +945,8 @@ int rpn_decode_nms_launch(const float* head, const float* anchors, const float* 
     if (pre_nms <= NMS_CAP && nms_ws != nullptr && post_nms > 0) {
         constexpr int W = NMS_CAP / 64;
         constexpr int matrix_bytes = NMS_CAP * W * 8;  // 128 KB next to 19 KB of static LDS
-        static bool attr = false;
-        if (!attr) {
-            HIP_TRY(hipFuncSetAttribute((const void*)rpn_nms_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, matrix_bytes));
-            attr = true;
-        }
+        static PerDeviceOnce attr;
+        if (attr.need()) HIP_TRY(hipFuncSetAttribute((const void*)rpn_nms_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, matrix_bytes));
         const int pairs = W * (W + 1) / 2;
         hipLaunchKernelGGL(rpn_nms_matrix_kernel, dim3(cdiv(pairs, 4), N), dim3(256), 0, st, head, anchors, tk_idx, tk_cnt, image_hw, HWA, A,
                            CH, pre_nms, thr, ge, (unsigned long long*)nms_ws);
@@ -1036,11 +1033,8 @@ int box_postprocess_launch(const isegmi_box_post_args* a, hipStream_t st) {
     if (rc) return rc;
     HIP_TRY(hipMemsetAsync(a->d_ws_kept_total, 0, sizeof(int) * (size_t)a->N, st));
     constexpr int matrix_bytes = NMS_CAP * (NMS_CAP / 64) * 8;  // 128 KB next to 26 KB of static LDS: one block per CU
-    static bool attr = false;
-    if (!attr) {
-        HIP_TRY(hipFuncSetAttribute((const void*)box_cls_nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, matrix_bytes));
-        attr = true;
-    }
+    static PerDeviceOnce attr;
+    if (attr.need()) HIP_TRY(hipFuncSetAttribute((const void*)box_cls_nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, matrix_bytes));
     hipLaunchKernelGGL(box_cls_nms_kernel, dim3(nc, a->N), dim3(BOX_NMS_THREADS), matrix_bytes, st, a->d_ws_prob, a->d_regr, a->regr_stride, a->d_props,
                        a->d_prop_cnt, a->d_image_hw, a->R, a->ncls, a->score_thresh, a->nms_thresh, a->nms_ge, a->d_ws_cand_scores,
                        a->d_ws_cand_boxes, a->d_ws_kept_total);

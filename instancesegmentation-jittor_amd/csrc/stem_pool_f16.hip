@@ -209,6 +209,7 @@ int stem_pool_f16_launch(int N, int H, int W, const void* halo, const void* w, c
                          hipStream_t st) {
     ARG_CHECK(halo && w && scale && shift && out, "null");
     ARG_CHECK(N > 0 && H > 0 && W > 0, "shape");
+    ARG_CHECK(kExperimentFlags || (flags & ~3) == 0, "stem flags: only the test hooks (bits 0, 1) exist in a release build (timing-only experiment bits need -DISEGMI_EXPERIMENT_FLAGS)");
     StemPoolK k;
     k.in = (const half_t*)halo; k.w = (const half_t*)w; k.scale = scale; k.shift = shift; k.out = (half_t*)out;
     k.N = N; k.Hh = H + 6; k.Wh = (W + 7) & ~1;
@@ -226,8 +227,8 @@ int stem_pool_f16_launch(int N, int H, int W, const void* halo, const void* w, c
     k.total = (int)total;
     k.dbg = (flags >> 2) & 15 ? (flags & 60) : 0;
     const int grid = (flags & 1) ? (k.total < 8 ? k.total : 8) : (k.total < ncu ? k.total : ncu);   // flags bit 0 (test hook): blocks that walk many units
-    static bool attr = false;
-    if (!attr) { HIP_TRY(hipFuncSetAttribute((const void*)stem_pool_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS)); attr = true; }
+    static PerDeviceOnce attr;
+    if (attr.need()) HIP_TRY(hipFuncSetAttribute((const void*)stem_pool_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS));
     hipLaunchKernelGGL(stem_pool_f16_kernel, dim3((unsigned)grid), dim3(256), SP_LDS, st, k);
     HIP_TRY(hipGetLastError());
     return ISEGMI_OK;

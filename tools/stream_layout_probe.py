@@ -4,9 +4,14 @@ import ctypes as C, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path[:0] = [ROOT, os.path.join(ROOT, "instancesegmentation-jittor_amd")]
 if len(sys.argv) > 2 or (len(sys.argv) == 2 and "," in sys.argv[1]):
     ks = sys.argv[1].split(",") if "," in sys.argv[1] else sys.argv[1:]
+    rc = 0
     for k in ks:   # one fresh process per k: the placement is a property of the process's history
-        print(subprocess.run([sys.executable, os.path.abspath(__file__), str(k)], capture_output=True, text=True).stdout.strip(), flush=True)
-    sys.exit(0)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), str(k)], capture_output=True, text=True)
+        print(r.stdout.strip(), flush=True)
+        if r.returncode != 0:   # a failed child is this tool's failure, with its reason
+            sys.stderr.write("k=%s: child exited with %d\n%s\n" % (k, r.returncode, r.stderr[-2000:]))
+            rc = rc or r.returncode
+    sys.exit(rc)
 import numpy as np
 from isegmi import _ffi
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 0
