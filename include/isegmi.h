@@ -130,6 +130,15 @@ int isegmi_op_pad_c3_to_f16_halo(const float* d_in_nhwc3, int N, int H, int W, v
 int isegmi_op_stem_pool_f16(int N, int H, int W, const void* d_halo, const void* d_w, const float* d_scale, const float* d_shift, void* d_out,
                             int flags, void* stream);
 
+/* MFMA shape of the fp16 backbone tiles (process-wide tuning knob): 0: v_mfma_f32_32x32x16_f16 everywhere; 1 (default): the 192 x 256 row-strip tile of the
+ * 3x3 layers and the fused RPN head on v_mfma_f32_16x16x32_f16 (same output tile per wave, same LDS images; the chip holds a higher clock on it in
+ * power-bound loops: +8 % on the 634-GF layer); 2: the persistent 192 x 256 / 256 x 128 / 128 x 256 tiles and the UP2X merge as well (memory-bound: no gain).
+ * RESULTS DO NOT DEPEND ON THE SHAPE: one 16 x 16 x 32 instruction sums its 32 products bit for bit as two chained 32 x 32 x 16 instructions do
+ * (tools/microbench/mfma_shape.hip), so every fused-vs-unfused bit identity of the fp16 family holds under any setting.
+ * conv tile ids 40 / 44 / 47 / 49 force the 16 x 16 x 32 form of 30 / 34 / 37 / 39 for one launch. */
+int isegmi_set_f16_mfma_shape(int shape);
+int isegmi_get_f16_mfma_shape(int* shape);
+
 /* device front end (Y1 FastBaseTransform, README.md:243-249 `--image=...`; M1 build_transform + to_image_list, README.md:320-331): a uint8
  * [N][Hin][Win][3] batch -> fp32 NHWC3 [N][Hpad][Wpad][3]: bilinear (align_corners = False) to Hout x Wout (identity when the sizes match),
  * out[.., swap_rb ? 2-c : c] = (v[c] - mean3[c]) / std3[c], zeros in the padding; bit-identical to the oracle's ora_fast_base_transform /
@@ -276,6 +285,16 @@ int isegmi_op_rpn_level(const float* d_head, const float* d_anchors, const int32
                         int32_t* d_out_cnt, void* d_ws_nms /* optional: N * 131072 bytes, the suppression
                         matrix of the chip-wide NMS used when pre_nms <= 1024; NULL = single-block NMS */,
                         void* stream);
+/* the same for nl <= 5 FPN levels at once (SURVEY 2.1 "level x image as one batch dimension"): five launches -- sigmoid, two-level top-k, suppression
+ * matrix, greedy scan -- over all (level, image) rows; 256 < pre_nms <= 1024.  d_heads / d_anchors: HOST arrays of nl DEVICE pointers ([N][HW_l][A*5] /
+ * [HW_l*A][4]).  Outputs [N][nl][post_nms][4], [N][nl][post_nms] (-1 beyond the count), [N][nl]: level l's list is what isegmi_op_rpn_level gives for it,
+ * bit for bit.  Workspaces (isegmi_op_rpn_levels_workspace): prob prob_elems floats, cand_vals / cand_idx cand_elems each, tk_vals / tk_idx
+ * nl*N*pre_nms, tk_cnt nl*N, nms nl*N*131072 bytes. */
+int isegmi_op_rpn_levels_workspace(int nl, int N, const int32_t* HW, int A, int pre_nms, int64_t* prob_elems, int64_t* cand_elems);
+int isegmi_op_rpn_levels(int nl, const float* const* d_heads, const float* const* d_anchors, const int32_t* HW, const int32_t* d_image_hw, int N, int A,
+                         int pre_nms, int post_nms, float nms_thr, float min_size, int nms_ge, float* d_ws_prob, float* d_ws_cand_vals,
+                         int32_t* d_ws_cand_idx, float* d_ws_tk_vals, int32_t* d_ws_tk_idx, int32_t* d_ws_tk_cnt, void* d_ws_nms,
+                         float* d_out_boxes, float* d_out_scores, int32_t* d_out_cnt, void* stream);
 
 /* ---- COCO run-length encoding on the device (the on-disk format behind inference() / tools/test_net.py,
  * README.md:344-347, annotation layout README.md:55-66; Yolact eval.py Detections.add_mask / dump, README.md:243-249) ----

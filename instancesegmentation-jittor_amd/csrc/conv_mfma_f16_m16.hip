@@ -1,16 +1,57 @@
-// conv_mfma_f16.hip -- NHWC implicit-GEMM convolution on v_mfma_f32_32x32x16_f16 (gfx950): fp16 storage,
-// fp32 accumulate.  BASELINE.json configs[4] ("Mask R-CNN R101-FPN ... with fp16 MFMA conv"); SURVEY 8a M2-M11
-// "num. type f32 (f16 cfg5)".
-//
-// One accumulator per output, K walked as (r, s, cin) in 64-half chunks, padding by the buffer range check, fused
-// scale/shift/residual/ReLU epilogue in fp32.  The f16 MFMA consumes 8 consecutive k per lane half (lane (r,h) holds
-// k = 8h..8h+7 of a 16-deep step), so the NHWC channel run is used as stored.  Numerics: products are exact in fp32, the
-// 16-term sum inside one MFMA is not an ordered fmaf chain, so parity with the oracle is TOLERANCE-based here (tests
-// state it).
+// conv_mfma_f16_m16.hip -- the fp16 backbone tiles on v_mfma_f32_16x16x32_f16 (round 5): the 192 x 256 row-strip kernel (3x3 / 1 / 1) and the
+// persistent loader-wave kernel of csrc/conv_mfma_f16.hip with the SAME loaders, LDS chunk images, barrier protocol, tile walk and output tile per wave
+// (64 x 64) -- only the MFMA waves' fragment reads, the instruction and the accumulator layout (hence the epilogues' staging) differ.  Its own translation
+// unit so that the 32 x 32 x 16 kernels' code generation is untouched (co-compiled template variants share register-allocation context: the first attempt,
+// one template with a shape parameter, spilled in the 32 x 32 x 16 instantiations that had not spilled before).  The kernels keep the shape parameter MS
+// (only MS = 1 is instantiated here) so that the two files can be diffed.
 #include "conv_f16.h"
 
 namespace isegmi {
 
+// ---- the two f16 MFMA shapes (round 5).  A wave tile of TM*32 rows x TN*32 columns is held either as TM x TN blocks of 32 x 32 (sixteen registers each,
+// v_mfma_f32_32x32x16_f16: lane (lr = lane & 31, lh = lane >> 5), register e <-> row (e & 3) + 8 (e >> 2) + 4 lh, column lr) or as 2TM x 2TN blocks of
+// 16 x 16 (four registers each, v_mfma_f32_16x16x32_f16: lane (l15 = lane & 15, lq = lane >> 4), register e <-> row 4 lq + e, column l15).  Both read their
+// operand fragments -- 8 consecutive k per lane -- from the SAME LDS chunk images: row r's 16-B column c sits at slot c ^ ((r >> 1) & 7); the 32 x 32 form
+// reads column 2 s + lh of row lr in 16-deep step s, the 16 x 16 form column 4 s + lq of row l15 in 32-deep step s, conflict-free for ds_read_b128 either
+// way (every 16-lane service group meets eight distinct (r >> 1) & 7 values x two row parities).  The chip holds a higher clock on the 16 x 16 x 32 form in
+// power-bound loops (MI355X_MICROARCH.md "DVFS give-back" 7; tools/microbench/mfma_shape.hip: 1.12-1.13x on random data at equal cycles).  The 32-term sum
+// of one 16 x 16 x 32 instruction is bit for bit what two chained 32 x 32 x 16 instructions give (same microbenchmark: 0 of 204 800 elements differ), and the
+// kernels here walk K exactly as their twins do: results do not depend on the shape (tests/test_conv_f16_gpu.py::test_mfma_shape_does_not_change_results).
+template <class T> struct acc_traits;
+template <int TM_, int TN_> struct acc_traits<f32x16h[TM_][TN_]> { static constexpr int TM = TM_, TN = TN_, MS = 0, SR = 8; };
+template <int TM2, int TN2> struct acc_traits<f32x4h[TM2][TN2]> { static constexpr int TM = TM2 / 2, TN = TN2 / 2, MS = 1, SR = 16; };
+
+// rows [32 a, 32 a + 32) of the wave tile -> ew[row in strip][column], y = fmaf(acc, scale, shift)
+template <int TM, int TN>
+__device__ __forceinline__ void epi_stage32(const ConvKH& p, f32x16h (&acc)[TM][TN], int a, float* ew, int lane, int wn, int n0) {
+    constexpr int PITCH = TN * 32 + 4;
+    const int lr = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int co = n0 + (wn * TN + b) * 32 + lr;
+        const bool cok = co < p.Cout;
+        const float sc = (cok && p.scale) ? p.scale[co] : 1.0f;
+        const float sh = (cok && p.shift) ? p.shift[co] : 0.0f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) ew[((e & 3) + 8 * (e >> 2) + 4 * lh) * PITCH + b * 32 + lr] = fmaf(acc[a][b][e], sc, sh);
+    }
+}
+template <int TM2, int TN2>
+__device__ __forceinline__ void epi_stage32(const ConvKH& p, f32x4h (&acc)[TM2][TN2], int a, float* ew, int lane, int wn, int n0) {
+    constexpr int TN = TN2 / 2, PITCH = TN * 32 + 4;
+    const int l15 = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int jb = 0; jb < TN2; ++jb) {
+        const int co = n0 + wn * TN * 32 + jb * 16 + l15;
+        const bool cok = co < p.Cout;
+        const float sc = (cok && p.scale) ? p.scale[co] : 1.0f;
+        const float sh = (cok && p.shift) ? p.shift[co] : 0.0f;
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ew[(i2 * 16 + 4 * lq + e) * PITCH + jb * 16 + l15] = fmaf(acc[2 * a + i2][jb][e], sc, sh);
+    }
+}
 
 // Shared epilogue (fp32 math): y = fmaf(acc, scale, shift) + residual -> act -> fp16 (or fp32) NHWC store.  Vector path: each
 // wave transposes its 32-row fp32 strips through a private LDS region (all staging LDS is free by now) so that residual
@@ -18,12 +59,12 @@ namespace isegmi {
 // vector path of conv_f16_epilogue (32-row strips through the wave's private LDS region).  RES: a residual is added -- its 16-B loads run
 // a rolling window of two passes ahead of their use (see epi8_prefetch: a load awaited on the spot also drains the previous pass's stores);
 // without a residual no load is issued at all (round 2 sent a dropped out-of-range load per pass and waited for it).
-template <int TM, int TN, bool RES>
-__device__ __forceinline__ void conv_f16_epilogue_vec(const ConvKH& p, f32x16h (&acc)[TM][TN], char* smemg, int wave, int lane, int wm, int wn, int m0, int n0) {
+template <bool RES, class ACC>
+__device__ __forceinline__ void conv_f16_epilogue_vec(const ConvKH& p, ACC& acc, char* smemg, int wave, int lane, int wm, int wn, int m0, int n0) {
+    constexpr int TM = acc_traits<ACC>::TM, TN = acc_traits<ACC>::TN;
     constexpr unsigned OOB = 0x80000000u;
     constexpr int PITCH = TN * 32 + 4;
     constexpr int LPR = TN * 4, RPP = 64 / LPR, NPASS = 32 / RPP, NQ = TM * NPASS, D = 2 < NQ ? 2 : NQ;
-    const int lr = lane & 31, lh = lane >> 5;
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)(RES ? (const void*)p.res : (const void*)p.out), 0, RES ? p.res_bytes : 0u, 0x00020000);
     const unsigned esz = p.out_f32 ? 4u : 2u;
@@ -43,15 +84,7 @@ __device__ __forceinline__ void conv_f16_epilogue_vec(const ConvKH& p, f32x16h (
     }
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
-#pragma unroll
-        for (int b = 0; b < TN; ++b) {
-            const int co = n0 + (wn * TN + b) * 32 + lr;
-            const bool cok = co < p.Cout;
-            const float sc = (cok && p.scale) ? p.scale[co] : 1.0f;
-            const float sh = (cok && p.shift) ? p.shift[co] : 0.0f;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) ew[((e & 3) + 8 * (e >> 2) + 4 * lh) * PITCH + b * 32 + lr] = fmaf(acc[a][b][e], sc, sh);
-        }
+        epi_stage32(p, acc, a, ew, lane, wn, n0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
@@ -97,26 +130,24 @@ __device__ __forceinline__ void conv_f16_epilogue_vec(const ConvKH& p, f32x16h (
     }
 }
 
-template <int TM, int TN>
-__device__ __forceinline__ void conv_f16_epilogue(const ConvKH& p, f32x16h (&acc)[TM][TN], char* smemg, int wave, int lane, int wm, int wn,
-                                                  int m0, int n0) {
+// per-element path (strided destinations with Cout % 8 != 0: the RPN / prediction heads): y = fmaf(acc, scale, shift) + residual -> act; one accumulator
+// register at a time -- ROWB x COLB blocks of NE registers, register e of a lane at (row_of(e), its column)
+template <class ACC>
+__device__ __forceinline__ void conv_f16_epilogue_elem(const ConvKH& p, ACC& acc, int lane, int wm, int wn, int m0, int n0) {
+    constexpr int TM = acc_traits<ACC>::TM, TN = acc_traits<ACC>::TN, MS = acc_traits<ACC>::MS;
+    constexpr int RB = MS ? 16 : 32, NE = MS ? 4 : 16, NA = TM * 32 / RB, NC = TN * 32 / RB;
     constexpr unsigned OOB = 0x80000000u;
-    const int lr = lane & 31, lh = lane >> 5;
-    if (p.vec_epi) {  // uniform
-        if (p.res) conv_f16_epilogue_vec<TM, TN, true>(p, acc, smemg, wave, lane, wm, wn, m0, n0);
-        else conv_f16_epilogue_vec<TM, TN, false>(p, acc, smemg, wave, lane, wm, wn, m0, n0);
-        return;
-    }
-    // ---- per-element path (strided destinations with Cout % 8 != 0: the RPN / prediction heads): y = fmaf(acc, scale, shift) + residual -> act
+    const int lc = MS ? (lane & 15) : (lane & 31);
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? (const void*)p.res : (const void*)p.out), 0, p.res ? p.res_bytes : 0u, 0x00020000);
     const unsigned esz = p.out_f32 ? 4u : 2u;
 #pragma unroll
-    for (int a = 0; a < TM; ++a) {
-        unsigned rowoff[16], resoff[16];
+    for (int a = 0; a < NA; ++a) {
+        unsigned rowoff[NE], resoff[NE];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int m = m0 + (wm * TM + a) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        for (int e = 0; e < NE; ++e) {
+            const int rin = MS ? 4 * (lane >> 4) + e : (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+            const int m = m0 + wm * TM * 32 + a * RB + rin;
             resoff[e] = m < p.M ? (unsigned)m * (unsigned)p.Cout * 2u : OOB;
             if (p.contiguous) rowoff[e] = m < p.M ? (unsigned)m * (unsigned)p.out_pix_stride * esz : OOB;
             else {
@@ -125,14 +156,14 @@ __device__ __forceinline__ void conv_f16_epilogue(const ConvKH& p, f32x16h (&acc
             }
         }
 #pragma unroll
-        for (int b = 0; b < TN; ++b) {
-            const int co = n0 + (wn * TN + b) * 32 + lr;
+        for (int b = 0; b < NC; ++b) {
+            const int co = n0 + wn * TN * 32 + b * RB + lc;
             const bool cok = co < p.Cout;
             const float sc = (cok && p.scale) ? p.scale[co] : 1.0f;
             const float sh = (cok && p.shift) ? p.shift[co] : 0.0f;
             const unsigned cooff = cok ? (unsigned)co : OOB;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
+            for (int e = 0; e < NE; ++e) {
                 const unsigned short hb = __builtin_amdgcn_raw_buffer_load_b16(rs_res, (resoff[e] | cooff) >= OOB ? OOB : resoff[e] + cooff * 2u, 0, 0);
                 float y = fmaf(acc[a][b][e], sc, sh);
                 y = y + (float)__builtin_bit_cast(half_t, hb);
@@ -146,205 +177,14 @@ __device__ __forceinline__ void conv_f16_epilogue(const ConvKH& p, f32x16h (&acc
     }
 }
 
-// LW > 0: LW extra LOADER waves issue every LDS-DMA piece and the NW MFMA waves issue none (an LDS-DMA instruction stalls its
-// wave for 100-180 cycles while the fill path is busy -- time the MFMA waves then spend on matrix work); LW == 0: every wave
-// loads its share between its MFMAs.
-template <int BM, int BN, int WM, int WN, int NSTAGE, int OCC, bool STEM, int LW>
-__global__ __launch_bounds__((WM * WN + LW) * 64, OCC) void conv_f16_glds_kernel(const ConvKH p) {
-    constexpr int NW = WM * WN;
-    constexpr int NL = LW > 0 ? LW : NW;  // waves that issue loads
-    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int PA = BM / 8, PB = BN / 8;                          // 1-KiB pieces per chunk
-    constexpr int PPA = (PA + NL - 1) / NL, PPB = (PB + NL - 1) / NL;  // rounds per loading wave (the last one may be partial)
-    constexpr bool UNEVEN = (PA % NL != 0) || (PB % NL != 0);
-    static_assert(!UNEVEN || NSTAGE == 2, "a partial piece round changes a wave's vmcnt count: only with the vmcnt(0) ring");
-    constexpr int STAGEB = (BM + BN) * 128;
-    static_assert(PPA >= 1 && PPB >= 1 && TM >= 1 && TN >= 1, "tile/wave split");
-    extern __shared__ __attribute__((aligned(1024))) char smemg[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform, and known to be (scalar address arithmetic)
-    const int wm = wave / WN, wn = wave % WN;
-    const int lw = LW > 0 ? wave - NW : wave;           // index among the loading waves
-    const bool loads = LW == 0 || wave >= NW;
-
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int q8 = nwg >> 3, r8g = nwg & 7, xcd = bid & 7;
-    const int logical = (xcd < r8g ? xcd * (q8 + 1) : r8g * (q8 + 1) + (xcd - r8g) * q8) + (bid >> 3);
-    const int nt = logical % p.ntiles, mt = logical / p.ntiles;
-    const int m0 = mt * BM, n0 = nt * BN;
-
-    const int r8 = lane >> 3, cs = lane & 7;
-    int hi0[PPA], wi0[PPA], abase[PPA];
-#pragma unroll
-    for (int j = 0; j < PPA; ++j) {
-        if (!loads) break;
-        const int row = (lw + j * NL) * 8 + r8;
-        const int c = cs ^ ((row >> 1) & 7);
-        const int m = m0 + row;
-        if (m < p.M) {
-            const int hw = p.Ho * p.Wo;
-            const int n = m / hw, rem = m - n * hw;
-            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-            if (STEM) {  // haloed 4-channel image: chunk j = filter rows 2j, 2j+1; a row's 8 px x 4 ch = 64 B (see conv2d_f16_launch)
-                hi0[j] = 0;
-                wi0[j] = 0;
-                abase[j] = ((n * p.H + 2 * ho + (c >> 2)) * p.W + 2 * wo + 2 * (c & 3)) * 8;
-            } else {
-                hi0[j] = ho * p.stride - p.pad;
-                wi0[j] = wo * p.stride - p.pad;
-                abase[j] = (((n * p.H + hi0[j]) * p.W + wi0[j]) * p.Cin) * 2 + c * 16;
-            }
-        } else {
-            hi0[j] = -(1 << 28);
-            wi0[j] = 0;
-            abase[j] = 0;
-        }
-    }
-    unsigned bbase[PPB];
-#pragma unroll
-    for (int j = 0; j < PPB; ++j) {
-        if (!loads) break;
-        const int row = (lw + j * NL) * 8 + r8;
-        const int c = cs ^ ((row >> 1) & 7);
-        bbase[j] = (unsigned)(n0 + row) * (unsigned)(p.wrow * 2) + (unsigned)(c * 16);
-    }
-    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
-    // zero-length twins: every piece of a chunk past the last one is dropped by the range check (zeros land in LDS)
-    const __amdgpu_buffer_rsrc_t rs_in0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_w0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0, 0x00020000);
-    constexpr unsigned OOB = 0x80000000u;
-    int kr = 0, ks = 0, kc = 0, issued = 0;
-    // A vector instruction issued by ANY wave of a SIMD takes issue slots from that SIMD's MFMAs (tools/microbench/mfma_switch.hip),
-    // and the loader used to spend ~7 of them per A piece and 2 per B piece (93 per chunk and wave on the 192x256 tile).  Now a
-    // piece is its LDS-DMA instruction alone: the lane's voffset (pixel base + tap offset, or the out-of-range constant for a
-    // padding tap / a row past M) is rebuilt only when the tap changes, behind a scalar branch; the cin chunk inside the tap
-    // (stem: the filter-row pair) and B's chunk offset ride in the scalar offset operand, which is outside the range check and
-    // never leaves the pixel's Cin halfs / the weight row; past-the-end chunks take the zero-length descriptors (scalar selects).
-    unsigned avoff[PPA];
-#pragma unroll
-    for (int j = 0; j < PPA; ++j) {
-        if (!loads) break;
-        const bool ok = STEM ? hi0[j] == 0 : ((unsigned)hi0[j] < (unsigned)p.H && (unsigned)wi0[j] < (unsigned)p.W);
-        avoff[j] = ok ? (unsigned)abase[j] : OOB;
-    }
-    unsigned soffa = 0;
-
-    // one 1-KiB piece (i < PPA: A rows, else B rows) of the chunk being issued; `live` = not past the last chunk
-    auto piece = [&](int i, int stage, bool live) {
-        char* sA = smemg + stage * STAGEB;
-        if (i < PPA) {
-            if (PA % NL != 0 && lw + i * NL >= PA) return;  // wave-uniform: this wave has no piece in the partial round
-            // (named operands: hipcc 7.2 silently drops the host stub of the kernel when this builtin takes expressions)
-            const __amdgpu_buffer_rsrc_t rs = live ? rs_in : rs_in0;
-            const unsigned voff = avoff[i];
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(sA + (lw + i * NL) * 1024), 16, voff, soffa, 0, CONV_F16_A_AUX);
-        } else {
-            const int j = i - PPA;
-            if (PB % NL != 0 && lw + j * NL >= PB) return;
-            const __amdgpu_buffer_rsrc_t rs = live ? rs_w : rs_w0;
-            const unsigned voff = bbase[j], soffb = (unsigned)issued * 128u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(sA + BM * 128 + (lw + j * NL) * 1024), 16, voff, soffb, 0, 0);
-        }
-    };
-    auto advance = [&]() {
-        ++issued;
-        if (STEM) { soffa = (unsigned)(issued * 2 * p.W * 8); return; }
-        soffa += 128u;
-        if (++kc == p.cin_chunks) {  // uniform: next tap -- the only place with per-lane work
-            kc = 0;
-            soffa = 0;
-            if (++ks == p.S) { ks = 0; ++kr; }
-            int tr = __builtin_amdgcn_readfirstlane(kr), ts = __builtin_amdgcn_readfirstlane(ks);
-            asm volatile("" : "+s"(tr), "+s"(ts));  // keeps the tap change behind its branch: speculated, its VALU work would run every chunk
-            const int delta = ((tr * p.W + ts) * p.Cin) * 2;
-#pragma unroll
-            for (int j = 0; j < PPA; ++j) {
-                const bool ok = (unsigned)(hi0[j] + tr) < (unsigned)p.H && (unsigned)(wi0[j] + ts) < (unsigned)p.W;
-                avoff[j] = ok ? (unsigned)(abase[j] + delta) : OOB;
-            }
-        }
-    };
-    auto is_live = [&]() -> bool { return issued < p.nchunks; };  // the chunk about to be issued exists
-
-    f32x16h acc[TM][TN];
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.0f;
-
-    const int lr = lane & 31, lh = lane >> 5;
-    const int swz = lr * 128 + ((lh ^ ((lr >> 1) & 7)) << 4);  // k-step s adds ^ (s << 5)
-    const int a_off = wm * TM * 32 * 128;
-    const int b_off = BM * 128 + wn * TN * 32 * 128;
-    constexpr int PP = PPA + PPB;
-    constexpr int ISSUE_STEPS = 4;  // the next chunk's pieces are spread over this chunk's four MFMA steps
-
-    if (loads) {
-#pragma unroll
-        for (int s = 0; s < NSTAGE - 1; ++s) {
-            const bool live = is_live();
-#pragma unroll
-            for (int i = 0; i < PP; ++i) piece(i, s, live);
-            advance();
-        }
-    }
-    int wr = NSTAGE - 1;
-    if (LW > 0) conv_f16_role_prio(wave >= NW);
-    if (LW > 0 && wave >= NW) {  // loader wave: same barrier sequence as the MFMA waves, no matrix work
-        for (int t = 0; t < p.nchunks; ++t) {
-            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NSTAGE - 2) * PP) : "memory");
-            const bool live = is_live();
-#pragma unroll
-            for (int i = 0; i < PP; ++i) piece(i, wr, live);
-            advance();
-            wr = wr + 1 == NSTAGE ? 0 : wr + 1;
-        }
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+template <class ACC>
+__device__ __forceinline__ void conv_f16_epilogue(const ConvKH& p, ACC& acc, char* smemg, int wave, int lane, int wm, int wn, int m0, int n0) {
+    if (p.vec_epi) {  // uniform
+        if (p.res) conv_f16_epilogue_vec<true>(p, acc, smemg, wave, lane, wm, wn, m0, n0);
+        else conv_f16_epilogue_vec<false>(p, acc, smemg, wave, lane, wm, wn, m0, n0);
         return;
     }
-    // the chunk loop is unrolled over the ring so that the stage is a compile-time term: fragment addresses are then a
-    // per-lane base plus an immediate (the per-chunk v_add of the stage offset took MFMA issue slots, see above)
-    for (int t0 = 0; t0 < p.nchunks; t0 += NSTAGE) {
-#pragma unroll
-        for (int u = 0; u < NSTAGE; ++u) {
-            if (t0 + u >= p.nchunks) break;  // uniform
-            const int rd = u, wr = (u + NSTAGE - 1) % NSTAGE;
-            if (LW == 0) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NSTAGE - 2) * PP) : "memory");
-            else asm volatile("s_barrier" ::: "memory");
-            const bool live = LW == 0 ? is_live() : true;
-            const char* sb = smemg + rd * STAGEB;
-            f16x8 fa[2][TM], fb[2][TN];
-#pragma unroll
-            for (int a = 0; a < TM; ++a) fa[0][a] = *(const f16x8*)(sb + a_off + a * 4096 + swz);
-#pragma unroll
-            for (int b = 0; b < TN; ++b) fb[0][b] = *(const f16x8*)(sb + b_off + b * 4096 + swz);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {  // four 16-deep MFMA steps per chunk; fragments of step s+1 and the next chunk's pieces issue under step s
-                if (s < 3) {
-                    const int so = swz ^ ((s + 1) << 5);
-#pragma unroll
-                    for (int a = 0; a < TM; ++a) fa[(s + 1) & 1][a] = *(const f16x8*)(sb + a_off + a * 4096 + so);
-#pragma unroll
-                    for (int b = 0; b < TN; ++b) fb[(s + 1) & 1][b] = *(const f16x8*)(sb + b_off + b * 4096 + so);
-                }
-#pragma unroll
-                for (int i = 0; i < PP; ++i)
-                    if (LW == 0 && i * ISSUE_STEPS / PP == s) piece(i, wr, live);
-#pragma unroll
-                for (int a = 0; a < TM; ++a)
-#pragma unroll
-                    for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s & 1][a], fb[s & 1][b], acc[a][b], 0, 0, 0);
-            }
-            if (LW == 0) advance();
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // trailing all-OOB pieces have landed; LDS is free
-
-    conv_f16_epilogue<TM, TN>(p, acc, smemg, wave, lane, wm, wn, m0, n0);
+    conv_f16_epilogue_elem(p, acc, lane, wm, wn, m0, n0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -370,6 +210,35 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, OCC) void conv_f16_glds_kernel
 // Offsets: a lane's residual / output offset is ONE add per strip -- lane base (its row inside the strip, its 8 channels; the out-of-range
 // constant for a column past Cout) plus a wave-uniform row term; rows past M fall behind descriptors cut at M rows (contiguous
 // destinations; strided ones keep the general arithmetic).
+// One 64-deep chunk on v_mfma_f32_16x16x32_f16: NA x NC blocks of 16 x 16, two 32-deep steps.  oa[i] / ob + j * 2048 = byte offsets (from sa / sb) of the
+// lane's step-0 fragment of block i / j (row l15 of the block, 16-B column lq, swizzled); oa1 / ob1 = the same for step 1: the offset ^ 64 (every other
+// term is a multiple of 128).  Registers: the wave tile's 64 accumulators (the kernels run four waves per SIMD: 128 registers) leave room for SIX fragment
+// sets, not for the sixteen a chunk reads: the B fragments of a step stay (four sets), the A fragments go through TWO sets -- the chunk is 2 NA block rows
+// (step 0's, then step 1's), row r multiplies out of set r & 1, and as soon as its MFMAs are issued the set is refilled with row r + 2's fragment: one row
+// of MFMAs (64 cycles of this wave's, more with the SIMD's other waves in between) covers the read.  Step 1's B fragments replace step 0's one per MFMA
+// inside step 0's last row.  sched_barrier pins this placement (left alone, hipcc sinks every reload to just in front of its first use).
+template <int NA, int NC>
+__device__ __forceinline__ void mfma16_chunk(f32x4h (&acc)[NA][NC], const char* sa, const int (&oa)[NA], const int (&oa1)[NA], const char* sb, int ob, int ob1) {
+    static_assert(NA % 2 == 0 && NA >= 2, "two A sets alternate over an even number of block rows");
+    f16x8 fa[2], fb[NC];
+    fa[0] = *(const f16x8*)(sa + oa[0]);
+#pragma unroll
+    for (int j = 0; j < NC; ++j) fb[j] = *(const f16x8*)(sb + ob + j * 2048);
+    fa[1] = *(const f16x8*)(sa + oa[1]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 2 * NA; ++r) {
+        const int i = r % NA;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[r & 1], fb[j], acc[i][j], 0, 0, 0);
+            if (r == NA - 1) fb[j] = *(const f16x8*)(sb + ob1 + j * 2048);
+        }
+        if (r + 2 < 2 * NA) fa[r & 1] = *(const f16x8*)(sa + (r + 2 < NA ? oa[(r + 2) % NA] : oa1[(r + 2) % NA]));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 constexpr int EPI_D = 2;
 
 template <int TM, int TN>
@@ -423,12 +292,16 @@ __device__ __forceinline__ void epi8_prefetch(const ConvKH& p, Epi8<TM, TN>& E, 
     for (int q = 0; q < Epi8<TM, TN>::D; ++q) { E.r[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, E.rnext, 0, CONV_F16_RES_AUX); E.rnext += rstep; }
 }
 
-template <int TM, int TN, bool RES, bool UP2X = false>
-__device__ __forceinline__ void epi8_finish_impl(const ConvKH& p, f32x16h (&acc)[TM][TN], Epi8<TM, TN>& E, float* ew, int lane, int wm, int wn, int m0, int n0) {
+// SR-row strips: 8 rows (registers 4g .. 4g + 3 of the 32 x 32 blocks) or 16 rows (one row of 16 x 16 blocks); ew = the wave's SR x PITCH floats of scratch
+template <bool RES, bool UP2X, class ACC>
+__device__ __forceinline__ void epi8_finish_impl(const ConvKH& p, ACC& acc, Epi8<acc_traits<ACC>::TM, acc_traits<ACC>::TN>& E, float* ew, int lane, int wm, int wn, int m0, int n0) {
+    constexpr int TM = acc_traits<ACC>::TM, TN = acc_traits<ACC>::TN, MS = acc_traits<ACC>::MS, SR = acc_traits<ACC>::SR;
     constexpr unsigned OOB = 0x80000000u;
     constexpr int PITCH = TN * 32 + 4;
-    constexpr int LPR = Epi8<TM, TN>::LPR, RPP = Epi8<TM, TN>::RPP, NPASS = Epi8<TM, TN>::NPASS, NQ = Epi8<TM, TN>::NQ, D = Epi8<TM, TN>::D;
-    const int lr = lane & 31, lh = lane >> 5;
+    constexpr int LPR = Epi8<TM, TN>::LPR, RPP = Epi8<TM, TN>::RPP, NPASS = SR / RPP, NQ = Epi8<TM, TN>::NQ, D = Epi8<TM, TN>::D;
+    constexpr int NCB = MS ? 2 * TN : TN, CB = MS ? 16 : 32;   // column blocks of the wave tile
+    static_assert(TM * (32 / SR) * NPASS == NQ, "passes per wave tile");
+    const int lr = MS ? (lane & 15) : (lane & 31), lh = lane >> 5;
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)(RES ? (const void*)p.res : (const void*)p.out), 0, RES ? p.res_bytes : 0u, 0x00020000);
     const unsigned esz = p.out_f32 ? 4u : 2u;
@@ -439,10 +312,10 @@ __device__ __forceinline__ void epi8_finish_impl(const ConvKH& p, f32x16h (&acc)
     // contiguous destination: offset = lane base + pass * step, rows past M are out of the descriptor's range
     const unsigned ostep = (unsigned)p.out_pix_stride * esz * RPP;
     unsigned onext = cok8 ? ((unsigned)(m0 + wm * TM * 32 + er) * (unsigned)p.out_pix_stride + (unsigned)co8) * esz : OOB;
-    float sc[TN], sh[TN];
+    float sc[NCB], sh[NCB];
 #pragma unroll
-    for (int b = 0; b < TN; ++b) {
-        const int co = n0 + (wn * TN + b) * 32 + lr;
+    for (int b = 0; b < NCB; ++b) {
+        const int co = n0 + wn * TN * 32 + b * CB + lr;
         const bool cok = co < p.Cout;
         sc[b] = (cok && p.scale) ? p.scale[co] : 1.0f;
         sh[b] = (cok && p.shift) ? p.shift[co] : 0.0f;
@@ -450,15 +323,22 @@ __device__ __forceinline__ void epi8_finish_impl(const ConvKH& p, f32x16h (&acc)
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {  // accumulator registers 4g..4g+3 = tile rows 8g + (0..3) + 4 * (lane >> 5)
+        for (int g = 0; g < 32 / SR; ++g) {
+            if constexpr (MS == 0) {   // accumulator registers 4g..4g+3 = tile rows 8g + (0..3) + 4 * (lane >> 5)
 #pragma unroll
-            for (int b = 0; b < TN; ++b)
+                for (int b = 0; b < TN; ++b)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) ew[(j + 4 * lh) * PITCH + b * 32 + lr] = fmaf(acc[a][b][4 * g + j], sc[b], sh[b]);
+                    for (int j = 0; j < 4; ++j) ew[(j + 4 * lh) * PITCH + b * 32 + lr] = fmaf(acc[a][b][4 * g + j], sc[b], sh[b]);
+            } else {                   // block row 2a + g: register j = tile row 16g + 4 * (lane >> 4) + j
+#pragma unroll
+                for (int b = 0; b < NCB; ++b)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ew[(j + 4 * (lane >> 4)) * PITCH + b * 16 + lr] = fmaf(acc[2 * a + g][b][j], sc[b], sh[b]);
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int ps = 0; ps < NPASS; ++ps) {
-                const int q = (a * 4 + g) * NPASS + ps;
+                const int q = (a * (32 / SR) + g) * NPASS + ps;
                 const int rr = ps * RPP + er;
                 const f32x4h v0 = *(const f32x4h*)(ew + rr * PITCH + ec);
                 const f32x4h v1 = *(const f32x4h*)(ew + rr * PITCH + ec + 4);
@@ -508,14 +388,14 @@ __device__ __forceinline__ void epi8_finish_impl(const ConvKH& p, f32x16h (&acc)
     }
 }
 
-template <int TM, int TN, bool UP2X = false>
-__device__ __forceinline__ void epi8_finish(const ConvKH& p, f32x16h (&acc)[TM][TN], Epi8<TM, TN>& E, float* ew, int lane, int wm, int wn, int m0, int n0) {
-    if constexpr (UP2X) { epi8_finish_impl<TM, TN, true, true>(p, acc, E, ew, lane, wm, wn, m0, n0); return; }
-    if (p.res) epi8_finish_impl<TM, TN, true>(p, acc, E, ew, lane, wm, wn, m0, n0);   // uniform
-    else epi8_finish_impl<TM, TN, false>(p, acc, E, ew, lane, wm, wn, m0, n0);
+template <bool UP2X, class ACC>
+__device__ __forceinline__ void epi8_finish(const ConvKH& p, ACC& acc, Epi8<acc_traits<ACC>::TM, acc_traits<ACC>::TN>& E, float* ew, int lane, int wm, int wn, int m0, int n0) {
+    if constexpr (UP2X) { epi8_finish_impl<true, true>(p, acc, E, ew, lane, wm, wn, m0, n0); return; }
+    if (p.res) epi8_finish_impl<true, false>(p, acc, E, ew, lane, wm, wn, m0, n0);   // uniform
+    else epi8_finish_impl<false, false>(p, acc, E, ew, lane, wm, wn, m0, n0);
 }
 
-template <int BM, int BN, int WM, int WN, int NSTAGE, int OCC, int LW, bool UP2X = false>
+template <int BM, int BN, int WM, int WN, int NSTAGE, int OCC, int LW, bool UP2X = false, int MS = 0>
 __global__ __launch_bounds__((WM * WN + LW) * 64, OCC) void conv_f16_persist_kernel(const ConvKH p_arg) {
     static_assert(LW > 0 && NSTAGE >= 2 && NSTAGE <= 3, "loader waves, a 2- or 3-deep ring");
     // Kernel arguments are read where they are used, per role: taken by value the ~45 dwords of ConvKH are all loaded at entry and stay
@@ -534,7 +414,8 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, OCC) void conv_f16_persist_ker
     static_assert(!UNEVEN || NSTAGE == 2, "a partial piece round changes a wave's vmcnt count: only with the vmcnt(0) ring");
     constexpr int STAGEB = (BM + BN) * 128;
     constexpr int PP = PPA + PPB;
-    static_assert(NW * 8 * (TN * 32 + 4) * 4 <= STAGEB, "the epilogue's 8-row strips must fit one ring stage");
+    constexpr int ESR = MS ? 16 : 8;   // rows per epilogue strip (acc_traits::SR)
+    static_assert(NW * ESR * (TN * 32 + 4) * 4 <= STAGEB, "the epilogue's strips must fit one ring stage");
     extern __shared__ __attribute__((aligned(1024))) char smemg[];
     constexpr unsigned OOB = 0x80000000u;
 
@@ -658,9 +539,19 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, OCC) void conv_f16_persist_ker
     const int swz = lr * 128 + ((lh ^ ((lr >> 1) & 7)) << 4);  // k-step s adds ^ (s << 5)
     const int a_off = wm * TM * 32 * 128;
     const int b_off = BM * 128 + wn * TN * 32 * 128;
-    f32x16h acc[TM][TN];
+    typedef typename std::conditional<MS == 0, f32x16h[TM][TN], f32x4h[2 * TM][2 * TN]>::type acc_t;
+    constexpr int NA = MS ? 2 * TM : TM, NC = MS ? 2 * TN : TN, NE = MS ? 4 : 16;   // accumulator blocks down / across, registers per block
+    acc_t acc;
+    const int swz16 = (lane & 15) * 128 + (((lane >> 4) ^ (((lane & 15) >> 1) & 7)) << 4);   // 16 x 16 x 32 form: 32-deep step s adds ^ (s << 6)
     auto chunk = [&](int rd) {  // run-time stage: branching over compile-time stages made hipcc copy and spill the accumulators
         const char* sb = smemg + rd * STAGEB;
+        if constexpr (MS == 1) {
+            int oa[NA], oa1[NA];
+#pragma unroll
+            for (int i = 0; i < NA; ++i) { oa[i] = a_off + swz16 + i * 2048; oa1[i] = a_off + (swz16 ^ 64) + i * 2048; }
+            mfma16_chunk<NA, NC>(acc, sb, oa, oa1, sb, b_off + swz16, b_off + (swz16 ^ 64));
+            return;
+        } else {
         f16x8 fa[2][TM], fb[2][TN];
 #pragma unroll
         for (int a = 0; a < TM; ++a) fa[0][a] = *(const f16x8*)(sb + a_off + a * 4096 + swz);
@@ -680,17 +571,18 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, OCC) void conv_f16_persist_ker
 #pragma unroll
                 for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s & 1][a], fb[s & 1][b], acc[a][b], 0, 0, 0);
         }
+        }
     };
     int st = 0;
     for (int v = bid; v < total; v += G) {
         int m0, n0;
         tile_origin(v, m0, n0);
 #pragma unroll
-        for (int a = 0; a < TM; ++a)
+        for (int a = 0; a < NA; ++a)
 #pragma unroll
-            for (int b = 0; b < TN; ++b)
+            for (int b = 0; b < NC; ++b)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.0f;
+                for (int e = 0; e < NE; ++e) acc[a][b][e] = 0.0f;
         Epi8<TM, TN> E;
         {
             karg_t k1 = kp0;
@@ -709,8 +601,8 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, OCC) void conv_f16_persist_ker
         karg_t k2 = kp0;
         asm volatile("" : "+s"(k2));
         const ConvKH& p = *(const ConvKH*)k2;
-        if (p.vec_epi) epi8_finish<TM, TN, UP2X>(p, acc, E, (float*)(smemg + last * STAGEB) + wave * 8 * (TN * 32 + 4), lane, wm, wn, m0, n0);
-        else conv_f16_epilogue<TM, TN>(p, acc, smemg, wave, lane, wm, wn, m0, n0);  // per-element path: no LDS
+        if (p.vec_epi) epi8_finish<UP2X>(p, acc, E, (float*)(smemg + last * STAGEB) + wave * ESR * (TN * 32 + 4), lane, wm, wn, m0, n0);
+        else conv_f16_epilogue(p, acc, smemg, wave, lane, wm, wn, m0, n0);  // per-element path: no LDS
     }
 }
 
@@ -721,8 +613,10 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, OCC) void conv_f16_persist_ker
 // rounds it when it stores t -- in a row-major [pixel][256] image (16-B columns XOR-swizzled by the row), the head's packed weights (32 rows) next to
 // it, and six waves multiply one 32-pixel tile each on the same 16 k-steps the stand-alone 1x1 launch would walk.  t is never written (275 MB per
 // P2 level at R101 bs=8) nor read back.  Bit-identical to the two launches (tests/test_rpn_head_f16_gpu.py).
-template <int TM, int TN>
-__device__ __forceinline__ void conv_f16_epilogue_head(const ConvKH& p, f32x16h (&acc)[TM][TN], char* smemg, int wave, int lane, int wm, int wn, int m0) {
+template <class ACC>
+__device__ __forceinline__ void conv_f16_epilogue_head(const ConvKH& p, ACC& acc, char* smemg, int wave, int lane, int wm, int wn, int m0) {
+    constexpr int TM = acc_traits<ACC>::TM, TN = acc_traits<ACC>::TN, MS = acc_traits<ACC>::MS;
+    constexpr int RB = MS ? 16 : 32, NE = MS ? 4 : 16, NA = TM * 32 / RB, NC = TN * 32 / RB;
     constexpr unsigned OOB = 0x80000000u;
     constexpr int BMH = 192, T_BYTES = BMH * 512;   // the tile image; the head's weights follow it (32 rows x 512 B)
     const int lr = lane & 31, lh = lane >> 5;
@@ -736,14 +630,14 @@ __device__ __forceinline__ void conv_f16_epilogue_head(const ConvKH& p, f32x16h 
     }
     // 1. y = relu(fmaf(acc, scale, shift)) -> fp16 -> T[row][channel]
 #pragma unroll
-    for (int a = 0; a < TM; ++a)
+    for (int a = 0; a < NA; ++a)
 #pragma unroll
-        for (int b = 0; b < TN; ++b) {
-            const int co = (wn * TN + b) * 32 + lr;
+        for (int b = 0; b < NC; ++b) {
+            const int co = wn * TN * 32 + b * RB + (MS ? (lane & 15) : lr);
             const float sc = p.scale ? p.scale[co] : 1.0f, sh = p.shift ? p.shift[co] : 0.0f;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = (wm * TM + a) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            for (int e = 0; e < NE; ++e) {
+                const int row = wm * TM * 32 + a * RB + (MS ? 4 * (lane >> 4) + e : (e & 3) + 8 * (e >> 2) + 4 * lh);
                 float y = fmaf(acc[a][b][e], sc, sh);
                 y = y > 0.0f ? y : 0.0f;
                 *(half_t*)(smemg + row * 512 + (((co >> 3) ^ (row & 15)) << 4) + (co & 7) * 2) = (half_t)y;
@@ -811,7 +705,7 @@ __device__ __forceinline__ void conv_f16_epilogue_head(const ConvKH& p, f32x16h 
 #else
 #define STRIP_TRACE(u, slot) do {} while (0)
 #endif
-template <int BM, int BN, int WM, int WN, int LW, int NB = 2>
+template <int BM, int BN, int WM, int WN, int LW, int NB = 2, int MS = 0>
 __global__ __launch_bounds__((WM * WN + LW) * 64, 1) void conv3x3_f16_strip_kernel(const ConvKH p) {
     static_assert(NB == 2 || (NB == 3 && LW > 0 && (BN / 8) % LW == 0), "the three-buffer form needs loader waves and whole B piece rounds");
     constexpr int NW = WM * WN;
@@ -940,25 +834,28 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, 1) void conv3x3_f16_strip_kern
         if (++b_s == 3) { b_s = 0; if (++b_kc == p.cin_chunks) { b_kc = 0; ++b_r; } }
     };
 
-    f32x16h acc[TM][TN];
+    typedef typename std::conditional<MS == 0, f32x16h[TM][TN], f32x4h[2 * TM][2 * TN]>::type acc_t;
+    constexpr int NA = MS ? 2 * TM : TM, NC = MS ? 2 * TN : TN, NE = MS ? 4 : 16, RBLK = MS ? 16 : 32;   // accumulator blocks down / across, registers per block, block rows
+    acc_t acc;
 #pragma unroll
-    for (int a = 0; a < TM; ++a)
+    for (int a = 0; a < NA; ++a)
 #pragma unroll
-        for (int b = 0; b < TN; ++b)
+        for (int b = 0; b < NC; ++b)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.0f;
+            for (int e = 0; e < NE; ++e) acc[a][b][e] = 0.0f;
 
-    // ---- fragment addressing: A rows are strip rows j(m) + s - 1 (per lane, per 32-row tile a, per tap s)
-    const int lr = lane & 31, lh = lane >> 5;
-    int abase_s[TM][3];
+    // ---- fragment addressing: A rows are strip rows j(m) + s - 1 (per lane, per block row a, per tap s); the lane's row inside a block is lane & 31
+    // (32 x 32 x 16 form, 16-B column 2 ks + (lane >> 5)) or lane & 15 (16 x 16 x 32 form, column 4 ks + (lane >> 4))
+    const int lr = MS ? (lane & 15) : (lane & 31), lh = MS ? (lane >> 4) : (lane >> 5);
+    int abase_s[NA][3];
 #pragma unroll
-    for (int a = 0; a < TM; ++a) {
-        const int m = m0 + (wm * TM + a) * 32 + lr;
+    for (int a = 0; a < NA; ++a) {
+        const int m = m0 + wm * TM * 32 + a * RBLK + lr;
         const int jm = (m - m0) + 1 + 2 * (m / W - row0);
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
             const int row = jm + s - 1;
-            abase_s[a][s] = row * 128 + ((lh ^ ((row >> 1) & 7)) << 4);  // k-step ks adds ^ (ks << 5)
+            abase_s[a][s] = row * 128 + ((lh ^ ((row >> 1) & 7)) << 4);  // k-step ks adds ^ (ks << 5) (16-deep steps) / ^ (ks << 6) (32-deep steps)
         }
     }
     const int swzb = lr * 128 + ((lh ^ ((lr >> 1) & 7)) << 4);
@@ -1026,6 +923,13 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, 1) void conv3x3_f16_strip_kern
                 STRIP_TRACE((g0 + gg) * 3 + s, 1);
                 const int ub = NB == 3 ? s : (gg + s) & 1;   // step u = 3 gi + s: u % 3 = s
                 const char* sb = smemg + b_off + ub * BBYTES;
+                if constexpr (MS == 1) {
+                    static_assert(MS == 0 || LW > 0, "the 16 x 16 x 32 form exists with loader waves only");
+                    int oa0[NA], oa1[NA];
+#pragma unroll
+                    for (int a = 0; a < NA; ++a) { oa0[a] = abase_s[a][s]; oa1[a] = abase_s[a][s] ^ 64; }
+                    mfma16_chunk<NA, NC>(acc, sa, oa0, oa1, sb, swzb, swzb ^ 64);
+                } else {
                 f16x8 fa[2][TM], fb[2][TN];
 #pragma unroll
                 for (int a = 0; a < TM; ++a) fa[0][a] = *(const f16x8*)(sa + abase_s[a][s]);
@@ -1046,6 +950,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, 1) void conv3x3_f16_strip_kern
 #pragma unroll
                         for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks & 1][a], fb[ks & 1][b], acc[a][b], 0, 0, 0);
                 }
+                }
             }
             if (LW == 0) next_group();
         }
@@ -1053,9 +958,9 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, 1) void conv3x3_f16_strip_kern
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     STRIP_TRACE(63, 0);
     if constexpr (BM == 192 && BN == 256 && WM == 3 && WN == 4 && NB == 3) {
-        if (p.f_w) { conv_f16_epilogue_head<TM, TN>(p, acc, smemg, wave, lane, wm, wn, m0); return; }   // uniform
+        if (p.f_w) { conv_f16_epilogue_head(p, acc, smemg, wave, lane, wm, wn, m0); return; }   // uniform
     }
-    conv_f16_epilogue<TM, TN>(p, acc, smemg, wave, lane, wm, wn, m0, n0);
+    conv_f16_epilogue(p, acc, smemg, wave, lane, wm, wn, m0, n0);
     STRIP_TRACE(63, 1);
 #ifdef ISEGMI_STRIP_TRACE
     if (bid == 0 && p.trace && wave == 0 && lane == 0) {
@@ -1066,7 +971,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, 1) void conv3x3_f16_strip_kern
 #endif
 }
 
-template <int BM, int BN, int WM, int WN, int LW = 0, int NB = 2>
+template <int BM, int BN, int WM, int WN, int LW = 0, int NB = 2, int MS = 0>
 static int launch_strip(ConvKH& k, hipStream_t st) {
     k.mtiles = cdiv(k.M, BM);
     k.ntiles = cdiv(k.Cout, BN);
@@ -1089,8 +994,8 @@ static int launch_strip(ConvKH& k, hipStream_t st) {
     if (tracing && getenv("ISEGMI_STRIP_TRACE_LIGHT")) k.dbg |= 16;
 #endif
     static PerDeviceOnce attr;
-    if (attr.need()) HIP_TRY(hipFuncSetAttribute((const void*)conv3x3_f16_strip_kernel<BM, BN, WM, WN, LW, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_attr));
-    hipLaunchKernelGGL((conv3x3_f16_strip_kernel<BM, BN, WM, WN, LW, NB>), dim3((unsigned)(k.mtiles * k.ntiles)), dim3((NW + LW) * 64), lds, st, k);
+    if (attr.need()) HIP_TRY(hipFuncSetAttribute((const void*)conv3x3_f16_strip_kernel<BM, BN, WM, WN, LW, NB, MS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_attr));
+    hipLaunchKernelGGL((conv3x3_f16_strip_kernel<BM, BN, WM, WN, LW, NB, MS>), dim3((unsigned)(k.mtiles * k.ntiles)), dim3((NW + LW) * 64), lds, st, k);
     HIP_TRY(hipGetLastError());
 #ifdef ISEGMI_STRIP_TRACE
     if (tracing) {
@@ -1109,24 +1014,9 @@ static int launch_strip(ConvKH& k, hipStream_t st) {
     return ISEGMI_OK;
 }
 
-template <int BM, int BN, int WM, int WN, int NSTAGE, int OCC, bool STEM = false, int LW = 0>
-static int launch_g(ConvKH& k, hipStream_t st) {
-    k.mtiles = cdiv(k.M, BM);
-    k.ntiles = cdiv(k.Cout, BN);
-    constexpr int NW = WM * WN, TN = BN / WN / 32;
-    size_t lds = (size_t)NSTAGE * (BM + BN) * 128;
-    const size_t epi = (size_t)NW * 32 * (TN * 32 + 4) * 4;
-    if (epi > lds) lds = epi;
-    static PerDeviceOnce attr;
-    if (attr.need()) HIP_TRY(hipFuncSetAttribute((const void*)conv_f16_glds_kernel<BM, BN, WM, WN, NSTAGE, OCC, STEM, LW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((conv_f16_glds_kernel<BM, BN, WM, WN, NSTAGE, OCC, STEM, LW>), dim3((unsigned)(k.mtiles * k.ntiles)), dim3((NW + LW) * 64), lds, st, k);
-    HIP_TRY(hipGetLastError());
-    return ISEGMI_OK;
-}
-
 // persistent loader-wave kernel: at most one block per CU slot, each walking tiles bid, bid + grid, ...; `few` (test hook) forces
 // an 8-block grid so that small test shapes exercise the multi-tile stream
-template <int BM, int BN, int WM, int WN, int NSTAGE, int OCC, int LW, bool UP2X = false>
+template <int BM, int BN, int WM, int WN, int NSTAGE, int OCC, int LW, bool UP2X = false, int MS = 0>
 static int launch_p(ConvKH& k, hipStream_t st, bool few) {
     k.mtiles = cdiv(k.M, BM);
     k.ntiles = cdiv(k.Cout, BN);
@@ -1135,270 +1025,28 @@ static int launch_p(ConvKH& k, hipStream_t st, bool few) {
     const size_t epi = (size_t)NW * 32 * (TN * 32 + 4) * 4;  // the per-element epilogue path uses none; kept >= the one-tile kernel's request
     (void)epi;
     static PerDeviceOnce attr;
-    if (attr.need()) HIP_TRY(hipFuncSetAttribute((const void*)conv_f16_persist_kernel<BM, BN, WM, WN, NSTAGE, OCC, LW, UP2X>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (attr.need()) HIP_TRY(hipFuncSetAttribute((const void*)conv_f16_persist_kernel<BM, BN, WM, WN, NSTAGE, OCC, LW, UP2X, MS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int ncu = device_cu_count();
     const int64_t total = (int64_t)k.mtiles * k.ntiles;
     int64_t slots = few ? 8 : (int64_t)(ncu / 8) * 8 * OCC;  // a multiple of 8, so that a block's tiles stay on its XCD
     if (slots < 8) slots = 8;
     const unsigned grid = (unsigned)(total < slots ? total : slots);
-    hipLaunchKernelGGL((conv_f16_persist_kernel<BM, BN, WM, WN, NSTAGE, OCC, LW, UP2X>), dim3(grid), dim3((NW + LW) * 64), lds, st, k);
+    hipLaunchKernelGGL((conv_f16_persist_kernel<BM, BN, WM, WN, NSTAGE, OCC, LW, UP2X, MS>), dim3(grid), dim3((NW + LW) * 64), lds, st, k);
     HIP_TRY(hipGetLastError());
     return ISEGMI_OK;
 }
 
-// 0: v_mfma_f32_32x32x16_f16 everywhere; 1 (default): the row-strip tile (30 -> 40) and the fused RPN head on v_mfma_f32_16x16x32_f16; 2: the persistent tiles
-// (34 / 37 / 39 -> 44 / 47 / 49) and the UP2X merge too
-static int g_f16_mfma16 = 1;
-int conv_f16_mfma_shape(int set) { if (set >= 0) g_f16_mfma16 = set > 2 ? 2 : set; return g_f16_mfma16; }
-static int cout_pad_h(int Cout) { return cdiv(Cout, 128) * 128; }
-static bool is_stem_h(const isegmi_conv_desc* d) { return d->Cin == 4 && d->R == 7 && d->S == 7; }
 
-// fp16 conv: in/w/res are fp16; out is fp16, or fp32 when out_f32 (predictor heads feeding fp32 selection kernels)
-// `head` != nullptr: the 3x3 conv with the fused 1x1 head of conv_f16_epilogue_head (out is then unused and may be null); *head->fused tells whether the
-// launch happened -- from half a round of 192 x 256 row-strip tiles on (otherwise nothing is launched)
-struct ConvHeadF16 { const void* w; const float* scale; const float* shift; float* out; int cout; bool* fused; int up_hc, up_wc; };   // up_hc > 0: not a head but the UP2X residual mode (res = the coarser level)
-static int conv2d_f16_launch_impl(const isegmi_conv_desc* d, const void* in, const void* w, const float* scale, const float* shift, const void* res,
-                                  void* out, int out_f32, hipStream_t st, const ConvHeadF16* head);
-int conv2d_f16_launch(const isegmi_conv_desc* d, const void* in, const void* w, const float* scale, const float* shift, const void* res,
-                      void* out, int out_f32, hipStream_t st) {
-    return conv2d_f16_launch_impl(d, in, w, scale, shift, res, out, out_f32, st, nullptr);
-}
-// FPN top-down merge in the lateral conv's epilogue (UP2X, see epi8_up2x_next): out = fp16(fp16(conv1x1(x) + bias) + coarse[n, y >> 1, x >> 1]) -- the lateral
-// result is rounded to fp16 before the add exactly as the two-launch path (conv, then nearest2x_add_f16) stores it, so the result is bit-identical to it
-int conv2d_f16_up2x_launch(const isegmi_conv_desc* d, const void* in, const void* w, const float* scale, const float* shift, const void* coarse, int Hc, int Wc,
-                           void* out, hipStream_t st) {
-    ARG_CHECK(d && coarse && Hc > 0 && Wc > 0, "up2x: null / shape");
-    ARG_CHECK(d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0 && d->out_pix_stride == 0 && d->out_img_stride == 0 && d->Cout % 8 == 0 && d->W >= 8 &&
-              (d->tile & 255) == 0 && ((uintptr_t)coarse & 15) == 0, "up2x: a contiguous 1x1 / 1 / 0 conv with Cout % 8 == 0, W >= 8, tile 0");
-    ARG_CHECK((d->H + 1) / 2 <= Hc + 1 && (d->W + 1) / 2 <= Wc + 1, "up2x: the coarser level is about half the size");
-    const ConvHeadF16 h = {nullptr, nullptr, nullptr, nullptr, 0, nullptr, Hc, Wc};
-    return conv2d_f16_launch_impl(d, in, w, scale, shift, coarse, out, 0, st, &h);
-}
-int conv2d_f16_head_launch(const isegmi_conv_desc* d, const void* in, const void* w, const float* scale, const float* shift, const void* w2,
-                           const float* scale2, const float* shift2, int cout2, float* out2, bool* fused, hipStream_t st) {
-    ARG_CHECK(d && w2 && out2 && fused && cout2 > 0 && cout2 <= 32, "fused head: null / more than 32 outputs");
-    *fused = false;
-    if (!(d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1 && d->Cout == 256 && d->act == 1 && (d->tile & 255) == 0 && d->out_pix_stride == 0 && d->out_img_stride == 0))
-        return ISEGMI_OK;
-    const ConvHeadF16 h = {w2, scale2, shift2, out2, cout2, fused, 0, 0};
-    return conv2d_f16_launch_impl(d, in, w, scale, shift, nullptr, out2 /* never written: a non-null placeholder */, 0, st, &h);
-}
-static int conv2d_f16_launch_impl(const isegmi_conv_desc* d, const void* in, const void* w, const float* scale, const float* shift, const void* res,
-                                  void* out, int out_f32, hipStream_t st, const ConvHeadF16* head) {
-    ARG_CHECK(d && in && w && out, "null");
-    const bool stem = is_stem_h(d);
-    ARG_CHECK(stem || (d->Cin > 0 && d->Cin % 64 == 0), "fp16 conv needs Cin % 64 == 0 (or the 7x7/2 Cin=4 stem)");
-    ARG_CHECK(!stem || (d->stride == 2 && d->pad == 3 && res == nullptr), "fp16 stem is 7x7 stride 2 pad 3, no residual");
-    ARG_CHECK(d->act == 0 || d->act == 1, "fp16 conv supports act none/relu");
-    ConvKH k;
-    k.in = (const half_t*)in; k.w = (const half_t*)w; k.scale = scale; k.shift = shift; k.res = (const half_t*)res; k.out = out;
-    k.N = d->N; k.H = d->H; k.W = d->W; k.Cin = d->Cin; k.Cout = d->Cout; k.R = d->R; k.S = d->S; k.stride = d->stride; k.pad = d->pad;
-    k.Ho = (d->H + 2 * d->pad - d->R) / d->stride + 1;
-    k.Wo = (d->W + 2 * d->pad - d->S) / d->stride + 1;
-    const int64_t M64 = (int64_t)d->N * k.Ho * k.Wo;
-    ARG_CHECK(M64 < (1ll << 31) - 256, "too many output pixels");
-    k.M = (int)M64;
-    k.cin_chunks = stem ? 1 : d->Cin / 64;
-    k.nchunks = stem ? 4 : d->R * d->S * k.cin_chunks;
-    k.wrow = (int64_t)k.nchunks * 64;
-    // stem: `in` is the haloed image [N][H+6][(W+7)&~1][4] written by pad_c3_to_f16_halo (3 zero pixels on every side), so a
-    // filter row's taps wi0..wi0+7 of an output pixel are one aligned 64-B run and need no bounds test; K is laid out as
-    // 8 rows x 8 taps x 4 channels = 256 with zero weights at tap 7 / row 7 / channel 3 (4 chunks of two filter rows).
-    if (stem) { k.H = d->H + 6; k.W = (d->W + 7) & ~1; }
-    const int64_t in_bytes = stem ? (int64_t)d->N * k.H * k.W * 8 : (int64_t)d->N * d->H * d->W * d->Cin * 2;
-    ARG_CHECK(in_bytes < (1ll << 31), "conv input must be < 2 GiB");
-    k.in_bytes = (unsigned)in_bytes;
-    k.act = d->act; k.out_f32 = out_f32;
-    k.out_div = d->out_div > 0 ? d->out_div : k.Ho * k.Wo;
-    k.out_pix_stride = d->out_pix_stride > 0 ? d->out_pix_stride : d->Cout;
-    k.out_img_stride = d->out_img_stride > 0 ? d->out_img_stride : (int64_t)k.out_div * k.out_pix_stride;
-    k.contiguous = (k.out_img_stride == (int64_t)k.out_div * k.out_pix_stride) ? 1 : 0;
-    const int64_t n_img = (k.M + k.out_div - 1) / k.out_div;
-    const int64_t out_extent = ((n_img - 1) * k.out_img_stride + (int64_t)(k.out_div - 1) * k.out_pix_stride + d->Cout) * (out_f32 ? 4 : 2);
-    ARG_CHECK(out_extent < (1ll << 31), "conv output span must be < 2 GiB");
-    k.out_bytes = (unsigned)out_extent;
-    k.res_bytes = (unsigned)((int64_t)k.M * d->Cout * 2);
-    k.w_bytes = (unsigned)((int64_t)cout_pad_h(d->Cout) * k.wrow * 2);
-    const int64_t align_mask = out_f32 ? 3 : 7;
-    k.vec_epi = (d->Cout % 8 == 0 && (k.out_pix_stride & align_mask) == 0 && (k.out_img_stride & align_mask) == 0 && ((uintptr_t)out & 15) == 0 &&
-                 (res == nullptr || ((uintptr_t)res & 15) == 0)) ? 1 : 0;
-    int tile = d->tile;
-    ARG_CHECK(kExperimentFlags || (tile & ~(255 | 2048)) == 0, "conv tile: bits 256 / 512 / 1024 / 4096 are timing-only experiments (-DISEGMI_EXPERIMENT_FLAGS builds only)");
-    if (tile & 256) { k.in_bytes = 0; k.w_bytes = 0; }
-    if (tile & 512) k.in_bytes = 0;
-    if (tile & 1024) k.w_bytes = 0;
-    k.dbg = (tile & 4096) ? 1 : 0;
-    k.f_w = nullptr; k.f_scale = nullptr; k.f_shift = nullptr; k.f_out = nullptr; k.f_cout = 0; k.f_out_bytes = 0;
-    const bool few = (tile & 2048) != 0;  // TEST HOOK: persistent kernels run on an 8-block grid (multi-tile blocks on small shapes)
-    tile &= 255;  // (bits 256 / 512 / 1024: TIMING-ONLY experiments, every A / B load dropped by the range check)
-    if (stem) {
-        if (tile == 8) return launch_g<128, 64, 2, 2, 3, 2, true>(k, st);
-        return launch_g<64, 64, 2, 2, 3, 3, true>(k, st);
-    }
-    if (tile == 0) {
-        // Cost model: time ~ (blocks on the busiest CU) x BM x BN x (K / eff + epi) -- eff = the tile's relative MFMA efficiency (a 64x64
-        // tile cannot exceed ~1/2 of the MFMA rate: 32 FLOP per L2 byte), epi = its per-tile fixed cost in K units (ring fill + epilogue:
-        // small for the persistent kernels, which overlap both with the neighbouring tiles).  Tiles that share a CU (occ > 1) are assumed
-        // packed onto as few CUs as the dispatcher may choose.  Round 2: persistent forms of the loader-wave tiles (32-39), and (eff, epi)
-        // refitted on an in-model sweep of R101 bs 8 and R50 bs 2 with every generic tile forced in turn (tools/conv_tile_sweep.py ... f16
-        // -> profiles/r02_conv_f16_tile_sweep.txt).  Same-box A/B in bench.py, R101 bs 8, two runs each: round-1 table 815 / 813 img/s
-        // (conv 8.98 ms per step), persistent ids with the round-1 parameters 855 / 853 (8.53), refit 865 / 864 (8.33 ms = 656 TF/s).
-        // The non-persistent big tiles 1 / 2 / 7 / 9 / 11 / 12-14 / 17 / 19 left the candidate list.
-        static const struct { int id, bm, bn, occ; double eff, epi; } T[] = {
-            {3, 128, 128, 2, 0.613, 176}, {4, 64, 64, 3, 0.642, 106}, {5, 64, 128, 3, 0.751, 79}, {6, 64, 256, 2, 0.452, 266}, {10, 192, 128, 2, 0.772, 91},
-            {16, 160, 256, 1, 0.529, 200}, {20, 192, 128, 2, 0.300, 60},
-            // persistent, 4 loader waves (32: 8 MFMA waves of 96x64; 37: 12 of 64x64)
-            {32, 192, 256, 1, 0.929, 447}, {34, 256, 128, 1, 1.043, 127}, {37, 192, 256, 1, 1.197, 83}, {39, 128, 256, 1, 1.032, 99},
-            // row-strip variants (3x3 / stride 1 / pad 1 only: ~2.7x fewer A bytes through the CU's fill path) + 4 loader waves; measured
-            // level with tile 37 on every 3x3 layer of the sweep
-            {26, 192, 256, 1, 1.18, 83}, {27, 256, 128, 1, 1.03, 127}, {28, 160, 256, 1, 0.5, 200}, {29, 192, 256, 1, 1.21, 83},
-            {30, 192, 256, 1, 1.24, 83}};  // 29 with three B buffers (round 4): +3 % on the big layers, never slower (tools/conv_f16_bench.py)
-        const bool strip_ok = d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1;
-        double best = 0.0;
-        for (const auto& t : T) {
-            if (t.id >= 26 && t.id <= 31 && !(strip_ok && (t.bm - 1) / d->W + 2 <= 32)) continue;
-            const int64_t blocks = (int64_t)cdiv(k.M, t.bm) * cdiv(d->Cout, t.bn);
-            int64_t per_cu = (blocks + 255) / 256;
-            if (t.occ > 1 && blocks <= 256 * t.occ) per_cu = blocks < t.occ ? blocks : t.occ;
-            const double c = (double)per_cu * t.bm * t.bn * ((double)k.nchunks * 64.0 / t.eff + t.epi);
-            if (tile == 0 || c < best) { best = c; tile = t.id; }
-        }
-    }
-    k.res_up2x = 0; k.rHc = 0; k.rWc = 0;
-    if (head && head->up_hc > 0) {
-        ARG_CHECK(k.vec_epi, "up2x needs 16-byte aligned tensors");
-        const int64_t rb = (int64_t)d->N * head->up_hc * head->up_wc * d->Cout * 2;
-        ARG_CHECK(rb < (1ll << 31), "up2x: coarse level must be < 2 GiB");
-        k.res_up2x = 1; k.rHc = head->up_hc; k.rWc = head->up_wc; k.res_bytes = (unsigned)rb;
-        if (g_f16_mfma16 >= 2) return conv_f16_m16_launch(48, k, st, few);
-        return launch_p<192, 256, 3, 4, 2, 1, 4, true>(k, st, few);   // "tile 38": tile 37 with the walked residual
-    }
-    if (head) {
-        // fused where the 192 x 256 row-strip tile is usable and the layer has at least half a round of such tiles (the fusion saves the 1x1 launch and t's
-        // round trip, worth more than the tile quantisation the cost model might avoid with another tile); smaller levels: the caller runs the two launches
-        if (!(191 / d->W + 2 <= 32) || cdiv(k.M, 192) < 128) return ISEGMI_OK;
-        const int64_t ob = (int64_t)k.M * head->cout * 4;
-        ARG_CHECK(ob < (1ll << 31), "fused head output must be < 2 GiB");
-        k.f_w = (const half_t*)head->w; k.f_scale = head->scale; k.f_shift = head->shift; k.f_out = head->out; k.f_cout = head->cout; k.f_out_bytes = (unsigned)ob;
-        *head->fused = true;
-        tile = g_f16_mfma16 >= 1 ? 40 : 30;
-    }
-    // the MFMA shape of the tiles that carry the fp16 backbone: 30 / 34 / 37 / 39 run on v_mfma_f32_32x32x16_f16 (this file), 40 / 44 / 47 / 49 are the same tiles
-    // on v_mfma_f32_16x16x32_f16 (csrc/conv_mfma_f16_m16.hip).  The cost model chooses among the former; g_f16_mfma16 (isegmi_set_f16_mfma_shape) maps its
-    // choice onto the latter: 1 (default) the row-strip tile and the fused head that lives on it -- +8 % on the 634-GF layer (983 -> 1062 TF/s, same box;
-    // profiles/r05_experiments.txt 1) -- 2 the persistent tiles and the UP2X merge as well (memory-bound layers: level or 1-3 % slower, kept for A/B).
-    // Results do not depend on the shape: one 16 x 16 x 32 instruction sums its 32 products exactly as two chained 32 x 32 x 16 instructions do
-    // (tools/microbench/mfma_shape.hip: 0 of 204 800 elements differ).
-    if (g_f16_mfma16 >= 1 && (d->tile & 255) == 0 && tile == 30) tile = 40;
-    if (g_f16_mfma16 >= 2 && (d->tile & 255) == 0) tile = tile == 34 ? 44 : tile == 37 ? 47 : tile == 39 ? 49 : tile;
-    if (tile == 40) ARG_CHECK(d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1 && 191 / d->W + 2 <= 32, "strip tiles are for 3x3 / stride 1 / pad 1, <= 32 image-row segments");
-    if (tile == 40 || tile == 44 || tile == 47 || tile == 49) return conv_f16_m16_launch(tile, k, st, few);
-    if (tile >= 26 && tile <= 31) {
-        ARG_CHECK(d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1, "strip tiles are for 3x3 / stride 1 / pad 1");
-        const int bm = tile == 27 ? 256 : tile == 28 ? 160 : 192;
-        ARG_CHECK((bm - 1) / d->W + 2 <= 32, "strip tile: too many image-row segments (W too small)");
-        switch (tile) {  // row strips + 4 loader waves
-            case 26: return launch_strip<192, 256, 2, 4, 4>(k, st);
-            case 27: return launch_strip<256, 128, 4, 2, 4>(k, st);
-            case 29: return launch_strip<192, 256, 3, 4, 4>(k, st);  // 12 MFMA waves (64x64 each) + 4 loader waves
-            case 30: return launch_strip<192, 256, 3, 4, 4, 3>(k, st);  // the same with three B buffers and a counted wait (round 4)
-            case 31: return launch_strip<192, 256, 2, 4, 4, 3>(k, st);  // 8 MFMA waves (96x64 each), three B buffers
-            default: return launch_strip<160, 256, 1, 8, 4>(k, st);
-        }
-    }
+int conv_f16_m16_launch(int tile, ConvKH& k, hipStream_t st, bool few) {
     switch (tile) {
-        case 1: return launch_g<256, 256, 2, 4, 2, 1>(k, st);  // 8 waves, wave tile 128x64
-        case 2: return launch_g<256, 128, 4, 2, 3, 1>(k, st);  // 8 waves, wave tile 64x64, 3-deep ring
-        case 3: return launch_g<128, 128, 2, 2, 2, 2>(k, st);
-        case 4: return launch_g<64, 64, 2, 2, 3, 3>(k, st);
-        case 5: return launch_g<64, 128, 1, 4, 2, 3>(k, st);
-        case 6: return launch_g<64, 256, 1, 4, 2, 2>(k, st);
-        case 7: return launch_g<128, 256, 2, 4, 3, 1>(k, st);
-        case 8: return launch_g<128, 64, 2, 2, 3, 2>(k, st);
-        case 9: return launch_g<192, 256, 2, 4, 2, 1>(k, st);   // wave tile 96x64
-        case 10: return launch_g<192, 128, 2, 2, 2, 2>(k, st);
-        case 11: return launch_g<160, 256, 1, 8, 2, 1>(k, st);
-        case 12: return launch_g<192, 256, 2, 4, 2, 1, false, 4>(k, st);  // 8 MFMA waves + 4 loader waves
-        case 13: return launch_g<256, 256, 2, 4, 2, 1, false, 4>(k, st);
-        case 14: return launch_g<256, 128, 4, 2, 3, 1, false, 4>(k, st);
-        case 16: return launch_g<160, 256, 1, 8, 2, 1, false, 4>(k, st);
-        case 17: return launch_g<192, 256, 3, 4, 2, 1, false, 4>(k, st);  // 12 MFMA waves (64x64 each) + 4 loader waves
-        case 19: return launch_g<128, 256, 2, 4, 3, 1, false, 4>(k, st);  // 128x256, 3-deep ring, 8 MFMA + 4 loader waves
-        case 20: return launch_g<192, 128, 3, 2, 2, 2, false, 2>(k, st);  // 6 MFMA + 2 loader waves, 2 blocks/CU  // wave tile 160x32; 20 A pieces over 8 waves (partial round)
-        // persistent forms of 12 / 14 / 17 / 19 (loader waves stream the next tile during this tile's epilogue; 13's 256x256 form was dropped in
-        // round 3: 128 accumulator registers + the residual window spill, and the cost model never chose it); the two-blocks-
-        // per-CU tile 20 has no persistent form: 128 registers per wave do not hold its accumulators next to the tile loop (it spilled)
-        case 32: return launch_p<192, 256, 2, 4, 2, 1, 4>(k, st, few);
-        case 34: return launch_p<256, 128, 4, 2, 3, 1, 4>(k, st, few);
-        case 37: return launch_p<192, 256, 3, 4, 2, 1, 4>(k, st, few);
-        case 39: return launch_p<128, 256, 2, 4, 3, 1, 4>(k, st, few);
+        case 40: return launch_strip<192, 256, 3, 4, 4, 3, 1>(k, st);
+        case 44: return launch_p<256, 128, 4, 2, 3, 1, 4, false, 1>(k, st, few);
+        case 47: return launch_p<192, 256, 3, 4, 2, 1, 4, false, 1>(k, st, few);
+        case 48: return launch_p<192, 256, 3, 4, 2, 1, 4, true, 1>(k, st, few);
+        case 49: return launch_p<128, 256, 2, 4, 3, 1, 4, false, 1>(k, st, few);
         default: break;
     }
-    ARG_CHECK(false, "unknown fp16 conv tile");
+    ARG_CHECK(false, "unknown 16 x 16 x 32 conv tile");
 }
 
 }  // namespace isegmi
-
-using namespace isegmi;
-
-extern "C" int isegmi_conv_packed_halfs(const isegmi_conv_desc* d, int64_t* n) {
-    ARG_CHECK(d && n && d->Cin > 0 && (d->Cin % 64 == 0 || is_stem_h(d)), "fp16 pack needs Cin % 64 == 0 (or the stem)");
-    *n = is_stem_h(d) ? (int64_t)cout_pad_h(d->Cout) * 256 : (int64_t)cout_pad_h(d->Cout) * d->R * d->S * d->Cin;
-    return ISEGMI_OK;
-}
-
-// host: natural fp32 [Cout][R][S][Cin] -> fp16 [Cout padded to 128][R*S*Cin] (round to nearest even)
-extern "C" int isegmi_pack_conv_weights_f16(const isegmi_conv_desc* d, const float* w, uint16_t* packed) {
-    ARG_CHECK(d && w && packed && d->Cin > 0 && (d->Cin % 64 == 0 || is_stem_h(d)), "fp16 pack needs Cin % 64 == 0 (or the stem)");
-    if (is_stem_h(d)) {  // [Cout][7][7][4] -> [Cout padded][8 rows][8 taps][4 ch], zero at row 7 / tap 7
-        const int64_t total = (int64_t)cout_pad_h(d->Cout) * 256;
-        for (int64_t i = 0; i < total; ++i) packed[i] = 0;
-        for (int co = 0; co < d->Cout; ++co)
-            for (int r = 0; r < 7; ++r)
-                for (int t = 0; t < 7; ++t)
-                    for (int c = 0; c < 4; ++c) {
-                        const half_t h = (half_t)w[(((int64_t)co * 7 + r) * 7 + t) * 4 + c];
-                        packed[(int64_t)co * 256 + r * 32 + t * 4 + c] = __builtin_bit_cast(uint16_t, h);
-                    }
-        return ISEGMI_OK;
-    }
-    const int64_t K = (int64_t)d->R * d->S * d->Cin;
-    const int64_t total = (int64_t)cout_pad_h(d->Cout) * K;
-    for (int64_t i = 0; i < total; ++i) packed[i] = 0;
-    for (int co = 0; co < d->Cout; ++co)
-        for (int64_t k = 0; k < K; ++k) {
-            const half_t h = (half_t)w[(int64_t)co * K + k];
-            packed[(int64_t)co * K + k] = __builtin_bit_cast(uint16_t, h);
-        }
-    return ISEGMI_OK;
-}
-
-extern "C" int isegmi_op_conv1x1_up2x_add_f16(const isegmi_conv_desc* d, const void* d_in, const void* d_wpacked, const float* d_scale, const float* d_shift,
-                                              const void* d_coarse, int Hc, int Wc, void* d_out, void* stream) {
-    return conv2d_f16_up2x_launch(d, d_in, d_wpacked, d_scale, d_shift, d_coarse, Hc, Wc, d_out, (hipStream_t)stream);
-}
-
-extern "C" int isegmi_op_conv3x3_head_f16(const isegmi_conv_desc* d, const void* d_in, const void* d_wpacked, const float* d_scale, const float* d_shift,
-                                          const void* d_w2packed, const float* d_scale2, const float* d_shift2, int cout2, float* d_out2, int* fused, void* stream) {
-    ARG_CHECK(fused, "null");
-    bool f = false;
-    const int rc = conv2d_f16_head_launch(d, d_in, d_wpacked, d_scale, d_shift, d_w2packed, d_scale2, d_shift2, cout2, d_out2, &f, (hipStream_t)stream);
-    *fused = f ? 1 : 0;
-    return rc;
-}
-
-extern "C" int isegmi_op_conv2d_f16(const isegmi_conv_desc* d, const void* d_in, const void* d_wpacked, const float* d_scale,
-                                    const float* d_shift, const void* d_residual, void* d_out, int out_f32, void* stream) {
-    return conv2d_f16_launch(d, d_in, d_wpacked, d_scale, d_shift, d_residual, d_out, out_f32, (hipStream_t)stream);
-}
-
-extern "C" int isegmi_set_f16_mfma_shape(int shape) {
-    ARG_CHECK(shape >= 0 && shape <= 2, "0: v_mfma_f32_32x32x16_f16 everywhere, 1: row strips on v_mfma_f32_16x16x32_f16, 2: persistent tiles too");
-    conv_f16_mfma_shape(shape);
-    return ISEGMI_OK;
-}
-extern "C" int isegmi_get_f16_mfma_shape(int* shape) {
-    ARG_CHECK(shape, "null");
-    *shape = conv_f16_mfma_shape(-1);
-    return ISEGMI_OK;
-}

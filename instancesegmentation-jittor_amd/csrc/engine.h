@@ -1,5 +1,6 @@
 // engine.h -- model engine: packed-weight registry, named activation buffers, per-model forward graphs.
 #pragma once
+#include "rpn_levels.h"
 #include <functional>
 #include <map>
 #include <string>

@@ -197,6 +197,37 @@ int maskrcnn_forward(Engine& e, const float* d_images, int N) {
     // Per level, finest first: FPN output conv -> RPN head convs on the main stream, then that level's
     // selection (sigmoid, top-k, decode, NMS: small latency-bound grids) on a side stream so it hides under the
     // next level's convolutions.  P2's selection (201 600 anchors) gets all the remaining levels to hide under.
+    // SELECTION BATCHED OVER (level, image) (round 5; SURVEY 2.1 "level x image as ONE batch dimension"): the levels' sigmoid, pre-NMS top-k, suppression
+    // matrix and greedy scan run as five launches per GROUP of levels instead of four or five per level (22 launches, 520 us of latency-bound grids per
+    // bs = 2 step).  Batches of two or more: one group of all five levels on the tail stream behind the last head conv (it hides under the next forward's
+    // backbone anyway).  One image (latency): P2 -- 201 600 anchors, the longest chain -- goes first on a side stream under the other levels' convolutions,
+    // P3..P6 as one group behind P6's head.  "rpn_select_groups": 0 = the per-level launches (A/B; also taken for pre_nms outside 257..1024), 1 / 2 force.
+    const int sel_groups_param = (int)e.param("rpn_select_groups", -1.0f);
+    const bool batched_sel = sel_groups_param != 0 && pre_nms > 256 && pre_nms <= 1024 && post_nms > 0;
+    const int sel_groups = !batched_sel ? 0 : (sel_groups_param > 0 ? (sel_groups_param > 2 ? 2 : sel_groups_param) : (N >= 2 ? 1 : 2));
+    const float* lvl_head[5]; const float* lvl_anc[5]; int lvl_hwa[5];
+    auto select_group = [&](int l0, int l1) -> int {   // levels [l0, l1) on e.cur
+        const int nl = l1 - l0;
+        const std::string gs = std::to_string(l0) + "_" + std::to_string(l1);
+        int slot[5];
+        for (int l = l0; l < l1; ++l) slot[l - l0] = l;
+        int64_t pe = 0, ce = 0;
+        TRY(rpn_levels_workspace(nl, N, lvl_hwa + l0, pre_nms, &pe, &ce));
+        void* q;
+        float *prob, *cv, *tkv; int *ci, *tki, *tkc; void* nws;
+        TRY(eng_buf(e, "rpn.g_prob" + gs, pe * 4, &q)); prob = (float*)q;
+        TRY(eng_buf(e, "rpn.g_cand_vals" + gs, ce * 4, &q)); cv = (float*)q;
+        TRY(eng_buf(e, "rpn.g_cand_idx" + gs, ce * 4, &q, 1)); ci = (int*)q;
+        TRY(eng_buf(e, "rpn.g_tk_vals" + gs, (int64_t)nl * N * pre_nms * 4, &q)); tkv = (float*)q;
+        TRY(eng_buf(e, "rpn.g_tk_idx" + gs, (int64_t)nl * N * pre_nms * 4, &q, 1)); tki = (int*)q;
+        TRY(eng_buf(e, "rpn.g_tk_cnt" + gs, (int64_t)nl * N * 4, &q, 1)); tkc = (int*)q;
+        TRY(eng_buf(e, "rpn.g_nms_ws" + gs, (int64_t)nl * N * 131072, &nws, 1));
+        double bytes = 0;   // SURVEY 8d, as for the per-level form: logits once + deltas and anchors of the pre-NMS top-k + the kept boxes and scores
+        for (int l = l0; l < l1; ++l) bytes += (double)N * ((double)lvl_hwa[l] * 4 + (double)(pre_nms < lvl_hwa[l] ? pre_nms : lvl_hwa[l]) * 32 + (double)post_nms * 20);
+        OpScope op(e, st, "rpn_select (sigmoid + top-k + decode + NMS, per FPN level)", bytes);
+        return rpn_levels_select_launch(nl, lvl_head + l0, lvl_anc + l0, lvl_hwa + l0, slot, d_hw, N, A, CH, pre_nms, post_nms, rpn_thr, rpn_min, ge, L, post_nms,
+                                        prob, cv, ci, tkv, tki, tkc, nws, cand_boxes, cand_scores, cand_cnt, st);
+    };
     auto rpn_level = [&](int l) -> int {
         const std::string ls = std::to_string(l);
         Tensor t, head;
@@ -209,6 +240,17 @@ int maskrcnn_forward(Engine& e, const float* d_images, int N) {
         const int HW = head.H * head.W, HWA = HW * A;
         const float* anc;
         TRY(level_anchors(e, l, A, head.H, head.W, regen_anchors, &anc));
+        lvl_head[l] = head.d; lvl_anc[l] = anc; lvl_hwa[l] = HWA;
+        if (sel_groups == 1) return ISEGMI_OK;                 // all five levels: one group on the tail stream, below
+        if (sel_groups == 2) {
+            if (l != 0) return ISEGMI_OK;                      // P3..P6: one group behind P6's head, below
+            if (e.multi_stream && !e.capturing) {              // P2: its own group, now, under the remaining levels' convolutions
+                TRY(eng_fork(e, 0));
+                SideScope sc(e, 0);
+                return select_group(0, 1);
+            }
+            return select_group(0, 1);
+        }
         float *prob, *tkv;
         int *tki, *tkc;
         void* q;
@@ -284,6 +326,8 @@ int maskrcnn_forward(Engine& e, const float* d_images, int N) {
         }
         e.cur = e.tail;
     }
+    if (sel_groups == 1) TRY(select_group(0, L));
+    else if (sel_groups == 2) TRY(select_group(1, L));
     eng_mark(e, "fpn_out+rpn");
     TRY(sum_counts_launch(cand_cnt, N, L, cand_total, st));
     float *fin_vals, *props, *prop_scores;

@@ -15,7 +15,9 @@
 // Reference anchor: COCODemo.run_on_opencv_image (README.md:331) reaches every one of these.
 #include "../../include/isegmi.h"
 #include "common.h"
+#include "rpn_levels.h"
 #include "detmath.h"
+#include <string.h>
 
 namespace isegmi {
 
@@ -236,6 +238,33 @@ __global__ void rpn_sigmoid_kernel(const float* __restrict__ head, int64_t total
     }
 }
 
+// RPN selection batched over (level, image) -- SURVEY 2.1 "level x image as ONE batch dimension" (round 5): the five levels' sigmoid,
+// pre-NMS top-k, suppression matrix and greedy scan as FIVE launches instead of five per level.  Row (l, n) = level slot l of the batch, image n; per-level
+// constants come from the table, per-row arrays (tk_*, nms workspace) are laid out [l][N][...].  Same kernels, same total order, same ballot ranking as the
+// per-level path (which is this one with nl = 1): indices are bit-identical.
+struct RpnLevels {
+    int nl, N, A, CH, pre_nms, post_nms, post_cap, L;
+    float thr, min_size;
+    int ge;
+    const float* head[RPN_MAX_LEVELS];      // [N][HW_l][CH]: A objectness logits, then A * 4 deltas per pixel
+    const float* anchors[RPN_MAX_LEVELS];   // [HWA_l][4]
+    int HWA[RPN_MAX_LEVELS];
+    int level[RPN_MAX_LEVELS];              // slot of the level in the [N][L][post_cap] candidate lists
+    int64_t prob_off[RPN_MAX_LEVELS + 1];   // floats: level l's probabilities [N][HWA_l] start at prob + prob_off[l]
+};
+
+__global__ void rpn_sigmoid_levels_kernel(const RpnLevels b, float* __restrict__ prob) {
+    const int64_t total = b.prob_off[b.nl];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int l = 0;
+        while (l + 1 < b.nl && i >= b.prob_off[l + 1]) ++l;
+        const int64_t j = i - b.prob_off[l];
+        const int64_t pix = j / b.A;
+        const int a = (int)(j - pix * b.A);
+        prob[i] = dm_sigmoid(b.head[l][pix * b.CH + a]);
+    }
+}
+
 // grid (N); one (image, level) per block.  tk_vals/tk_idx [N][pre_nms] sorted; tk_cnt [N].
 // out_boxes [N][L][post_cap][4], out_scores [N][L][post_cap] (-1 beyond count), out_cnt [N][L].
 template <int CAP>
@@ -378,14 +407,17 @@ __device__ __forceinline__ float4 rpn_candidate_box(const float* __restrict__ he
     return clip_box(decode_box(an, d, 1.f, 1.f, 1.f, 1.f), im_w, im_h);
 }
 
-__global__ __launch_bounds__(256) void rpn_nms_matrix_kernel(const float* __restrict__ head, const float* __restrict__ anchors,
-                                                             const int* __restrict__ tk_idx, const int* __restrict__ tk_cnt,
-                                                             const int* __restrict__ image_hw, int HWA, int A, int CH, int pre_nms,
-                                                             float thr, int ge, unsigned long long* __restrict__ ws) {
+__global__ __launch_bounds__(256) void rpn_nms_matrix_kernel(const RpnLevels b, const int* __restrict__ tk_idx, const int* __restrict__ tk_cnt,
+                                                             const int* __restrict__ image_hw, unsigned long long* __restrict__ ws) {
     constexpr int W = NMS_CAP / 64;
     __shared__ float4 cols[4][64];
-    const int n = blockIdx.y;
-    const int cnt = tk_cnt[n];
+    const int row = blockIdx.y;                      // (l, n)
+    const int l = row / b.N, n = row - l * b.N;
+    const float* __restrict__ head = b.head[l];
+    const float* __restrict__ anchors = b.anchors[l];
+    const int HWA = b.HWA[l], A = b.A, CH = b.CH, pre_nms = b.pre_nms;
+    tk_idx += (int64_t)l * b.N * pre_nms;            // level l's [N][pre_nms]
+    const int cnt = tk_cnt[row];
     const int nwords = (cnt + 63) >> 6;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pair = blockIdx.x * 4 + wave;  // wave-uniform
@@ -394,7 +426,7 @@ __global__ __launch_bounds__(256) void rpn_nms_matrix_kernel(const float* __rest
     const int r = pair - w * (w + 1) / 2;
     if (w >= nwords) return;  // whole wave; no block-level barrier below
     const float im_h = (float)image_hw[2 * n], im_w = (float)image_hw[2 * n + 1];
-    const IouThr T = make_iou_thr(thr, ge);
+    const IouThr T = make_iou_thr(b.thr, b.ge);
     const int i = (r << 6) + lane, jc = (w << 6) + lane;
     const float4 mine = rpn_candidate_box(head, anchors, tk_idx, n, i < cnt ? i : 0, pre_nms, HWA, A, CH, im_w, im_h);
     cols[wave][lane] = rpn_candidate_box(head, anchors, tk_idx, n, jc < cnt ? jc : 0, pre_nms, HWA, A, CH, im_w, im_h);
@@ -402,43 +434,47 @@ __global__ __launch_bounds__(256) void rpn_nms_matrix_kernel(const float* __rest
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's own LDS writes have landed
     unsigned long long m = 0ull;
 #pragma unroll 8
-    for (int b = 0; b < 64; ++b) {
-        const int j = (w << 6) + b;
-        const bool sup = j > i && j < cnt && iou_exceeds(mine, cols[wave][b], 1.0f, T);
-        m |= sup ? (1ull << b) : 0ull;
+    for (int bb = 0; bb < 64; ++bb) {
+        const int j = (w << 6) + bb;
+        const bool sup = j > i && j < cnt && iou_exceeds(mine, cols[wave][bb], 1.0f, T);
+        m |= sup ? (1ull << bb) : 0ull;
     }
-    if (i < cnt) ws[((int64_t)n * NMS_CAP + i) * W + w] = m;
+    if (i < cnt) ws[((int64_t)row * NMS_CAP + i) * W + w] = m;
 }
 
-__global__ __launch_bounds__(1024) void rpn_nms_scan_kernel(const float* __restrict__ head, const float* __restrict__ anchors,
-                                                            const float* __restrict__ tk_vals, const int* __restrict__ tk_idx,
+__global__ __launch_bounds__(1024) void rpn_nms_scan_kernel(const RpnLevels b, const float* __restrict__ tk_vals, const int* __restrict__ tk_idx,
                                                             const int* __restrict__ tk_cnt, const int* __restrict__ image_hw,
-                                                            int HWA, int A, int CH, int pre_nms, int post_nms, float min_size,
-                                                            int level, int L, int post_cap, const unsigned long long* __restrict__ ws,
-                                                            float* __restrict__ out_boxes, float* __restrict__ out_scores,
-                                                            int* __restrict__ out_cnt) {
+                                                            const unsigned long long* __restrict__ ws, float* __restrict__ out_boxes,
+                                                            float* __restrict__ out_scores, int* __restrict__ out_cnt) {
     constexpr int W = NMS_CAP / 64;
     extern __shared__ unsigned long long M[];  // [NMS_CAP][W]
     __shared__ float4 sb[NMS_CAP];
     __shared__ unsigned short kept[NMS_CAP];
     __shared__ unsigned char dead[NMS_CAP];
     __shared__ int kc_sh;
-    const int n = blockIdx.x;
-    const int cnt = tk_cnt[n];
+    const int row = blockIdx.x;                      // (l, n)
+    const int l = row / b.N, n = row - l * b.N;
+    const float* __restrict__ head = b.head[l];
+    const float* __restrict__ anchors = b.anchors[l];
+    const int HWA = b.HWA[l], A = b.A, CH = b.CH, pre_nms = b.pre_nms, post_nms = b.post_nms, post_cap = b.post_cap, L = b.L, level = b.level[l];
+    const float min_size = b.min_size;
+    tk_idx += (int64_t)l * b.N * pre_nms;
+    tk_vals += (int64_t)l * b.N * pre_nms;
+    const int cnt = tk_cnt[row];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float im_h = (float)image_hw[2 * n], im_w = (float)image_hw[2 * n + 1];
     {   // matrix rows [0, cnt) -> LDS, 16 bytes per thread and step (rows past cnt and words left of the diagonal are stale
         // workspace; the scan never selects them)
         typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-        const u32x4* src = (const u32x4*)(ws + (int64_t)n * NMS_CAP * W);
+        const u32x4* src = (const u32x4*)(ws + (int64_t)row * NMS_CAP * W);
         u32x4* dst = (u32x4*)M;
         const int n16 = cnt * W / 2;
         for (int q = tid; q < n16; q += 1024) dst[q] = src[q];
     }
     for (int j = tid; j < cnt; j += 1024) {
-        const float4 b = rpn_candidate_box(head, anchors, tk_idx, n, j, pre_nms, HWA, A, CH, im_w, im_h);
-        sb[j] = b;
-        const float ws_ = b.z - b.x + 1.0f, hs = b.w - b.y + 1.0f;
+        const float4 bx = rpn_candidate_box(head, anchors, tk_idx, n, j, pre_nms, HWA, A, CH, im_w, im_h);
+        sb[j] = bx;
+        const float ws_ = bx.z - bx.x + 1.0f, hs = bx.w - bx.y + 1.0f;
         dead[j] = (ws_ >= min_size && hs >= min_size) ? 0 : 1;
     }
     __syncthreads();
@@ -936,6 +972,61 @@ int rpn_sigmoid_launch(const float* head, int64_t total, int A, int CH, float* p
     return ISEGMI_OK;
 }
 
+// suppression matrix + greedy scan of b.nl x b.N rows (tk_* laid out [l][N][pre_nms], tk_cnt [l][N], nms_ws b.nl * b.N * 131072 bytes): two launches
+static int rpn_nms_levels_launch(const RpnLevels& b, const float* tk_vals, const int* tk_idx, const int* tk_cnt, const int* image_hw, void* nms_ws,
+                                 float* out_boxes, float* out_scores, int* out_cnt, hipStream_t st) {
+    constexpr int W = NMS_CAP / 64;
+    constexpr int matrix_bytes = NMS_CAP * W * 8;  // 128 KB next to 19 KB of static LDS
+    static PerDeviceOnce attr;
+    if (attr.need()) HIP_TRY(hipFuncSetAttribute((const void*)rpn_nms_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, matrix_bytes));
+    const int pairs = W * (W + 1) / 2;
+    hipLaunchKernelGGL(rpn_nms_matrix_kernel, dim3(cdiv(pairs, 4), b.nl * b.N), dim3(256), 0, st, b, tk_idx, tk_cnt, image_hw, (unsigned long long*)nms_ws);
+    hipLaunchKernelGGL(rpn_nms_scan_kernel, dim3(b.nl * b.N), dim3(1024), matrix_bytes, st, b, tk_vals, tk_idx, tk_cnt, image_hw,
+                       (const unsigned long long*)nms_ws, out_boxes, out_scores, out_cnt);
+    HIP_TRY(hipGetLastError());
+    return ISEGMI_OK;
+}
+
+// Workspace of the batched selection (all in elements of the buffer's type): prob Sum N * HWA_l floats; cand_vals / cand_idx: the level-1 top-k candidates
+// (rpn_topk_plan); tk_vals / tk_idx nl * N * pre_nms; tk_cnt nl * N; nms_ws nl * N * 131072 bytes.
+int rpn_levels_workspace(int nl, int N, const int* HWA, int pre_nms, int64_t* prob_elems, int64_t* cand_elems) {
+    ARG_CHECK(nl >= 1 && nl <= RPN_MAX_LEVELS && N >= 1 && prob_elems && cand_elems, "rpn levels");
+    int slices[RPN_MAX_LEVELS];
+    int64_t coff[RPN_MAX_LEVELS + 1], p = 0;
+    for (int l = 0; l < nl; ++l) p += (int64_t)N * HWA[l];
+    rpn_topk_plan(nl, N, HWA, pre_nms, slices, coff);
+    *prob_elems = p;
+    *cand_elems = coff[nl];
+    return ISEGMI_OK;
+}
+
+// sigmoid -> top-k (two launches) -> decode + suppression matrix -> greedy scan for nl levels x N images: five launches on `st`.
+// heads[l] [N][HW_l][A * 5] fp32, anchors[l] [HW_l * A][4]; level_slot[l] = the level's slot in the [N][L][post_cap] outputs.
+int rpn_levels_select_launch(int nl, const float* const* heads, const float* const* anchors, const int* HWA, const int* level_slot, const int* image_hw, int N,
+                             int A, int CH, int pre_nms, int post_nms, float thr, float min_size, int ge, int L, int post_cap, float* prob, float* cand_vals,
+                             int* cand_idx, float* tk_vals, int* tk_idx, int* tk_cnt, void* nms_ws, float* out_boxes, float* out_scores, int* out_cnt,
+                             hipStream_t st) {
+    ARG_CHECK(nl >= 1 && nl <= RPN_MAX_LEVELS && N >= 1, "rpn levels");
+    ARG_CHECK(pre_nms > 256 && pre_nms <= NMS_CAP && post_nms > 0 && post_nms <= post_cap && nms_ws, "batched RPN selection: 256 < pre_nms <= 1024, a matrix workspace");
+    ARG_CHECK(thr > 0.0f, "nms threshold must be > 0");
+    RpnLevels b;
+    memset(&b, 0, sizeof(b));
+    b.nl = nl; b.N = N; b.A = A; b.CH = CH; b.pre_nms = pre_nms; b.post_nms = post_nms; b.post_cap = post_cap; b.L = L;
+    b.thr = thr; b.min_size = min_size; b.ge = ge;
+    int slices[RPN_MAX_LEVELS];
+    int64_t coff[RPN_MAX_LEVELS + 1];
+    for (int l = 0; l < nl; ++l) {
+        ARG_CHECK(heads[l] && anchors[l] && HWA[l] > 0 && HWA[l] % A == 0 && level_slot[l] >= 0 && level_slot[l] < L, "rpn level table");
+        b.head[l] = heads[l]; b.anchors[l] = anchors[l]; b.HWA[l] = HWA[l]; b.level[l] = level_slot[l];
+        b.prob_off[l + 1] = b.prob_off[l] + (int64_t)N * HWA[l];
+    }
+    rpn_topk_plan(nl, N, HWA, pre_nms, slices, coff);
+    hipLaunchKernelGGL(rpn_sigmoid_levels_kernel, dim3(grid_for(b.prob_off[nl])), dim3(256), 0, st, b, prob);
+    int rc = rpn_topk_levels_launch(nl, N, prob, b.prob_off, HWA, pre_nms, slices, coff, cand_vals, cand_idx, tk_vals, tk_idx, tk_cnt, st);
+    if (rc) return rc;
+    return rpn_nms_levels_launch(b, tk_vals, tk_idx, tk_cnt, image_hw, nms_ws, out_boxes, out_scores, out_cnt, st);
+}
+
 int rpn_decode_nms_launch(const float* head, const float* anchors, const float* tk_vals, const int* tk_idx, const int* tk_cnt,
                           const int* image_hw, int N, int HWA, int A, int CH, int pre_nms, int post_nms, float thr, float min_size,
                           int ge, int level, int L, int post_cap, float* out_boxes, float* out_scores, int* out_cnt, void* nms_ws,
@@ -943,16 +1034,12 @@ int rpn_decode_nms_launch(const float* head, const float* anchors, const float* 
     ARG_CHECK(pre_nms <= NMS_CAP_BIG && post_nms <= post_cap, "rpn sizes (pre_nms <= 6144)");
     ARG_CHECK(thr > 0.0f, "nms threshold must be > 0");
     if (pre_nms <= NMS_CAP && nms_ws != nullptr && post_nms > 0) {
-        constexpr int W = NMS_CAP / 64;
-        constexpr int matrix_bytes = NMS_CAP * W * 8;  // 128 KB next to 19 KB of static LDS
-        static PerDeviceOnce attr;
-        if (attr.need()) HIP_TRY(hipFuncSetAttribute((const void*)rpn_nms_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, matrix_bytes));
-        const int pairs = W * (W + 1) / 2;
-        hipLaunchKernelGGL(rpn_nms_matrix_kernel, dim3(cdiv(pairs, 4), N), dim3(256), 0, st, head, anchors, tk_idx, tk_cnt, image_hw, HWA, A,
-                           CH, pre_nms, thr, ge, (unsigned long long*)nms_ws);
-        hipLaunchKernelGGL(rpn_nms_scan_kernel, dim3(N), dim3(1024), matrix_bytes, st, head, anchors, tk_vals, tk_idx, tk_cnt, image_hw, HWA,
-                           A, CH, pre_nms, post_nms, min_size, level, L, post_cap, (const unsigned long long*)nms_ws, out_boxes, out_scores,
-                           out_cnt);
+        RpnLevels b;
+        memset(&b, 0, sizeof(b));
+        b.nl = 1; b.N = N; b.A = A; b.CH = CH; b.pre_nms = pre_nms; b.post_nms = post_nms; b.post_cap = post_cap; b.L = L;
+        b.thr = thr; b.min_size = min_size; b.ge = ge;
+        b.head[0] = head; b.anchors[0] = anchors; b.HWA[0] = HWA; b.level[0] = level;
+        return rpn_nms_levels_launch(b, tk_vals, tk_idx, tk_cnt, image_hw, nms_ws, out_boxes, out_scores, out_cnt, st);
     } else if (pre_nms <= NMS_CAP)
         hipLaunchKernelGGL(rpn_decode_nms_kernel<NMS_CAP>, dim3(N), dim3(1024), 0, st, head, anchors, tk_vals, tk_idx, tk_cnt, image_hw, HWA, A,
                            CH, pre_nms, post_nms, thr, min_size, ge, level, L, post_cap, out_boxes, out_scores, out_cnt);
@@ -1132,4 +1219,23 @@ extern "C" int isegmi_op_rpn_level(const float* d_head, const float* d_anchors, 
     (void)k;
     return rpn_decode_nms_launch(d_head, d_anchors, d_ws_tk_vals, d_ws_tk_idx, d_ws_tk_cnt, d_image_hw, N, HWA, A, CH, pre_nms, post_nms,
                                  nms_thr, min_size, nms_ge, 0, 1, post_nms, d_out_boxes, d_out_scores, d_out_cnt, d_ws_nms, st);
+}
+
+// All FPN levels of the RPN selection in one call (five launches): see rpn_levels_select_launch.  d_heads / d_anchors: HOST arrays of nl device pointers.
+extern "C" int isegmi_op_rpn_levels(int nl, const float* const* d_heads, const float* const* d_anchors, const int32_t* HW, const int32_t* d_image_hw, int N, int A,
+                                    int pre_nms, int post_nms, float nms_thr, float min_size, int nms_ge, float* d_ws_prob, float* d_ws_cand_vals,
+                                    int32_t* d_ws_cand_idx, float* d_ws_tk_vals, int32_t* d_ws_tk_idx, int32_t* d_ws_tk_cnt, void* d_ws_nms,
+                                    float* d_out_boxes, float* d_out_scores, int32_t* d_out_cnt, void* stream) {
+    ARG_CHECK(nl >= 1 && nl <= RPN_MAX_LEVELS && d_heads && d_anchors && HW && d_image_hw, "rpn levels: null / 1-5 levels");
+    int HWA[RPN_MAX_LEVELS], slot[RPN_MAX_LEVELS];
+    for (int l = 0; l < nl; ++l) { HWA[l] = HW[l] * A; slot[l] = l; }
+    return rpn_levels_select_launch(nl, d_heads, d_anchors, HWA, slot, d_image_hw, N, A, A * 5, pre_nms, post_nms, nms_thr, min_size, nms_ge, nl, post_nms,
+                                    d_ws_prob, d_ws_cand_vals, d_ws_cand_idx, d_ws_tk_vals, d_ws_tk_idx, d_ws_tk_cnt, d_ws_nms, d_out_boxes, d_out_scores,
+                                    d_out_cnt, (hipStream_t)stream);
+}
+extern "C" int isegmi_op_rpn_levels_workspace(int nl, int N, const int32_t* HW, int A, int pre_nms, int64_t* prob_elems, int64_t* cand_elems) {
+    ARG_CHECK(nl >= 1 && nl <= RPN_MAX_LEVELS && HW, "rpn levels");
+    int HWA[RPN_MAX_LEVELS];
+    for (int l = 0; l < nl; ++l) HWA[l] = HW[l] * A;
+    return rpn_levels_workspace(nl, N, HWA, pre_nms, prob_elems, cand_elems);
 }

@@ -14,6 +14,7 @@
 //   C. bitonic sort of <= KCAP 64-bit keys (ordered score << 32 | ~index) in LDS.
 #include "../../include/isegmi.h"
 #include "common.h"
+#include "rpn_levels.h"
 #include <mutex>
 #include <unordered_map>
 
@@ -44,6 +45,16 @@ struct TopkArgs {
     // the smallest key, never selected); level 2 selects over a row's slices * k candidates and reports remap[row][position]
     int slices, slice_len;
     const int* remap;
+    int klim;               // > 0: k_eff = min(k, n, klim) -- a host-side bound (level 2 of a row whose level-1 slices hold fewer than k real keys)
+};
+
+// several uniform top-k problems in ONE launch (the RPN's per-level rows, csrc/rcnn_ops.hip rpn_levels_select_launch): group g owns blocks
+// [blk0[g], blk0[g + 1]) and runs them exactly as its own launch of `g[g]` would
+constexpr int TOPK_MAX_GROUPS = 5;
+struct TopkGroups {
+    int ng;
+    int blk0[TOPK_MAX_GROUPS + 1];
+    TopkArgs g[TOPK_MAX_GROUPS];
 };
 
 // SEG: the logical row is the concatenation of the first seg_take keys of every seg_len-long segment (element e lives at
@@ -51,7 +62,7 @@ struct TopkArgs {
 // monotonic the (score desc, index asc) order is the full row's.  For rows made of per-class lists that are already sorted
 // (the final top-100 over 80 x 1000 per-class NMS outputs: nothing past a class's first 100 entries can make the top 100).
 template <int NT, int KCAP, bool SEG = false>
-__global__ __launch_bounds__(NT) void topk_kernel(const TopkArgs a) {
+__device__ __forceinline__ void topk_block(const TopkArgs& a, const int bx) {   // bx: the block's index inside its launch / group
     constexpr int NW = NT / 64;
     constexpr int BINS = 4096;
     constexpr int UNR = 16;
@@ -61,14 +72,15 @@ __global__ __launch_bounds__(NT) void topk_kernel(const TopkArgs a) {
     __shared__ unsigned w_gt[NW], w_eq[NW];
     __shared__ unsigned sel_digit, sel_kk;
 
-    const int row = a.slices > 0 ? (int)blockIdx.x / a.slices : (int)blockIdx.x;
-    const int orow = blockIdx.x;                                   // output row
-    const int slice_off = a.slices > 0 ? ((int)blockIdx.x - row * a.slices) * a.slice_len : 0;
+    const int row = a.slices > 0 ? bx / a.slices : bx;
+    const int orow = bx;                                           // output row
+    const int slice_off = a.slices > 0 ? (bx - row * a.slices) * a.slice_len : 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* keys = a.keys + (int64_t)row * a.row_stride + slice_off;
     const int n = a.slices > 0 ? (a.n - slice_off < a.slice_len ? a.n - slice_off : a.slice_len) : a.n;
     auto phys = [&](int e) { return SEG ? (e / a.seg_take) * a.seg_len + (e % a.seg_take) : e; };
     int k_eff = a.k < n ? a.k : n;
+    if (a.klim > 0 && a.klim < k_eff) k_eff = a.klim;
     if (a.limit) {
         const int l = a.limit[row / a.rows_per_limit];
         k_eff = k_eff < l ? k_eff : l;
@@ -213,6 +225,16 @@ __global__ __launch_bounds__(NT) void topk_kernel(const TopkArgs a) {
     if (tid == 0 && a.out_cnt) a.out_cnt[orow] = k_eff;
 }
 
+template <int NT, int KCAP, bool SEG = false>
+__global__ __launch_bounds__(NT) void topk_kernel(const TopkArgs a) { topk_block<NT, KCAP, SEG>(a, (int)blockIdx.x); }
+
+template <int NT, int KCAP>
+__global__ __launch_bounds__(NT) void topk_groups_kernel(const TopkGroups t) {
+    int g = 0;
+    while (g + 1 < t.ng && (int)blockIdx.x >= t.blk0[g + 1]) ++g;   // uniform
+    topk_block<NT, KCAP, false>(t.g[g], (int)blockIdx.x - t.blk0[g]);
+}
+
 // Candidate buffers of the two-level top-k for callers that bring none (the op-level C ABI): one grow-only pair per stream (calls on
 // one stream are ordered).  The engines pass their own named buffers instead (topk_launch_ws), so nothing captured into a hipGraph
 // or shared between engines ever points into this pool.
@@ -246,7 +268,7 @@ int topk_launch_ws(const float* keys, int64_t row_stride, int rows, int n, int k
                    float* out_vals, int* out_idx, int* out_cnt, float* ws_vals, int* ws_idx, hipStream_t st) {
     ARG_CHECK(rows >= 0 && n >= 0 && k > 0 && k <= 8192, "topk sizes (k <= 8192)");
     if (rows == 0) return ISEGMI_OK;
-    TopkArgs a{keys, row_stride, n, k, limit, rows_per_limit > 0 ? rows_per_limit : 1, out_vals, out_idx, out_cnt, 0, 0, 0, 0, nullptr};
+    TopkArgs a{keys, row_stride, n, k, limit, rows_per_limit > 0 ? rows_per_limit : 1, out_vals, out_idx, out_cnt, 0, 0, 0, 0, nullptr, 0};
     // A few very long rows (RPN pre-NMS top-k: one row of up to 201 600 anchors per image and level): a row's five latency-bound passes in
     // ONE block took 56-108 us with the rest of the chip idle.  Two levels instead: every (row, slice of ~12 K keys) block keeps its k best
     // (select + ordered compaction, no sort), then the row's slices * k candidates go through the full kernel.  Exact: a global top-k key is
@@ -258,7 +280,7 @@ int topk_launch_ws(const float* keys, int64_t row_stride, int rows, int n, int k
         TopkArgs l1 = a;
         l1.slices = slices; l1.slice_len = slice_len; l1.out_vals = cv; l1.out_idx = ci; l1.out_cnt = nullptr;
         hipLaunchKernelGGL((topk_kernel<1024, 1024>), dim3(rows * slices), dim3(1024), 0, st, l1);
-        TopkArgs l2{cv, (int64_t)slices * k, slices * k, k, nullptr, 1, out_vals, out_idx, out_cnt, 0, 0, 0, 0, ci};
+        TopkArgs l2{cv, (int64_t)slices * k, slices * k, k, nullptr, 1, out_vals, out_idx, out_cnt, 0, 0, 0, 0, ci, 0};
         hipLaunchKernelGGL((topk_kernel<1024, 1024>), dim3(rows), dim3(1024), 0, st, l2);
         HIP_TRY(hipGetLastError());
         return ISEGMI_OK;
@@ -282,6 +304,43 @@ int topk_launch_ws(const float* keys, int64_t row_stride, int rows, int n, int k
     return ISEGMI_OK;
 }
 
+// The RPN's pre-NMS top-k of `nl` levels x N images in TWO launches (level x image as one batch dimension): level l's rows hold n[l] keys at
+// keys + key_off[l] (row stride n[l]); every row is cut into slices[l] slices of ~12 K keys (rpn_topk_plan), launch 1 keeps each slice's k best in index
+// order (cand_* + cand_off[l]: [N][slices[l]][k]), launch 2 selects and sorts a row's candidates into out_* [l][N][k], out_cnt [l][N] = min(k, n[l]).
+// Exact for the reasons given at topk_launch_ws -- a one-slice level simply sorts in launch 2 -- so indices equal the per-level launches'.
+int rpn_topk_plan(int nl, int N, const int* n, int k, int* slices, int64_t* cand_off) {
+    int64_t off = 0;
+    for (int l = 0; l < nl; ++l) {
+        int s = (n[l] + 12287) / 12288;
+        s = s < 1 ? 1 : (s > 32 ? 32 : s);
+        slices[l] = s;
+        cand_off[l] = off;
+        off += (int64_t)N * s * k;
+    }
+    cand_off[nl] = off;
+    return ISEGMI_OK;
+}
+int rpn_topk_levels_launch(int nl, int N, const float* keys, const int64_t* key_off, const int* n, int k, const int* slices, const int64_t* cand_off,
+                           float* cand_vals, int* cand_idx, float* out_vals, int* out_idx, int* out_cnt, hipStream_t st) {
+    ARG_CHECK(nl >= 1 && nl <= TOPK_MAX_GROUPS && N >= 1 && k > 256 && k <= 1024, "batched RPN top-k: 1-5 levels, 256 < k <= 1024");
+    TopkGroups l1, l2;
+    l1.ng = l2.ng = nl;
+    l1.blk0[0] = l2.blk0[0] = 0;
+    for (int l = 0; l < nl; ++l) {
+        ARG_CHECK(n[l] > 0 && slices[l] >= 1 && slices[l] <= 32, "batched RPN top-k: level size / slices");
+        const int slice_len = (n[l] + slices[l] - 1) / slices[l];
+        l1.g[l] = TopkArgs{keys + key_off[l], (int64_t)n[l], n[l], k, nullptr, 1, cand_vals + cand_off[l], cand_idx + cand_off[l], nullptr, 0, 0, slices[l], slice_len, nullptr, 0};
+        l1.blk0[l + 1] = l1.blk0[l] + N * slices[l];
+        l2.g[l] = TopkArgs{cand_vals + cand_off[l], (int64_t)slices[l] * k, slices[l] * k, k, nullptr, 1, out_vals + (int64_t)l * N * k, out_idx + (int64_t)l * N * k,
+                           out_cnt + (int64_t)l * N, 0, 0, 0, 0, cand_idx + cand_off[l], k < n[l] ? k : n[l]};
+        l2.blk0[l + 1] = l2.blk0[l] + N;
+    }
+    hipLaunchKernelGGL((topk_groups_kernel<1024, 1024>), dim3(l1.blk0[nl]), dim3(1024), 0, st, l1);
+    hipLaunchKernelGGL((topk_groups_kernel<1024, 1024>), dim3(l2.blk0[nl]), dim3(1024), 0, st, l2);
+    HIP_TRY(hipGetLastError());
+    return ISEGMI_OK;
+}
+
 int topk_launch(const float* keys, int64_t row_stride, int rows, int n, int k, const int* limit, int rows_per_limit,
                 float* out_vals, int* out_idx, int* out_cnt, hipStream_t st) {
     return topk_launch_ws(keys, row_stride, rows, n, k, limit, rows_per_limit, out_vals, out_idx, out_cnt, nullptr, nullptr, st);
@@ -292,7 +351,7 @@ int topk_segmented_launch(const float* keys, int64_t row_stride, int rows, int n
                           int rows_per_limit, float* out_vals, int* out_idx, int* out_cnt, hipStream_t st) {
     ARG_CHECK(rows >= 0 && nseg > 0 && seg_len > 0 && seg_take > 0 && seg_take <= seg_len && k > 0 && k <= 128, "segmented topk sizes (k <= 128)");
     if (rows == 0) return ISEGMI_OK;
-    TopkArgs a{keys, row_stride, nseg * seg_take, k, limit, rows_per_limit > 0 ? rows_per_limit : 1, out_vals, out_idx, out_cnt, seg_len, seg_take, 0, 0, nullptr};
+    TopkArgs a{keys, row_stride, nseg * seg_take, k, limit, rows_per_limit > 0 ? rows_per_limit : 1, out_vals, out_idx, out_cnt, seg_len, seg_take, 0, 0, nullptr, 0};
     hipLaunchKernelGGL((topk_kernel<1024, 128, true>), dim3(rows), dim3(1024), 0, st, a);
     HIP_TRY(hipGetLastError());
     return ISEGMI_OK;

@@ -58,6 +58,18 @@ def sync():
     check(lib().isegmi_sync())
 
 
+def set_f16_mfma_shape(shape):
+    """0: v_mfma_f32_32x32x16_f16 everywhere; 1 (default): row strips + fused RPN head on v_mfma_f32_16x16x32_f16; 2: persistent tiles too
+    (process-wide; isegmi_set_f16_mfma_shape).  Results are bit-identical under every setting."""
+    check(lib().isegmi_set_f16_mfma_shape(int(shape)))
+
+
+def get_f16_mfma_shape():
+    v = C.c_int()
+    check(lib().isegmi_get_f16_mfma_shape(C.byref(v)))
+    return v.value
+
+
 def box_calibrate(ms_per_leg=30.0):
     """{mfma_f32_tflops, mfma_f16_tflops, hbm_copy_gbs} of bare loops on the current device (isegmi_box_calibrate)."""
     a, b, c = C.c_double(), C.c_double(), C.c_double()
@@ -417,6 +429,27 @@ def rpn_level(head, anchors, image_hw, A, pre_nms, post_nms, nms_thr=0.7, min_si
                                     wp.ptr, tv.ptr, ti.ptr, tc.ptr, ob.ptr, os_.ptr, oc.ptr, wn.ptr if wn is not None else None, None))
     c = oc.numpy(); B = ob.numpy(); S = os_.numpy()
     return [(B[i, : c[i]], S[i, : c[i]]) for i in range(N)]
+
+
+def rpn_levels(heads, anchors, image_hw, A, pre_nms, post_nms, nms_thr=0.7, min_size=0.0, nms_ge=0):
+    """All FPN levels at once (isegmi_op_rpn_levels): heads[l] [N,H_l,W_l,A*5], anchors[l] [H_l*W_l*A,4] -> per level a list over images of (boxes, scores)."""
+    nl = len(heads)
+    hs = [np.ascontiguousarray(h, np.float32) for h in heads]
+    N = hs[0].shape[0]
+    HW = (C.c_int32 * nl)(*[h.shape[1] * h.shape[2] for h in hs])
+    dh = [DeviceBuffer.from_numpy(h) for h in hs]; da = [DeviceBuffer.from_numpy(np.ascontiguousarray(a, np.float32)) for a in anchors]
+    ph = (C.c_void_p * nl)(*[b.ptr.value for b in dh]); pa = (C.c_void_p * nl)(*[b.ptr.value for b in da])
+    dhw = DeviceBuffer.from_numpy(np.ascontiguousarray(image_hw, np.int32))
+    pe, ce = C.c_int64(), C.c_int64()
+    check(lib().isegmi_op_rpn_levels_workspace(nl, N, HW, A, pre_nms, C.byref(pe), C.byref(ce)))
+    wp = DeviceBuffer((pe.value,)); cv = DeviceBuffer((ce.value,)); ci = DeviceBuffer((ce.value,), np.int32)
+    tv = DeviceBuffer((nl, N, pre_nms)); ti = DeviceBuffer((nl, N, pre_nms), np.int32); tc = DeviceBuffer((nl, N), np.int32)
+    wn = DeviceBuffer((nl * N, 131072), np.uint8)
+    ob = DeviceBuffer((N, nl, post_nms, 4)); os_ = DeviceBuffer((N, nl, post_nms)); oc = DeviceBuffer((N, nl), np.int32)
+    check(lib().isegmi_op_rpn_levels(nl, ph, pa, HW, dhw.ptr, N, A, pre_nms, post_nms, C.c_float(nms_thr), C.c_float(min_size), nms_ge, wp.ptr, cv.ptr, ci.ptr,
+                                     tv.ptr, ti.ptr, tc.ptr, wn.ptr, ob.ptr, os_.ptr, oc.ptr, None))
+    c = oc.numpy(); B = ob.numpy(); S = os_.numpy()
+    return [[(B[i, l, : c[i, l]], S[i, l, : c[i, l]]) for i in range(N)] for l in range(nl)]
 
 
 # ---------------------------------------------------------------- fp16 conv (configs[4])

@@ -144,6 +144,53 @@ def test_rpn_level_matches_oracle(ffi, chip_wide):
             assert len(rs) > 10
 
 
+@pytest.mark.parametrize("N", [1, 2, 3])
+def test_rpn_levels_batched_matches_oracle_and_per_level(ffi, N):
+    """the RPN selection with (level, image) as ONE batch dimension (isegmi_op_rpn_levels: five launches for all levels) against the oracle's
+    per-level selection and against the per-level op, level by level -- ties in the top-k, a level with fewer anchors than pre_nms (P6: 6 x 8 x 3 = 144),
+    levels above and below the 12 288-key slice of the two-level top-k, min-size removals and the post_nms cut included."""
+    from isegmi.maskrcnn import generate_anchors, grid_anchors
+    rng = np.random.default_rng(50 + N)
+    A = 3
+    shapes = [(88, 120, 4, 32), (44, 60, 8, 64), (22, 30, 16, 128), (11, 15, 32, 256), (6, 8, 64, 512)]   # (H, W, stride, anchor size): 31 680 ... 144 anchors
+    heads, anchors = [], []
+    for li, (H, W, stride, size) in enumerate(shapes):
+        h = np.concatenate([rng.normal(-2, 2, (N, H, W, A)), rng.normal(0, 0.3, (N, H, W, 4 * A))], -1).astype(np.float32)
+        h[0, :3, :3, :A] = 1.25                       # ties in the top-k
+        if li == 1:
+            h[N - 1, 10:30, 10:50, A:] *= 0.02        # near-identical boxes: long suppression chains
+        heads.append(h); anchors.append(grid_anchors(H, W, stride, generate_anchors(stride, size, (0.5, 1.0, 2.0))))
+    hw = np.array([[340 + 7 * n, 470 - 5 * n] for n in range(N)], np.int32)
+    for pre, post, min_size in ((1000, 1000, 0.0), (300, 50, 0.0), (1024, 1000, 24.0), (1000, 37, 0.0)):
+        got = ffi.rpn_levels(heads, anchors, hw, A, pre, post, min_size=min_size)
+        for l in range(len(shapes)):
+            one = ffi.rpn_level(heads[l], anchors[l], hw, A, pre, post, min_size=min_size)
+            for n in range(N):
+                rb, rs = ora.rpn_level(heads[l][n, ..., :A].reshape(-1), heads[l][n, ..., A:].reshape(-1, 4), anchors[l], pre, post, 0.7, min_size,
+                                       float(hw[n, 1]), float(hw[n, 0]))
+                assert np.array_equal(got[l][n][1], rs) and np.array_equal(got[l][n][0], rb), (pre, post, min_size, l, n)
+                assert np.array_equal(got[l][n][1], one[n][1]) and np.array_equal(got[l][n][0], one[n][0])
+            assert sum(len(got[l][n][1]) for n in range(N)) > 5
+
+
+def test_rpn_levels_batched_at_the_bench_size(ffi):
+    """the five levels of the 800 x 1344 canvas (201 600 ... 819 anchors per image: P2 is cut into 17 slices, P6 holds fewer keys than pre_nms), two images;
+    checked against the per-level op (itself checked against the oracle above and, end to end, by the full-size Mask R-CNN test)"""
+    from isegmi.maskrcnn import generate_anchors, grid_anchors
+    rng = np.random.default_rng(77)
+    A, N = 3, 2
+    shapes = [(200, 336, 4, 32), (100, 168, 8, 64), (50, 84, 16, 128), (25, 42, 32, 256), (13, 21, 64, 512)]
+    heads = [np.concatenate([rng.normal(-2, 2, (N, H, W, A)), rng.normal(0, 0.3, (N, H, W, 4 * A))], -1).astype(np.float32) for H, W, _, _ in shapes]
+    anchors = [grid_anchors(H, W, s, generate_anchors(s, z, (0.5, 1.0, 2.0))) for H, W, s, z in shapes]
+    hw = np.array([[800, 1333], [768, 1344]], np.int32)
+    got = ffi.rpn_levels(heads, anchors, hw, A, 1000, 1000)
+    for l in range(5):
+        one = ffi.rpn_level(heads[l], anchors[l], hw, A, 1000, 1000)
+        for n in range(N):
+            assert np.array_equal(got[l][n][1], one[n][1]) and np.array_equal(got[l][n][0], one[n][0]), (l, n)
+            assert len(one[n][1]) > 100
+
+
 def test_rpn_single_map_6000_matches_oracle(ffi):
     """R-50-C4 style RPN: one stride-16 map, 15 anchors per location (5 sizes x 3 ratios), PRE_NMS_TOP_N_TEST 6000 ->
     NMS 0.7 -> 1000 (README.md:267-269).  Exercises the k <= 8192 top-k and the 6144-box NMS kernels."""

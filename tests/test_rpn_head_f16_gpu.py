@@ -39,3 +39,24 @@ def test_small_levels_are_not_fused(ffi):
     x, w, sc, sh, w2, sc2, sh2 = _case(rng, 1, 13, 21)
     got, fused = ffi.conv3x3_head_f16(x, w, sc, sh, w2, sc2, sh2)
     assert not fused and got is None
+
+
+@pytest.mark.parametrize("shape", [(2, 100, 168), (1, 131, 197)])
+def test_fused_head_close_to_oracle(ffi, shape):
+    """The fused RPN head against the ORACLE: t = fp16(relu(ora.conv2d 3x3 on the fp16 operands)), logits / deltas = ora.conv2d 1x1 on t in fp32.
+    TOLERANCE (stated): t may differ from the ordered chain by one fp16 ulp per element (the f16 MFMA's own association of 16 products:
+    tests/test_conv_f16_gpu.py); the 1x1 sums 256 products t * w2: an ulp flip of t[k] moves an output by 2^-10 |t[k] w2[k]|, so
+    |got - ref| <= 2^-10 * sum_k |t[k] w2[k]| (every t flipped the same way: the worst case) + 2e-5 * max(1, |ref|max) for the fp32
+    association of the 1x1 itself."""
+    from oracle import ora
+    N, H, W = shape
+    rng = np.random.default_rng(H * 31 + W)
+    x, w, sc, sh, w2, sc2, sh2 = _case(rng, N, H, W, 256, 15)
+    got, fused = ffi.conv3x3_head_f16(x, w, sc, sh, w2, sc2, sh2)
+    assert fused
+    t = ora.conv2d(x.astype(np.float32), w, 1, 1, sc, sh, None, 1).astype(np.float16).astype(np.float32)
+    ref = ora.conv2d(t, w2, 1, 0, sc2, sh2, None, 0)
+    bound = ora.conv2d(t, np.abs(w2), 1, 0, None, None, None, 0) * 2.0 ** -10 + 2e-5 * max(1.0, float(np.abs(ref).max()))
+    d = np.abs(got - ref)
+    assert got.shape == ref.shape and np.all(d <= bound), float((d - bound).max())
+    assert np.mean(d <= 2e-5 * max(1.0, float(np.abs(ref).max()))) >= 0.9   # and most outputs see no flipped t at all

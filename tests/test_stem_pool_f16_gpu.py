@@ -55,3 +55,23 @@ def test_fused_stem_at_the_bench_size(ffi):
     got = ffi.stem_pool_f16(x, w, sc, sh, 0)
     assert got.shape == (2, 200, 336, 64)
     assert np.array_equal(got.view(np.uint16), _pool(conv).view(np.uint16))
+
+
+@pytest.mark.parametrize("shape", [(2, 50, 70), (1, 123, 251), (1, 64, 33)])
+def test_fused_stem_close_to_oracle(ffi, shape):
+    """The fused launch against the ORACLE (not another HIP launch): ora.conv2d on the fp16-rounded image (fourth channel zero) with fp32
+    accumulation, rounded to fp16 where the engine stores fp16, then ora.maxpool 3x3/2/1 (exact on fp16 values).  TOLERANCE (stated, as
+    tests/test_conv_f16_gpu.py): the f16 MFMA sums 16 products per instruction in its own order, so a conv output may differ from the ordered
+    chain by one fp16 ulp (2^-10 relative) + 1e-3 absolute; a max over nine such values inherits the bound; >= 99 % exactly equal."""
+    from oracle import ora
+    N, H, W = shape
+    rng = np.random.default_rng(H * 77 + W)
+    x, w, sc, sh = _case(rng, N, H, W)
+    got = ffi.stem_pool_f16(x, w, sc, sh, 0)
+    x4 = np.concatenate([x.astype(np.float16).astype(np.float32), np.zeros((N, H, W, 1), np.float32)], -1)
+    conv16 = ora.conv2d(x4, w, 2, 3, sc, sh, None, 1).astype(np.float16)
+    ref = ora.maxpool(conv16.astype(np.float32), 3, 2, 1).astype(np.float16)
+    assert got.shape == ref.shape
+    d = np.abs(got.astype(np.float32) - ref.astype(np.float32))
+    assert np.all(d <= np.abs(ref.astype(np.float32)) * 2.0 ** -10 + 1e-3), float(d.max())
+    assert np.mean(got == ref) >= 0.99
