@@ -74,6 +74,7 @@ def parse():
     ap.add_argument("--no-r101f16", action="store_true", help="default yolact run: skip the extra Mask R-CNN R101-FPN fp16 bs=8 measurement (configs[4] per-GPU shape)")
     ap.add_argument("--no-box", action="store_true", help="skip the ~0.1 s box calibration (bare MFMA / copy loops)")
     ap.add_argument("--allow-stale-traffic", action="store_true", help="roofline.traffic may come from an older round's committed PMC summary")
+    ap.add_argument("--f16-mfma-shape", type=int, default=-1, choices=[-1, 0, 1, 2], help="A/B: isegmi_set_f16_mfma_shape (0: 32x32x16 everywhere, 1: row strips on 16x16x32 (library default), 2: persistent tiles too)")
     ap.add_argument("--no-h2d", action="store_true", help="skip the extra timed loops (batch resident in HBM; fp32 upload)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end loop (uint8 upload -> ... -> RLE -> record block on the host)")
     ap.add_argument("--param", action="append", default=[], metavar="NAME=VALUE", help="engine parameter for A/B runs (isegmi_engine_set_param), repeatable")
@@ -364,7 +365,7 @@ def box_calibration():
     b = _ffi.box_calibrate(30.0)
     b["note"] = ("~30 ms each: dependent v_mfma_f32_32x32x2_f32 / v_mfma_f32_32x32x16_f16 chains on random register operands, four waves per SIMD, no memory traffic "
                  "(nominal 157.3 / 2516 TF/s at 2.4 GHz: the quotient is the clock the box holds); float4 copy of 1 GiB, read + written bytes "
-                 "(~6.3 TB/s is what a copy reaches on this chip)")
+                 "(a figure to compare boxes with: 4.7-4.9 TB/s on the boxes seen so far; a tuned copy reaches ~6.3 on this chip)")
     return b
 
 
@@ -820,6 +821,8 @@ def main():
     from isegmi import _ffi
     if _ffi.device_count() < 1:
         raise SystemExit("no HIP device visible: bench.py measures the HIP path only (no CPU fallback)")
+    if a.f16_mfma_shape >= 0:
+        _ffi.set_f16_mfma_shape(a.f16_mfma_shape)
     box = None
     if not a.no_box and dist.rank == 0:
         _ffi.set_device(dist.local_rank)

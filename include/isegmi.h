@@ -81,6 +81,11 @@ int isegmi_pack_conv_weights(const isegmi_conv_desc* d, const float* h_w_krsc, f
 int isegmi_op_conv2d(const isegmi_conv_desc* d, const float* d_in, const float* d_wpacked,
                      const float* d_scale, const float* d_shift, const float* d_residual,
                      float* d_out, void* stream);
+/* n <= 10 independent fp32 convolutions (no stem, tile 0) as ONE launch: the shared-weight heads of all FPN levels, the FPN's lateral / output convs.
+ * Member i = descs[i] with d_in[i], d_w[i] (packed), d_scale[i] / d_shift[i] / d_res[i] (each array, or an entry, may be NULL), d_out[i]; every member's
+ * result is bit-identical to its own isegmi_op_conv2d call (one k-ordered chain per output either way).  The pointer arrays are HOST arrays. */
+int isegmi_op_conv2d_group(int n, const isegmi_conv_desc* descs, const float* const* d_in, const float* const* d_w, const float* const* d_scale,
+                           const float* const* d_shift, const float* const* d_res, float* const* d_out, void* stream);
 
 /* fp16 variant (BASELINE configs[4]: "fp16 MFMA conv"): fp16 storage, v_mfma_f32_32x32x16_f16, fp32 accumulate
  * and epilogue.  Cin % 64 == 0 (or the stem, below); act none/relu; d_in / d_wpacked / d_residual are fp16, d_out fp16 or (out_f32)

@@ -44,7 +44,8 @@ __global__ __launch_bounds__(256) void calib_mfma_kernel(float* __restrict__ out
     out[blockIdx.x * 256 + threadIdx.x] = acc[0] + acc[15];
 }
 
-// four independent 16-byte loads in flight per lane before the first store (a one-load-per-iteration loop reads ~4.9 TB/s on this chip, this form ~6)
+// four independent 16-byte loads in flight per lane before the first store; 4.7-4.9 TB/s of read + written bytes on the boxes measured so far (a
+// figure to compare boxes with, not the chip's ceiling: MI355X_MICROARCH.md quotes 6.3 TB/s for a tuned copy)
 __global__ __launch_bounds__(256) void calib_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n4) {
     const int64_t stride = (int64_t)gridDim.x * 256;
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;

@@ -861,6 +861,30 @@ __global__ __launch_bounds__(256, 4) void conv_hybrid_kernel(const ConvK pm, con
     else conv_mfma16_body<4, false, 1>(pt, smem, (int)blockIdx.x - nmain, (int)gridDim.x - nmain);
 }
 
+// GROUPED launch (round 5): up to CONV_GROUP_MAX independent convolutions in ONE launch -- the shared-weight heads of all FPN levels (Yolact upfeature /
+// head_cat over P3..P7, Mask R-CNN's RPN head over P2..P6), the FPN's lateral and output convs.  Part i owns blocks [blk0[i], blk0[i + 1]) and runs them
+// exactly as its own launch would (kind 0: 64 x 64 v2 tiles, kind 1: 32 x 32 blocks; the tile -> XCD walk is by the block's index inside its part), so
+// every output keeps its single k-ordered chain: bit-identical to separate launches.  What it buys: the small levels (P5..P7: 16-164 tiles of 64 x 64 at
+// bs 8, 10-41 TF/s and ~23 us each as launches of their own) run inside the big level's launch on CUs that would idle in its last round, and a forward
+// is 12-14 launches shorter.  Big parts first: the launch ends on short blocks.
+constexpr int CONV_GROUP_MAX = 10;
+struct ConvGroupK {
+    int n;
+    int blk0[CONV_GROUP_MAX + 1];
+    int kind[CONV_GROUP_MAX];
+    ConvK k[CONV_GROUP_MAX];
+};
+static_assert(sizeof(ConvGroupK) <= 4096, "kernel arguments");
+template <int RING>
+__global__ __launch_bounds__(256, 4) void conv_group_kernel(const ConvGroupK g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int i = 0;
+    while (i + 1 < g.n && (int)blockIdx.x >= g.blk0[i + 1]) ++i;   // uniform
+    const int bid = (int)blockIdx.x - g.blk0[i], nwg = g.blk0[i + 1] - g.blk0[i];
+    if (g.kind[i] == 0) conv_v2_body<RING, false>(g.k[i], smem, bid, nwg);
+    else conv_mfma16_body<4, false, 1>(g.k[i], smem, bid, nwg);
+}
+
 static inline int perm8(int e) { return 4 * (e & 1) + (e >> 1); }
 static bool is_stem(const isegmi_conv_desc* d) { return d->Cin == 4 && d->R == 7 && d->S == 7; }
 static int cout_pad(const isegmi_conv_desc* d) { return cdiv(d->Cout, 128) * 128; }
@@ -941,11 +965,11 @@ int device_cu_count() {
     return cached[dev];
 }
 
-int conv2d_launch(const isegmi_conv_desc* d, const float* in, const float* w, const float* scale, const float* shift,
-                  const float* res, float* out, hipStream_t st) {
+// desc + operands -> the kernel argument block (everything but the tile grid: mtiles / ntiles / nband / m_begin belong to the launch form)
+static int conv_fill(const isegmi_conv_desc* d, const float* in, const float* w, const float* scale, const float* shift, const float* res, float* out,
+                     ConvK& k) {
     int rc = check_desc(d);
     if (rc) return rc;
-    ConvK k;
     k.in = in; k.w = w; k.scale = scale; k.shift = shift; k.res = res; k.out = out;
     k.N = d->N; k.H = d->H; k.W = d->W; k.Cin = d->Cin; k.Cout = d->Cout; k.R = d->R; k.S = d->S;
     k.stride = d->stride; k.pad = d->pad;
@@ -983,6 +1007,15 @@ int conv2d_launch(const isegmi_conv_desc* d, const float* in, const float* w, co
     k.out_bytes = (unsigned)out_extent;
     k.res_bytes = (unsigned)((int64_t)k.M * d->Cout * 4);
     ARG_CHECK(res == nullptr || (int64_t)k.M * d->Cout * 4 < (1ll << 31), "residual must be < 2 GiB");
+    k.mtiles = 0; k.ntiles = 0; k.nband = 0;
+    return ISEGMI_OK;
+}
+
+int conv2d_launch(const isegmi_conv_desc* d, const float* in, const float* w, const float* scale, const float* shift,
+                  const float* res, float* out, hipStream_t st) {
+    ConvK k;
+    const int rc_fill = conv_fill(d, in, w, scale, shift, res, out, k);
+    if (rc_fill) return rc_fill;
     int tile = d->tile;
     if (tile == 0) {
         // Tile rule, refitted in round 2 on per-layer sweeps of both models at bs 1 / 2 / 8 with every kernel forced in turn
@@ -1076,9 +1109,69 @@ int conv2d_launch(const isegmi_conv_desc* d, const float* in, const float* w, co
     }
 }
 
+// n independent fp32 convolutions as one launch (see conv_group_kernel).  Parts: a conv of at least 256 tiles of 64 x 64 and more than 32 output channels
+// runs on v2 tiles when the group as a whole fills the chip twice over (> 480 such tiles), everything else on 32 x 32 blocks.
+int conv2d_group_launch(int n, const isegmi_conv_desc* const* d, const float* const* in, const float* const* w, const float* const* scale,
+                        const float* const* shift, const float* const* res, float* const* out, hipStream_t st) {
+    ARG_CHECK(n >= 1 && n <= CONV_GROUP_MAX && d && in && w && out, "conv group: 1..10 members");
+    ConvGroupK g;
+    ConvK ks[CONV_GROUP_MAX];
+    int64_t t64[CONV_GROUP_MAX], total64 = 0;
+    for (int i = 0; i < n; ++i) {
+        ARG_CHECK(d[i] && !is_stem(d[i]) && d[i]->tile == 0, "conv group: no stem, no forced tile");
+        const int rc = conv_fill(d[i], in[i], w[i], scale ? scale[i] : nullptr, shift ? shift[i] : nullptr, res ? res[i] : nullptr, out[i], ks[i]);
+        if (rc) return rc;
+        t64[i] = (int64_t)cdiv(ks[i].M, 64) * cdiv(d[i]->Cout, 64);
+        total64 += t64[i];
+    }
+    int order[CONV_GROUP_MAX], kind[CONV_GROUP_MAX];
+    int ring = 2;
+    for (int i = 0; i < n; ++i) {
+        order[i] = i;
+        kind[i] = (total64 > 480 && t64[i] >= 256 && d[i]->Cout > 32) ? 0 : 1;
+        if (kind[i] == 0 && ks[i].nchunks >= 72) ring = 4;
+    }
+    // v2 parts first, each kind by falling size (insertion sort: n <= 10)
+    for (int a = 1; a < n; ++a)
+        for (int b = a; b > 0; --b) {
+            const int x = order[b - 1], y = order[b];
+            const bool swap = kind[y] < kind[x] || (kind[y] == kind[x] && t64[y] > t64[x]);
+            if (!swap) break;
+            order[b - 1] = y; order[b] = x;
+        }
+    g.n = n;
+    g.blk0[0] = 0;
+    for (int j = 0; j < n; ++j) {
+        const int i = order[j];
+        ConvK& k = ks[i];
+        const int bt = kind[i] == 0 ? 64 : 32;
+        k.mtiles = cdiv(k.M, bt);
+        k.ntiles = cdiv(d[i]->Cout, bt);
+        conv_set_band(k, bt, kind[i] == 0 ? 4 : 8, k.in_touched);
+        const int64_t blocks = (int64_t)k.mtiles * k.ntiles;
+        ARG_CHECK(g.blk0[j] + blocks < (1ll << 30), "conv group: too many tiles");
+        g.k[j] = k;
+        g.kind[j] = kind[i];
+        g.blk0[j + 1] = g.blk0[j] + (int)blocks;
+    }
+    const size_t lds = 2 * (size_t)(64 + 64) * LDS_ROW * sizeof(float);
+    if (ring == 4) hipLaunchKernelGGL((conv_group_kernel<4>), dim3((unsigned)g.blk0[n]), dim3(256), lds, st, g);
+    else hipLaunchKernelGGL((conv_group_kernel<2>), dim3((unsigned)g.blk0[n]), dim3(256), lds, st, g);
+    HIP_TRY(hipGetLastError());
+    return ISEGMI_OK;
+}
+
 }  // namespace isegmi
 
 using namespace isegmi;
+
+extern "C" int isegmi_op_conv2d_group(int n, const isegmi_conv_desc* descs, const float* const* d_in, const float* const* d_w, const float* const* d_scale,
+                                      const float* const* d_shift, const float* const* d_res, float* const* d_out, void* stream) {
+    ARG_CHECK(n >= 1 && n <= CONV_GROUP_MAX && descs, "conv group: 1..10 members");
+    const isegmi_conv_desc* dp[CONV_GROUP_MAX];
+    for (int i = 0; i < n; ++i) dp[i] = descs + i;
+    return conv2d_group_launch(n, dp, d_in, d_w, d_scale, d_shift, d_res, d_out, (hipStream_t)stream);
+}
 
 extern "C" int isegmi_conv_out_hw(const isegmi_conv_desc* d, int32_t* Ho, int32_t* Wo) {
     int rc = check_desc(d);

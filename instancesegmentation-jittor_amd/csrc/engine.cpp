@@ -108,6 +108,71 @@ int eng_conv(Engine& e, const std::string& layer, const Tensor& in, int stride, 
     return timed_conv(e, layer, &d, in.d, L, residual ? residual->d : nullptr, out->d, out_f32);
 }
 
+int eng_conv_group(Engine& e, std::vector<ConvGroupItem>& items) {
+    const int n = (int)items.size();
+    if (n == 0) return ISEGMI_OK;
+    bool grouped = n > 1 && n <= 10 && e.param("conv_groups", 1.0f) != 0.0f && e.param("conv_tile", 0) == 0.0f;
+    std::vector<const ConvLayer*> Ls(n);
+    for (int i = 0; i < n; ++i) {
+        int rc = find_conv(e, items[i].layer, &Ls[i]);
+        if (rc) return rc;
+        if (Ls[i]->f16 || items[i].in.dt == 1 || (Ls[i]->Cin == 4 && Ls[i]->R == 7)) grouped = false;
+    }
+    if (!grouped) {
+        for (auto& it : items) {
+            int rc = it.dst ? eng_conv_into(e, it.layer, it.in, it.stride, it.pad, it.act, it.dst, it.out_div, it.out_img_stride, it.out_pix_stride, it.out_f32)
+                            : eng_conv(e, it.layer, it.in, it.stride, it.pad, it.act, it.residual, it.out_name, it.out, it.out_f32);
+            if (rc) return rc;
+        }
+        return ISEGMI_OK;
+    }
+    std::vector<isegmi_conv_desc> ds(n);
+    std::vector<const isegmi_conv_desc*> dp(n);
+    std::vector<const float*> in(n), w(n), sc(n), sh(n), rs(n);
+    std::vector<float*> out(n);
+    double fl = 0;
+    std::string label = "group[";
+    for (int i = 0; i < n; ++i) {
+        ConvGroupItem& it = items[i];
+        const ConvLayer* L = Ls[i];
+        if (L->Cin != it.in.C) { set_error("conv " + it.layer + ": Cin mismatch"); return ISEGMI_ERR_ARG; }
+        if (it.residual && it.residual->dt != it.in.dt) { set_error("conv " + it.layer + ": residual precision mismatch"); return ISEGMI_ERR_STATE; }
+        isegmi_conv_desc& d = ds[i];
+        memset(&d, 0, sizeof(d));
+        d.N = it.in.N; d.H = it.in.H; d.W = it.in.W; d.Cin = it.in.C; d.Cout = L->Cout; d.R = L->R; d.S = L->S; d.stride = it.stride; d.pad = it.pad; d.act = it.act;
+        const int Ho = (d.H + 2 * d.pad - d.R) / d.stride + 1, Wo = (d.W + 2 * d.pad - d.S) / d.stride + 1;
+        if (it.dst) {
+            d.out_div = it.out_div; d.out_img_stride = it.out_img_stride; d.out_pix_stride = it.out_pix_stride;
+            out[i] = (float*)it.dst;
+        } else {
+            int rc = eng_act(e, it.out_name, d.N, Ho, Wo, L->Cout, it.out, 0);
+            if (rc) return rc;
+            out[i] = it.out->d;
+        }
+        dp[i] = &d; in[i] = it.in.d; w[i] = (const float*)L->d_w; sc[i] = L->d_scale; sh[i] = L->d_shift; rs[i] = it.residual ? it.residual->d : nullptr;
+        fl += 2.0 * d.N * Ho * Wo * (double)d.Cout * d.R * d.S * d.Cin;
+        if (e.conv_trace) fprintf(stderr, "convlaunch\t%s\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\n", (it.layer + (i == 0 ? ".group" : ".grouped")).c_str(), d.N, d.H, d.W, d.Cin,
+                                  d.Cout, d.R, d.stride, Ho * Wo * d.N, rs[i] ? 1 : 0);
+        if (i < 3) label += (i ? " " : "") + it.layer;
+    }
+    label += n > 3 ? " ... x" + std::to_string(n) + "]" : "]";
+    hipEvent_t a = nullptr, b = nullptr;
+    if (e.conv_timing) {
+        HIP_TRY(hipEventCreate(&a));
+        HIP_TRY(hipEventCreate(&b));
+        HIP_TRY(hipEventRecord(a, e.cur));
+    }
+    int rc = conv2d_group_launch(n, dp.data(), in.data(), w.data(), sc.data(), sh.data(), rs.data(), out.data(), e.cur);
+    if (rc) return rc;
+    if (e.conv_timing) {
+        HIP_TRY(hipEventRecord(b, e.cur));
+        e.conv_evs.push_back({a, b});
+        e.conv_flops_pending += fl;
+        e.conv_ev_info.push_back({label + " [" + std::to_string(n) + " convolutions, one launch]", fl});
+    }
+    return ISEGMI_OK;
+}
+
 // fp16 bottleneck `block` (conv1 / conv2 / conv3 [/ downsample.0] of an upstream-named ResNet block, stride 1) as ONE launch of the fused kernel
 // (csrc/bottleneck_f16.hip) when the block's shape has one: identity blocks of res2 / res3, and -- `first` -- the first block of res2 with its
 // projection shortcut.  *fused tells the caller whether it ran (else: three or four eng_conv calls).
@@ -612,8 +677,18 @@ int yolact_forward(Engine& e, const float* d_images, int N) {
         HIP_TRY(hipStreamWaitEvent(e.stream, e.heads_done, 0));
         e.heads_pending = false;
     }
-    // FPN: the three laterals are independent; so are the three prediction convs
+    // FPN: the three laterals are independent; so are the three prediction convs.  fp32 (round 5): each trio is ONE grouped launch (eng_conv_group), and
+    // so are the five levels' upfeature and head_cat convs below: 16 launches become 4, and the small levels run inside the big level's launch instead of
+    // as 23-us launches of their own.  "conv_groups" 0 restores the per-layer launches (A/B; fp16 and the unfused head layout keep them anyway).
+    const bool grp = !dt && e.param("conv_groups", 1.0f) != 0.0f && e.param("conv_tile", 0) == 0.0f && e.convs.count("prediction_layers.0.head_cat") != 0;
     Tensor l5, l4, l3, x4f, x3f, P[5];
+    if (grp) {
+        std::vector<ConvGroupItem> g(3);
+        g[0].layer = "fpn.lat_layers.2"; g[0].in = C3; g[0].out_name = "fpn.lat3"; g[0].out = &l3;
+        g[1].layer = "fpn.lat_layers.1"; g[1].in = C4; g[1].out_name = "fpn.lat4"; g[1].out = &l4;
+        g[2].layer = "fpn.lat_layers.0"; g[2].in = C5; g[2].out_name = "fpn.lat5"; g[2].out = &l5;
+        TRY(eng_conv_group(e, g));
+    } else {
     TRY(eng_fork(e, 0));
     TRY(eng_fork(e, 1));
     { SideScope sc(e, 0); TRY(eng_conv(e, "fpn.lat_layers.1", C4, 1, 0, 0, nullptr, "fpn.lat4", &l4)); }
@@ -621,6 +696,7 @@ int yolact_forward(Engine& e, const float* d_images, int N) {
     TRY(eng_conv(e, "fpn.lat_layers.0", C5, 1, 0, 0, nullptr, "fpn.lat5", &l5));
     TRY(eng_join(e, 0));
     TRY(eng_join(e, 1));
+    }
     if (pipe) { HIP_TRY(hipEventRecord(e.lat_done, e.stream)); e.lat_pending = true; }
     TRY(eng_act(e, "fpn.x4", N, l4.H, l4.W, l4.C, &x4f, dt));
     if (dt) TRY(resize_bilinear_f16_launch(l5.d, N, l5.H, l5.W, l5.C, l4.H, l4.W, l4.d, 0, x4f.d, e.cur));
@@ -628,6 +704,16 @@ int yolact_forward(Engine& e, const float* d_images, int N) {
     TRY(eng_act(e, "fpn.x3", N, l3.H, l3.W, l3.C, &x3f, dt));
     if (dt) TRY(resize_bilinear_f16_launch(x4f.d, N, x4f.H, x4f.W, x4f.C, l3.H, l3.W, l3.d, 0, x3f.d, e.cur));
     else TRY(resize_bilinear_launch(x4f.d, N, x4f.H, x4f.W, x4f.C, l3.H, l3.W, l3.d, 0, x3f.d, e.cur));
+    if (grp) {
+        std::vector<ConvGroupItem> g(3);
+        g[0].layer = "fpn.pred_layers.2"; g[0].in = x3f; g[0].out_name = "P3"; g[0].out = &P[0];
+        g[1].layer = "fpn.pred_layers.1"; g[1].in = x4f; g[1].out_name = "P4"; g[1].out = &P[1];
+        g[2].layer = "fpn.pred_layers.0"; g[2].in = l5; g[2].out_name = "P5"; g[2].out = &P[2];
+        for (auto& it : g) { it.pad = 1; it.act = 1; }
+        TRY(eng_conv_group(e, g));
+        TRY(eng_conv(e, "fpn.downsample_layers.0", P[2], 2, 1, 0, nullptr, "P6", &P[3]));
+        TRY(eng_conv(e, "fpn.downsample_layers.1", P[3], 2, 1, 0, nullptr, "P7", &P[4]));
+    } else {
     TRY(eng_fork(e, 0));
     TRY(eng_fork(e, 1));
     {
@@ -640,6 +726,7 @@ int yolact_forward(Engine& e, const float* d_images, int N) {
     TRY(eng_conv(e, "fpn.pred_layers.2", x3f, 1, 1, 1, nullptr, "P3", &P[0]));
     TRY(eng_join(e, 0));
     TRY(eng_join(e, 1));
+    }
     eng_mark(e, "fpn");
     // shared prediction head geometry
     const int A = (int)e.param("num_priors", 3), ncls = 81, md = 32;  // 9 for YOLACT++ (3 scales x 3 aspect ratios per cell)
@@ -697,9 +784,24 @@ int yolact_forward(Engine& e, const float* d_images, int N) {
         TRY(eng_conv(e, "proto_net.8", u, 1, 1, 1, nullptr, "proto.t3", &t));
         TRY(eng_conv(e, "proto_net.10", t, 1, 0, 1, nullptr, "proto", &proto, /*out_f32=*/true));
     }
+    if (grp) {   // the shared head over all five levels: upfeature x 5 as one launch, head_cat x 5 as one launch (main stream; the protonet on side 0)
+        Tensor uf[5];
+        std::vector<ConvGroupItem> gu(5), gh(5);
+        for (int l = 0; l < 5; ++l) {
+            gu[l].layer = "prediction_layers.0.upfeature.0"; gu[l].in = P[l]; gu[l].pad = 1; gu[l].act = 1; gu[l].out_name = "head.up" + std::to_string(l); gu[l].out = &uf[l];
+        }
+        TRY(eng_conv_group(e, gu));
+        for (int l = 0; l < 5; ++l) {
+            gh[l].layer = "prediction_layers.0.head_cat"; gh[l].in = uf[l]; gh[l].pad = 1; gh[l].act = 0;
+            gh[l].dst = (float*)headcat + (int64_t)(off[l] / A) * CH; gh[l].out_div = uf[l].H * uf[l].W;
+            gh[l].out_img_stride = (int64_t)(Ptot / A) * CH; gh[l].out_pix_stride = CH; gh[l].out_f32 = true;
+        }
+        TRY(eng_conv_group(e, gh));
+    } else {
     { SideScope sc(e, 1); TRY(head_level(1)); TRY(head_level(3)); }
     { SideScope sc(e, 2); TRY(head_level(2)); TRY(head_level(4)); }
     TRY(head_level(0));
+    }
     TRY(eng_join(e, 0));
     TRY(eng_join(e, 1));
     TRY(eng_join(e, 2));

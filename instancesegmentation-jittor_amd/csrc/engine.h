@@ -144,6 +144,23 @@ int eng_stage_small(Engine& e, const void* h_src, size_t bytes, void* d_dst, hip
 hipStream_t eng_results_stream(Engine& e);  // the stream the last forward's results complete on  // st waits for a pending upload_async whose destination holds d_ptr
 int eng_bottleneck_f16(Engine& e, const std::string& block, const Tensor& x, bool first, const std::string& out_name, Tensor* out, bool* fused);
 int eng_conv_up2x_f16(Engine& e, const std::string& layer, const Tensor& x, const Tensor& coarse, const std::string& out_name, Tensor* out, bool* merged);
+// several independent convolutions of one point of the graph as ONE launch (fp32: conv2d_group_launch; fp16, a forced tile, a single member or
+// "conv_groups" 0: one launch per member, as eng_conv / eng_conv_into would issue them)
+struct ConvGroupItem {
+    std::string layer;
+    Tensor in;
+    int stride = 1, pad = 0, act = 0;
+    const Tensor* residual = nullptr;
+    std::string out_name;            // named activation (eng_conv) ...
+    Tensor* out = nullptr;
+    void* dst = nullptr;             // ... or an explicit strided destination (eng_conv_into)
+    int out_div = 0;
+    int64_t out_img_stride = 0, out_pix_stride = 0;
+    bool out_f32 = false;
+};
+int eng_conv_group(Engine& e, std::vector<ConvGroupItem>& items);
+int conv2d_group_launch(int n, const isegmi_conv_desc* const* d, const float* const* in, const float* const* w, const float* const* scale,
+                        const float* const* shift, const float* const* res, float* const* out, hipStream_t st);
 int eng_rpn_head_f16(Engine& e, const std::string& conv, const std::string& headl, const Tensor& x, const std::string& out_name, Tensor* out, bool* fused);
 int eng_stem_pool_f16(Engine& e, const std::string& layer, const Tensor& halo, int H, int W, const std::string& out_name, Tensor* out, bool* fused);
 int eng_conv_stem_f16(Engine& e, const std::string& layer, const Tensor& halo, int H, int W, const std::string& out_name, Tensor* out);

@@ -162,7 +162,26 @@ int maskrcnn_forward(Engine& e, const float* d_images, int N) {
     }
 
     // ---- FPN top-down chain (main stream); leaves (3x3 output convs) and the RPN follow per level
+    // fp32 (round 5): the four lateral convs, the four output convs, the RPN head's 3x3 over the five levels and its cls + bbox 1x1 over the five levels are
+    // ONE grouped launch each (eng_conv_group; bit-identical to the separate launches): 18 launches become 4, the small levels run inside the big levels'
+    // launches.  Needs the batched RPN selection (which then takes all five levels at once); "conv_groups" 0 restores the per-level launches.
+    const int pre_nms_g = (int)e.param("rpn_pre_nms_top_n", 1000);
+    const bool grp = !dt && e.param("conv_groups", 1.0f) != 0.0f && e.param("conv_tile", 0) == 0.0f && (int)e.param("rpn_select_groups", -1.0f) != 0 &&
+                     pre_nms_g > 256 && pre_nms_g <= 1024 && (int)e.param("rpn_post_nms_top_n", 1000) > 0;
     Tensor P[5], last[4], lat;
+    if (grp) {
+        Tensor lats[3];
+        std::vector<ConvGroupItem> g(4);
+        g[0].layer = "backbone.fpn.fpn_inner1"; g[0].in = C[0]; g[0].out_name = "fpn.lat1"; g[0].out = &lats[0];
+        g[1].layer = "backbone.fpn.fpn_inner2"; g[1].in = C[1]; g[1].out_name = "fpn.lat2"; g[1].out = &lats[1];
+        g[2].layer = "backbone.fpn.fpn_inner3"; g[2].in = C[2]; g[2].out_name = "fpn.lat3"; g[2].out = &lats[2];
+        g[3].layer = "backbone.fpn.fpn_inner4"; g[3].in = C[3]; g[3].out_name = "fpn.last4"; g[3].out = &last[3];
+        TRY(eng_conv_group(e, g));
+        for (int l = 2; l >= 0; --l) {
+            TRY(eng_act(e, "fpn.last" + std::to_string(l + 1), N, lats[l].H, lats[l].W, lats[l].C, &last[l], 0));
+            TRY(nearest2x_add_launch(last[l + 1].d, N, last[l + 1].H, last[l + 1].W, last[l + 1].C, lats[l].d, lats[l].H, lats[l].W, last[l].d, st));
+        }
+    } else {
     TRY(eng_conv(e, "backbone.fpn.fpn_inner4", C[3], 1, 0, 0, nullptr, "fpn.last4", &last[3]));
     for (int l = 2; l >= 0; --l) {
         const std::string ls = std::to_string(l + 1);
@@ -175,6 +194,7 @@ int maskrcnn_forward(Engine& e, const float* d_images, int N) {
         TRY(eng_act(e, "fpn.last" + ls, N, lat.H, lat.W, lat.C, &last[l], dt));
         if (dt) TRY(nearest2x_add_f16_launch(last[l + 1].d, N, last[l + 1].H, last[l + 1].W, last[l + 1].C, lat.d, lat.H, lat.W, last[l].d, st));
         else TRY(nearest2x_add_launch(last[l + 1].d, N, last[l + 1].H, last[l + 1].W, last[l + 1].C, lat.d, lat.H, lat.W, last[l].d, st));
+    }
     }
     eng_mark(e, "fpn_topdown");
 
@@ -204,7 +224,7 @@ int maskrcnn_forward(Engine& e, const float* d_images, int N) {
     // P3..P6 as one group behind P6's head.  "rpn_select_groups": 0 = the per-level launches (A/B; also taken for pre_nms outside 257..1024), 1 / 2 force.
     const int sel_groups_param = (int)e.param("rpn_select_groups", -1.0f);
     const bool batched_sel = sel_groups_param != 0 && pre_nms > 256 && pre_nms <= 1024 && post_nms > 0;
-    const int sel_groups = !batched_sel ? 0 : (sel_groups_param > 0 ? (sel_groups_param > 2 ? 2 : sel_groups_param) : (N >= 2 ? 1 : 2));
+    const int sel_groups = !batched_sel ? 0 : grp ? 1 : (sel_groups_param > 0 ? (sel_groups_param > 2 ? 2 : sel_groups_param) : (N >= 2 ? 1 : 2));
     const float* lvl_head[5]; const float* lvl_anc[5]; int lvl_hwa[5];
     auto select_group = [&](int l0, int l1) -> int {   // levels [l0, l1) on e.cur
         const int nl = l1 - l0;
@@ -301,6 +321,30 @@ int maskrcnn_forward(Engine& e, const float* d_images, int N) {
     // WAR: the previous forward's RoI heads (tail stream) still gather from P2..P5 and read proposals / det buffers;
     // everything up to here (backbone, top-down chain) was free to run underneath them.
     if (e.multi_stream && e.tail_pending && !e.capturing) HIP_TRY(hipStreamWaitEvent(e.stream, e.tail_done, 0));
+    if (grp) {
+        std::vector<ConvGroupItem> g(4), gt(5), gh(5);
+        for (int l = 0; l < 4; ++l) {
+            g[l].layer = "backbone.fpn.fpn_layer" + std::to_string(l + 1); g[l].in = last[l]; g[l].pad = 1; g[l].out_name = "P" + std::to_string(l + 2); g[l].out = &P[l];
+        }
+        TRY(eng_conv_group(e, g));
+        const int Ho = (P[3].H - 1) / 2 + 1, Wo = (P[3].W - 1) / 2 + 1;
+        TRY(eng_act(e, "P6", N, Ho, Wo, P[3].C, &P[4], 0));
+        TRY(maxpool_launch(P[3].d, N, P[3].H, P[3].W, P[3].C, 1, 2, 0, P[4].d, st));
+        Tensor t[5], head[5];
+        for (int l = 0; l < 5; ++l) {
+            gt[l].layer = "rpn.head.conv"; gt[l].in = P[l]; gt[l].pad = 1; gt[l].act = 1; gt[l].out_name = "rpn.t" + std::to_string(l); gt[l].out = &t[l];
+        }
+        TRY(eng_conv_group(e, gt));
+        for (int l = 0; l < 5; ++l) {
+            gh[l].layer = "rpn.head.cls_bbox"; gh[l].in = t[l]; gh[l].out_name = "rpn.head" + std::to_string(l); gh[l].out = &head[l]; gh[l].out_f32 = true;
+        }
+        TRY(eng_conv_group(e, gh));
+        for (int l = 0; l < 5; ++l) {
+            const float* anc;
+            TRY(level_anchors(e, l, A, head[l].H, head[l].W, regen_anchors, &anc));
+            lvl_head[l] = head[l].d; lvl_anc[l] = anc; lvl_hwa[l] = head[l].H * head[l].W * A;
+        }
+    } else {
     for (int l = 0; l < 4; ++l) {
         TRY(eng_conv(e, "backbone.fpn.fpn_layer" + std::to_string(l + 1), last[l], 1, 1, 0, nullptr, "P" + std::to_string(l + 2), &P[l]));
         TRY(rpn_level(l));
@@ -311,6 +355,7 @@ int maskrcnn_forward(Engine& e, const float* d_images, int N) {
         if (dt) TRY(maxpool_to_f16_launch(P[3].d, 1, N, P[3].H, P[3].W, P[3].C, 1, 2, 0, P[4].d, st));
         else TRY(maxpool_launch(P[3].d, N, P[3].H, P[3].W, P[3].C, 1, 2, 0, P[4].d, st));
         TRY(rpn_level(4));
+    }
     }
     e.anchor_H = H; e.anchor_W = W;
     // From here on everything runs on the TAIL stream: it (not the main stream) joins the side streams, so the main

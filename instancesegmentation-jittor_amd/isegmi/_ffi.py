@@ -195,6 +195,32 @@ def conv2d(x, w_krsc, stride=1, pad=0, scale=None, shift=None, residual=None, ac
     return do.numpy()
 
 
+def conv2d_group(items):
+    """isegmi_op_conv2d_group: several independent fp32 convolutions as ONE launch.  items: dicts with x, w (KRSC) and optionally stride, pad, scale,
+    shift, residual, act.  -> list of outputs (each what conv2d gives for the member alone, bit for bit)."""
+    n = len(items)
+    descs = (ConvDesc * n)()
+    keep, ins, ws, scs, shs, rss, outs, shapes = [], [], [], [], [], [], [], []
+    for i, it in enumerate(items):
+        x = np.ascontiguousarray(it["x"], np.float32)
+        N, H, W, Cin = x.shape
+        Cout, R, S, _ = it["w"].shape
+        d = make_conv_desc(N, H, W, Cin, Cout, R, S, it.get("stride", 1), it.get("pad", 0), it.get("act", 0), 0)
+        descs[i] = d
+        ho, wo = conv_out_hw(d)
+        dx = DeviceBuffer.from_numpy(x); dw = DeviceBuffer.from_numpy(pack_conv_weights(d, it["w"]))
+        ds = None if it.get("scale") is None else DeviceBuffer.from_numpy(np.asarray(it["scale"], np.float32))
+        dh = None if it.get("shift") is None else DeviceBuffer.from_numpy(np.asarray(it["shift"], np.float32))
+        dr = None if it.get("residual") is None else DeviceBuffer.from_numpy(np.asarray(it["residual"], np.float32))
+        do = DeviceBuffer((N, ho, wo, Cout))
+        keep += [dx, dw, ds, dh, dr, do]
+        for lst, b in ((ins, dx), (ws, dw), (scs, ds), (shs, dh), (rss, dr), (outs, do)):
+            lst.append(None if b is None else b.ptr.value)
+    arr = lambda lst: (C.c_void_p * n)(*lst)
+    check(lib().isegmi_op_conv2d_group(n, descs, arr(ins), arr(ws), arr(scs), arr(shs), arr(rss), arr(outs), None))
+    return [keep[6 * i + 5].numpy() for i in range(n)]
+
+
 def maxpool(x, k, s, p):
     x = np.ascontiguousarray(x, np.float32)
     N, H, W, Cc = x.shape

@@ -135,3 +135,43 @@ def test_conv_hybrid_split_bit_exact(ffi, case, tile):
         ref = ora.conv2d(x, w, stride, pad, sc, sh, res if use_res else None, act)
         got = ffi.conv2d(x, w, stride, pad, sc, sh, res if use_res else None, act, tile)
         assert np.array_equal(got, ref)
+
+
+def _member(rng, N, H, W, Cin, Cout, R, stride=1, pad=None, act=1, res=False, bn=True):
+    pad = R // 2 if pad is None else pad
+    x = rng.standard_normal((N, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((Cout, R, R, Cin)) * (2.0 / (R * R * Cin)) ** 0.5).astype(np.float32)
+    it = dict(x=x, w=w, stride=stride, pad=pad, act=act)
+    if bn:
+        it["scale"] = rng.uniform(0.5, 1.5, Cout).astype(np.float32); it["shift"] = (rng.standard_normal(Cout) * 0.1).astype(np.float32)
+    if res:
+        ho, wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
+        it["residual"] = rng.standard_normal((N, ho, wo, Cout)).astype(np.float32)
+    return it
+
+
+@pytest.mark.parametrize("case", ["heads", "small", "mixed", "one"])
+def test_conv_group_bit_exact(ffi, case):
+    """isegmi_op_conv2d_group (several independent convolutions in ONE launch: csrc/conv_mfma.hip conv_group_kernel) against the oracle, member by member,
+    bit for bit -- shared-weight heads over five pyramid levels (large enough that the big levels run on 64 x 64 tiles and the small ones on 32 x 32
+    blocks inside the same launch), a group small enough to run on 32 x 32 blocks only, members that differ in everything (1x1 / 3x3 / stride 2,
+    residual, no BN, Cout <= 32, ragged Cout), and a group of one."""
+    rng = np.random.default_rng({"heads": 1, "small": 2, "mixed": 3, "one": 4}[case])
+    if case == "heads":
+        w = (rng.standard_normal((96, 3, 3, 64)) * 0.06).astype(np.float32)
+        items = []
+        for hw in (69, 35, 18, 9, 5):
+            it = _member(rng, 4, hw, hw, 64, 96, 3)
+            it["w"] = w
+            items.append(it)
+    elif case == "small":
+        items = [_member(rng, 1, 9, 9, 64, 64, 3), _member(rng, 1, 5, 5, 64, 351, 3, act=0, bn=False), _member(rng, 2, 7, 11, 32, 40, 1)]
+    elif case == "mixed":
+        items = [_member(rng, 2, 40, 56, 64, 128, 3, res=True), _member(rng, 1, 33, 31, 128, 24, 1, act=0), _member(rng, 2, 40, 56, 64, 64, 3, stride=2),
+                 _member(rng, 3, 50, 50, 32, 70, 1, bn=False), _member(rng, 1, 64, 64, 256, 256, 3)]
+    else:
+        items = [_member(rng, 2, 30, 30, 64, 64, 3, res=True)]
+    got = ffi.conv2d_group(items)
+    for g, it in zip(got, items):
+        ref = ora.conv2d(it["x"], it["w"], it["stride"], it["pad"], it.get("scale"), it.get("shift"), it.get("residual"), it["act"])
+        assert g.shape == ref.shape and np.array_equal(g, ref), (case, it["x"].shape, it["w"].shape)
