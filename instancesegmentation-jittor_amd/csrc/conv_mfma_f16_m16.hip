@@ -17,9 +17,11 @@ namespace isegmi {
 // power-bound loops (MI355X_MICROARCH.md "DVFS give-back" 7; tools/microbench/mfma_shape.hip: 1.12-1.13x on random data at equal cycles).  The 32-term sum
 // of one 16 x 16 x 32 instruction is bit for bit what two chained 32 x 32 x 16 instructions give (same microbenchmark: 0 of 204 800 elements differ), and the
 // kernels here walk K exactly as their twins do: results do not depend on the shape (tests/test_conv_f16_gpu.py::test_mfma_shape_does_not_change_results).
+// In this file a wave tile is NA x NC blocks of 16 x 16: WR = 16 NA rows (48 or 64), 16 NC = 32 TN columns.  (The 32 x 32 x 16 branches kept from the
+// twin file are never instantiated here; their TM is only a placeholder.)
 template <class T> struct acc_traits;
-template <int TM_, int TN_> struct acc_traits<f32x16h[TM_][TN_]> { static constexpr int TM = TM_, TN = TN_, MS = 0, SR = 8; };
-template <int TM2, int TN2> struct acc_traits<f32x4h[TM2][TN2]> { static constexpr int TM = TM2 / 2, TN = TN2 / 2, MS = 1, SR = 16; };
+template <int TM_, int TN_> struct acc_traits<f32x16h[TM_][TN_]> { static constexpr int TM = TM_, TN = TN_, MS = 0, SR = 8, NA = TM_, NC = TN_, WR = 32 * TM_; };
+template <int NA_, int NC_> struct acc_traits<f32x4h[NA_][NC_]> { static constexpr int TM = (NA_ + 1) / 2, TN = NC_ / 2, MS = 1, SR = 16, NA = NA_, NC = NC_, WR = 16 * NA_; };
 
 // rows [32 a, 32 a + 32) of the wave tile -> ew[row in strip][column], y = fmaf(acc, scale, shift)
 template <int TM, int TN>
@@ -36,20 +38,19 @@ __device__ __forceinline__ void epi_stage32(const ConvKH& p, f32x16h (&acc)[TM][
         for (int e = 0; e < 16; ++e) ew[((e & 3) + 8 * (e >> 2) + 4 * lh) * PITCH + b * 32 + lr] = fmaf(acc[a][b][e], sc, sh);
     }
 }
-template <int TM2, int TN2>
-__device__ __forceinline__ void epi_stage32(const ConvKH& p, f32x4h (&acc)[TM2][TN2], int a, float* ew, int lane, int wn, int n0) {
-    constexpr int TN = TN2 / 2, PITCH = TN * 32 + 4;
+// block row i (rows [16 i, 16 i + 16) of the wave tile) -> ew[row in strip][column], y = fmaf(acc, scale, shift)
+template <int NA, int NC>
+__device__ __forceinline__ void epi_stage16(const ConvKH& p, f32x4h (&acc)[NA][NC], int i, float* ew, int lane, int wn, int n0) {
+    constexpr int PITCH = NC * 16 + 4;
     const int l15 = lane & 15, lq = lane >> 4;
 #pragma unroll
-    for (int jb = 0; jb < TN2; ++jb) {
-        const int co = n0 + wn * TN * 32 + jb * 16 + l15;
+    for (int jb = 0; jb < NC; ++jb) {
+        const int co = n0 + wn * NC * 16 + jb * 16 + l15;
         const bool cok = co < p.Cout;
         const float sc = (cok && p.scale) ? p.scale[co] : 1.0f;
         const float sh = (cok && p.shift) ? p.shift[co] : 0.0f;
 #pragma unroll
-        for (int i2 = 0; i2 < 2; ++i2)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) ew[(i2 * 16 + 4 * lq + e) * PITCH + jb * 16 + l15] = fmaf(acc[2 * a + i2][jb][e], sc, sh);
+        for (int e = 0; e < 4; ++e) ew[(4 * lq + e) * PITCH + jb * 16 + l15] = fmaf(acc[i][jb][e], sc, sh);
     }
 }
 
@@ -61,30 +62,31 @@ __device__ __forceinline__ void epi_stage32(const ConvKH& p, f32x4h (&acc)[TM2][
 // without a residual no load is issued at all (round 2 sent a dropped out-of-range load per pass and waited for it).
 template <bool RES, class ACC>
 __device__ __forceinline__ void conv_f16_epilogue_vec(const ConvKH& p, ACC& acc, char* smemg, int wave, int lane, int wm, int wn, int m0, int n0) {
-    constexpr int TM = acc_traits<ACC>::TM, TN = acc_traits<ACC>::TN;
+    constexpr int TN = acc_traits<ACC>::TN, NA = acc_traits<ACC>::NA, WR = acc_traits<ACC>::WR;
+    static_assert(acc_traits<ACC>::MS == 1, "this file holds the 16 x 16 x 32 kernels");
     constexpr unsigned OOB = 0x80000000u;
     constexpr int PITCH = TN * 32 + 4;
-    constexpr int LPR = TN * 4, RPP = 64 / LPR, NPASS = 32 / RPP, NQ = TM * NPASS, D = 2 < NQ ? 2 : NQ;
+    constexpr int LPR = TN * 4, RPP = 64 / LPR, NPASS = 16 / RPP, NQ = NA * NPASS, D = 2 < NQ ? 2 : NQ;   // 16-row strips: one block row each
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)(RES ? (const void*)p.res : (const void*)p.out), 0, RES ? p.res_bytes : 0u, 0x00020000);
     const unsigned esz = p.out_f32 ? 4u : 2u;
-    float* ew = (float*)smemg + wave * 32 * PITCH;
+    float* ew = (float*)smemg + wave * 16 * PITCH;
     const int er = lane / LPR, ec = (lane % LPR) * 8;
     const int co8 = n0 + wn * TN * 32 + ec;
     const bool cok8 = co8 < p.Cout;
     // pass q covers tile rows RPP q ..: a lane's offsets advance by one stride per pass; rows past M are behind the descriptors' ranges
     // (contiguous destinations; strided ones take the general arithmetic)
     const unsigned rstep = (unsigned)p.Cout * (2u * RPP), ostep = (unsigned)p.out_pix_stride * esz * RPP;
-    unsigned rnext = cok8 ? ((unsigned)(m0 + wm * TM * 32 + er) * (unsigned)p.Cout + (unsigned)co8) * 2u : OOB;
-    unsigned onext = cok8 ? ((unsigned)(m0 + wm * TM * 32 + er) * (unsigned)p.out_pix_stride + (unsigned)co8) * esz : OOB;
+    unsigned rnext = cok8 ? ((unsigned)(m0 + wm * WR + er) * (unsigned)p.Cout + (unsigned)co8) * 2u : OOB;
+    unsigned onext = cok8 ? ((unsigned)(m0 + wm * WR + er) * (unsigned)p.out_pix_stride + (unsigned)co8) * esz : OOB;
     u32x4h rw[D];
     if (RES) {
 #pragma unroll
         for (int q = 0; q < D; ++q) { rw[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, rnext, 0, CONV_F16_RES_AUX); rnext += rstep; }
     }
 #pragma unroll
-    for (int a = 0; a < TM; ++a) {
-        epi_stage32(p, acc, a, ew, lane, wn, n0);
+    for (int a = 0; a < NA; ++a) {
+        epi_stage16(p, acc, a, ew, lane, wn, n0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
@@ -95,7 +97,7 @@ __device__ __forceinline__ void conv_f16_epilogue_vec(const ConvKH& p, ACC& acc,
             unsigned ooff;
             if (p.contiguous) { ooff = onext; onext += ostep; }
             else {
-                const int m = m0 + wm * TM * 32 + q * RPP + er;
+                const int m = m0 + wm * WR + q * RPP + er;
                 const int ni = m / p.out_div, pi = m - ni * p.out_div;
                 ooff = (m < p.M && cok8) ? (unsigned)(((int64_t)ni * p.out_img_stride + (int64_t)pi * p.out_pix_stride + co8) * esz) : OOB;
             }
@@ -134,8 +136,8 @@ __device__ __forceinline__ void conv_f16_epilogue_vec(const ConvKH& p, ACC& acc,
 // register at a time -- ROWB x COLB blocks of NE registers, register e of a lane at (row_of(e), its column)
 template <class ACC>
 __device__ __forceinline__ void conv_f16_epilogue_elem(const ConvKH& p, ACC& acc, int lane, int wm, int wn, int m0, int n0) {
-    constexpr int TM = acc_traits<ACC>::TM, TN = acc_traits<ACC>::TN, MS = acc_traits<ACC>::MS;
-    constexpr int RB = MS ? 16 : 32, NE = MS ? 4 : 16, NA = TM * 32 / RB, NC = TN * 32 / RB;
+    constexpr int TN = acc_traits<ACC>::TN, MS = acc_traits<ACC>::MS, NA = acc_traits<ACC>::NA, NC = acc_traits<ACC>::NC, WR = acc_traits<ACC>::WR;
+    constexpr int RB = MS ? 16 : 32, NE = MS ? 4 : 16;
     constexpr unsigned OOB = 0x80000000u;
     const int lc = MS ? (lane & 15) : (lane & 31);
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
@@ -147,7 +149,7 @@ __device__ __forceinline__ void conv_f16_epilogue_elem(const ConvKH& p, ACC& acc
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
             const int rin = MS ? 4 * (lane >> 4) + e : (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-            const int m = m0 + wm * TM * 32 + a * RB + rin;
+            const int m = m0 + wm * WR + a * RB + rin;
             resoff[e] = m < p.M ? (unsigned)m * (unsigned)p.Cout * 2u : OOB;
             if (p.contiguous) rowoff[e] = m < p.M ? (unsigned)m * (unsigned)p.out_pix_stride * esz : OOB;
             else {
@@ -241,10 +243,10 @@ __device__ __forceinline__ void mfma16_chunk(f32x4h (&acc)[NA][NC], const char* 
 
 constexpr int EPI_D = 2;
 
-template <int TM, int TN>
+template <int WR, int TN>   // WR rows x 32 TN columns per wave
 struct Epi8 {
-    static_assert(TN == 2 || TN == 4, "8-row strips are 64 or 128 channels wide");
-    static constexpr int LPR = TN * 4, RPP = 64 / LPR, NPASS = 8 / RPP, NQ = TM * 4 * NPASS;  // passes (b128 per lane) per wave tile
+    static_assert(TN == 2 || TN == 4, "strips are 64 or 128 channels wide");
+    static constexpr int LPR = TN * 4, RPP = 64 / LPR, NQ = WR / RPP;  // passes (b128 per lane) per wave tile
     static constexpr int D = EPI_D < NQ ? EPI_D : NQ;
     u32x4h r[D];
     unsigned rnext;   // residual offset (bytes) of the next pass to request, or >= OOB for a column past Cout; pass q covers tile rows RPP q ..
@@ -254,53 +256,54 @@ struct Epi8 {
 // UP2X (FPN top-down merge, SURVEY 8a M3: `last_inner = inner_lateral + interpolate(last_inner, scale_factor=2, mode="nearest")`): the residual of output pixel
 // (n, y, x) is pixel (n, min(y >> 1, Hc - 1), min(x >> 1, Wc - 1)) of the coarser level.  A lane's pass-to-pass step is RPP pixels along the row: the walk is
 // incremental (one wrap test per pass), the two divisions that start it are per tile.
-template <int TM, int TN>
-__device__ __forceinline__ unsigned epi8_up2x_next(const ConvKH& p, Epi8<TM, TN>& E, int co8) {
+template <int WR, int TN>
+__device__ __forceinline__ unsigned epi8_up2x_next(const ConvKH& p, Epi8<WR, TN>& E, int co8) {
     constexpr unsigned OOB = 0x80000000u;
     int yc = E.uy >> 1, xc = E.ux >> 1;
     yc = yc > p.rHc - 1 ? p.rHc - 1 : yc;
     xc = xc > p.rWc - 1 ? p.rWc - 1 : xc;
     const unsigned off = co8 < p.Cout ? ((unsigned)((E.un * p.rHc + yc) * p.rWc + xc) * (unsigned)p.Cout + (unsigned)co8) * 2u : OOB;   // images past N are past the range
-    E.ux += Epi8<TM, TN>::RPP;
+    E.ux += Epi8<WR, TN>::RPP;
     if (E.ux >= p.Wo) { E.ux -= p.Wo; E.uy += 1; if (E.uy >= p.Ho) { E.uy = 0; E.un += 1; } }
     return off;
 }
 
 // before the K loop: the first D residual passes of the wave's tile
-template <int TM, int TN, bool UP2X = false>
-__device__ __forceinline__ void epi8_prefetch(const ConvKH& p, Epi8<TM, TN>& E, int lane, int wm, int wn, int m0, int n0) {
+template <int WR, int TN, bool UP2X = false>
+__device__ __forceinline__ void epi8_prefetch(const ConvKH& p, Epi8<WR, TN>& E, int lane, int wm, int wn, int m0, int n0) {
     constexpr unsigned OOB = 0x80000000u;
-    constexpr int LPR = Epi8<TM, TN>::LPR, RPP = Epi8<TM, TN>::RPP;
+    constexpr int LPR = Epi8<WR, TN>::LPR, RPP = Epi8<WR, TN>::RPP;
     // no branch on p.res here: a conditional prefetch makes the window a phi, and the compiler then parks the loaded registers in copies
     // behind an s_waitcnt vmcnt(0) in FRONT of the K loop; without a residual the descriptor is empty and the loads return zeros unused
     const int er = lane / LPR, ec = (lane % LPR) * 8;
     const int co8 = n0 + wn * TN * 32 + ec;
-    E.rnext = co8 < p.Cout ? ((unsigned)(m0 + wm * TM * 32 + er) * (unsigned)p.Cout + (unsigned)co8) * 2u : OOB;
+    E.rnext = co8 < p.Cout ? ((unsigned)(m0 + wm * WR + er) * (unsigned)p.Cout + (unsigned)co8) * 2u : OOB;
     const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? (const void*)p.res : (const void*)p.out), 0, p.res ? p.res_bytes : 0u, 0x00020000);
     const unsigned rstep = (unsigned)p.Cout * (2u * RPP);
     if constexpr (UP2X) {
-        const int m = m0 + wm * TM * 32 + er, hw = p.Ho * p.Wo;
+        const int m = m0 + wm * WR + er, hw = p.Ho * p.Wo;
         E.un = m / hw;
         const int rem = m - E.un * hw;
         E.uy = rem / p.Wo;
         E.ux = rem - E.uy * p.Wo;
 #pragma unroll
-        for (int q = 0; q < Epi8<TM, TN>::D; ++q) E.r[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, epi8_up2x_next<TM, TN>(p, E, co8), 0, CONV_F16_RES_AUX);
+        for (int q = 0; q < Epi8<WR, TN>::D; ++q) E.r[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, epi8_up2x_next<WR, TN>(p, E, co8), 0, CONV_F16_RES_AUX);
         return;
     }
 #pragma unroll
-    for (int q = 0; q < Epi8<TM, TN>::D; ++q) { E.r[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, E.rnext, 0, CONV_F16_RES_AUX); E.rnext += rstep; }
+    for (int q = 0; q < Epi8<WR, TN>::D; ++q) { E.r[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, E.rnext, 0, CONV_F16_RES_AUX); E.rnext += rstep; }
 }
 
 // SR-row strips: 8 rows (registers 4g .. 4g + 3 of the 32 x 32 blocks) or 16 rows (one row of 16 x 16 blocks); ew = the wave's SR x PITCH floats of scratch
 template <bool RES, bool UP2X, class ACC>
-__device__ __forceinline__ void epi8_finish_impl(const ConvKH& p, ACC& acc, Epi8<acc_traits<ACC>::TM, acc_traits<ACC>::TN>& E, float* ew, int lane, int wm, int wn, int m0, int n0) {
-    constexpr int TM = acc_traits<ACC>::TM, TN = acc_traits<ACC>::TN, MS = acc_traits<ACC>::MS, SR = acc_traits<ACC>::SR;
+__device__ __forceinline__ void epi8_finish_impl(const ConvKH& p, ACC& acc, Epi8<acc_traits<ACC>::WR, acc_traits<ACC>::TN>& E, float* ew, int lane, int wm, int wn, int m0, int n0) {
+    constexpr int TN = acc_traits<ACC>::TN, MS = acc_traits<ACC>::MS, SR = acc_traits<ACC>::SR, NA = acc_traits<ACC>::NA, WR = acc_traits<ACC>::WR;
+    static_assert(MS == 1, "this file holds the 16 x 16 x 32 kernels");
     constexpr unsigned OOB = 0x80000000u;
     constexpr int PITCH = TN * 32 + 4;
-    constexpr int LPR = Epi8<TM, TN>::LPR, RPP = Epi8<TM, TN>::RPP, NPASS = SR / RPP, NQ = Epi8<TM, TN>::NQ, D = Epi8<TM, TN>::D;
-    constexpr int NCB = MS ? 2 * TN : TN, CB = MS ? 16 : 32;   // column blocks of the wave tile
-    static_assert(TM * (32 / SR) * NPASS == NQ, "passes per wave tile");
+    constexpr int LPR = Epi8<WR, TN>::LPR, RPP = Epi8<WR, TN>::RPP, NPASS = SR / RPP, NQ = Epi8<WR, TN>::NQ, D = Epi8<WR, TN>::D;
+    constexpr int NCB = 2 * TN, CB = 16;   // column blocks of the wave tile
+    static_assert(NA * NPASS == NQ, "passes per wave tile");
     const int lr = MS ? (lane & 15) : (lane & 31), lh = lane >> 5;
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)(RES ? (const void*)p.res : (const void*)p.out), 0, RES ? p.res_bytes : 0u, 0x00020000);
@@ -311,7 +314,7 @@ __device__ __forceinline__ void epi8_finish_impl(const ConvKH& p, ACC& acc, Epi8
     const unsigned rstep = (unsigned)p.Cout * (2u * RPP);
     // contiguous destination: offset = lane base + pass * step, rows past M are out of the descriptor's range
     const unsigned ostep = (unsigned)p.out_pix_stride * esz * RPP;
-    unsigned onext = cok8 ? ((unsigned)(m0 + wm * TM * 32 + er) * (unsigned)p.out_pix_stride + (unsigned)co8) * esz : OOB;
+    unsigned onext = cok8 ? ((unsigned)(m0 + wm * WR + er) * (unsigned)p.out_pix_stride + (unsigned)co8) * esz : OOB;
     float sc[NCB], sh[NCB];
 #pragma unroll
     for (int b = 0; b < NCB; ++b) {
@@ -321,31 +324,24 @@ __device__ __forceinline__ void epi8_finish_impl(const ConvKH& p, ACC& acc, Epi8
         sh[b] = (cok && p.shift) ? p.shift[co] : 0.0f;
     }
 #pragma unroll
-    for (int a = 0; a < TM; ++a) {
+    for (int a = 0; a < NA; ++a) {   // block row a: register j = tile row 16 a + 4 * (lane >> 4) + j
+        {
+            (void)lh;
 #pragma unroll
-        for (int g = 0; g < 32 / SR; ++g) {
-            if constexpr (MS == 0) {   // accumulator registers 4g..4g+3 = tile rows 8g + (0..3) + 4 * (lane >> 5)
+            for (int b = 0; b < NCB; ++b)
 #pragma unroll
-                for (int b = 0; b < TN; ++b)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) ew[(j + 4 * lh) * PITCH + b * 32 + lr] = fmaf(acc[a][b][4 * g + j], sc[b], sh[b]);
-            } else {                   // block row 2a + g: register j = tile row 16g + 4 * (lane >> 4) + j
-#pragma unroll
-                for (int b = 0; b < NCB; ++b)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) ew[(j + 4 * (lane >> 4)) * PITCH + b * 16 + lr] = fmaf(acc[2 * a + g][b][j], sc[b], sh[b]);
-            }
+                for (int j = 0; j < 4; ++j) ew[(j + 4 * (lane >> 4)) * PITCH + b * 16 + lr] = fmaf(acc[a][b][j], sc[b], sh[b]);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int ps = 0; ps < NPASS; ++ps) {
-                const int q = (a * (32 / SR) + g) * NPASS + ps;
+                const int q = a * NPASS + ps;
                 const int rr = ps * RPP + er;
                 const f32x4h v0 = *(const f32x4h*)(ew + rr * PITCH + ec);
                 const f32x4h v1 = *(const f32x4h*)(ew + rr * PITCH + ec + 4);
                 unsigned ooff;
                 if (p.contiguous) { ooff = onext; onext += ostep; }
                 else {
-                    const int m = m0 + wm * TM * 32 + q * RPP + er;
+                    const int m = m0 + wm * WR + q * RPP + er;
                     const int ni = m / p.out_div, pi = m - ni * p.out_div;
                     ooff = (m < p.M && cok8) ? (unsigned)(((int64_t)ni * p.out_img_stride + (int64_t)pi * p.out_pix_stride + co8) * esz) : OOB;
                 }
@@ -356,7 +352,7 @@ __device__ __forceinline__ void epi8_finish_impl(const ConvKH& p, ACC& acc, Epi8
                         // the lateral conv's result is rounded to fp16 FIRST, as the two-launch path stores it before nearest2x_add_f16 adds the coarser level
 #pragma unroll
                         for (int i = 0; i < 8; ++i) y[i] = (float)(half_t)(i < 4 ? v0[i] : v1[i - 4]) + (float)rh[i];
-                        if (q + D < NQ) E.r[q % D] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, epi8_up2x_next<TM, TN>(p, E, co8), 0, CONV_F16_RES_AUX);
+                        if (q + D < NQ) E.r[q % D] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, epi8_up2x_next<WR, TN>(p, E, co8), 0, CONV_F16_RES_AUX);
                     } else {
 #pragma unroll
                         for (int i = 0; i < 8; ++i) y[i] = (i < 4 ? v0[i] : v1[i - 4]) + (float)rh[i];
@@ -389,7 +385,7 @@ __device__ __forceinline__ void epi8_finish_impl(const ConvKH& p, ACC& acc, Epi8
 }
 
 template <bool UP2X, class ACC>
-__device__ __forceinline__ void epi8_finish(const ConvKH& p, ACC& acc, Epi8<acc_traits<ACC>::TM, acc_traits<ACC>::TN>& E, float* ew, int lane, int wm, int wn, int m0, int n0) {
+__device__ __forceinline__ void epi8_finish(const ConvKH& p, ACC& acc, Epi8<acc_traits<ACC>::WR, acc_traits<ACC>::TN>& E, float* ew, int lane, int wm, int wn, int m0, int n0) {
     if constexpr (UP2X) { epi8_finish_impl<true, true>(p, acc, E, ew, lane, wm, wn, m0, n0); return; }
     if (p.res) epi8_finish_impl<true, false>(p, acc, E, ew, lane, wm, wn, m0, n0);   // uniform
     else epi8_finish_impl<false, false>(p, acc, E, ew, lane, wm, wn, m0, n0);
@@ -407,15 +403,20 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, OCC) void conv_f16_persist_ker
     karg_t kp0 = (karg_t)__builtin_amdgcn_kernarg_segment_ptr();
     const int p_mtiles = kp0->mtiles, p_ntiles = kp0->ntiles, p_nchunks = kp0->nchunks;
     constexpr int NW = WM * WN, NL = LW;
-    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    static_assert(MS == 1 && (BM / WM) % 16 == 0 && BM % WM == 0, "16 x 16 x 32: a wave owns a whole number of 16-row blocks");
+    constexpr int WR = BM / WM, TM = (WR + 31) / 32, TN = BN / WN / 32;   // rows per wave; (TM: placeholder of the uninstantiated 32 x 32 x 16 branch)
     constexpr int PA = BM / 8, PB = BN / 8;
     constexpr int PPA = (PA + NL - 1) / NL, PPB = (PB + NL - 1) / NL;
     constexpr bool UNEVEN = (PA % NL != 0) || (PB % NL != 0);
-    static_assert(!UNEVEN || NSTAGE == 2, "a partial piece round changes a wave's vmcnt count: only with the vmcnt(0) ring");
+    // (a partial piece round issues one dropped piece in its place -- see issue_chunk -- so a wave's vmcnt count stays uniform)
     constexpr int STAGEB = (BM + BN) * 128;
     constexpr int PP = PPA + PPB;
-    constexpr int ESR = MS ? 16 : 8;   // rows per epilogue strip (acc_traits::SR)
-    static_assert(NW * ESR * (TN * 32 + 4) * 4 <= STAGEB, "the epilogue's strips must fit one ring stage");
+    constexpr int ESR = 16;            // rows per epilogue strip (acc_traits::SR)
+    constexpr int EWB = ESR * (TN * 32 + 4) * 4;   // a wave's strip scratch (bytes)
+    // the epilogue's strips live in the ring stage the MFMA waves read last; where that stage is too small for all of them (144 x 256: 51 200 B for
+    // twelve strips of 4352 B) the waves past EFIT take theirs from the spare LDS behind the ring (launch_p sizes it)
+    constexpr int EFIT = STAGEB / EWB < NW ? STAGEB / EWB : NW;
+    (void)UNEVEN;
     extern __shared__ __attribute__((aligned(1024))) char smemg[];
     constexpr unsigned OOB = 0x80000000u;
 
@@ -537,10 +538,10 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, OCC) void conv_f16_persist_ker
     const int wm = wave / WN, wn = wave % WN;
     const int lr = lane & 31, lh = lane >> 5;
     const int swz = lr * 128 + ((lh ^ ((lr >> 1) & 7)) << 4);  // k-step s adds ^ (s << 5)
-    const int a_off = wm * TM * 32 * 128;
+    const int a_off = wm * WR * 128;
     const int b_off = BM * 128 + wn * TN * 32 * 128;
-    typedef typename std::conditional<MS == 0, f32x16h[TM][TN], f32x4h[2 * TM][2 * TN]>::type acc_t;
-    constexpr int NA = MS ? 2 * TM : TM, NC = MS ? 2 * TN : TN, NE = MS ? 4 : 16;   // accumulator blocks down / across, registers per block
+    constexpr int NA = WR / 16, NC = 2 * TN, NE = 4;   // accumulator blocks down / across, registers per block
+    typedef f32x4h acc_t[NA][NC];
     acc_t acc;
     const int swz16 = (lane & 15) * 128 + (((lane >> 4) ^ (((lane & 15) >> 1) & 7)) << 4);   // 16 x 16 x 32 form: 32-deep step s adds ^ (s << 6)
     auto chunk = [&](int rd) {  // run-time stage: branching over compile-time stages made hipcc copy and spill the accumulators
@@ -583,12 +584,12 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, OCC) void conv_f16_persist_ker
             for (int b = 0; b < NC; ++b)
 #pragma unroll
                 for (int e = 0; e < NE; ++e) acc[a][b][e] = 0.0f;
-        Epi8<TM, TN> E;
+        Epi8<WR, TN> E;
         {
             karg_t k1 = kp0;
             asm volatile("" : "+s"(k1));
             const ConvKH& p = *(const ConvKH*)k1;
-            if (p.vec_epi) epi8_prefetch<TM, TN, UP2X>(p, E, lane, wm, wn, m0, n0);  // the tile's first residual strips travel under its K loop
+            if (p.vec_epi) epi8_prefetch<WR, TN, UP2X>(p, E, lane, wm, wn, m0, n0);  // the tile's first residual strips travel under its K loop
         }
         int last = 0;
         for (int t = 0; t < p_nchunks; ++t) {
@@ -601,7 +602,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, OCC) void conv_f16_persist_ker
         karg_t k2 = kp0;
         asm volatile("" : "+s"(k2));
         const ConvKH& p = *(const ConvKH*)k2;
-        if (p.vec_epi) epi8_finish<UP2X>(p, acc, E, (float*)(smemg + last * STAGEB) + wave * ESR * (TN * 32 + 4), lane, wm, wn, m0, n0);
+        if (p.vec_epi) epi8_finish<UP2X>(p, acc, E, (float*)(wave < EFIT ? smemg + last * STAGEB + wave * EWB : smemg + NSTAGE * STAGEB + (wave - EFIT) * EWB), lane, wm, wn, m0, n0);
         else conv_f16_epilogue(p, acc, smemg, wave, lane, wm, wn, m0, n0);  // per-element path: no LDS
     }
 }

@@ -631,12 +631,20 @@ int yolact_forward(Engine& e, const float* d_images, int N) {
                 TRY(eng_bottleneck_f16(e, nm, x, b == 0, out_name, &y, &fused));
                 if (fused) { x = y; continue; }
             }
+            const bool pair = b == 0 && !dt && e.param("conv_groups", 1.0f) != 0.0f && e.param("conv_tile", 0) == 0.0f;
+            if (pair) {  // fp32: the projection shortcut and conv1 read the same x: one grouped launch (round 5) instead of a side stream
+                std::vector<ConvGroupItem> g(2);
+                g[0].layer = nm + ".conv1"; g[0].in = x; g[0].act = 1; g[0].out_name = sg + ".t1"; g[0].out = &t1;
+                g[1].layer = nm + ".downsample.0"; g[1].in = x; g[1].stride = st; g[1].out_name = nm + ".ds"; g[1].out = &idt;
+                TRY(eng_conv_group(e, g));
+            } else {
             if (b == 0) {  // the projection shortcut is independent of conv1 -> conv2: side stream
                 TRY(eng_fork(e, 0));
                 SideScope sc(e, 0);
                 TRY(eng_conv(e, nm + ".downsample.0", x, st, 0, 0, nullptr, nm + ".ds", &idt));
             }
             TRY(eng_conv(e, nm + ".conv1", x, 1, 0, 1, nullptr, sg + ".t1", &t1));
+            }
             if (e.convs.count(nm + ".conv2.conv_offset_mask")) {
                 // DCNv2 3x3 (YOLACT++ backbones): offsets + mask logits from a plain 3x3 -> the nine taps sampled into columns ->
                 // the deformable conv proper as a 1x1 over 9*C channels (weights handed over in KRSC order, bias folded into BN)
@@ -649,7 +657,7 @@ int yolact_forward(Engine& e, const float* d_images, int N) {
             } else {
                 TRY(eng_conv(e, nm + ".conv2", t1, st, 1, 1, nullptr, sg + ".t2", &t2));
             }
-            if (b == 0) TRY(eng_join(e, 0));
+            if (b == 0 && !pair) TRY(eng_join(e, 0));
             // C3 (then C4, C5) is about to be overwritten: the previous step's lateral convs, running on the heads streams, must
             // have read them (they are the first thing of that phase, so this wait practically never blocks)
             if (li == 1 && b == blocks[1] - 1 && e.lat_pending) HIP_TRY(hipStreamWaitEvent(e.stream, e.lat_done, 0));

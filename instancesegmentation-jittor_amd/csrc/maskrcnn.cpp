@@ -145,14 +145,22 @@ int maskrcnn_forward(Engine& e, const float* d_images, int N) {
             // fp16: the identity blocks of res2 / res3 and res2's first block (projection included) are ONE launch each, t1 / t2 stay in LDS
             if (b > 0 || sd == 1) TRY(eng_bottleneck_f16(e, nm, x, b == 0, out_name, &y, &fused));
             if (!fused) {
+                const bool pair = b == 0 && !dt && e.param("conv_groups", 1.0f) != 0.0f && e.param("conv_tile", 0) == 0.0f;
+                if (pair) {  // fp32: the projection shortcut and conv1 read the same x: one grouped launch (round 5) instead of a side stream
+                    std::vector<ConvGroupItem> g(2);
+                    g[0].layer = nm + ".conv1"; g[0].in = x; g[0].stride = sd; g[0].act = 1; g[0].out_name = sg + ".t1"; g[0].out = &t1;
+                    g[1].layer = nm + ".downsample.0"; g[1].in = x; g[1].stride = sd; g[1].out_name = nm + ".ds"; g[1].out = &idt;
+                    TRY(eng_conv_group(e, g));
+                } else {
                 if (b == 0) {  // projection shortcut on a side stream, concurrent with conv1 -> conv2
                     TRY(eng_fork(e, 0));
                     SideScope sc(e, 0);
                     TRY(eng_conv(e, nm + ".downsample.0", x, sd, 0, 0, nullptr, nm + ".ds", &idt));
                 }
                 TRY(eng_conv(e, nm + ".conv1", x, sd, 0, 1, nullptr, sg + ".t1", &t1));  // STRIDE_IN_1X1
+                }
                 TRY(eng_conv(e, nm + ".conv2", t1, 1, 1, 1, nullptr, sg + ".t2", &t2));
-                if (b == 0) TRY(eng_join(e, 0));
+                if (b == 0 && !pair) TRY(eng_join(e, 0));
                 TRY(eng_conv(e, nm + ".conv3", t2, 1, 0, 1, &idt, out_name, &y));
             }
             x = y;
@@ -453,11 +461,13 @@ int maskrcnn_forward(Engine& e, const float* d_images, int N) {
         // ConvTranspose2d(2,2,s2): out[r, 2i+a, 2j+b, :] = W_ab * in[r, i, j, :] + bias  -> four strided 1x1 convs.
         Tensor rows;  // view: (r, i) as "images" of 1 x 14 pixels
         rows.d = m.d; rows.N = N * cap * 14; rows.H = 1; rows.W = 14; rows.C = 256; rows.dt = dt;
+        std::vector<ConvGroupItem> g(4);   // the four parities are independent: one grouped launch under fp32 (eng_conv_group), four launches under fp16
         for (int ab = 0; ab < 4; ++ab) {
             const int aa = ab >> 1, bb = ab & 1;
-            TRY(eng_conv_into(e, "roi_heads.mask.predictor.conv5_mask." + std::to_string(ab), rows, 1, 0, 1,
-                              (char*)up.d + (int64_t)(aa * 28 + bb) * 256 * (dt ? 2 : 4), 14, (int64_t)2 * 28 * 256, 2 * 256));
+            g[ab].layer = "roi_heads.mask.predictor.conv5_mask." + std::to_string(ab); g[ab].in = rows; g[ab].act = 1;
+            g[ab].dst = (char*)up.d + (int64_t)(aa * 28 + bb) * 256 * (dt ? 2 : 4); g[ab].out_div = 14; g[ab].out_img_stride = (int64_t)2 * 28 * 256; g[ab].out_pix_stride = 2 * 256;
         }
+        TRY(eng_conv_group(e, g));
     }
     const RawBuf *lw, *lb;
     TRY(need_tensor(e, "mask_logits.w", (int64_t)ncls * 256 * 4, &lw));
