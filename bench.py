@@ -74,7 +74,7 @@ def parse():
     ap.add_argument("--no-r101f16", action="store_true", help="default yolact run: skip the extra Mask R-CNN R101-FPN fp16 bs=8 measurement (configs[4] per-GPU shape)")
     ap.add_argument("--no-box", action="store_true", help="skip the ~0.1 s box calibration (bare MFMA / copy loops)")
     ap.add_argument("--allow-stale-traffic", action="store_true", help="roofline.traffic may come from an older round's committed PMC summary")
-    ap.add_argument("--f16-mfma-shape", type=int, default=-1, choices=[-1, 0, 1, 2], help="A/B: isegmi_set_f16_mfma_shape (0: 32x32x16 everywhere, 1: row strips on 16x16x32 (library default), 2: persistent tiles too)")
+    ap.add_argument("--f16-mfma-shape", type=int, default=-1, choices=[-1, 0, 1, 2, 3], help="A/B: isegmi_set_f16_mfma_shape (0: 32x32x16 everywhere, 1: row strips on 16x16x32, 2: persistent tiles too, 3 (library default): 1 + the 144-row tiles)")
     ap.add_argument("--no-h2d", action="store_true", help="skip the extra timed loops (batch resident in HBM; fp32 upload)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end loop (uint8 upload -> ... -> RLE -> record block on the host)")
     ap.add_argument("--param", action="append", default=[], metavar="NAME=VALUE", help="engine parameter for A/B runs (isegmi_engine_set_param), repeatable")

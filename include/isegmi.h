@@ -135,12 +135,13 @@ int isegmi_op_pad_c3_to_f16_halo(const float* d_in_nhwc3, int N, int H, int W, v
 int isegmi_op_stem_pool_f16(int N, int H, int W, const void* d_halo, const void* d_w, const float* d_scale, const float* d_shift, void* d_out,
                             int flags, void* stream);
 
-/* MFMA shape of the fp16 backbone tiles (process-wide tuning knob): 0: v_mfma_f32_32x32x16_f16 everywhere; 1 (default): the 192 x 256 row-strip tile of the
- * 3x3 layers and the fused RPN head on v_mfma_f32_16x16x32_f16 (same output tile per wave, same LDS images; the chip holds a higher clock on it in
- * power-bound loops: +8 % on the 634-GF layer); 2: the persistent 192 x 256 / 256 x 128 / 128 x 256 tiles and the UP2X merge as well (memory-bound: no gain).
+/* MFMA shape of the fp16 backbone tiles (process-wide tuning knob): 0: v_mfma_f32_32x32x16_f16 everywhere; 1: the 192 x 256 row-strip tile of the 3x3
+ * layers and the fused RPN head on v_mfma_f32_16x16x32_f16 (same output tile per wave, same LDS images; the chip holds a higher clock on it in power-bound
+ * loops: +8 % on the 634-GF layer); 2: 1 + the persistent 192 x 256 / 256 x 128 / 128 x 256 tiles and the UP2X merge (memory-bound: no gain); 3 (default):
+ * 1 + the 144-row forms (48-row wave tiles, possible with 16 x 16 blocks only) for Cout <= 256 layers whose 192-row tiles leave CUs idle in one round.
  * RESULTS DO NOT DEPEND ON THE SHAPE: one 16 x 16 x 32 instruction sums its 32 products bit for bit as two chained 32 x 32 x 16 instructions do
  * (tools/microbench/mfma_shape.hip), so every fused-vs-unfused bit identity of the fp16 family holds under any setting.
- * conv tile ids 40 / 44 / 47 / 49 force the 16 x 16 x 32 form of 30 / 34 / 37 / 39 for one launch. */
+ * conv tile ids 40 / 44 / 47 / 49 force the 16 x 16 x 32 form of 30 / 34 / 37 / 39 for one launch, 41 / 46 the 144-row forms of 40 / 47. */
 int isegmi_set_f16_mfma_shape(int shape);
 int isegmi_get_f16_mfma_shape(int* shape);
 

@@ -83,8 +83,8 @@ struct ConvKH {
 // Epilogue: each wave transposes its fp32 strip through LDS and stores / loads the residual 16 B per lane.
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-// the 16 x 16 x 32 tiles (conv_mfma_f16_m16.hip): tile 40 = row strips 192 x 256 (three B buffers), 44 / 47 / 49 = persistent 256 x 128 / 192 x 256 / 128 x 256,
-// 48 = 47 with the UP2X residual walk.  k is filled by conv2d_f16_launch_impl exactly as for the 32 x 32 x 16 tiles.
+// the 16 x 16 x 32 tiles (conv_mfma_f16_m16.hip): tile 40 = row strips 192 x 256 (three B buffers), 41 = row strips 144 x 256, 44 / 47 / 49 = persistent
+// 256 x 128 / 192 x 256 / 128 x 256, 46 = persistent 144 x 256 (three-deep ring), 48 = 47 with the UP2X residual walk.  k is filled by conv2d_f16_launch_impl exactly as for the 32 x 32 x 16 tiles.
 int conv_f16_m16_launch(int tile, ConvKH& k, hipStream_t st, bool few);
 
 }  // namespace isegmi

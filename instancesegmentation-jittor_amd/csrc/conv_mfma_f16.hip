@@ -1146,10 +1146,10 @@ static int launch_p(ConvKH& k, hipStream_t st, bool few) {
     return ISEGMI_OK;
 }
 
-// 0: v_mfma_f32_32x32x16_f16 everywhere; 1 (default): the row-strip tile (30 -> 40) and the fused RPN head on v_mfma_f32_16x16x32_f16; 2: the persistent tiles
-// (34 / 37 / 39 -> 44 / 47 / 49) and the UP2X merge too
-static int g_f16_mfma16 = 1;
-int conv_f16_mfma_shape(int set) { if (set >= 0) g_f16_mfma16 = set > 2 ? 2 : set; return g_f16_mfma16; }
+// 0: v_mfma_f32_32x32x16_f16 everywhere; 1: the row-strip tile (30 -> 40) and the fused RPN head on v_mfma_f32_16x16x32_f16; 2: 1 + the persistent tiles
+// (34 / 37 / 39 -> 44 / 47 / 49) and the UP2X merge; 3 (default): 1 + the 144-row forms (41 / 46) where 192-row tiles leave CUs idle in a single round
+static int g_f16_mfma16 = 3;
+int conv_f16_mfma_shape(int set) { if (set >= 0) g_f16_mfma16 = set > 3 ? 3 : set; return g_f16_mfma16; }
 static int cout_pad_h(int Cout) { return cdiv(Cout, 128) * 128; }
 static bool is_stem_h(const isegmi_conv_desc* d) { return d->Cin == 4 && d->R == 7 && d->S == 7; }
 
@@ -1270,7 +1270,7 @@ static int conv2d_f16_launch_impl(const isegmi_conv_desc* d, const void* in, con
         const int64_t rb = (int64_t)d->N * head->up_hc * head->up_wc * d->Cout * 2;
         ARG_CHECK(rb < (1ll << 31), "up2x: coarse level must be < 2 GiB");
         k.res_up2x = 1; k.rHc = head->up_hc; k.rWc = head->up_wc; k.res_bytes = (unsigned)rb;
-        if (g_f16_mfma16 >= 2) return conv_f16_m16_launch(48, k, st, few);
+        if (g_f16_mfma16 == 2) return conv_f16_m16_launch(48, k, st, few);
         return launch_p<192, 256, 3, 4, 2, 1, 4, true>(k, st, few);   // "tile 38": tile 37 with the walked residual
     }
     if (head) {
@@ -1285,14 +1285,25 @@ static int conv2d_f16_launch_impl(const isegmi_conv_desc* d, const void* in, con
     }
     // the MFMA shape of the tiles that carry the fp16 backbone: 30 / 34 / 37 / 39 run on v_mfma_f32_32x32x16_f16 (this file), 40 / 44 / 47 / 49 are the same tiles
     // on v_mfma_f32_16x16x32_f16 (csrc/conv_mfma_f16_m16.hip).  The cost model chooses among the former; g_f16_mfma16 (isegmi_set_f16_mfma_shape) maps its
-    // choice onto the latter: 1 (default) the row-strip tile and the fused head that lives on it -- +8 % on the 634-GF layer (983 -> 1062 TF/s, same box;
-    // profiles/r05_experiments.txt 1) -- 2 the persistent tiles and the UP2X merge as well (memory-bound layers: level or 1-3 % slower, kept for A/B).
+    // choice onto the latter: 1 the row-strip tile and the fused head that lives on it -- +8 % on the 634-GF layer (983 -> 1062 TF/s, same box;
+    // profiles/r05_experiments.txt 1) -- 2 the persistent tiles and the UP2X merge as well (memory-bound layers: level or 1-3 % slower, kept for A/B), 3 (default)
+    // = 1 + the 144-row forms below.
     // Results do not depend on the shape: one 16 x 16 x 32 instruction sums its 32 products exactly as two chained 32 x 32 x 16 instructions do
     // (tools/microbench/mfma_shape.hip: 0 of 204 800 elements differ).
     if (g_f16_mfma16 >= 1 && (d->tile & 255) == 0 && tile == 30) tile = 40;
-    if (g_f16_mfma16 >= 2 && (d->tile & 255) == 0) tile = tile == 34 ? 44 : tile == 37 ? 47 : tile == 39 ? 49 : tile;
-    if (tile == 40) ARG_CHECK(d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1 && 191 / d->W + 2 <= 32, "strip tiles are for 3x3 / stride 1 / pad 1, <= 32 image-row segments");
-    if (tile == 40 || tile == 44 || tile == 47 || tile == 49) return conv_f16_m16_launch(tile, k, st, few);
+    if (g_f16_mfma16 == 2 && (d->tile & 255) == 0) tile = tile == 34 ? 44 : tile == 37 ? 47 : tile == 39 ? 49 : tile;
+    // 144-row forms (16 x 16 blocks allow 48-row wave tiles): where the 192-row tiles of a Cout <= 256 layer leave CUs idle in their last round and
+    // 144-row tiles fill it better -- M = 33 600, res4 / P4 at bs 8: 175 -> 234 tiles on 256 CUs, each 3/4 of the work: 0.046 -> 0.040 ms -- the
+    // row-strip tile runs as 41 and the persistent 192 x 256 tile of a 1x1 layer as 46 (three-deep ring: 3 x 51 200 B)
+    if (g_f16_mfma16 == 3 && (d->tile & 255) == 0 && !head && d->Cout <= 256 && (tile == 40 || tile == 37)) {
+        const int ncu = device_cu_count();
+        // rounds x rows: M = 33 600 one round either way (192 -> 144 rows per CU); the mask head's M = 156 800: 817 tiles = 4 rounds of 192 against 1089 = 5
+        // rounds of 144 (768 -> 720, measured +3.5 %); P3's M = 134 400 ties (576 = 576) and keeps the larger tile
+        const int b192 = cdiv(k.M, 192), b144 = cdiv(k.M, 144);
+        if (cdiv(b144, ncu) * 144 < cdiv(b192, ncu) * 192 && (tile != 40 || 143 / d->W + 2 <= 32)) tile = tile == 40 ? 41 : 46;
+    }
+    if (tile == 40 || tile == 41) ARG_CHECK(d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1 && (tile == 40 ? 191 : 143) / d->W + 2 <= 32, "strip tiles are for 3x3 / stride 1 / pad 1, <= 32 image-row segments");
+    if (tile == 40 || tile == 41 || tile == 44 || tile == 46 || tile == 47 || tile == 49) return conv_f16_m16_launch(tile, k, st, few);
     if (tile >= 26 && tile <= 31) {
         ARG_CHECK(d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1, "strip tiles are for 3x3 / stride 1 / pad 1");
         const int bm = tile == 27 ? 256 : tile == 28 ? 160 : 192;
@@ -1393,7 +1404,7 @@ extern "C" int isegmi_op_conv2d_f16(const isegmi_conv_desc* d, const void* d_in,
 }
 
 extern "C" int isegmi_set_f16_mfma_shape(int shape) {
-    ARG_CHECK(shape >= 0 && shape <= 2, "0: v_mfma_f32_32x32x16_f16 everywhere, 1: row strips on v_mfma_f32_16x16x32_f16, 2: persistent tiles too");
+    ARG_CHECK(shape >= 0 && shape <= 3, "0: v_mfma_f32_32x32x16_f16 everywhere, 1: row strips on v_mfma_f32_16x16x32_f16, 2: persistent tiles too, 3: 1 + 144-row forms");
     conv_f16_mfma_shape(shape);
     return ISEGMI_OK;
 }

@@ -221,7 +221,7 @@ __device__ __forceinline__ void conv_f16_epilogue(const ConvKH& p, ACC& acc, cha
 // inside step 0's last row.  sched_barrier pins this placement (left alone, hipcc sinks every reload to just in front of its first use).
 template <int NA, int NC>
 __device__ __forceinline__ void mfma16_chunk(f32x4h (&acc)[NA][NC], const char* sa, const int (&oa)[NA], const int (&oa1)[NA], const char* sb, int ob, int ob1) {
-    static_assert(NA % 2 == 0 && NA >= 2, "two A sets alternate over an even number of block rows");
+    static_assert(NA >= 2, "two A sets alternate over the chunk's 2 NA block rows");
     f16x8 fa[2], fb[NC];
     fa[0] = *(const f16x8*)(sa + oa[0]);
 #pragma unroll
@@ -484,12 +484,16 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, OCC) void conv_f16_persist_ker
             const unsigned soffb = (unsigned)in_tile * 128u;
 #pragma unroll
             for (int i = 0; i < PPA; ++i) {
-                if (PA % NL != 0 && lw + i * NL >= PA) continue;  // wave-uniform
+                // a wave without a piece in the partial last round (144 rows = 18 pieces over 4 loaders) sends a DROPPED one (zero-length descriptor: zeros
+                // land in the wave's own dummy KiB behind the ring) so that every wave's vmcnt count per chunk stays PP (wave-uniform branch)
+                const bool dummy = PA % NL != 0 && lw + i * NL >= PA;
                 // (named operands: hipcc 7.2 silently drops the host stub of the kernel when this builtin takes expressions)
-                const __amdgpu_buffer_rsrc_t rs = live ? rs_in : rs_in0;
+                const __amdgpu_buffer_rsrc_t rs = (live && !dummy) ? rs_in : rs_in0;
                 const unsigned voff = avoff[i];
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(sA + (lw + i * NL) * 1024), 16, voff, soffa, 0, CONV_F16_A_AUX);
+                char* dstp = dummy ? smemg + NSTAGE * STAGEB + 5120 + lw * 1024 : sA + (lw + i * NL) * 1024;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)dstp, 16, voff, soffa, 0, CONV_F16_A_AUX);
             }
+            static_assert(PB % NL == 0, "whole B piece rounds");
 #pragma unroll
             for (int j = 0; j < PPB; ++j) {
                 if (PB % NL != 0 && lw + j * NL >= PB) continue;
@@ -616,8 +620,8 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, OCC) void conv_f16_persist_ker
 // P2 level at R101 bs=8) nor read back.  Bit-identical to the two launches (tests/test_rpn_head_f16_gpu.py).
 template <class ACC>
 __device__ __forceinline__ void conv_f16_epilogue_head(const ConvKH& p, ACC& acc, char* smemg, int wave, int lane, int wm, int wn, int m0) {
-    constexpr int TM = acc_traits<ACC>::TM, TN = acc_traits<ACC>::TN, MS = acc_traits<ACC>::MS;
-    constexpr int RB = MS ? 16 : 32, NE = MS ? 4 : 16, NA = TM * 32 / RB, NC = TN * 32 / RB;
+    constexpr int TN = acc_traits<ACC>::TN, MS = acc_traits<ACC>::MS, NA = acc_traits<ACC>::NA, NC = acc_traits<ACC>::NC, WR = acc_traits<ACC>::WR;
+    constexpr int RB = MS ? 16 : 32, NE = MS ? 4 : 16;
     constexpr unsigned OOB = 0x80000000u;
     constexpr int BMH = 192, T_BYTES = BMH * 512;   // the tile image; the head's weights follow it (32 rows x 512 B)
     const int lr = lane & 31, lh = lane >> 5;
@@ -638,7 +642,7 @@ __device__ __forceinline__ void conv_f16_epilogue_head(const ConvKH& p, ACC& acc
             const float sc = p.scale ? p.scale[co] : 1.0f, sh = p.shift ? p.shift[co] : 0.0f;
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
-                const int row = wm * TM * 32 + a * RB + (MS ? 4 * (lane >> 4) + e : (e & 3) + 8 * (e >> 2) + 4 * lh);
+                const int row = wm * WR + a * RB + (MS ? 4 * (lane >> 4) + e : (e & 3) + 8 * (e >> 2) + 4 * lh);
                 float y = fmaf(acc[a][b][e], sc, sh);
                 y = y > 0.0f ? y : 0.0f;
                 *(half_t*)(smemg + row * 512 + (((co >> 3) ^ (row & 15)) << 4) + (co & 7) * 2) = (half_t)y;
@@ -711,7 +715,8 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, 1) void conv3x3_f16_strip_kern
     static_assert(NB == 2 || (NB == 3 && LW > 0 && (BN / 8) % LW == 0), "the three-buffer form needs loader waves and whole B piece rounds");
     constexpr int NW = WM * WN;
     constexpr int NL = LW > 0 ? LW : NW;            // waves that issue loads (LW > 0: dedicated loader waves, see above)
-    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    static_assert(MS == 1 && (BM / WM) % 16 == 0 && BM % WM == 0, "16 x 16 x 32: a wave owns a whole number of 16-row blocks");
+    constexpr int WR = BM / WM, TM = (WR + 31) / 32, TN = BN / WN / 32;   // rows per wave; (TM: placeholder of the uninstantiated 32 x 32 x 16 branch)
     constexpr int SR_CAP = BM + 64;                 // strip rows: BM + 2 per image-row segment (<= 32 segments)
     constexpr int SP = SR_CAP / 8, PB = BN / 8;     // 1-KiB pieces: strip, B chunk
     constexpr int SP3 = (SP + 2) / 3;               // strip pieces issued per step (a third of the strip)
@@ -835,8 +840,8 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, 1) void conv3x3_f16_strip_kern
         if (++b_s == 3) { b_s = 0; if (++b_kc == p.cin_chunks) { b_kc = 0; ++b_r; } }
     };
 
-    typedef typename std::conditional<MS == 0, f32x16h[TM][TN], f32x4h[2 * TM][2 * TN]>::type acc_t;
-    constexpr int NA = MS ? 2 * TM : TM, NC = MS ? 2 * TN : TN, NE = MS ? 4 : 16, RBLK = MS ? 16 : 32;   // accumulator blocks down / across, registers per block, block rows
+    constexpr int NA = WR / 16, NC = 2 * TN, NE = 4, RBLK = 16;   // accumulator blocks down / across, registers per block, block rows
+    typedef f32x4h acc_t[NA][NC];
     acc_t acc;
 #pragma unroll
     for (int a = 0; a < NA; ++a)
@@ -851,7 +856,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, 1) void conv3x3_f16_strip_kern
     int abase_s[NA][3];
 #pragma unroll
     for (int a = 0; a < NA; ++a) {
-        const int m = m0 + wm * TM * 32 + a * RBLK + lr;
+        const int m = m0 + wm * WR + a * RBLK + lr;
         const int jm = (m - m0) + 1 + 2 * (m / W - row0);
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
@@ -958,6 +963,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, 1) void conv3x3_f16_strip_kern
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     STRIP_TRACE(63, 0);
+    (void)TM;
     if constexpr (BM == 192 && BN == 256 && WM == 3 && WN == 4 && NB == 3) {
         if (p.f_w) { conv_f16_epilogue_head(p, acc, smemg, wave, lane, wm, wn, m0); return; }   // uniform
     }
@@ -979,7 +985,7 @@ static int launch_strip(ConvKH& k, hipStream_t st) {
     constexpr int NW = WM * WN, TN = BN / WN / 32;
     size_t lds = 2 * (size_t)(BM + 64) * 128 + NB * (size_t)BN * 128;
     static_assert(2 * (BM + 64) * 128 + NB * BN * 128 <= 163840, "LDS");
-    const size_t epi = (size_t)NW * 32 * (TN * 32 + 4) * 4;
+    const size_t epi = (size_t)NW * 16 * (TN * 32 + 4) * 4;
     if (epi > lds) lds = epi;
     size_t lds_attr = lds;
 #ifdef ISEGMI_STRIP_TRACE
@@ -1023,8 +1029,10 @@ static int launch_p(ConvKH& k, hipStream_t st, bool few) {
     k.ntiles = cdiv(k.Cout, BN);
     constexpr int NW = WM * WN, TN = BN / WN / 32;
     size_t lds = (size_t)NSTAGE * (BM + BN) * 128;
-    const size_t epi = (size_t)NW * 32 * (TN * 32 + 4) * 4;  // the per-element epilogue path uses none; kept >= the one-tile kernel's request
-    (void)epi;
+    // behind the ring: 5120 B for the strip scratch of the waves that do not fit the last stage, LW KiB of landing zone for dropped pieces
+    // (conv_f16_persist_kernel: EFIT, issue_chunk) -- only where the tile needs them
+    if ((BM / 8) % LW != 0 || (size_t)NW * 16 * (TN * 32 + 4) * 4 > (size_t)(BM + BN) * 128) lds += 5120 + (size_t)LW * 1024;
+    static_assert(NSTAGE * (BM + BN) * 128 + 5120 + LW * 1024 <= 163840 || ((BM / 8) % LW == 0 && NW * 16 * (TN * 32 + 4) * 4 <= (BM + BN) * 128), "LDS");
     static PerDeviceOnce attr;
     if (attr.need()) HIP_TRY(hipFuncSetAttribute((const void*)conv_f16_persist_kernel<BM, BN, WM, WN, NSTAGE, OCC, LW, UP2X, MS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int ncu = device_cu_count();
@@ -1041,6 +1049,8 @@ static int launch_p(ConvKH& k, hipStream_t st, bool few) {
 int conv_f16_m16_launch(int tile, ConvKH& k, hipStream_t st, bool few) {
     switch (tile) {
         case 40: return launch_strip<192, 256, 3, 4, 4, 3, 1>(k, st);
+        case 41: return launch_strip<144, 256, 3, 4, 4, 3, 1>(k, st);                 // 12 MFMA waves of 48 x 64: M = 33 600 (res4 at bs 8) is 234 tiles, one round
+        case 46: return launch_p<144, 256, 3, 4, 3, 1, 4, false, 1>(k, st, few);      // the same rows for the 1x1 layers, three-deep ring
         case 44: return launch_p<256, 128, 4, 2, 3, 1, 4, false, 1>(k, st, few);
         case 47: return launch_p<192, 256, 3, 4, 2, 1, 4, false, 1>(k, st, few);
         case 48: return launch_p<192, 256, 3, 4, 2, 1, 4, true, 1>(k, st, few);

@@ -59,8 +59,8 @@ def sync():
 
 
 def set_f16_mfma_shape(shape):
-    """0: v_mfma_f32_32x32x16_f16 everywhere; 1 (default): row strips + fused RPN head on v_mfma_f32_16x16x32_f16; 2: persistent tiles too
-    (process-wide; isegmi_set_f16_mfma_shape).  Results are bit-identical under every setting."""
+    """0: v_mfma_f32_32x32x16_f16 everywhere; 1: row strips + fused RPN head on v_mfma_f32_16x16x32_f16; 2: persistent tiles too; 3 (default): 1 + the
+    144-row tiles (process-wide; isegmi_set_f16_mfma_shape).  Results are bit-identical under every setting."""
     check(lib().isegmi_set_f16_mfma_shape(int(shape)))
 
 

@@ -19,14 +19,14 @@ CASES = [(2, 19, 23, 64, 48, 3, 1, 1), (3, 14, 14, 128, 96, 3, 1, 1), (1, 30, 30
 PERSIST = [32, 34, 37, 39]
 # round 5: the row-strip tile (40 = 30) and the persistent tiles (44 / 47 / 49 = 34 / 37 / 39) on v_mfma_f32_16x16x32_f16 (csrc/conv_mfma_f16_m16.hip):
 # against the oracle here, and bit-identical to their 32 x 32 x 16 twins below
-M16 = [40, 44, 47, 49, 2048 + 44, 2048 + 47, 2048 + 49]
+M16 = [40, 41, 44, 46, 47, 49, 2048 + 44, 2048 + 46, 2048 + 47, 2048 + 49]   # (41 / 46: the 144-row forms, 48-row wave tiles)
 
 
 @pytest.mark.parametrize("case", CASES)
 @pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 17, 19, 20, 26, 27, 28, 29, 30, 31] + PERSIST + [2048 + t for t in PERSIST] + M16)
 def test_conv_f16_close_to_oracle(ffi, case, tile):
     N, H, W, Cin, Cout, R, stride, pad = case
-    strip = 26 <= tile <= 31 or tile == 40
+    strip = 26 <= tile <= 31 or tile in (40, 41)
     if strip and not (R == 3 and stride == 1 and pad == 1):
         pytest.skip("row-strip tiles are 3x3 / stride 1 / pad 1 only")
     if strip and W < 9:
@@ -74,7 +74,7 @@ def test_stem_f16_close_to_oracle(ffi, shape, tile):
 
 
 @pytest.mark.parametrize("case", [(2, 100, 168, 256, 256, 3, 1, 1), (1, 50, 84, 1024, 256, 1, 1, 0), (2, 50, 84, 256, 1024, 1, 1, 0), (1, 100, 168, 128, 512, 1, 1, 0),
-                                  (1, 40, 56, 256, 256, 3, 1, 1)])
+                                  (1, 40, 56, 256, 256, 3, 1, 1), (8, 50, 84, 256, 256, 3, 1, 1), (8, 50, 84, 1024, 256, 1, 1, 0)])
 def test_mfma_shape_does_not_change_results(ffi, case):
     """One v_mfma_f32_16x16x32_f16 sums its 32 products bit for bit as two chained v_mfma_f32_32x32x16_f16 do (tools/microbench/mfma_shape.hip), and the
     16 x 16 x 32 tiles walk K in the order of their 32 x 32 x 16 twins: every tile pair, and tile 0 under every isegmi_set_f16_mfma_shape setting, is
@@ -85,16 +85,16 @@ def test_mfma_shape_does_not_change_results(ffi, case):
     w = (rng.standard_normal((Cout, R, R, Cin)) * (2.0 / (R * R * Cin)) ** 0.5).astype(np.float16).astype(np.float32)
     sc = rng.uniform(0.5, 1.5, Cout).astype(np.float32); sh = (rng.standard_normal(Cout) * 0.1).astype(np.float32)
     res = rng.standard_normal((N, H, W, Cout)).astype(np.float16)
-    assert ffi.get_f16_mfma_shape() == 1, "the default: row strips on 16 x 16 x 32"
+    assert ffi.get_f16_mfma_shape() == 3, "the default: row strips on 16 x 16 x 32 + the 144-row forms"
     for act, r, f32 in ((1, res, False), (0, None, False), (0, None, True)):
         run = lambda t: ffi.conv2d_f16(x, w, stride, pad, sc, sh, r, act, t, out_f32=f32)
-        for a, b in (((30, 40),) if R == 3 else ((34, 44), (37, 47), (39, 49), (2048 + 37, 2048 + 47))):
+        for a, b in (((30, 40), (40, 41)) if R == 3 else ((34, 44), (37, 47), (39, 49), (2048 + 37, 2048 + 47), (47, 46), (2048 + 47, 2048 + 46))):
             assert np.array_equal(run(a), run(b)), (a, b, act, f32)
         outs = []
-        for shape in (0, 1, 2):
+        for shape in (0, 1, 2, 3):
             ffi.set_f16_mfma_shape(shape)
             try:
                 outs.append(run(0))
             finally:
-                ffi.set_f16_mfma_shape(1)
-        assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+                ffi.set_f16_mfma_shape(3)
+        assert all(np.array_equal(outs[0], o) for o in outs[1:])
