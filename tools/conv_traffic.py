@@ -14,7 +14,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CONV_KERNELS = ("conv_mfma", "conv_hybrid_kernel", "conv_f16_glds_kernel", "conv_f16_persist_kernel", "conv3x3_f16_strip_kernel", "bottleneck_f16_kernel", "stem_pool_f16_kernel")
+CONV_KERNELS = ("conv_mfma", "conv_hybrid_kernel", "conv_group_kernel", "conv_f16_glds_kernel", "conv_f16_persist_kernel", "conv3x3_f16_strip_kernel", "bottleneck_f16_kernel", "stem_pool_f16_kernel")
 STEPS_WARM, STEPS_AFTER = 2, 3
 
 

@@ -1,5 +1,9 @@
 """Counter bytes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes) of the HBM-bound stages bench.py times (roofline_hbm), per STEP:
-   python tools/hbm_stage_traffic.py <fetch_dir> <write_dir> <steps in the profiled run> <out.json>
+   python tools/hbm_stage_traffic.py <fetch_dir> <write_dir> <forward steps of the profiled process> <out.json>
+<forward steps> = EVERY forward the profiled process ran: tools/profile_round.sh runs bench.py with --warmup 2 --steps 10 and bench.py adds its
+single-stream roofline pass of another 10 steps: 22.  (Round 4 passed 12: every figure it wrote is 22 / 12 = 1.83x too large -- the "1.6-1.9x
+counter-over-algorithmic bytes" of RoIAlign and mask_logits_select in VERDICT r4 were this divisor, not over-fetch.)  A stage kernel that runs a fixed
+number of times per forward must divide evenly: checked.
 Stages that map to kernels of their own are summed by kernel name; stages built from shared kernels (top-k, NMS) are left out (null in the bench
 line).  bytes = 2 x FETCH_SIZE + WRITE_SIZE (KB -> B): the gfx950 wide-read correction is calibrated for 16 B per lane loads -- RoIAlign's gathers,
 the mask / paste kernels' vector loads -- and an upper bound where a kernel reads narrower."""
@@ -30,11 +34,13 @@ def main():
         tot, found = 0.0, False
         for kname, which in parts:
             for k in f:
-                if k.startswith(kname):
+                if k.startswith(kname) or ("isegmi" in k and kname in k):   # (some kernels reach the CSV under their mangled names)
                     fv, wv = f[k], w.get(k, [0.0] * len(f[k]))
                     per = len(fv) // steps if steps else 0
                     if per == 0:
                         continue
+                    if which is not None and len(fv) % steps != 0:
+                        raise SystemExit("%s: %d launches do not divide over %d forward steps -- wrong step count?" % (k, len(fv), steps))
                     idx = range(len(fv)) if which is None else [i for i in range(len(fv)) if i % per == which]
                     tot += sum(2 * fv[i] + wv[i] for i in idx) / steps
                     found = True

@@ -33,7 +33,7 @@ def main():
         fb = f[k][1] / nl * 1024.0
         wb = w[k][1] / max(w[k][0], 1) * 1024.0
         out["kernels"][k] = {"launches": nl, "fetch_bytes_raw": round(fb), "fetch_bytes_corrected": round(2 * fb), "write_bytes": round(wb)}
-        if any(t in k for t in ("conv_mfma", "conv_hybrid_kernel", "conv_f16_glds_kernel", "conv_f16_persist_kernel", "conv3x3_f16_strip_kernel", "bottleneck_f16_kernel", "stem_pool_f16_kernel")):  # every conv launch bench.py times
+        if any(t in k for t in ("conv_mfma", "conv_hybrid_kernel", "conv_group_kernel", "conv_f16_glds_kernel", "conv_f16_persist_kernel", "conv3x3_f16_strip_kernel", "bottleneck_f16_kernel", "stem_pool_f16_kernel")):  # every conv launch bench.py times
             cf += f[k][1] * 1024.0
             cw += w[k][1] * 1024.0
             n += nl

@@ -10,7 +10,7 @@ tag=$1; shift
 root=$(pwd)
 out=$root/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-args="$root/bench.py $* --steps 10 --warmup 2 --no-cpu-baseline --no-latency --no-maskrcnn --no-h2d --no-e2e"
+args="$root/bench.py $* --steps 10 --warmup 2 --no-cpu-baseline --no-latency --no-maskrcnn --no-h2d --no-e2e --no-box"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_${tag}_stats -o run -- python3 $args --single-stream > $out/prof_${tag}_stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/prof_${tag}_fetch -o run -- python3 $args > $out/prof_${tag}_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/prof_${tag}_write -o run -- python3 $args > $out/prof_${tag}_write.log 2>&1
