@@ -305,3 +305,76 @@ def test_inference_schedule_world8_with_empty_steps_and_overflow_redo(monkeypatc
     if n_img >= 16:
         assert preds[0].model.redone >= 1, "the fixture is meant to overflow the initial capacity"
         assert len(set(ex.sizes)) >= 2, "the block size grew in step on every rank"
+
+
+# ------------------------------------------------------------------------------------------------ bench.py's N > 1 harness at world 8 (no GPU)
+_BENCH_WORKER = r'''
+import os, sys, types
+sys.path[:0] = [%(root)r, %(pkg)r]
+import numpy as np
+import torch, torch.distributed as td
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+td.init_process_group("gloo", init_method="tcp://127.0.0.1:%(gloo_port)d", rank=rank, world_size=world)
+from isegmi import _ffi, dist as idist
+_ffi.set_device = lambda i: None          # no HIP device here: the harness logic is what runs
+log = []
+class FakeGather:                          # RcclGather's surface as bench.Dist uses it, on gloo
+    SLOTS = 2
+    made = 0
+    def __init__(self, rank, world, uid, nbytes):
+        assert len(uid) == 128
+        FakeGather.made += 1
+        self.rank, self.world, self.nbytes, self.capacity, self.init_seconds, self.uid = rank, world, int(nbytes), int(nbytes), 0.01, bytes(uid)
+    @staticmethod
+    def unique_id():
+        return bytes([42]) * 128
+    def allgather_bytes(self, data):
+        a = torch.frombuffer(bytearray(data), dtype=torch.uint8)
+        assert 0 < a.numel() <= self.capacity
+        out = [torch.empty_like(a) for _ in range(self.world)]
+        td.all_gather(out, a)
+        log.append(("ctl", a.numel()))
+        return np.stack([o.numpy() for o in out])
+    def resize(self, n):
+        self.nbytes = int(n); self.capacity = max(self.capacity, self.nbytes); log.append(("resize", int(n)))
+    def wait(self): pass
+    def close(self): log.append(("close",))
+idist.RcclGather = FakeGather
+import bench
+a = types.SimpleNamespace(gpus=world)
+d = bench.Dist(a)
+assert d.on and d.rank == rank and d.world == world
+d.barrier()
+m = d.max(1.0 + rank)                      # MAX over ranks of the wall time
+assert m == float(world), m
+g1 = d.make_gather(123456)                 # the record blocks of the timed loops
+g2 = d.make_gather(7890123)                # the COCO blocks of the end-to-end loop: the SAME communicator, re-sized
+assert g1 is g2 and g1.nbytes == 7890123 and FakeGather.made == 1, "one communicator per rank"
+assert g1.uid == bytes([42]) * 128         # rank 0's id reached this rank through the TCP rendezvous
+info = d.info()
+assert info["rccl_communicators_per_rank"] == 1 and [r["rank"] for r in info["ranks"]] == list(range(world))
+assert [r["device_id"] for r in info["ranks"]] == list(range(world))
+d.barrier()
+d.close()
+assert log[-1] == ("close",)
+# every rank issued the same sequence of collectives and re-sizes
+seq = repr([x for x in log]).encode()
+allseq = [None] * world
+td.all_gather_object(allseq, seq)
+assert len(set(allseq)) == 1, "ranks disagree about the order of collectives"
+open(os.path.join(%(out)r, "ok%%d" %% rank), "w").write("ok")
+td.destroy_process_group()
+'''
+
+
+def test_bench_dist_harness_world8_one_communicator(tmp_path):
+    """bench.py's N > 1 harness (class Dist) at the world size the driver will use, on gloo: the ranks meet through the package's own TCP rendezvous ONCE,
+    hold ONE communicator each (control words, record blocks and COCO blocks share it), issue the same sequence of collectives, and the N > 1 JSON keys
+    (`rccl_communicators_per_rank`, `ranks`) come out as documented.  (ADVICE r4: the three-communicator harness had never run with more than one rank.)"""
+    pytest.importorskip("torch")
+    w = tmp_path / "w.py"
+    w.write_text(_BENCH_WORKER % dict(root=ROOT, pkg=PKG, gloo_port=_free_port_base(), out=str(tmp_path)))
+    env = dict(os.environ, PYTHONPATH=PKG, OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "isegmi.launch", "--nproc", "8", "--timeout", "240", str(w)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert all((tmp_path / ("ok%d" % i)).exists() for i in range(8))
