@@ -113,6 +113,12 @@ def test_maskrcnn_upload_u8_equals_oracle_to_image_list():
     s_dev = net.fetch("det.score", n).copy()
     net.upload(ref, hw); net.forward_device(n); net.sync()
     assert np.array_equal(s_dev, net.fetch("det.score", n))
+    # images of one size go through ONE front-end launch for the batch (round 5): same result
+    same = [rng.integers(0, 256, (200, 333, 3), dtype=np.uint8) for _ in range(2)]
+    ref2, hw2 = ora.to_image_list(same)
+    n = net.upload_u8(same, canvas=(ref.shape[1], ref.shape[2]))
+    got2 = _fetch_input(net, n, ref.shape[1:])
+    assert np.array_equal(got2[:, : ref2.shape[1], : ref2.shape[2]], ref2) and not got2[:, ref2.shape[1]:].any() and not got2[:, :, ref2.shape[2]:].any()
     net.close()
 
 
