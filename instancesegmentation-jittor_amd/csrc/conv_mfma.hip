@@ -738,7 +738,7 @@ __device__ __forceinline__ void conv_mfma16_body(const ConvK& p, float* smem16, 
                     if (t0 + j >= p.nchunks) break;  // uniform
                     store_chunk((j + 2) % RING, st2, Steady());
                     load_chunk((j + 2) % RING);
-                    __syncthreads();
+                    if (!(EXPERIMENT_MODE & 4)) __syncthreads();   // (bit 2, timing only: the loader-wave variant without its per-chunk barrier)
                     st2 = st2 == NST - 1 ? 0 : st2 + 1;
                 }
             }
@@ -752,13 +752,20 @@ __device__ __forceinline__ void conv_mfma16_body(const ConvK& p, float* smem16, 
                 if (t0 + j >= p.nchunks) break;  // uniform
                 read_frags((j + 1) & 1, st1);
                 mma(j & 1);
-                // issue order: one fragment read in the shadow of each dependent MFMA (32 cycles apart)
+                // issue order (round 5): the chunk's fragment reads (eight ds_read2_b32) two per MFMA in the shadow of the FIRST four dependent MFMAs, so that
+                // they have landed when the wave reaches the barrier's lgkmcnt(0) behind the seventh.  One read per MFMA (round 2) issued the last two
+                // right in front of that wait: an LDS latency exposed per chunk (0.28 us per 32-k chunk against 0.13 of MFMA chain at one block per CU).
+                // CONV_LW_READS_PER_MFMA = 1 restores it for A/B.
+#ifndef CONV_LW_READS_PER_MFMA
+#define CONV_LW_READS_PER_MFMA 2
+#endif
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+                    if (s < 8 / CONV_LW_READS_PER_MFMA) __builtin_amdgcn_sched_group_barrier(0x100, CONV_LW_READS_PER_MFMA, 0);  // DS read
                 }
-                __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);   // (register-only MFMAs are not ordered by the barrier's fence: without this hipcc sinks four of them below it)
+                if (!(EXPERIMENT_MODE & 4)) __syncthreads();
                 st1 = st1 == NST - 1 ? 0 : st1 + 1;
             }
         }
