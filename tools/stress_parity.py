@@ -146,3 +146,55 @@ for it in range(max(rounds // 3, 4)):
     if rng.uniform() < 0.5: om[..., :18] = np.round(om[..., :18] * 2) / 2
     if not np.array_equal(ffi.deform_im2col(x, om, 3, 3, stride, pad, dil), ora.deform_im2col(x, om, 3, 3, stride, pad, dil)): fail(("deform", it, x.shape, stride, dil))
 print("deform_im2col ok", max(rounds // 3, 4))
+
+# ---- round 5: grouped conv launches (random member count, shapes, kinds of destination), bit-exact per member
+for it in range(max(rounds // 3, 4)):
+    n = int(rng.integers(1, 8))
+    items, refs = [], []
+    big = rng.uniform() < 0.4   # now and then a member large enough for the v2-tile kind inside the same launch
+    for m in range(n):
+        N = int(rng.integers(1, 4)); H = int(rng.integers(3, 30)); W = int(rng.integers(3, 30))
+        if big and m == 0: N, H, W = 4, int(rng.integers(90, 130)), int(rng.integers(90, 130))
+        Cin = 32 * int(rng.integers(1, 9)); Cout = int(rng.choice([5, 16, 32, 33, 64, 96, 130, 256, 351]))
+        R = int(rng.choice([1, 3])); stride = int(rng.choice([1, 1, 2])); pad = R // 2
+        x = rng.standard_normal((N, H, W, Cin)).astype(np.float32); w = (rng.standard_normal((Cout, R, R, Cin)) * 0.1).astype(np.float32)
+        Ho = (H + 2 * pad - R) // stride + 1; Wo = (W + 2 * pad - R) // stride + 1
+        itm = dict(x=x, w=w, stride=stride, pad=pad, act=int(rng.integers(0, 2)))
+        if rng.uniform() < 0.7: itm["scale"] = rng.uniform(0.5, 1.5, Cout).astype(np.float32); itm["shift"] = rng.standard_normal(Cout).astype(np.float32)
+        if rng.uniform() < 0.4: itm["residual"] = rng.standard_normal((N, Ho, Wo, Cout)).astype(np.float32)
+        items.append(itm)
+        refs.append(ora.conv2d(x, w, stride, pad, itm.get("scale"), itm.get("shift"), itm.get("residual"), itm["act"]))
+    got = ffi.conv2d_group(items)
+    for m in range(n):
+        if not np.array_equal(got[m], refs[m]): fail(("conv group", it, m, items[m]["x"].shape, items[m]["w"].shape))
+print("conv group ok", max(rounds // 3, 4))
+
+# ---- round 5: RPN selection batched over (level, image) against the oracle, level by level
+for it in range(max(rounds // 6, 3)):
+    N = int(rng.integers(1, 4)); A = 3; nl = int(rng.integers(1, 6))
+    heads, ancs = [], []
+    for l in range(nl):
+        H = int(rng.integers(3, 110 >> l) + 3); W = int(rng.integers(3, 130 >> l) + 3); stride = 4 << l
+        h = np.concatenate([rng.normal(-2, 2, (N, H, W, A)), rng.normal(0, 0.3, (N, H, W, 4 * A))], -1).astype(np.float32)
+        if rng.uniform() < 0.5: h[0, :2, :3, :A] = 0.75   # ties
+        heads.append(h); ancs.append(grid_anchors(H, W, stride, generate_anchors(stride, 8 * stride, (0.5, 1.0, 2.0))))
+    hw = np.array([[int(rng.integers(200, 500)), int(rng.integers(200, 600))] for _ in range(N)], np.int32)
+    pre = int(rng.integers(257, 1025)); post = int(rng.integers(1, pre + 1)); ms = float(rng.choice([0.0, 0.0, 16.0]))
+    got = ffi.rpn_levels(heads, ancs, hw, A, pre, post, min_size=ms)
+    for l in range(nl):
+        for n_ in range(N):
+            rb, rs = ora.rpn_level(heads[l][n_, ..., :A].reshape(-1), heads[l][n_, ..., A:].reshape(-1, 4), ancs[l], pre, post, 0.7, ms, float(hw[n_, 1]), float(hw[n_, 0]))
+            if not (np.array_equal(got[l][n_][1], rs) and np.array_equal(got[l][n_][0], rb)): fail(("rpn levels", it, l, n_, pre, post, ms))
+print("rpn levels ok", max(rounds // 6, 3))
+
+# ---- round 5: every fp16 tile form of a layer gives the same bits (16x16x32 / 144-row forms against their 32x32x16 twins)
+for it in range(max(rounds // 6, 3)):
+    N = int(rng.integers(1, 4)); H = int(rng.integers(12, 60)); W = int(rng.integers(12, 90)); Cin = 64 * int(rng.integers(1, 9)); Cout = int(rng.choice([64, 128, 256, 512]))
+    R = int(rng.choice([1, 3])); pad = R // 2
+    x = rng.standard_normal((N, H, W, Cin)).astype(np.float16); w = (rng.standard_normal((Cout, R, R, Cin)) * 0.05).astype(np.float16).astype(np.float32)
+    res = rng.standard_normal((N, H, W, Cout)).astype(np.float16) if rng.uniform() < 0.5 else None
+    tiles = (30, 40, 41) if R == 3 else (37, 47, 46, 34, 44, 39, 49)
+    outs = [ffi.conv2d_f16(x, w, 1, pad, None, None, res, 1, t) for t in tiles]
+    for t, o in zip(tiles[1:], outs[1:]):
+        if not np.array_equal(o, outs[0]): fail(("f16 tile forms", it, tiles[0], t, x.shape, w.shape))
+print("f16 tile forms ok", max(rounds // 6, 3))
