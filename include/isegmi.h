@@ -252,6 +252,28 @@ int isegmi_op_avgpool_full(const float* d_x, int64_t R, int HW, int C, float* d_
 int isegmi_op_roi_align_f16(const void* const* d_feats, const int32_t* Hs, const int32_t* Ws,
                             const float* scales, int nlevels, const float* d_rois, const int32_t* d_counts,
                             int N, int K, int C, int PH, int PW, int sampling, int k_min, void* d_out, void* stream);
+/* The FPN heads' RoIAlign (sampling 2, LevelMapper) as two launches.  isegmi_op_roi_prep, one thread per RoI: d_table [N*K][2*(PH+PW)+1][4]
+ * int32 -- for each of the RoI's 2*PH sample rows and 2*PW sample columns {byte offset of the low tap, of the high tap, weight of the low
+ * tap, of the high tap (fp32 bits)} with the validity test and clamps of the scalar op applied, then {level index, H, W, 0} -- and, when
+ * d_order is not NULL, d_order [N][K] = every image's RoI rows n*K + k sorted by (level, Morton code of the RoI centre on that level's map),
+ * rows past count last.  K <= 2048; elem_bytes 4 (fp32 features) or 2 (fp16); a level's map must stay under 2 GiB per image.
+ * isegmi_op_roi_align_ordered / _f16_ordered then run workgroup L on one 128-byte channel slice of RoI d_order[L / 8 ...] (d_order NULL: row
+ * order) so that RoIs sharing pixels are in flight together and every XCD's L2 holds its own slice of them; 7x7 or 14x14 bins, C in
+ * {32..256} (fp32) / {64..512} (fp16).  Outputs are those of isegmi_op_roi_align / _f16 bit for bit on finite features, whatever permutation
+ * d_order holds (entries outside [0, N*K) are skipped, rows it leaves out are not written).  d_rois / d_counts / scales / k_min must be the
+ * ones the table was made from. */
+int64_t isegmi_op_roi_table_bytes(int N, int K, int PH, int PW);
+int isegmi_op_roi_prep(const float* d_rois, const int32_t* d_counts, int N, int K, const int32_t* Hs, const int32_t* Ws,
+                       const float* scales, int nlevels, int k_min, int C, int PH, int PW, int elem_bytes,
+                       int32_t* d_order, void* d_table, void* stream);
+int isegmi_op_roi_align_ordered(const float* const* d_feats, const int32_t* Hs, const int32_t* Ws,
+                                const float* scales, int nlevels, const float* d_rois, const int32_t* d_counts,
+                                const int32_t* d_order, const void* d_table, int N, int K, int C, int PH, int PW,
+                                int k_min, float* d_out, void* stream);
+int isegmi_op_roi_align_f16_ordered(const void* const* d_feats, const int32_t* Hs, const int32_t* Ws,
+                                    const float* scales, int nlevels, const float* d_rois, const int32_t* d_counts,
+                                    const int32_t* d_order, const void* d_table, int N, int K, int C, int PH, int PW,
+                                    int k_min, void* d_out, void* stream);
 /* PostProcessor.filter_results (A.5): softmax, per-class decode(10,10,5,5)+clip, score filter, NMS,
  * kth-value cut to det_per_img.  Output order: class ascending, NMS order inside a class. */
 typedef struct isegmi_box_post_args {

@@ -24,7 +24,7 @@ int gather_proposals_launch(const float* cand_boxes, const float* fin_vals, cons
                             int cand_per_img, int K, float* props, float* prop_scores, int* prop_cnt, hipStream_t st);
 int roi_align_launch(const float* const* feats, const int* Hs, const int* Ws, const float* scales, int nlevels, const float* rois,
                      const int* counts, int N, int K, int C, int PH, int PW, int g, int k_min, int fixed_level, float* out,
-                     int* out_level, hipStream_t st);
+                     int* out_level, hipStream_t st, const int* order = nullptr, const void* tab = nullptr);
 int box_postprocess_launch(const isegmi_box_post_args* a, hipStream_t st);
 int mask_logits_select_launch(const float* feat, int R, int HW, int C, const float* w, const float* b, const int* labels, float* out,
                               hipStream_t st);
@@ -404,14 +404,27 @@ int maskrcnn_forward(Engine& e, const float* d_images, int N) {
     const int Hs[4] = {P[0].H, P[1].H, P[2].H, P[3].H}, Ws[4] = {P[0].W, P[1].W, P[2].W, P[3].W};
     const float scales[4] = {0.25f, 0.125f, 0.0625f, 0.03125f};
     Tensor roi7, f6, f7, cb;
+    // "roi_table": bit 0 box head, bit 1 mask head -- RoIAlign as roi_prep (per-RoI sample table + launch order) and the table-driven channel-slice launch
+    // instead of one workgroup per RoI in proposal order (same bits; A/B).  Same-box A/B, profiles/r05_experiments.txt 10: the box head gains in both
+    // dtypes; the mask head's N x 100 RoIs gain in fp16 (125 -> 79 us) and lose the prep launch's time in fp32 (43 -> 52 us): default 3 fp16, 1 fp32.
+    const int roi_table = (int)e.param("roi_table", dt ? 3.0f : 1.0f);
     TRY(eng_act(e, "box.roi_feat", N * R, 7, 7, 256, &roi7, dt));
     // SURVEY 8d "RoIAlign box: read rois + P2-P5 once (compulsory) + write the pooled features"
     double feat_bytes = 0;
     for (int l = 0; l < 4; ++l) feat_bytes += (double)N * Hs[l] * Ws[l] * 256 * (dt ? 2 : 4);
     {
+        // (roi_prep is launched inside the stage's scope: its time counts against the same algorithmic bytes)
         OpScope op(e, st, "roi_align 7x7 (box head)", feat_bytes + (double)N * R * 20 + (double)N * R * 49 * 256 * (dt ? 2 : 4));
-        if (dt) TRY(roi_align_f16_launch((const void* const*)feats, Hs, Ws, scales, 4, props, prop_cnt, N, R, 256, 7, 7, 2, 2, roi7.d, st));
-        else TRY(roi_align_launch(feats, Hs, Ws, scales, 4, props, prop_cnt, N, R, 256, 7, 7, 2, 2, -1, roi7.d, nullptr, st));
+        int* order = nullptr;
+        void* tab = nullptr;
+        if ((roi_table & 1) && R <= 2048) {
+            TRY(eng_buf(e, "roi_order", (int64_t)N * R * 4, &p, 1, {N, R}));
+            order = (int*)p;
+            TRY(eng_buf(e, "box.roi_table", (int64_t)N * R * 29 * 16, &tab, 1, {N * R, 29, 4}));
+            TRY(roi_prep_launch(props, prop_cnt, N, R, Hs, Ws, scales, 4, 2, 256, 7, 7, dt ? 2 : 4, order, tab, st));
+        }
+        if (dt) TRY(roi_align_f16_launch((const void* const*)feats, Hs, Ws, scales, 4, props, prop_cnt, N, R, 256, 7, 7, 2, 2, roi7.d, st, order, tab));
+        else TRY(roi_align_launch(feats, Hs, Ws, scales, 4, props, prop_cnt, N, R, 256, 7, 7, 2, 2, -1, roi7.d, nullptr, st, order, tab));
     }
     TRY(eng_conv(e, "roi_heads.box.feature_extractor.fc6", roi7, 1, 0, 1, nullptr, "box.fc6", &f6));
     TRY(eng_conv(e, "roi_heads.box.feature_extractor.fc7", f6, 1, 0, 1, nullptr, "box.fc7", &f7));
@@ -447,8 +460,16 @@ int maskrcnn_forward(Engine& e, const float* d_images, int N) {
     TRY(eng_act(e, "mask.roi_feat", N * cap, 14, 14, 256, &m, dt));
     {
         OpScope op(e, st, "roi_align 14x14 (mask head)", feat_bytes + (double)N * cap * 20 + (double)N * cap * 196 * 256 * (dt ? 2 : 4));
-        if (dt) TRY(roi_align_f16_launch((const void* const*)feats, Hs, Ws, scales, 4, a.d_out_boxes, a.d_out_count, N, cap, 256, 14, 14, 2, 2, m.d, st));
-        else TRY(roi_align_launch(feats, Hs, Ws, scales, 4, a.d_out_boxes, a.d_out_count, N, cap, 256, 14, 14, 2, 2, -1, m.d, nullptr, st));
+        int* order = nullptr;
+        void* tab = nullptr;
+        if ((roi_table & 2) && cap <= 2048) {
+            TRY(eng_buf(e, "mask.roi_order", (int64_t)N * cap * 4, &p, 1, {N, cap}));
+            order = (int*)p;
+            TRY(eng_buf(e, "mask.roi_table", (int64_t)N * cap * 57 * 16, &tab, 1, {N * cap, 57, 4}));
+            TRY(roi_prep_launch(a.d_out_boxes, a.d_out_count, N, cap, Hs, Ws, scales, 4, 2, 256, 14, 14, dt ? 2 : 4, order, tab, st));
+        }
+        if (dt) TRY(roi_align_f16_launch((const void* const*)feats, Hs, Ws, scales, 4, a.d_out_boxes, a.d_out_count, N, cap, 256, 14, 14, 2, 2, m.d, st, order, tab));
+        else TRY(roi_align_launch(feats, Hs, Ws, scales, 4, a.d_out_boxes, a.d_out_count, N, cap, 256, 14, 14, 2, 2, -1, m.d, nullptr, st, order, tab));
     }
     for (int i = 1; i <= 4; ++i) {
         Tensor o;

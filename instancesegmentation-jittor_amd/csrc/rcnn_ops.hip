@@ -624,6 +624,161 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiLevels lv, cons
     }
 }
 
+// ---- RoIAlign of the FPN heads (sampling 2, LevelMapper) in two launches: roi_prep_kernel, then roi_align_tab_kernel (fp32) or its fp16 twin in
+// spatial_f16.hip.  Counters of the one-workgroup-per-RoI form (profiles/r05_hbm_stage_traffic_*.json, tools/roi_align_fetch.sh): the box head fetched
+// 2.8x the P2-P5 maps -- the RoIs' footprints cover the maps 2.5x, every workgroup of the launch is resident at once and which of the eight L2s
+// sees a RoI is its index mod 8, so nothing is re-used between RoIs -- and its VALU work (sample coordinates, clamps, bilinear weights, two IEEE
+// divisions per coordinate, all repeated by every lane of a bin) was 2.5x the arithmetic on the taps.
+//   roi_prep_kernel, one thread per RoI: (a) everything that depends on the RoI alone -- level, and for each of the 2*PH sample rows and 2*PW sample
+//   columns {byte offset of the low / high tap row (column), weight of the low / high tap} with the validity test and the clamps of the scalar form
+//   applied -- into a table of 2*(PH+PW)+1 16-byte entries per RoI; (b) the launch order: the image's RoIs ranked by (level, Morton code of the
+//   centre on that level's map), by counting smaller keys in LDS.
+//   roi_align_tab_kernel: workgroup L -- dispatched to XCD L % 8 -- takes one 128-byte channel slice of RoI order[L / 8 ...]: the whole chip works on
+//   one window of spatially adjacent RoIs and every L2 holds its own slice of the window's pixels, so a pixel two RoIs share is fetched once (box
+//   head, fp32 bs = 2: 874 -> 171 MB).  A lane reads its bin's four table entries from LDS, forms the 16 tap offsets with one add3 each and the
+//   16 weights with one multiply each, has all 16 taps in flight, and runs the same multiply / add sequence per sample as roi_bilinear4.
+// Per output element the arithmetic is roi_align_kernel<2>'s, operation for operation, with two exceptions that cannot change a bit on finite
+// features: a sample outside the map is added as 0 * tap (+-0) instead of skipped, and the divisions by the powers of two 2 (half-bin offset) and 4
+// (sample count) are exact multiplications.  Results do not depend on `order` (one that is not a permutation leaves rows unwritten, entries outside
+// [0, N*K) are skipped).
+__device__ __forceinline__ unsigned morton9(unsigned v) {   // 9 bits -> every second bit
+    v &= 0x1ffu;
+    v = (v | (v << 8)) & 0x00ff00ffu;
+    v = (v | (v << 4)) & 0x0f0f0f0fu;
+    v = (v | (v << 2)) & 0x33333333u;
+    v = (v | (v << 1)) & 0x55555555u;
+    return v;
+}
+struct RoiPrepLevels {
+    int H[4], W[4];
+    float scale[4];
+};
+constexpr int ROI_ORDER_MAX = 2048;
+// invalid:1 | level:2 | morton(cy, cx):18 | k:11
+__device__ __forceinline__ unsigned roi_key(const float* __restrict__ rois, int64_t row0, int i, int K, int cnt, const RoiPrepLevels& lv, int k_min, int k_max) {
+    if (i >= K) return 0xffffffffu;
+    if (i >= cnt) return 0x80000000u | (unsigned)i;
+    const float4 b = *(const float4*)(rois + (row0 + i) * 4);
+    const int li = level_of(b, k_min, k_max) - k_min;
+    const float s = lv.scale[li];
+    const unsigned cx = (unsigned)fminf(fmaxf((b.x + b.z) * 0.5f * s, 0.0f), 511.0f);
+    const unsigned cy = (unsigned)fminf(fmaxf((b.y + b.w) * 0.5f * s, 0.0f), 511.0f);
+    return ((unsigned)li << 29) | (((morton9(cy) << 1) | morton9(cx)) << 11) | (unsigned)i;
+}
+// one table entry: a sample coordinate -> {low tap, high tap} x {byte offset, weight}; `stride` = bytes between consecutive taps along this axis
+__device__ __forceinline__ int4 roi_tab_entry(float v, int size, int stride) {
+    if (v < -1.0f || v > (float)size) return make_int4(0, 0, 0, 0);   // the sample contributes nothing: both weights +0
+    if (v <= 0.0f) v = 0.0f;
+    int lo = (int)v, hi;
+    if (lo >= size - 1) { hi = lo = size - 1; v = (float)lo; } else hi = lo + 1;
+    const float l = v - (float)lo, h = 1.0f - l;
+    return make_int4(lo * stride, hi * stride, __float_as_int(h), __float_as_int(l));
+}
+// grid (N, ceil(K / 32)), 256 threads = 32 RoIs x 8 lanes; esize = bytes per feature element; tab [N*K][2*(PH+PW)+1] int4; order [N][K].
+// Every workgroup builds the image's K keys in LDS; a RoI's rank = the number of smaller keys (keys are distinct: k is part of them), counted by
+// its eight lanes over an eighth of the keys each; its table entries are spread over the same eight lanes (128-byte stores).
+__global__ __launch_bounds__(256) void roi_prep_kernel(const float* __restrict__ rois, const int* __restrict__ counts, int K, RoiPrepLevels lv, int k_min,
+                                                        int k_max, int C, int PH, int PW, int esize, int* __restrict__ order, int4* __restrict__ tab) {
+    __shared__ unsigned key[ROI_ORDER_MAX];
+    const int n = blockIdx.x, cnt = counts[n];
+    const int64_t row0 = (int64_t)n * K;
+    const int K4 = (K + 3) & ~3;
+    const int l = threadIdx.x & 7, i = blockIdx.y * 32 + (threadIdx.x >> 3);
+    if (order) {
+        for (int q = threadIdx.x; q < K4; q += 256) key[q] = roi_key(rois, row0, q, K, cnt, lv, k_min, k_max);
+        __syncthreads();
+        if (i < K) {
+            const unsigned mine = key[i];
+            int rank = 0;
+            for (int j = l * 4; j < K4; j += 32) {
+                const uint4 q = *(const uint4*)(key + j);
+                rank += (q.x < mine) + (q.y < mine) + (q.z < mine) + (q.w < mine);
+            }
+            rank += __shfl_xor(rank, 1);
+            rank += __shfl_xor(rank, 2);
+            rank += __shfl_xor(rank, 4);
+            if (l == 0) order[row0 + rank] = (int)row0 + i;
+        }
+    }
+    if (i >= K || i >= cnt) return;
+    const float4 b = *(const float4*)(rois + (row0 + i) * 4);
+    const int li = level_of(b, k_min, k_max) - k_min;
+    const int H = lv.H[li], W = lv.W[li];
+    const float sc = lv.scale[li];
+    const float sw = b.x * sc, sh = b.y * sc, ew = b.z * sc, eh = b.w * sc;
+    float rw = ew - sw, rh = eh - sh;
+    rw = rw > 1.0f ? rw : 1.0f;
+    rh = rh > 1.0f ? rh : 1.0f;
+    const float bh = dm_div(rh, (float)PH), bw = dm_div(rw, (float)PW);
+    const int TS = 2 * (PH + PW) + 1;
+    int4* t = tab + (row0 + i) * TS;
+    for (int s = l; s < TS; s += 8) {
+        int4 e;
+        if (s < 2 * PH) e = roi_tab_entry(sh + (float)(s >> 1) * bh + dm_div(((float)(s & 1) + 0.5f) * bh, 2.0f), H, W * C * esize);
+        else if (s < TS - 1) {
+            const int q = s - 2 * PH;
+            e = roi_tab_entry(sw + (float)(q >> 1) * bw + dm_div(((float)(q & 1) + 0.5f) * bw, 2.0f), W, C * esize);
+        } else e = make_int4(li, H, W, 0);
+        t[s] = e;
+    }
+}
+__device__ __forceinline__ float4 roi_tap4(const char* fb, unsigned off) { return *(const float4*)(fb + off); }
+// one sample of roi_bilinear4 from its table entries: v = w1*v1; v += w2*v2; v += w3*v3; v += w4*v4; o += v
+#define ROI_SAMPLE(o, ye, xe, a, b, c, d)                                                                                   \
+    {                                                                                                                       \
+        const float hy = __int_as_float((ye).z), ly = __int_as_float((ye).w), hx = __int_as_float((xe).z), lx = __int_as_float((xe).w); \
+        const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;                                              \
+        float4 v;                                                                                                           \
+        v.x = w1 * a.x; v.x = v.x + w2 * b.x; v.x = v.x + w3 * c.x; v.x = v.x + w4 * d.x;                                   \
+        v.y = w1 * a.y; v.y = v.y + w2 * b.y; v.y = v.y + w3 * c.y; v.y = v.y + w4 * d.y;                                   \
+        v.z = w1 * a.z; v.z = v.z + w2 * b.z; v.z = v.z + w3 * c.z; v.z = v.z + w4 * d.z;                                   \
+        v.w = w1 * a.w; v.w = v.w + w2 * b.w; v.w = v.w + w3 * c.w; v.w = v.w + w4 * d.w;                                   \
+        o.x = o.x + v.x; o.y = o.y + v.y; o.z = o.z + v.z; o.w = o.w + v.w;                                                 \
+    }
+// C / 4 = 8 * ns float4 columns, ns in {1, 2, 4, 8} slices of 128 B; 8 / ns RoIs per group of eight workgroups
+template <int PH, int PW>
+__global__ __launch_bounds__(256) void roi_align_tab_kernel(const RoiLevels lv, const int4* __restrict__ tab, const int* __restrict__ counts,
+                                                             const int* __restrict__ order, int NK, int K, int C, int ns, float* __restrict__ out) {
+    constexpr int TS = 2 * (PH + PW) + 1, NB = PH * PW;
+    __shared__ int4 t[TS];
+    const int x = blockIdx.x & 7, rpg = 8 / ns;
+    const int seq = (blockIdx.x >> 3) * rpg + x / ns, slice = x % ns;
+    if (seq >= NK) return;
+    const int roi = order ? order[seq] : seq;
+    if ((unsigned)roi >= (unsigned)NK) return;
+    const int n = roi / K, k = roi - n * K;
+    const int c4n = C >> 2;
+    float4* o4 = (float4*)out + (int64_t)roi * (NB * c4n) + slice * 8 + (threadIdx.x & 7);
+    if (k >= counts[n]) {
+        for (int j = threadIdx.x; j < NB * 8; j += 256) o4[(j >> 3) * c4n] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    const int4* tr = tab + (int64_t)roi * TS;
+    if (threadIdx.x < TS) t[threadIdx.x] = tr[threadIdx.x];
+    const int4 hd = tr[TS - 1];   // (uniform address: a scalar load)
+    const int li = hd.x;
+    const float* f0 = li == 0 ? lv.feat[0] : li == 1 ? lv.feat[1] : li == 2 ? lv.feat[2] : lv.feat[3];
+    const char* fb = (const char*)(f0 + (int64_t)n * hd.y * hd.z * C) + slice * 128;
+    const unsigned lo = (threadIdx.x & 7) * 16;
+    __syncthreads();
+    for (int j = threadIdx.x; j < NB * 8; j += 256) {
+        const int bin = j >> 3;
+        const int ph = bin / PW, pw = bin - ph * PW;
+        const int4 y0 = t[2 * ph], y1 = t[2 * ph + 1], x0 = t[2 * PH + 2 * pw], x1 = t[2 * PH + 2 * pw + 1];
+        const float4 a00 = roi_tap4(fb, y0.x + x0.x + lo), b00 = roi_tap4(fb, y0.x + x0.y + lo), c00 = roi_tap4(fb, y0.y + x0.x + lo), d00 = roi_tap4(fb, y0.y + x0.y + lo);
+        const float4 a01 = roi_tap4(fb, y0.x + x1.x + lo), b01 = roi_tap4(fb, y0.x + x1.y + lo), c01 = roi_tap4(fb, y0.y + x1.x + lo), d01 = roi_tap4(fb, y0.y + x1.y + lo);
+        const float4 a10 = roi_tap4(fb, y1.x + x0.x + lo), b10 = roi_tap4(fb, y1.x + x0.y + lo), c10 = roi_tap4(fb, y1.y + x0.x + lo), d10 = roi_tap4(fb, y1.y + x0.y + lo);
+        const float4 a11 = roi_tap4(fb, y1.x + x1.x + lo), b11 = roi_tap4(fb, y1.x + x1.y + lo), c11 = roi_tap4(fb, y1.y + x1.x + lo), d11 = roi_tap4(fb, y1.y + x1.y + lo);
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        ROI_SAMPLE(o, y0, x0, a00, b00, c00, d00)
+        ROI_SAMPLE(o, y0, x1, a01, b01, c01, d01)
+        ROI_SAMPLE(o, y1, x0, a10, b10, c10, d10)
+        ROI_SAMPLE(o, y1, x1, a11, b11, c11, d11)
+        o.x = o.x * 0.25f; o.y = o.y * 0.25f; o.z = o.z * 0.25f; o.w = o.w * 0.25f;
+        o4[bin * c4n] = o;
+    }
+}
+
 // AvgPool2d over the whole HW window of every RoI (C4 FastRCNNPredictor): x [R][HW][C] -> out [R][C]; sequential fp32 sum, one division
 __global__ void avgpool_full_kernel(const float* __restrict__ x, int64_t R, int HW, int C, float* __restrict__ out) {
     const int c4n = C >> 2;
@@ -1066,7 +1221,7 @@ int gather_proposals_launch(const float* cand_boxes, const float* fin_vals, cons
 
 int roi_align_launch(const float* const* feats, const int* Hs, const int* Ws, const float* scales, int nlevels, const float* rois,
                      const int* counts, int N, int K, int C, int PH, int PW, int g, int k_min, int fixed_level, float* out,
-                     int* out_level, hipStream_t st) {
+                     int* out_level, hipStream_t st, const int* order = nullptr, const void* tab = nullptr) {
     ARG_CHECK(nlevels >= 1 && nlevels <= 4 && C % 4 == 0, "roi_align levels/C");
     RoiLevels lv;
     for (int i = 0; i < 4; ++i) {
@@ -1074,6 +1229,20 @@ int roi_align_launch(const float* const* feats, const int* Hs, const int* Ws, co
         lv.feat[i] = feats[s]; lv.H[i] = Hs[s]; lv.W[i] = Ws[s]; lv.scale[i] = scales[s];
     }
     ARG_CHECK(N > 0 && K > 0 && (int64_t)N * K < (1ll << 31) && (int64_t)PH * PW * (C / 4) < (1ll << 30), "roi_align sizes");
+    if (tab) {
+        const int ns = C / 32;
+        ARG_CHECK(g == 2 && fixed_level < 0 && !out_level && C % 32 == 0 && (ns == 1 || ns == 2 || ns == 4 || ns == 8) && (int64_t)N * K < (1ll << 27) &&
+                      ((PH == 7 && PW == 7) || (PH == 14 && PW == 14)),
+                  "roi_align from a table: sampling 2, LevelMapper, 7x7 or 14x14 bins, C in {32, 64, 128, 256}");
+        const int rpg = 8 / ns, NK = N * K;
+        const dim3 grid((unsigned)((NK + rpg - 1) / rpg * 8));
+        if (PH == 7)
+            hipLaunchKernelGGL((roi_align_tab_kernel<7, 7>), grid, dim3(256), 0, st, lv, (const int4*)tab, counts, order, NK, K, C, ns, out);
+        else
+            hipLaunchKernelGGL((roi_align_tab_kernel<14, 14>), grid, dim3(256), 0, st, lv, (const int4*)tab, counts, order, NK, K, C, ns, out);
+        HIP_TRY(hipGetLastError());
+        return ISEGMI_OK;
+    }
     // one block per (RoI, slice): enough slices that few-RoI launches (the mask head: N x 100 RoIs of 14 x 14 bins) still fill the chip
     const int per = PH * PW * (C / 4);
     int slices = (2048 + N * K - 1) / (N * K);
@@ -1086,6 +1255,26 @@ int roi_align_launch(const float* const* feats, const int* Hs, const int* Ws, co
     else
         hipLaunchKernelGGL(roi_align_kernel<0>, dim3((unsigned)(N * K), (unsigned)slices), dim3(256), 0, st, lv, rois, counts, N, K, C, PH, PW, g, k_min,
                            k_min + nlevels - 1, fixed_level, out, out_level);
+    HIP_TRY(hipGetLastError());
+    return ISEGMI_OK;
+}
+
+// The FPN heads' RoIAlign, first launch: tab [N*K][2*(PH+PW)+1][4] int32 (sample-row / sample-column entries, then {level index, H, W, 0}) and, when
+// `order` is given, order [N][K] = each image's RoI rows (n*K + k) sorted by (level, Morton code of the centre on that level's map), rows beyond
+// counts[n] last.  esize = bytes per feature element (4 fp32, 2 fp16): the table holds byte offsets.
+int roi_prep_launch(const float* rois, const int* counts, int N, int K, const int* Hs, const int* Ws, const float* scales, int nlevels, int k_min, int C,
+                    int PH, int PW, int esize, int* order, void* tab, hipStream_t st) {
+    ARG_CHECK(nlevels >= 1 && nlevels <= 4 && N > 0 && K > 0 && K <= ROI_ORDER_MAX && PH > 0 && PW > 0 && PH <= 64 && PW <= 64 && C > 0 &&
+                  (esize == 2 || esize == 4) && tab,
+              "roi_prep: 1..4 levels, K <= 2048");
+    RoiPrepLevels lv;
+    for (int i = 0; i < 4; ++i) {
+        const int s = i < nlevels ? i : nlevels - 1;
+        lv.H[i] = Hs[s]; lv.W[i] = Ws[s]; lv.scale[i] = scales[s];
+        ARG_CHECK(Hs[s] > 0 && Ws[s] > 0 && (int64_t)Hs[s] * Ws[s] * C * esize < (1ll << 31), "roi_prep: a level's map must stay under 2 GiB per image");
+    }
+    hipLaunchKernelGGL(roi_prep_kernel, dim3((unsigned)N, (unsigned)((K + 31) / 32)), dim3(256), 0, st, rois, counts, K, lv, k_min, k_min + nlevels - 1, C,
+                       PH, PW, esize, order, (int4*)tab);
     HIP_TRY(hipGetLastError());
     return ISEGMI_OK;
 }
@@ -1175,6 +1364,21 @@ extern "C" int isegmi_op_roi_align(const float* const* d_feats, const int32_t* H
                                    int k_min, int fixed_level, float* d_out, int32_t* d_out_level, void* stream) {
     return roi_align_launch(d_feats, Hs, Ws, scales, nlevels, d_rois, d_counts, N, K, C, PH, PW, sampling, k_min, fixed_level, d_out,
                             d_out_level, (hipStream_t)stream);
+}
+extern "C" int64_t isegmi_op_roi_table_bytes(int N, int K, int PH, int PW) {
+    return N > 0 && K > 0 && PH > 0 && PW > 0 ? (int64_t)N * K * (2 * (PH + PW) + 1) * 16 : 0;
+}
+extern "C" int isegmi_op_roi_prep(const float* d_rois, const int32_t* d_counts, int N, int K, const int32_t* Hs, const int32_t* Ws, const float* scales,
+                                  int nlevels, int k_min, int C, int PH, int PW, int elem_bytes, int32_t* d_order, void* d_table, void* stream) {
+    ARG_CHECK(d_rois && d_counts && Hs && Ws && scales && d_table, "args");
+    return roi_prep_launch(d_rois, d_counts, N, K, Hs, Ws, scales, nlevels, k_min, C, PH, PW, elem_bytes, d_order, d_table, (hipStream_t)stream);
+}
+extern "C" int isegmi_op_roi_align_ordered(const float* const* d_feats, const int32_t* Hs, const int32_t* Ws, const float* scales, int nlevels,
+                                           const float* d_rois, const int32_t* d_counts, const int32_t* d_order, const void* d_table, int N, int K,
+                                           int C, int PH, int PW, int k_min, float* d_out, void* stream) {
+    ARG_CHECK(d_feats && Hs && Ws && scales && d_rois && d_counts && d_table && d_out && N > 0 && K > 0 && PH > 0 && PW > 0, "args");
+    return roi_align_launch(d_feats, Hs, Ws, scales, nlevels, d_rois, d_counts, N, K, C, PH, PW, 2, k_min, -1, d_out, nullptr, (hipStream_t)stream,
+                            d_order, d_table);
 }
 
 extern "C" int isegmi_op_avgpool_full(const float* d_x, int64_t R, int HW, int C, float* d_out, void* stream) {

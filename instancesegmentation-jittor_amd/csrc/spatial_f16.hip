@@ -275,6 +275,69 @@ __global__ __launch_bounds__(256) void roi_align_f16_c8_kernel(const RoiLevelsH 
     }
 }
 
+// The FPN heads' RoIAlign from the table of rcnn_ops.hip's roi_prep_kernel (see there): workgroup L (XCD L % 8) takes one 128-byte channel slice --
+// eight lanes of 8 channels -- of RoI order[...]; C / 8 = 8 * ns lanes per pixel, ns in {1, 2, 4, 8}, 8 / ns RoIs per group of eight workgroups.
+// Per-element arithmetic is roi_align_f16_c8_kernel's g == 2 branch (same bits out on finite features; the division by the sample count 4 is an
+// exact multiplication).
+template <int PH, int PW>
+__global__ __launch_bounds__(256) void roi_align_f16_tab_kernel(const RoiLevelsH lv, const int4* __restrict__ tab, const int* __restrict__ counts,
+                                                                 const int* __restrict__ order, int NK, int K, int C, int ns, half_t* __restrict__ out) {
+    constexpr int TS = 2 * (PH + PW) + 1, NB = PH * PW;
+    __shared__ int4 t[TS];
+    const int x = blockIdx.x & 7, rpg = 8 / ns;
+    const int seq = (blockIdx.x >> 3) * rpg + x / ns, slice = x % ns;
+    if (seq >= NK) return;
+    const int roi = order ? order[seq] : seq;
+    if ((unsigned)roi >= (unsigned)NK) return;
+    const int n = roi / K, k = roi - n * K;
+    half_t* o = out + ((int64_t)roi * NB) * C + slice * 64 + (threadIdx.x & 7) * 8;
+    if (k >= counts[n]) {
+        const h8 z = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+        for (int b = threadIdx.x >> 3; b < NB; b += 32) *(h8*)(o + (int64_t)b * C) = z;
+        return;
+    }
+    const int4* tr = tab + (int64_t)roi * TS;
+    if (threadIdx.x < TS) t[threadIdx.x] = tr[threadIdx.x];
+    const int4 hd = tr[TS - 1];   // (uniform address: a scalar load)
+    const int li = hd.x;
+    const half_t* f0 = li == 0 ? lv.feat[0] : li == 1 ? lv.feat[1] : li == 2 ? lv.feat[2] : lv.feat[3];
+    const char* fb = (const char*)(f0 + (int64_t)n * hd.y * hd.z * C) + slice * 128;
+    const unsigned lo = (threadIdx.x & 7) * 16;
+    __syncthreads();
+    for (int b = threadIdx.x >> 3; b < NB; b += 32) {
+        const int ph = b / PW, pw = b - ph * PW;
+        int4 e[4];
+        e[0] = t[2 * ph]; e[1] = t[2 * ph + 1]; e[2] = t[2 * PH + 2 * pw]; e[3] = t[2 * PH + 2 * pw + 1];
+        h8 v[4][4];
+        float wt[4][4];
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx) {
+            const int4 ye = e[sidx >> 1], xe = e[2 + (sidx & 1)];
+            const float hy = __int_as_float(ye.z), ly = __int_as_float(ye.w), hx = __int_as_float(xe.z), lx = __int_as_float(xe.w);
+            wt[sidx][0] = hy * hx; wt[sidx][1] = hy * lx; wt[sidx][2] = ly * hx; wt[sidx][3] = ly * lx;
+            v[sidx][0] = *(const h8*)(fb + (unsigned)(ye.x + xe.x + lo)); v[sidx][1] = *(const h8*)(fb + (unsigned)(ye.x + xe.y + lo));
+            v[sidx][2] = *(const h8*)(fb + (unsigned)(ye.y + xe.x + lo)); v[sidx][3] = *(const h8*)(fb + (unsigned)(ye.y + xe.y + lo));
+        }
+        float acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = 0.0f;
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float q = wt[sidx][0] * (float)v[sidx][0][i];
+                q = q + wt[sidx][1] * (float)v[sidx][1][i];
+                q = q + wt[sidx][2] * (float)v[sidx][2][i];
+                q = q + wt[sidx][3] * (float)v[sidx][3][i];
+                acc[i] = acc[i] + q;
+            }
+        h8 r;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r[i] = (half_t)(acc[i] * 0.25f);
+        *(h8*)(o + (int64_t)b * C) = r;
+    }
+}
+
 __global__ __launch_bounds__(256) void mask_logits_select_f16_kernel(const half_t* __restrict__ feat, int HW, int C, const float* __restrict__ w,
                                                                       const float* __restrict__ b, const int* __restrict__ labels,
                                                                       float* __restrict__ out) {
@@ -439,12 +502,27 @@ int nearest2x_add_f16_launch(const void* coarse, int N, int Hc, int Wc, int C, c
     return ISEGMI_OK;
 }
 int roi_align_f16_launch(const void* const* feats, const int* Hs, const int* Ws, const float* scales, int nlevels, const float* rois,
-                         const int* counts, int N, int K, int C, int PH, int PW, int g, int k_min, void* out, hipStream_t st) {
+                         const int* counts, int N, int K, int C, int PH, int PW, int g, int k_min, void* out, hipStream_t st,
+                         const int* order = nullptr, const void* tab = nullptr) {
     ARG_CHECK(nlevels >= 1 && nlevels <= 4 && C % 4 == 0, "roi_align levels/C");
     RoiLevelsH lv;
     for (int i = 0; i < 4; ++i) {
         const int s = i < nlevels ? i : nlevels - 1;
         lv.feat[i] = (const half_t*)feats[s]; lv.H[i] = Hs[s]; lv.W[i] = Ws[s]; lv.scale[i] = scales[s];
+    }
+    if (tab) {
+        const int ns = C / 64;
+        ARG_CHECK(g == 2 && C % 64 == 0 && (ns == 1 || ns == 2 || ns == 4 || ns == 8) && N > 0 && K > 0 && (int64_t)N * K < (1ll << 27) &&
+                      ((PH == 7 && PW == 7) || (PH == 14 && PW == 14)),
+                  "roi_align_f16 from a table: sampling 2, 7x7 or 14x14 bins, C in {64, 128, 256, 512}");
+        const int rpg = 8 / ns, NK = N * K;
+        const dim3 grid((unsigned)((NK + rpg - 1) / rpg * 8));
+        if (PH == 7)
+            hipLaunchKernelGGL((roi_align_f16_tab_kernel<7, 7>), grid, dim3(256), 0, st, lv, (const int4*)tab, counts, order, NK, K, C, ns, (half_t*)out);
+        else
+            hipLaunchKernelGGL((roi_align_f16_tab_kernel<14, 14>), grid, dim3(256), 0, st, lv, (const int4*)tab, counts, order, NK, K, C, ns, (half_t*)out);
+        HIP_TRY(hipGetLastError());
+        return ISEGMI_OK;
     }
     if (C % 8 == 0 && 256 % (C / 8) == 0 && (int64_t)N * K < (1ll << 31)) {
         if (N * K > 0)
@@ -480,4 +558,11 @@ extern "C" int isegmi_op_roi_align_f16(const void* const* d_feats, const int32_t
     ARG_CHECK(d_feats && Hs && Ws && scales && d_rois && d_counts && d_out && N > 0 && K > 0 && PH > 0 && PW > 0 && sampling > 0, "args");
     return isegmi::roi_align_f16_launch(d_feats, Hs, Ws, scales, nlevels, d_rois, d_counts, N, K, C, PH, PW, sampling, k_min, d_out,
                                         (hipStream_t)stream);
+}
+extern "C" int isegmi_op_roi_align_f16_ordered(const void* const* d_feats, const int32_t* Hs, const int32_t* Ws, const float* scales, int nlevels,
+                                               const float* d_rois, const int32_t* d_counts, const int32_t* d_order, const void* d_table, int N, int K,
+                                               int C, int PH, int PW, int k_min, void* d_out, void* stream) {
+    ARG_CHECK(d_feats && Hs && Ws && scales && d_rois && d_counts && d_table && d_out && N > 0 && K > 0 && PH > 0 && PW > 0, "args");
+    return isegmi::roi_align_f16_launch(d_feats, Hs, Ws, scales, nlevels, d_rois, d_counts, N, K, C, PH, PW, 2, k_min, d_out, (hipStream_t)stream,
+                                        d_order, d_table);
 }

@@ -30,6 +30,7 @@ def lib():
                 "or `make -C instancesegmentation-jittor_amd`; there is no CPU fallback" % LIB_PATH)
         _lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
         _lib.isegmi_last_error.restype = C.c_char_p
+        _lib.isegmi_op_roi_table_bytes.restype = C.c_int64
     return _lib
 
 
@@ -367,6 +368,40 @@ def roi_align(feats, scales, rois, counts, PH, PW, sampling=2, k_min=2, fixed_le
     check(lib().isegmi_op_roi_align(ptrs, Hs, Ws, sc, len(fb), dr.ptr, dcnt.ptr, N, K, Cc, PH, PW, sampling, k_min, fixed_level,
                                     do.ptr, dl.ptr, None))
     return do.numpy(), dl.numpy()
+
+
+def roi_prep(rois, counts, shapes, scales, Cc, PH, PW, k_min=2, f16=False, want_order=True):
+    """first launch of the FPN heads' RoIAlign: rois [N,K,4], counts [N], shapes [(H, W)] per level -> (order [N,K] int32 or None, table [N*K, 2*(PH+PW)+1, 4]
+    int32): per-RoI sample rows / columns {low byte offset, high byte offset, low weight bits, high weight bits}, then {level index, H, W, 0}"""
+    N, K = rois.shape[:2]
+    dr = DeviceBuffer.from_numpy(np.ascontiguousarray(rois, np.float32)); dcnt = DeviceBuffer.from_numpy(np.ascontiguousarray(counts, np.int32))
+    do = DeviceBuffer((N, K), np.int32) if want_order else None
+    TS = 2 * (PH + PW) + 1
+    assert lib().isegmi_op_roi_table_bytes(N, K, PH, PW) == N * K * TS * 16
+    dtab = DeviceBuffer.from_numpy(np.full((N * K, TS, 4), -1, np.int32))
+    Hs = (C.c_int32 * len(shapes))(*[h for h, _ in shapes]); Ws = (C.c_int32 * len(shapes))(*[w for _, w in shapes])
+    sc = (C.c_float * len(scales))(*scales)
+    check(lib().isegmi_op_roi_prep(dr.ptr, dcnt.ptr, N, K, Hs, Ws, sc, len(scales), k_min, Cc, PH, PW, 2 if f16 else 4, do.ptr if do else None, dtab.ptr, None))
+    return (do.numpy() if do else None), dtab.numpy()
+
+
+def roi_align_ordered(feats, scales, rois, counts, PH, PW, order, table, k_min=2, f16=False):
+    """second launch: RoIAlign (sampling 2, LevelMapper) from roi_prep's `table`, launched in `order` [N,K] (any permutation of the rows, or None = row order)
+    -> out [N*K,PH,PW,C], pre-filled with NaN so that a row the launch did not write shows"""
+    dt = np.float16 if f16 else np.float32
+    fb = [DeviceBuffer.from_numpy(np.ascontiguousarray(f, dt)) for f in feats]
+    N, K = rois.shape[:2]
+    Cc = feats[0].shape[3]
+    ptrs = (C.c_void_p * len(fb))(*[b.ptr.value for b in fb])
+    Hs = (C.c_int32 * len(fb))(*[f.shape[1] for f in feats]); Ws = (C.c_int32 * len(fb))(*[f.shape[2] for f in feats])
+    sc = (C.c_float * len(fb))(*scales)
+    dr = DeviceBuffer.from_numpy(np.ascontiguousarray(rois, np.float32)); dcnt = DeviceBuffer.from_numpy(np.ascontiguousarray(counts, np.int32))
+    dord = DeviceBuffer.from_numpy(np.ascontiguousarray(order, np.int32)) if order is not None else None
+    dtab = DeviceBuffer.from_numpy(np.ascontiguousarray(table, np.int32))
+    do = DeviceBuffer.from_numpy(np.full((N * K, PH, PW, Cc), np.nan, dt))
+    fn = lib().isegmi_op_roi_align_f16_ordered if f16 else lib().isegmi_op_roi_align_ordered
+    check(fn(ptrs, Hs, Ws, sc, len(fb), dr.ptr, dcnt.ptr, dord.ptr if dord else None, dtab.ptr, N, K, Cc, PH, PW, k_min, do.ptr, None))
+    return do.numpy()
 
 
 def avgpool_full(x):

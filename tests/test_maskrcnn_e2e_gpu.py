@@ -258,6 +258,32 @@ def test_maskrcnn_fp16_fused_fpn_merge_equals_conv_then_add(ffi, sd):
         assert np.array_equal(a["boxes"][i], b["boxes"][i])
 
 
+@pytest.mark.parametrize("fp16", [False, True])
+def test_maskrcnn_roi_align_from_table_does_not_change_results(ffi, sd, fp16):
+    """Both heads' RoIAlign as roi_prep + the table-driven channel-slice launch (default) against `roi_table` 0 (one workgroup per RoI in proposal order, every
+    lane deriving its own sample coordinates): pooled features of both heads, detections and masks are BIT-identical, and the order buffer holds every
+    proposal row once."""
+    from isegmi.maskrcnn import MaskRCNN, prepare_images
+    rng = np.random.default_rng(79)
+    x, hw = prepare_images([rng.uniform(0, 255, (250, 340, 3)).astype(np.float32), rng.uniform(0, 255, (203, 317, 3)).astype(np.float32)])
+    outs = {}
+    for on in (1, 0):
+        model = MaskRCNN(sd, x.shape[1], x.shape[2], max_batch=2, fp16=fp16)
+        model.set_param("roi_table", 3.0 if on else 0.0)
+        bl = model(x, hw)
+        outs[on] = dict(roi=model.fetch("box.roi_feat"), mroi=model.fetch("mask.roi_feat"), boxes=[b.bbox.copy() for b in bl], scores=[b.get_field("scores").copy() for b in bl],
+                        masks=[b.get_field("mask").copy() for b in bl])
+        if on:
+            order = model.fetch("roi_order", 2)
+            assert sorted(order.reshape(-1).tolist()) == list(range(order.size))
+        model.close()
+    a, b = outs[1], outs[0]
+    assert a["roi"].any() and np.array_equal(a["roi"], b["roi"])
+    assert a["mroi"].any() and np.array_equal(a["mroi"], b["mroi"])
+    for i in range(2):
+        assert np.array_equal(a["boxes"][i], b["boxes"][i]) and np.array_equal(a["scores"][i], b["scores"][i]) and np.array_equal(a["masks"][i], b["masks"][i])
+
+
 def test_maskrcnn_fp16_fused_rpn_head_equals_two_launches(ffi, sd):
     """configs[4] engine at the full canvas (2 x 800 x 1344) with the RPN head of the big levels as one launch (default) against `fused_rpn_head` 0: the
     objectness / delta tensor of P2 is BIT-identical (both paths run the 3x3 on the row-strip tile), P3's within fp16 conv tolerance (the cost model may put

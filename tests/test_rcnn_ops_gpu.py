@@ -96,6 +96,112 @@ def test_roi_align_adaptive_sampling_and_avgpool_match_oracle(ffi):
     assert np.array_equal(ffi.avgpool_full(x), ora.avgpool_full(x))
 
 
+def _oracle_roi_align_levels(feats, scales, rois, counts, PH, f16=False):
+    """oracle LevelMapper + RoIAlign (sampling 2) over the FPN levels -> [N, K, PH, PH, C], rows past count zero"""
+    N, K = rois.shape[:2]
+    out = np.zeros((N, K, PH, PH, feats[0].shape[3]), np.float16 if f16 else np.float32)
+    for n in range(N):
+        k = counts[n]
+        lv = ora.level_map(rois[n, :k])
+        for L in range(2, 6):
+            idx = np.nonzero(lv == L)[0]
+            if len(idx):
+                r5 = np.concatenate([np.full((len(idx), 1), n, np.float32), rois[n, idx]], 1)
+                out[n, idx] = ora.roi_align(feats[L - 2].astype(np.float32), r5, scales[L - 2], PH, PH, 2).astype(out.dtype)
+    return out
+
+
+@pytest.mark.parametrize("K", [1, 37, 150, 1000, 2048])
+def test_roi_prep_order_is_a_level_then_morton_permutation(ffi, K):
+    """isegmi_op_roi_prep's launch order: every image's rows exactly once, valid rows first, levels ascending, Morton codes of the centres ascending inside a
+    level; its table's last entry names the oracle's level and that level's map size"""
+    rng = np.random.default_rng(K)
+    N = 3
+    scales = [0.25, 0.125, 0.0625, 0.03125]
+    shapes = [(200, 336), (100, 168), (50, 84), (25, 42)]
+    rois = np.stack([_boxes(rng, K, 1344, 800) for _ in range(N)])
+    counts = np.array([K, K // 2, 0], np.int32)
+    order, tab = ffi.roi_prep(rois, counts, shapes, scales, 256, 7, 7)
+    assert order.shape == (N, K) and tab.shape == (N * K, 29, 4)
+    tab = tab.reshape(N, K, 29, 4)
+
+    def spread(v):
+        return sum(((int(v) >> i) & 1) << (2 * i) for i in range(9))
+
+    for n in range(N):
+        ks = order[n] - n * K
+        assert sorted(ks.tolist()) == list(range(K))
+        c = counts[n]
+        assert (ks[:c] < c).all() and list(ks[c:]) == list(range(c, K))   # invalid rows last, in index order
+        assert (tab[n, c:] == -1).all()                                    # ... and without a table row
+        lv = ora.level_map(rois[n, :c]) if c else np.zeros(0, np.int64)
+        assert np.array_equal(tab[n, :c, 28, 0], lv - 2)
+        assert all(tuple(tab[n, k, 28, 1:3]) == shapes[lv[k] - 2] for k in range(c))
+        keys = []
+        for k in ks[:c]:
+            b, s = rois[n, k], np.float32(scales[lv[k] - 2])
+            cx = int(min(max(np.float32(np.float32(b[0] + b[2]) * np.float32(0.5)) * s, 0), 511))
+            cy = int(min(max(np.float32(np.float32(b[1] + b[3]) * np.float32(0.5)) * s, 0), 511))
+            keys.append((int(lv[k]), (spread(cy) << 1) | spread(cx), int(k)))
+        assert keys == sorted(keys)
+
+
+@pytest.mark.parametrize("f16", [False, True])
+@pytest.mark.parametrize("Cc", [256, 128, 64])
+def test_roi_align_from_table_is_the_plain_op_bit_for_bit(ffi, Cc, f16):
+    """The FPN heads' launch form (roi_prep's table; one 128-byte channel slice of one RoI per workgroup): against the oracle and against the plain op,
+    under roi_prep's order, no order, and a random permutation -- the order is a scheduling hint only."""
+    rng = np.random.default_rng(31 + Cc)
+    N, K = 2, 203
+    shapes = [(50, 84), (25, 42), (13, 21), (7, 11)]
+    dt = np.float16 if f16 else np.float32
+    feats = [rng.standard_normal((N, h, w, Cc)).astype(dt) for h, w in shapes]
+    scales = [0.25, 0.125, 0.0625, 0.03125]
+    rois = np.stack([_boxes(rng, K, 336, 200) for _ in range(N)])
+    rois[0, 0] = [-50, -40, -10, -5]        # fully outside: every sample invalid
+    rois[0, 1] = [10, 10, 10.2, 10.1]       # tiny -> roi size clamp to 1
+    rois[1, 2] = [0, 0, 335, 199]
+    rois[0, 3] = [300, 150, 420, 260]       # hangs over the right / bottom edge: clamped and invalid samples mixed
+    rois[0, 4] = [-30, -20, 40, 50]
+    counts = np.array([K, 97], np.int32)
+    for PH in (7, 14):
+        order, tab = ffi.roi_prep(rois, counts, shapes, scales, Cc, PH, PH, f16=f16)
+        ref = _oracle_roi_align_levels(feats, scales, rois, counts, PH, f16)
+        plain = (ffi.roi_align_f16(feats, scales, rois, counts, PH, PH) if f16 else ffi.roi_align(feats, scales, rois, counts, PH, PH)[0])
+        assert np.array_equal(plain.reshape(ref.shape), ref)
+        for o in (order, None, rng.permutation(N * K).astype(np.int32).reshape(N, K)):
+            got = ffi.roi_align_ordered(feats, scales, rois, counts, PH, PH, o, tab, f16=f16).reshape(ref.shape)
+            assert np.array_equal(got, ref), (PH, Cc, f16)
+    # an order that is not a permutation: rows it names are right, rows it leaves out keep what was there, entries outside [0, N*K) are skipped
+    order, tab = ffi.roi_prep(rois, counts, shapes, scales, Cc, 7, 7, f16=f16)
+    bad = order.copy().reshape(-1)
+    left = {int(bad[5]), int(bad[9])}
+    bad[5], bad[9] = -1, N * K + 3
+    got = ffi.roi_align_ordered(feats, scales, rois, counts, 7, 7, bad.reshape(N, K), tab, f16=f16).reshape(N * K, 7, 7, Cc)
+    ref = _oracle_roi_align_levels(feats, scales, rois, counts, 7, f16).reshape(N * K, 7, 7, Cc)
+    for r in range(N * K):
+        if r in left:
+            assert np.isnan(got[r].astype(np.float32)).all()
+        else:
+            assert np.array_equal(got[r], ref[r])
+
+
+def test_roi_align_from_table_rejects_what_it_does_not_cover(ffi):
+    from isegmi import _ffi
+    rois = np.zeros((1, 4, 4), np.float32)
+    cnt = np.array([4], np.int32)
+    _, tab = ffi.roi_prep(rois, cnt, [(8, 8)], [0.25], 48, 7, 7)
+    with pytest.raises(_ffi.IsegmiError):
+        ffi.roi_align_ordered([np.zeros((1, 8, 8, 48), np.float32)], [0.25], rois, cnt, 7, 7, None, tab)             # C = 48
+    _, tab = ffi.roi_prep(rois, cnt, [(8, 8)], [0.25], 64, 5, 5)
+    with pytest.raises(_ffi.IsegmiError):
+        ffi.roi_align_ordered([np.zeros((1, 8, 8, 64), np.float32)], [0.25], rois, cnt, 5, 5, None, tab)             # 5 x 5 bins
+    with pytest.raises(_ffi.IsegmiError):
+        ffi.roi_prep(np.zeros((1, 2049, 4), np.float32), np.array([2049], np.int32), [(8, 8)], [0.25], 64, 7, 7)    # K > 2048
+    with pytest.raises(_ffi.IsegmiError):
+        ffi.roi_prep(rois, cnt, [(40000, 40000)], [0.25], 256, 7, 7)                                                  # byte offsets would not fit
+
+
 @pytest.mark.parametrize("Cc", [256, 64, 36])  # 256 / 64: 8-channel-per-lane kernel; 36: generic 4-channel kernel
 def test_roi_align_f16_matches_oracle_on_fp16_features(ffi, Cc):
     """fp16-storage RoIAlign: same fp32 arithmetic on fp16-rounded features, result rounded to fp16 -> exact match."""

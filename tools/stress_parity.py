@@ -198,3 +198,25 @@ for it in range(max(rounds // 6, 3)):
     for t, o in zip(tiles[1:], outs[1:]):
         if not np.array_equal(o, outs[0]): fail(("f16 tile forms", it, tiles[0], t, x.shape, w.shape))
 print("f16 tile forms ok", max(rounds // 6, 3))
+
+# ---- round 5: RoIAlign from roi_prep's table (channel-slice launch, any order) against the plain launch and, on a sample of RoIs, the oracle
+for it in range(max(rounds // 6, 3)):
+    N = int(rng.integers(1, 4)); K = int(rng.choice([1, 7, 100, 333, 1000])); Cc = int(rng.choice([64, 128, 256])); PH = int(rng.choice([7, 14])); f16 = bool(rng.integers(0, 2))
+    Hc = int(rng.integers(40, 210)); Wc = int(rng.integers(40, 340))
+    shapes = [(max(Hc >> l, 1), max(Wc >> l, 1)) for l in range(4)]; scales = [0.25, 0.125, 0.0625, 0.03125]
+    dt = np.float16 if f16 else np.float32
+    feats = [rng.standard_normal((N, h, w, Cc)).astype(dt) for h, w in shapes]
+    rois = np.stack([boxes(K, Wc * 4 + 40, Hc * 4 + 40) - 20 for _ in range(N)]).astype(np.float32)   # some hang over every edge
+    cnt = rng.integers(0, K + 1, N).astype(np.int32); cnt[0] = K
+    plain = ffi.roi_align_f16(feats, scales, rois, cnt, PH, PH) if f16 else ffi.roi_align(feats, scales, rois, cnt, PH, PH)[0]
+    order, tab = ffi.roi_prep(rois, cnt, shapes, scales, Cc, PH, PH, f16=f16)
+    if sorted(order.reshape(-1).tolist()) != list(range(N * K)): fail(("roi_prep order", it, N, K))
+    for o in (order, None, rng.permutation(N * K).astype(np.int32).reshape(N, K)):
+        got = ffi.roi_align_ordered(feats, scales, rois, cnt, PH, PH, o, tab, f16=f16)
+        if not np.array_equal(got, plain): fail(("roi_align table", it, N, K, Cc, PH, f16))
+    lv = ora.level_map(rois[0])
+    for k in rng.choice(K, min(K, 5), replace=False):
+        L = int(lv[k]); r5 = np.concatenate([[0.0], rois[0, k]]).astype(np.float32)[None]
+        ref = ora.roi_align(feats[L - 2].astype(np.float32), r5, scales[L - 2], PH, PH, 2).astype(dt)
+        if not np.array_equal(plain.reshape(N, K, PH, PH, Cc)[0, k], ref[0]): fail(("roi_align oracle", it, k))
+print("roi_align table ok", max(rounds // 6, 3))
