@@ -1,21 +1,24 @@
 """Counter bytes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes) of the HBM-bound stages bench.py times (roofline_hbm), per STEP:
    python tools/hbm_stage_traffic.py <fetch_dir> <write_dir> <forward steps of the profiled process> <out.json>
 <forward steps> = EVERY forward the profiled process ran: tools/profile_round.sh runs bench.py with --warmup 2 --steps 10 and bench.py adds its
-single-stream roofline pass of another 10 steps: 22.  (Round 4 passed 12: every figure it wrote is 22 / 12 = 1.83x too large -- the "1.6-1.9x
-counter-over-algorithmic bytes" of RoIAlign and mask_logits_select in VERDICT r4 were this divisor, not over-fetch.)  A stage kernel that runs a fixed
-number of times per forward must divide evenly: checked.
+single-stream roofline pass of another 10 steps: 22.  (Round 4 passed 12; with 12 the RoIAlign launches of a step were also dealt to the wrong head,
+profiles/r05_experiments.txt 7 and 10.)  A stage kernel that runs a fixed number of times per forward must divide evenly: checked.
 Stages that map to kernels of their own are summed by kernel name; stages built from shared kernels (top-k, NMS) are left out (null in the bench
 line).  bytes = 2 x FETCH_SIZE + WRITE_SIZE (KB -> B): the gfx950 wide-read correction is calibrated for 16 B per lane loads -- RoIAlign's gathers,
-the mask / paste kernels' vector loads -- and an upper bound where a kernel reads narrower."""
-import collections, csv, glob, json, os, sys
-STAGES = {
-    "roi_align 7x7 (box head)": [("roi_align_kernel", 0), ("roi_align_f16_c8_kernel", 0)],
-    "roi_align 14x14 (mask head)": [("roi_align_kernel", 1), ("roi_align_f16_c8_kernel", 1)],
-    "paste_masks (Masker: resize + threshold + paste, whole uint8 planes)": [("paste_masks_kernel", None)],
-    "mask_logits_select (1x1 -> the label's channel + sigmoid)": [("mask_logits_select", None)],
-    "yolact_masks (proto @ coeff -> sigmoid -> crop -> upsample -> threshold, whole uint8 planes)": [("yolact_proto_masks", None), ("yolact_upsample_masks", None)],
-    "front end (uint8 -> resize / normalise / pad -> fp32 input)": [("preprocess_u8_kernel", None)],
+the mask / paste kernels' vector loads -- and an upper bound where a kernel reads narrower.
+RoIAlign: a head is either one plain launch (roi_align_kernel<2> / roi_align_f16_c8_kernel: box head first, mask head second when both are plain)
+or roi_prep_kernel + the table-driven launch (<7, 7> box head, <14, 14> mask head); roi_prep_kernel's launches of a step go to the heads in order."""
+import collections, csv, glob, json, os, re, sys
+
+BOX, MASK = "roi_align 7x7 (box head)", "roi_align 14x14 (mask head)"
+SIMPLE = {
+    "paste_masks (Masker: resize + threshold + paste, whole uint8 planes)": r"paste_masks_kernel",
+    "mask_logits_select (1x1 -> the label's channel + sigmoid)": r"mask_logits_select",
+    "yolact_masks (proto @ coeff -> sigmoid -> crop -> upsample -> threshold, whole uint8 planes)": r"yolact_proto_masks|yolact_upsample_masks",
 }
+# one launch per batch, timed by bench.py in a loop of its own: per LAUNCH.  Its loads are single bytes (the uint8 taps), not 16 B per lane: the x2 correction
+# does not apply -- calibrated on its known input, raw FETCH_SIZE 7.5 MB against the 6.4 MB uint8 batch of Mask R-CNN bs = 2 (taps shared between rows)
+FRONT = "front end (uint8 -> resize / normalise / pad -> fp32 input)"
 
 
 def rows(d, counter):
@@ -23,29 +26,56 @@ def rows(d, counter):
     out = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == counter:
-            out[r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0].split("::")[-1]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"]) * 1024.0))
+            out[r["Kernel_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"]) * 1024.0))
     return {k: [v for _, v in sorted(vs)] for k, vs in out.items()}
 
 
 def main():
     f, w, steps = rows(sys.argv[1], "FETCH_SIZE"), rows(sys.argv[2], "WRITE_SIZE"), int(sys.argv[3])
+
+    def launches(pat, fetch_factor=2):
+        """[bytes of launch 0, launch 1, ...] over every kernel whose name matches, in dispatch order per kernel"""
+        out = []
+        for k in f:
+            if re.search(pat, k):
+                wv = w.get(k, [0.0] * len(f[k]))
+                out.append([fetch_factor * a + b for a, b in zip(f[k], wv)])
+        return out
+
+    def per_step(vals, which=None, of=None):
+        if len(vals) % steps:
+            raise SystemExit("%d launches do not divide over %d forward steps -- wrong step count?" % (len(vals), steps))
+        per = len(vals) // steps
+        if of is not None and per != of:
+            raise SystemExit("expected %d launches per step, found %d" % (of, per))
+        return sum(v for i, v in enumerate(vals) if which is None or i % per == which) / steps
+
     out = {}
-    for label, parts in STAGES.items():
-        tot, found = 0.0, False
-        for kname, which in parts:
-            for k in f:
-                if k.startswith(kname) or ("isegmi" in k and kname in k):   # (some kernels reach the CSV under their mangled names)
-                    fv, wv = f[k], w.get(k, [0.0] * len(f[k]))
-                    per = len(fv) // steps if steps else 0
-                    if per == 0:
-                        continue
-                    if which is not None and len(fv) % steps != 0:
-                        raise SystemExit("%s: %d launches do not divide over %d forward steps -- wrong step count?" % (k, len(fv), steps))
-                    idx = range(len(fv)) if which is None else [i for i in range(len(fv)) if i % per == which]
-                    tot += sum(2 * fv[i] + wv[i] for i in idx) / steps
-                    found = True
-        if found:
-            out[label] = int(tot)
+    for label, pat in SIMPLE.items():
+        ls = launches(pat)
+        if ls:
+            out[label] = int(sum(per_step(v) for v in ls))
+    ls = launches(r"preprocess_u8_kernel", 1)
+    if ls:
+        out[FRONT] = int(sum(sum(v) / len(v) for v in ls))
+    box = sum((launches(p) for p in (r"roi_align_tab_kernel<7, 7>", r"roi_align_f16_tab_kernel(<7, 7>|ILi7ELi7E)")), [])
+    mask = sum((launches(p) for p in (r"roi_align_tab_kernel<14, 14>", r"roi_align_f16_tab_kernel(<14, 14>|ILi14ELi14E)")), [])
+    plain = launches(r"roi_align_kernel<2>|roi_align_kernelILi2E|roi_align_f16_c8_kernel")
+    prep = launches(r"roi_prep_kernel")
+    tot = {BOX: sum(per_step(v) for v in box), MASK: sum(per_step(v) for v in mask)}
+    for v in plain:
+        if box and mask:
+            raise SystemExit("plain RoIAlign launches next to both table-driven heads")
+        if box or mask:
+            tot[MASK if box else BOX] += per_step(v, of=1)
+        else:
+            tot[BOX] += per_step(v, 0, of=2); tot[MASK] += per_step(v, 1, of=2)
+    for v in prep:
+        heads = [h for h, t in ((BOX, box), (MASK, mask)) if t]
+        for i, h in enumerate(heads):
+            tot[h] += per_step(v, i, of=len(heads))
+    if box or mask or plain:
+        out[BOX], out[MASK] = int(tot[BOX]), int(tot[MASK])
     json.dump(out, open(sys.argv[4], "w"), indent=1)
     print(json.dumps(out, indent=1))
 
