@@ -679,7 +679,7 @@ __device__ __forceinline__ int4 roi_tab_entry(float v, int size, int stride) {
 // its eight lanes over an eighth of the keys each; its table entries are spread over the same eight lanes (128-byte stores).
 __global__ __launch_bounds__(256) void roi_prep_kernel(const float* __restrict__ rois, const int* __restrict__ counts, int K, RoiPrepLevels lv, int k_min,
                                                         int k_max, int C, int PH, int PW, int esize, int* __restrict__ order, int4* __restrict__ tab) {
-    __shared__ unsigned key[ROI_ORDER_MAX];
+    __shared__ __attribute__((aligned(16))) unsigned key[ROI_ORDER_MAX];   // (read four at a time)
     const int n = blockIdx.x, cnt = counts[n];
     const int64_t row0 = (int64_t)n * K;
     const int K4 = (K + 3) & ~3;
@@ -722,7 +722,11 @@ __global__ __launch_bounds__(256) void roi_prep_kernel(const float* __restrict__
         t[s] = e;
     }
 }
-__device__ __forceinline__ float4 roi_tap4(const char* fb, unsigned off) { return *(const float4*)(fb + off); }
+// a tap = a 16-byte buffer load range-checked against the image's map: whatever the table holds, no load leaves the level's allocation (out of range reads 0)
+typedef unsigned int roi_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 roi_tap4(const __amdgpu_buffer_rsrc_t rs, unsigned off) {
+    return __builtin_bit_cast(float4, (roi_u32x4)__builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+}
 // one sample of roi_bilinear4 from its table entries: v = w1*v1; v += w2*v2; v += w3*v3; v += w4*v4; o += v
 #define ROI_SAMPLE(o, ye, xe, a, b, c, d)                                                                                   \
     {                                                                                                                       \
@@ -755,11 +759,11 @@ __global__ __launch_bounds__(256) void roi_align_tab_kernel(const RoiLevels lv, 
     }
     const int4* tr = tab + (int64_t)roi * TS;
     if (threadIdx.x < TS) t[threadIdx.x] = tr[threadIdx.x];
-    const int4 hd = tr[TS - 1];   // (uniform address: a scalar load)
-    const int li = hd.x;
+    const int li = tr[TS - 1].x;   // (uniform address: a scalar load); the level's geometry comes from the launch arguments, not from the table
     const float* f0 = li == 0 ? lv.feat[0] : li == 1 ? lv.feat[1] : li == 2 ? lv.feat[2] : lv.feat[3];
-    const char* fb = (const char*)(f0 + (int64_t)n * hd.y * hd.z * C) + slice * 128;
-    const unsigned lo = (threadIdx.x & 7) * 16;
+    const int64_t img = (int64_t)(li == 0 ? lv.H[0] : li == 1 ? lv.H[1] : li == 2 ? lv.H[2] : lv.H[3]) * (li == 0 ? lv.W[0] : li == 1 ? lv.W[1] : li == 2 ? lv.W[2] : lv.W[3]) * C;
+    const __amdgpu_buffer_rsrc_t fb = __builtin_amdgcn_make_buffer_rsrc((void*)(f0 + (int64_t)n * img), 0, (unsigned)(img * 4), 0x00020000);
+    const unsigned lo = slice * 128 + (threadIdx.x & 7) * 16;
     __syncthreads();
     for (int j = threadIdx.x; j < NB * 8; j += 256) {
         const int bin = j >> 3;
@@ -1234,6 +1238,7 @@ int roi_align_launch(const float* const* feats, const int* Hs, const int* Ws, co
         ARG_CHECK(g == 2 && fixed_level < 0 && !out_level && C % 32 == 0 && (ns == 1 || ns == 2 || ns == 4 || ns == 8) && (int64_t)N * K < (1ll << 27) &&
                       ((PH == 7 && PW == 7) || (PH == 14 && PW == 14)),
                   "roi_align from a table: sampling 2, LevelMapper, 7x7 or 14x14 bins, C in {32, 64, 128, 256}");
+        for (int i = 0; i < nlevels; ++i) ARG_CHECK((int64_t)Hs[i] * Ws[i] * C * 4 < (1ll << 31), "roi_align from a table: a level's map must stay under 2 GiB per image");
         const int rpg = 8 / ns, NK = N * K;
         const dim3 grid((unsigned)((NK + rpg - 1) / rpg * 8));
         if (PH == 7)

@@ -279,6 +279,10 @@ __global__ __launch_bounds__(256) void roi_align_f16_c8_kernel(const RoiLevelsH 
 // eight lanes of 8 channels -- of RoI order[...]; C / 8 = 8 * ns lanes per pixel, ns in {1, 2, 4, 8}, 8 / ns RoIs per group of eight workgroups.
 // Per-element arithmetic is roi_align_f16_c8_kernel's g == 2 branch (same bits out on finite features; the division by the sample count 4 is an
 // exact multiplication).
+typedef unsigned int roi_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ h8 tap8(const __amdgpu_buffer_rsrc_t rs, unsigned off) {
+    return __builtin_bit_cast(h8, (roi_u32x4)__builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+}
 template <int PH, int PW>
 __global__ __launch_bounds__(256) void roi_align_f16_tab_kernel(const RoiLevelsH lv, const int4* __restrict__ tab, const int* __restrict__ counts,
                                                                  const int* __restrict__ order, int NK, int K, int C, int ns, half_t* __restrict__ out) {
@@ -298,11 +302,12 @@ __global__ __launch_bounds__(256) void roi_align_f16_tab_kernel(const RoiLevelsH
     }
     const int4* tr = tab + (int64_t)roi * TS;
     if (threadIdx.x < TS) t[threadIdx.x] = tr[threadIdx.x];
-    const int4 hd = tr[TS - 1];   // (uniform address: a scalar load)
-    const int li = hd.x;
+    const int li = tr[TS - 1].x;   // (uniform address: a scalar load); the level's geometry comes from the launch arguments, not from the table
     const half_t* f0 = li == 0 ? lv.feat[0] : li == 1 ? lv.feat[1] : li == 2 ? lv.feat[2] : lv.feat[3];
-    const char* fb = (const char*)(f0 + (int64_t)n * hd.y * hd.z * C) + slice * 128;
-    const unsigned lo = (threadIdx.x & 7) * 16;
+    const int64_t img = (int64_t)(li == 0 ? lv.H[0] : li == 1 ? lv.H[1] : li == 2 ? lv.H[2] : lv.H[3]) * (li == 0 ? lv.W[0] : li == 1 ? lv.W[1] : li == 2 ? lv.W[2] : lv.W[3]) * C;
+    // taps are 16-byte buffer loads range-checked against the image's map: whatever the table holds, no load leaves the level's allocation
+    const __amdgpu_buffer_rsrc_t fb = __builtin_amdgcn_make_buffer_rsrc((void*)(f0 + (int64_t)n * img), 0, (unsigned)(img * 2), 0x00020000);
+    const unsigned lo = slice * 128 + (threadIdx.x & 7) * 16;
     __syncthreads();
     for (int b = threadIdx.x >> 3; b < NB; b += 32) {
         const int ph = b / PW, pw = b - ph * PW;
@@ -315,8 +320,8 @@ __global__ __launch_bounds__(256) void roi_align_f16_tab_kernel(const RoiLevelsH
             const int4 ye = e[sidx >> 1], xe = e[2 + (sidx & 1)];
             const float hy = __int_as_float(ye.z), ly = __int_as_float(ye.w), hx = __int_as_float(xe.z), lx = __int_as_float(xe.w);
             wt[sidx][0] = hy * hx; wt[sidx][1] = hy * lx; wt[sidx][2] = ly * hx; wt[sidx][3] = ly * lx;
-            v[sidx][0] = *(const h8*)(fb + (unsigned)(ye.x + xe.x + lo)); v[sidx][1] = *(const h8*)(fb + (unsigned)(ye.x + xe.y + lo));
-            v[sidx][2] = *(const h8*)(fb + (unsigned)(ye.y + xe.x + lo)); v[sidx][3] = *(const h8*)(fb + (unsigned)(ye.y + xe.y + lo));
+            v[sidx][0] = tap8(fb, (unsigned)(ye.x + xe.x) + lo); v[sidx][1] = tap8(fb, (unsigned)(ye.x + xe.y) + lo);
+            v[sidx][2] = tap8(fb, (unsigned)(ye.y + xe.x) + lo); v[sidx][3] = tap8(fb, (unsigned)(ye.y + xe.y) + lo);
         }
         float acc[8];
 #pragma unroll
@@ -515,6 +520,7 @@ int roi_align_f16_launch(const void* const* feats, const int* Hs, const int* Ws,
         ARG_CHECK(g == 2 && C % 64 == 0 && (ns == 1 || ns == 2 || ns == 4 || ns == 8) && N > 0 && K > 0 && (int64_t)N * K < (1ll << 27) &&
                       ((PH == 7 && PW == 7) || (PH == 14 && PW == 14)),
                   "roi_align_f16 from a table: sampling 2, 7x7 or 14x14 bins, C in {64, 128, 256, 512}");
+        for (int i = 0; i < nlevels; ++i) ARG_CHECK((int64_t)Hs[i] * Ws[i] * C * 2 < (1ll << 31), "roi_align_f16 from a table: a level's map must stay under 2 GiB per image");
         const int rpg = 8 / ns, NK = N * K;
         const dim3 grid((unsigned)((NK + rpg - 1) / rpg * 8));
         if (PH == 7)

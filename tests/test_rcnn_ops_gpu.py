@@ -186,6 +186,27 @@ def test_roi_align_from_table_is_the_plain_op_bit_for_bit(ffi, Cc, f16):
             assert np.array_equal(got[r], ref[r])
 
 
+@pytest.mark.parametrize("f16", [False, True])
+def test_roi_align_from_a_garbage_table_stays_inside_the_maps(ffi, f16):
+    """The table is caller-supplied device memory: its offsets go through range-checked buffer loads and its level index through a select over the launch's own
+    levels, so a table of random words yields finite garbage, not a fault -- and the next call with the real table is right."""
+    rng = np.random.default_rng(5)
+    N, K, Cc = 1, 64, 64
+    shapes = [(20, 30), (10, 15), (5, 8), (3, 4)]
+    dt = np.float16 if f16 else np.float32
+    feats = [rng.uniform(-1, 1, (N, h, w, Cc)).astype(dt) for h, w in shapes]
+    scales = [0.25, 0.125, 0.0625, 0.03125]
+    rois = np.stack([_boxes(rng, K, 120, 80) for _ in range(N)])
+    counts = np.array([K], np.int32)
+    order, tab = ffi.roi_prep(rois, counts, shapes, scales, Cc, 7, 7, f16=f16)
+    junk = rng.integers(-2**31, 2**31 - 1, tab.shape, dtype=np.int64).astype(np.int32)
+    junk[..., 2:] = tab[..., 2:]   # keep the weights (finite): only the offsets and the level are wild
+    got = ffi.roi_align_ordered(feats, scales, rois, counts, 7, 7, order, junk, f16=f16)
+    assert np.isfinite(got.astype(np.float32)).all() and np.abs(got.astype(np.float32)).max() <= 1.0 + 1e-3   # convex combinations of map values or zeros
+    ref = _oracle_roi_align_levels(feats, scales, rois, counts, 7, f16)
+    assert np.array_equal(ffi.roi_align_ordered(feats, scales, rois, counts, 7, 7, order, tab, f16=f16).reshape(ref.shape), ref)
+
+
 def test_roi_align_from_table_rejects_what_it_does_not_cover(ffi):
     from isegmi import _ffi
     rois = np.zeros((1, 4, 4), np.float32)
