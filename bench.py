@@ -532,9 +532,10 @@ def bench_yolact(a, dist):
                                   " / all-gathered over RCCL" if gather is not None else "", int(a.batch * 100 * size * size / 1e6))}
     if rccl:
         out.update(rccl)
-    hbm = hbm_rooflines(ops, a.steps, hbm_traffic("hbm_stage_traffic_yolact.json") if (a.yolact_config == "resnet50" and not a.fp16) else None)
+    traffic = hbm_traffic("hbm_stage_traffic_yolact.json") if (a.yolact_config == "resnet50" and not a.fp16 and a.batch == 8) else None
+    hbm = hbm_rooflines(ops, a.steps, traffic)
     if rle_op:
-        hbm += hbm_rooflines(rle_op, 5)
+        hbm += hbm_rooflines(rle_op, 5, traffic)   # (the front end's counter bytes are per launch, as its algorithmic bytes are)
     out["roofline_hbm"] = hbm
     out["roofline_hbm_note"] = ("SURVEY 8(d) HBM-bound stages, per step of %d images, in the single-stream pass of `roofline`: achieved = ALGORITHMIC bytes (each "
                                 "stage's compulsory reads + writes, SURVEY 8d) / HIP-event time on the launching stream; peak 8 TB/s (spec); frac well under 1 on a "
@@ -742,9 +743,14 @@ def bench_maskrcnn(a, dist, summary=None):
                           " / all-gathered over RCCL" if gather is not None else "", int(batch * 100 * 800 * 1333 / 1e6))}
     if rccl:
         out.update(rccl)
-    hbm = hbm_rooflines(ops, steps, hbm_traffic("hbm_stage_traffic_maskrcnn.json") if (not fp16 and not c4 and depth == 50 and batch == 2) else None)
+    traffic = None
+    if not c4 and not fp16 and depth == 50 and batch == 2:
+        traffic = hbm_traffic("hbm_stage_traffic_maskrcnn.json")
+    elif not c4 and fp16 and depth == 101 and batch == 8:
+        traffic = hbm_traffic("hbm_stage_traffic_r101f16.json")
+    hbm = hbm_rooflines(ops, steps, traffic)
     if rle_op:
-        hbm += hbm_rooflines(rle_op, 5)
+        hbm += hbm_rooflines(rle_op, 5, traffic)   # (the front end's counter bytes are per launch, as its algorithmic bytes are)
     out["roofline_hbm"] = hbm
     out["roofline_hbm_note"] = ("SURVEY 8(d) HBM-bound stages, per step of %d images, in the single-stream pass of `roofline`: achieved = ALGORITHMIC bytes / "
                                 "HIP-event time on the launching stream; peak 8 TB/s (spec)" % batch)

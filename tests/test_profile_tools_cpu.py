@@ -70,6 +70,17 @@ def test_table_driven_heads_take_their_prep_launch(tmp_path):
     assert o["roi_align 7x7 (box head)"] == (2 * 1 + 2 + 2 * 70 + 200) * 1024 and o["roi_align 14x14 (mask head)"] == (2 * 3 + 4 + 2 * 25 + 80) * 1024
 
 
+def test_the_zero_fill_of_the_mask_planes_counts_with_the_stage_that_writes_them(tmp_path):
+    steps = 2
+    PASTE = "isegmi::paste_masks_kernel(float const*, float const*, int const*, int, int, int, int, int, float, unsigned char*, int*)"
+    FILL = "__amd_rocclr_fillBufferAligned"
+    f = [(FILL, 0), (FILL, 0), (PASTE, 3)] * steps
+    w = [(FILL, 1000), (FILL, 1000), (PASTE, 30)] * steps
+    r, o = _run(tmp_path, f, w, steps)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert o["paste_masks (Masker: resize + threshold + paste, whole uint8 planes)"] == (2 * 3 + 30 + 2000) * 1024
+
+
 def test_a_wrong_step_count_is_refused(tmp_path):
     f = [(PLAIN, 100), (PLAIN, 10)] * 22
     w = [(PLAIN, 50), (PLAIN, 20)] * 22

@@ -6,6 +6,8 @@ profiles/r05_experiments.txt 7 and 10.)  A stage kernel that runs a fixed number
 Stages that map to kernels of their own are summed by kernel name; stages built from shared kernels (top-k, NMS) are left out (null in the bench
 line).  bytes = 2 x FETCH_SIZE + WRITE_SIZE (KB -> B): the gfx950 wide-read correction is calibrated for 16 B per lane loads -- RoIAlign's gathers,
 the mask / paste kernels' vector loads -- and an upper bound where a kernel reads narrower.
+The zero fill of the uint8 mask planes (hipMemsetAsync -> __amd_rocclr_fillBufferAligned; the only memsets of a forward) belongs to the stage that then
+writes the masks into them: paste_masks (Mask R-CNN) / yolact_masks.
 RoIAlign: a head is either one plain launch (roi_align_kernel<2> / roi_align_f16_c8_kernel: box head first, mask head second when both are plain)
 or roi_prep_kernel + the table-driven launch (<7, 7> box head, <14, 14> mask head); roi_prep_kernel's launches of a step go to the heads in order."""
 import collections, csv, glob, json, os, re, sys
@@ -55,6 +57,8 @@ def main():
         ls = launches(pat)
         if ls:
             out[label] = int(sum(per_step(v) for v in ls))
+            if "uint8 planes" in label:
+                out[label] += int(sum(sum(v) for v in launches(r"fillBufferAligned")) / steps)
     ls = launches(r"preprocess_u8_kernel", 1)
     if ls:
         out[FRONT] = int(sum(sum(v) / len(v) for v in ls))
