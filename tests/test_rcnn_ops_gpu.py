@@ -207,6 +207,35 @@ def test_roi_align_from_a_garbage_table_stays_inside_the_maps(ffi, f16):
     assert np.array_equal(ffi.roi_align_ordered(feats, scales, rois, counts, 7, 7, order, tab, f16=f16).reshape(ref.shape), ref)
 
 
+@pytest.mark.parametrize("f16", [False, True])
+def test_roi_align_from_table_on_degenerate_boxes_equals_the_plain_op(ffi, f16):
+    """Boxes no detector should emit -- reversed corners, zero area, far outside, 1e8-sized, inf, NaN -- and the proposal cap (K = 2048): the table-driven
+    launch does exactly what the one-workgroup-per-RoI launch does (NaNs included), and both return."""
+    rng = np.random.default_rng(9)
+    N, K, Cc = 2, 2048, 64
+    shapes = [(40, 60), (20, 30), (10, 15), (5, 8)]
+    dt = np.float16 if f16 else np.float32
+    feats = [rng.standard_normal((N, h, w, Cc)).astype(dt) for h, w in shapes]
+    scales = [0.25, 0.125, 0.0625, 0.03125]
+    rois = np.stack([_boxes(rng, K, 240, 160) for _ in range(N)])
+    rois[0, 0] = [100, 80, 20, 10]                      # reversed corners
+    rois[0, 1] = [50, 50, 50, 50]                       # zero area
+    rois[0, 2] = [1e6, 1e6, 1e6 + 30, 1e6 + 30]         # far outside
+    rois[0, 3] = [-1e8, -1e8, 1e8, 1e8]                 # covers everything many times over
+    rois[0, 4] = [0, 0, np.inf, 40]
+    rois[0, 5] = [np.nan, 10, 40, 50]
+    rois[0, 6] = [-np.inf, -np.inf, np.inf, np.inf]
+    rois[1, 7] = [239.5, 159.5, 239.9, 159.9]           # the last pixel's corner
+    counts = np.array([K, 1500], np.int32)
+    for PH in (7, 14):
+        plain = ffi.roi_align_f16(feats, scales, rois, counts, PH, PH) if f16 else ffi.roi_align(feats, scales, rois, counts, PH, PH)[0]
+        order, tab = ffi.roi_prep(rois, counts, shapes, scales, Cc, PH, PH, f16=f16)
+        assert sorted(order.reshape(-1).tolist()) == list(range(N * K))
+        got = ffi.roi_align_ordered(feats, scales, rois, counts, PH, PH, order, tab, f16=f16)
+        assert np.array_equal(got.astype(np.float32), plain.astype(np.float32), equal_nan=True), PH
+        assert np.isfinite(plain.reshape(N, K, -1)[1, :1500].astype(np.float32)).all()   # (the wild rows are all in image 0)
+
+
 def test_roi_align_from_table_rejects_what_it_does_not_cover(ffi):
     from isegmi import _ffi
     rois = np.zeros((1, 4, 4), np.float32)
