@@ -224,7 +224,8 @@ int isegmi_op_yolact_detect(const isegmi_yolact_detect_args* a, void* stream);
 
 /* ---- Yolact postprocess masks (Y7; App. A.9) ----
  * d_proto [N][PH][PW][32]; d_coeffs [N][K][32]; d_boxes [N][K][4] relative; d_count [N].
- * d_ws_lo [N][K][PH][PW] fp32 workspace; d_out_masks [N][K][h][w] uint8 {0,1} (only the first
+ * d_ws_lo [N][K][PH][PW] fp32 workspace (holds the crop windows' pixels of the proto-resolution masks afterwards, the rest is
+ * undefined); d_out_masks [N][K][h][w] uint8 {0,1} (only the first
  * count[n] masks of image n are written); d_out_boxes [N][K][4] int64 (may be NULL). */
 int isegmi_op_yolact_masks(const float* d_proto, const float* d_coeffs, const float* d_boxes,
                            const int32_t* d_count, int N, int PH, int PW, int mask_dim, int K, int h,

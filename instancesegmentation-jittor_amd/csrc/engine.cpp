@@ -897,7 +897,7 @@ int yolact_postprocess(Engine& e, int h, int w, const int32_t* h_image_hw) {
                    (double)N * PH * PW * md * 4 + (double)N * K * md * 4 + (whole ? (double)N * K * h * w : 0.0));
         TRY(yolact_masks_launch((const float*)proto.d, (const float*)e.bufs["det.coeff"].d, (const float*)e.bufs["det.box"].d,
                                 (const int*)e.bufs["det.count"].d, N, PH, PW, md, K, h, w, (float*)lo, (uint8_t*)masks, (int64_t*)ib,
-                                rs, d_ihw, (int*)wq, whole));
+                                rs, d_ihw, (int*)wq, whole, /*dense_lo=*/e.convs.count("maskiou_net.2") != 0));
     }
     if (e.convs.count("maskiou_net.2")) {
         // YOLACT++ fast mask re-scoring on the proto-resolution masks just written to ws.lo: first layer (1 input channel) and

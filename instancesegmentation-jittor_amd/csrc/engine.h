@@ -249,7 +249,7 @@ int topk_launch(const float* keys, int64_t row_stride, int rows, int n, int k, c
 int yolact_detect_launch(const isegmi_yolact_detect_args* a, hipStream_t st);
 int yolact_masks_launch(const float* proto, const float* coeffs, const float* boxes, const int* count, int N, int PH, int PW,
                         int mask_dim, int K, int h, int w, float* ws_lo, uint8_t* out_masks, int64_t* out_boxes, hipStream_t st,
-                        const int* image_hw = nullptr, int* win = nullptr, bool clear = true);
+                        const int* image_hw = nullptr, int* win = nullptr, bool clear = true, bool dense_lo = false);
 
 }  // namespace isegmi
 

@@ -196,8 +196,13 @@ __device__ __forceinline__ void sanitize(float a, float b, int img, float paddin
 // proto [N][PH][PW][32]; coeffs [N][K][32]; boxes [N][K][4]; lo [N][K][PH][PW].
 // grid (ceil(PH*PW/256), N); one thread per proto pixel keeps its 32 prototype values in registers
 // and loops over the image's detections (coefficients + crop windows staged in LDS).
+// DENSE = false (round 5): a pixel outside a detection's crop window is neither computed nor written -- the upsampling kernel below takes such a tap as
+// the 0 it is by its own window test -- so `lo` holds the window's pixels only (the rest is stale): 62 MB of zeros per bs = 8 step were written here and
+// a dot product + sigmoid spent on each.  A wave none of whose 64 pixels lies in the window skips the detection.  DENSE = true keeps the full
+// zero-padded masks (YOLACT++'s MaskIoU head convolves them).
 constexpr int MD = 32;
 constexpr int PROTO_DG = 25;
+template <bool DENSE>
 __global__ __launch_bounds__(256) void yolact_proto_masks_kernel(const float* __restrict__ proto, const float* __restrict__ coeffs,
                                                                   const float* __restrict__ boxes, const int* __restrict__ count,
                                                                   int PH, int PW, int K, float* __restrict__ lo) {
@@ -228,12 +233,13 @@ __global__ __launch_bounds__(256) void yolact_proto_masks_kernel(const float* __
     for (int k = 0; k < MD / 4; ++k) { const float4 v = ps[k]; pv[4 * k] = v.x; pv[4 * k + 1] = v.y; pv[4 * k + 2] = v.z; pv[4 * k + 3] = v.w; }
     const float fx = (float)x, fy = (float)y;
     for (int d = d_lo; d < cnt; ++d) {
+        const bool inside = fx >= sw[d * 4] && fx < sw[d * 4 + 1] && fy >= sw[d * 4 + 2] && fy < sw[d * 4 + 3];
+        if (!DENSE && !inside) continue;
         const float* cf = sc + d * MD;
         float acc = 0.0f;
 #pragma unroll
         for (int k = 0; k < MD; ++k) acc = fmaf(pv[k], cf[k], acc);
         const float v = dm_sigmoid(acc);
-        const bool inside = fx >= sw[d * 4] && fx < sw[d * 4 + 1] && fy >= sw[d * 4 + 2] && fy < sw[d * 4 + 3];
         lo[(((int64_t)n * K + d) * PH * PW) + pix] = inside ? v : 0.0f;
     }
 }
@@ -273,14 +279,19 @@ __global__ __launch_bounds__(256) void yolact_upsample_masks_kernel(const float*
     const float sy = dm_div((float)PH, (float)h), sx = dm_div((float)PW, (float)w);  // dm_bil_coef's scale, hoisted
     const float* m = lo + ((int64_t)n * K + d) * PH * PW;
     uint8_t* o = out + ((int64_t)n * K + d) * plane;
+    // a tap outside the crop window is 0 by definition (the crop): read as such, never from `lo` (which holds the window's pixels only)
+    auto tap = [&](int yy, int xx) -> float {
+        const float fx = (float)xx, fy = (float)yy;
+        return (fx >= x1 && fx < x2 && fy >= y1 && fy < y2) ? m[yy * PW + xx] : 0.0f;
+    };
     for (int i = blockIdx.x * 256 + threadIdx.x; i < area; i += gridDim.x * 256) {
         const int ry = i / ww;
         const int y = oy0 + ry, x = ox0 + (i - ry * ww);
         int y0, yb, x0, xb; float ly0, ly1, lx0, lx1;
         dm_bil_coef_s(y, PH, sy, y0, yb, ly0, ly1);
         dm_bil_coef_s(x, PW, sx, x0, xb, lx0, lx1);
-        float top = lx0 * m[y0 * PW + x0]; top = fmaf(lx1, m[y0 * PW + xb], top);
-        float bot = lx0 * m[yb * PW + x0]; bot = fmaf(lx1, m[yb * PW + xb], bot);
+        float top = lx0 * tap(y0, x0); top = fmaf(lx1, tap(y0, xb), top);
+        float bot = lx0 * tap(yb, x0); bot = fmaf(lx1, tap(yb, xb), bot);
         float v = ly0 * top; v = fmaf(ly1, bot, v);
         o[y * plane_w + x] = v > 0.5f ? (uint8_t)1 : (uint8_t)0;
     }
@@ -412,12 +423,17 @@ int maskiou_rescore_launch(const float* feat, int N, int K, int HW, int C, const
 
 int yolact_masks_launch(const float* proto, const float* coeffs, const float* boxes, const int* count, int N, int PH, int PW,
                         int mask_dim, int K, int h, int w, float* ws_lo, uint8_t* out_masks, int64_t* out_boxes, hipStream_t st,
-                        const int* image_hw, int* win, bool clear) {
+                        const int* image_hw, int* win, bool clear, bool dense_lo) {
     ARG_CHECK(mask_dim == MD, "mask_dim must be 32");
     ARG_CHECK(N > 0 && K > 0 && K <= 128 && h > 0 && w > 0, "mask sizes");
     const size_t lds = (size_t)K * (MD + 4) * sizeof(float);
-    hipLaunchKernelGGL(yolact_proto_masks_kernel, dim3(cdiv(PH * PW, 256), N, cdiv(K, PROTO_DG)), dim3(256), lds, st, proto, coeffs, boxes, count, PH,
-                       PW, K, ws_lo);
+    // dense_lo: ws_lo receives the complete zero-padded proto-resolution masks (a consumer other than the upsampling below reads them)
+    if (dense_lo)
+        hipLaunchKernelGGL(yolact_proto_masks_kernel<true>, dim3(cdiv(PH * PW, 256), N, cdiv(K, PROTO_DG)), dim3(256), lds, st, proto, coeffs, boxes, count,
+                           PH, PW, K, ws_lo);
+    else
+        hipLaunchKernelGGL(yolact_proto_masks_kernel<false>, dim3(cdiv(PH * PW, 256), N, cdiv(K, PROTO_DG)), dim3(256), lds, st, proto, coeffs, boxes, count,
+                           PH, PW, K, ws_lo);
     HIP_TRY(hipGetLastError());
     ARG_CHECK((int64_t)h * w < (1ll << 31), "h * w must stay below 2^31");
     if (clear) HIP_TRY(hipMemsetAsync(out_masks, 0, (size_t)N * K * h * w, st));  // skipped when the planes are read through their windows only
@@ -446,5 +462,5 @@ extern "C" int isegmi_op_yolact_masks(const float* d_proto, const float* d_coeff
                                       int N, int PH, int PW, int mask_dim, int K, int h, int w, float* d_ws_lo,
                                       uint8_t* d_out_masks, int64_t* d_out_boxes, void* stream) {
     return yolact_masks_launch(d_proto, d_coeffs, d_boxes, d_count, N, PH, PW, mask_dim, K, h, w, d_ws_lo, d_out_masks, d_out_boxes,
-                               (hipStream_t)stream, nullptr, nullptr, true);
+                               (hipStream_t)stream, nullptr, nullptr, true, false);
 }

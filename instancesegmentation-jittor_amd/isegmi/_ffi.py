@@ -337,7 +337,8 @@ def yolact_masks(proto, coeffs, boxes, counts, h, w):
     K = coeffs.shape[1]
     dp = DeviceBuffer.from_numpy(proto); dc = DeviceBuffer.from_numpy(np.asarray(coeffs, np.float32))
     db = DeviceBuffer.from_numpy(np.asarray(boxes, np.float32)); dn = DeviceBuffer.from_numpy(np.asarray(counts, np.int32))
-    dlo = DeviceBuffer((N, K, PH, PW)); dm = DeviceBuffer((N, K, h, w), np.uint8); dm.zero()
+    dlo = DeviceBuffer.from_numpy(np.full((N, K, PH, PW), np.nan, np.float32))   # the workspace arrives dirty: only crop-window pixels may be read back
+    dm = DeviceBuffer((N, K, h, w), np.uint8); dm.zero()
     dob = DeviceBuffer((N, K, 4), np.int64)
     check(lib().isegmi_op_yolact_masks(dp.ptr, dc.ptr, db.ptr, dn.ptr, N, PH, PW, md, K, h, w, dlo.ptr, dm.ptr, dob.ptr, None))
     return dm.numpy(), dob.numpy()
