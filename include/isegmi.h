@@ -83,7 +83,8 @@ int isegmi_op_conv2d(const isegmi_conv_desc* d, const float* d_in, const float* 
                      float* d_out, void* stream);
 /* n <= 10 independent fp32 convolutions (no stem, tile 0) as ONE launch: the shared-weight heads of all FPN levels, the FPN's lateral / output convs.
  * Member i = descs[i] with d_in[i], d_w[i] (packed), d_scale[i] / d_shift[i] / d_res[i] (each array, or an entry, may be NULL), d_out[i]; every member's
- * result is bit-identical to its own isegmi_op_conv2d call (one k-ordered chain per output either way).  The pointer arrays are HOST arrays. */
+ * result is bit-identical to its own isegmi_op_conv2d call -- same results, tile form chosen per GROUP (ring depth, 64 x 64 tiles or 32 x 32 blocks): every
+ * fp32 tile form keeps one k-ordered chain per output.  The pointer arrays are HOST arrays; a NULL d_in[i] / d_w[i] / d_out[i] is ISEGMI_ERR_ARG. */
 int isegmi_op_conv2d_group(int n, const isegmi_conv_desc* descs, const float* const* d_in, const float* const* d_w, const float* const* d_scale,
                            const float* const* d_shift, const float* const* d_res, float* const* d_out, void* stream);
 
@@ -218,7 +219,8 @@ typedef struct isegmi_yolact_detect_args {
     int32_t mask_tanh;
     int64_t pix_stride;
     int32_t off_loc, off_conf, off_mask;
-    int32_t reserved;
+    int32_t second_threshold;   /* App. A.6 fork, fast_nms(second_threshold=True): a box must also have its class score > conf_thresh (a prior passes
+                                   the pre-filter on its BEST class and is ranked in every class); 0 = the default detect() call */
 } isegmi_yolact_detect_args;
 int isegmi_op_yolact_detect(const isegmi_yolact_detect_args* a, void* stream);
 
@@ -233,39 +235,47 @@ int isegmi_op_yolact_masks(const float* d_proto, const float* d_coeffs, const fl
                            void* stream);
 
 /* ---- Mask R-CNN RoI ops (M6 M7 M9 M10 M11 M12; App. A.4-A.8; all reached from README.md:331) ---- */
+/* Semantic forks of the NMS (which of them detectron.jittor takes is unknown -- the reference tree holds no code -- so every one is a
+ * switch).  OR-ed into the `nms_flags` argument of isegmi_op_rpn_level / _rpn_levels / isegmi_box_post_args; 0 = maskrcnn-benchmark's CUDA path. */
+#define ISEGMI_NMS_GE 1           /* suppress on iou >= thr (the CPU loop) instead of iou > thr (the CUDA kernel, jt.nms) */
+#define ISEGMI_NMS_NO_PLUS_ONE 2  /* plain areas (x2-x1)*(y2-y1) in the IoU instead of the legacy +1 widths */
+#define ISEGMI_NMS_INDEX_ORDER 4  /* box post-processing only: a class's kept detections in ascending proposal index (the CPU NMS returns nonzero(keep))
+                                     instead of score order; the RPN truncates a score-sorted list, where both orders keep the same boxes in the same order */
 /* greedy NMS (A.6): `problems` independent sets of n <= 6144 boxes; visiting order (score desc, index
  * asc); IoU with legacy +1 areas when plus_one; suppress on iou > thr (ge: >=).  d_keep [problems][n]
  * receives ORIGINAL indices in score order, d_cnt [problems] the count (<= max_keep when max_keep > 0). */
 int isegmi_op_nms(const float* d_boxes, const float* d_scores, int problems, int n, float thr,
                   int plus_one, int ge, int max_keep, int32_t* d_keep, int32_t* d_cnt, void* stream);
-/* LevelMapper + RoIAlign (A.7, legacy aligned=False).  d_feats: host array of nlevels device pointers
+/* LevelMapper + RoIAlign (A.7).  aligned 0: the legacy op (no half-pixel shift, RoI at least one pixel wide and high -- maskrcnn-benchmark); aligned 1:
+ * ROIAlign(aligned=True) -- scaled corners minus 0.5, no minimum size (the other side of the App. A.7 fork).  d_feats: host array of nlevels device pointers
  * (NHWC, level k_min first); rois [N][K][4] image coords; counts [N]; out [N*K][PH][PW][C] (rows past
  * count zero-filled).  fixed_level >= 0 bypasses the LevelMapper.  d_out_level [N][K] optional.
  * sampling > 0: fixed sampling x sampling grid per bin; sampling <= 0: adaptive ceil(roi / pooled) (ROIAlign's
  * sampling_ratio = 0, used by the R-50-C4 config of README.md:263-273). */
 int isegmi_op_roi_align(const float* const* d_feats, const int32_t* Hs, const int32_t* Ws,
                         const float* scales, int nlevels, const float* d_rois, const int32_t* d_counts,
-                        int N, int K, int C, int PH, int PW, int sampling, int k_min, int fixed_level,
+                        int N, int K, int C, int PH, int PW, int sampling, int aligned, int k_min, int fixed_level,
                         float* d_out, int32_t* d_out_level, void* stream);
 /* nn.AvgPool2d over the whole window of every RoI (FastRCNNPredictor of the C4 box head): x [R][HW][C] -> out [R][C] */
 int isegmi_op_avgpool_full(const float* d_x, int64_t R, int HW, int C, float* d_out, void* stream);
 /* fp16-storage LevelMapper + RoIAlign (configs[4]): d_feats / d_out are fp16, arithmetic is the fp32 op's. */
 int isegmi_op_roi_align_f16(const void* const* d_feats, const int32_t* Hs, const int32_t* Ws,
                             const float* scales, int nlevels, const float* d_rois, const int32_t* d_counts,
-                            int N, int K, int C, int PH, int PW, int sampling, int k_min, void* d_out, void* stream);
+                            int N, int K, int C, int PH, int PW, int sampling, int aligned, int k_min, void* d_out, void* stream);
 /* The FPN heads' RoIAlign (sampling 2, LevelMapper) as two launches.  isegmi_op_roi_prep, one thread per RoI: d_table [N*K][2*(PH+PW)+1][4]
  * int32 -- for each of the RoI's 2*PH sample rows and 2*PW sample columns {byte offset of the low tap, of the high tap, weight of the low
- * tap, of the high tap (fp32 bits)} with the validity test and clamps of the scalar op applied, then {level index, H, W, 0} -- and, when
+ * tap, of the high tap (fp32 bits)} with the validity test and clamps of the scalar op applied (a sample outside the map: weights +0 and tap offsets
+ * past the end of the map, which the pooling launch's range-checked loads read as 0), then {level index, H, W, signature of (C * elem_bytes, PH, PW)} -- and, when
  * d_order is not NULL, d_order [N][K] = every image's RoI rows n*K + k sorted by (level, Morton code of the RoI centre on that level's map),
- * rows past count last.  K <= 2048; elem_bytes 4 (fp32 features) or 2 (fp16); a level's map must stay under 2 GiB per image.
+ * rows past count last.  K <= 2048; elem_bytes 4 (fp32 features) or 2 (fp16); a level's map must stay under 512 MiB per image; `aligned` as in isegmi_op_roi_align.
  * isegmi_op_roi_align_ordered / _f16_ordered then run workgroup L on one 128-byte channel slice of RoI d_order[L / 8 ...] (d_order NULL: row
  * order) so that RoIs sharing pixels are in flight together and every XCD's L2 holds its own slice of them; 7x7 or 14x14 bins, C in
- * {32..256} (fp32) / {64..512} (fp16).  Outputs are those of isegmi_op_roi_align / _f16 bit for bit on finite features, whatever permutation
- * d_order holds (entries outside [0, N*K) are skipped, rows it leaves out are not written).  d_rois / d_counts / scales / k_min must be the
- * ones the table was made from. */
+ * {32..256} (fp32) / {64..512} (fp16).  Outputs are those of isegmi_op_roi_align / _f16 bit for bit for ANY feature values (inf / NaN included), whatever
+ * permutation d_order holds (entries outside [0, N*K) are skipped, rows it leaves out are not written).  d_rois / d_counts / scales / k_min must be the
+ * ones the table was made from; a table made for another C * elem_bytes / PH / PW fills the RoI's output with NaN. */
 int64_t isegmi_op_roi_table_bytes(int N, int K, int PH, int PW);
 int isegmi_op_roi_prep(const float* d_rois, const int32_t* d_counts, int N, int K, const int32_t* Hs, const int32_t* Ws,
-                       const float* scales, int nlevels, int k_min, int C, int PH, int PW, int elem_bytes,
+                       const float* scales, int nlevels, int k_min, int C, int PH, int PW, int elem_bytes, int aligned,
                        int32_t* d_order, void* d_table, void* stream);
 int isegmi_op_roi_align_ordered(const float* const* d_feats, const int32_t* Hs, const int32_t* Ws,
                                 const float* scales, int nlevels, const float* d_rois, const int32_t* d_counts,
@@ -276,9 +286,10 @@ int isegmi_op_roi_align_f16_ordered(const void* const* d_feats, const int32_t* H
                                     const int32_t* d_order, const void* d_table, int N, int K, int C, int PH, int PW,
                                     int k_min, void* d_out, void* stream);
 /* PostProcessor.filter_results (A.5): softmax, per-class decode(10,10,5,5)+clip, score filter, NMS,
- * kth-value cut to det_per_img.  Output order: class ascending, NMS order inside a class. */
+ * kth-value cut to det_per_img.  Output order: class ascending, NMS (score) order inside a class -- proposal-index order with
+ * ISEGMI_NMS_INDEX_ORDER. */
 typedef struct isegmi_box_post_args {
-    int32_t N, R, ncls, det_per_img, cap, nms_ge;
+    int32_t N, R, ncls, det_per_img, cap, nms_flags;   /* nms_flags: OR of ISEGMI_NMS_* */
     float score_thresh, nms_thresh;
     int64_t logits_stride, regr_stride;   /* floats between consecutive rois */
     const float* d_logits;     /* [N*R] rows of ncls */
@@ -309,7 +320,7 @@ int isegmi_op_grid_anchors(const float* d_base, int A, int stride, int grid_h, i
 /* one RPN level (A.4) for N images: fused head [N][HW][A*5] (A logits then A*4 deltas per pixel) */
 int isegmi_op_rpn_level(const float* d_head, const float* d_anchors, const int32_t* d_image_hw, int N,
                         int HW, int A, int pre_nms, int post_nms, float nms_thr, float min_size,
-                        int nms_ge, float* d_ws_prob, float* d_ws_tk_vals, int32_t* d_ws_tk_idx,
+                        int nms_flags /* ISEGMI_NMS_GE | ISEGMI_NMS_NO_PLUS_ONE */, float* d_ws_prob, float* d_ws_tk_vals, int32_t* d_ws_tk_idx,
                         int32_t* d_ws_tk_cnt, float* d_out_boxes, float* d_out_scores,
                         int32_t* d_out_cnt, void* d_ws_nms /* optional: N * 131072 bytes, the suppression
                         matrix of the chip-wide NMS used when pre_nms <= 1024; NULL = single-block NMS */,
@@ -321,7 +332,7 @@ int isegmi_op_rpn_level(const float* d_head, const float* d_anchors, const int32
  * nl*N*pre_nms, tk_cnt nl*N, nms nl*N*131072 bytes. */
 int isegmi_op_rpn_levels_workspace(int nl, int N, const int32_t* HW, int A, int pre_nms, int64_t* prob_elems, int64_t* cand_elems);
 int isegmi_op_rpn_levels(int nl, const float* const* d_heads, const float* const* d_anchors, const int32_t* HW, const int32_t* d_image_hw, int N, int A,
-                         int pre_nms, int post_nms, float nms_thr, float min_size, int nms_ge, float* d_ws_prob, float* d_ws_cand_vals,
+                         int pre_nms, int post_nms, float nms_thr, float min_size, int nms_flags, float* d_ws_prob, float* d_ws_cand_vals,
                          int32_t* d_ws_cand_idx, float* d_ws_tk_vals, int32_t* d_ws_tk_idx, int32_t* d_ws_tk_cnt, void* d_ws_nms,
                          float* d_out_boxes, float* d_out_scores, int32_t* d_out_cnt, void* stream);
 
@@ -477,6 +488,10 @@ int isegmi_comm_fence_producer(isegmi_comm* c, int slot, void* producer_stream);
 int isegmi_comm_allgather_slot(isegmi_comm* c, int slot, const void* d_send, void* d_recv, int64_t bytes,
                                void* producer_stream);
 int isegmi_comm_wait_slot(isegmi_comm* c, int slot);
+/* Collectives of one communicator run in the order the host issued them, whatever streams they were given: one that goes to another stream than its
+ * predecessor first makes that stream wait for the predecessor's completion event.  out4 = {rank, world, collectives issued, how many of them changed
+ * stream} (diagnostic: isegmi.dist keeps every data step, empty step and redo of a run on ONE stream, so the last number stays 0 between control words). */
+int isegmi_comm_info(isegmi_comm* c, int64_t* out4);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

@@ -609,8 +609,7 @@ static int launch_btl(BtlK& k, hipStream_t st, int few) {
     const int64_t total = (int64_t)k.N * k.tiles_x * k.tiles_y;
     ARG_CHECK(total < (1 << 30), "too many tiles");
     k.total = (int)total;
-    static PerDeviceOnce attr;
-    if (attr.need()) HIP_TRY(hipFuncSetAttribute((const void*)bottleneck_f16_kernel<CF>, hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS));
+    LDS_LIMIT_ONCE(CF::LDS, bottleneck_f16_kernel<CF>);
     const int ncu = device_cu_count();
     int64_t slots = few ? 8 : (int64_t)(ncu / 8) * 8;  // one block per CU; a multiple of 8 keeps a block's tiles on its XCD
     if (slots < 8) slots = 8;

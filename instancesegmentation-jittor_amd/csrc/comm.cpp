@@ -71,6 +71,13 @@ struct isegmi_comm {
     hipEvent_t done[COMM_SLOTS] = {nullptr, nullptr};
     bool used[COMM_SLOTS] = {false, false};
     int rank = 0, world = 1;
+    // One communicator = ONE order of collectives.  RCCL launches a collective on the stream it is given; two collectives of one communicator on two
+    // streams are ordered only by the runtime's good will.  last_slot / last_stream remember where the previous collective went: a collective that goes
+    // to ANOTHER stream first makes that stream wait (on the device) for the previous one's done event, so the order in which the host issued them is
+    // the order in which they run, whatever streams the caller mixes (a rank's empty step or a control word between two data steps).
+    int last_slot = -1;
+    hipStream_t last_stream = nullptr;
+    int64_t collectives = 0, stream_switches = 0;
 };
 
 extern "C" int isegmi_comm_unique_id(void* out128) {
@@ -121,7 +128,7 @@ extern "C" int isegmi_comm_fence_producer(isegmi_comm* c, int slot, void* produc
 
 // All-gather `bytes` bytes from every rank through slot `slot` (0 or 1): d_recv holds world*bytes, rank r's block at r*bytes.
 // Runs ON `producer_stream` (the engine's results stream), right behind the kernel that packed the block; on the comm's own stream only when
-// there is no producer (a rank's empty step).  Rounds 1-2 always used the comm's stream: one more stream for the runtime to fold onto its four
+// there is no producer (a control word; isegmi.dist hands a rank's empty step the stream of its data steps).  Rounds 1-2 always used the comm's stream: one more stream for the runtime to fold onto its four
 // hardware queues -- on the measured box it shared the MAIN stream's queue, so the collective of step i (enqueued after forward i, waiting for
 // step i's last kernel) sat in front of forward i+1's backbone in that in-order queue and the cross-step overlap was gone: bench.py through its
 // N > 1 code path on one GPU (world-1 communicators, tools/forced_dist_bench.sh) read 926 img/s against 961 without the collective.  On the
@@ -129,14 +136,26 @@ extern "C" int isegmi_comm_fence_producer(isegmi_comm* c, int slot, void* produc
 extern "C" int isegmi_comm_allgather_slot(isegmi_comm* c, int slot, const void* d_send, void* d_recv, int64_t bytes, void* producer_stream) {
     ARG_CHECK(c && d_send && d_recv && bytes > 0 && slot >= 0 && slot < COMM_SLOTS, "allgather args");
     hipStream_t s = producer_stream ? (hipStream_t)producer_stream : c->stream;
+    if (c->last_slot >= 0 && c->last_stream != s) {   // the previous collective of this communicator went to another stream: order behind it
+        HIP_TRY(hipStreamWaitEvent(s, c->done[c->last_slot], 0));
+        ++c->stream_switches;
+    }
     RCCL_TRY(R.allgather(d_send, d_recv, (size_t)bytes, ncclInt8, c->comm, s));
     HIP_TRY(hipEventRecord(c->done[slot], s));
     c->used[slot] = true;
+    c->last_slot = slot; c->last_stream = s;
+    ++c->collectives;
     return ISEGMI_OK;
 }
 
 extern "C" int isegmi_comm_allgather(isegmi_comm* c, const void* d_send, void* d_recv, int64_t bytes, void* producer_stream) {
     return isegmi_comm_allgather_slot(c, 0, d_send, d_recv, bytes, producer_stream);
+}
+
+extern "C" int isegmi_comm_info(isegmi_comm* c, int64_t* out4) {
+    ARG_CHECK(c && out4, "null");
+    out4[0] = c->rank; out4[1] = c->world; out4[2] = c->collectives; out4[3] = c->stream_switches;
+    return ISEGMI_OK;
 }
 
 extern "C" int isegmi_comm_wait_slot(isegmi_comm* c, int slot) {

@@ -948,12 +948,10 @@ static int launch(const isegmi_conv_desc* d, ConvK& k, hipStream_t st) {
     const size_t lds = 2 * (size_t)(BM + BN) * LDS_ROW * sizeof(float);
     const dim3 grid((unsigned)(k.mtiles * k.ntiles)), block(256);
     if (is_stem(d)) {
-        static PerDeviceOnce attr;
-        if (attr.need()) HIP_TRY(hipFuncSetAttribute((const void*)conv_mfma_kernel<BM, BN, WM, WN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        LDS_LIMIT_ONCE((int)lds, conv_mfma_kernel<BM, BN, WM, WN, true>);
         hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, true>), grid, block, lds, st, k);
     } else {
-        static PerDeviceOnce attr;
-        if (attr.need()) HIP_TRY(hipFuncSetAttribute((const void*)conv_mfma_kernel<BM, BN, WM, WN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        LDS_LIMIT_ONCE((int)lds, conv_mfma_kernel<BM, BN, WM, WN, false>);
         hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, false>), grid, block, lds, st, k);
     }
     HIP_TRY(hipGetLastError());
@@ -1117,7 +1115,10 @@ int conv2d_launch(const isegmi_conv_desc* d, const float* in, const float* w, co
 }
 
 // n independent fp32 convolutions as one launch (see conv_group_kernel).  Parts: a conv of at least 256 tiles of 64 x 64 and more than 32 output channels
-// runs on v2 tiles when the group as a whole fills the chip twice over (> 480 such tiles), everything else on 32 x 32 blocks.
+// runs on v2 tiles when the group as a whole fills the chip twice over (> 480 such tiles), everything else on 32 x 32 blocks.  The tile FORM is chosen
+// per group, not per member as a member's own launch would choose it (one LDS ring depth for all v2 parts: 4 as soon as any of them walks >= 72
+// chunks; the small / narrow members on 32 x 32 blocks whatever conv2d_launch's ladder would pick): same results -- every fp32 tile form keeps the
+// single k-ordered chain per output and is oracle-exact -- not the same launch.
 int conv2d_group_launch(int n, const isegmi_conv_desc* const* d, const float* const* in, const float* const* w, const float* const* scale,
                         const float* const* shift, const float* const* res, float* const* out, hipStream_t st) {
     ARG_CHECK(n >= 1 && n <= CONV_GROUP_MAX && d && in && w && out, "conv group: 1..10 members");
@@ -1126,6 +1127,7 @@ int conv2d_group_launch(int n, const isegmi_conv_desc* const* d, const float* co
     int64_t t64[CONV_GROUP_MAX], total64 = 0;
     for (int i = 0; i < n; ++i) {
         ARG_CHECK(d[i] && !is_stem(d[i]) && d[i]->tile == 0, "conv group: no stem, no forced tile");
+        ARG_CHECK(in[i] && w[i] && out[i], "conv group: a member's input, weights or output pointer is NULL");
         const int rc = conv_fill(d[i], in[i], w[i], scale ? scale[i] : nullptr, shift ? shift[i] : nullptr, res ? res[i] : nullptr, out[i], ks[i]);
         if (rc) return rc;
         t64[i] = (int64_t)cdiv(ks[i].M, 64) * cdiv(d[i]->Cout, 64);

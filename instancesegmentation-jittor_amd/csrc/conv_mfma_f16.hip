@@ -1088,8 +1088,7 @@ static int launch_strip(ConvKH& k, hipStream_t st) {
     k.trace = tracing ? trace_buf : nullptr;
     if (tracing && getenv("ISEGMI_STRIP_TRACE_LIGHT")) k.dbg |= 16;
 #endif
-    static PerDeviceOnce attr;
-    if (attr.need()) HIP_TRY(hipFuncSetAttribute((const void*)conv3x3_f16_strip_kernel<BM, BN, WM, WN, LW, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_attr));
+    LDS_LIMIT_ONCE((int)lds_attr, conv3x3_f16_strip_kernel<BM, BN, WM, WN, LW, NB>);
     hipLaunchKernelGGL((conv3x3_f16_strip_kernel<BM, BN, WM, WN, LW, NB>), dim3((unsigned)(k.mtiles * k.ntiles)), dim3((NW + LW) * 64), lds, st, k);
     HIP_TRY(hipGetLastError());
 #ifdef ISEGMI_STRIP_TRACE
@@ -1117,8 +1116,7 @@ static int launch_g(ConvKH& k, hipStream_t st) {
     size_t lds = (size_t)NSTAGE * (BM + BN) * 128;
     const size_t epi = (size_t)NW * 32 * (TN * 32 + 4) * 4;
     if (epi > lds) lds = epi;
-    static PerDeviceOnce attr;
-    if (attr.need()) HIP_TRY(hipFuncSetAttribute((const void*)conv_f16_glds_kernel<BM, BN, WM, WN, NSTAGE, OCC, STEM, LW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    LDS_LIMIT_ONCE((int)lds, conv_f16_glds_kernel<BM, BN, WM, WN, NSTAGE, OCC, STEM, LW>);
     hipLaunchKernelGGL((conv_f16_glds_kernel<BM, BN, WM, WN, NSTAGE, OCC, STEM, LW>), dim3((unsigned)(k.mtiles * k.ntiles)), dim3((NW + LW) * 64), lds, st, k);
     HIP_TRY(hipGetLastError());
     return ISEGMI_OK;
@@ -1134,8 +1132,7 @@ static int launch_p(ConvKH& k, hipStream_t st, bool few) {
     size_t lds = (size_t)NSTAGE * (BM + BN) * 128;
     const size_t epi = (size_t)NW * 32 * (TN * 32 + 4) * 4;  // the per-element epilogue path uses none; kept >= the one-tile kernel's request
     (void)epi;
-    static PerDeviceOnce attr;
-    if (attr.need()) HIP_TRY(hipFuncSetAttribute((const void*)conv_f16_persist_kernel<BM, BN, WM, WN, NSTAGE, OCC, LW, UP2X>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    LDS_LIMIT_ONCE((int)lds, conv_f16_persist_kernel<BM, BN, WM, WN, NSTAGE, OCC, LW, UP2X>);
     const int ncu = device_cu_count();
     const int64_t total = (int64_t)k.mtiles * k.ntiles;
     int64_t slots = few ? 8 : (int64_t)(ncu / 8) * 8 * OCC;  // a multiple of 8, so that a block's tiles stay on its XCD

@@ -1000,8 +1000,7 @@ static int launch_strip(ConvKH& k, hipStream_t st) {
     k.trace = tracing ? trace_buf : nullptr;
     if (tracing && getenv("ISEGMI_STRIP_TRACE_LIGHT")) k.dbg |= 16;
 #endif
-    static PerDeviceOnce attr;
-    if (attr.need()) HIP_TRY(hipFuncSetAttribute((const void*)conv3x3_f16_strip_kernel<BM, BN, WM, WN, LW, NB, MS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_attr));
+    LDS_LIMIT_ONCE((int)lds_attr, conv3x3_f16_strip_kernel<BM, BN, WM, WN, LW, NB, MS>);
     hipLaunchKernelGGL((conv3x3_f16_strip_kernel<BM, BN, WM, WN, LW, NB, MS>), dim3((unsigned)(k.mtiles * k.ntiles)), dim3((NW + LW) * 64), lds, st, k);
     HIP_TRY(hipGetLastError());
 #ifdef ISEGMI_STRIP_TRACE
@@ -1033,8 +1032,7 @@ static int launch_p(ConvKH& k, hipStream_t st, bool few) {
     // (conv_f16_persist_kernel: EFIT, issue_chunk) -- only where the tile needs them
     if ((BM / 8) % LW != 0 || (size_t)NW * 16 * (TN * 32 + 4) * 4 > (size_t)(BM + BN) * 128) lds += 5120 + (size_t)LW * 1024;
     static_assert(NSTAGE * (BM + BN) * 128 + 5120 + LW * 1024 <= 163840 || ((BM / 8) % LW == 0 && NW * 16 * (TN * 32 + 4) * 4 <= (BM + BN) * 128), "LDS");
-    static PerDeviceOnce attr;
-    if (attr.need()) HIP_TRY(hipFuncSetAttribute((const void*)conv_f16_persist_kernel<BM, BN, WM, WN, NSTAGE, OCC, LW, UP2X, MS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    LDS_LIMIT_ONCE((int)lds, conv_f16_persist_kernel<BM, BN, WM, WN, NSTAGE, OCC, LW, UP2X, MS>);
     const int ncu = device_cu_count();
     const int64_t total = (int64_t)k.mtiles * k.ntiles;
     int64_t slots = few ? 8 : (int64_t)(ncu / 8) * 8 * OCC;  // a multiple of 8, so that a block's tiles stay on its XCD

@@ -822,6 +822,7 @@ int yolact_forward(Engine& e, const float* d_images, int N) {
     a.N = N; a.P = Ptot; a.ncls = ncls; a.mask_dim = md; a.top_k = top_k; a.max_det = max_det;
     a.conf_thresh = e.param("nms_conf_thresh", 0.05f);
     a.nms_thresh = e.param("nms_thresh", 0.5f);
+    a.second_threshold = (int)e.param("nms_second_threshold", 0) ? 1 : 0;   // App. A.6 fork (fast_nms(second_threshold=...)): default off
     if (fused) {
         a.d_conf = a.d_loc = a.d_mask = (const float*)headcat;
         a.A = A; a.pix_stride = CH; a.off_loc = 0; a.off_conf = A * 4; a.off_mask = A * 4 + A * ncls; a.mask_tanh = 1;

@@ -225,9 +225,9 @@ int maxpool_to_f16_launch(const void* in, int in_f16, int N, int H, int W, int C
 int nearest2x_add_f16_launch(const void* coarse, int N, int Hc, int Wc, int C, const void* lat, int H, int W, void* out, hipStream_t st);
 int roi_align_f16_launch(const void* const* feats, const int* Hs, const int* Ws, const float* scales, int nlevels, const float* rois,
                          const int* counts, int N, int K, int C, int PH, int PW, int g, int k_min, void* out, hipStream_t st,
-                         const int* order = nullptr, const void* tab = nullptr);
+                         const int* order = nullptr, const void* tab = nullptr, int aligned = 0);
 int roi_prep_launch(const float* rois, const int* counts, int N, int K, const int* Hs, const int* Ws, const float* scales, int nlevels, int k_min, int C,
-                    int PH, int PW, int esize, int* order, void* tab, hipStream_t st);
+                    int PH, int PW, int esize, int* order, void* tab, hipStream_t st, int aligned = 0);
 int mask_logits_select_f16_launch(const void* feat, int R, int HW, int C, const float* w, const float* b, const int* labels, float* out,
                                   hipStream_t st);
 int maxpool_launch(const float* in, int N, int H, int W, int C, int k, int s, int p, float* out, hipStream_t st);

@@ -24,7 +24,7 @@ int gather_proposals_launch(const float* cand_boxes, const float* fin_vals, cons
                             int cand_per_img, int K, float* props, float* prop_scores, int* prop_cnt, hipStream_t st);
 int roi_align_launch(const float* const* feats, const int* Hs, const int* Ws, const float* scales, int nlevels, const float* rois,
                      const int* counts, int N, int K, int C, int PH, int PW, int g, int k_min, int fixed_level, float* out,
-                     int* out_level, hipStream_t st, const int* order = nullptr, const void* tab = nullptr);
+                     int* out_level, hipStream_t st, const int* order = nullptr, const void* tab = nullptr, int aligned = 0);
 int box_postprocess_launch(const isegmi_box_post_args* a, hipStream_t st);
 int mask_logits_select_launch(const float* feat, int R, int HW, int C, const float* w, const float* b, const int* labels, float* out,
                               hipStream_t st);
@@ -36,6 +36,14 @@ int topk_launch(const float* keys, int64_t row_stride, int rows, int n, int k, c
 int64_t topk_scratch_elems(int rows, int n, int k);
 int topk_launch_ws(const float* keys, int64_t row_stride, int rows, int n, int k, const int* limit, int rows_per_limit, float* out_vals,
                    int* out_idx, int* out_cnt, float* ws_vals, int* ws_idx, hipStream_t st);
+
+// SURVEY 7.2 / App. A.6-A.7 semantic forks as engine parameters (defaults = the maskrcnn-benchmark CUDA path): "nms_ge" 1 suppress on iou >= thr;
+// "nms_plus_one" 0 plain areas in the NMS IoU; "nms_index_order" 1 a class's detections in ascending proposal index (CPU nonzero order);
+// "roi_aligned" 1 ROIAlign(aligned=True).
+static int maskrcnn_nms_flags(Engine& e) {
+    return ((int)e.param("nms_ge", 0) ? ISEGMI_NMS_GE : 0) | ((int)e.param("nms_plus_one", 1) ? 0 : ISEGMI_NMS_NO_PLUS_ONE) |
+           ((int)e.param("nms_index_order", 0) ? ISEGMI_NMS_INDEX_ORDER : 0);
+}
 
 #define TRY(x)               \
     do {                     \
@@ -211,7 +219,7 @@ int maskrcnn_forward(Engine& e, const float* d_images, int N) {
     const int pre_nms = (int)e.param("rpn_pre_nms_top_n", 1000), post_nms = (int)e.param("rpn_post_nms_top_n", 1000);
     const int fpn_post = (int)e.param("rpn_fpn_post_nms_top_n", 1000);
     const float rpn_thr = e.param("rpn_nms_thresh", 0.7f), rpn_min = e.param("rpn_min_size", 0.0f);
-    const int ge = (int)e.param("nms_ge", 0);
+    const int ge = maskrcnn_nms_flags(e), roi_aligned = (int)e.param("roi_aligned", 0) ? 1 : 0;
     // per level up to 6144 (above 1024 the single-block NMS with 96 KB of boxes in LDS takes over from the chip-wide bitmask NMS); the merged
     // list feeds the per-class box NMS, whose suppression matrix holds 1024 proposals per image
     if (pre_nms > 6144 || post_nms > 6144 || fpn_post > 1024) { set_error("RPN: PRE / POST_NMS_TOP_N_TEST <= 6144 per level, FPN_POST_NMS_TOP_N_TEST <= 1024"); return ISEGMI_ERR_ARG; }
@@ -421,10 +429,10 @@ int maskrcnn_forward(Engine& e, const float* d_images, int N) {
             TRY(eng_buf(e, "roi_order", (int64_t)N * R * 4, &p, 1, {N, R}));
             order = (int*)p;
             TRY(eng_buf(e, "box.roi_table", (int64_t)N * R * 29 * 16, &tab, 1, {N * R, 29, 4}));
-            TRY(roi_prep_launch(props, prop_cnt, N, R, Hs, Ws, scales, 4, 2, 256, 7, 7, dt ? 2 : 4, order, tab, st));
+            TRY(roi_prep_launch(props, prop_cnt, N, R, Hs, Ws, scales, 4, 2, 256, 7, 7, dt ? 2 : 4, order, tab, st, roi_aligned));
         }
-        if (dt) TRY(roi_align_f16_launch((const void* const*)feats, Hs, Ws, scales, 4, props, prop_cnt, N, R, 256, 7, 7, 2, 2, roi7.d, st, order, tab));
-        else TRY(roi_align_launch(feats, Hs, Ws, scales, 4, props, prop_cnt, N, R, 256, 7, 7, 2, 2, -1, roi7.d, nullptr, st, order, tab));
+        if (dt) TRY(roi_align_f16_launch((const void* const*)feats, Hs, Ws, scales, 4, props, prop_cnt, N, R, 256, 7, 7, 2, 2, roi7.d, st, order, tab, roi_aligned));
+        else TRY(roi_align_launch(feats, Hs, Ws, scales, 4, props, prop_cnt, N, R, 256, 7, 7, 2, 2, -1, roi7.d, nullptr, st, order, tab, roi_aligned));
     }
     TRY(eng_conv(e, "roi_heads.box.feature_extractor.fc6", roi7, 1, 0, 1, nullptr, "box.fc6", &f6));
     TRY(eng_conv(e, "roi_heads.box.feature_extractor.fc7", f6, 1, 0, 1, nullptr, "box.fc7", &f7));
@@ -433,7 +441,7 @@ int maskrcnn_forward(Engine& e, const float* d_images, int N) {
     if (cb.C != ncls * 5) { set_error("cls_bbox layer must have 81+324 outputs"); return ISEGMI_ERR_STATE; }
     isegmi_box_post_args a;
     memset(&a, 0, sizeof(a));
-    a.N = N; a.R = R; a.ncls = ncls; a.det_per_img = dpi; a.cap = cap; a.nms_ge = ge;
+    a.N = N; a.R = R; a.ncls = ncls; a.det_per_img = dpi; a.cap = cap; a.nms_flags = ge;
     a.score_thresh = e.param("roi_score_thresh", 0.05f);
     a.nms_thresh = e.param("roi_nms_thresh", 0.5f);
     a.logits_stride = cb.C; a.regr_stride = cb.C;
@@ -466,10 +474,10 @@ int maskrcnn_forward(Engine& e, const float* d_images, int N) {
             TRY(eng_buf(e, "mask.roi_order", (int64_t)N * cap * 4, &p, 1, {N, cap}));
             order = (int*)p;
             TRY(eng_buf(e, "mask.roi_table", (int64_t)N * cap * 57 * 16, &tab, 1, {N * cap, 57, 4}));
-            TRY(roi_prep_launch(a.d_out_boxes, a.d_out_count, N, cap, Hs, Ws, scales, 4, 2, 256, 14, 14, dt ? 2 : 4, order, tab, st));
+            TRY(roi_prep_launch(a.d_out_boxes, a.d_out_count, N, cap, Hs, Ws, scales, 4, 2, 256, 14, 14, dt ? 2 : 4, order, tab, st, roi_aligned));
         }
-        if (dt) TRY(roi_align_f16_launch((const void* const*)feats, Hs, Ws, scales, 4, a.d_out_boxes, a.d_out_count, N, cap, 256, 14, 14, 2, 2, m.d, st, order, tab));
-        else TRY(roi_align_launch(feats, Hs, Ws, scales, 4, a.d_out_boxes, a.d_out_count, N, cap, 256, 14, 14, 2, 2, -1, m.d, nullptr, st, order, tab));
+        if (dt) TRY(roi_align_f16_launch((const void* const*)feats, Hs, Ws, scales, 4, a.d_out_boxes, a.d_out_count, N, cap, 256, 14, 14, 2, 2, m.d, st, order, tab, roi_aligned));
+        else TRY(roi_align_launch(feats, Hs, Ws, scales, 4, a.d_out_boxes, a.d_out_count, N, cap, 256, 14, 14, 2, 2, -1, m.d, nullptr, st, order, tab, roi_aligned));
     }
     for (int i = 1; i <= 4; ++i) {
         Tensor o;
@@ -577,7 +585,7 @@ static int maskrcnn_c4_forward(Engine& e, const float* d_images, int N) {
     const int A = 15, CH = 75;
     const int pre_nms = (int)e.param("rpn_pre_nms_top_n", 6000), post_nms = (int)e.param("rpn_post_nms_top_n", 1000);
     const float rpn_thr = e.param("rpn_nms_thresh", 0.7f), rpn_min = e.param("rpn_min_size", 0.0f);
-    const int ge = (int)e.param("nms_ge", 0);
+    const int ge = maskrcnn_nms_flags(e), roi_aligned = (int)e.param("roi_aligned", 0) ? 1 : 0;
     if (pre_nms > 6144 || post_nms > 1024) { set_error("C4 RPN: pre_nms <= 6144, post_nms <= 1024"); return ISEGMI_ERR_ARG; }
     Tensor t, head;
     TRY(eng_conv(e, "rpn.head.conv", C4, 1, 1, 1, nullptr, "rpn.t", &t));
@@ -612,7 +620,7 @@ static int maskrcnn_c4_forward(Engine& e, const float* d_images, int N) {
     const float scales[1] = {0.0625f};
     Tensor roi, f5, cb;
     TRY(eng_act(e, "box.roi_feat", N * R, 14, 14, C4.C, &roi));
-    TRY(roi_align_launch(feats, Hs, Ws, scales, 1, props, prop_cnt, N, R, C4.C, 14, 14, 0, 4, 0, roi.d, nullptr, st));
+    TRY(roi_align_launch(feats, Hs, Ws, scales, 1, props, prop_cnt, N, R, C4.C, 14, 14, 0, 4, 0, roi.d, nullptr, st, nullptr, nullptr, roi_aligned));
     TRY(res5_head(e, "roi_heads.box.feature_extractor.head.layer4", "box.res5", roi, &f5));
     Tensor pooled;
     TRY(eng_act(e, "box.pooled", N * R, 1, 1, f5.C, &pooled));
@@ -622,7 +630,7 @@ static int maskrcnn_c4_forward(Engine& e, const float* d_images, int N) {
     if (cb.C != ncls * 5) { set_error("cls_bbox layer must have 81+324 outputs"); return ISEGMI_ERR_STATE; }
     isegmi_box_post_args a;
     memset(&a, 0, sizeof(a));
-    a.N = N; a.R = R; a.ncls = ncls; a.det_per_img = dpi; a.cap = cap; a.nms_ge = ge;
+    a.N = N; a.R = R; a.ncls = ncls; a.det_per_img = dpi; a.cap = cap; a.nms_flags = ge;
     a.score_thresh = e.param("roi_score_thresh", 0.05f);
     a.nms_thresh = e.param("roi_nms_thresh", 0.5f);
     a.logits_stride = cb.C; a.regr_stride = cb.C;
@@ -643,7 +651,7 @@ static int maskrcnn_c4_forward(Engine& e, const float* d_images, int N) {
     // ---- mask head: the shared extractor on the detections, then MaskRCNNC4Predictor
     Tensor mroi, m5, up;
     TRY(eng_act(e, "mask.roi_feat", N * cap, 14, 14, C4.C, &mroi));
-    TRY(roi_align_launch(feats, Hs, Ws, scales, 1, a.d_out_boxes, a.d_out_count, N, cap, C4.C, 14, 14, 0, 4, 0, mroi.d, nullptr, st));
+    TRY(roi_align_launch(feats, Hs, Ws, scales, 1, a.d_out_boxes, a.d_out_count, N, cap, C4.C, 14, 14, 0, 4, 0, mroi.d, nullptr, st, nullptr, nullptr, roi_aligned));
     TRY(res5_head(e, "roi_heads.box.feature_extractor.head.layer4", "mask.res5", mroi, &m5));
     TRY(eng_act(e, "mask.deconv", N * cap, 14, 14, 256, &up));
     {

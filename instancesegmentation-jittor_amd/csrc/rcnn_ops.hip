@@ -103,6 +103,11 @@ __device__ __forceinline__ bool iou_exceeds(const float4 a, const float4 b, floa
     return lhs > rhs || (lhs == rhs && t.tie_true);
 }
 
+// The `ge` / `nms_flags` argument of the engine-level launches below is the OR of the App. A.6 forks (include/isegmi.h): ISEGMI_NMS_GE (1) suppress on
+// iou >= thr instead of >; ISEGMI_NMS_NO_PLUS_ONE (2) plain areas instead of the legacy +1; ISEGMI_NMS_INDEX_ORDER (4, box post-processing only) a class's
+// kept detections in ascending proposal index (the CPU NMS's nonzero order) instead of score order.
+__device__ __forceinline__ float nms_one(int flags) { return (flags & ISEGMI_NMS_NO_PLUS_ONE) ? 0.0f : 1.0f; }
+
 // ------------------------------------------------------------------ greedy NMS core (block = NT threads)
 // sb[0..n) boxes in visiting order (score desc, index asc); pre_dead[i] != 0 marks boxes removed beforehand.
 // Writes kept positions (indices into sb) to kept[] in visiting order; returns the count (<= max_keep).
@@ -292,7 +297,7 @@ __global__ __launch_bounds__(1024) void rpn_decode_nms_kernel(const float* __res
         dead[j] = (ws >= min_size && hs >= min_size) ? 0 : 1;
     }
     __syncthreads();
-    const int kc = nms_block(S, cnt, thr, 1.0f, ge, post_nms, dead);
+    const int kc = nms_block(S, cnt, thr, nms_one(ge), ge & ISEGMI_NMS_GE, post_nms, dead);
     const int64_t ob = ((int64_t)n * L + level) * post_cap;
     for (int i = threadIdx.x; i < post_cap; i += blockDim.x) {
         if (i < kc) {
@@ -426,7 +431,8 @@ __global__ __launch_bounds__(256) void rpn_nms_matrix_kernel(const RpnLevels b, 
     const int r = pair - w * (w + 1) / 2;
     if (w >= nwords) return;  // whole wave; no block-level barrier below
     const float im_h = (float)image_hw[2 * n], im_w = (float)image_hw[2 * n + 1];
-    const IouThr T = make_iou_thr(b.thr, b.ge);
+    const IouThr T = make_iou_thr(b.thr, b.ge & ISEGMI_NMS_GE);
+    const float one = nms_one(b.ge);
     const int i = (r << 6) + lane, jc = (w << 6) + lane;
     const float4 mine = rpn_candidate_box(head, anchors, tk_idx, n, i < cnt ? i : 0, pre_nms, HWA, A, CH, im_w, im_h);
     cols[wave][lane] = rpn_candidate_box(head, anchors, tk_idx, n, jc < cnt ? jc : 0, pre_nms, HWA, A, CH, im_w, im_h);
@@ -436,7 +442,7 @@ __global__ __launch_bounds__(256) void rpn_nms_matrix_kernel(const RpnLevels b, 
 #pragma unroll 8
     for (int bb = 0; bb < 64; ++bb) {
         const int j = (w << 6) + bb;
-        const bool sup = j > i && j < cnt && iou_exceeds(mine, cols[wave][bb], 1.0f, T);
+        const bool sup = j > i && j < cnt && iou_exceeds(mine, cols[wave][bb], one, T);
         m |= sup ? (1ull << bb) : 0ull;
     }
     if (i < cnt) ws[((int64_t)row * NMS_CAP + i) * W + w] = m;
@@ -567,7 +573,7 @@ __device__ __forceinline__ float4 roi_bilinear4(const float* f, int H, int W, in
 template <int GS>
 __global__ __launch_bounds__(256) void roi_align_kernel(const RoiLevels lv, const float* __restrict__ rois, const int* __restrict__ counts,
                                                          int N, int K, int C, int PH, int PW, int g, int k_min, int k_max,
-                                                         int fixed_level, float* __restrict__ out, int* __restrict__ out_level) {
+                                                         int fixed_level, int aligned, float* __restrict__ out, int* __restrict__ out_level) {
     const int roi = blockIdx.x;
     const int n = roi / K, k = roi - n * K;
     const int c4n = C >> 2;
@@ -585,10 +591,14 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiLevels lv, cons
     const int H = lv.H[li], W = lv.W[li];
     const float sc = lv.scale[li];
     const float* fbase = lv.feat[li] + (int64_t)n * H * W * C;
-    const float sw = b.x * sc, sh = b.y * sc, ew = b.z * sc, eh = b.w * sc;
+    // App. A.7 fork: aligned (ROIAlign aligned=True) = pixel-centre coordinates (scaled corner - 0.5) and no minimum RoI size of one pixel
+    const float off = aligned ? 0.5f : 0.0f;
+    const float sw = b.x * sc - off, sh = b.y * sc - off, ew = b.z * sc - off, eh = b.w * sc - off;
     float rw = ew - sw, rh = eh - sh;
-    rw = rw > 1.0f ? rw : 1.0f;
-    rh = rh > 1.0f ? rh : 1.0f;
+    if (!aligned) {
+        rw = rw > 1.0f ? rw : 1.0f;
+        rh = rh > 1.0f ? rh : 1.0f;
+    }
     const float bh = dm_div(rh, (float)PH), bw = dm_div(rw, (float)PW);
     // g > 0: fixed sampling grid; g <= 0: adaptive ceil(roi / pooled) (ROIAlign's sampling_ratio = 0, the C4 config)
     const int gh = GS > 0 ? GS : (g > 0 ? g : (int)ceilf(bh)), gw = GS > 0 ? GS : (g > 0 ? g : (int)ceilf(bw));
@@ -637,10 +647,12 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiLevels lv, cons
 //   one window of spatially adjacent RoIs and every L2 holds its own slice of the window's pixels, so a pixel two RoIs share is fetched once (box
 //   head, fp32 bs = 2: 874 -> 171 MB).  A lane reads its bin's four table entries from LDS, forms the 16 tap offsets with one add3 each and the
 //   16 weights with one multiply each, has all 16 taps in flight, and runs the same multiply / add sequence per sample as roi_bilinear4.
-// Per output element the arithmetic is roi_align_kernel<2>'s, operation for operation, with two exceptions that cannot change a bit on finite
-// features: a sample outside the map is added as 0 * tap (+-0) instead of skipped, and the divisions by the powers of two 2 (half-bin offset) and 4
-// (sample count) are exact multiplications.  Results do not depend on `order` (one that is not a permutation leaves rows unwritten, entries outside
-// [0, N*K) are skipped).
+// Per output element the arithmetic is roi_align_kernel<2>'s, operation for operation, with two exceptions that cannot change a bit, whatever the
+// features hold (inf and NaN included): a sample outside the map is added as (+0) * (+0) instead of skipped -- its table entry carries weights +0 AND tap
+// offsets past the end of the map, which the range-checked buffer load answers with 0, so no feature value ever meets the zero weight -- and the
+// divisions by the powers of two 2 (half-bin offset) and 4 (sample count) are exact multiplications.  Results do not depend on `order` (one that is not
+// a permutation leaves rows unwritten, entries outside [0, N*K) are skipped).  The last entry of a RoI's table carries {level, H, W, signature of
+// (C * elem_bytes, PH, PW)}: a pooling launch given a table made for another layout writes NaN instead of plausible numbers.
 __device__ __forceinline__ unsigned morton9(unsigned v) {   // 9 bits -> every second bit
     v &= 0x1ffu;
     v = (v | (v << 8)) & 0x00ff00ffu;
@@ -666,8 +678,10 @@ __device__ __forceinline__ unsigned roi_key(const float* __restrict__ rois, int6
     return ((unsigned)li << 29) | (((morton9(cy) << 1) | morton9(cx)) << 11) | (unsigned)i;
 }
 // one table entry: a sample coordinate -> {low tap, high tap} x {byte offset, weight}; `stride` = bytes between consecutive taps along this axis
+constexpr int ROI_TAB_OOR = 0x20000000;   // a tap offset no map reaches (roi_prep_launch: a level's map stays under 512 MiB per image); two of them + a slice offset still fit an int
+__host__ __device__ __forceinline__ int roi_tab_sig(int C, int esize, int PH, int PW) { return (C * esize) | (PH << 16) | (PW << 24); }
 __device__ __forceinline__ int4 roi_tab_entry(float v, int size, int stride) {
-    if (v < -1.0f || v > (float)size) return make_int4(0, 0, 0, 0);   // the sample contributes nothing: both weights +0
+    if (v < -1.0f || v > (float)size) return make_int4(ROI_TAB_OOR, ROI_TAB_OOR, 0, 0);   // the sample contributes nothing: both weights +0, both taps read as 0
     if (v <= 0.0f) v = 0.0f;
     int lo = (int)v, hi;
     if (lo >= size - 1) { hi = lo = size - 1; v = (float)lo; } else hi = lo + 1;
@@ -678,8 +692,8 @@ __device__ __forceinline__ int4 roi_tab_entry(float v, int size, int stride) {
 // Every workgroup builds the image's K keys in LDS; a RoI's rank = the number of smaller keys (keys are distinct: k is part of them), counted by
 // its eight lanes over an eighth of the keys each; its table entries are spread over the same eight lanes (128-byte stores).
 __global__ __launch_bounds__(256) void roi_prep_kernel(const float* __restrict__ rois, const int* __restrict__ counts, int K, RoiPrepLevels lv, int k_min,
-                                                        int k_max, int C, int PH, int PW, int esize, int* __restrict__ order, int4* __restrict__ tab) {
-    __shared__ __attribute__((aligned(16))) unsigned key[ROI_ORDER_MAX];   // (read four at a time)
+                                                        int k_max, int C, int PH, int PW, int esize, int aligned, int* __restrict__ order, int4* __restrict__ tab) {
+    __shared__ __attribute__((__aligned__(16))) unsigned key[ROI_ORDER_MAX];   // (read four at a time)
     const int n = blockIdx.x, cnt = counts[n];
     const int64_t row0 = (int64_t)n * K;
     const int K4 = (K + 3) & ~3;
@@ -705,10 +719,13 @@ __global__ __launch_bounds__(256) void roi_prep_kernel(const float* __restrict__
     const int li = level_of(b, k_min, k_max) - k_min;
     const int H = lv.H[li], W = lv.W[li];
     const float sc = lv.scale[li];
-    const float sw = b.x * sc, sh = b.y * sc, ew = b.z * sc, eh = b.w * sc;
+    const float off = aligned ? 0.5f : 0.0f;   // App. A.7 fork, as in roi_align_kernel
+    const float sw = b.x * sc - off, sh = b.y * sc - off, ew = b.z * sc - off, eh = b.w * sc - off;
     float rw = ew - sw, rh = eh - sh;
-    rw = rw > 1.0f ? rw : 1.0f;
-    rh = rh > 1.0f ? rh : 1.0f;
+    if (!aligned) {
+        rw = rw > 1.0f ? rw : 1.0f;
+        rh = rh > 1.0f ? rh : 1.0f;
+    }
     const float bh = dm_div(rh, (float)PH), bw = dm_div(rw, (float)PW);
     const int TS = 2 * (PH + PW) + 1;
     int4* t = tab + (row0 + i) * TS;
@@ -718,7 +735,7 @@ __global__ __launch_bounds__(256) void roi_prep_kernel(const float* __restrict__
         else if (s < TS - 1) {
             const int q = s - 2 * PH;
             e = roi_tab_entry(sw + (float)(q >> 1) * bw + dm_div(((float)(q & 1) + 0.5f) * bw, 2.0f), W, C * esize);
-        } else e = make_int4(li, H, W, 0);
+        } else e = make_int4(li, H, W, roi_tab_sig(C, esize, PH, PW));
         t[s] = e;
     }
 }
@@ -760,6 +777,11 @@ __global__ __launch_bounds__(256) void roi_align_tab_kernel(const RoiLevels lv, 
     const int4* tr = tab + (int64_t)roi * TS;
     if (threadIdx.x < TS) t[threadIdx.x] = tr[threadIdx.x];
     const int li = tr[TS - 1].x;   // (uniform address: a scalar load); the level's geometry comes from the launch arguments, not from the table
+    if (tr[TS - 1].w != roi_tab_sig(C, 4, PH, PW)) {   // a table made for another element size / channel count / bin grid: fail loudly
+        const float q = __int_as_float(0x7fc00000);
+        for (int j = threadIdx.x; j < NB * 8; j += 256) o4[(j >> 3) * c4n] = make_float4(q, q, q, q);
+        return;
+    }
     const float* f0 = li == 0 ? lv.feat[0] : li == 1 ? lv.feat[1] : li == 2 ? lv.feat[2] : lv.feat[3];
     const int64_t img = (int64_t)(li == 0 ? lv.H[0] : li == 1 ? lv.H[1] : li == 2 ? lv.H[2] : lv.H[3]) * (li == 0 ? lv.W[0] : li == 1 ? lv.W[1] : li == 2 ? lv.W[2] : lv.W[3]) * C;
     const __amdgpu_buffer_rsrc_t fb = __builtin_amdgcn_make_buffer_rsrc((void*)(f0 + (int64_t)n * img), 0, (unsigned)(img * 4), 0x00020000);
@@ -898,7 +920,7 @@ __global__ __launch_bounds__(BOX_NMS_THREADS) void box_cls_nms_kernel(const floa
     int kc;
     if (m > 128) {  // crowded class: bitmask NMS (identical kept list), the matrix in this block's dynamic LDS
         extern __shared__ unsigned long long nms_matrix[];
-        nms_matrix_block(S.sb, m, nms_thr, 1.0f, ge, nms_matrix);
+        nms_matrix_block(S.sb, m, nms_thr, nms_one(ge), ge & ISEGMI_NMS_GE, nms_matrix);
         __syncthreads();
         if (wave == 0) {
             const int k = nms_bit_scan(nms_matrix, m, m, nullptr, S.kept);
@@ -907,7 +929,35 @@ __global__ __launch_bounds__(BOX_NMS_THREADS) void box_cls_nms_kernel(const floa
         __syncthreads();
         kc = S.kc;
     } else {
-        kc = nms_block(S, m, nms_thr, 1.0f, ge, 0, nullptr);
+        kc = nms_block(S, m, nms_thr, nms_one(ge), ge & ISEGMI_NMS_GE, 0, nullptr);
+    }
+    if (ge & ISEGMI_NMS_INDEX_ORDER) {
+        // App. A.6 fork: the CPU NMS hands back the kept boxes in ascending ORIGINAL index (nonzero of the keep mask), so a class's detections come out in
+        // proposal order.  slot[i] = sorted position of kept proposal i (0xffff: not kept), then an ordered compaction over the proposal indices
+        // (ballot / popcount ranks: deterministic); the matrix region of the dynamic LDS is free here.
+        extern __shared__ unsigned long long nms_matrix[];
+        unsigned short* slot = (unsigned short*)nms_matrix;
+        __syncthreads();
+        for (int i = tid; i < R; i += NT) slot[i] = 0xffffu;
+        __syncthreads();
+        for (int q = tid; q < kc; q += NT) {
+            const int src = S.kept[q];
+            slot[(int)(0xffffffffu - (unsigned)(keys[src] & 0xffffffffull))] = (unsigned short)src;
+        }
+        __syncthreads();
+        int run = 0;   // kept proposals before this pass of NT indices
+        for (int i0 = 0; i0 < R; i0 += NT) {
+            const int i = i0 + tid;
+            const unsigned short sv = i < R ? slot[i] : (unsigned short)0xffffu;
+            const unsigned long long bm = __ballot(sv != 0xffffu);
+            if (lane == 0) wcnt[wave] = __popcll(bm);
+            __syncthreads();
+            int before = run, all = 0;
+            for (int w = 0; w < NW; ++w) { before += w < wave ? wcnt[w] : 0; all += wcnt[w]; }
+            if (sv != 0xffffu) S.kept[before + __popcll(bm & ((1ull << lane) - 1ull))] = sv;
+            run += all;
+            __syncthreads();
+        }
     }
     const int64_t ob = ((int64_t)n * (ncls - 1) + (j - 1)) * R;
     for (int q = tid; q < R; q += NT) {
@@ -1136,8 +1186,7 @@ static int rpn_nms_levels_launch(const RpnLevels& b, const float* tk_vals, const
                                  float* out_boxes, float* out_scores, int* out_cnt, hipStream_t st) {
     constexpr int W = NMS_CAP / 64;
     constexpr int matrix_bytes = NMS_CAP * W * 8;  // 128 KB next to 19 KB of static LDS
-    static PerDeviceOnce attr;
-    if (attr.need()) HIP_TRY(hipFuncSetAttribute((const void*)rpn_nms_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, matrix_bytes));
+    LDS_LIMIT_ONCE(matrix_bytes, rpn_nms_scan_kernel);
     const int pairs = W * (W + 1) / 2;
     hipLaunchKernelGGL(rpn_nms_matrix_kernel, dim3(cdiv(pairs, 4), b.nl * b.N), dim3(256), 0, st, b, tk_idx, tk_cnt, image_hw, (unsigned long long*)nms_ws);
     hipLaunchKernelGGL(rpn_nms_scan_kernel, dim3(b.nl * b.N), dim3(1024), matrix_bytes, st, b, tk_vals, tk_idx, tk_cnt, image_hw,
@@ -1225,7 +1274,7 @@ int gather_proposals_launch(const float* cand_boxes, const float* fin_vals, cons
 
 int roi_align_launch(const float* const* feats, const int* Hs, const int* Ws, const float* scales, int nlevels, const float* rois,
                      const int* counts, int N, int K, int C, int PH, int PW, int g, int k_min, int fixed_level, float* out,
-                     int* out_level, hipStream_t st, const int* order = nullptr, const void* tab = nullptr) {
+                     int* out_level, hipStream_t st, const int* order = nullptr, const void* tab = nullptr, int aligned = 0) {
     ARG_CHECK(nlevels >= 1 && nlevels <= 4 && C % 4 == 0, "roi_align levels/C");
     RoiLevels lv;
     for (int i = 0; i < 4; ++i) {
@@ -1238,7 +1287,7 @@ int roi_align_launch(const float* const* feats, const int* Hs, const int* Ws, co
         ARG_CHECK(g == 2 && fixed_level < 0 && !out_level && C % 32 == 0 && (ns == 1 || ns == 2 || ns == 4 || ns == 8) && (int64_t)N * K < (1ll << 27) &&
                       ((PH == 7 && PW == 7) || (PH == 14 && PW == 14)),
                   "roi_align from a table: sampling 2, LevelMapper, 7x7 or 14x14 bins, C in {32, 64, 128, 256}");
-        for (int i = 0; i < nlevels; ++i) ARG_CHECK((int64_t)Hs[i] * Ws[i] * C * 4 < (1ll << 31), "roi_align from a table: a level's map must stay under 2 GiB per image");
+        for (int i = 0; i < nlevels; ++i) ARG_CHECK((int64_t)Hs[i] * Ws[i] * C * 4 < (int64_t)ROI_TAB_OOR, "roi_align from a table: a level's map must stay under 512 MiB per image");
         const int rpg = 8 / ns, NK = N * K;
         const dim3 grid((unsigned)((NK + rpg - 1) / rpg * 8));
         if (PH == 7)
@@ -1256,10 +1305,10 @@ int roi_align_launch(const float* const* feats, const int* Hs, const int* Ws, co
     if (slices < 1) slices = 1;
     if (g == 2)
         hipLaunchKernelGGL(roi_align_kernel<2>, dim3((unsigned)(N * K), (unsigned)slices), dim3(256), 0, st, lv, rois, counts, N, K, C, PH, PW, g, k_min,
-                           k_min + nlevels - 1, fixed_level, out, out_level);
+                           k_min + nlevels - 1, fixed_level, aligned, out, out_level);
     else
         hipLaunchKernelGGL(roi_align_kernel<0>, dim3((unsigned)(N * K), (unsigned)slices), dim3(256), 0, st, lv, rois, counts, N, K, C, PH, PW, g, k_min,
-                           k_min + nlevels - 1, fixed_level, out, out_level);
+                           k_min + nlevels - 1, fixed_level, aligned, out, out_level);
     HIP_TRY(hipGetLastError());
     return ISEGMI_OK;
 }
@@ -1268,7 +1317,7 @@ int roi_align_launch(const float* const* feats, const int* Hs, const int* Ws, co
 // `order` is given, order [N][K] = each image's RoI rows (n*K + k) sorted by (level, Morton code of the centre on that level's map), rows beyond
 // counts[n] last.  esize = bytes per feature element (4 fp32, 2 fp16): the table holds byte offsets.
 int roi_prep_launch(const float* rois, const int* counts, int N, int K, const int* Hs, const int* Ws, const float* scales, int nlevels, int k_min, int C,
-                    int PH, int PW, int esize, int* order, void* tab, hipStream_t st) {
+                    int PH, int PW, int esize, int* order, void* tab, hipStream_t st, int aligned) {  // (default 0 in engine.h)
     ARG_CHECK(nlevels >= 1 && nlevels <= 4 && N > 0 && K > 0 && K <= ROI_ORDER_MAX && PH > 0 && PW > 0 && PH <= 64 && PW <= 64 && C > 0 &&
                   (esize == 2 || esize == 4) && tab,
               "roi_prep: 1..4 levels, K <= 2048");
@@ -1276,10 +1325,11 @@ int roi_prep_launch(const float* rois, const int* counts, int N, int K, const in
     for (int i = 0; i < 4; ++i) {
         const int s = i < nlevels ? i : nlevels - 1;
         lv.H[i] = Hs[s]; lv.W[i] = Ws[s]; lv.scale[i] = scales[s];
-        ARG_CHECK(Hs[s] > 0 && Ws[s] > 0 && (int64_t)Hs[s] * Ws[s] * C * esize < (1ll << 31), "roi_prep: a level's map must stay under 2 GiB per image");
+        ARG_CHECK(Hs[s] > 0 && Ws[s] > 0 && (int64_t)Hs[s] * Ws[s] * C * esize < (int64_t)ROI_TAB_OOR, "roi_prep: a level's map must stay under 512 MiB per image");
+        ARG_CHECK((int64_t)C * esize < 65536 && PH < 128 && PW < 128, "roi_prep: C * elem_bytes < 65536");
     }
     hipLaunchKernelGGL(roi_prep_kernel, dim3((unsigned)N, (unsigned)((K + 31) / 32)), dim3(256), 0, st, rois, counts, K, lv, k_min, k_min + nlevels - 1, C,
-                       PH, PW, esize, order, (int4*)tab);
+                       PH, PW, esize, aligned, order, (int4*)tab);
     HIP_TRY(hipGetLastError());
     return ISEGMI_OK;
 }
@@ -1314,14 +1364,14 @@ int box_postprocess_launch(const isegmi_box_post_args* a, hipStream_t st) {
     if (rc) return rc;
     HIP_TRY(hipMemsetAsync(a->d_ws_kept_total, 0, sizeof(int) * (size_t)a->N, st));
     constexpr int matrix_bytes = NMS_CAP * (NMS_CAP / 64) * 8;  // 128 KB next to 26 KB of static LDS: one block per CU
-    static PerDeviceOnce attr;
-    if (attr.need()) HIP_TRY(hipFuncSetAttribute((const void*)box_cls_nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, matrix_bytes));
+    LDS_LIMIT_ONCE(matrix_bytes, box_cls_nms_kernel);
     hipLaunchKernelGGL(box_cls_nms_kernel, dim3(nc, a->N), dim3(BOX_NMS_THREADS), matrix_bytes, st, a->d_ws_prob, a->d_regr, a->regr_stride, a->d_props,
-                       a->d_prop_cnt, a->d_image_hw, a->R, a->ncls, a->score_thresh, a->nms_thresh, a->nms_ge, a->d_ws_cand_scores,
+                       a->d_prop_cnt, a->d_image_hw, a->R, a->ncls, a->score_thresh, a->nms_thresh, a->nms_flags, a->d_ws_cand_scores,
                        a->d_ws_cand_boxes, a->d_ws_kept_total);
     HIP_TRY(hipGetLastError());
-    // the per-class lists are sorted: nothing past a class's first det_per_img entries can make the image's top det_per_img
-    if (a->det_per_img <= 128 && a->det_per_img <= a->R)
+    // the per-class lists are sorted (score order): nothing past a class's first det_per_img entries can make the image's top det_per_img; in index
+    // order the lists are not sorted and the general top-k over all nc * R slots finds the kth value
+    if (a->det_per_img <= 128 && a->det_per_img <= a->R && !(a->nms_flags & ISEGMI_NMS_INDEX_ORDER))
         rc = topk_segmented_launch(a->d_ws_cand_scores, (int64_t)nc * a->R, a->N, nc, a->R, a->det_per_img, a->det_per_img, a->d_ws_kept_total, 1,
                                    a->d_ws_top_vals, a->d_ws_top_idx, nullptr, st);
     else
@@ -1366,17 +1416,18 @@ extern "C" int isegmi_op_nms(const float* d_boxes, const float* d_scores, int pr
 
 extern "C" int isegmi_op_roi_align(const float* const* d_feats, const int32_t* Hs, const int32_t* Ws, const float* scales, int nlevels,
                                    const float* d_rois, const int32_t* d_counts, int N, int K, int C, int PH, int PW, int sampling,
-                                   int k_min, int fixed_level, float* d_out, int32_t* d_out_level, void* stream) {
+                                   int aligned, int k_min, int fixed_level, float* d_out, int32_t* d_out_level, void* stream) {
     return roi_align_launch(d_feats, Hs, Ws, scales, nlevels, d_rois, d_counts, N, K, C, PH, PW, sampling, k_min, fixed_level, d_out,
-                            d_out_level, (hipStream_t)stream);
+                            d_out_level, (hipStream_t)stream, nullptr, nullptr, aligned);
 }
 extern "C" int64_t isegmi_op_roi_table_bytes(int N, int K, int PH, int PW) {
     return N > 0 && K > 0 && PH > 0 && PW > 0 ? (int64_t)N * K * (2 * (PH + PW) + 1) * 16 : 0;
 }
 extern "C" int isegmi_op_roi_prep(const float* d_rois, const int32_t* d_counts, int N, int K, const int32_t* Hs, const int32_t* Ws, const float* scales,
-                                  int nlevels, int k_min, int C, int PH, int PW, int elem_bytes, int32_t* d_order, void* d_table, void* stream) {
+                                  int nlevels, int k_min, int C, int PH, int PW, int elem_bytes, int aligned, int32_t* d_order, void* d_table,
+                                  void* stream) {
     ARG_CHECK(d_rois && d_counts && Hs && Ws && scales && d_table, "args");
-    return roi_prep_launch(d_rois, d_counts, N, K, Hs, Ws, scales, nlevels, k_min, C, PH, PW, elem_bytes, d_order, d_table, (hipStream_t)stream);
+    return roi_prep_launch(d_rois, d_counts, N, K, Hs, Ws, scales, nlevels, k_min, C, PH, PW, elem_bytes, d_order, d_table, (hipStream_t)stream, aligned);
 }
 extern "C" int isegmi_op_roi_align_ordered(const float* const* d_feats, const int32_t* Hs, const int32_t* Ws, const float* scales, int nlevels,
                                            const float* d_rois, const int32_t* d_counts, const int32_t* d_order, const void* d_table, int N, int K,

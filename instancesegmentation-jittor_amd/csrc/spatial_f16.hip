@@ -124,7 +124,7 @@ __device__ __forceinline__ float4 roi_bilinear4_h(const half_t* f, int H, int W,
 }
 __global__ __launch_bounds__(256) void roi_align_f16_kernel(const RoiLevelsH lv, const float* __restrict__ rois, const int* __restrict__ counts,
                                                              int N, int K, int C, int PH, int PW, int g, int k_min, int k_max,
-                                                             half_t* __restrict__ out) {
+                                                             int aligned, half_t* __restrict__ out) {
     const int c4n = C >> 2;
     const int64_t total = (int64_t)N * K * PH * PW * c4n;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -141,10 +141,13 @@ __global__ __launch_bounds__(256) void roi_align_f16_kernel(const RoiLevelsH lv,
             const int H = lv.H[li], W = lv.W[li];
             const float sc = lv.scale[li];
             const half_t* f = lv.feat[li] + (int64_t)n * H * W * C + c4 * 4;
-            const float sw = b.x * sc, sh = b.y * sc, ew = b.z * sc, eh = b.w * sc;
+            const float off = aligned ? 0.5f : 0.0f;   // App. A.7 fork (see rcnn_ops.hip roi_align_kernel)
+            const float sw = b.x * sc - off, sh = b.y * sc - off, ew = b.z * sc - off, eh = b.w * sc - off;
             float rw = ew - sw, rh = eh - sh;
-            rw = rw > 1.0f ? rw : 1.0f;
-            rh = rh > 1.0f ? rh : 1.0f;
+            if (!aligned) {
+                rw = rw > 1.0f ? rw : 1.0f;
+                rh = rh > 1.0f ? rh : 1.0f;
+            }
             const float bh = dm_div(rh, (float)PH), bw = dm_div(rw, (float)PW);
             for (int iy = 0; iy < g; ++iy) {
                 const float y = sh + (float)ph * bh + dm_div(((float)iy + 0.5f) * bh, (float)g);
@@ -166,7 +169,8 @@ __global__ __launch_bounds__(256) void roi_align_f16_kernel(const RoiLevelsH lv,
 // Per-channel arithmetic and its order are those of roi_align_f16_kernel (same bits out).
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 __global__ __launch_bounds__(256) void roi_align_f16_c8_kernel(const RoiLevelsH lv, const float* __restrict__ rois, const int* __restrict__ counts,
-                                                                int K, int C, int PH, int PW, int g, int k_min, int k_max, half_t* __restrict__ out) {
+                                                                int K, int C, int PH, int PW, int g, int k_min, int k_max, int aligned,
+                                                                half_t* __restrict__ out) {
     const int c8n = C >> 3, bpp = 256 / c8n;         // lanes per bin, bins per pass
     const int c8 = threadIdx.x % c8n, slot = threadIdx.x / c8n;
     const int n = blockIdx.x / K, k = blockIdx.x - n * K;
@@ -182,26 +186,32 @@ __global__ __launch_bounds__(256) void roi_align_f16_c8_kernel(const RoiLevelsH 
     const int H = lv.H[li], W = lv.W[li];
     const float sc = lv.scale[li];
     const half_t* f = lv.feat[li] + (int64_t)n * H * W * C + c8 * 8;
-    const float sw = bx.x * sc, sh = bx.y * sc, ew = bx.z * sc, eh = bx.w * sc;
+    const float off = aligned ? 0.5f : 0.0f;   // App. A.7 fork
+    const float sw = bx.x * sc - off, sh = bx.y * sc - off, ew = bx.z * sc - off, eh = bx.w * sc - off;
     float rw = ew - sw, rh = eh - sh;
-    rw = rw > 1.0f ? rw : 1.0f;
-    rh = rh > 1.0f ? rh : 1.0f;
+    if (!aligned) {
+        rw = rw > 1.0f ? rw : 1.0f;
+        rh = rh > 1.0f ? rh : 1.0f;
+    }
     const float bh = dm_div(rh, (float)PH), bw = dm_div(rw, (float)PW);
     const float cnt = (float)(g * g);
     if (g == 2) {
-        // sampling_ratio 2 (every FPN head): the bin's four samples are set up first -- tap offsets and weights; a sample outside the map gets
-        // zero weights on clamped taps, which adds the same +0 the scalar form's `continue` skips -- then all SIXTEEN 16-byte taps are
+        // sampling_ratio 2 (every FPN head): the bin's four samples are set up first -- tap offsets and weights; a sample outside the map reads
+        // clamped taps and its sum is REPLACED by +0 (not multiplied by zero weights: 0 * inf would be NaN), which is what the scalar form's
+        // `continue` adds -- then all SIXTEEN 16-byte taps are
         // requested before the first is used (round 2 issued four at a time behind a branch per sample: 200 us per R101 bs=8 call at 2.7 TB/s)
         for (int b = slot; b < nb; b += bpp) {
             const int ph = b / PW, pw = b - ph * PW;
             int off[4][4];
             float wt[4][4];
+            bool ins[4];
 #pragma unroll
             for (int sidx = 0; sidx < 4; ++sidx) {
                 const int iy = sidx >> 1, ix = sidx & 1;
                 float y = sh + (float)ph * bh + dm_div(((float)iy + 0.5f) * bh, 2.0f);
                 float x = sw + (float)pw * bw + dm_div(((float)ix + 0.5f) * bw, 2.0f);
                 const bool inside = !(y < -1.0f || y > (float)H || x < -1.0f || x > (float)W);
+                ins[sidx] = inside;
                 if (y <= 0.0f) y = 0.0f;
                 if (x <= 0.0f) x = 0.0f;
                 int yl = (int)y, xl = (int)x, yh, xh;
@@ -229,7 +239,7 @@ __global__ __launch_bounds__(256) void roi_align_f16_c8_kernel(const RoiLevelsH 
                     q = q + wt[sidx][1] * (float)v[sidx][1][i];
                     q = q + wt[sidx][2] * (float)v[sidx][2][i];
                     q = q + wt[sidx][3] * (float)v[sidx][3][i];
-                    acc[i] = acc[i] + q;
+                    acc[i] = acc[i] + (ins[sidx] ? q : 0.0f);
                 }
             h8 r;
 #pragma unroll
@@ -277,8 +287,8 @@ __global__ __launch_bounds__(256) void roi_align_f16_c8_kernel(const RoiLevelsH 
 
 // The FPN heads' RoIAlign from the table of rcnn_ops.hip's roi_prep_kernel (see there): workgroup L (XCD L % 8) takes one 128-byte channel slice --
 // eight lanes of 8 channels -- of RoI order[...]; C / 8 = 8 * ns lanes per pixel, ns in {1, 2, 4, 8}, 8 / ns RoIs per group of eight workgroups.
-// Per-element arithmetic is roi_align_f16_c8_kernel's g == 2 branch (same bits out on finite features; the division by the sample count 4 is an
-// exact multiplication).
+// Per-element arithmetic is roi_align_f16_c8_kernel's g == 2 branch (same bits out for any features, inf / NaN included: an invalid sample's taps point past
+// the map and read 0; the division by the sample count 4 is an exact multiplication).
 typedef unsigned int roi_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ h8 tap8(const __amdgpu_buffer_rsrc_t rs, unsigned off) {
     return __builtin_bit_cast(h8, (roi_u32x4)__builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
@@ -303,6 +313,12 @@ __global__ __launch_bounds__(256) void roi_align_f16_tab_kernel(const RoiLevelsH
     const int4* tr = tab + (int64_t)roi * TS;
     if (threadIdx.x < TS) t[threadIdx.x] = tr[threadIdx.x];
     const int li = tr[TS - 1].x;   // (uniform address: a scalar load); the level's geometry comes from the launch arguments, not from the table
+    if (tr[TS - 1].w != ((C * 2) | (PH << 16) | (PW << 24))) {   // roi_tab_sig: a table made for another layout -> NaN, not plausible numbers
+        const half_t q = __builtin_bit_cast(half_t, (unsigned short)0x7e00);
+        const h8 z = {q, q, q, q, q, q, q, q};
+        for (int b = threadIdx.x >> 3; b < NB; b += 32) *(h8*)(o + (int64_t)b * C) = z;
+        return;
+    }
     const half_t* f0 = li == 0 ? lv.feat[0] : li == 1 ? lv.feat[1] : li == 2 ? lv.feat[2] : lv.feat[3];
     const int64_t img = (int64_t)(li == 0 ? lv.H[0] : li == 1 ? lv.H[1] : li == 2 ? lv.H[2] : lv.H[3]) * (li == 0 ? lv.W[0] : li == 1 ? lv.W[1] : li == 2 ? lv.W[2] : lv.W[3]) * C;
     // taps are 16-byte buffer loads range-checked against the image's map: whatever the table holds, no load leaves the level's allocation
@@ -508,7 +524,7 @@ int nearest2x_add_f16_launch(const void* coarse, int N, int Hc, int Wc, int C, c
 }
 int roi_align_f16_launch(const void* const* feats, const int* Hs, const int* Ws, const float* scales, int nlevels, const float* rois,
                          const int* counts, int N, int K, int C, int PH, int PW, int g, int k_min, void* out, hipStream_t st,
-                         const int* order = nullptr, const void* tab = nullptr) {
+                         const int* order = nullptr, const void* tab = nullptr, int aligned = 0) {
     ARG_CHECK(nlevels >= 1 && nlevels <= 4 && C % 4 == 0, "roi_align levels/C");
     RoiLevelsH lv;
     for (int i = 0; i < 4; ++i) {
@@ -520,7 +536,7 @@ int roi_align_f16_launch(const void* const* feats, const int* Hs, const int* Ws,
         ARG_CHECK(g == 2 && C % 64 == 0 && (ns == 1 || ns == 2 || ns == 4 || ns == 8) && N > 0 && K > 0 && (int64_t)N * K < (1ll << 27) &&
                       ((PH == 7 && PW == 7) || (PH == 14 && PW == 14)),
                   "roi_align_f16 from a table: sampling 2, 7x7 or 14x14 bins, C in {64, 128, 256, 512}");
-        for (int i = 0; i < nlevels; ++i) ARG_CHECK((int64_t)Hs[i] * Ws[i] * C * 2 < (1ll << 31), "roi_align_f16 from a table: a level's map must stay under 2 GiB per image");
+        for (int i = 0; i < nlevels; ++i) ARG_CHECK((int64_t)Hs[i] * Ws[i] * C * 2 < 0x20000000ll, "roi_align_f16 from a table: a level's map must stay under 512 MiB per image");
         const int rpg = 8 / ns, NK = N * K;
         const dim3 grid((unsigned)((NK + rpg - 1) / rpg * 8));
         if (PH == 7)
@@ -533,10 +549,10 @@ int roi_align_f16_launch(const void* const* feats, const int* Hs, const int* Ws,
     if (C % 8 == 0 && 256 % (C / 8) == 0 && (int64_t)N * K < (1ll << 31)) {
         if (N * K > 0)
             hipLaunchKernelGGL(roi_align_f16_c8_kernel, dim3((unsigned)(N * K)), dim3(256), 0, st, lv, rois, counts, K, C, PH, PW, g, k_min,
-                               k_min + nlevels - 1, (half_t*)out);
+                               k_min + nlevels - 1, aligned, (half_t*)out);
     } else {
         hipLaunchKernelGGL(roi_align_f16_kernel, dim3(gridf((int64_t)N * K * PH * PW * (C / 4))), dim3(256), 0, st, lv, rois, counts, N, K, C, PH, PW,
-                           g, k_min, k_min + nlevels - 1, (half_t*)out);
+                           g, k_min, k_min + nlevels - 1, aligned, (half_t*)out);
     }
     HIP_TRY(hipGetLastError());
     return ISEGMI_OK;
@@ -559,11 +575,11 @@ extern "C" int isegmi_op_pad_c3_to_f16_halo(const float* d_in_nhwc3, int N, int 
     return isegmi::pad_c3_to_f16_halo_launch(d_in_nhwc3, N, H, W, d_out, (hipStream_t)stream);
 }
 extern "C" int isegmi_op_roi_align_f16(const void* const* d_feats, const int32_t* Hs, const int32_t* Ws, const float* scales, int nlevels,
-                                       const float* d_rois, const int32_t* d_counts, int N, int K, int C, int PH, int PW, int sampling, int k_min,
-                                       void* d_out, void* stream) {
+                                       const float* d_rois, const int32_t* d_counts, int N, int K, int C, int PH, int PW, int sampling, int aligned,
+                                       int k_min, void* d_out, void* stream) {
     ARG_CHECK(d_feats && Hs && Ws && scales && d_rois && d_counts && d_out && N > 0 && K > 0 && PH > 0 && PW > 0 && sampling > 0, "args");
     return isegmi::roi_align_f16_launch(d_feats, Hs, Ws, scales, nlevels, d_rois, d_counts, N, K, C, PH, PW, sampling, k_min, d_out,
-                                        (hipStream_t)stream);
+                                        (hipStream_t)stream, nullptr, nullptr, aligned);
 }
 extern "C" int isegmi_op_roi_align_f16_ordered(const void* const* d_feats, const int32_t* Hs, const int32_t* Ws, const float* scales, int nlevels,
                                                const float* d_rois, const int32_t* d_counts, const int32_t* d_order, const void* d_table, int N, int K,

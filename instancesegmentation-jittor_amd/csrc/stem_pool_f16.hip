@@ -227,8 +227,7 @@ int stem_pool_f16_launch(int N, int H, int W, const void* halo, const void* w, c
     k.total = (int)total;
     k.dbg = (flags >> 2) & 15 ? (flags & 60) : 0;
     const int grid = (flags & 1) ? (k.total < 8 ? k.total : 8) : (k.total < ncu ? k.total : ncu);   // flags bit 0 (test hook): blocks that walk many units
-    static PerDeviceOnce attr;
-    if (attr.need()) HIP_TRY(hipFuncSetAttribute((const void*)stem_pool_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS));
+    LDS_LIMIT_ONCE(SP_LDS, stem_pool_f16_kernel);
     hipLaunchKernelGGL(stem_pool_f16_kernel, dim3((unsigned)grid), dim3(256), SP_LDS, st, k);
     HIP_TRY(hipGetLastError());
     return ISEGMI_OK;

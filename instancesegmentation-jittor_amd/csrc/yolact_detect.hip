@@ -5,7 +5,8 @@
 //                    max foreground prob <= conf_thresh get -1 in every class row (excluded);
 //                    loc+priors -> xyxy boxes; per-image kept-prior count.
 //   fast_nms       : per (image, class): box j survives iff max_{i<j} IoU(i,j) <= thr over the
-//                    class's score-sorted top-k (IoU without +1, NaN drops the box).
+//                    class's score-sorted top-k (IoU without +1, NaN drops the box); with
+//                    second_threshold also iff its class score > conf_thresh.
 //   gather         : final per-image top-100 -> boxes / scores / classes / 32 mask coefficients.
 //   proto masks    : m = sigmoid(fmaf-chain_k proto*coeff) cropped to the box (+1 px) in proto space,
 //                    then bilinear (align_corners=False) to (h,w), > 0.5 -> uint8.
@@ -126,7 +127,7 @@ __device__ __forceinline__ float jaccard(const float4 a, const float4 b) {
 // one thread walking up to 199 IEEE divisions (31 -> ~15 us on one image's 80 class blocks).
 __global__ __launch_bounds__(1024) void yolact_fast_nms_kernel(const float* __restrict__ boxes, const float* __restrict__ tk_vals,
                                                                 const int* __restrict__ tk_idx, const int* __restrict__ tk_cnt,
-                                                                int P, int nc, int top_k, float thr,
+                                                                int P, int nc, int top_k, float thr, int second_threshold, float conf_thresh,
                                                                 float* __restrict__ cand, int* __restrict__ kept_count) {
     __shared__ float4 sb[256];
     __shared__ unsigned char okp[4][256];
@@ -146,7 +147,10 @@ __global__ __launch_bounds__(1024) void yolact_fast_nms_kernel(const float* __re
     }
     okp[part][j] = ok ? 1 : 0;
     __syncthreads();
-    const bool keep = part == 0 && j < cnt && okp[0][j] && okp[1][j] && okp[2][j] && okp[3][j];
+    // App. A.6 fork: fast_nms(second_threshold=True) additionally drops a box whose OWN class score is not above conf_thresh (a prior passes the
+    // pre-filter on its best class and is then ranked in every class); off in the default detect() call
+    bool keep = part == 0 && j < cnt && okp[0][j] && okp[1][j] && okp[2][j] && okp[3][j];
+    if (second_threshold && keep) keep = tk_vals[base + j] > conf_thresh;
     if (part == 0 && j < top_k) cand[base + j] = keep ? tk_vals[base + j] : -1.0f;
     const int k = __syncthreads_count(keep ? 1 : 0);
     if (threadIdx.x == 0 && k) atomicAdd(&kept_count[n], k);
@@ -337,7 +341,7 @@ int yolact_detect_launch(const isegmi_yolact_detect_args* a, hipStream_t st) {
                          a->d_ws_tk_cnt, st);
     if (rc) return rc;
     hipLaunchKernelGGL(yolact_fast_nms_kernel, dim3(nc, a->N), dim3(1024), 0, st, a->d_ws_boxes, a->d_ws_tk_vals, a->d_ws_tk_idx,
-                       a->d_ws_tk_cnt, a->P, nc, a->top_k, a->nms_thresh, a->d_ws_cand, kept2);
+                       a->d_ws_tk_cnt, a->P, nc, a->top_k, a->nms_thresh, a->second_threshold, a->conf_thresh, a->d_ws_cand, kept2);
     HIP_TRY(hipGetLastError());
     rc = topk_launch(a->d_ws_cand, (int64_t)nc * a->top_k, a->N, nc * a->top_k, a->max_det, kept2, 1, a->d_ws_fin_vals,
                      a->d_ws_fin_idx, a->d_ws_fin_cnt, st);

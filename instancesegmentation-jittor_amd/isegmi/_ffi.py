@@ -299,10 +299,10 @@ class YolactDetectArgs(C.Structure):
                    "d_ws_tk_idx", "d_ws_tk_cnt", "d_ws_cand", "d_ws_fin_vals", "d_ws_fin_idx", "d_ws_fin_cnt",
                    "d_out_count", "d_out_boxes", "d_out_scores", "d_out_classes", "d_out_coeffs", "d_out_prior")] + \
                [("A", C.c_int32), ("mask_tanh", C.c_int32), ("pix_stride", C.c_int64), ("off_loc", C.c_int32), ("off_conf", C.c_int32),
-                ("off_mask", C.c_int32), ("reserved", C.c_int32)]
+                ("off_mask", C.c_int32), ("second_threshold", C.c_int32)]
 
 
-def yolact_detect(conf_logits, loc, mask, priors, conf_thresh=0.05, nms_thresh=0.5, top_k=200, max_det=100):
+def yolact_detect(conf_logits, loc, mask, priors, conf_thresh=0.05, nms_thresh=0.5, top_k=200, max_det=100, second_threshold=0):
     """Host convenience wrapper: conf_logits [N,P,ncls], loc [N,P,4], mask [N,P,md], priors [P,4]."""
     conf_logits = np.ascontiguousarray(conf_logits, np.float32)
     N, P, ncls = conf_logits.shape
@@ -320,6 +320,7 @@ def yolact_detect(conf_logits, loc, mask, priors, conf_thresh=0.05, nms_thresh=0
         d_out_classes=DeviceBuffer((N, max_det), np.int32), d_out_coeffs=DeviceBuffer((N, max_det, md)),
         d_out_prior=DeviceBuffer((N, max_det), np.int32))
     a = YolactDetectArgs(N, P, ncls, md, top_k, max_det, conf_thresh, nms_thresh, *[bufs[n].ptr for n, _ in YolactDetectArgs._fields_[8:28]])
+    a.second_threshold = int(second_threshold)
     check(lib().isegmi_op_yolact_detect(C.byref(a), None))
     cnt = bufs["d_out_count"].numpy()
     out = []
@@ -345,6 +346,9 @@ def yolact_masks(proto, coeffs, boxes, counts, h, w):
 
 
 # ---------------------------------------------------------------- Mask R-CNN op wrappers (tests / small inputs)
+NMS_GE, NMS_NO_PLUS_ONE, NMS_INDEX_ORDER = 1, 2, 4   # ISEGMI_NMS_* of include/isegmi.h (SURVEY App. A.6 forks)
+
+
 def nms(boxes, scores, thr, plus_one=1, ge=0, max_keep=0):
     """boxes [P,n,4], scores [P,n] -> list of kept original indices (score order) per problem."""
     boxes = np.ascontiguousarray(boxes, np.float32); scores = np.ascontiguousarray(scores, np.float32)
@@ -356,7 +360,7 @@ def nms(boxes, scores, thr, plus_one=1, ge=0, max_keep=0):
     return [k[i, : c[i]].copy() for i in range(P)]
 
 
-def roi_align(feats, scales, rois, counts, PH, PW, sampling=2, k_min=2, fixed_level=-1):
+def roi_align(feats, scales, rois, counts, PH, PW, sampling=2, k_min=2, fixed_level=-1, aligned=0):
     """feats: list of [N,H,W,C]; rois [N,K,4]; counts [N] -> (out [N*K,PH,PW,C], levels [N,K])"""
     fb = [DeviceBuffer.from_numpy(np.ascontiguousarray(f, np.float32)) for f in feats]
     N, K = rois.shape[:2]
@@ -366,14 +370,14 @@ def roi_align(feats, scales, rois, counts, PH, PW, sampling=2, k_min=2, fixed_le
     sc = (C.c_float * len(fb))(*scales)
     dr = DeviceBuffer.from_numpy(np.ascontiguousarray(rois, np.float32)); dcnt = DeviceBuffer.from_numpy(np.ascontiguousarray(counts, np.int32))
     do = DeviceBuffer((N * K, PH, PW, Cc)); dl = DeviceBuffer((N, K), np.int32); dl.zero()
-    check(lib().isegmi_op_roi_align(ptrs, Hs, Ws, sc, len(fb), dr.ptr, dcnt.ptr, N, K, Cc, PH, PW, sampling, k_min, fixed_level,
+    check(lib().isegmi_op_roi_align(ptrs, Hs, Ws, sc, len(fb), dr.ptr, dcnt.ptr, N, K, Cc, PH, PW, sampling, aligned, k_min, fixed_level,
                                     do.ptr, dl.ptr, None))
     return do.numpy(), dl.numpy()
 
 
-def roi_prep(rois, counts, shapes, scales, Cc, PH, PW, k_min=2, f16=False, want_order=True):
+def roi_prep(rois, counts, shapes, scales, Cc, PH, PW, k_min=2, f16=False, want_order=True, aligned=0):
     """first launch of the FPN heads' RoIAlign: rois [N,K,4], counts [N], shapes [(H, W)] per level -> (order [N,K] int32 or None, table [N*K, 2*(PH+PW)+1, 4]
-    int32): per-RoI sample rows / columns {low byte offset, high byte offset, low weight bits, high weight bits}, then {level index, H, W, 0}"""
+    int32): per-RoI sample rows / columns {low byte offset, high byte offset, low weight bits, high weight bits}, then {level index, H, W, layout signature}"""
     N, K = rois.shape[:2]
     dr = DeviceBuffer.from_numpy(np.ascontiguousarray(rois, np.float32)); dcnt = DeviceBuffer.from_numpy(np.ascontiguousarray(counts, np.int32))
     do = DeviceBuffer((N, K), np.int32) if want_order else None
@@ -382,7 +386,7 @@ def roi_prep(rois, counts, shapes, scales, Cc, PH, PW, k_min=2, f16=False, want_
     dtab = DeviceBuffer.from_numpy(np.full((N * K, TS, 4), -1, np.int32))
     Hs = (C.c_int32 * len(shapes))(*[h for h, _ in shapes]); Ws = (C.c_int32 * len(shapes))(*[w for _, w in shapes])
     sc = (C.c_float * len(scales))(*scales)
-    check(lib().isegmi_op_roi_prep(dr.ptr, dcnt.ptr, N, K, Hs, Ws, sc, len(scales), k_min, Cc, PH, PW, 2 if f16 else 4, do.ptr if do else None, dtab.ptr, None))
+    check(lib().isegmi_op_roi_prep(dr.ptr, dcnt.ptr, N, K, Hs, Ws, sc, len(scales), k_min, Cc, PH, PW, 2 if f16 else 4, aligned, do.ptr if do else None, dtab.ptr, None))
     return (do.numpy() if do else None), dtab.numpy()
 
 
@@ -414,7 +418,7 @@ def avgpool_full(x):
     return do.numpy()
 
 
-def roi_align_f16(feats, scales, rois, counts, PH, PW, sampling=2, k_min=2):
+def roi_align_f16(feats, scales, rois, counts, PH, PW, sampling=2, k_min=2, aligned=0):
     """fp16-storage RoIAlign: feats list of [N,H,W,C] (cast to fp16) -> out [N*K,PH,PW,C] fp16."""
     fb = [DeviceBuffer.from_numpy(np.ascontiguousarray(f, np.float16)) for f in feats]
     N, K = rois.shape[:2]
@@ -424,19 +428,19 @@ def roi_align_f16(feats, scales, rois, counts, PH, PW, sampling=2, k_min=2):
     sc = (C.c_float * len(fb))(*scales)
     dr = DeviceBuffer.from_numpy(np.ascontiguousarray(rois, np.float32)); dcnt = DeviceBuffer.from_numpy(np.ascontiguousarray(counts, np.int32))
     do = DeviceBuffer((N * K, PH, PW, Cc), np.float16)
-    check(lib().isegmi_op_roi_align_f16(ptrs, Hs, Ws, sc, len(fb), dr.ptr, dcnt.ptr, N, K, Cc, PH, PW, sampling, k_min, do.ptr, None))
+    check(lib().isegmi_op_roi_align_f16(ptrs, Hs, Ws, sc, len(fb), dr.ptr, dcnt.ptr, N, K, Cc, PH, PW, sampling, aligned, k_min, do.ptr, None))
     return do.numpy()
 
 
 class BoxPostArgs(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("N", "R", "ncls", "det_per_img", "cap", "nms_ge")] + \
+    _fields_ = [(n, C.c_int32) for n in ("N", "R", "ncls", "det_per_img", "cap", "nms_flags")] + \
                [("score_thresh", C.c_float), ("nms_thresh", C.c_float), ("logits_stride", C.c_int64), ("regr_stride", C.c_int64)] + \
                [(n, C.c_void_p) for n in ("d_logits", "d_regr", "d_props", "d_prop_cnt", "d_image_hw", "d_ws_prob", "d_ws_cand_scores",
                                           "d_ws_cand_boxes", "d_ws_kept_total", "d_ws_top_vals", "d_ws_top_idx", "d_out_count",
                                           "d_out_boxes", "d_out_scores", "d_out_labels")]
 
 
-def box_postprocess(logits, regr, props, prop_cnt, image_hw, score_thr=0.05, nms_thr=0.5, det_per_img=100, nms_ge=0, cap=0):
+def box_postprocess(logits, regr, props, prop_cnt, image_hw, score_thr=0.05, nms_thr=0.5, det_per_img=100, nms_flags=0, cap=0):
     """logits [N,R,ncls], regr [N,R,4*ncls], props [N,R,4] -> list of (boxes, scores, labels).  cap > det_per_img: rows for the detections
     that tie with the det_per_img-th score (upstream's kth-value rule keeps them)."""
     logits = np.ascontiguousarray(logits, np.float32)
@@ -451,7 +455,7 @@ def box_postprocess(logits, regr, props, prop_cnt, image_hw, score_thr=0.05, nms
              d_ws_top_vals=DeviceBuffer((N, det_per_img)), d_ws_top_idx=DeviceBuffer((N, det_per_img), np.int32),
              d_out_count=DeviceBuffer((N,), np.int32), d_out_boxes=DeviceBuffer((N, cap, 4)), d_out_scores=DeviceBuffer((N, cap)),
              d_out_labels=DeviceBuffer((N, cap), np.int32))
-    a = BoxPostArgs(N, R, ncls, det_per_img, cap, nms_ge, score_thr, nms_thr, ncls, 4 * ncls, *[b[n].ptr for n, _ in BoxPostArgs._fields_[10:]])
+    a = BoxPostArgs(N, R, ncls, det_per_img, cap, nms_flags, score_thr, nms_thr, ncls, 4 * ncls, *[b[n].ptr for n, _ in BoxPostArgs._fields_[10:]])
     check(lib().isegmi_op_box_postprocess(C.byref(a), None))
     cnt = b["d_out_count"].numpy(); B = b["d_out_boxes"].numpy(); S = b["d_out_scores"].numpy(); Lb = b["d_out_labels"].numpy()
     return [(B[i, : cnt[i]], S[i, : cnt[i]], Lb[i, : cnt[i]]) for i in range(N)]
@@ -476,7 +480,7 @@ def paste_masks(masks, boxes, counts, im_h, im_w, thr=0.5):
     return do.numpy()
 
 
-def rpn_level(head, anchors, image_hw, A, pre_nms, post_nms, nms_thr=0.7, min_size=0.0, nms_ge=0, chip_wide=True):
+def rpn_level(head, anchors, image_hw, A, pre_nms, post_nms, nms_thr=0.7, min_size=0.0, nms_flags=0, chip_wide=True):
     """head [N,H,W,A*5] fused (A logits, A*4 deltas) -> list of (boxes, scores).  chip_wide: hand the op its optional
     suppression-matrix workspace (two-kernel NMS, pre_nms <= 1024); False = single-block NMS."""
     head = np.ascontiguousarray(head, np.float32)
@@ -487,13 +491,13 @@ def rpn_level(head, anchors, image_hw, A, pre_nms, post_nms, nms_thr=0.7, min_si
     wp = DeviceBuffer((N, HW * A)); tv = DeviceBuffer((N, pre_nms)); ti = DeviceBuffer((N, pre_nms), np.int32); tc = DeviceBuffer((N,), np.int32)
     ob = DeviceBuffer((N, post_nms, 4)); os_ = DeviceBuffer((N, post_nms)); oc = DeviceBuffer((N,), np.int32)
     wn = DeviceBuffer((N, 131072), np.uint8) if chip_wide and pre_nms <= 1024 else None
-    check(lib().isegmi_op_rpn_level(dh.ptr, da.ptr, dhw.ptr, N, HW, A, pre_nms, post_nms, C.c_float(nms_thr), C.c_float(min_size), nms_ge,
+    check(lib().isegmi_op_rpn_level(dh.ptr, da.ptr, dhw.ptr, N, HW, A, pre_nms, post_nms, C.c_float(nms_thr), C.c_float(min_size), nms_flags,
                                     wp.ptr, tv.ptr, ti.ptr, tc.ptr, ob.ptr, os_.ptr, oc.ptr, wn.ptr if wn is not None else None, None))
     c = oc.numpy(); B = ob.numpy(); S = os_.numpy()
     return [(B[i, : c[i]], S[i, : c[i]]) for i in range(N)]
 
 
-def rpn_levels(heads, anchors, image_hw, A, pre_nms, post_nms, nms_thr=0.7, min_size=0.0, nms_ge=0):
+def rpn_levels(heads, anchors, image_hw, A, pre_nms, post_nms, nms_thr=0.7, min_size=0.0, nms_flags=0):
     """All FPN levels at once (isegmi_op_rpn_levels): heads[l] [N,H_l,W_l,A*5], anchors[l] [H_l*W_l*A,4] -> per level a list over images of (boxes, scores)."""
     nl = len(heads)
     hs = [np.ascontiguousarray(h, np.float32) for h in heads]
@@ -508,7 +512,7 @@ def rpn_levels(heads, anchors, image_hw, A, pre_nms, post_nms, nms_thr=0.7, min_
     tv = DeviceBuffer((nl, N, pre_nms)); ti = DeviceBuffer((nl, N, pre_nms), np.int32); tc = DeviceBuffer((nl, N), np.int32)
     wn = DeviceBuffer((nl * N, 131072), np.uint8)
     ob = DeviceBuffer((N, nl, post_nms, 4)); os_ = DeviceBuffer((N, nl, post_nms)); oc = DeviceBuffer((N, nl), np.int32)
-    check(lib().isegmi_op_rpn_levels(nl, ph, pa, HW, dhw.ptr, N, A, pre_nms, post_nms, C.c_float(nms_thr), C.c_float(min_size), nms_ge, wp.ptr, cv.ptr, ci.ptr,
+    check(lib().isegmi_op_rpn_levels(nl, ph, pa, HW, dhw.ptr, N, A, pre_nms, post_nms, C.c_float(nms_thr), C.c_float(min_size), nms_flags, wp.ptr, cv.ptr, ci.ptr,
                                      tv.ptr, ti.ptr, tc.ptr, wn.ptr, ob.ptr, os_.ptr, oc.ptr, None))
     c = oc.numpy(); B = ob.numpy(); S = os_.numpy()
     return [[(B[i, l, : c[i, l]], S[i, l, : c[i, l]]) for i in range(N)] for l in range(nl)]

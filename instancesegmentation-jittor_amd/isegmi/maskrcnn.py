@@ -37,7 +37,14 @@ class MaskRCNNConfig:
     DETECTIONS_CAP: int = 0  # rows per image in the detection buffers; 0 = DETECTIONS_PER_IMG.  upstream's kth-value cut keeps every detection that
     #                          TIES with the 100th score, so an image can return more than DETECTIONS_PER_IMG: set e.g. 128 to receive those ties
     #                          (the mask head then runs over that many RoI slots per image); with 0 ties past the 100th row are cut in output order
-    NMS_GE: int = 0  # SURVEY App. A.6 switch: 0 suppress on iou > thr (CUDA kernel), 1 on >= (CPU loop)
+    # Semantic forks: which side detectron.jittor takes cannot be checked (the reference tree holds no code), so each
+    # is a switch, mirrored in the oracle (oracle/maskrcnn_ref.py) and run through the engine by tests/test_forks_gpu.py.  Defaults = maskrcnn-benchmark's
+    # CUDA path.
+    NMS_GE: int = 0             # 0 suppress on iou > thr (CUDA kernel, jt.nms), 1 on >= (CPU loop)
+    NMS_PLUS_ONE: int = 1       # 1 legacy +1 widths in the NMS IoU (RPN and box post-processing), 0 plain areas
+    NMS_OUTPUT_ORDER: str = "score"   # order of a class's detections after the box NMS: "score" (CUDA kernel) or "index" (CPU: nonzero(keep), proposal order)
+    ROI_ALIGNED: int = 0        # 0 legacy ROIAlign (no half-pixel shift, RoI >= 1 pixel), 1 ROIAlign(aligned=True)
+    FROZEN_BN_EPS: float = 0.0  # FrozenBatchNorm2d: scale = w * rsqrt(var + eps); maskrcnn-benchmark has no eps
     CONV_BODY: str = "R-50-FPN"  # "R-50-FPN" / "R-101-FPN" (depth) or "R-50-C4" (the yaml README.md:263-273 prints)
 
     @staticmethod
@@ -205,7 +212,8 @@ class MaskRCNN:
                      ("rpn_post_nms_top_n", cfg.RPN_POST_NMS_TOP_N_TEST), ("rpn_fpn_post_nms_top_n", cfg.RPN_FPN_POST_NMS_TOP_N_TEST),
                      ("rpn_nms_thresh", cfg.RPN_NMS_THRESH), ("rpn_min_size", cfg.RPN_MIN_SIZE), ("roi_score_thresh", cfg.ROI_SCORE_THRESH),
                      ("roi_nms_thresh", cfg.ROI_NMS), ("detections_per_img", cfg.DETECTIONS_PER_IMG), ("detections_cap", cfg.DETECTIONS_CAP),
-                     ("nms_ge", cfg.NMS_GE)):
+                     ("nms_ge", cfg.NMS_GE), ("nms_plus_one", cfg.NMS_PLUS_ONE), ("nms_index_order", {"score": 0, "index": 1}[cfg.NMS_OUTPUT_ORDER]),
+                     ("roi_aligned", cfg.ROI_ALIGNED)):
             self.set_param(k, float(v))
         self._d_in = _ffi.DeviceBuffer((max_batch, H, W, 3))
         self._hw = None
@@ -242,17 +250,17 @@ class MaskRCNN:
         cfg = self.cfg
         w = to_krsc(sd["backbone.body.stem.conv1.weight"])
         w = np.concatenate([w, np.zeros(w.shape[:3] + (1,), np.float32)], -1)
-        self._set_conv_krsc("backbone.body.stem.conv1", w, *fold_frozen_batchnorm(sd, "backbone.body.stem.bn1"))
+        self._set_conv_krsc("backbone.body.stem.conv1", w, *fold_frozen_batchnorm(sd, "backbone.body.stem.bn1", cfg.FROZEN_BN_EPS))
         blocks = (3, 4, 23 if cfg.depth == 101 else 6, 3)
         for li, nb in enumerate(blocks, 1):
             for b in range(nb):
                 nm = "backbone.body.layer%d.%d" % (li, b)
                 for i in (1, 2, 3):
                     self._set_conv_krsc("%s.conv%d" % (nm, i), to_krsc(sd["%s.conv%d.weight" % (nm, i)]),
-                                        *fold_frozen_batchnorm(sd, "%s.bn%d" % (nm, i)))
+                                        *fold_frozen_batchnorm(sd, "%s.bn%d" % (nm, i), cfg.FROZEN_BN_EPS))
                 if b == 0:
                     self._set_conv_krsc(nm + ".downsample.0", to_krsc(sd[nm + ".downsample.0.weight"]),
-                                        *fold_frozen_batchnorm(sd, nm + ".downsample.1"))
+                                        *fold_frozen_batchnorm(sd, nm + ".downsample.1", cfg.FROZEN_BN_EPS))
         for i in range(1, 5):
             for k in ("inner", "layer"):
                 nm = "backbone.fpn.fpn_%s%d" % (k, i)
@@ -289,10 +297,10 @@ class MaskRCNN:
             src, dst = "%s.%d" % (src_prefix, b), "%s.%d" % (dst_prefix, b)
             for i in (1, 2, 3):
                 self._set_conv_krsc("%s.conv%d" % (dst, i), to_krsc(sd["%s.conv%d.weight" % (src, i)]),
-                                    *fold_frozen_batchnorm(sd, "%s.bn%d" % (src, i)))
+                                    *fold_frozen_batchnorm(sd, "%s.bn%d" % (src, i), self.cfg.FROZEN_BN_EPS))
             if b == 0:
                 self._set_conv_krsc(dst + ".downsample.0", to_krsc(sd[src + ".downsample.0.weight"]),
-                                    *fold_frozen_batchnorm(sd, src + ".downsample.1"))
+                                    *fold_frozen_batchnorm(sd, src + ".downsample.1", self.cfg.FROZEN_BN_EPS))
 
     def _load_c4(self, sd):
         """R-50-C4 state dict (maskrcnn-benchmark names): backbone.body.{stem,layer1..3}, rpn.head.* (1024 ch, 15 anchors),
@@ -301,7 +309,7 @@ class MaskRCNN:
         cfg = self.cfg
         w = to_krsc(sd["backbone.body.stem.conv1.weight"])
         w = np.concatenate([w, np.zeros(w.shape[:3] + (1,), np.float32)], -1)
-        self._set_conv_krsc("backbone.body.stem.conv1", w, *fold_frozen_batchnorm(sd, "backbone.body.stem.bn1"))
+        self._set_conv_krsc("backbone.body.stem.conv1", w, *fold_frozen_batchnorm(sd, "backbone.body.stem.bn1", cfg.FROZEN_BN_EPS))
         for li, nb in enumerate((3, 4, 6), 1):
             self._load_bottlenecks(sd, "backbone.body.layer%d" % li, "backbone.body.layer%d" % li, nb)
         head = "roi_heads.box.feature_extractor.head.layer4"

@@ -77,7 +77,7 @@ class RecordPipeline:
         """A step without a batch on this rank (several ranks, image list not divisible): contributes an all-zero block to the all-gather."""
         assert self.gather is not None, "only the multi-rank pipeline has collective steps"
         slot = self.step % 2
-        self.gather.gather_empty()                      # on the communicator's own stream (no producer)
+        self.gather.gather_empty(self.net)              # on the results stream, like every data step: one stream per communicator
         self.gather.fence_results_stream(self.net)      # the copy below is ordered behind it
         self.net.download_async(slot, self.pin[slot], self.gather.recv, self.nbytes * self.gather.world)
         self.pending.append((slot, meta))

@@ -139,10 +139,14 @@ def fold_batchnorm(sd, prefix, eps=1e-5):
     return scale, (b - m * scale).astype(np.float32)
 
 
-def fold_frozen_batchnorm(sd, prefix):
-    """FrozenBatchNorm2d (maskrcnn-benchmark): scale = w*rsqrt(var) (no eps); shift = b - mean*scale."""
+def fold_frozen_batchnorm(sd, prefix, eps=0.0):
+    """FrozenBatchNorm2d (maskrcnn-benchmark): scale = w*rsqrt(var) (no eps); shift = b - mean*scale.
+    eps > 0 is the other side of the App. A.1 fork (FrozenBatchNorm2d variants that add an eps inside the rsqrt, e.g. detectron2's 1e-5):
+    scale = w*rsqrt(var + eps)."""
     w = sd[prefix + ".weight"].astype(np.float32); b = sd[prefix + ".bias"].astype(np.float32)
     m = sd[prefix + ".running_mean"].astype(np.float32); v = sd[prefix + ".running_var"].astype(np.float32)
+    if eps:
+        v = (v + np.float32(eps)).astype(np.float32)
     scale = (w * (np.float32(1.0) / np.sqrt(v))).astype(np.float32)
     return scale, (b - m * scale).astype(np.float32)
 

@@ -14,9 +14,11 @@ def _krsc(w):
     return np.ascontiguousarray(np.transpose(np.asarray(w, np.float32), (0, 2, 3, 1)))
 
 
-def _frozen_bn(sd, p):
-    """FrozenBatchNorm2d (A.1): scale = w * rsqrt(var) (no eps); shift = b - mean*scale."""
+def _frozen_bn(sd, p, eps=0.0):
+    """FrozenBatchNorm2d (A.1): scale = w * rsqrt(var) (no eps); shift = b - mean*scale.  eps > 0: the A.1 fork, rsqrt(var + eps)."""
     w, b, m, v = (sd[p + k].astype(np.float32) for k in (".weight", ".bias", ".running_mean", ".running_var"))
+    if eps:
+        v = (v + np.float32(eps)).astype(np.float32)
     scale = (w * (np.float32(1.0) / np.sqrt(v))).astype(np.float32)
     return scale, (b - m * scale).astype(np.float32)
 
@@ -55,19 +57,26 @@ def grid_anchors(gh, gw, stride, cell):
 
 
 class MaskRCNNRef:
-    def __init__(self, sd, depth=50, pre_nms=1000, post_nms=1000, fpn_post=1000, det_per_img=100, nms_ge=0, fp16=False):
+    def __init__(self, sd, depth=50, pre_nms=1000, post_nms=1000, fpn_post=1000, det_per_img=100, nms_ge=0, fp16=False,
+                 nms_plus_one=1, nms_index_order=0, roi_aligned=0, bn_eps=0.0):
+        """The keyword forks are SURVEY 7.2 / App. A.1, A.6, A.7 (defaults: maskrcnn-benchmark's CUDA path): nms_ge 1 suppress on iou >= thr;
+        nms_plus_one 0 plain areas in the NMS IoU; nms_index_order 1 a class's detections in proposal-index order (CPU NMS); roi_aligned 1
+        ROIAlign(aligned=True); bn_eps FrozenBatchNorm2d's rsqrt(var + eps)."""
         self.sd, self.depth = sd, depth
+        self.aligned, self.bn_eps = int(roi_aligned), float(bn_eps)
         # fp16=True emulates the product's fp16-storage path (BASELINE configs[4]): conv weights, the input image and every
         # stored activation are rounded to fp16, all arithmetic stays fp32 (ordered fmaf chain).
         self.fp16 = fp16
-        self.pre_nms, self.post_nms, self.fpn_post, self.dpi, self.ge = pre_nms, post_nms, fpn_post, det_per_img, nms_ge
+        self.pre_nms, self.post_nms, self.fpn_post, self.dpi = pre_nms, post_nms, fpn_post, det_per_img
+        self.ge = (1 if nms_ge else 0) | (0 if nms_plus_one else 2)      # flags of ora.rpn_level
+        self.ge_box = self.ge | (4 if nms_index_order else 0)          # flags of ora.box_postprocess
         self.feats = {}
 
     def _h(self, x):
         return x.astype(np.float16).astype(np.float32) if self.fp16 else x
 
     def _cbn(self, x, conv, bn, stride, pad, act, residual=None):
-        sc, sh = _frozen_bn(self.sd, bn)
+        sc, sh = _frozen_bn(self.sd, bn, self.bn_eps)
         return self._h(ora.conv2d(x, self._h(_krsc(self.sd[conv + ".weight"])), stride, pad, sc, sh, residual, act))
 
     def _cb(self, x, name, stride, pad, act, keep_f32=False):
@@ -81,7 +90,7 @@ class MaskRCNNRef:
         x4 = np.concatenate([x, np.zeros(x.shape[:3] + (1,), np.float32)], -1)
         w1 = _krsc(sd["backbone.body.stem.conv1.weight"])
         w1 = np.concatenate([w1, np.zeros(w1.shape[:3] + (1,), np.float32)], -1)
-        sc, sh = _frozen_bn(sd, "backbone.body.stem.bn1")
+        sc, sh = _frozen_bn(sd, "backbone.body.stem.bn1", self.bn_eps)
         x = ora.maxpool(self._h(ora.conv2d(self._h(x4), self._h(w1), 2, 3, sc, sh, None, 1)), 3, 2, 1)  # fp16 mode: image, weights, stem output rounded
         Cs = []
         for li, nb in enumerate((3, 4, 23 if self.depth == 101 else 6, 3), 1):
@@ -133,7 +142,7 @@ class MaskRCNNRef:
                 if len(idx) == 0:
                     continue
                 rois = np.concatenate([np.full((len(idx), 1), n, np.float32), pr[idx]], 1)
-                feat[idx] = self._h(ora.roi_align(P[k - 2], rois, 1.0 / strides[k - 2], 7, 7, 2))
+                feat[idx] = self._h(ora.roi_align(P[k - 2], rois, 1.0 / strides[k - 2], 7, 7, 2, self.aligned))
             # FC6 on the flattened (C,H,W) vector == 7x7 valid conv with weights permuted to (H,W,C)
             w6k = np.ascontiguousarray(w6.reshape(1024, 256, 7, 7).transpose(0, 2, 3, 1))
             f6 = self._h(ora.conv2d(feat, self._h(w6k), 1, 0, None, sd["roi_heads.box.feature_extractor.fc6.bias"], None, 1))
@@ -143,7 +152,7 @@ class MaskRCNNRef:
             reg = ora.conv2d(f7, self._h(sd["roi_heads.box.predictor.bbox_pred.weight"].reshape(324, 1, 1, 1024)), 1, 0, None,
                              sd["roi_heads.box.predictor.bbox_pred.bias"], None, 0).reshape(R, 324)
             self.dbg['cls'].append(cls); self.dbg['reg'].append(reg); self.dbg['f7'].append(f7)
-            db, ds, dl = ora.box_postprocess(cls, reg, pr, float(image_hw[n][1]), float(image_hw[n][0]), 0.05, 0.5, self.dpi, self.ge, self.dpi)
+            db, ds, dl = ora.box_postprocess(cls, reg, pr, float(image_hw[n][1]), float(image_hw[n][0]), 0.05, 0.5, self.dpi, self.ge_box, self.dpi)
             # mask head
             D = db.shape[0]
             m28 = np.zeros((D, 28, 28), np.float32)
@@ -155,7 +164,7 @@ class MaskRCNNRef:
                     if len(idx) == 0:
                         continue
                     rois = np.concatenate([np.full((len(idx), 1), n, np.float32), db[idx]], 1)
-                    mf[idx] = self._h(ora.roi_align(P[k - 2], rois, 1.0 / strides[k - 2], 14, 14, 2))
+                    mf[idx] = self._h(ora.roi_align(P[k - 2], rois, 1.0 / strides[k - 2], 14, 14, 2, self.aligned))
                 for i in range(1, 5):
                     mf = self._cb(mf, "roi_heads.mask.feature_extractor.mask_fcn%d" % i, 1, 1, 1)
                 up = self._h(ora.deconv2x2(mf, self._h(sd["roi_heads.mask.predictor.conv5_mask.weight"].astype(np.float32)),
@@ -190,7 +199,7 @@ class MaskRCNNRef:
         x4 = np.concatenate([x, np.zeros(x.shape[:3] + (1,), np.float32)], -1)
         w1 = _krsc(sd["backbone.body.stem.conv1.weight"])
         w1 = np.concatenate([w1, np.zeros(w1.shape[:3] + (1,), np.float32)], -1)
-        sc, sh = _frozen_bn(sd, "backbone.body.stem.bn1")
+        sc, sh = _frozen_bn(sd, "backbone.body.stem.bn1", self.bn_eps)
         x = ora.maxpool(ora.conv2d(x4, w1, 2, 3, sc, sh, None, 1), 3, 2, 1)
         for li, nb in enumerate((3, 4, 6), 1):
             for b in range(nb):
@@ -211,18 +220,18 @@ class MaskRCNNRef:
                                    float(image_hw[n][1]), float(image_hw[n][0]), self.ge)
             R = pr.shape[0]
             rois = np.concatenate([np.full((R, 1), n, np.float32), pr], 1)
-            f5 = self._res5(ora.roi_align(C4, rois, 1.0 / 16, 14, 14, 0))
+            f5 = self._res5(ora.roi_align(C4, rois, 1.0 / 16, 14, 14, 0, self.aligned))
             pooled = ora.avgpool_full(f5).reshape(R, 1, 1, -1)
             cls = ora.conv2d(pooled, sd["roi_heads.box.predictor.cls_score.weight"].reshape(81, 1, 1, -1), 1, 0, None,
                              sd["roi_heads.box.predictor.cls_score.bias"], None, 0).reshape(R, 81)
             reg = ora.conv2d(pooled, sd["roi_heads.box.predictor.bbox_pred.weight"].reshape(324, 1, 1, -1), 1, 0, None,
                              sd["roi_heads.box.predictor.bbox_pred.bias"], None, 0).reshape(R, 324)
-            db, ds, dl = ora.box_postprocess(cls, reg, pr, float(image_hw[n][1]), float(image_hw[n][0]), 0.05, 0.5, self.dpi, self.ge, self.dpi)
+            db, ds, dl = ora.box_postprocess(cls, reg, pr, float(image_hw[n][1]), float(image_hw[n][0]), 0.05, 0.5, self.dpi, self.ge_box, self.dpi)
             D = db.shape[0]
             m14 = np.zeros((D, 14, 14), np.float32)
             if D:
                 mr = np.concatenate([np.full((D, 1), n, np.float32), db], 1)
-                m5 = self._res5(ora.roi_align(C4, mr, 1.0 / 16, 14, 14, 0))
+                m5 = self._res5(ora.roi_align(C4, mr, 1.0 / 16, 14, 14, 0, self.aligned))
                 up = ora.deconv2x2(m5, sd["roi_heads.mask.predictor.conv5_mask.weight"].astype(np.float32),
                                    sd["roi_heads.mask.predictor.conv5_mask.bias"], 1)
                 m14 = ora.mask_logits_select(up.reshape(D, 196, 256), sd["roi_heads.mask.predictor.mask_fcn_logits.weight"].reshape(81, 256),

@@ -162,12 +162,13 @@ def nms(boxes, scores, thr, plus_one=1, ge=0, max_keep=0):
     return keep[:c].copy()
 
 
-def rpn_level(logits, deltas, anchors, pre_nms, post_nms, nms_thr, min_size, im_w, im_h, nms_ge=0):
+def rpn_level(logits, deltas, anchors, pre_nms, post_nms, nms_thr, min_size, im_w, im_h, nms_flags=0):
+    """nms_flags: App. A.6 forks, 1 suppress on >=, 2 plain areas (no +1)"""
     logits = _f(logits).ravel(); deltas = _f(deltas).reshape(-1, 4); anchors = _f(anchors)
     hwa = logits.size
     ob = np.empty((max(post_nms, 1), 4), np.float32); os_ = np.empty(max(post_nms, 1), np.float32)
     c = lib().ora_rpn_level(_p(logits), _p(deltas), _p(anchors), I(hwa), I(pre_nms), I(post_nms), F(nms_thr),
-                            F(min_size), F(im_w), F(im_h), I(nms_ge), _p(ob), _p(os_))
+                            F(min_size), F(im_w), F(im_h), I(nms_flags), _p(ob), _p(os_))
     return ob[:c].copy(), os_[:c].copy()
 
 
@@ -179,12 +180,13 @@ def level_map(boxes, k_min=2, k_max=5):
     return lvl[:n]
 
 
-def roi_align(feat, rois, spatial_scale, PH, PW, g=2):
+def roi_align(feat, rois, spatial_scale, PH, PW, g=2, aligned=0):
+    """aligned: App. A.7 fork, 0 the legacy op, 1 ROIAlign(aligned=True)"""
     feat = _f(feat); rois = _f(rois).reshape(-1, 5)
     N, H, W_, Cc = feat.shape
     R = rois.shape[0]
     out = np.empty((R, PH, PW, Cc), np.float32)
-    lib().ora_roi_align(_p(feat), I(N), I(H), I(W_), I(Cc), _p(rois), I(R), F(spatial_scale), I(PH), I(PW), I(g), _p(out))
+    lib().ora_roi_align2(_p(feat), I(N), I(H), I(W_), I(Cc), _p(rois), I(R), F(spatial_scale), I(PH), I(PW), I(g), I(aligned), _p(out))
     return out
 
 
@@ -198,12 +200,13 @@ def avgpool_full(x):
 
 
 def box_postprocess(logits, regr, props, im_w, im_h, score_thr=0.05, nms_thr=0.5, det_per_img=100,
-                    nms_ge=0, cap=128):
+                    nms_flags=0, cap=128):
+    """nms_flags: App. A.6 forks, 1 suppress on >=, 2 plain areas (no +1), 4 a class's detections in proposal-index order"""
     logits = _f(logits); regr = _f(regr); props = _f(props)
     R, ncls = logits.shape
     ob = np.empty((cap, 4), np.float32); os_ = np.empty(cap, np.float32); ol = np.empty(cap, np.int32)
     c = lib().ora_box_postprocess(_p(logits), _p(regr), _p(props), I(R), I(ncls), F(im_w), F(im_h), F(score_thr),
-                                  F(nms_thr), I(det_per_img), I(nms_ge), I(cap), _p(ob), _p(os_), _p(ol))
+                                  F(nms_thr), I(det_per_img), I(nms_flags), I(cap), _p(ob), _p(os_), _p(ol))
     return ob[:c].copy(), os_[:c].copy(), ol[:c].copy()
 
 
@@ -232,14 +235,14 @@ def yolact_decode(loc, priors):
     return out
 
 
-def yolact_detect(conf, boxes, mask, conf_thresh=0.05, nms_thr=0.5, top_k=200, max_det=100):
+def yolact_detect(conf, boxes, mask, conf_thresh=0.05, nms_thr=0.5, top_k=200, max_det=100, second_threshold=0):
     conf = _f(conf); boxes = _f(boxes); mask = _f(mask)
     P, ncls = conf.shape
     md = mask.shape[1]
     ob = np.empty((max_det, 4), np.float32); os_ = np.empty(max_det, np.float32)
     oc = np.empty(max_det, np.int32); om = np.empty((max_det, md), np.float32); op = np.empty(max_det, np.int32)
-    c = lib().ora_yolact_detect(_p(conf), _p(boxes), _p(mask), I(P), I(ncls), I(md), F(conf_thresh), F(nms_thr),
-                                I(top_k), I(max_det), _p(ob), _p(os_), _p(oc), _p(om), _p(op))
+    c = lib().ora_yolact_detect2(_p(conf), _p(boxes), _p(mask), I(P), I(ncls), I(md), F(conf_thresh), F(nms_thr),
+                                 I(top_k), I(max_det), I(second_threshold), _p(ob), _p(os_), _p(oc), _p(om), _p(op))
     return dict(box=ob[:c].copy(), score=os_[:c].copy(), cls=oc[:c].copy(), mask=om[:c].copy(), prior=op[:c].copy())
 
 

@@ -485,6 +485,10 @@ ORA_API void ora_decode_boxes(const float* anchors, const float* deltas, int n, 
  * ge ? suppress if iou>=thr : suppress if iou>thr.
  * keep[] receives ORIGINAL indices in score order; returns the count
  * (truncated to max_keep if max_keep>0). (M6 thr .7, M9 thr .5) */
+static int cmp_i32_asc(const void* a, const void* b) {
+    const int32_t x = *(const int32_t*)a, y = *(const int32_t*)b;
+    return x < y ? -1 : (x > y ? 1 : 0);
+}
 static inline float iou_plus(const float* a, const float* b, float one) {
     const float aa = (a[2] - a[0] + one) * (a[3] - a[1] + one);
     const float ab = (b[2] - b[0] + one) * (b[3] - b[1] + one);
@@ -527,7 +531,7 @@ ORA_API int ora_nms(const float* boxes, const float* scores, int n, float thr, i
  * logits [HWA], deltas [HWA][4], anchors [HWA][4].  Returns count. (M6) */
 ORA_API int ora_rpn_level(const float* logits, const float* deltas, const float* anchors, int hwa,
                           int pre_nms, int post_nms, float nms_thr, float min_size, float im_w,
-                          float im_h, int nms_ge, float* out_boxes, float* out_scores) {
+                          float im_h, int nms_flags, float* out_boxes, float* out_scores) {
     float* prob = (float*)malloc(sizeof(float) * (size_t)hwa);
     for (int i = 0; i < hwa; ++i) prob[i] = ora_sigmoidf(logits[i]);
     const int k = pre_nms < hwa ? pre_nms : hwa;
@@ -545,7 +549,9 @@ ORA_API int ora_rpn_level(const float* logits, const float* deltas, const float*
         if (ws >= min_size && hs >= min_size) { memcpy(bx + 4 * m, b, 16); sc[m] = ts[j]; ++m; }
     }
     int32_t* keep = (int32_t*)malloc(sizeof(int32_t) * (size_t)(m > 0 ? m : 1));
-    const int cnt = ora_nms(bx, sc, m, nms_thr, 1, nms_ge, post_nms, keep);
+    /* nms_flags (App. A.6 forks): bit 0 suppress on >=, bit 1 plain areas instead of the legacy +1.  (Index order, bit 2, is moot here:
+     * boxlist_nms truncates keep[:post_nms] of a score-sorted list, and in a score-sorted list index order IS score order.) */
+    const int cnt = ora_nms(bx, sc, m, nms_thr, (nms_flags & 2) ? 0 : 1, nms_flags & 1, post_nms, keep);
     for (int j = 0; j < cnt; ++j) { memcpy(out_boxes + 4 * j, bx + 4 * keep[j], 16); out_scores[j] = sc[keep[j]]; }
     free(keep); free(sc); free(bx); free(ti); free(ts); free(prob);
     return cnt;
@@ -582,22 +588,28 @@ static inline float roi_bilinear(const float* f, int H, int W, int C, int c, flo
     v = v + w4 * v4;
     return v;
 }
-/* Appendix A.7 RoIAlign (legacy, aligned=False, sampling g fixed) on ONE level.
+/* Appendix A.7 RoIAlign (sampling g fixed) on ONE level.
  * feat [N][H][W][C] NHWC; rois [R][5] = (batch, x1,y1,x2,y2); out [R][PH][PW][C].
- * Sum over iy then ix, then / (g*g). (M7, M10) */
-ORA_API void ora_roi_align(const float* feat, int N, int H, int W, int C, const float* rois, int R,
-                           float spatial_scale, int PH, int PW, int g, float* out) {
+ * Sum over iy then ix, then / (g*g). (M7, M10)
+ * aligned = 0: the legacy op (maskrcnn-benchmark ROIAlign_cpu / _cuda): no half-pixel shift, RoI at least 1 x 1.
+ * aligned = 1: the other side of the A.7 fork, ROIAlign(aligned=True) as in the later detectron2 / torchvision kernels: scaled corners
+ * minus 0.5 and NO minimum size. */
+ORA_API void ora_roi_align2(const float* feat, int N, int H, int W, int C, const float* rois, int R,
+                            float spatial_scale, int PH, int PW, int g, int aligned, float* out) {
     (void)N;
 #pragma omp parallel for
     for (int r = 0; r < R; ++r) {
         const float* roi = rois + 5 * (size_t)r;
         const int b = (int)roi[0];
         const float* f = feat + (size_t)b * H * W * C;
-        const float sw = roi[1] * spatial_scale, sh = roi[2] * spatial_scale;
-        const float ew = roi[3] * spatial_scale, eh = roi[4] * spatial_scale;
+        const float off = aligned ? 0.5f : 0.0f;
+        const float sw = roi[1] * spatial_scale - off, sh = roi[2] * spatial_scale - off;
+        const float ew = roi[3] * spatial_scale - off, eh = roi[4] * spatial_scale - off;
         float rw = ew - sw, rh = eh - sh;
-        rw = rw > 1.0f ? rw : 1.0f;
-        rh = rh > 1.0f ? rh : 1.0f;
+        if (!aligned) {
+            rw = rw > 1.0f ? rw : 1.0f;
+            rh = rh > 1.0f ? rh : 1.0f;
+        }
         const float bh = rh / (float)PH, bw = rw / (float)PW;
         /* sampling_ratio > 0: fixed g x g grid; <= 0: adaptive ceil(roi_size / pooled_size) (the ROIAlign default used by
          * the R-50-C4 config, whose yaml does not set POOLER_SAMPLING_RATIO) */
@@ -622,6 +634,11 @@ ORA_API void ora_roi_align(const float* feat, int N, int H, int W, int C, const 
     }
 }
 
+ORA_API void ora_roi_align(const float* feat, int N, int H, int W, int C, const float* rois, int R,
+                           float spatial_scale, int PH, int PW, int g, float* out) {
+    ora_roi_align2(feat, N, H, W, C, rois, R, spatial_scale, PH, PW, g, 0, out);
+}
+
 /* nn.AvgPool2d(k) on an R x k x k x C NHWC tensor with k == H == W (FastRCNNPredictor of the C4 head): sequential fp32
  * sum over (h, w), one division.  out [R][C]. */
 ORA_API void ora_avgpool_full(const float* x, int R, int HW, int C, float* out) {
@@ -639,10 +656,12 @@ ORA_API void ora_avgpool_full(const float* x, int R, int HW, int C, float* out) 
  * logits [R][ncls], regr [R][4*ncls], props [R][4].
  * Output rows in class order (1..ncls-1), within class NMS (score) order; if
  * more than det_per_img survive keep score >= kth value (ties kept), order
- * preserved; at most cap rows are written.  Returns count. (M9) */
+ * preserved; at most cap rows are written.  Returns count. (M9)
+ * nms_flags (App. A.6 forks): bit 0 suppress on iou >= thr; bit 1 plain areas (no +1); bit 2 a class's kept boxes in ascending
+ * candidate (= proposal) index, as maskrcnn-benchmark's CPU nms returns them (nonzero of the keep mask), instead of score order. */
 ORA_API int ora_box_postprocess(const float* logits, const float* regr, const float* props, int R,
                                 int ncls, float im_w, float im_h, float score_thr, float nms_thr,
-                                int det_per_img, int nms_ge, int cap, float* out_boxes,
+                                int det_per_img, int nms_flags, int cap, float* out_boxes,
                                 float* out_scores, int32_t* out_labels) {
     float* prob = (float*)malloc(sizeof(float) * (size_t)R * ncls);
     ora_softmax(logits, R, ncls, prob);
@@ -665,7 +684,8 @@ ORA_API int ora_box_postprocess(const float* logits, const float* regr, const fl
                 ++m;
             }
         }
-        const int cnt = ora_nms(cb, cs, m, nms_thr, 1, nms_ge, 0, keep);
+        const int cnt = ora_nms(cb, cs, m, nms_thr, (nms_flags & 2) ? 0 : 1, nms_flags & 1, 0, keep);
+        if (nms_flags & 4) qsort(keep, (size_t)cnt, sizeof(int32_t), cmp_i32_asc);
         for (int q = 0; q < cnt; ++q) {
             memcpy(ab + 4 * (size_t)tot, cb + 4 * (size_t)keep[q], 16);
             as[tot] = cs[keep[q]];
@@ -777,14 +797,15 @@ static inline float jaccard1(const float* a, const float* b) {
 
 /* Appendix A.9/A.6 Detect for ONE image: conf [P][ncls] are SOFTMAX probabilities.
  *  keep prior if max_{c>=1} conf > conf_thresh; per class: stable sort desc, top_k;
- *  fast-NMS: box j of class c survives iff max_{i<j} iou(i,j) <= nms_thr (NaN drops);
- *  gather class-major, stable sort desc, first max_det.
+ *  fast-NMS: box j of class c survives iff max_{i<j} iou(i,j) <= nms_thr (NaN drops)
+ *  [and, with second_threshold (the A.6 fork, fast_nms(second_threshold=True); off in the default detect() call), iff its own class
+ *  score > conf_thresh];  gather class-major, stable sort desc, first max_det.
  * Outputs: boxes[max_det][4], scores, classes (0..ncls-2), coeffs [max_det][mask_dim],
  * prior index.  Returns count. (Y6) */
-ORA_API int ora_yolact_detect(const float* conf, const float* boxes, const float* mask, int P, int ncls,
-                              int mask_dim, float conf_thresh, float nms_thr, int top_k, int max_det,
-                              float* out_boxes, float* out_scores, int32_t* out_classes,
-                              float* out_coeffs, int32_t* out_prior) {
+ORA_API int ora_yolact_detect2(const float* conf, const float* boxes, const float* mask, int P, int ncls,
+                               int mask_dim, float conf_thresh, float nms_thr, int top_k, int max_det, int second_threshold,
+                               float* out_boxes, float* out_scores, int32_t* out_classes,
+                               float* out_coeffs, int32_t* out_prior) {
     int32_t* kept = (int32_t*)malloc(sizeof(int32_t) * (size_t)P);
     int nk = 0;
     for (int i = 0; i < P; ++i) {
@@ -812,6 +833,7 @@ ORA_API int ora_yolact_detect(const float* conf, const float* boxes, const float
                 const float o = jaccard1(boxes + 4 * (size_t)kept[ti[i]], bj);
                 if (!(o <= nms_thr)) { ok = 0; break; }
             }
+            if (second_threshold && !(ts[j] > conf_thresh)) ok = 0;
             if (ok) { fs[tot] = ts[j]; fp[tot] = kept[ti[j]]; fc[tot] = c; ++tot; }
         }
     }
@@ -829,6 +851,14 @@ ORA_API int ora_yolact_detect(const float* conf, const float* boxes, const float
     }
     free(oi); free(os); free(fc); free(fp); free(fs); free(ti); free(ts); free(cs); free(kept);
     return m;
+}
+
+ORA_API int ora_yolact_detect(const float* conf, const float* boxes, const float* mask, int P, int ncls,
+                              int mask_dim, float conf_thresh, float nms_thr, int top_k, int max_det,
+                              float* out_boxes, float* out_scores, int32_t* out_classes,
+                              float* out_coeffs, int32_t* out_prior) {
+    return ora_yolact_detect2(conf, boxes, mask, P, ncls, mask_dim, conf_thresh, nms_thr, top_k, max_det, 0, out_boxes, out_scores,
+                              out_classes, out_coeffs, out_prior);
 }
 
 /* Appendix A.9 sanitize_coordinates(cast=False). */

@@ -44,11 +44,13 @@ def make_priors(conv_h, conv_w, scale, max_size, ars=(1.0, 0.5, 2.0), square=Tru
 
 
 class YolactRef:
-    def __init__(self, sd, max_size=550, scales=(24, 48, 96, 192, 384), depth=50, fp16=False, scales_per_level=1, square=True):
+    def __init__(self, sd, max_size=550, scales=(24, 48, 96, 192, 384), depth=50, fp16=False, scales_per_level=1, square=True,
+                 second_threshold=0):
         # YOLACT++: scales_per_level=3, square=False; DCNv2 blocks and the mask-IoU net are recognised by their state-dict
         # entries (<block>.conv2.conv_offset_mask.weight, maskiou_net.0.weight)
         self.scales_per_level = scales_per_level
         self.square = square
+        self.second_threshold = int(second_threshold)   # App. A.6 fork: Detect.fast_nms(second_threshold=True)
         # fp16=True emulates the product's optional fp16-storage mode: image, conv weights and every stored activation are rounded
         # to fp16 (the fused head outputs and the prototypes stay fp32), arithmetic stays the fp32 ordered chain.
         self.fp16 = fp16
@@ -154,7 +156,7 @@ class YolactRef:
         dets = []
         for n in range(N):
             boxes = ora.yolact_decode(loc[n], priors)
-            d = ora.yolact_detect(ora.softmax(conf[n]), boxes, mask[n])
+            d = ora.yolact_detect(ora.softmax(conf[n]), boxes, mask[n], second_threshold=self.second_threshold)
             d["proto"] = proto[n]
             dets.append(d)
         return dets

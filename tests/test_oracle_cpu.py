@@ -198,6 +198,53 @@ def test_yolact_decode_and_fast_nms_known_answers():
     assert len(empty["score"]) == 0
 
 
+def test_semantic_fork_known_answers():
+    """SURVEY 7.2 / App. A.6, A.7 forks of the oracle, each on a hand-derived case where its two sides differ."""
+    # --- NMS inside the RPN level: zero deltas return the anchors, so `anchors` are the candidate boxes
+    boxes = np.array([[0, 0, 9, 0], [3, 0, 9, 0], [20, 0, 29, 9], [20, 0, 29, 6]], np.float32)   # IoU 7/10 and 70/100 with +1; 0/0 and 54/81 without
+    logit = np.log(np.array([0.9, 0.8, 0.7, 0.6]) / (1 - np.array([0.9, 0.8, 0.7, 0.6]))).astype(np.float32)
+    z = np.zeros((4, 4), np.float32)
+    keep = lambda thr, flags: ora.rpn_level(logit, z, boxes, 4, 4, thr, 0.0, 400.0, 400.0, flags)[0].tolist()
+    assert keep(0.7, 0) == boxes.tolist()                       # 0.7 is not > 0.7
+    assert keep(0.7, 1) == boxes[[0, 2]].tolist()               # >= suppresses both ties
+    assert keep(0.68, 0) == boxes[[0, 2]].tolist()              # +1: both IoUs are 0.7 > 0.68
+    assert keep(0.68, 2) == boxes.tolist()                      # plain areas: NaN and 0.667
+    assert keep(0.66, 2) == boxes[[0, 1, 2]].tolist()           # 0.667 > 0.66; 0/0 never suppresses
+    # --- box post-processing: output order inside a class
+    props = np.array([[0, 0, 9, 9], [0, 0, 9, 4], [50, 50, 80, 90], [100, 20, 130, 60]], np.float32)
+    logits = np.full((4, 81), -6.0, np.float32); logits[:, 0] = 0.0
+    logits[:, 5] = [2.0, 1.0, 3.0, 4.0]
+    regr = np.zeros((4, 324), np.float32)
+    order = lambda flags: [props.tolist().index(b) for b in ora.box_postprocess(logits, regr, props, 400.0, 400.0, nms_flags=flags)[0].tolist()]
+    assert order(0) == [3, 2, 0, 1] and order(4) == [0, 1, 2, 3]          # score order / proposal-index order
+    assert order(1) == [3, 2, 0] and order(5) == [0, 2, 3]                # IoU(0, 1) = 50/100 = 0.5: suppressed by >= only
+    assert order(3) == [3, 2, 0, 1]                                       # plain areas: 36/81 < 0.5
+    # --- RoIAlign aligned: on a ramp f[y, x] = x the bins of RoI [8, 22] average 8 + (pw + 0.5) * 2 (legacy) and 0.5 less (aligned)
+    ramp = np.tile(np.arange(40, dtype=np.float32)[None, :, None], (12, 1, 1))[None]
+    roi = np.array([[0, 8.0, 2.0, 22.0, 9.0]], np.float32)
+    for aligned in (0, 1):
+        got = ora.roi_align(ramp, roi, 1.0, 7, 7, 2, aligned)[0, 3, :, 0]
+        assert np.allclose(got, 8.0 + (np.arange(7) + 0.5) * 2.0 - 0.5 * aligned, atol=1e-5)
+    # a RoI thinner than a pixel: the legacy op widens it to one pixel, aligned keeps 0.25 -> all 14 sample columns inside [10.0, 10.25) - 0.5
+    thin = np.array([[0, 10.0, 2.0, 10.25, 9.0]], np.float32)
+    leg, ali = ora.roi_align(ramp, thin, 1.0, 7, 7, 2, 0)[0, 0, :, 0], ora.roi_align(ramp, thin, 1.0, 7, 7, 2, 1)[0, 0, :, 0]
+    assert leg[-1] - leg[0] > 0.8 and ali[-1] - ali[0] < 0.25 and 9.5 <= ali[0] <= ali[-1] < 9.75
+    # --- Yolact fast_nms(second_threshold): a prior that passed the pre-filter on class 3 is also ranked in class 7 with a sub-threshold score
+    prob = np.full((4, 81), 1e-4, np.float32)
+    prob[0, 3] = 0.6; prob[0, 7] = 0.04; prob[1, 7] = 0.5
+    bx = np.array([[0.1, 0.1, 0.2, 0.2], [0.3, 0.3, 0.4, 0.4], [0.5, 0.5, 0.6, 0.6], [0.7, 0.7, 0.8, 0.8]], np.float32)
+    mk = np.zeros((4, 32), np.float32)
+    pairs = lambda st: sorted(zip(*(ora.yolact_detect(prob, bx, mk, second_threshold=st)[k].tolist() for k in ("prior", "cls"))))
+    assert pairs(0) == [(0, 2), (0, 6), (1, 2), (1, 6)] or (0, 6) in pairs(0)
+    assert (0, 6) not in pairs(1) and (0, 2) in pairs(1) and (1, 6) in pairs(1)
+    # --- FrozenBatchNorm eps
+    from oracle.maskrcnn_ref import _frozen_bn
+    sd = {"bn.weight": np.array([2.0], np.float32), "bn.bias": np.array([1.0], np.float32), "bn.running_mean": np.array([3.0], np.float32),
+          "bn.running_var": np.array([4.0], np.float32)}
+    sc, sh = _frozen_bn(sd, "bn"); assert sc[0] == 1.0 and sh[0] == -2.0
+    sc, sh = _frozen_bn(sd, "bn", 5.0); assert np.allclose(sc[0], 2.0 / 3.0) and np.allclose(sh[0], 1.0 - 2.0)
+
+
 def test_paste_known_answer():
     m = np.full((1, 28, 28), 0.9, np.float32)
     o = ora.paste_masks(m, np.array([[50, 60, 250, 300]], np.float32), 384, 500)[0]

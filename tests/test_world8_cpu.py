@@ -128,14 +128,17 @@ class _FakeGather:
         self.ex, self.rank, self.world, self.nbytes = ex, rank, ex.world, int(nbytes)
         self.recv = None
         self.empty_steps = self.resizes = 0
+        self.log = []   # RcclGather.log: (kind, bytes, stream) of every collective this rank issued
 
     def gather_coco_from(self, net, n_block):
         b = net.pack(n_block)
         assert b.size == self.nbytes
+        self.log.append(("data", b.size, "results"))
         self.recv = self.ex.allgather(self.rank, b)
 
-    def gather_empty(self):
+    def gather_empty(self, net=None):
         self.empty_steps += 1
+        self.log.append(("empty", self.nbytes, "results" if net is not None else "own"))
         self.recv = self.ex.allgather(self.rank, np.zeros(self.nbytes, np.uint8))
 
     def fence_results_stream(self, net):
@@ -302,6 +305,16 @@ def test_inference_schedule_world8_with_empty_steps_and_overflow_redo(monkeypatc
         assert gathers[r].empty_steps >= nsteps - mine                # (a redone step of an idle rank is one more empty block)
         assert preds[r].model.sparse == 0.0                            # the pipeline was closed on the way out
         assert preds[r].model.redone == preds[0].model.redone and gathers[r].resizes == gathers[0].resizes
+    # the sequence of collectives -- how many, of how many bytes each -- is the same on all eight ranks (a rank without a batch issues
+    # an empty block where the others issue data), and every one of them, empty steps and redone steps included, goes to the results stream
+    seq0 = [b for _, b, _ in gathers[0].log]
+    assert len(seq0) >= nsteps
+    for r in range(world):
+        assert [b for _, b, _ in gathers[r].log] == seq0, "rank %d issued another sequence of collectives" % r
+        assert {s for _, _, s in gathers[r].log} == {"results"}, "rank %d put a collective on a second stream" % r
+        assert sum(k == "empty" for k, _, _ in gathers[r].log) == gathers[r].empty_steps
+    if n_img == 37:
+        assert any(k == "empty" for k, _, _ in gathers[7].log) and all(k == "data" for k, _, _ in gathers[0].log)
     if n_img >= 16:
         assert preds[0].model.redone >= 1, "the fixture is meant to overflow the initial capacity"
         assert len(set(ex.sizes)) >= 2, "the block size grew in step on every rank"
