@@ -136,4 +136,5 @@ def test_yolact_fallback_launch_forms_are_bit_identical_to_the_default(ffi, fp16
             same(run(v), base)
         except AssertionError as e:
             raise AssertionError("variant %r: %s" % (v, e))
-    same(run({}, fuse_heads=False), base)
+    if not fp16:   # (the fp16 engine has the fused prediction head only)
+        same(run({}, fuse_heads=False), base)
