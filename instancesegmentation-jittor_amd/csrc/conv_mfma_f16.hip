@@ -370,7 +370,10 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, OCC) void conv_f16_glds_kernel
 // Offsets: a lane's residual / output offset is ONE add per strip -- lane base (its row inside the strip, its 8 channels; the out-of-range
 // constant for a column past Cout) plus a wave-uniform row term; rows past M fall behind descriptors cut at M rows (contiguous
 // destinations; strided ones keep the general arithmetic).
-constexpr int EPI_D = 2;
+#ifndef ISEGMI_EPI_D
+#define ISEGMI_EPI_D 2
+#endif
+constexpr int EPI_D = ISEGMI_EPI_D;   // residual passes in flight per lane (tools/build_variant.sh ... -DISEGMI_EPI_D=4 for an A/B)
 
 template <int TM, int TN>
 struct Epi8 {

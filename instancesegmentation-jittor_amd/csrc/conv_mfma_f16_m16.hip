@@ -241,12 +241,20 @@ __device__ __forceinline__ void mfma16_chunk(f32x4h (&acc)[NA][NC], const char* 
     }
 }
 
-constexpr int EPI_D = 2;
+#ifndef ISEGMI_EPI_D
+#define ISEGMI_EPI_D 2
+#endif
+constexpr int EPI_D = ISEGMI_EPI_D;   // residual passes in flight per lane (tools/build_variant.sh ... -DISEGMI_EPI_D=4 for an A/B)
 
 template <int WR, int TN>   // WR rows x 32 TN columns per wave
 struct Epi8 {
     static_assert(TN == 2 || TN == 4, "strips are 64 or 128 channels wide");
     static constexpr int LPR = TN * 4, RPP = 64 / LPR, NQ = WR / RPP;  // passes (b128 per lane) per wave tile
+    // residual passes in flight per lane: a 64-row wave tile (64 accumulator registers of the 128 a wave has at 16 waves per CU) leaves room for two.
+    // Round 6 tried the other end -- a 96 x 256 tile, 32-row wave tiles, ALL four passes of a wave in flight under the K loop (100 registers, no
+    // spill, bit-identical) -- on R101 res4 conv3 (M = 33 600, K = 256, Cout = 1024, with residual): 45 us against 47 (tile 37) / 44 (47) alone, level
+    // in the model: the residual round trips are not what bounds these layers, the CU's LDS fill path is (224 KB of A + B per 192 x 256 tile for
+    // 25 MFLOP; profiles/r06_experiments.txt 2).  Not kept.
     static constexpr int D = EPI_D < NQ ? EPI_D : NQ;
     u32x4h r[D];
     unsigned rnext;   // residual offset (bytes) of the next pass to request, or >= OOB for a column past Cout; pass q covers tile rows RPP q ..
@@ -391,6 +399,15 @@ __device__ __forceinline__ void epi8_finish(const ConvKH& p, ACC& acc, Epi8<acc_
     else epi8_finish_impl<false, false>(p, acc, E, ew, lane, wm, wn, m0, n0);
 }
 
+// bytes of strip scratch the persistent kernel needs BEHIND its ring: the epilogue strips of the waves that do not fit the stage read last (at least the
+// 5120 B of round 5's 144 x 256 tile, whose layout tests pin)
+template <int BM, int BN, int WM, int WN>
+constexpr int p_espare() {
+    constexpr int NW = WM * WN, TN = BN / WN / 32, STAGEB = (BM + BN) * 128, EWB = 16 * (TN * 32 + 4) * 4;
+    constexpr int EFIT = STAGEB / EWB < NW ? STAGEB / EWB : NW;
+    constexpr int need = (NW - EFIT) * EWB;
+    return need > 5120 ? (need + 1023) / 1024 * 1024 : 5120;
+}
 template <int BM, int BN, int WM, int WN, int NSTAGE, int OCC, int LW, bool UP2X = false, int MS = 0>
 __global__ __launch_bounds__((WM * WN + LW) * 64, OCC) void conv_f16_persist_kernel(const ConvKH p_arg) {
     static_assert(LW > 0 && NSTAGE >= 2 && NSTAGE <= 3, "loader waves, a 2- or 3-deep ring");
@@ -416,6 +433,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, OCC) void conv_f16_persist_ker
     // the epilogue's strips live in the ring stage the MFMA waves read last; where that stage is too small for all of them (144 x 256: 51 200 B for
     // twelve strips of 4352 B) the waves past EFIT take theirs from the spare LDS behind the ring (launch_p sizes it)
     constexpr int EFIT = STAGEB / EWB < NW ? STAGEB / EWB : NW;
+    constexpr int ESPARE = p_espare<BM, BN, WM, WN>();   // bytes behind the ring for those waves' strips (launch_p sizes the same)
     (void)UNEVEN;
     extern __shared__ __attribute__((aligned(1024))) char smemg[];
     constexpr unsigned OOB = 0x80000000u;
@@ -490,7 +508,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, OCC) void conv_f16_persist_ker
                 // (named operands: hipcc 7.2 silently drops the host stub of the kernel when this builtin takes expressions)
                 const __amdgpu_buffer_rsrc_t rs = (live && !dummy) ? rs_in : rs_in0;
                 const unsigned voff = avoff[i];
-                char* dstp = dummy ? smemg + NSTAGE * STAGEB + 5120 + lw * 1024 : sA + (lw + i * NL) * 1024;
+                char* dstp = dummy ? smemg + NSTAGE * STAGEB + ESPARE + lw * 1024 : sA + (lw + i * NL) * 1024;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)dstp, 16, voff, soffa, 0, CONV_F16_A_AUX);
             }
             static_assert(PB % NL == 0, "whole B piece rounds");
@@ -1030,8 +1048,9 @@ static int launch_p(ConvKH& k, hipStream_t st, bool few) {
     size_t lds = (size_t)NSTAGE * (BM + BN) * 128;
     // behind the ring: 5120 B for the strip scratch of the waves that do not fit the last stage, LW KiB of landing zone for dropped pieces
     // (conv_f16_persist_kernel: EFIT, issue_chunk) -- only where the tile needs them
-    if ((BM / 8) % LW != 0 || (size_t)NW * 16 * (TN * 32 + 4) * 4 > (size_t)(BM + BN) * 128) lds += 5120 + (size_t)LW * 1024;
-    static_assert(NSTAGE * (BM + BN) * 128 + 5120 + LW * 1024 <= 163840 || ((BM / 8) % LW == 0 && NW * 16 * (TN * 32 + 4) * 4 <= (BM + BN) * 128), "LDS");
+    constexpr int ESPARE = p_espare<BM, BN, WM, WN>();
+    if ((BM / 8) % LW != 0 || (size_t)NW * 16 * (TN * 32 + 4) * 4 > (size_t)(BM + BN) * 128) lds += ESPARE + (size_t)LW * 1024;
+    static_assert(NSTAGE * (BM + BN) * 128 + ESPARE + LW * 1024 <= 163840 || ((BM / 8) % LW == 0 && NW * 16 * (TN * 32 + 4) * 4 <= (BM + BN) * 128), "LDS");
     LDS_LIMIT_ONCE((int)lds, conv_f16_persist_kernel<BM, BN, WM, WN, NSTAGE, OCC, LW, UP2X, MS>);
     const int ncu = device_cu_count();
     const int64_t total = (int64_t)k.mtiles * k.ntiles;
