@@ -307,6 +307,12 @@ typedef struct isegmi_box_post_args {
     float* d_out_boxes;        /* [N][cap][4] */
     float* d_out_scores;       /* [N][cap] */
     int32_t* d_out_labels;     /* [N][cap] 1..ncls-1 (0 = empty) */
+    /* optional (all four or none): classes with more than 128 candidates get their suppression matrix from the whole chip (three launches instead of
+     * one block per class building it alone: ~85 us for a 1000-candidate class); same kept lists */
+    void* d_ws_crowd_matrix;     /* [N][ncls-1] x 131072 bytes */
+    void* d_ws_crowd_keys;       /* [N][ncls-1][R] 8-byte keys */
+    float* d_ws_crowd_boxes;     /* [N][ncls-1][R][4] */
+    int32_t* d_ws_crowd_m;       /* [N][ncls-1] */
 } isegmi_box_post_args;
 int isegmi_op_box_postprocess(const isegmi_box_post_args* a, void* stream);
 /* mask predictor tail (A.8): out[r,p] = sigmoid(<feat[r,p,:], w[label_r,:]> + b[label_r]); label 0 -> zeros */

@@ -2,8 +2,10 @@
 // persistent loader-wave kernel of csrc/conv_mfma_f16.hip with the SAME loaders, LDS chunk images, barrier protocol, tile walk and output tile per wave
 // (64 x 64) -- only the MFMA waves' fragment reads, the instruction and the accumulator layout (hence the epilogues' staging) differ.  Its own translation
 // unit so that the 32 x 32 x 16 kernels' code generation is untouched (co-compiled template variants share register-allocation context: the first attempt,
-// one template with a shape parameter, spilled in the 32 x 32 x 16 instantiations that had not spilled before).  The kernels keep the shape parameter MS
-// (only MS = 1 is instantiated here) so that the two files can be diffed.
+// one template with a shape parameter, spilled in the 32 x 32 x 16 instantiations that had not spilled before).  What the two forms share lives ONCE
+// (round 6): the persistent kernel's loader role in conv_f16.h (conv_f16_persist_loader), the strip kernel's geometry / loader state / loader loop in
+// conv_f16_strip_state.inc and conv_f16_strip_loader_loop.inc; what remains here is what the shape decides -- accumulator layout, fragment reads, the chunk
+// of MFMAs, the epilogues' staging.  (The template parameter MS = 1 only marks the form in the kernels' mangled names.)
 #include "conv_f16.h"
 
 namespace isegmi {
@@ -17,27 +19,10 @@ namespace isegmi {
 // power-bound loops (MI355X_MICROARCH.md "DVFS give-back" 7; tools/microbench/mfma_shape.hip: 1.12-1.13x on random data at equal cycles).  The 32-term sum
 // of one 16 x 16 x 32 instruction is bit for bit what two chained 32 x 32 x 16 instructions give (same microbenchmark: 0 of 204 800 elements differ), and the
 // kernels here walk K exactly as their twins do: results do not depend on the shape (tests/test_conv_f16_gpu.py::test_mfma_shape_does_not_change_results).
-// In this file a wave tile is NA x NC blocks of 16 x 16: WR = 16 NA rows (48 or 64), 16 NC = 32 TN columns.  (The 32 x 32 x 16 branches kept from the
-// twin file are never instantiated here; their TM is only a placeholder.)
+// In this file a wave tile is NA x NC blocks of 16 x 16: WR = 16 NA rows (48 or 64), 16 NC = 32 TN columns.
 template <class T> struct acc_traits;
-template <int TM_, int TN_> struct acc_traits<f32x16h[TM_][TN_]> { static constexpr int TM = TM_, TN = TN_, MS = 0, SR = 8, NA = TM_, NC = TN_, WR = 32 * TM_; };
 template <int NA_, int NC_> struct acc_traits<f32x4h[NA_][NC_]> { static constexpr int TM = (NA_ + 1) / 2, TN = NC_ / 2, MS = 1, SR = 16, NA = NA_, NC = NC_, WR = 16 * NA_; };
 
-// rows [32 a, 32 a + 32) of the wave tile -> ew[row in strip][column], y = fmaf(acc, scale, shift)
-template <int TM, int TN>
-__device__ __forceinline__ void epi_stage32(const ConvKH& p, f32x16h (&acc)[TM][TN], int a, float* ew, int lane, int wn, int n0) {
-    constexpr int PITCH = TN * 32 + 4;
-    const int lr = lane & 31, lh = lane >> 5;
-#pragma unroll
-    for (int b = 0; b < TN; ++b) {
-        const int co = n0 + (wn * TN + b) * 32 + lr;
-        const bool cok = co < p.Cout;
-        const float sc = (cok && p.scale) ? p.scale[co] : 1.0f;
-        const float sh = (cok && p.shift) ? p.shift[co] : 0.0f;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) ew[((e & 3) + 8 * (e >> 2) + 4 * lh) * PITCH + b * 32 + lr] = fmaf(acc[a][b][e], sc, sh);
-    }
-}
 // block row i (rows [16 i, 16 i + 16) of the wave tile) -> ew[row in strip][column], y = fmaf(acc, scale, shift)
 template <int NA, int NC>
 __device__ __forceinline__ void epi_stage16(const ConvKH& p, f32x4h (&acc)[NA][NC], int i, float* ew, int lane, int wn, int n0) {
@@ -421,13 +406,11 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, OCC) void conv_f16_persist_ker
     const int p_mtiles = kp0->mtiles, p_ntiles = kp0->ntiles, p_nchunks = kp0->nchunks;
     constexpr int NW = WM * WN, NL = LW;
     static_assert(MS == 1 && (BM / WM) % 16 == 0 && BM % WM == 0, "16 x 16 x 32: a wave owns a whole number of 16-row blocks");
-    constexpr int WR = BM / WM, TM = (WR + 31) / 32, TN = BN / WN / 32;   // rows per wave; (TM: placeholder of the uninstantiated 32 x 32 x 16 branch)
+    constexpr int WR = BM / WM, TN = BN / WN / 32;   // rows per wave, 32-column units per wave
     constexpr int PA = BM / 8, PB = BN / 8;
-    constexpr int PPA = (PA + NL - 1) / NL, PPB = (PB + NL - 1) / NL;
     constexpr bool UNEVEN = (PA % NL != 0) || (PB % NL != 0);
     // (a partial piece round issues one dropped piece in its place -- see issue_chunk -- so a wave's vmcnt count stays uniform)
     constexpr int STAGEB = (BM + BN) * 128;
-    constexpr int PP = PPA + PPB;
     constexpr int ESR = 16;            // rows per epilogue strip (acc_traits::SR)
     constexpr int EWB = ESR * (TN * 32 + 4) * 4;   // a wave's strip scratch (bytes)
     // the epilogue's strips live in the ring stage the MFMA waves read last; where that stage is too small for all of them (144 x 256: 51 200 B for
@@ -436,7 +419,6 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, OCC) void conv_f16_persist_ker
     constexpr int ESPARE = p_espare<BM, BN, WM, WN>();   // bytes behind the ring for those waves' strips (launch_p sizes the same)
     (void)UNEVEN;
     extern __shared__ __attribute__((aligned(1024))) char smemg[];
-    constexpr unsigned OOB = 0x80000000u;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -451,115 +433,13 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, OCC) void conv_f16_persist_ker
     const int my_tiles = (total - bid + G - 1) / G;  // >= 1: the launcher never starts more blocks than tiles
 
     conv_f16_role_prio(wave >= NW);
-    if (wave >= NW) {
-        // ---------------- loader waves
-        karg_t kl = kp0;
-        asm volatile("" : "+s"(kl));
-        const ConvKH& p = *(const ConvKH*)kl;
-        const int lw = wave - NW;
-        const int r8 = lane >> 3, cs = lane & 7;
-        const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_in0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, 0, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_w0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0, 0x00020000);
-        int hi0[PPA], wi0[PPA], abase[PPA];
-        unsigned avoff[PPA], bbase[PPB];
-        int kr = 0, ks = 0, kc = 0, in_tile = 0, v = bid;
-        unsigned soffa = 0;
-        bool live = true;
-        auto setup_tile = [&](int vv) {  // per-lane row bases of tile vv; the only place with integer divisions
-            int m0, n0;
-            tile_origin(vv, m0, n0);
-#pragma unroll
-            for (int j = 0; j < PPA; ++j) {
-                const int row = (lw + j * NL) * 8 + r8;
-                const int c = cs ^ ((row >> 1) & 7);
-                const int m = m0 + row;
-                if (m < p.M) {
-                    const int hw = p.Ho * p.Wo;
-                    const int n = m / hw, rem = m - n * hw;
-                    const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-                    hi0[j] = ho * p.stride - p.pad;
-                    wi0[j] = wo * p.stride - p.pad;
-                    abase[j] = (((n * p.H + hi0[j]) * p.W + wi0[j]) * p.Cin) * 2 + c * 16;
-                } else {
-                    hi0[j] = -(1 << 28); wi0[j] = 0; abase[j] = 0;
-                }
-                const bool ok = (unsigned)hi0[j] < (unsigned)p.H && (unsigned)wi0[j] < (unsigned)p.W;
-                avoff[j] = ok ? (unsigned)abase[j] : OOB;
-            }
-#pragma unroll
-            for (int j = 0; j < PPB; ++j) {
-                const int row = (lw + j * NL) * 8 + r8;
-                const int c = cs ^ ((row >> 1) & 7);
-                bbase[j] = (unsigned)(n0 + row) * (unsigned)(p.wrow * 2) + (unsigned)(c * 16);
-            }
-            kr = 0; ks = 0; kc = 0; in_tile = 0; soffa = 0;
-        };
-        setup_tile(v);
-        auto issue_chunk = [&](int stage) {  // all of this wave's pieces of the next chunk of the stream, then advance the stream
-            char* sA = smemg + stage * STAGEB;
-            const unsigned soffb = (unsigned)in_tile * 128u;
-#pragma unroll
-            for (int i = 0; i < PPA; ++i) {
-                // a wave without a piece in the partial last round (144 rows = 18 pieces over 4 loaders) sends a DROPPED one (zero-length descriptor: zeros
-                // land in the wave's own dummy KiB behind the ring) so that every wave's vmcnt count per chunk stays PP (wave-uniform branch)
-                const bool dummy = PA % NL != 0 && lw + i * NL >= PA;
-                // (named operands: hipcc 7.2 silently drops the host stub of the kernel when this builtin takes expressions)
-                const __amdgpu_buffer_rsrc_t rs = (live && !dummy) ? rs_in : rs_in0;
-                const unsigned voff = avoff[i];
-                char* dstp = dummy ? smemg + NSTAGE * STAGEB + ESPARE + lw * 1024 : sA + (lw + i * NL) * 1024;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)dstp, 16, voff, soffa, 0, CONV_F16_A_AUX);
-            }
-            static_assert(PB % NL == 0, "whole B piece rounds");
-#pragma unroll
-            for (int j = 0; j < PPB; ++j) {
-                if (PB % NL != 0 && lw + j * NL >= PB) continue;
-                const __amdgpu_buffer_rsrc_t rs = live ? rs_w : rs_w0;
-                const unsigned voff = bbase[j];
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(sA + BM * 128 + (lw + j * NL) * 1024), 16, voff, soffb, 0, 0);
-            }
-            if (!live) return;
-            soffa += 128u;
-            if (++in_tile == p.nchunks) {  // uniform: the stream moves on to this block's next tile
-                v += G;
-                live = v < total;
-                if (live) setup_tile(v);
-                return;
-            }
-            if (++kc == p.cin_chunks) {  // uniform: next tap -- the only per-lane work inside a tile
-                kc = 0;
-                soffa = 0;
-                if (++ks == p.S) { ks = 0; ++kr; }
-                int tr = __builtin_amdgcn_readfirstlane(kr), ts = __builtin_amdgcn_readfirstlane(ks);
-                asm volatile("" : "+s"(tr), "+s"(ts));  // keeps the tap change behind its branch
-                const int delta = ((tr * p.W + ts) * p.Cin) * 2;
-#pragma unroll
-                for (int j = 0; j < PPA; ++j) {
-                    const bool ok = (unsigned)(hi0[j] + tr) < (unsigned)p.H && (unsigned)(wi0[j] + ts) < (unsigned)p.W;
-                    avoff[j] = ok ? (unsigned)(abase[j] + delta) : OOB;
-                }
-            }
-        };
-#pragma unroll
-        for (int s = 0; s < NSTAGE - 1; ++s) issue_chunk(s);
-        int wr = NSTAGE - 1;
-        for (int i = 0; i < my_tiles; ++i) {
-            for (int t = 0; t < p.nchunks; ++t) {
-                asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NSTAGE - 2) * PP) : "memory");
-                issue_chunk(wr);
-                wr = wr + 1 == NSTAGE ? 0 : wr + 1;
-            }
-            asm volatile("s_barrier" ::: "memory");  // E: see the MFMA waves
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing dead pieces have landed
+    if (wave >= NW) {   // ---------------- loader waves (conv_f16.h: shared with the other MFMA shape's translation unit)
+        conv_f16_persist_loader<BM, BN, NW, NL, NSTAGE, ESPARE>(kp0, smemg, wave, lane, bid, G, total, my_tiles, p_ntiles);
         return;
     }
 
     // ---------------- MFMA waves (K loop: tile geometry only; the epilogue reads its arguments per tile)
     const int wm = wave / WN, wn = wave % WN;
-    const int lr = lane & 31, lh = lane >> 5;
-    const int swz = lr * 128 + ((lh ^ ((lr >> 1) & 7)) << 4);  // k-step s adds ^ (s << 5)
     const int a_off = wm * WR * 128;
     const int b_off = BM * 128 + wn * TN * 32 * 128;
     constexpr int NA = WR / 16, NC = 2 * TN, NE = 4;   // accumulator blocks down / across, registers per block
@@ -568,33 +448,10 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, OCC) void conv_f16_persist_ker
     const int swz16 = (lane & 15) * 128 + (((lane >> 4) ^ (((lane & 15) >> 1) & 7)) << 4);   // 16 x 16 x 32 form: 32-deep step s adds ^ (s << 6)
     auto chunk = [&](int rd) {  // run-time stage: branching over compile-time stages made hipcc copy and spill the accumulators
         const char* sb = smemg + rd * STAGEB;
-        if constexpr (MS == 1) {
-            int oa[NA], oa1[NA];
+        int oa[NA], oa1[NA];
 #pragma unroll
-            for (int i = 0; i < NA; ++i) { oa[i] = a_off + swz16 + i * 2048; oa1[i] = a_off + (swz16 ^ 64) + i * 2048; }
-            mfma16_chunk<NA, NC>(acc, sb, oa, oa1, sb, b_off + swz16, b_off + (swz16 ^ 64));
-            return;
-        } else {
-        f16x8 fa[2][TM], fb[2][TN];
-#pragma unroll
-        for (int a = 0; a < TM; ++a) fa[0][a] = *(const f16x8*)(sb + a_off + a * 4096 + swz);
-#pragma unroll
-        for (int b = 0; b < TN; ++b) fb[0][b] = *(const f16x8*)(sb + b_off + b * 4096 + swz);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            if (s < 3) {
-                const int so = swz ^ ((s + 1) << 5);
-#pragma unroll
-                for (int a = 0; a < TM; ++a) fa[(s + 1) & 1][a] = *(const f16x8*)(sb + a_off + a * 4096 + so);
-#pragma unroll
-                for (int b = 0; b < TN; ++b) fb[(s + 1) & 1][b] = *(const f16x8*)(sb + b_off + b * 4096 + so);
-            }
-#pragma unroll
-            for (int a = 0; a < TM; ++a)
-#pragma unroll
-                for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s & 1][a], fb[s & 1][b], acc[a][b], 0, 0, 0);
-        }
-        }
+        for (int i = 0; i < NA; ++i) { oa[i] = a_off + swz16 + i * 2048; oa1[i] = a_off + (swz16 ^ 64) + i * 2048; }
+        mfma16_chunk<NA, NC>(acc, sb, oa, oa1, sb, b_off + swz16, b_off + (swz16 ^ 64));
     };
     int st = 0;
     for (int v = bid; v < total; v += G) {
@@ -734,129 +591,8 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, 1) void conv3x3_f16_strip_kern
     constexpr int NW = WM * WN;
     constexpr int NL = LW > 0 ? LW : NW;            // waves that issue loads (LW > 0: dedicated loader waves, see above)
     static_assert(MS == 1 && (BM / WM) % 16 == 0 && BM % WM == 0, "16 x 16 x 32: a wave owns a whole number of 16-row blocks");
-    constexpr int WR = BM / WM, TM = (WR + 31) / 32, TN = BN / WN / 32;   // rows per wave; (TM: placeholder of the uninstantiated 32 x 32 x 16 branch)
-    constexpr int SR_CAP = BM + 64;                 // strip rows: BM + 2 per image-row segment (<= 32 segments)
-    constexpr int SP = SR_CAP / 8, PB = BN / 8;     // 1-KiB pieces: strip, B chunk
-    constexpr int SP3 = (SP + 2) / 3;               // strip pieces issued per step (a third of the strip)
-    constexpr int RA = (SP3 + NL - 1) / NL, RB = (PB + NL - 1) / NL;  // piece rounds per loading wave and step
-    constexpr int ABYTES = SR_CAP * 128, BBYTES = BN * 128;
-    constexpr int TRACE_OFF = 2 * ABYTES + NB * BBYTES;
-    (void)TRACE_OFF;
-    extern __shared__ __attribute__((aligned(1024))) char smemg[];  // [A strip 0][A strip 1][B 0][B 1]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform, and known to be (scalar address arithmetic)
-    const int wm = wave / WN, wn = wave % WN;
-    const int lw = LW > 0 ? wave - NW : wave;
-    const bool loads = LW == 0 || wave >= NW;
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int q8 = nwg >> 3, r8g = nwg & 7, xcd = bid & 7;
-    const int logical = (xcd < r8g ? xcd * (q8 + 1) : r8g * (q8 + 1) + (xcd - r8g) * q8) + (bid >> 3);
-    const int nt = logical % p.ntiles, mt = logical / p.ntiles;
-    const int m0 = mt * BM, n0 = nt * BN;
-
-    const int W = p.W, H = p.H;
-    const int row0 = m0 / W, wo0 = m0 - row0 * W;       // first image row (flattened n*H + ho) and column of the tile
-    const int len0 = W - wo0;                           // pixels of the first segment (if the tile reaches the row end)
-    const int mlast = m0 + BM - 1;
-    const int nseg = mlast / W - row0 + 1;
-    const int SR = BM + 2 * nseg;                       // strip rows in use (<= SR_CAP, checked by the launcher)
-
-    // ---- loader state: strip pieces this lane fills.  Strip piece index sp = (third t)*SP3 + wave + j*NW, row q = sp*8 + r8.
-    const int r8 = lane >> 3, cs = lane & 7;
-    int a_hi0[3][RA], a_base[3][RA];
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
-#pragma unroll
-        for (int j = 0; j < RA; ++j) {
-            if (!loads) break;
-            const int sp = t * SP3 + lw + j * NL;
-            const int q = sp * 8 + r8;
-            const int c = cs ^ ((q >> 1) & 7);
-            // strip row q -> segment g, position pos inside [left | pixels | right]
-            int g, pos;
-            if (q < len0 + 2) { g = 0; pos = q; }
-            else { const int qq = q - (len0 + 2); g = 1 + qq / (W + 2); pos = qq - (g - 1) * (W + 2); }
-            const int wi = (g == 0 ? wo0 : 0) + pos - 1;
-            const int rid = row0 + g;                   // flattened image row n*H + ho
-            const int n = rid / H, ho = rid - n * H;
-            const bool okw = (unsigned)wi < (unsigned)W && q < SR && n < p.N;
-            a_hi0[t][j] = okw ? ho - 1 : -(1 << 28);
-            a_base[t][j] = (((rid - 1) * W + wi) * p.Cin) * 2 + c * 16;
-        }
-    unsigned bbase[RB];
-#pragma unroll
-    for (int j = 0; j < RB; ++j) {
-        if (!loads) break;
-        const int row = (lw + j * NL) * 8 + r8;
-        const int c = cs ^ ((row >> 1) & 7);
-        bbase[j] = (unsigned)(n0 + row) * (unsigned)(p.wrow * 2) + (unsigned)(c * 16);
-    }
-    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
-    constexpr unsigned OOB = 0x80000000u;
-    const int ngroups = 3 * p.cin_chunks, nsteps = 3 * ngroups;
-
-    // Loader state, all scalar except the per-piece voffsets (see the generic kernel: a vector instruction of ANY wave takes MFMA
-    // issue slots of its SIMD, and an integer division by a run-time value is vector code even on uniform operands):
-    //  * strips: group being issued (s_r, s_kc); a piece's voffset = its row base + r * W * Cin halfs, or out of range where the
-    //    filter row falls off the image -- rebuilt when r changes (three times per tile), cin chunk in the scalar offset;
-    //  * B: step being issued (b_r, b_kc, b_s), chunk offset in the scalar offset; steps / groups past the end issue nothing
-    //    (every step waits on vmcnt(0), so the count need not stay uniform).
-    unsigned avoff[3][RA];
-    auto strip_row = [&](int r) {
-        const int delta = r * W * p.Cin * 2;
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-            for (int j = 0; j < RA; ++j) {
-                const bool ok = (unsigned)(a_hi0[t][j] + r) < (unsigned)H;
-                avoff[t][j] = ok ? (unsigned)(a_base[t][j] + delta) : OOB;
-            }
-    };
-    if (loads) strip_row(0);
-    int s_gi = 0, s_r = 0, s_kc = 0;
-    // a third (t) of the strip of the current group into A buffer `ab`
-    auto issue_strip = [&](int t, int ab) {
-        if (s_gi >= ngroups) return;
-        char* dst = smemg + ab * ABYTES;
-        const unsigned soff = (unsigned)s_kc * 128u;
-#pragma unroll
-        for (int j = 0; j < RA; ++j) {
-            const int spl = lw + j * NL;                 // piece inside the third
-            const int sp = t * SP3 + spl;
-            if (spl >= SP3 || sp >= SP || sp * 8 >= SR) continue;  // wave-uniform
-            const unsigned voff = avoff[t][j];  // (a named operand: hipcc 7.2 silently drops the host stub of the kernel otherwise)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(dst + sp * 1024), 16, voff, soff, 0, CONV_F16_A_AUX);
-        }
-    };
-    auto next_group = [&]() {
-        ++s_gi;
-        if (++s_kc == p.cin_chunks) {  // uniform: next filter row
-            s_kc = 0;
-            ++s_r;
-            int tr = __builtin_amdgcn_readfirstlane(s_r);
-            asm volatile("" : "+s"(tr));  // keeps the row change behind its branch
-            strip_row(tr);
-        }
-    };
-    int b_u = 0, b_r = 0, b_kc = 0, b_s = 0;
-    // the B chunk of the current step (r, kc, s) into B buffer `bb`: packed weights are (r, s, cin) ordered
-    auto issue_b = [&](int bb) {
-        if (b_u >= nsteps) return;
-        const unsigned koff = (unsigned)(((b_r * 3 + b_s) * p.cin_chunks + b_kc) * 128);
-        char* dst = smemg + 2 * ABYTES + bb * BBYTES;   // bb: 0 .. NB - 1
-#pragma unroll
-        for (int j = 0; j < RB; ++j) {
-            if (PB % NL != 0 && lw + j * NL >= PB) continue;
-            const unsigned voff = bbase[j];
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(dst + (lw + j * NL) * 1024), 16, voff, koff, 0, 0);
-        }
-    };
-    auto next_b = [&]() {
-        ++b_u;
-        if (++b_s == 3) { b_s = 0; if (++b_kc == p.cin_chunks) { b_kc = 0; ++b_r; } }
-    };
+    constexpr int WR = BM / WM, TN = BN / WN / 32;   // rows per wave, 32-column units per wave
+#include "conv_f16_strip_state.inc"   // tile geometry, loader state, issue_strip / next_group / issue_b / next_b: shared with the other MFMA shape's translation unit
 
     constexpr int NA = WR / 16, NC = 2 * TN, NE = 4, RBLK = 16;   // accumulator blocks down / across, registers per block, block rows
     typedef f32x4h acc_t[NA][NC];
@@ -898,40 +634,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, 1) void conv3x3_f16_strip_kern
     if (bid == 0) { tr_c0 = __builtin_amdgcn_s_memtime(); tr_r0 = __builtin_amdgcn_s_memrealtime(); }
 #endif
     if (LW > 0) conv_f16_role_prio(wave >= NW);
-    if (LW > 0 && wave >= NW) {  // loader wave: the MFMA waves' barrier sequence, loads only
-        int u = 0;
-        for (int gi = 0; gi < ngroups; ++gi) {
-            if ((p.dbg & 1) && gi >= 2) { b_u = nsteps + 1; s_gi = ngroups; }
-#pragma unroll
-            for (int s = 0; s < 3; ++s, ++u) {
-                if (NB == 3) {
-                    // landed: B(u) (issued two steps ago) and the strip third of the previous step; the B pieces issued last step (B(u + 1)) may still fly.
-                    // Once no B chunk is left to issue (the last two steps) nothing younger covers the older pieces: drain.
-                    if (b_u <= nsteps) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(RB) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-                    issue_strip(s, (gi + 1) & 1);   // first: it has to be down at the NEXT barrier
-                    issue_b(s == 0 ? 2 : s - 1);     // B(u + 2) -> buffer (u + 2) % 3 = (s + 2) % 3 (u = 3 gi + s), which step u - 1 read
-                    next_b();
-                } else {
-                    STRIP_TRACE(u, 0);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    STRIP_TRACE(u, 1);
-                    asm volatile("s_barrier" ::: "memory");
-                    STRIP_TRACE(u, 2);
-                    issue_b((u + 1) & 1);
-                    next_b();
-                    issue_strip(s, (gi + 1) & 1);
-                    STRIP_TRACE(u, 3);
-                }
-            }
-            next_group();
-        }
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-#ifdef ISEGMI_STRIP_TRACE
-        if (bid == 0 && p.trace) for (int i = lane; i < 256; i += 64) p.trace[wave * 256 + i] = *(volatile unsigned*)(smemg + TRACE_OFF + (wave * 256 + i) * 4);
-#endif
-        return;
-    }
+#include "conv_f16_strip_loader_loop.inc"   // loader waves: the barrier sequence of the chunk loop below, loads only (shared text)
     // unrolled over two groups so that both LDS stages are compile-time terms (A buffer = gi & 1, B buffer = (gi + s) & 1, because
     // u = 3 gi + s): fragment addresses are a per-lane base plus an immediate
     for (int g0 = 0; g0 < ngroups; g0 += 2) {
@@ -947,41 +650,17 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, 1) void conv3x3_f16_strip_kern
                 STRIP_TRACE((g0 + gg) * 3 + s, 1);
                 const int ub = NB == 3 ? s : (gg + s) & 1;   // step u = 3 gi + s: u % 3 = s
                 const char* sb = smemg + b_off + ub * BBYTES;
-                if constexpr (MS == 1) {
-                    static_assert(MS == 0 || LW > 0, "the 16 x 16 x 32 form exists with loader waves only");
-                    int oa0[NA], oa1[NA];
+                static_assert(LW > 0, "the 16 x 16 x 32 form exists with loader waves only");
+                int oa0[NA], oa1[NA];
 #pragma unroll
-                    for (int a = 0; a < NA; ++a) { oa0[a] = abase_s[a][s]; oa1[a] = abase_s[a][s] ^ 64; }
-                    mfma16_chunk<NA, NC>(acc, sa, oa0, oa1, sb, swzb, swzb ^ 64);
-                } else {
-                f16x8 fa[2][TM], fb[2][TN];
-#pragma unroll
-                for (int a = 0; a < TM; ++a) fa[0][a] = *(const f16x8*)(sa + abase_s[a][s]);
-#pragma unroll
-                for (int b = 0; b < TN; ++b) fb[0][b] = *(const f16x8*)(sb + b * 4096 + swzb);
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    if (ks < 3) {
-#pragma unroll
-                        for (int a = 0; a < TM; ++a) fa[(ks + 1) & 1][a] = *(const f16x8*)(sa + (abase_s[a][s] ^ ((ks + 1) << 5)));
-#pragma unroll
-                        for (int b = 0; b < TN; ++b) fb[(ks + 1) & 1][b] = *(const f16x8*)(sb + b * 4096 + (swzb ^ ((ks + 1) << 5)));
-                    }
-                    if (LW == 0 && ks == 0) { issue_b(ub ^ 1); next_b(); }
-                    if (LW == 0 && ks == 1) issue_strip(s, gg ^ 1);
-#pragma unroll
-                    for (int a = 0; a < TM; ++a)
-#pragma unroll
-                        for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks & 1][a], fb[ks & 1][b], acc[a][b], 0, 0, 0);
-                }
-                }
+                for (int a = 0; a < NA; ++a) { oa0[a] = abase_s[a][s]; oa1[a] = abase_s[a][s] ^ 64; }
+                mfma16_chunk<NA, NC>(acc, sa, oa0, oa1, sb, swzb, swzb ^ 64);
             }
             if (LW == 0) next_group();
         }
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     STRIP_TRACE(63, 0);
-    (void)TM;
     if constexpr (BM == 192 && BN == 256 && WM == 3 && WN == 4 && NB == 3) {
         if (p.f_w) { conv_f16_epilogue_head(p, acc, smemg, wave, lane, wm, wn, m0); return; }   // uniform
     }

@@ -452,6 +452,12 @@ int maskrcnn_forward(Engine& e, const float* d_images, int N) {
     TRY(eng_buf(e, "box.kept_total", (int64_t)N * 4, &p, 1, {N})); a.d_ws_kept_total = (int*)p;
     TRY(eng_buf(e, "box.top_vals", (int64_t)N * dpi * 4, &p)); a.d_ws_top_vals = (float*)p;
     TRY(eng_buf(e, "box.top_idx", (int64_t)N * dpi * 4, &p, 1)); a.d_ws_top_idx = (int*)p;
+    if ((int)e.param("box_nms_chip_wide", 1)) {   // crowded classes: suppression matrix on the whole chip (rcnn_ops.hip BoxCrowd); 0 = every class in its own block (A/B)
+        TRY(eng_buf(e, "box.crowd_matrix", (int64_t)N * (ncls - 1) * 131072, &p, 1)); a.d_ws_crowd_matrix = p;
+        TRY(eng_buf(e, "box.crowd_keys", (int64_t)N * (ncls - 1) * R * 8, &p, 1)); a.d_ws_crowd_keys = p;
+        TRY(eng_buf(e, "box.crowd_boxes", (int64_t)N * (ncls - 1) * R * 16, &p)); a.d_ws_crowd_boxes = (float*)p;
+        TRY(eng_buf(e, "box.crowd_m", (int64_t)N * (ncls - 1) * 4, &p, 1)); a.d_ws_crowd_m = (int*)p;
+    }
     TRY(eng_buf(e, "det.count", (int64_t)N * 4, &p, 1, {N})); a.d_out_count = (int*)p;
     TRY(eng_buf(e, "det.box", (int64_t)N * cap * 16, &p, 0, {N, cap, 4})); a.d_out_boxes = (float*)p;
     TRY(eng_buf(e, "det.score", (int64_t)N * cap * 4, &p, 0, {N, cap})); a.d_out_scores = (float*)p;
@@ -641,6 +647,12 @@ static int maskrcnn_c4_forward(Engine& e, const float* d_images, int N) {
     TRY(eng_buf(e, "box.kept_total", (int64_t)N * 4, &p, 1, {N})); a.d_ws_kept_total = (int*)p;
     TRY(eng_buf(e, "box.top_vals", (int64_t)N * dpi * 4, &p)); a.d_ws_top_vals = (float*)p;
     TRY(eng_buf(e, "box.top_idx", (int64_t)N * dpi * 4, &p, 1)); a.d_ws_top_idx = (int*)p;
+    if ((int)e.param("box_nms_chip_wide", 1)) {   // crowded classes: suppression matrix on the whole chip (rcnn_ops.hip BoxCrowd); 0 = every class in its own block (A/B)
+        TRY(eng_buf(e, "box.crowd_matrix", (int64_t)N * (ncls - 1) * 131072, &p, 1)); a.d_ws_crowd_matrix = p;
+        TRY(eng_buf(e, "box.crowd_keys", (int64_t)N * (ncls - 1) * R * 8, &p, 1)); a.d_ws_crowd_keys = p;
+        TRY(eng_buf(e, "box.crowd_boxes", (int64_t)N * (ncls - 1) * R * 16, &p)); a.d_ws_crowd_boxes = (float*)p;
+        TRY(eng_buf(e, "box.crowd_m", (int64_t)N * (ncls - 1) * 4, &p, 1)); a.d_ws_crowd_m = (int*)p;
+    }
     TRY(eng_buf(e, "det.count", (int64_t)N * 4, &p, 1, {N})); a.d_out_count = (int*)p;
     TRY(eng_buf(e, "det.box", (int64_t)N * cap * 16, &p, 0, {N, cap, 4})); a.d_out_boxes = (float*)p;
     TRY(eng_buf(e, "det.score", (int64_t)N * cap * 4, &p, 0, {N, cap})); a.d_out_scores = (float*)p;

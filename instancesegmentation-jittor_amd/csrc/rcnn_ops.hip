@@ -865,19 +865,55 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
 // prop_cnt [N].  cand_scores/cand_boxes [N][ncls-1][R] in NMS (score) order, -1 beyond the kept count.
 // 16 waves: a crowded class's suppression matrix is ~60 dependent instructions per IoU test, and a wave alone on its SIMD
 // issues one every ~6 cycles (11 us per 64x64 matrix block); four waves per SIMD fill the issue slots.
+// CROWDED CLASSES ON THE WHOLE CHIP (round 6).  A class with more than 128 candidates needs its suppression matrix: m^2 / 2 exact IoU tests, ~60 dependent
+// instructions each, and inside this kernel ONE block -- one CU -- builds it (m = 1000: 136 wave tasks of 64 x 64 tests over 16 waves, ~85 us; the
+// bench's calibrated random weights put a few classes there, a crowded street scene would too).  With a `BoxCrowd` workspace the class is handed over
+// instead: phase 0 (this kernel) stops after the sort + decode and parks the class's sorted keys and boxes; box_nms_matrix_kernel builds the matrices of
+// all parked classes with one WAVE per 64 x 64 block over the whole chip (the RPN's rpn_nms_matrix_kernel, same predicate); phase 1 (this kernel again)
+// reads a parked class back, runs the bit scan and emits.  Same predicate, same visiting order: the kept lists are those of the single-block path
+// (tests/test_rcnn_ops_gpu.py::test_box_postprocess_matches_oracle runs both).  Uncrowded classes finish in phase 0 as before; for them the two extra
+// launches are empty grids.  Mask R-CNN bs = 1: box_cls_nms 103 us -> phase 0 + matrix + phase 1 (profiles/r06_experiments.txt 3).
+struct BoxCrowd {
+    unsigned long long* matrix;   // [N * nc][NMS_CAP][NMS_CAP / 64]; nullptr: no hand-over (single-block path for every class)
+    unsigned long long* keys;     // [N * nc][R] sorted (score desc, index asc) keys of a parked class
+    float* boxes;                 // [N * nc][R][4] its decoded, clipped boxes in that order
+    int* m;                       // [N * nc] candidates of a parked class, 0 = not parked
+};
 constexpr int BOX_NMS_THREADS = 1024;
 __global__ __launch_bounds__(BOX_NMS_THREADS) void box_cls_nms_kernel(const float* __restrict__ prob, const float* __restrict__ regr,
                                                            int64_t regr_stride, const float* __restrict__ props,
                                                            const int* __restrict__ prop_cnt, const int* __restrict__ image_hw, int R,
                                                            int ncls, float score_thr, float nms_thr, int ge,
                                                            float* __restrict__ cand_scores, float* __restrict__ cand_boxes,
-                                                           int* __restrict__ kept_total) {
+                                                           int* __restrict__ kept_total, const BoxCrowd crowd, const int phase) {
     __shared__ NmsShared S;
     __shared__ unsigned long long keys[NMS_CAP];
     constexpr int NT = BOX_NMS_THREADS, NW = NT / 64;
     __shared__ int wcnt[NW];
     const int j = blockIdx.x + 1, n = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int crow = n * (ncls - 1) + (j - 1);
+    int m = 0, kc = 0;
+    if (phase == 1) {   // a parked class comes back: keys + boxes into LDS, its finished matrix into the dynamic LDS, then the scan
+        m = crowd.m[crow];
+        if (m == 0) return;   // (uniform) finished in phase 0
+        extern __shared__ unsigned long long nms_matrix[];
+        for (int q = tid; q < m; q += NT) {
+            keys[q] = crowd.keys[(int64_t)crow * R + q];
+            S.sb[q] = *(const float4*)(crowd.boxes + ((int64_t)crow * R + q) * 4);
+        }
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4* src = (const u32x4*)(crowd.matrix + (int64_t)crow * NMS_CAP * (NMS_CAP / 64));
+        u32x4* dst = (u32x4*)nms_matrix;
+        for (int q = tid; q < m * (NMS_CAP / 64) / 2; q += NT) dst[q] = src[q];   // rows [0, m): words left of the diagonal are stale workspace the scan never selects
+        __syncthreads();
+        if (wave == 0) {
+            const int k = nms_bit_scan(nms_matrix, m, m, nullptr, S.kept);
+            if (lane == 0) S.kc = k;
+        }
+        __syncthreads();
+        kc = S.kc;
+    } else {
     const int Rn = prop_cnt[n];
     // ordered compaction of candidates (proposal order): wave w owns a contiguous share
     const int seg = ((Rn + NW - 1) / NW + 63) & ~63;
@@ -891,7 +927,6 @@ __global__ __launch_bounds__(BOX_NMS_THREADS) void box_cls_nms_kernel(const floa
     __syncthreads();
     int base = 0;
     for (int w = 0; w < wave; ++w) base += wcnt[w];
-    int m = 0;
     for (int w = 0; w < NW; ++w) m += wcnt[w];
     int run = base;
     for (int i = s0 + lane; (i - lane) < s1; i += 64) {
@@ -917,7 +952,17 @@ __global__ __launch_bounds__(BOX_NMS_THREADS) void box_cls_nms_kernel(const floa
         S.sb[q] = clip_box(decode_box(pr, d, 10.f, 10.f, 5.f, 5.f), im_w, im_h);
     }
     __syncthreads();
-    int kc;
+    if (crowd.matrix != nullptr) {   // (uniform)
+        if (m > 128) {   // park the class for the chip-wide matrix
+            for (int q = tid; q < m; q += NT) {
+                crowd.keys[(int64_t)crow * R + q] = keys[q];
+                *(float4*)(crowd.boxes + ((int64_t)crow * R + q) * 4) = S.sb[q];
+            }
+            if (tid == 0) crowd.m[crow] = m;
+            return;
+        }
+        if (tid == 0) crowd.m[crow] = 0;
+    }
     if (m > 128) {  // crowded class: bitmask NMS (identical kept list), the matrix in this block's dynamic LDS
         extern __shared__ unsigned long long nms_matrix[];
         nms_matrix_block(S.sb, m, nms_thr, nms_one(ge), ge & ISEGMI_NMS_GE, nms_matrix);
@@ -931,6 +976,7 @@ __global__ __launch_bounds__(BOX_NMS_THREADS) void box_cls_nms_kernel(const floa
     } else {
         kc = nms_block(S, m, nms_thr, nms_one(ge), ge & ISEGMI_NMS_GE, 0, nullptr);
     }
+    }   // phase 0
     if (ge & ISEGMI_NMS_INDEX_ORDER) {
         // App. A.6 fork: the CPU NMS hands back the kept boxes in ascending ORIGINAL index (nonzero of the keep mask), so a class's detections come out in
         // proposal order.  slot[i] = sorted position of kept proposal i (0xffff: not kept), then an ordered compaction over the proposal indices
@@ -968,6 +1014,39 @@ __global__ __launch_bounds__(BOX_NMS_THREADS) void box_cls_nms_kernel(const floa
         } else cand_scores[ob + q] = -1.0f;
     }
     if (tid == 0 && kc) atomicAdd(&kept_total[n], kc);
+}
+
+// grid (ceil(136 / 4), N * nc), 256 threads: wave (r, w), r <= w, of a parked class builds the 64 x 64 block of its suppression matrix -- rows 64r.., columns
+// 64w.. -- as rpn_nms_matrix_kernel does for the RPN levels; classes that were not parked leave at once
+__global__ __launch_bounds__(256) void box_nms_matrix_kernel(const BoxCrowd crowd, int R, float nms_thr, int flags) {
+    constexpr int W = NMS_CAP / 64;
+    __shared__ float4 cols[4][64];
+    const int crow = blockIdx.y;
+    const int m = crowd.m[crow];
+    if (m == 0) return;
+    const int nwords = (m + 63) >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pair = blockIdx.x * 4 + wave;  // wave-uniform
+    int w = 0;
+    while ((w + 1) * (w + 2) / 2 <= pair) ++w;
+    const int r = pair - w * (w + 1) / 2;
+    if (w >= nwords) return;  // whole wave; no block-level barrier below
+    const IouThr T = make_iou_thr(nms_thr, flags & ISEGMI_NMS_GE);
+    const float one = nms_one(flags);
+    const float4* sb = (const float4*)(crowd.boxes + (int64_t)crow * R * 4);
+    const int i = (r << 6) + lane, jc = (w << 6) + lane;
+    const float4 mine = sb[i < m ? i : 0];
+    cols[wave][lane] = sb[jc < m ? jc : 0];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's own LDS writes have landed
+    unsigned long long bits = 0ull;
+#pragma unroll 8
+    for (int bb = 0; bb < 64; ++bb) {
+        const int jj = (w << 6) + bb;
+        const bool sup = jj > i && jj < m && iou_exceeds(mine, cols[wave][bb], one, T);
+        bits |= sup ? (1ull << bb) : 0ull;
+    }
+    if (i < m) crowd.matrix[((int64_t)crow * NMS_CAP + i) * W + w] = bits;
 }
 
 // grid (N), block 1024 (16 waves).  Keeps score >= thr (thr = the det_per_img-th largest when more than det_per_img
@@ -1365,9 +1444,22 @@ int box_postprocess_launch(const isegmi_box_post_args* a, hipStream_t st) {
     HIP_TRY(hipMemsetAsync(a->d_ws_kept_total, 0, sizeof(int) * (size_t)a->N, st));
     constexpr int matrix_bytes = NMS_CAP * (NMS_CAP / 64) * 8;  // 128 KB next to 26 KB of static LDS: one block per CU
     LDS_LIMIT_ONCE(matrix_bytes, box_cls_nms_kernel);
-    hipLaunchKernelGGL(box_cls_nms_kernel, dim3(nc, a->N), dim3(BOX_NMS_THREADS), matrix_bytes, st, a->d_ws_prob, a->d_regr, a->regr_stride, a->d_props,
-                       a->d_prop_cnt, a->d_image_hw, a->R, a->ncls, a->score_thresh, a->nms_thresh, a->nms_flags, a->d_ws_cand_scores,
-                       a->d_ws_cand_boxes, a->d_ws_kept_total);
+    BoxCrowd crowd;
+    crowd.matrix = (unsigned long long*)a->d_ws_crowd_matrix; crowd.keys = (unsigned long long*)a->d_ws_crowd_keys;
+    crowd.boxes = a->d_ws_crowd_boxes; crowd.m = a->d_ws_crowd_m;
+    ARG_CHECK((crowd.matrix && crowd.keys && crowd.boxes && crowd.m) || (!crowd.matrix && !crowd.keys && !crowd.boxes && !crowd.m),
+              "box post-processing: the four crowd workspaces come together or not at all");
+    // phase 0 with a hand-over needs the dynamic LDS only for the index-order fork's slot table (2 KB): two blocks share a CU
+    hipLaunchKernelGGL(box_cls_nms_kernel, dim3(nc, a->N), dim3(BOX_NMS_THREADS), crowd.matrix ? 4096 : matrix_bytes, st, a->d_ws_prob, a->d_regr,
+                       a->regr_stride, a->d_props, a->d_prop_cnt, a->d_image_hw, a->R, a->ncls, a->score_thresh, a->nms_thresh, a->nms_flags,
+                       a->d_ws_cand_scores, a->d_ws_cand_boxes, a->d_ws_kept_total, crowd, 0);
+    if (crowd.matrix) {
+        constexpr int W = NMS_CAP / 64, pairs = W * (W + 1) / 2;
+        hipLaunchKernelGGL(box_nms_matrix_kernel, dim3(cdiv(pairs, 4), nc * a->N), dim3(256), 0, st, crowd, a->R, a->nms_thresh, a->nms_flags);
+        hipLaunchKernelGGL(box_cls_nms_kernel, dim3(nc, a->N), dim3(BOX_NMS_THREADS), matrix_bytes, st, a->d_ws_prob, a->d_regr, a->regr_stride,
+                           a->d_props, a->d_prop_cnt, a->d_image_hw, a->R, a->ncls, a->score_thresh, a->nms_thresh, a->nms_flags,
+                           a->d_ws_cand_scores, a->d_ws_cand_boxes, a->d_ws_kept_total, crowd, 1);
+    }
     HIP_TRY(hipGetLastError());
     // the per-class lists are sorted (score order): nothing past a class's first det_per_img entries can make the image's top det_per_img; in index
     // order the lists are not sorted and the general top-k over all nc * R slots finds the kth value

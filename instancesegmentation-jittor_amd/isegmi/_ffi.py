@@ -437,12 +437,14 @@ class BoxPostArgs(C.Structure):
                [("score_thresh", C.c_float), ("nms_thresh", C.c_float), ("logits_stride", C.c_int64), ("regr_stride", C.c_int64)] + \
                [(n, C.c_void_p) for n in ("d_logits", "d_regr", "d_props", "d_prop_cnt", "d_image_hw", "d_ws_prob", "d_ws_cand_scores",
                                           "d_ws_cand_boxes", "d_ws_kept_total", "d_ws_top_vals", "d_ws_top_idx", "d_out_count",
-                                          "d_out_boxes", "d_out_scores", "d_out_labels")]
+                                          "d_out_boxes", "d_out_scores", "d_out_labels", "d_ws_crowd_matrix", "d_ws_crowd_keys",
+                                          "d_ws_crowd_boxes", "d_ws_crowd_m")]
 
 
-def box_postprocess(logits, regr, props, prop_cnt, image_hw, score_thr=0.05, nms_thr=0.5, det_per_img=100, nms_flags=0, cap=0):
+def box_postprocess(logits, regr, props, prop_cnt, image_hw, score_thr=0.05, nms_thr=0.5, det_per_img=100, nms_flags=0, cap=0, chip_wide=True):
     """logits [N,R,ncls], regr [N,R,4*ncls], props [N,R,4] -> list of (boxes, scores, labels).  cap > det_per_img: rows for the detections
-    that tie with the det_per_img-th score (upstream's kth-value rule keeps them)."""
+    that tie with the det_per_img-th score (upstream's kth-value rule keeps them).  chip_wide: hand the op its optional crowd workspaces (classes
+    with more than 128 candidates get their suppression matrix from the whole chip: three launches); False = every class in its own block."""
     logits = np.ascontiguousarray(logits, np.float32)
     N, R, ncls = logits.shape
     cap = max(det_per_img, cap)
@@ -455,7 +457,10 @@ def box_postprocess(logits, regr, props, prop_cnt, image_hw, score_thr=0.05, nms
              d_ws_top_vals=DeviceBuffer((N, det_per_img)), d_ws_top_idx=DeviceBuffer((N, det_per_img), np.int32),
              d_out_count=DeviceBuffer((N,), np.int32), d_out_boxes=DeviceBuffer((N, cap, 4)), d_out_scores=DeviceBuffer((N, cap)),
              d_out_labels=DeviceBuffer((N, cap), np.int32))
-    a = BoxPostArgs(N, R, ncls, det_per_img, cap, nms_flags, score_thr, nms_thr, ncls, 4 * ncls, *[b[n].ptr for n, _ in BoxPostArgs._fields_[10:]])
+    if chip_wide:   # dirty on purpose: nothing may be read before it is written
+        b.update(d_ws_crowd_matrix=DeviceBuffer.from_numpy(np.full((N, ncls - 1, 131072), 0xa5, np.uint8)), d_ws_crowd_keys=DeviceBuffer((N, ncls - 1, R), np.int64),
+                 d_ws_crowd_boxes=DeviceBuffer((N, ncls - 1, R, 4)), d_ws_crowd_m=DeviceBuffer.from_numpy(np.full((N, ncls - 1), 777, np.int32)))
+    a = BoxPostArgs(N, R, ncls, det_per_img, cap, nms_flags, score_thr, nms_thr, ncls, 4 * ncls, *[b[n].ptr if n in b else None for n, _ in BoxPostArgs._fields_[10:]])
     check(lib().isegmi_op_box_postprocess(C.byref(a), None))
     cnt = b["d_out_count"].numpy(); B = b["d_out_boxes"].numpy(); S = b["d_out_scores"].numpy(); Lb = b["d_out_labels"].numpy()
     return [(B[i, : cnt[i]], S[i, : cnt[i]], Lb[i, : cnt[i]]) for i in range(N)]

@@ -117,8 +117,9 @@ def test_box_postprocess_forks_on_a_crafted_input(ffi):
         assert np.array_equal(gb, props[0][c5 + c9]) and list(gl) == [5] * len(c5) + [9] * len(c9), (flags, gb, gl)
 
 
+@pytest.mark.parametrize("chip_wide", [True, False])
 @pytest.mark.parametrize("flags", range(8))
-def test_box_postprocess_forks_match_oracle(ffi, flags):
+def test_box_postprocess_forks_match_oracle(ffi, flags, chip_wide):
     """1000 proposals, crowded classes (the in-block bitmask NMS), the kth-value cut to 100 and ragged counts under every combination of the forks"""
     rng = np.random.default_rng(9)
     N, R, ncls = 2, 1000, 81
@@ -131,7 +132,7 @@ def test_box_postprocess_forks_match_oracle(ffi, flags):
     cnt = np.array([R, 613], np.int32)
     hw = np.array([[800, 1333], [750, 1200]], np.int32)
     for lg, rg in ((logits, regr), (logits + np.where(np.arange(ncls) == 7, 1.5, 0).astype(np.float32), regr * 0.05)):
-        got = ffi.box_postprocess(lg, rg, props, cnt, hw, nms_flags=flags, cap=128)
+        got = ffi.box_postprocess(lg, rg, props, cnt, hw, nms_flags=flags, cap=128, chip_wide=chip_wide)
         for n in range(N):
             k = cnt[n]
             rb, rs, rl = ora.box_postprocess(lg[n, :k], rg[n, :k], props[n, :k], float(hw[n, 1]), float(hw[n, 0]), nms_flags=flags, cap=128)

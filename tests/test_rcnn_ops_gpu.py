@@ -367,7 +367,11 @@ def test_rpn_single_map_6000_matches_oracle(ffi):
             assert len(rs) > 100
 
 
-def test_box_postprocess_matches_oracle(ffi):
+@pytest.mark.parametrize("chip_wide", [True, False])
+def test_box_postprocess_matches_oracle(ffi, chip_wide):
+    """chip_wide: classes with more than 128 candidates handed to the chip-wide suppression matrix (three launches) or kept in their own block"""
+    import functools
+    ffi_box = functools.partial(ffi.box_postprocess, chip_wide=chip_wide)
     rng = np.random.default_rng(9)
     N, R, ncls = 2, 1000, 81
     logits = rng.normal(0, 1.0, (N, R, ncls)).astype(np.float32)
@@ -377,7 +381,7 @@ def test_box_postprocess_matches_oracle(ffi):
     props = np.stack([_boxes(rng, R) for _ in range(N)])
     cnt = np.array([R, 613], np.int32)
     hw = np.array([[800, 1333], [750, 1200]], np.int32)
-    got = ffi.box_postprocess(logits, regr, props, cnt, hw)
+    got = ffi_box(logits, regr, props, cnt, hw)
     for n in range(N):
         k = cnt[n]
         rb, rs, rl = ora.box_postprocess(logits[n, :k], regr[n, :k], props[n, :k], float(hw[n, 1]), float(hw[n, 0]), cap=100)
@@ -387,7 +391,7 @@ def test_box_postprocess_matches_oracle(ffi):
     props3 = props.copy()
     props3[:, 200:] = props3[:, :800] + rng.normal(0, 1.5, (N, 800, 4)).astype(np.float32)
     logits3 = logits.copy(); logits3[..., [7, 31]] += 1.5
-    got = ffi.box_postprocess(logits3, regr * 0.05, props3, cnt, hw)
+    got = ffi_box(logits3, regr * 0.05, props3, cnt, hw)
     for n in range(N):
         k = cnt[n]
         rb, rs, rl = ora.box_postprocess(logits3[n, :k], regr[n, :k] * 0.05, props3[n, :k], float(hw[n, 1]), float(hw[n, 0]), cap=100)
@@ -402,14 +406,14 @@ def test_box_postprocess_matches_oracle(ffi):
     regt = np.zeros((1, Rt, 4 * ncls), np.float32)
     cntt, hwt = np.array([Rt], np.int32), np.array([[800, 1333]], np.int32)
     for cap, want in ((100, 100), (128, 128), (256, 210)):
-        (gb, gs, gl), = ffi.box_postprocess(logt, regt, propt, cntt, hwt, cap=cap)
+        (gb, gs, gl), = ffi_box(logt, regt, propt, cntt, hwt, cap=cap)
         rb, rs, rl = ora.box_postprocess(logt[0], regt[0], propt[0], 1333.0, 800.0, cap=cap)
         assert len(rs) == want == len(gs), (cap, len(rs), len(gs))
         assert np.array_equal(gl, rl) and np.array_equal(gs, rs) and np.array_equal(gb, rb)
     assert (gl == 5).sum() == 60 and (gl == 9).sum() == 150 and len(np.unique(gs[gl == 9])) == 1
     # fewer than det_per_img survivors: everything kept, order preserved
     logits2 = logits.copy(); logits2[..., 0] += 6.0
-    got = ffi.box_postprocess(logits2, regr, props, cnt, hw)
+    got = ffi_box(logits2, regr, props, cnt, hw)
     for n in range(N):
         k = cnt[n]
         rb, rs, rl = ora.box_postprocess(logits2[n, :k], regr[n, :k], props[n, :k], float(hw[n, 1]), float(hw[n, 0]), cap=100)
