@@ -546,6 +546,12 @@ def bench_yolact(a, dist):
         out["bs1"]["roofline"] = {"bound": "mfma", "achieved": round(f1 / (m1 * 1e-3) / 1e12, 2) if m1 > 0 else 0.0, "peak": ypeak, "unit": "TFLOP/s",
                                   "frac": round(f1 / (m1 * 1e-3) / 1e12 / ypeak, 4) if m1 > 0 else 0.0, "conv_ms_per_image": round(m1 / 10, 3),
                                   "pass": "10 single-stream bs=1 steps, HIP events around every conv launch"}
+        if not a.fp16:   # the opt-in latency numerics mode (fixed-tree split-K on the backbone's small-M / large-K layers): same pass, reported NEXT TO the default
+            net.set_param("conv_split_k", 1.0)
+            sk = latency_pass(net, lambda: (net.forward_device(1), net.postprocess_device(size, size)))
+            net.set_param("conv_split_k", 0.0)
+            out["bs1"]["conv_split_k"] = dict(sk, note="engine parameter conv_split_k = 1 (default 0): another fp32 association of the same sums, bit-exact against the "
+                                                       "oracle run in the same mode (tests/test_split_k_gpu.py); bs1.p50_ms_per_image above is the DEFAULT numerics")
         net.set_param("timing", 1.0)
         net.forward_device(a.batch); net.postprocess_device(size, size); net.sync()
         out["stage_ms_bs%d" % a.batch] = {k: round(v, 3) for k, v in net.timings()}
@@ -761,6 +767,11 @@ def bench_maskrcnn(a, dist, summary=None):
         out["bs1"]["roofline"] = {"bound": "mfma", "achieved": round(f1 / (m1 * 1e-3) / 1e12, 2) if m1 > 0 else 0.0, "peak": peak, "unit": "TFLOP/s",
                                   "frac": round(f1 / (m1 * 1e-3) / 1e12 / peak, 4) if m1 > 0 else 0.0, "conv_ms_per_image": round(m1 / 10, 3),
                                   "pass": "10 single-stream bs=1 steps, HIP events around every conv launch"}
+        if not model.fp16:
+            model.set_param("conv_split_k", 1.0)
+            sk = latency_pass(model, lambda: (model.forward_device(1), model.paste_device(800, 1333)), iters=11, drop=3)
+            model.set_param("conv_split_k", 0.0)
+            out["bs1"]["conv_split_k"] = dict(sk, note="engine parameter conv_split_k = 1 (default 0): see the Yolact block")
         model.upload(x, hw)
         if not summary:
             model.set_param("timing", 1.0)

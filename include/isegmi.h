@@ -62,6 +62,9 @@ typedef struct isegmi_conv_desc {
     int32_t tile;                    /* 0 auto; fp32: 1: 128x128  2: 128x64  3: 64x64 (round-1 schedule; the stem)  4: 32x32 on 16x16x4 MFMA  5: 32x32 with four loader waves, software-pipelined  6: 32x64, two 16x16 tiles per wave (block tile MxN)
                                         10 / 12: 64x64, v2 schedule, loads 2 / 4 chunks ahead (the default for large grids)  7 / 9: the same with the early LDS store (measured slower; kept for A/B)
                                         13 / 14: hybrid launch -- v2 tiles (loads 2 / 4 ahead) on the rows that fill the CUs a whole number of times, 32x32 blocks on the left-over rows (the default for 513-2600-tile grids with a small left-over);
+                                        15 (fp32, NEVER chosen by tile 0): FIXED-TREE SPLIT-K -- a 32x32 block whose K chunks are cut over four sets of waves, out = ((p0 + p1) + p2) + p3 of four
+                                        k-ordered partial chains over the chunk ranges [q L, (q + 1) L), L = ceil(K / 32 / 4): an opt-in numerics mode (bit-exact against the oracle's
+                                        ora_conv2d_split, NOT against isegmi_op_conv2d's other tiles) for the small-M, large-K layers of a bs = 1 forward; the engines' `conv_split_k`;
                                         fp16: 1: 256x256  2: 256x128  3: 128x128  4: 64x64  5: 64x128  6: 64x256  7: 128x256  8: 128x64  9: 192x256  10: 192x128  11: 160x256;
                                         12/13/14/16: 192x256, 256x256, 256x128, 160x256 with 4 loader waves, 17: 192x256 as 12 MFMA + 4 loader waves, 19: 128x256 + 4, 20: 192x128 as 6 + 2;
                                         26/27/28/29: row-strip kernel for 3x3/1/1 (192x256, 256x128, 160x256, 192x256 on 12 MFMA waves) with 4 loader waves; 30/31: 29/26 with three B chunk buffers;
@@ -73,6 +76,9 @@ typedef struct isegmi_conv_desc {
 } isegmi_conv_desc;
 
 int isegmi_conv_out_hw(const isegmi_conv_desc* d, int32_t* Ho, int32_t* Wo);
+/* 1 when the split-K mode's shape rule takes this fp32 layer (at most 176 tiles of 64 x 64 and K >= 1024; not the stem), else 0.  The engines apply it, under
+ * `conv_split_k`, to the bottleneck convolutions of the backbone except a stage's first conv1 / projection; the oracle models mirror it (oracle/ora.py). */
+int isegmi_conv_split_qualifies(const isegmi_conv_desc* d);
 /* number of floats of the packed weight image */
 int isegmi_conv_packed_floats(const isegmi_conv_desc* d, int64_t* n);
 /* host: natural [Cout][R][S][Cin] -> packed image consumed by isegmi_op_conv2d */

@@ -552,13 +552,26 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef EXPERIMENT_MODE  // bit 0: no per-chunk barrier, bit 1: no LDS stores (plain 16x16x4 loop)
 #define EXPERIMENT_MODE 0
 #endif
-template <int RING, bool LW, int WN = 1>
+// KS > 1 (round 6, tile 15: FIXED-TREE SPLIT-K, an opt-in numerics mode -- see conv2d_launch): the block is KS sets of 256 threads; set q walks the K
+// chunks [q L, (q + 1) L), L = ceil(nchunks / KS), of the kernel's ordinary K order as its own k-ordered chain from +0 -- every set runs the plain
+// variant's loop on its own LDS stages -- and set 0 adds the partial sums in the fixed order ((p0 + p1) + p2) + p3 before the epilogue.  A 16 x 16 output
+// tile is then FOUR dependent MFMA chains of a quarter of the length on the four waves a SIMD holds, instead of one chain on one wave with the other
+// three slots empty: what a small-M layer at bs = 1 lacks is independent work, not CUs.  The oracle restates exactly this sum (ora_conv2d_split).
+template <int RING, bool LW, int WN = 1, int KS = 1>
 __device__ __forceinline__ void conv_mfma16_body(const ConvK& p, float* smem16, const int bid, const int nwg) {
     static_assert(WN == 1 || !LW, "the loader-wave variant runs one tile per wave");
+    static_assert(KS == 1 || (!LW && WN == 1), "split-K runs KS plain 32 x 32 sets");
     constexpr int BM = 32, BN = 32 * WN;
     constexpr int ROW = 34;  // floats; pitch = 2 mod 32: bank = 2*row + k for the fragment reads
     constexpr int STAGE = (BM + BN) * ROW;
     constexpr int NST = LW ? 3 : 2;  // LDS stages (LW: chunk t computed while t+1 is read into registers and t+2 written)
+    float* const smem_block = smem16;
+    const int kset = KS > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;   // wave-uniform
+    if (KS > 1) smem16 += kset * NST * STAGE;
+    // this set's chunks [c_begin, c_end); every set runs `count` iterations (the block's barriers are shared): chunks past c_end are dead (zeros)
+    const int count = KS > 1 ? (p.nchunks + KS - 1) / KS : p.nchunks;
+    const int c_begin = KS > 1 ? min(kset * count, p.nchunks) : 0;
+    const int c_end = KS > 1 ? min(c_begin + count, p.nchunks) : p.nchunks;
 
     const int tid = threadIdx.x & 255;
     const bool loader = LW && __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) != 0;  // wave-uniform, and known to be
@@ -608,18 +621,27 @@ __device__ __forceinline__ void conv_mfma16_body(const ConvK& p, float* smem16, 
     const u32x4 rs_in = make_rsrc(p.in, p.in_bytes), rs_w = make_rsrc(p.w, p.w_bytes);
     const u32x4 rs_null = u32x4{rs_in.x, rs_in.y, 0u, rs_in.w};
     u32x4 ra[RING], rb[RING][WN];
-    int kr = 0, ks = 0, kc = 0, kg = 0, glen = p.kgroup, chunk = 0;  // position of the next chunk to load (they are loaded strictly in order)
+    int kr = 0, ks = 0, kc = 0, kg = 0, glen = p.kgroup, chunk = c_begin;  // position of the next chunk to load (they are loaded strictly in order)
+    if (KS > 1 && c_begin > 0) {   // the K position of chunk c_begin: channel group, tap, chunk inside the group (scalar; once per block)
+        int rem = c_begin;
+        glen = min(p.kgroup, p.cin_chunks);
+        while (rem >= p.R * p.S * glen && kg + glen < p.cin_chunks) { rem -= p.R * p.S * glen; kg += glen; glen = min(p.kgroup, p.cin_chunks - kg); }
+        const int tap = rem / glen;
+        kc = rem - tap * glen;
+        kr = tap / p.S;
+        ks = tap - kr * p.S;
+    }
     // Per-chunk vector work is ZERO instructions (see conv_mfma_v2_kernel: every VALU instruction costs matrix-pipe cycles): the
     // lane's voffset = pixel base + tap offset, or the out-of-range constant for a padding tap / a row past M, is rebuilt only
     // when the tap changes (a scalar branch); the cin chunk inside the tap and B's chunk offset ride in the scalar offset
     // operand (not part of the range check, and it never leaves the pixel's Cin floats); past-the-end chunks swap in a
     // zero-length descriptor (scalar selects).
     const bool taps = p.R * p.S > 1 || p.pad > 0;
-    const bool ok0 = taps ? ((unsigned)hi0 < (unsigned)p.H && (unsigned)wi0 < (unsigned)p.W) : hi0 >= 0;
-    unsigned avoff = ok0 ? abase : OOB;
-    unsigned soffa = 0;
+    const bool ok0 = taps ? ((unsigned)(hi0 + kr) < (unsigned)p.H && (unsigned)(wi0 + ks) < (unsigned)p.W) : hi0 >= 0;   // (kr = ks = 0 unless a split set starts mid-K)
+    unsigned avoff = ok0 ? abase + (unsigned)((kr * p.W + ks) * p.Cin) * 4u : OOB;
+    unsigned soffa = (unsigned)(kg + kc) * 128u;
     auto load_chunk = [&](int slot) {
-        const bool live = chunk < p.nchunks && !EXPERIMENT_NO_LOADS;
+        const bool live = chunk < c_end && !EXPERIMENT_NO_LOADS;
         const u32x4 rsa = live ? rs_in : rs_null, rsb = live ? rs_w : rs_null;
         const unsigned soffb = (unsigned)((kr * p.S + ks) * p.cin_chunks + kg + kc) * 128u;
         asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(ra[slot]) : "v"(avoff), "s"(rsa), "s"(soffa) : "memory");
@@ -699,10 +721,10 @@ __device__ __forceinline__ void conv_mfma16_body(const ConvK& p, float* smem16, 
         for (int i = 0; i < RING; ++i) load_chunk(i);
         store_chunk(0, 0, Steady());
         __syncthreads();
-        for (int t0 = 0; t0 < p.nchunks; t0 += RING) {
+        for (int t0 = 0; t0 < count; t0 += RING) {
 #pragma unroll
             for (int j = 0; j < RING; ++j) {
-                if (t0 + j >= p.nchunks) break;  // uniform
+                if (t0 + j >= count) break;  // uniform
                 const int cur = j & 1;  // compile-time (t0 is a multiple of the even ring depth): LDS addresses are immediates
                 load_chunk(j);
                 __builtin_amdgcn_sched_barrier(0);
@@ -768,6 +790,18 @@ __device__ __forceinline__ void conv_mfma16_body(const ConvK& p, float* smem16, 
                 if (!(EXPERIMENT_MODE & 4)) __syncthreads();
                 st1 = st1 == NST - 1 ? 0 : st1 + 1;
             }
+        }
+    }
+
+    if (KS > 1) {   // ((p0 + p1) + p2) + ...: sets 1.. park their partial tile in LDS (every stage is free: the loop ended on a barrier), set 0 adds them in order
+        float* red = smem_block + (kset > 0 ? (kset - 1) * 1024 : 0) + tid * 4;
+        if (kset > 0) *(f32x4*)red = acc[0];
+        __syncthreads();
+        if (kset > 0) return;
+#pragma unroll
+        for (int q = 1; q < KS; ++q) {
+            const f32x4 v = *(const f32x4*)(smem_block + (q - 1) * 1024 + tid * 4);
+            acc[0][0] = acc[0][0] + v[0]; acc[0][1] = acc[0][1] + v[1]; acc[0][2] = acc[0][2] + v[2]; acc[0][3] = acc[0][3] + v[3];
         }
     }
 
@@ -852,6 +886,13 @@ __global__ __launch_bounds__(LW ? 512 : 256) void conv_mfma16_kernel(const ConvK
     conv_mfma16_body<RING, LW, WN>(p, smem16, (int)blockIdx.x, (int)gridDim.x);
 }
 
+// tile 15: the 32 x 32 block with its K range cut over KS sets of four waves (fixed-tree split-K, see conv_mfma16_body)
+template <int KS>
+__global__ __launch_bounds__(256 * KS) void conv_mfma16_split_kernel(const ConvK p) {
+    extern __shared__ __attribute__((aligned(16))) float smem_split[];   // KS x 2 stages x (32 + 32) rows x 34 floats
+    conv_mfma16_body<4, false, 1, KS>(p, smem_split, (int)blockIdx.x, (int)gridDim.x);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // HYBRID launch (tiles 13 / 14 = v2 with loads 2 / 4 chunks ahead): a grid of 64x64 tiles that does not divide over the 256 CUs
 // (528 tiles: two per CU and sixteen left over; 1050: four per CU and 26 left over) loses up to a third of a layer to the CUs
@@ -904,7 +945,7 @@ static int check_desc(const isegmi_conv_desc* d) {
     ARG_CHECK(is_stem(d) || (d->Cin > 0 && d->Cin % 32 == 0), "Cin must be a multiple of 32 (or the Cin=4 7x7 stem)");
     ARG_CHECK(d->H + 2 * d->pad >= d->R && d->W + 2 * d->pad >= d->S, "kernel larger than padded input");
     ARG_CHECK(d->act >= 0 && d->act <= 4, "act");
-    ARG_CHECK(d->tile >= 0 && d->tile <= 14, "tile");
+    ARG_CHECK(d->tile >= 0 && d->tile <= 15, "tile");
     return ISEGMI_OK;
 }
 
@@ -1082,6 +1123,22 @@ int conv2d_launch(const isegmi_conv_desc* d, const float* in, const float* w, co
             return ISEGMI_OK;
         }
     }
+    if (tile == 15) {
+        // FIXED-TREE SPLIT-K (round 6).  NOT the default numerics: the output is ((p0 + p1) + p2) + p3 of four k-ordered partial chains over
+        // the chunk ranges [q L, (q + 1) L), L = ceil(nchunks / 4), instead of ONE chain -- another valid fp32 evaluation of the same sum, restated by the
+        // oracle as ora_conv2d_split(..., 4) and bit-exact against it.  The engines take it only under `conv_split_k` (default 0) and only for the backbone
+        // layers the oracle models split by the same rule (isegmi_conv_split_qualifies); bs = 8 / bs = 2 numerics and every default-mode test are untouched.
+        ARG_CHECK(!is_stem(d), "split-K: not for the stem");
+        constexpr int KS = 4;
+        k.mtiles = cdiv(k.M, 32);
+        k.ntiles = cdiv(d->Cout, 32);
+        conv_set_band(k, 32, 1, k.in_touched);
+        const size_t lds = (size_t)KS * 2 * (32 + 32) * 34 * sizeof(float);
+        LDS_LIMIT_ONCE((int)lds, conv_mfma16_split_kernel<KS>);
+        hipLaunchKernelGGL((conv_mfma16_split_kernel<KS>), dim3((unsigned)(k.mtiles * k.ntiles)), dim3(256 * KS), lds, st, k);
+        HIP_TRY(hipGetLastError());
+        return ISEGMI_OK;
+    }
     if (tile >= 7) {
         ARG_CHECK(tile != 8 && tile != 11, "tiles 8 / 11 (ring of 3) were dropped: the LDS stage of an unrolled position is its parity");
         k.mtiles = cdiv(k.M, 64);
@@ -1180,6 +1237,16 @@ extern "C" int isegmi_op_conv2d_group(int n, const isegmi_conv_desc* descs, cons
     const isegmi_conv_desc* dp[CONV_GROUP_MAX];
     for (int i = 0; i < n; ++i) dp[i] = descs + i;
     return conv2d_group_launch(n, dp, d_in, d_w, d_scale, d_shift, d_res, d_out, (hipStream_t)stream);
+}
+
+// the shape rule of the split-K mode (mirrored by oracle/ora.py conv_split_qualifies): a layer of at most 176 tiles of 64 x 64 -- the grids the 16 x 16 x 4
+// kernels run at about one block per CU -- with at least 32 K chunks (K >= 1024)
+extern "C" int isegmi_conv_split_qualifies(const isegmi_conv_desc* d) {
+    if (!d || check_desc(d) != ISEGMI_OK || is_stem(d)) return 0;
+    const int Ho = (d->H + 2 * d->pad - d->R) / d->stride + 1, Wo = (d->W + 2 * d->pad - d->S) / d->stride + 1;
+    const int64_t M = (int64_t)d->N * Ho * Wo;
+    const int64_t t64 = ((M + 63) / 64) * ((d->Cout + 63) / 64);
+    return t64 <= 176 && n_chunks(d) >= 32 ? 1 : 0;
 }
 
 extern "C" int isegmi_conv_out_hw(const isegmi_conv_desc* d, int32_t* Ho, int32_t* Wo) {

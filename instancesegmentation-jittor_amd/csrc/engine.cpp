@@ -91,7 +91,7 @@ int eng_conv_into(Engine& e, const std::string& layer, const Tensor& in, int str
 }
 
 int eng_conv(Engine& e, const std::string& layer, const Tensor& in, int stride, int pad, int act, const Tensor* residual,
-             const std::string& out_name, Tensor* out, bool out_f32) {
+             const std::string& out_name, Tensor* out, bool out_f32, bool may_split) {
     const ConvLayer* L;
     int rc = find_conv(e, layer, &L);
     if (rc) return rc;
@@ -105,6 +105,10 @@ int eng_conv(Engine& e, const std::string& layer, const Tensor& in, int stride, 
     memset(&d, 0, sizeof(d));
     d.N = in.N; d.H = in.H; d.W = in.W; d.Cin = in.C; d.Cout = L->Cout; d.R = L->R; d.S = L->S; d.stride = stride; d.pad = pad;
     d.act = act; d.tile = (int)e.param("conv_tile", 0);
+    // `conv_split_k` (default 0): the fixed-tree split-K evaluation (conv tile 15) for the backbone's bottleneck convolutions the caller
+    // marks -- every conv2 / conv3 and the conv1 of a stage's later blocks -- where the shape rule takes them (small M, K >= 1024: a bs = 1 forward).  An
+    // OPT-IN NUMERICS MODE: results are bit-exact against the oracle models run with conv_split_k (the same layers, the same rule), not against the default.
+    if (may_split && !L->f16 && d.tile == 0 && (int)e.param("conv_split_k", 0) != 0 && isegmi_conv_split_qualifies(&d)) d.tile = 15;
     return timed_conv(e, layer, &d, in.d, L, residual ? residual->d : nullptr, out->d, out_f32);
 }
 
@@ -643,7 +647,7 @@ int yolact_forward(Engine& e, const float* d_images, int N) {
                 SideScope sc(e, 0);
                 TRY(eng_conv(e, nm + ".downsample.0", x, st, 0, 0, nullptr, nm + ".ds", &idt));
             }
-            TRY(eng_conv(e, nm + ".conv1", x, 1, 0, 1, nullptr, sg + ".t1", &t1));
+            TRY(eng_conv(e, nm + ".conv1", x, 1, 0, 1, nullptr, sg + ".t1", &t1, false, /*may_split=*/b > 0));
             }
             if (e.convs.count(nm + ".conv2.conv_offset_mask")) {
                 // DCNv2 3x3 (YOLACT++ backbones): offsets + mask logits from a plain 3x3 -> the nine taps sampled into columns ->
@@ -655,13 +659,13 @@ int yolact_forward(Engine& e, const float* d_images, int N) {
                 TRY(deform_im2col_launch((const float*)t1.d, N, t1.H, t1.W, t1.C, (const float*)om.d, 3, 3, st, 1, 1, (float*)col.d, e.cur));
                 TRY(eng_conv(e, nm + ".conv2", col, 1, 0, 1, nullptr, sg + ".t2", &t2));
             } else {
-                TRY(eng_conv(e, nm + ".conv2", t1, st, 1, 1, nullptr, sg + ".t2", &t2));
+                TRY(eng_conv(e, nm + ".conv2", t1, st, 1, 1, nullptr, sg + ".t2", &t2, false, /*may_split=*/true));
             }
             if (b == 0 && !pair) TRY(eng_join(e, 0));
             // C3 (then C4, C5) is about to be overwritten: the previous step's lateral convs, running on the heads streams, must
             // have read them (they are the first thing of that phase, so this wait practically never blocks)
             if (li == 1 && b == blocks[1] - 1 && e.lat_pending) HIP_TRY(hipStreamWaitEvent(e.stream, e.lat_done, 0));
-            TRY(eng_conv(e, nm + ".conv3", t2, 1, 0, 1, &idt, out_name, &y));
+            TRY(eng_conv(e, nm + ".conv3", t2, 1, 0, 1, &idt, out_name, &y, false, /*may_split=*/true));
             x = y;
         }
         outs[li] = x;

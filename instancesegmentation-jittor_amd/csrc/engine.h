@@ -133,7 +133,7 @@ int eng_buf(Engine& e, const std::string& name, int64_t bytes, void** out, int d
             std::vector<int64_t> shape = {});
 int eng_act(Engine& e, const std::string& name, int N, int H, int W, int C, Tensor* t, int dt = 0);
 int eng_conv(Engine& e, const std::string& layer, const Tensor& in, int stride, int pad, int act, const Tensor* residual,
-             const std::string& out_name, Tensor* out, bool out_f32 = false);
+             const std::string& out_name, Tensor* out, bool out_f32 = false, bool may_split = false);
 // conv writing into a caller-provided strided destination (heads -> concatenated buffers, deconv parities)
 int eng_graph_run(Engine& e, const std::string& key, const std::function<int()>& body);
 void eng_graph_reset(Engine& e);

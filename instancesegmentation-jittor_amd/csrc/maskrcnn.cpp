@@ -165,11 +165,11 @@ int maskrcnn_forward(Engine& e, const float* d_images, int N) {
                     SideScope sc(e, 0);
                     TRY(eng_conv(e, nm + ".downsample.0", x, sd, 0, 0, nullptr, nm + ".ds", &idt));
                 }
-                TRY(eng_conv(e, nm + ".conv1", x, sd, 0, 1, nullptr, sg + ".t1", &t1));  // STRIDE_IN_1X1
+                TRY(eng_conv(e, nm + ".conv1", x, sd, 0, 1, nullptr, sg + ".t1", &t1, false, /*may_split=*/b > 0));  // STRIDE_IN_1X1
                 }
-                TRY(eng_conv(e, nm + ".conv2", t1, 1, 1, 1, nullptr, sg + ".t2", &t2));
+                TRY(eng_conv(e, nm + ".conv2", t1, 1, 1, 1, nullptr, sg + ".t2", &t2, false, /*may_split=*/true));   // (`conv_split_k`: see eng_conv)
                 if (b == 0 && !pair) TRY(eng_join(e, 0));
-                TRY(eng_conv(e, nm + ".conv3", t2, 1, 0, 1, &idt, out_name, &y));
+                TRY(eng_conv(e, nm + ".conv3", t2, 1, 0, 1, &idt, out_name, &y, false, /*may_split=*/true));
             }
             x = y;
         }

@@ -45,6 +45,10 @@ class MaskRCNNConfig:
     NMS_OUTPUT_ORDER: str = "score"   # order of a class's detections after the box NMS: "score" (CUDA kernel) or "index" (CPU: nonzero(keep), proposal order)
     ROI_ALIGNED: int = 0        # 0 legacy ROIAlign (no half-pixel shift, RoI >= 1 pixel), 1 ROIAlign(aligned=True)
     FROZEN_BN_EPS: float = 0.0  # FrozenBatchNorm2d: scale = w * rsqrt(var + eps); maskrcnn-benchmark has no eps
+    # Opt-in NUMERICS MODE for latency (not a semantic fork: the same sums in another fp32 association): the backbone's small-M / large-K bottleneck
+    # convolutions (a bs = 1 forward) as four k-ordered partial chains added left to right -- conv tile 15, include/isegmi.h; bit-exact against the oracle
+    # model run with conv_split_k=1, NOT against the default mode; results then depend on the batch size a layer is run at (the rule is by shape)
+    CONV_SPLIT_K: int = 0
     CONV_BODY: str = "R-50-FPN"  # "R-50-FPN" / "R-101-FPN" (depth) or "R-50-C4" (the yaml README.md:263-273 prints)
 
     @staticmethod
@@ -213,7 +217,7 @@ class MaskRCNN:
                      ("rpn_nms_thresh", cfg.RPN_NMS_THRESH), ("rpn_min_size", cfg.RPN_MIN_SIZE), ("roi_score_thresh", cfg.ROI_SCORE_THRESH),
                      ("roi_nms_thresh", cfg.ROI_NMS), ("detections_per_img", cfg.DETECTIONS_PER_IMG), ("detections_cap", cfg.DETECTIONS_CAP),
                      ("nms_ge", cfg.NMS_GE), ("nms_plus_one", cfg.NMS_PLUS_ONE), ("nms_index_order", {"score": 0, "index": 1}[cfg.NMS_OUTPUT_ORDER]),
-                     ("roi_aligned", cfg.ROI_ALIGNED)):
+                     ("roi_aligned", cfg.ROI_ALIGNED), ("conv_split_k", cfg.CONV_SPLIT_K)):
             self.set_param(k, float(v))
         self._d_in = _ffi.DeviceBuffer((max_batch, H, W, 3))
         self._hw = None

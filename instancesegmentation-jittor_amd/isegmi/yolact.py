@@ -32,6 +32,7 @@ class YolactConfig:
     nms_top_k: int = 200
     max_num_detections: int = 100
     nms_second_threshold: int = 0  # SURVEY App. A.6 fork: Detect.fast_nms(second_threshold=True) -- a box must also have its own class score > nms_conf_thresh
+    conv_split_k: int = 0          # opt-in latency numerics mode (see MaskRCNNConfig.CONV_SPLIT_K): fixed-tree split-K for the backbone's small-M / large-K convolutions
     depth: int = 50  # 50 = yolact_resnet50_config, 101 = yolact_base_config / yolact_im700_config
     # YOLACT++ (yolact_plus_*_config, the YOLACT++ rows of README.md:216-221): three scales per level x three aspect ratios,
     # rectangular anchors, DCNv2 3x3s in the backbone, fast mask re-scoring
@@ -148,7 +149,7 @@ class Yolact:
         if self.fp16:  # must precede weight loading (weights are packed as fp16)
             self.set_param("fp16", 1.0)
         self._load(state_dict)
-        for k in ("nms_conf_thresh", "nms_thresh", "nms_top_k", "max_num_detections", "nms_second_threshold"):
+        for k in ("nms_conf_thresh", "nms_thresh", "nms_top_k", "max_num_detections", "nms_second_threshold", "conv_split_k"):
             self.set_param(k, float(getattr(cfg, k)))
         self._d_in = _ffi.DeviceBuffer((max_batch, self.size, self.size, 3))
         self._forward_id = 0

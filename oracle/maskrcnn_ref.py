@@ -58,12 +58,13 @@ def grid_anchors(gh, gw, stride, cell):
 
 class MaskRCNNRef:
     def __init__(self, sd, depth=50, pre_nms=1000, post_nms=1000, fpn_post=1000, det_per_img=100, nms_ge=0, fp16=False,
-                 nms_plus_one=1, nms_index_order=0, roi_aligned=0, bn_eps=0.0):
+                 nms_plus_one=1, nms_index_order=0, roi_aligned=0, bn_eps=0.0, conv_split_k=0):
         """The keyword forks are SURVEY 7.2 / App. A.1, A.6, A.7 (defaults: maskrcnn-benchmark's CUDA path): nms_ge 1 suppress on iou >= thr;
         nms_plus_one 0 plain areas in the NMS IoU; nms_index_order 1 a class's detections in proposal-index order (CPU NMS); roi_aligned 1
         ROIAlign(aligned=True); bn_eps FrozenBatchNorm2d's rsqrt(var + eps)."""
         self.sd, self.depth = sd, depth
         self.aligned, self.bn_eps = int(roi_aligned), float(bn_eps)
+        self.conv_split_k = int(conv_split_k)   # the product's opt-in split-K numerics mode (see YolactRef): conv2 / conv3 and conv1 of later blocks, by the shape rule
         # fp16=True emulates the product's fp16-storage path (BASELINE configs[4]): conv weights, the input image and every
         # stored activation are rounded to fp16, all arithmetic stays fp32 (ordered fmaf chain).
         self.fp16 = fp16
@@ -75,9 +76,14 @@ class MaskRCNNRef:
     def _h(self, x):
         return x.astype(np.float16).astype(np.float32) if self.fp16 else x
 
-    def _cbn(self, x, conv, bn, stride, pad, act, residual=None):
+    def _cbn(self, x, conv, bn, stride, pad, act, residual=None, may_split=False):
         sc, sh = _frozen_bn(self.sd, bn, self.bn_eps)
-        return self._h(ora.conv2d(x, self._h(_krsc(self.sd[conv + ".weight"])), stride, pad, sc, sh, residual, act))
+        w = self._h(_krsc(self.sd[conv + ".weight"]))
+        ks = 1
+        if may_split and self.conv_split_k and not self.fp16:
+            ho, wo = (x.shape[1] + 2 * pad - w.shape[1]) // stride + 1, (x.shape[2] + 2 * pad - w.shape[2]) // stride + 1
+            ks = 4 if ora.conv_split_qualifies(x.shape[0] * ho * wo, w.shape[0], w.shape[1], w.shape[2], w.shape[3]) else 1
+        return self._h(ora.conv2d(x, w, stride, pad, sc, sh, residual, act, ksplit=ks))
 
     def _cb(self, x, name, stride, pad, act, keep_f32=False):
         y = ora.conv2d(x, self._h(_krsc(self.sd[name + ".weight"])), stride, pad, None, self.sd[name + ".bias"], None, act)
@@ -98,9 +104,9 @@ class MaskRCNNRef:
                 nm = "backbone.body.layer%d.%d" % (li, b)
                 st = 2 if (b == 0 and li > 1) else 1
                 idt = self._cbn(x, nm + ".downsample.0", nm + ".downsample.1", st, 0, 0) if b == 0 else x
-                t = self._cbn(x, nm + ".conv1", nm + ".bn1", st, 0, 1)
-                t = self._cbn(t, nm + ".conv2", nm + ".bn2", 1, 1, 1)
-                x = self._cbn(t, nm + ".conv3", nm + ".bn3", 1, 0, 1, residual=idt)
+                t = self._cbn(x, nm + ".conv1", nm + ".bn1", st, 0, 1, may_split=b > 0)
+                t = self._cbn(t, nm + ".conv2", nm + ".bn2", 1, 1, 1, may_split=True)
+                x = self._cbn(t, nm + ".conv3", nm + ".bn3", 1, 0, 1, residual=idt, may_split=True)
             Cs.append(x)
         last = self._cb(Cs[3], "backbone.fpn.fpn_inner4", 1, 0, 0)
         P = [None, None, None, self._cb(last, "backbone.fpn.fpn_layer4", 1, 1, 0)]

@@ -58,9 +58,15 @@ def map_f32(x, fn):
     return y
 
 
+def conv_split_qualifies(M, Cout, R, S, Cin):
+    """The shape rule of the split-K mode (the product's isegmi_conv_split_qualifies): at most 176 tiles of 64 x 64 and at least 32 K chunks of 32."""
+    return Cin % 32 == 0 and -(-M // 64) * -(-Cout // 64) <= 176 and R * S * (Cin // 32) >= 32
+
+
 def conv2d(x, w, stride=1, pad=0, scale=None, shift=None, residual=None, act=0, out=None,
-           out_img_stride=None, out_pix_stride=None):
-    """x [N,H,W,Cin] NHWC, w [Cout,R,S,Cin]; returns [N,Ho,Wo,Cout] (or writes into `out`)."""
+           out_img_stride=None, out_pix_stride=None, ksplit=1):
+    """x [N,H,W,Cin] NHWC, w [Cout,R,S,Cin]; returns [N,Ho,Wo,Cout] (or writes into `out`).  ksplit > 1: the fixed-tree split-K evaluation
+    (ora_conv2d_split: ((p0 + p1) + ...) of ksplit k-ordered partial chains over equal chunk ranges)."""
     x = _f(x); w = _f(w)
     N, H, W_, Cin = x.shape
     Cout, R, S, Cin2 = w.shape
@@ -75,8 +81,8 @@ def conv2d(x, w, stride=1, pad=0, scale=None, shift=None, residual=None, act=0, 
         ret = out = np.empty((N, Ho, Wo, Cout), np.float32)
         out_img_stride = Ho * Wo * Cout
         out_pix_stride = Cout
-    lib().ora_conv2d(_p(x), I(N), I(H), I(W_), I(Cin), _p(w), I(Cout), I(R), I(S), I(stride), I(pad),
-                     _p(scale), _p(shift), _p(residual), I(act), _p(out), L(out_img_stride), L(out_pix_stride))
+    lib().ora_conv2d_split(_p(x), I(N), I(H), I(W_), I(Cin), _p(w), I(Cout), I(R), I(S), I(stride), I(pad),
+                           _p(scale), _p(shift), _p(residual), I(act), _p(out), L(out_img_stride), L(out_pix_stride), I(ksplit))
     return ret
 
 

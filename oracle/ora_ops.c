@@ -140,10 +140,16 @@ static int g_conv_sum_mode = 0;
 #define ORA_CONV_CGROUP 128
 ORA_API void ora_set_conv_sum_mode(int mode) { g_conv_sum_mode = mode; }
 
-ORA_API void ora_conv2d(const float* in, int N, int H, int W, int Cin,
+/* ksplit > 1: the FIXED-TREE SPLIT-K evaluation (round 6; the product's conv tile 15, an opt-in mode of the engines: `conv_split_k`).  The K order above is
+ * a sequence of 32-channel chunks t = 0 .. R*S*Cin/32 - 1; with L = ceil(chunks / ksplit) the output is
+ *     ((p_0 + p_1) + p_2) + ... ,   p_q = the k-ordered fmaf chain from +0 over the chunks [q L, (q + 1) L)
+ * (individually rounded fp32 adds, left to right), then the same epilogue.  Another valid fp32 evaluation of the same sum, one that a GPU can run as
+ * ksplit independent dependency chains per output.  Cin % 32 == 0. */
+static void conv2d_impl(const float* in, int N, int H, int W, int Cin,
                         const float* w, int Cout, int R, int S, int stride, int pad,
                         const float* scale, const float* shift, const float* residual, int act,
-                        float* out, int64_t out_img_stride, int64_t out_pix_stride) {
+                        float* out, int64_t out_img_stride, int64_t out_pix_stride, int ksplit) {
+    const int split_L = (ksplit > 1 && Cin % 32 == 0) ? (R * S * (Cin / 32) + ksplit - 1) / ksplit : 0;
     const int Ho = (H + 2 * pad - R) / stride + 1;
     const int Wo = (W + 2 * pad - S) / stride + 1;
     const int K = R * S * Cin;
@@ -164,14 +170,15 @@ ORA_API void ora_conv2d(const float* in, int N, int H, int W, int Cin,
                 for (int wo0 = 0; wo0 < Wo; wo0 += PB) {
                 const int np = (Wo - wo0) < PB ? (Wo - wo0) : PB;
 #ifdef __AVX2__
-                    __m256 acc[PB][4];
+                    __m256 acc[PB][4], tot[PB][4];
                     for (int p = 0; p < PB; ++p)
-                        for (int j = 0; j < 4; ++j) acc[p][j] = _mm256_setzero_ps();
+                        for (int j = 0; j < 4; ++j) { acc[p][j] = _mm256_setzero_ps(); tot[p][j] = _mm256_setzero_ps(); }
 #else
-                    float acc[PB][32];
+                    float acc[PB][32], tot[PB][32];
                     for (int p = 0; p < PB; ++p)
-                        for (int j = 0; j < 32; ++j) acc[p][j] = 0.0f;
+                        for (int j = 0; j < 32; ++j) { acc[p][j] = 0.0f; tot[p][j] = 0.0f; }
 #endif
+                    int t_chunk = 0, nflush = 0;   /* split-K: chunk counter along the K order, partial sums folded so far */
                     for (int cg = 0; cg < Cin; cg += ORA_CONV_CGROUP)
                     for (int r = 0; r < R; ++r)
                         for (int s = 0; s < S; ++s) {
@@ -206,6 +213,18 @@ ORA_API void ora_conv2d(const float* in, int N, int H, int W, int Cin,
                                 continue;
                             }
                             for (int c = cg; c < cge; ++c, wk += Cp) {
+                                if (split_L && (c & 31) == 0) {   /* a 32-channel chunk starts: fold the finished partial chain when a split range ends here */
+                                    if (t_chunk > 0 && t_chunk % split_L == 0) {
+                                        for (int p = 0; p < PB; ++p)
+#ifdef __AVX2__
+                                            for (int j = 0; j < 4; ++j) { tot[p][j] = nflush ? _mm256_add_ps(tot[p][j], acc[p][j]) : acc[p][j]; acc[p][j] = _mm256_setzero_ps(); }
+#else
+                                            for (int j = 0; j < 32; ++j) { tot[p][j] = nflush ? tot[p][j] + acc[p][j] : acc[p][j]; acc[p][j] = 0.0f; }
+#endif
+                                        ++nflush;
+                                    }
+                                    ++t_chunk;
+                                }
 #ifdef __AVX2__
                                 const __m256 w0 = _mm256_load_ps(wk), w1 = _mm256_load_ps(wk + 8),
                                              w2 = _mm256_load_ps(wk + 16), w3 = _mm256_load_ps(wk + 24);
@@ -224,6 +243,13 @@ ORA_API void ora_conv2d(const float* in, int N, int H, int W, int Cin,
 #endif
                             }
                         }
+                    if (nflush)   /* ((p0 + p1) + ...) + the last partial chain */
+                        for (int p = 0; p < PB; ++p)
+#ifdef __AVX2__
+                            for (int j = 0; j < 4; ++j) acc[p][j] = _mm256_add_ps(tot[p][j], acc[p][j]);
+#else
+                            for (int j = 0; j < 32; ++j) acc[p][j] = tot[p][j] + acc[p][j];
+#endif
                     for (int p = 0; p < np; ++p) {
                         float av[32];
 #ifdef __AVX2__
@@ -255,6 +281,18 @@ ORA_API void ora_conv2d(const float* in, int N, int H, int W, int Cin,
         }
     free(zrow);
     free(wt);
+}
+ORA_API void ora_conv2d(const float* in, int N, int H, int W, int Cin,
+                        const float* w, int Cout, int R, int S, int stride, int pad,
+                        const float* scale, const float* shift, const float* residual, int act,
+                        float* out, int64_t out_img_stride, int64_t out_pix_stride) {
+    conv2d_impl(in, N, H, W, Cin, w, Cout, R, S, stride, pad, scale, shift, residual, act, out, out_img_stride, out_pix_stride, 1);
+}
+ORA_API void ora_conv2d_split(const float* in, int N, int H, int W, int Cin,
+                              const float* w, int Cout, int R, int S, int stride, int pad,
+                              const float* scale, const float* shift, const float* residual, int act,
+                              float* out, int64_t out_img_stride, int64_t out_pix_stride, int ksplit) {
+    conv2d_impl(in, N, H, W, Cin, w, Cout, R, S, stride, pad, scale, shift, residual, act, out, out_img_stride, out_pix_stride, ksplit);
 }
 
 /* Appendix A.1 ConvTranspose2d(k2,s2,p0): w [Cin][Cout][2][2] (upstream layout),

@@ -45,12 +45,15 @@ def make_priors(conv_h, conv_w, scale, max_size, ars=(1.0, 0.5, 2.0), square=Tru
 
 class YolactRef:
     def __init__(self, sd, max_size=550, scales=(24, 48, 96, 192, 384), depth=50, fp16=False, scales_per_level=1, square=True,
-                 second_threshold=0):
+                 second_threshold=0, conv_split_k=0):
         # YOLACT++: scales_per_level=3, square=False; DCNv2 blocks and the mask-IoU net are recognised by their state-dict
         # entries (<block>.conv2.conv_offset_mask.weight, maskiou_net.0.weight)
         self.scales_per_level = scales_per_level
         self.square = square
         self.second_threshold = int(second_threshold)   # App. A.6 fork: Detect.fast_nms(second_threshold=True)
+        # the product's opt-in `conv_split_k` numerics mode: conv2 / conv3 of every bottleneck and conv1 of a stage's later blocks are evaluated as FOUR
+        # k-ordered partial chains added left to right (ora.conv2d(ksplit=4)) where the shape rule takes the layer (ora.conv_split_qualifies)
+        self.conv_split_k = int(conv_split_k)
         # fp16=True emulates the product's optional fp16-storage mode: image, conv weights and every stored activation are rounded
         # to fp16 (the fused head outputs and the prototypes stay fp32), arithmetic stays the fp32 ordered chain.
         self.fp16 = fp16
@@ -63,9 +66,14 @@ class YolactRef:
     def _h(self, x):
         return x.astype(np.float16).astype(np.float32) if self.fp16 else x
 
-    def _conv_bn(self, x, name, bn, stride, pad, act, residual=None):
+    def _conv_bn(self, x, name, bn, stride, pad, act, residual=None, may_split=False):
         sc, sh = _fold_bn(self.sd, bn)
-        return self._h(ora.conv2d(x, self._h(_krsc(self.sd[name + ".weight"])), stride, pad, sc, sh, residual, act))
+        w = self._h(_krsc(self.sd[name + ".weight"]))
+        ks = 1
+        if may_split and self.conv_split_k and not self.fp16:
+            ho, wo = (x.shape[1] + 2 * pad - w.shape[1]) // stride + 1, (x.shape[2] + 2 * pad - w.shape[2]) // stride + 1
+            ks = 4 if ora.conv_split_qualifies(x.shape[0] * ho * wo, w.shape[0], w.shape[1], w.shape[2], w.shape[3]) else 1
+        return self._h(ora.conv2d(x, w, stride, pad, sc, sh, residual, act, ksplit=ks))
 
     def _conv_b(self, x, name, stride, pad, act, keep_f32=False, **kw):
         y = ora.conv2d(x, self._h(_krsc(self.sd[name + ".weight"])), stride, pad, None, self.sd[name + ".bias"], None, act, **kw)
@@ -106,7 +114,7 @@ class YolactRef:
                 idt = x
                 if b == 0:
                     idt = self._conv_bn(x, nm + ".downsample.0", nm + ".downsample.1", st, 0, 0)
-                t = self._conv_bn(x, nm + ".conv1", nm + ".bn1", 1, 0, 1)
+                t = self._conv_bn(x, nm + ".conv1", nm + ".bn1", 1, 0, 1, may_split=b > 0)
                 if nm + ".conv2.conv_offset_mask.weight" in self.sd:
                     # DCNv2 (modulated deformable 3x3): offsets / mask logits from a plain 3x3 on the same input, the nine taps
                     # sampled bilinearly (ora_deform_im2col), then the weights applied in (r, s, cin) order; bias, then BN + ReLU
@@ -117,8 +125,8 @@ class YolactRef:
                     sh = (sh + self.sd[nm + ".conv2.bias"].astype(np.float32) * sc).astype(np.float32)
                     t = ora.conv2d(col, w.reshape(w.shape[0], 1, 1, -1), 1, 0, sc, sh, None, 1)
                 else:
-                    t = self._conv_bn(t, nm + ".conv2", nm + ".bn2", st, 1, 1)
-                x = self._conv_bn(t, nm + ".conv3", nm + ".bn3", 1, 0, 1, residual=idt)
+                    t = self._conv_bn(t, nm + ".conv2", nm + ".bn2", st, 1, 1, may_split=True)
+                x = self._conv_bn(t, nm + ".conv3", nm + ".bn3", 1, 0, 1, residual=idt, may_split=True)
             outs.append(x)
         return self._heads(N, outs[1], outs[2], outs[3])
 

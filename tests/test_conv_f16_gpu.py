@@ -88,7 +88,7 @@ def test_mfma_shape_does_not_change_results(ffi, case):
     assert ffi.get_f16_mfma_shape() == 3, "the default: row strips on 16 x 16 x 32 + the 144-row forms"
     for act, r, f32 in ((1, res, False), (0, None, False), (0, None, True)):
         run = lambda t: ffi.conv2d_f16(x, w, stride, pad, sc, sh, r, act, t, out_f32=f32)
-        for a, b in (((30, 40), (40, 41)) if R == 3 else ((34, 44), (37, 47), (39, 49), (2048 + 37, 2048 + 47), (47, 46), (2048 + 47, 2048 + 46)))):
+        for a, b in (((30, 40), (40, 41)) if R == 3 else ((34, 44), (37, 47), (39, 49), (2048 + 37, 2048 + 47), (47, 46), (2048 + 47, 2048 + 46))):
             assert np.array_equal(run(a), run(b)), (a, b, act, f32)
         outs = []
         for shape in (0, 1, 2, 3):

@@ -43,6 +43,63 @@ def test_conv_bit_exact(ffi, case, tile):
         assert np.array_equal(got, ref), "max abs diff %g" % np.max(np.abs(got - ref))
 
 
+# Round 6: FIXED-TREE SPLIT-K (conv tile 15, the engines' opt-in `conv_split_k`): the output is ((p0 + p1) + p2) + p3 of four k-ordered partial chains over
+# equal ranges of the K chunks -- bit-exact against the oracle's restatement of exactly that sum (ora.conv2d(..., ksplit=4)), and NOT the default chain
+SPLIT_CASES = [
+    # N, H, W, Cin, Cout, R, stride, pad
+    (1, 35, 35, 256, 256, 3, 1, 1),    # Yolact res4 conv2 at bs 1: 72 chunks, two channel groups of 128 (a split range ends inside a tap's group)
+    (1, 18, 18, 512, 512, 3, 1, 1),    # res5 conv2: 144 chunks, four channel groups
+    (1, 35, 35, 1024, 256, 1, 1, 0),   # res4 conv1: 32 chunks, plain (r, s, c) order
+    (1, 25, 42, 2048, 512, 1, 1, 0),   # Mask R-CNN res5 conv1 at bs 1
+    (2, 9, 9, 320, 40, 3, 2, 1),       # 90 chunks: ranges of 23 / 23 / 23 / 21, ragged channel groups 128 + 128 + 64, stride 2, Cout tail
+    (1, 5, 7, 96, 48, 3, 1, 1),        # 27 chunks (a layer the engines' rule would not split: the kernel must still be right)
+    (1, 6, 6, 64, 32, 1, 1, 0),        # 2 chunks over four sets: two sets have nothing to do
+    (3, 11, 13, 128, 72, 3, 1, 1),     # 36 chunks, rows past M in the last tile, three images
+]
+
+
+@pytest.mark.parametrize("case", SPLIT_CASES)
+def test_conv_split_k_bit_exact_against_the_oracle_split(ffi, case):
+    N, H, W, Cin, Cout, R, stride, pad = case
+    rng = np.random.default_rng(hash(case) % (2**32))
+    x = _rand(rng, (N, H, W, Cin))
+    w = _rand(rng, (Cout, R, R, Cin), (2.0 / (R * R * Cin)) ** 0.5)
+    sc = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+    sh = _rand(rng, (Cout,), 0.1)
+    Ho = (H + 2 * pad - R) // stride + 1
+    Wo = (W + 2 * pad - R) // stride + 1
+    res = _rand(rng, (N, Ho, Wo, Cout))
+    differs = False
+    for act, use_res in [(1, True), (0, False)]:
+        ref = ora.conv2d(x, w, stride, pad, sc, sh, res if use_res else None, act, ksplit=4)
+        got = ffi.conv2d(x, w, stride, pad, sc, sh, res if use_res else None, act, 15)
+        assert np.array_equal(got, ref), "max abs diff %g" % np.max(np.abs(got - ref))
+        one = ora.conv2d(x, w, stride, pad, sc, sh, res if use_res else None, act)
+        assert np.allclose(got, one, rtol=0, atol=2e-5 * max(1.0, np.abs(one).max()))   # the same sum, another association
+        differs |= not np.array_equal(got, one)
+    if R * R * (Cin // 32) >= 8:
+        assert differs   # (it IS another evaluation: a test that passed with the split ignored would prove nothing)
+
+
+def test_conv_split_rule_matches_the_oracle_rule(ffi):
+    """isegmi_conv_split_qualifies == oracle.ora.conv_split_qualifies over the layer shapes of both models at bs 1 / 2 / 8"""
+    import ctypes as C
+    shapes = [(n, h, w, ci, co, r, st) for n in (1, 2, 8) for (h, w) in ((35, 35), (18, 18), (69, 69), (138, 138), (50, 84), (25, 42), (100, 168), (7, 7))
+              for (ci, co, r, st) in ((256, 256, 3, 1), (1024, 256, 1, 1), (256, 1024, 1, 1), (512, 512, 3, 1), (2048, 512, 1, 1), (512, 2048, 1, 1), (128, 128, 3, 1),
+                                      (512, 128, 1, 1), (256, 1024, 7, 1), (64, 64, 3, 1), (1024, 512, 1, 2))]
+    n_true = 0
+    for (n, h, w, ci, co, r, st) in shapes:
+        pad = r // 2
+        if h + 2 * pad < r:
+            continue
+        d = ffi.make_conv_desc(n, h, w, ci, co, r, r, st, pad, 0, 0)
+        ho, wo = (h + 2 * pad - r) // st + 1, (w + 2 * pad - r) // st + 1
+        got = ffi.lib().isegmi_conv_split_qualifies(C.byref(d))
+        assert got == int(ora.conv_split_qualifies(n * ho * wo, co, r, r, ci)), (n, h, w, ci, co, r, st)
+        n_true += got
+    assert 0 < n_true < len(shapes)
+
+
 # Round 3: the K walk (128-channel groups outermost) with a ragged last group, and the banded tile walk over the XCDs with a last band narrower
 # than the others (conv_set_band picks 2 / 3 / 6 / 11 / 4-wide bands for these shapes; a wrong tile decode leaves tiles uncomputed or computed twice)
 WALK_CASES = [

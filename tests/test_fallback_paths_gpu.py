@@ -66,7 +66,7 @@ def test_maskrcnn_fallback_launch_forms_are_bit_identical_to_the_default(ffi, sd
     base = _maskrcnn_run(sd, x, hw, fp16, {})
     assert int(base["det.count"].sum()) > 10 * N
     variants = [dict(rpn_select_groups=0), dict(rpn_select_groups=1), dict(rpn_select_groups=2), dict(rpn_select_groups=0, rpn_select_on_tail=0),
-                dict(rpn_select_groups=0, rpn_select_on_tail=1), dict(multi_stream=0)]
+                dict(rpn_select_groups=0, rpn_select_on_tail=1), dict(multi_stream=0), dict(box_nms_chip_wide=0)]
     if not fp16:   # the fp16 engine has no grouped convolutions to switch off
         variants += [dict(conv_groups=0), dict(conv_groups=0, rpn_select_groups=0), dict(conv_groups=0, rpn_select_groups=2), dict(conv_groups=1, rpn_select_groups=0)]
     for v in variants:

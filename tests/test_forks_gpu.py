@@ -300,7 +300,7 @@ def sd():
 def small_batch():
     from isegmi.maskrcnn import prepare_images
     rng = np.random.default_rng(20261003)
-    return prepare_images([rng.uniform(0, 255, (250, 340, 3)).astype(np.float32), rng.uniform(0, 255, (256, 300, 3)).astype(np.float32)])
+    return prepare_images([rng.uniform(0, 255, (250, 340, 3)).astype(np.float32)])   # one image: the oracle model runs once per fork
 
 
 def _run_engine(sd, cfg, x, hw, fp16=False):
@@ -329,7 +329,7 @@ def _assert_engine_is_oracle(res, ref, rd, n_img, x):
         rm, _ = MaskRCNNRef.paste(r, x.shape[1], x.shape[2])
         assert np.array_equal(res["masks"][n, : len(rm)], rm)
         total += len(bl)
-    assert total > 20
+    assert total > 10
 
 
 def _same_detections(a, b, n_img):
@@ -366,11 +366,11 @@ def test_maskrcnn_engine_fork_equals_oracle_fork(ffi, sd, small_batch, default_r
     res = _run_engine(sd, dataclasses.replace(MaskRCNNConfig(), **over), x, hw)
     ref = MaskRCNNRef(sd, **refkw)
     rd = ref.forward(x, hw)
-    _assert_engine_is_oracle(res, ref, rd, 2, x)
+    _assert_engine_is_oracle(res, ref, rd, x.shape[0], x)
     if must_differ:
-        assert not _same_detections(res, default_run, 2), fork
+        assert not _same_detections(res, default_run, x.shape[0]), fork
     if fork == "nms_index_order":   # same detections as the default run, another order inside a class
-        for n in range(2):
+        for n in range(x.shape[0]):
             a, b = res["out"][n], default_run["out"][n]
             assert sorted(map(tuple, np.column_stack([a.bbox, a.get_field("scores")]).tolist())) == \
                 sorted(map(tuple, np.column_stack([b.bbox, b.get_field("scores")]).tolist()))
@@ -405,8 +405,8 @@ def test_maskrcnn_fp16_engine_takes_the_forks(ffi, sd, small_batch):
     base = _run_engine(sd, MaskRCNNConfig(), x, hw, fp16=True)
     idx = _run_engine(sd, dataclasses.replace(MaskRCNNConfig(), NMS_OUTPUT_ORDER="index"), x, hw, fp16=True)
     ali = _run_engine(sd, dataclasses.replace(MaskRCNNConfig(), ROI_ALIGNED=1), x, hw, fp16=True)
-    assert not _same_detections(idx, base, 2) and not _same_detections(ali, base, 2)
-    for n in range(2):
+    assert not _same_detections(idx, base, x.shape[0]) and not _same_detections(ali, base, x.shape[0])
+    for n in range(x.shape[0]):
         a, b = idx["out"][n], base["out"][n]
         assert sorted(map(tuple, np.column_stack([a.bbox, a.get_field("scores")]).tolist())) == \
             sorted(map(tuple, np.column_stack([b.bbox, b.get_field("scores")]).tolist()))

@@ -245,6 +245,33 @@ def test_semantic_fork_known_answers():
     sc, sh = _frozen_bn(sd, "bn", 5.0); assert np.allclose(sc[0], 2.0 / 3.0) and np.allclose(sh[0], 1.0 - 2.0)
 
 
+def test_conv_split_k_is_the_stated_sum():
+    """ora.conv2d(ksplit=4): ((p0 + p1) + p2) + p3 of four k-ordered fmaf chains over equal ranges of the 32-channel chunks in the K order (channel groups of
+    128 outermost, then (r, s), then the group's chunks) -- restated here in plain Python for a few outputs; ksplit = 1 is the default chain."""
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((1, 9, 11, 256)).astype(np.float32)
+    w = (rng.standard_normal((64, 3, 3, 256)) * 0.05).astype(np.float32)
+    one, four = ora.conv2d(x, w, 1, 1), ora.conv2d(x, w, 1, 1, ksplit=4)
+    assert np.array_equal(one, ora.conv2d(x, w, 1, 1, ksplit=1)) and not np.array_equal(one, four)
+    assert np.abs(one - four).max() < 1e-4
+
+    def fma32(a, b, c):   # fp32 x fp32 is exact in fp64; the one rounding of the fp64 sum to fp32 can differ from a true fma only by double rounding
+        return np.float32(np.float64(a) * np.float64(b) + np.float64(c))
+    chunks = [(r, s, c0) for cg in (0, 128) for r in range(3) for s in range(3) for c0 in range(cg, cg + 128, 32)]
+    L = -(-len(chunks) // 4)
+    xp = np.pad(x, ((0, 0), (1, 1), (1, 1), (0, 0)))
+    for (ho, wo, co) in [(0, 0, 0), (4, 5, 17), (8, 10, 63), (3, 0, 40)]:
+        tot = None
+        for q in range(4):
+            acc = np.float32(0)
+            for (r, s, c0) in chunks[q * L:(q + 1) * L]:
+                for c in range(c0, c0 + 32):
+                    acc = fma32(xp[0, ho + r, wo + s, c], w[co, r, s, c], acc)
+            tot = acc if tot is None else np.float32(tot + acc)
+        assert tot == four[0, ho, wo, co]
+    assert ora.conv_split_qualifies(1225, 256, 3, 3, 256) and not ora.conv_split_qualifies(1225, 1024, 1, 1, 256) and not ora.conv_split_qualifies(38088, 256, 3, 3, 256)
+
+
 def test_paste_known_answer():
     m = np.full((1, 28, 28), 0.9, np.float32)
     o = ora.paste_masks(m, np.array([[50, 60, 250, 300]], np.float32), 384, 500)[0]
