@@ -38,7 +38,7 @@ import numpy as np  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32-input MFMA peak (spec)
 PEAK_F16_MFMA_TFLOPS = 2500.0  # dense f16 MFMA peak (spec, no sparsity)
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
 ALLOW_STALE_TRAFFIC = False   # --allow-stale-traffic
 
 
